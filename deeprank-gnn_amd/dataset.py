@@ -1,0 +1,141 @@
+"""Graph store -> ``Data`` objects, with the tensor layout the hot path expects.
+
+Counterpart of HDF5DataSet.load_one_graph (reference DataSet.py:231-366): same feature
+stacking order (order of the ``node_feature`` list, 1-D features become one column,
+:251-256), same edge symmetrisation (``[pairs ; flipped pairs]``, :266-269), same
+``edge_feature_transform`` default ``tanh(-d/2+2)+1`` (:96,281), same target and
+cluster handling (:318-357).
+
+Storage: the reference keeps graphs in HDF5 (h5py, absent on the target image).  The
+same group/dataset tree is accepted here either as an ``.npz`` whose keys are
+``"<mol>/<dataset path>"`` plus ``__mols__`` (what tests/golden/gen/export_fixture.py
+writes) or, when h5py is importable, as the original ``.hdf5`` file.
+"""
+import numpy as np
+import torch
+
+from .data import Data
+
+__all__ = ["GraphStore", "GraphDataSet", "default_edge_transform"]
+
+
+def default_edge_transform(d):
+    return np.tanh(-d / 2.0 + 2.0) + 1.0
+
+
+class GraphStore(object):
+    """Read-only ``{mol: {dataset path: ndarray}}`` view of a graph file."""
+
+    def __init__(self, path):
+        self.path = path
+        self._mols = {}
+        if str(path).endswith(".npz"):
+            with np.load(path) as z:
+                order = [str(m) for m in z["__mols__"]]
+                for m in order:
+                    self._mols[m] = {}
+                for key in z.files:
+                    if key == "__mols__":
+                        continue
+                    mol, _, rest = key.partition("/")
+                    self._mols[mol][rest] = z[key]
+        else:
+            try:
+                import h5py
+            except ImportError as exc:  # pragma: no cover - depends on the image
+                raise ImportError("reading %s needs h5py; export it to .npz with "
+                                  "tests/golden/gen/export_fixture.py" % path) from exc
+            with h5py.File(path, "r") as f:
+                for mol in f.keys():
+                    tree = {}
+
+                    def visit(name, obj, tree=tree):
+                        if isinstance(obj, h5py.Dataset) and obj.dtype.kind in "fiub":
+                            tree[name] = obj[()]
+                    f[mol].visititems(visit)
+                    self._mols[mol] = tree
+
+    def mols(self):
+        return list(self._mols.keys())
+
+    def has(self, mol, path):
+        return path in self._mols[mol]
+
+    def get(self, mol, path):
+        return self._mols[mol][path]
+
+    def children(self, mol, prefix):
+        prefix = prefix.rstrip("/") + "/"
+        return sorted({k[len(prefix):].split("/")[0] for k in self._mols[mol] if k.startswith(prefix)})
+
+
+class GraphDataSet(torch.utils.data.Dataset):
+    """Indexable dataset of ``Data`` graphs (role of reference HDF5DataSet)."""
+
+    def __init__(self, database, node_feature="all", edge_feature=("dist",), target=None,
+                 clustering_method="mcl", edge_feature_transform=default_edge_transform,
+                 index=None):
+        self.store = database if isinstance(database, GraphStore) else GraphStore(database)
+        mols = self.store.mols()
+        if index is not None:
+            mols = [mols[i] for i in index]
+        self.mols = mols
+        if node_feature == "all":
+            node_feature = self.store.children(mols[0], "node_data")
+        for feat in node_feature:
+            if not self.store.has(mols[0], "node_data/" + feat):
+                raise KeyError("node feature %r not found; available: %s"
+                               % (feat, self.store.children(mols[0], "node_data")))
+        self.node_feature = list(node_feature)
+        self.edge_feature = None if edge_feature is None else list(edge_feature)
+        self.target = target
+        self.clustering_method = clustering_method
+        self.edge_feature_transform = edge_feature_transform
+
+    def __len__(self):
+        return len(self.mols)
+
+    def len(self):
+        return len(self.mols)
+
+    def __getitem__(self, i):
+        return self.load_one_graph(self.mols[i])
+
+    get = __getitem__
+
+    def _stack(self, mol, group, names):
+        cols = []
+        for feat in names:
+            v = np.asarray(self.store.get(mol, group + "/" + feat))
+            cols.append(v.reshape(-1, 1) if v.ndim == 1 else v)
+        return np.hstack(cols)
+
+    def _edges(self, mol, index_key, data_group):
+        pairs = np.asarray(self.store.get(mol, index_key))
+        both = np.vstack((pairs, pairs[:, ::-1])).T
+        edge_index = torch.tensor(np.ascontiguousarray(both), dtype=torch.long)
+        edge_attr = None
+        if self.edge_feature is not None:
+            vals = self._stack(mol, data_group, self.edge_feature)
+            vals = self.edge_feature_transform(np.vstack((vals, vals)))
+            edge_attr = torch.tensor(vals, dtype=torch.float).contiguous()
+        return edge_index, edge_attr
+
+    def load_one_graph(self, mol):
+        st = self.store
+        x = torch.tensor(self._stack(mol, "node_data", self.node_feature), dtype=torch.float)
+        edge_index, edge_attr = self._edges(mol, "edge_index", "edge_data")
+        iei, iea = self._edges(mol, "internal_edge_index", "internal_edge_data")
+        y = None
+        if self.target is not None and st.has(mol, "score/" + self.target):
+            y = torch.tensor([st.get(mol, "score/" + self.target)[()]], dtype=torch.float)
+        pos = torch.tensor(np.asarray(st.get(mol, "node_data/pos")), dtype=torch.float)
+        g = Data(x=x, edge_index=edge_index, edge_attr=edge_attr, y=y, pos=pos)
+        g.internal_edge_index = iei
+        g.internal_edge_attr = iea
+        g.mol = mol
+        base = "clustering/%s/" % self.clustering_method
+        if st.has(mol, base + "depth_0") and st.has(mol, base + "depth_1"):
+            g.cluster0 = torch.tensor(np.asarray(st.get(mol, base + "depth_0")), dtype=torch.long)
+            g.cluster1 = torch.tensor(np.asarray(st.get(mol, base + "depth_1")), dtype=torch.long)
+        return g

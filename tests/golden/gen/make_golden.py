@@ -1,0 +1,227 @@
+"""Generate the golden vectors in tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Build-container only (needs /root/reference; never runs on the GPU box):
+    python tests/golden/gen/make_golden.py
+
+The reference's own, unmodified modules deeprank_gnn/{ginet,sGAT,foutnet,
+community_pooling,DataSet}.py are imported from /root/reference against the
+third-party stand-ins of pyg_shims.py ("hybrid oracle").  Only
+ARRAYS are written: inputs that are not reproducible from a seed (fixture tensors are
+re-derived from fixture_1ATN.npz by the tests; parameters are stored), outputs, losses,
+every parameter gradient and per-stage intermediates.
+
+Cases
+  fix8_<Net>.npz      first 8 fixture graphs, node features of reference tests/test_nn.py:13-14
+                      (F=28), target irmsd, MSE loss, dropout off            (GINet, sGAT, FoutNet)
+  fix8_GINet_class.npz same graphs, 2-class head, cross-entropy on synthetic labels
+  syn4_<Net>.npz      4 small synthetic graphs (deeprank_gnn_amd.synthetic, ids 0-3)
+  layers_isolated.npz the three conv layers on a graph that has an isolated node
+  pretrained_class.npz shipped GINet classifier checkpoint on all 10 fixture graphs
+  toy6.npz            6-node graph of reference tests/test_community_pooling.py:12-19
+  collate.npz         Batch.from_data_list result for fixture graphs 0-2 (key layout)
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import pyg_shims
+
+pyg_shims.install()
+H5 = "/root/reference/tests/hdf5/1ATN_residue.hdf5"
+pyg_shims.register_npz(H5, os.path.join(ROOT, "tests/golden/fixture_1ATN.npz"))
+
+from deeprank_gnn.DataSet import HDF5DataSet                      # noqa: E402  (reference)
+from deeprank_gnn.ginet import GINet, GINetConvLayer               # noqa: E402
+from deeprank_gnn.sGAT import sGAT, sGraphAttentionLayer          # noqa: E402
+from deeprank_gnn.foutnet import FoutNet, FoutLayer               # noqa: E402
+from deeprank_gnn.community_pooling import get_preloaded_cluster, community_pooling  # noqa: E402
+from torch_geometric.data import Batch, Data                      # noqa: E402  (stand-in)
+from torch_geometric.nn import max_pool_x                         # noqa: E402
+from torch_scatter import scatter_mean                            # noqa: E402
+
+import deeprank_gnn_amd.synthetic as synth                         # noqa: E402  (ours: data only)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+NODE_FEATURES = ['type', 'polarity', 'bsa', 'depth', 'hse', 'ic', 'pssm']
+NETS = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def staged(net, name, batch, store, tag, c1, c2):
+    """Replays one conv->pool->conv->pool branch with the reference's functions and
+    records every intermediate (mirrors reference ginet.py:103-114)."""
+    d = batch.clone()
+    fout = name == "FoutNet"
+    z1 = c1(d.x, d.edge_index) if fout else c1(d.x, d.edge_index, d.edge_attr)
+    d.x = F.relu(z1)
+    cl = get_preloaded_cluster(d.cluster0, d.batch)
+    store[tag + "cluster0_offset"] = npy(cl)
+    dp = community_pooling(cl, d)
+    xp = dp.x
+    store[tag + "z1"] = npy(z1)
+    store[tag + "xp"] = npy(xp)
+    store[tag + "pool_edge_index"] = npy(dp.edge_index)
+    store[tag + "pool_edge_attr"] = npy(dp.edge_attr)
+    store[tag + "pool_batch"] = npy(dp.batch)
+    store[tag + "pool_internal_edge_index"] = npy(dp.internal_edge_index)
+    store[tag + "pool_pos"] = npy(dp.pos)
+    z2 = c2(dp.x, dp.edge_index) if fout else c2(dp.x, dp.edge_index, dp.edge_attr)
+    dp.x = F.relu(z2)
+    cl1 = get_preloaded_cluster(dp.cluster1, dp.batch)
+    store[tag + "cluster1_offset"] = npy(cl1)
+    x2, b2 = max_pool_x(cl1, dp.x, dp.batch)
+    store[tag + "z2"] = npy(z2)
+    store[tag + "x2"] = npy(x2)
+    store[tag + "batch2"] = npy(b2)
+    return scatter_mean(x2, b2, dim=0)
+
+
+def run_case(name, graphs, n_feat, n_out, target, task, fname, seed=0):
+    torch.manual_seed(seed)
+    net = NETS[name](n_feat, n_out, 1)
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0
+    net.train()
+    store = {}
+    for k, v in net.state_dict().items():
+        store["param/" + k] = npy(v)
+    batch = Batch.from_data_list([g.clone() for g in graphs])
+    out = net(batch.clone())
+    if task == "reg":
+        loss = F.mse_loss(out.reshape(-1), target)
+    else:
+        loss = F.cross_entropy(out, target)
+    loss.backward()
+    store["target"] = npy(target)
+    store["out"] = npy(out)
+    store["loss"] = npy(loss)
+    for k, p in net.named_parameters():
+        store["grad/" + k] = npy(p.grad if p.grad is not None else torch.zeros_like(p))
+    with torch.no_grad():
+        ro = staged(net, name, batch, store, "a.", net.conv1, net.conv2)
+        if name == "GINet":
+            ro_b = staged(net, name, batch, store, "b.", net.conv1_ext, net.conv2_ext)
+            ro = torch.cat([ro, ro_b], dim=1)
+        store["readout"] = npy(ro)
+    np.savez_compressed(os.path.join(OUT, fname), **store)
+    print("%-24s out[:3]=%s loss=%.6f" % (fname, npy(out).reshape(-1)[:3], float(loss)))
+
+
+def to_shim(g):
+    d = Data(x=g.x, edge_index=g.edge_index, edge_attr=g.edge_attr, y=g.y, pos=g.pos)
+    d.internal_edge_index = g.internal_edge_index
+    d.internal_edge_attr = g.internal_edge_attr
+    d.mol = g.mol
+    d.cluster0 = g.cluster0
+    d.cluster1 = g.cluster1
+    return d
+
+
+def main():
+    ds = HDF5DataSet(root='./', database=H5, node_feature=list(NODE_FEATURES),
+                     edge_feature=['dist'], target='irmsd', tqdm=False)
+    fix = [ds.get(i) for i in range(len(ds))]
+    fix8 = fix[:8]
+    y8 = torch.cat([g.y for g in fix8])
+
+    # -- collate layout ---------------------------------------------------
+    b3 = Batch.from_data_list([g.clone() for g in fix[:3]])
+    np.savez_compressed(os.path.join(OUT, "collate.npz"),
+                        **{k: npy(b3[k]) for k in b3.keys if torch.is_tensor(b3[k])},
+                        mol=np.array(b3.mol))
+
+    # -- FIX8 -------------------------------------------------------------
+    for name in NETS:
+        run_case(name, fix8, 28, 1, y8, "reg", "fix8_%s.npz" % name)
+    labels = torch.tensor([0, 1, 1, 0, 1, 0, 0, 1])
+    run_case("GINet", fix8, 28, 2, labels, "class", "fix8_GINet_class.npz", seed=1)
+
+    # -- SYN4 (small synthetic graphs from OUR generator; data only) --------
+    syn = [to_shim(synth.make_graph(i, n_nodes=40, n_pairs=70, n_feat=12, n_c1=4, n_internal=40))
+           for i in range(4)]
+    ys = torch.cat([g.y for g in syn])
+    for name in NETS:
+        run_case(name, syn, 12, 1, ys, "reg", "syn4_%s.npz" % name, seed=2)
+
+    # -- conv layers with an isolated node ----------------------------------
+    g = synth.make_graph(7, n_nodes=24, n_pairs=40, n_feat=6, n_c1=3, n_internal=10, isolate_node=5)
+    torch.manual_seed(3)
+    store = {"isolated_node": np.array(5)}
+    lay = GINetConvLayer(6, 16, 1)
+    store["ginet.fc"] = npy(lay.fc.weight)
+    store["ginet.fc_edge_attr"] = npy(lay.fc_edge_attr.weight)
+    store["ginet.fc_attention"] = npy(lay.fc_attention.weight)
+    store["ginet.out"] = npy(lay(g.x, g.edge_index, g.edge_attr))
+    lay = sGraphAttentionLayer(6, 16)
+    store["sgat.weight"] = npy(lay.weight)
+    store["sgat.bias"] = npy(lay.bias)
+    store["sgat.out"] = npy(lay(g.x, g.edge_index, g.edge_attr))
+    lay = FoutLayer(6, 16)
+    store["fout.Wc"] = npy(lay.Wc)
+    store["fout.Wn"] = npy(lay.Wn)
+    store["fout.bias"] = npy(lay.bias)
+    store["fout.out"] = npy(lay(g.x, g.edge_index))
+    np.savez_compressed(os.path.join(OUT, "layers_isolated.npz"), **store)
+    print("layers_isolated: fout row5 =", store["fout.out"][5][:3], " sgat row5-bias =",
+          np.abs(store["sgat.out"][5] - store["sgat.bias"]).max())
+
+    # -- shipped classifier checkpoint (real weights, known answer) ----------
+    ck_path = ("/root/reference/paper_pretrained_models/biological_vs_crystal_interfaces/"
+               "tclass_ybio_interface_b128_e50_lr0.001_26.pth.tar")
+    ck = torch.load(ck_path, map_location="cpu", weights_only=False)
+    ds_p = HDF5DataSet(root='./', database=H5, node_feature=list(ck["node"]),
+                       edge_feature=list(ck["edge"]), target=None, tqdm=False)
+    gp = [ds_p.get(i) for i in range(len(ds_p))]
+    n_out = ck["model"]["fc2.weight"].shape[0]
+    net = GINet(gp[0].num_features, n_out, len(ck["edge"]))
+    net.load_state_dict(ck["model"], strict=True)
+    net.eval()
+    store = {"node_feature": np.array(list(ck["node"])), "edge_feature": np.array(list(ck["edge"]))}
+    for k, v in ck["model"].items():
+        store["param/" + k] = npy(v)
+    with torch.no_grad():
+        store["logits_batched"] = npy(net(Batch.from_data_list([g.clone() for g in gp])))
+        store["logits_single"] = np.concatenate(
+            [npy(net(Batch.from_data_list([g.clone()]))) for g in gp])
+    np.savez_compressed(os.path.join(OUT, "pretrained_class.npz"), **store)
+    print("pretrained_class: logits[0] =", store["logits_single"][0],
+          " batched-vs-single max diff =",
+          np.abs(store["logits_batched"] - store["logits_single"]).max())
+
+    # -- 6-node toy graph ------------------------------------------------------
+    ei = torch.tensor([[0, 1, 1, 2, 3, 4, 4, 5], [1, 0, 2, 1, 4, 3, 5, 4]], dtype=torch.long)
+    x = torch.tensor([[0.], [1.], [2.], [3.], [4.], [5.]])
+    d = Data(x=x, edge_index=ei, edge_attr=torch.ones(8, 1))
+    d.pos = torch.arange(18, dtype=torch.float).view(6, 3)
+    two = Batch.from_data_list([d.clone(), d.clone()])
+    cluster = torch.tensor([0, 0, 0, 1, 1, 1, 2, 2, 2, 3, 3, 3])
+    pooled = community_pooling(cluster, two)
+    np.savez_compressed(os.path.join(OUT, "toy6.npz"), x=npy(pooled.x),
+                        edge_index=npy(pooled.edge_index), batch=npy(pooled.batch),
+                        pos=npy(pooled.pos), cluster=npy(cluster))
+    # a second toy: clusters that DO leave edges, with weights, to pin coalesce-sum
+    cluster = torch.tensor([0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5])
+    two = Batch.from_data_list([d.clone(), d.clone()])
+    two.edge_attr = torch.arange(1, 17, dtype=torch.float).view(16, 1)
+    pooled = community_pooling(cluster, two)
+    np.savez_compressed(os.path.join(OUT, "toy6_edges.npz"), x=npy(pooled.x),
+                        edge_index=npy(pooled.edge_index), edge_attr=npy(pooled.edge_attr),
+                        batch=npy(pooled.batch), cluster=npy(cluster),
+                        in_edge_attr=npy(two.edge_attr))
+    print("toy6:", npy(pooled.edge_index).tolist(), npy(pooled.edge_attr).reshape(-1).tolist())
+
+
+if __name__ == "__main__":
+    main()
