@@ -1,0 +1,183 @@
+"""ctypes binding of the C ABI in include/drgnn.h.
+
+``get()`` loads ``csrc/libdrgnn.so`` (built by ``__graft_entry__.build()`` /
+``make -C deeprank-gnn_amd/csrc``) and raises if it is missing: there is no CPU fallback.
+``Api`` itself is device-agnostic pointer plumbing (it only reads ``data_ptr()``), which
+is what lets the CPU test-suite drive the host-emulation build of the same kernels.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdrgnn.so")
+
+GINET, SGAT, FOUT = 0, 1, 2
+MAX_BRANCH = 2
+
+# enum drgnn_topo_i32 / drgnn_topo_f32 (include/drgnn.h)
+TI = {name: i for i, name in enumerate([
+    "NPTR", "EPTR", "ROWPTR0", "COL0", "EID0", "COLPTR0", "ROWIDX0", "TSLOT0", "CL0", "NC0",
+    "MPTR0", "MEM0", "ROWPTR1", "COL1", "NE1", "COLPTR1", "ROWIDX1", "TSLOT1", "CL1", "NC1",
+    "MPTR1", "MEM1", "CPTR0", "E1PTR", "CPTR1", "ERR"])}
+TI_COUNT = len(TI)
+TF = {"W0": 0, "W1": 1}
+TF_COUNT = 2
+
+STATUS_BITS = {1: "edge endpoint outside its graph's node range",
+               2: "batch vector / edge list not grouped by graph",
+               4: "cluster ids of one graph span too large a range",
+               8: "len(cluster1) != number of depth-0 clusters"}
+
+_c_i64 = ctypes.c_int64
+_c_i32 = ctypes.c_int32
+_vp = ctypes.c_void_p
+
+
+class ConvParams(ctypes.Structure):
+    _fields_ = [("w_nbr", _vp), ("nbr_sk", _c_i64), ("nbr_sh", _c_i64),
+                ("w_self", _vp), ("self_sk", _c_i64), ("self_sh", _c_i64),
+                ("bias", _vp)]
+
+
+class ConvGrads(ctypes.Structure):
+    _fields_ = [("w_nbr", _vp), ("w_self", _vp), ("bias", _vp)]
+
+
+class NetDesc(ctypes.Structure):
+    _fields_ = [("kind", _c_i32), ("n_branch", _c_i32), ("n_feat", _c_i32), ("reserved", _c_i32),
+                ("conv1", ConvParams * MAX_BRANCH), ("conv2", ConvParams * MAX_BRANCH)]
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+class DrgnnError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        kind = {-1: "bad argument", -2: "workspace/capacity", -3: "unsupported width"}.get(
+            rc, "hipError_t %d" % rc if rc > 0 else "error %d" % rc)
+        raise DrgnnError("%s failed: %s" % (what, kind))
+
+
+class Api(object):
+    """Typed wrapper around one loaded libdrgnn*.so."""
+
+    def __init__(self, path):
+        self.path = path
+        lib = ctypes.CDLL(path)
+        self.lib = lib
+        lib.drgnn_abi_version.restype = ctypes.c_int
+        lib.drgnn_topology_layout.argtypes = [_c_i64, _c_i64, _c_i64, ctypes.POINTER(_c_i64),
+                                              ctypes.POINTER(_c_i64)]
+        lib.drgnn_topology_scratch_elems.argtypes = [_c_i64] * 3
+        lib.drgnn_topology_scratch_elems.restype = _c_i64
+        lib.drgnn_topology_lds_bytes.argtypes = [_c_i32, _c_i32]
+        lib.drgnn_topology_lds_bytes.restype = _c_i64
+        lib.drgnn_topology_build.argtypes = [_vp] * 8 + [_c_i64] * 4 + [_c_i32] * 2 + [_vp] * 4
+        lib.drgnn_topology_finalize.argtypes = [_vp, _c_i64, _c_i64, _c_i64, _vp]
+        lib.drgnn_topology_status.argtypes = [_vp, _c_i64, _c_i64, _c_i64, ctypes.POINTER(_c_i32), _vp]
+        lib.drgnn_net_lds_bytes.argtypes = [_c_i32] * 4
+        lib.drgnn_net_lds_bytes.restype = _c_i64
+        lib.drgnn_net_partial_elems.argtypes = [_c_i32, _c_i32]
+        lib.drgnn_net_partial_elems.restype = _c_i64
+        lib.drgnn_net_scratch_elems.argtypes = [_c_i32, _c_i32, _c_i64, _c_i64, _c_i64]
+        lib.drgnn_net_scratch_elems.restype = _c_i64
+        lib.drgnn_net_forward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 3 + [_c_i64] * 3 +
+                                          [_c_i32] * 2 + [_vp] * 6)
+        lib.drgnn_net_backward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 4 + [_c_i64] * 3 +
+                                           [_c_i32] * 2 + [_vp] * 3 +
+                                           [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 4)
+        if lib.drgnn_abi_version() != 1:
+            raise DrgnnError("ABI mismatch in %s" % path)
+
+    # -- topology ---------------------------------------------------------------
+    def topology_layout(self, n_nodes, n_edges, n_graphs):
+        oi = (_c_i64 * (TI_COUNT + 1))()
+        of = (_c_i64 * (TF_COUNT + 1))()
+        _check(self.lib.drgnn_topology_layout(n_nodes, n_edges, n_graphs, oi, of), "drgnn_topology_layout")
+        return list(oi), list(of)
+
+    def topology_scratch_elems(self, n_nodes, n_edges, n_graphs):
+        return int(self.lib.drgnn_topology_scratch_elems(n_nodes, n_edges, n_graphs))
+
+    def topology_lds_bytes(self, max_nodes, max_edges):
+        return int(self.lib.drgnn_topology_lds_bytes(max_nodes, max_edges))
+
+    def topology_build(self, edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr,
+                       c1_ptr, n_nodes, n_edges, len_c1, n_graphs, max_nodes, max_edges, ws_i32,
+                       ws_f32, scratch, stream):
+        _check(self.lib.drgnn_topology_build(
+            _ptr(edge_index), _ptr(edge_attr), _ptr(batch), _ptr(cluster0), _ptr(cluster1),
+            _ptr(node_ptr), _ptr(edge_ptr), _ptr(c1_ptr), n_nodes, n_edges, len_c1, n_graphs,
+            max_nodes, max_edges, _ptr(ws_i32), _ptr(ws_f32), _ptr(scratch), stream),
+            "drgnn_topology_build")
+
+    def topology_finalize(self, ws_i32, n_nodes, n_edges, n_graphs, stream):
+        _check(self.lib.drgnn_topology_finalize(_ptr(ws_i32), n_nodes, n_edges, n_graphs, stream),
+               "drgnn_topology_finalize")
+
+    def topology_status(self, ws_i32, n_nodes, n_edges, n_graphs, stream):
+        st = (_c_i32 * 4)()
+        _check(self.lib.drgnn_topology_status(_ptr(ws_i32), n_nodes, n_edges, n_graphs, st, stream),
+               "drgnn_topology_status")
+        return list(st)
+
+    # -- fused net --------------------------------------------------------------
+    def net_lds_bytes(self, kind, n_feat, max_nodes, max_c0):
+        return int(self.lib.drgnn_net_lds_bytes(kind, n_feat, max_nodes, max_c0))
+
+    def net_partial_elems(self, kind, n_feat):
+        return int(self.lib.drgnn_net_partial_elems(kind, n_feat))
+
+    def net_scratch_elems(self, kind, n_feat, n_nodes, n_edges, n_graphs):
+        return int(self.lib.drgnn_net_scratch_elems(kind, n_feat, n_nodes, n_edges, n_graphs))
+
+    def net_forward(self, desc, x, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, max_nodes, max_c0,
+                    xp, arg0, arg1, readout, scratch, stream):
+        _check(self.lib.drgnn_net_forward(
+            ctypes.byref(desc), _ptr(x), _ptr(ws_i32), _ptr(ws_f32), n_nodes, n_edges, n_graphs,
+            max_nodes, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1), _ptr(readout), _ptr(scratch), stream),
+            "drgnn_net_forward")
+
+    def net_backward(self, desc, x, grad_readout, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
+                     max_nodes, max_c0, xp, arg0, arg1, g1, g2, grad_x, partials, scratch, stream):
+        _check(self.lib.drgnn_net_backward(
+            ctypes.byref(desc), _ptr(x), _ptr(grad_readout), _ptr(ws_i32), _ptr(ws_f32), n_nodes,
+            n_edges, n_graphs, max_nodes, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1), g1, g2,
+            _ptr(grad_x), _ptr(partials), _ptr(scratch), stream), "drgnn_net_backward")
+
+
+_API = None
+
+
+def get():
+    """The product library.  Raises if it has not been built: no CPU fallback."""
+    global _API
+    if _API is None:
+        if not os.path.exists(LIB_PATH):
+            raise DrgnnError(
+                "HIP library %s not found. Build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` or `make -C deeprank-gnn_amd/csrc` (hipcc, gfx950)." % LIB_PATH)
+        _API = Api(LIB_PATH)
+    return _API
+
+
+def require_device(*tensors):
+    """The kernels run on the GPU only; refuse anything else loudly."""
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DrgnnError("deeprank_gnn_amd kernels need CUDA/HIP tensors (MI355X); got a %s "
+                             "tensor. There is no CPU path." % t.device.type)
+
+
+def current_stream(ref):
+    """Raw hipStream_t of torch's current stream on the device of ``ref``."""
+    if ref.is_cuda:
+        return torch.cuda.current_stream(ref.device).cuda_stream
+    return None

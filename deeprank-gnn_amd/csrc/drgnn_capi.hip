@@ -1,0 +1,504 @@
+// drgnn_capi.hip -- kernels + the extern "C" surface declared in include/drgnn.h.
+//
+// Built twice from this one source:
+//   hipcc --offload-arch=gfx950 -> csrc/libdrgnn.so        (the product)
+//   g++ -x c++ -DDRGNN_EMU      -> tests/emu/build/libdrgnn_emu.so (CPU test-suite only:
+//        every "launch" becomes a loop over workgroups on host pointers)
+#include "drgnn_net.h"
+
+#ifdef DRGNN_EMU
+#include <vector>
+#define DRGNN_LDS_LIMIT (160 * 1024)
+#else
+#define DRGNN_LDS_LIMIT (160 * 1024)
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) return (int)e_;           \
+    } while (0)
+#endif
+
+// =====================================================================================
+// kernels
+// =====================================================================================
+struct PtrArgs {
+    const int64_t* batch;
+    const int64_t* edge_row;
+    int64_t n_nodes, n_edges;
+    int n_graphs;
+    int32_t* nptr;
+    int32_t* eptr;
+    int32_t* err;
+};
+
+// per-graph offsets from the (sorted) batch vector and the graph-grouped edge list
+DEV void ptr_item(const PtrArgs& a, int64_t i) {
+    const int B = a.n_graphs;
+    if (i < a.n_nodes) {
+        long long b = a.batch[i];
+        long long prev = (i > 0) ? (long long)a.batch[i - 1] : -1;
+        if (b < prev || b < 0 || b >= B) { ATOMIC_OR(&a.err[0], DRGNN_S_UNSORTED); a.err[1] = 0; b = prev < 0 ? 0 : prev; }
+        for (long long gph = prev + 1; gph <= b && gph <= B; ++gph) a.nptr[gph] = (int32_t)i;
+        if (i == a.n_nodes - 1)
+            for (long long gph = b + 1; gph <= B; ++gph) a.nptr[gph] = (int32_t)a.n_nodes;
+    }
+    if (i < a.n_edges) {
+        auto graph_of = [&](int64_t e) -> long long {
+            const long long r = a.edge_row[e];
+            if (r < 0 || r >= a.n_nodes) return -2;
+            return (long long)a.batch[r];
+        };
+        long long b = graph_of(i);
+        long long prev = (i > 0) ? graph_of(i - 1) : -1;
+        if (b == -2 || prev == -2) { ATOMIC_OR(&a.err[0], DRGNN_S_EDGE_RANGE); a.err[1] = 0; if (b == -2) b = prev < 0 ? 0 : prev; if (prev == -2) prev = b; }
+        if (b < prev || b >= B) { ATOMIC_OR(&a.err[0], DRGNN_S_UNSORTED); a.err[1] = 0; b = prev; }
+        for (long long gph = prev + 1; gph <= b && gph <= B; ++gph) a.eptr[gph] = (int32_t)i;
+        if (i == a.n_edges - 1)
+            for (long long gph = b + 1; gph <= B; ++gph) a.eptr[gph] = (int32_t)a.n_edges;
+    }
+    if (i == 0) {
+        if (a.n_nodes == 0) for (int gph = 0; gph <= B; ++gph) a.nptr[gph] = 0;
+        if (a.n_edges == 0) for (int gph = 0; gph <= B; ++gph) a.eptr[gph] = 0;
+    }
+}
+
+struct TopoLaunch {
+    TopoView tv;
+    TopoArgs args;
+    int32_t* gscratch;     // global scratch (when not in LDS)
+    int capN, capE;        // LDS capacities (0 = use global scratch)
+    int level1_only;       // second pass: only depth-1 clusters, c1 offsets from NC0
+};
+
+DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
+    TopoScratch s;
+    const int n0 = L.tv.p[DRGNN_TI_NPTR][g], N = L.tv.p[DRGNN_TI_NPTR][g + 1] - n0;
+    const int e0 = L.tv.p[DRGNN_TI_EPTR][g], E = L.tv.p[DRGNN_TI_EPTR][g + 1] - e0;
+    if (L.capN > 0) {
+        const int capT = imax(L.capN, L.capE) + 1;
+        s = topo_carve(lds, L.capN, L.capE, capT, L.capN + L.capE + 2);
+        if (N > L.capN || E > L.capE) {   // caller's bound was wrong: refuse loudly
+            FOR_TID(i, 1) { topo_flag(L.tv, DRGNN_S_EDGE_RANGE, g); }
+            return;
+        }
+    } else {
+        // linear placement (see topo_gscratch_base): disjoint regions without a scan
+        s = topo_carve(L.gscratch + topo_gscratch_base(n0, e0, g), N, E, N + E + 1, N + E + 2);
+    }
+    if (!L.level1_only) {
+        topo_graph(L.tv, L.args, g, s);
+    } else {
+        // offset of this graph's ids inside cluster1 = number of depth-0 clusters before it
+        FOR_TID(i, 1) { s.part[0] = 0; }
+        BARRIER();
+        FOR_TID(t, DRGNN_NTHREADS) {
+            int acc = 0;
+            for (int q = t; q < g; q += DRGNN_NTHREADS) acc += L.tv.p[DRGNN_TI_NC0][q];
+            if (acc) ATOMIC_ADD(&s.part[0], acc);
+        }
+        BARRIER();
+        const int begin = s.part[0];
+        const int C0 = L.tv.p[DRGNN_TI_NC0][g];
+        BARRIER();
+        int len = C0;
+        if (g == L.args.n_graphs - 1 && (int64_t)begin + C0 != L.args.len_cluster1) len = -1;
+        if ((int64_t)begin + C0 > L.args.len_cluster1) len = -1;
+        topo_graph_level1(L.tv, L.args, g, begin, len, s);
+    }
+}
+
+struct ScanArgs { TopoView tv; int n_graphs; };
+DEV void finalize_block(const ScanArgs& a, int* part) {
+    const int B = a.n_graphs;
+    const int src[3] = {DRGNN_TI_NC0, DRGNN_TI_NE1, DRGNN_TI_NC1};
+    const int dst[3] = {DRGNN_TI_CPTR0, DRGNN_TI_E1PTR, DRGNN_TI_CPTR1};
+    for (int w = 0; w < 3; ++w) {
+        int32_t* out = a.tv.p[dst[w]];
+        const int32_t* in = a.tv.p[src[w]];
+        FOR_TID(i, B + 1) { out[i] = (i < B) ? in[i] : 0; }
+        BARRIER();
+        wg_exscan(out, B + 1, part);
+    }
+}
+
+struct ReduceArgs {
+    const float* partials;
+    int n_graphs, n_branch, n_feat, n_partial;
+    int kind;
+    drgnn_conv_params lay1[DRGNN_MAX_BRANCH], lay2[DRGNN_MAX_BRANCH];   // striding (pointers unused)
+    drgnn_conv_grads g1[DRGNN_MAX_BRANCH], g2[DRGNN_MAX_BRANCH];
+    float* grad_x; int64_t n_nodes;    // [n_branch][Ntot][F] -> summed into branch 0
+};
+
+// one work item per (branch, partial element): fixed-order sum over the graphs
+DEV void reduce_item(const ReduceArgs& a, int64_t item) {
+    const int P = a.n_partial, F = a.n_feat;
+    if (item < (int64_t)a.n_branch * P) {
+        const int br = (int)(item / P), p = (int)(item % P);
+        float acc = 0.0f;
+        for (int g = 0; g < a.n_graphs; ++g) acc += a.partials[((int64_t)g * a.n_branch + br) * P + p];
+        const int o_w1s = F * DRGNN_H1, o_b1 = 2 * F * DRGNN_H1, o_w2n = o_b1 + DRGNN_H1;
+        const int o_w2s = o_w2n + DRGNN_H1 * DRGNN_H2, o_b2 = o_w2s + DRGNN_H1 * DRGNN_H2;
+        if (p < o_w1s) {
+            if (a.g1[br].w_nbr) a.g1[br].w_nbr[(int64_t)(p / DRGNN_H1) * a.lay1[br].nbr_sk + (int64_t)(p % DRGNN_H1) * a.lay1[br].nbr_sh] = acc;
+        } else if (p < o_b1) {
+            const int q = p - o_w1s;
+            if (a.g1[br].w_self) a.g1[br].w_self[(int64_t)(q / DRGNN_H1) * a.lay1[br].self_sk + (int64_t)(q % DRGNN_H1) * a.lay1[br].self_sh] = acc;
+        } else if (p < o_w2n) {
+            if (a.g1[br].bias) a.g1[br].bias[p - o_b1] = acc;
+        } else if (p < o_w2s) {
+            const int q = p - o_w2n;
+            if (a.g2[br].w_nbr) a.g2[br].w_nbr[(int64_t)(q / DRGNN_H2) * a.lay2[br].nbr_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].nbr_sh] = acc;
+        } else if (p < o_b2) {
+            const int q = p - o_w2s;
+            if (a.g2[br].w_self) a.g2[br].w_self[(int64_t)(q / DRGNN_H2) * a.lay2[br].self_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].self_sh] = acc;
+        } else {
+            if (a.g2[br].bias) a.g2[br].bias[p - o_b2] = acc;
+        }
+    }
+    if (a.grad_x != nullptr && a.n_branch > 1 && item < a.n_nodes * F) {
+        float acc = a.grad_x[item];
+        for (int br = 1; br < a.n_branch; ++br) acc += a.grad_x[(int64_t)br * a.n_nodes * F + item];
+        a.grad_x[item] = acc;
+    }
+}
+
+struct NetLaunch {
+    NetArgs a;
+    float* gscratch;
+    int capN, capC;      // LDS capacities (0 = global scratch)
+    int64_t gstride_n;   // global scratch: floats per node / per graph constant
+};
+
+template <int KIND, bool BWD>
+DEV void net_block(const NetLaunch& L, int blk, float* lds) {
+    const int nb = L.a.net.n_branch;
+    const int g = blk / nb, br = blk % nb;
+    float* scratch;
+    int capN, capC;
+    if (L.capN > 0) {
+        scratch = lds; capN = L.capN; capC = L.capC;
+    } else {
+        const int n0 = L.a.tv.p[DRGNN_TI_NPTR][g];
+        capN = L.a.tv.p[DRGNN_TI_NPTR][g + 1] - n0;
+        capC = capN;
+        const int64_t per_branch = net_scratch_floats(KIND, L.a.n_nodes, L.a.n_nodes) + 64LL * L.a.n_graphs;
+        scratch = L.gscratch + (int64_t)br * per_branch + net_scratch_floats(KIND, n0, n0) + 64LL * g - 64;
+        // net_scratch_floats(n0,n0) includes one +64 constant; remove it and add 64 per graph
+    }
+    if (BWD) net_backward_graph<KIND>(L.a, g, br, scratch, capN, capC);
+    else net_forward_graph<KIND>(L.a, g, br, scratch, capN, capC);
+}
+
+#ifndef DRGNN_EMU
+__global__ void __launch_bounds__(256) k_ptrs(PtrArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ptr_item(a, i);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_topo(TopoLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) int smem_i[];
+    topo_block(L, blockIdx.x, smem_i);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_finalize(ScanArgs a) {
+    __shared__ int part[DRGNN_NTHREADS + 4];
+    finalize_block(a, part);
+}
+__global__ void __launch_bounds__(256) k_reduce(ReduceArgs a, int64_t n_items) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_items) reduce_item(a, i);
+}
+template <int KIND, bool BWD>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_net(NetLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    net_block<KIND, BWD>(L, blockIdx.x, smem_f);
+}
+__global__ void k_zero_i32(int32_t* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+#endif
+
+// =====================================================================================
+// host side
+// =====================================================================================
+extern "C" {
+
+int drgnn_abi_version(void) { return DRGNN_ABI_VERSION; }
+
+int drgnn_topology_layout(int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int64_t* off_i32,
+                          int64_t* off_f32) {
+    if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !off_i32 || !off_f32) return DRGNN_E_ARG;
+    TopoLayout L;
+    topo_layout(n_nodes, n_edges, n_graphs, &L);
+    for (int k = 0; k <= DRGNN_TI_COUNT; ++k) off_i32[k] = L.i32[k];
+    for (int k = 0; k <= DRGNN_TF_COUNT; ++k) off_f32[k] = L.f32[k];
+    return 0;
+}
+
+int64_t drgnn_topology_scratch_elems(int64_t n_nodes, int64_t n_edges, int64_t n_graphs) {
+    return topo_gscratch_base(n_nodes, n_edges, n_graphs) + TOPO_GSCRATCH_CONST;
+}
+
+static int64_t topo_lds_bytes(int capN, int capE) {
+    const int64_t capT = (capN > capE ? capN : capE) + 1;
+    return 4 * topo_scratch_ints(capN, capE, capT, (int64_t)capN + capE + 2);
+}
+
+int64_t drgnn_topology_lds_bytes(int32_t max_nodes, int32_t max_edges) {
+    if (max_nodes <= 0) return 0;
+    return topo_lds_bytes(max_nodes, max_edges > 0 ? max_edges : 1);
+}
+
+int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, const int64_t* batch,
+                         const int64_t* cluster0, const int64_t* cluster1, const int32_t* node_ptr,
+                         const int32_t* edge_ptr, const int32_t* c1_ptr, int64_t n_nodes,
+                         int64_t n_edges, int64_t len_cluster1, int64_t n_graphs, int32_t max_nodes,
+                         int32_t max_edges, int32_t* ws_i32, float* ws_f32, int32_t* scratch_i32,
+                         void* stream_) {
+    if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !ws_i32 || !batch || !cluster0) return DRGNN_E_ARG;
+    if (n_edges > 0 && !edge_index) return DRGNN_E_ARG;
+    if (edge_attr && !ws_f32) return DRGNN_E_ARG;
+    if (n_nodes + n_graphs >= INT32_MAX || n_edges >= INT32_MAX) return DRGNN_E_CAPACITY;
+    drgnn_stream_t stream = (drgnn_stream_t)stream_;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    TopoLaunch L;
+    L.tv = topo_view(ws_i32, ws_f32, lay);
+    L.args.edge_index = edge_index;
+    L.args.edge_attr = edge_attr;
+    L.args.cluster0 = cluster0;
+    L.args.cluster1 = cluster1;
+    L.args.c1_ptr = c1_ptr;
+    L.args.n_edges = n_edges;
+    L.args.len_cluster1 = len_cluster1;
+    L.args.n_graphs = (int)n_graphs;
+    L.gscratch = scratch_i32;
+    L.level1_only = 0;
+    int64_t lds = 0;
+    L.capN = 0; L.capE = 0;
+    if (max_nodes > 0) {
+        lds = topo_lds_bytes(max_nodes, max_edges > 0 ? max_edges : 1);
+        if (lds <= DRGNN_LDS_LIMIT) { L.capN = max_nodes; L.capE = max_edges > 0 ? max_edges : 1; }
+        else lds = 0;
+    }
+    if (L.capN == 0 && !scratch_i32) return DRGNN_E_CAPACITY;
+    if (n_graphs == 0) return 0;
+    PtrArgs pa;
+    pa.batch = batch; pa.edge_row = edge_index; pa.n_nodes = n_nodes; pa.n_edges = n_edges;
+    pa.n_graphs = (int)n_graphs; pa.nptr = L.tv.p[DRGNN_TI_NPTR]; pa.eptr = L.tv.p[DRGNN_TI_EPTR];
+    pa.err = L.tv.p[DRGNN_TI_ERR];
+    const bool need_ptrs = !(node_ptr && edge_ptr);
+    const int64_t span = n_nodes > n_edges ? n_nodes : n_edges;
+#ifdef DRGNN_EMU
+    for (int k = 0; k < 4; ++k) pa.err[k] = 0;
+    if (need_ptrs) {
+        for (int64_t i = 0; i < (span > 0 ? span : 1); ++i) ptr_item(pa, i);
+    } else {
+        for (int64_t gph = 0; gph <= n_graphs; ++gph) { pa.nptr[gph] = node_ptr[gph]; pa.eptr[gph] = edge_ptr[gph]; }
+    }
+    std::vector<int> lds_buf((size_t)(lds / 4) + 16);
+    for (int gph = 0; gph < n_graphs; ++gph) topo_block(L, gph, lds_buf.data());
+    if (cluster1 && !c1_ptr) {
+        L.level1_only = 1;
+        for (int gph = 0; gph < n_graphs; ++gph) topo_block(L, gph, lds_buf.data());
+    }
+    (void)stream;
+#else
+    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, pa.err, 4);
+    if (need_ptrs) {
+        const int64_t items = span > 0 ? span : 1;
+        hipLaunchKernelGGL(k_ptrs, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, pa);
+    } else {
+        HIP_TRY(hipMemcpyAsync(pa.nptr, node_ptr, sizeof(int32_t) * (n_graphs + 1), hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(pa.eptr, edge_ptr, sizeof(int32_t) * (n_graphs + 1), hipMemcpyDeviceToDevice, stream));
+    }
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_topo, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
+    if (cluster1 && !c1_ptr) {
+        L.level1_only = 1;
+        hipLaunchKernelGGL(k_topo, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
+    }
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_topology_finalize(int32_t* ws_i32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                            void* stream_) {
+    if (!ws_i32 || n_graphs < 0) return DRGNN_E_ARG;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    ScanArgs a;
+    a.tv = topo_view(ws_i32, nullptr, lay);
+    a.n_graphs = (int)n_graphs;
+#ifdef DRGNN_EMU
+    int part[DRGNN_NTHREADS + 4];
+    finalize_block(a, part);
+    (void)stream_;
+#else
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_topology_status(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                          int32_t* status4, void* stream_) {
+    if (!ws_i32 || !status4) return DRGNN_E_ARG;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    const int32_t* src = ws_i32 + lay.i32[DRGNN_TI_ERR];
+#ifdef DRGNN_EMU
+    for (int k = 0; k < 4; ++k) status4[k] = src[k];
+    (void)stream_;
+#else
+    HIP_TRY(hipMemcpyAsync(status4, src, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
+#endif
+    return 0;
+}
+
+// ---- fused net ----------------------------------------------------------------------
+int64_t drgnn_net_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_c0) {
+    (void)n_feat;
+    if (max_nodes <= 0) return 0;
+    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    return 4 * net_scratch_floats(kind, max_nodes, capC);
+}
+
+int64_t drgnn_net_partial_elems(int32_t kind, int32_t n_feat) { (void)kind; return net_partial_floats(n_feat); }
+
+int64_t drgnn_net_scratch_elems(int32_t kind, int32_t n_feat, int64_t n_nodes, int64_t n_edges,
+                                int64_t n_graphs) {
+    (void)n_feat; (void)n_edges;
+    const int nb = (kind == DRGNN_GINET) ? 2 : 1;
+    return nb * (net_scratch_floats(kind, n_nodes, n_nodes) + 64 * n_graphs) + 64;
+}
+
+}  // extern "C"
+
+static int net_check(const drgnn_net_desc* net) {
+    if (!net) return DRGNN_E_ARG;
+    if (net->kind < DRGNN_GINET || net->kind > DRGNN_FOUT) return DRGNN_E_ARG;
+    if (net->n_branch < 1 || net->n_branch > DRGNN_MAX_BRANCH) return DRGNN_E_ARG;
+    if (net->n_feat < 1) return DRGNN_E_WIDTH;
+    for (int b = 0; b < net->n_branch; ++b) {
+        if (!net->conv1[b].w_nbr || !net->conv2[b].w_nbr) return DRGNN_E_ARG;
+        if (net->kind != DRGNN_GINET &&
+            (!net->conv1[b].w_self || !net->conv2[b].w_self || !net->conv1[b].bias || !net->conv2[b].bias))
+            return DRGNN_E_ARG;
+    }
+    return 0;
+}
+
+template <bool BWD>
+static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_c0, float* scratch, void* stream_) {
+    const int kind = L.a.net.kind;
+    const int64_t lds = drgnn_net_lds_bytes(kind, L.a.net.n_feat, max_nodes, max_c0);
+    L.capN = 0; L.capC = 0; L.gscratch = scratch;
+    int64_t use_lds = 0;
+    if (lds > 0 && lds <= DRGNN_LDS_LIMIT) {
+        L.capN = max_nodes;
+        L.capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+        use_lds = lds;
+    } else if (!scratch) {
+        return DRGNN_E_CAPACITY;
+    }
+    const int blocks = L.a.n_graphs * L.a.net.n_branch;
+    if (blocks == 0) return 0;
+#ifdef DRGNN_EMU
+    std::vector<float> buf((size_t)(use_lds / 4) + 16);
+    for (int b = 0; b < blocks; ++b) {
+        if (kind == DRGNN_GINET) net_block<DRGNN_GINET, BWD>(L, b, buf.data());
+        else if (kind == DRGNN_SGAT) net_block<DRGNN_SGAT, BWD>(L, b, buf.data());
+        else net_block<DRGNN_FOUT, BWD>(L, b, buf.data());
+    }
+    (void)stream_;
+#else
+    hipStream_t stream = (hipStream_t)stream_;
+#define DRGNN_NET_LAUNCH(K)                                                                         \
+    do {                                                                                            \
+        if (use_lds > 64 * 1024)                                                                    \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_net<K, BWD>,                                 \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)use_lds)); \
+        hipLaunchKernelGGL((k_net<K, BWD>), dim3((unsigned)blocks), dim3(DRGNN_NTHREADS),           \
+                           (size_t)use_lds, stream, L);                                             \
+    } while (0)
+    if (kind == DRGNN_GINET) DRGNN_NET_LAUNCH(DRGNN_GINET);
+    else if (kind == DRGNN_SGAT) DRGNN_NET_LAUNCH(DRGNN_SGAT);
+    else DRGNN_NET_LAUNCH(DRGNN_FOUT);
+#undef DRGNN_NET_LAUNCH
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+extern "C" {
+
+int drgnn_net_forward(const drgnn_net_desc* net, const float* x, const int32_t* ws_i32,
+                      const float* ws_f32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                      int32_t max_nodes, int32_t max_c0, float* xp, int32_t* arg0, int32_t* arg1,
+                      float* readout, float* scratch_f32, void* stream_) {
+    int rc = net_check(net);
+    if (rc) return rc;
+    if (!x || !ws_i32 || !xp || !arg0 || !arg1 || !readout) return DRGNN_E_ARG;
+    if (net->kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    NetLaunch L;
+    L.a.net = *net;
+    L.a.x = x;
+    L.a.tv = topo_view(const_cast<int32_t*>(ws_i32), const_cast<float*>(ws_f32), lay);
+    L.a.n_nodes = n_nodes;
+    L.a.n_graphs = (int)n_graphs;
+    L.a.xp = xp; L.a.arg0 = arg0; L.a.arg1 = arg1; L.a.readout = readout;
+    L.a.grad_readout = nullptr; L.a.partials = nullptr; L.a.grad_x = nullptr; L.a.n_partial = 0;
+    return net_launch<false>(L, max_nodes, max_c0, scratch_f32, stream_);
+}
+
+int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* grad_readout,
+                       const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges,
+                       int64_t n_graphs, int32_t max_nodes, int32_t max_c0, const float* xp,
+                       const int32_t* arg0, const int32_t* arg1, drgnn_conv_grads* g_conv1,
+                       drgnn_conv_grads* g_conv2, float* grad_x, float* partials, float* scratch_f32,
+                       void* stream_) {
+    int rc = net_check(net);
+    if (rc) return rc;
+    if (!x || !grad_readout || !ws_i32 || !xp || !arg0 || !arg1 || !g_conv1 || !g_conv2 || !partials)
+        return DRGNN_E_ARG;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    NetLaunch L;
+    L.a.net = *net;
+    L.a.x = x;
+    L.a.tv = topo_view(const_cast<int32_t*>(ws_i32), const_cast<float*>(ws_f32), lay);
+    L.a.n_nodes = n_nodes;
+    L.a.n_graphs = (int)n_graphs;
+    L.a.xp = const_cast<float*>(xp); L.a.arg0 = const_cast<int32_t*>(arg0);
+    L.a.arg1 = const_cast<int32_t*>(arg1); L.a.readout = nullptr;
+    L.a.grad_readout = grad_readout; L.a.partials = partials; L.a.grad_x = grad_x;
+    L.a.n_partial = (int)net_partial_floats(net->n_feat);
+    rc = net_launch<true>(L, max_nodes, max_c0, scratch_f32, stream_);
+    if (rc) return rc;
+    ReduceArgs r;
+    r.partials = partials; r.n_graphs = (int)n_graphs; r.n_branch = net->n_branch;
+    r.n_feat = net->n_feat; r.n_partial = L.a.n_partial; r.kind = net->kind;
+    for (int b = 0; b < DRGNN_MAX_BRANCH; ++b) {
+        r.lay1[b] = net->conv1[b]; r.lay2[b] = net->conv2[b];
+        if (b < net->n_branch) { r.g1[b] = g_conv1[b]; r.g2[b] = g_conv2[b]; }
+        else { r.g1[b] = drgnn_conv_grads{nullptr, nullptr, nullptr}; r.g2[b] = r.g1[b]; }
+    }
+    r.grad_x = grad_x; r.n_nodes = n_nodes;
+    int64_t items = (int64_t)net->n_branch * r.n_partial;
+    if (grad_x && net->n_branch > 1 && n_nodes * net->n_feat > items) items = n_nodes * net->n_feat;
+#ifdef DRGNN_EMU
+    for (int64_t i = 0; i < items; ++i) reduce_item(r, i);
+#else
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, r, items);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,434 @@
+// drgnn_net.h -- fused network body: one workgroup per (graph, branch).
+//
+//   conv1 -> relu -> cluster max (depth 0) -> conv2 -> relu -> cluster max (depth 1) -> mean
+//
+// "conv" is the common form of the three reference layers
+//       z_i = s_i * (x_i Wself) + sum_{e: row(e)=i} c_e * (x_col(e) Wnbr) + b
+//   GINet   s = 0          c_e = 1                       no bias     (ginet.py:50-73, alpha==1)
+//   sGAT    s_i = mean a   c_e = a_e / max(deg_i,1)      bias        (sGAT.py:62-93)
+//   FoutNet s = 1          c_e = 1 / deg_i (NaN if 0)    bias        (foutnet.py:56-82)
+// The dense products run on the f32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32); the
+// neighbour aggregation is a CSR gather out of LDS with a fixed summation order; cluster
+// max keeps the first maximum in ascending member order (torch_scatter CPU tie rule).
+#pragma once
+#include "drgnn_topology.h"
+
+#define DRGNN_H1 16
+#define DRGNN_H2 32
+
+#ifdef DRGNN_EMU
+#define DRGNN_NAN (NAN)
+#define DRGNN_NEG_INF (-INFINITY)
+#else
+#define DRGNN_NAN (__builtin_nanf(""))
+#define DRGNN_NEG_INF (-__builtin_inff())
+#endif
+
+// ---------------------------------------------------------------------------------
+// Workgroup GEMM  C(i,j) = sum_k A(i,k) B(k,j),  i<M, j<N, k<K, fully strided operands.
+// gfx950: 16x16 output tiles spread over the 4 waves, K consumed 4 at a time by
+// v_mfma_f32_16x16x4_f32 (A: lane -> row l&15, k l>>4;  B: lane -> k l>>4, col l&15;
+// D: col l&15, rows 4*(l>>4)+r).  No barrier inside; callers separate phases.
+// ---------------------------------------------------------------------------------
+#ifdef DRGNN_EMU
+DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const float* B, int sbk,
+                 int sbj, float* C, int sci, int scj) {
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < N; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) acc = fmaf(A[i * sai + k * sak], B[k * sbk + j * sbj], acc);
+            C[i * sci + j * scj] = acc;
+        }
+}
+#else
+typedef float drgnn_f32x4 __attribute__((ext_vector_type(4)));
+DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const float* B, int sbk,
+                 int sbj, float* C, int sci, int scj) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int mt = (M + 15) >> 4, nt = (N + 15) >> 4;
+    for (int tile = wave; tile < mt * nt; tile += DRGNN_NWAVES) {
+        const int i0 = (tile / nt) << 4, j0 = (tile % nt) << 4;
+        const int ai = i0 + lr, bj = j0 + lr;
+        const bool a_ok = ai < M, b_ok = bj < N;
+        const float* ap = A + (long)ai * sai;
+        const float* bp = B + (long)bj * sbj;
+        drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            const int k = k0 + lq;
+            const bool k_ok = k < K;
+            const float a = (a_ok && k_ok) ? ap[(long)k * sak] : 0.0f;
+            const float b = (b_ok && k_ok) ? bp[(long)k * sbk] : 0.0f;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+        if (b_ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ci = i0 + lq * 4 + r;
+                if (ci < M) C[(long)ci * sci + (long)bj * scj] = acc[r];
+            }
+        }
+    }
+}
+#endif
+
+// ---- per-launch description ----------------------------------------------------------
+struct NetArgs {
+    drgnn_net_desc net;
+    const float* x;          // [Ntot, F]
+    TopoView tv;
+    int64_t n_nodes;         // Ntot
+    int n_graphs;
+    // forward outputs / backward inputs (padded per-graph layout)
+    float* xp;               // [n_branch][Ntot][16]
+    int32_t* arg0;           // [n_branch][Ntot][16]
+    int32_t* arg1;           // [n_branch][Ntot][32]
+    float* readout;          // [B][32*n_branch]
+    // backward
+    const float* grad_readout;
+    float* partials;         // [B*n_branch][P]
+    float* grad_x;           // [n_branch][Ntot][F] or null (summed over branches by the reducer)
+    int n_partial;           // P
+};
+
+DEV int net_hc(int kind, int h) { return kind == DRGNN_GINET ? h : 2 * h; }
+
+// scratch floats for one workgroup; capC bounds the number of depth-0 clusters
+HD int64_t net_scratch_floats(int kind, int64_t capN, int64_t capC) {
+    const int64_t hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
+    const int64_t hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
+    return capN * (hc1 + DRGNN_H1 + 2) + capC * (DRGNN_H1 + hc2 + DRGNN_H2 + DRGNN_H2 + 2) + 64;
+}
+
+struct NetScratch {
+    float* u1;    // [capN][hc1]   x W1 (nbr | self)      bwd: dU1
+    float* z1;    // [capN][16]    relu(conv1)            bwd: dZ1
+    float* dv0;   // [capN]        1/deg (mode dependent)
+    float* sc0;   // [capN]        self coefficient
+    float* xp;    // [capC][16]    pooled features        bwd: dXP
+    float* u2;    // [capC][hc2]                           bwd: dU2
+    float* z2;    // [capC][32]                            bwd: dZ2
+    float* p2;    // [capC][32]    depth-1 pooled
+    float* dv1;   // [capC]
+    float* sc1;   // [capC]
+    float* misc;  // [64]
+};
+
+DEV NetScratch net_carve(float* base, int kind, int capN, int capC) {
+    const int hc1 = net_hc(kind, DRGNN_H1), hc2 = net_hc(kind, DRGNN_H2);
+    NetScratch s;
+    float* p = base;
+    s.u1 = p;  p += (long)capN * hc1;
+    s.z1 = p;  p += (long)capN * DRGNN_H1;
+    s.dv0 = p; p += capN;
+    s.sc0 = p; p += capN;
+    s.xp = p;  p += (long)capC * DRGNN_H1;
+    s.u2 = p;  p += (long)capC * hc2;
+    s.z2 = p;  p += (long)capC * DRGNN_H2;
+    s.p2 = p;  p += (long)capC * DRGNN_H2;
+    s.dv1 = p; p += capC;
+    s.sc1 = p; p += capC;
+    s.misc = p;
+    return s;
+}
+
+// per-row coefficients of one level:  dv[i] (edge scale), sc[i] (self scale)
+template <int KIND>
+DEV void net_row_coefs(int n, const int32_t* rp, const float* w, float* dv, float* sc) {
+    if (KIND == DRGNN_GINET) return;
+    FOR_TID(i, n) {
+        const int lo = rp[i], hi = rp[i + 1];
+        const int deg = hi - lo;
+        if (KIND == DRGNN_SGAT) {
+            float asum = 0.0f;
+            for (int k = lo; k < hi; ++k) asum += w[k];
+            const float inv = 1.0f / (float)(deg > 0 ? deg : 1);
+            dv[i] = inv;
+            sc[i] = asum * inv;
+        } else {
+            dv[i] = deg > 0 ? 1.0f / (float)deg : 0.0f;   // deg == 0 handled explicitly (NaN fwd, 0 bwd)
+            sc[i] = 1.0f;
+        }
+    }
+}
+
+// z[i, :] = relu( sc[i]*u[i, H:2H] + sum_k coef_k * u[col[k], 0:H] + bias )   (H multiple of 4)
+template <int KIND, int H>
+DEV void net_aggregate(int n, const int32_t* rp, const int32_t* col, const float* w, const float* dv,
+                       const float* sc, const float* u, const float* bias, float* z) {
+    constexpr int HC = (KIND == DRGNN_GINET) ? H : 2 * H;
+    constexpr int G = H / 4;
+    FOR_TID(item, n * G) {
+        const int i = item / G, c = (item % G) * 4;
+        const int lo = rp[i], hi = rp[i + 1];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int k = lo; k < hi; ++k) {
+            const float* uj = u + (long)col[k] * HC + c;
+            float cf = 1.0f;
+            if (KIND == DRGNN_SGAT) cf = w[k];
+            a0 = fmaf(cf, uj[0], a0); a1 = fmaf(cf, uj[1], a1);
+            a2 = fmaf(cf, uj[2], a2); a3 = fmaf(cf, uj[3], a3);
+        }
+        if (KIND != DRGNN_GINET) {
+            const float d = dv[i], s = sc[i];
+            const float* us = u + (long)i * HC + H + c;
+            a0 = fmaf(s, us[0], a0 * d) + bias[c + 0];
+            a1 = fmaf(s, us[1], a1 * d) + bias[c + 1];
+            a2 = fmaf(s, us[2], a2 * d) + bias[c + 2];
+            a3 = fmaf(s, us[3], a3 * d) + bias[c + 3];
+            if (KIND == DRGNN_FOUT && hi == lo) { a0 = a1 = a2 = a3 = DRGNN_NAN; }
+        }
+        float* zi = z + (long)i * H + c;
+        // relu that lets NaN through, like torch (max(x,0) would swallow it)
+        zi[0] = (a0 < 0.f) ? 0.f : a0; zi[1] = (a1 < 0.f) ? 0.f : a1;
+        zi[2] = (a2 < 0.f) ? 0.f : a2; zi[3] = (a3 < 0.f) ? 0.f : a3;
+    }
+}
+
+// cluster max with argmax (first maximum in ascending member order; NaN never wins;
+// empty cluster -> 0).  arg = -1 where no gradient can flow (value <= 0 or empty).
+template <int H>
+DEV void net_cluster_max(int nc, const int32_t* mp, const int32_t* mem, const float* z, float* out,
+                         float* g_out, int32_t* g_arg) {
+    FOR_TID(item, nc * H) {
+        const int r = item / H, c = item % H;
+        float best = DRGNN_NEG_INF;
+        int arg = -1;
+        for (int p = mp[r]; p < mp[r + 1]; ++p) {
+            const int m = mem[p];
+            const float v = z[(long)m * H + c];
+            if (v > best) { best = v; arg = m; }
+        }
+        if (arg < 0) best = 0.0f;
+        out[item] = best;
+        if (g_out) g_out[item] = best;
+        g_arg[item] = (best > 0.0f) ? arg : -1;
+    }
+}
+
+struct GraphDims { int n0, N, e0, C, C1, rowbase; };
+
+DEV GraphDims net_dims(const TopoView& tv, int g) {
+    GraphDims d;
+    d.n0 = tv.p[DRGNN_TI_NPTR][g];
+    d.N = tv.p[DRGNN_TI_NPTR][g + 1] - d.n0;
+    d.e0 = tv.p[DRGNN_TI_EPTR][g];
+    d.C = tv.p[DRGNN_TI_NC0][g];
+    d.C1 = tv.p[DRGNN_TI_NC1][g];
+    d.rowbase = d.n0 + g;
+    return d;
+}
+
+// ---------------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------------
+template <int KIND>
+DEV void net_forward_graph(const NetArgs& a, int g, int br, float* scratch, int capN, int capC) {
+    constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
+    constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
+    const TopoView& tv = a.tv;
+    const GraphDims d = net_dims(tv, g);
+    const int F = a.net.n_feat;
+    NetScratch s = net_carve(scratch, KIND, capN, capC);
+    const drgnn_conv_params& c1 = a.net.conv1[br];
+    const drgnn_conv_params& c2 = a.net.conv2[br];
+    const float* xg = a.x + (long)d.n0 * F;
+    const int32_t* rp0 = tv.p[DRGNN_TI_ROWPTR0] + d.rowbase;
+    const int32_t* col0 = tv.p[DRGNN_TI_COL0] + d.e0;
+    const int32_t* rp1 = tv.p[DRGNN_TI_ROWPTR1] + d.rowbase;
+    const int32_t* col1 = tv.p[DRGNN_TI_COL1] + d.e0;
+    const float* w0 = tv.w0 ? tv.w0 + d.e0 : nullptr;
+    const float* w1 = tv.w1 ? tv.w1 + d.e0 : nullptr;
+    const long nodeoff = (long)br * a.n_nodes + d.n0;
+
+    // conv1 dense part:  U1 = X W1
+    wg_gemm(d.N, DRGNN_H1, F, xg, F, 1, c1.w_nbr, (int)c1.nbr_sk, (int)c1.nbr_sh, s.u1, HC1, 1);
+    if (KIND != DRGNN_GINET)
+        wg_gemm(d.N, DRGNN_H1, F, xg, F, 1, c1.w_self, (int)c1.self_sk, (int)c1.self_sh,
+                s.u1 + DRGNN_H1, HC1, 1);
+    net_row_coefs<KIND>(d.N, rp0, w0, s.dv0, s.sc0);
+    BARRIER();
+    net_aggregate<KIND, DRGNN_H1>(d.N, rp0, col0, w0, s.dv0, s.sc0, s.u1, c1.bias, s.z1);
+    BARRIER();
+    net_cluster_max<DRGNN_H1>(d.C, tv.p[DRGNN_TI_MPTR0] + d.rowbase, tv.p[DRGNN_TI_MEM0] + d.n0, s.z1,
+                              s.xp, a.xp + nodeoff * DRGNN_H1, a.arg0 + nodeoff * DRGNN_H1);
+    BARRIER();
+    // conv2 on the pooled graph
+    wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, c2.w_nbr, (int)c2.nbr_sk, (int)c2.nbr_sh, s.u2,
+            HC2, 1);
+    if (KIND != DRGNN_GINET)
+        wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, c2.w_self, (int)c2.self_sk, (int)c2.self_sh,
+                s.u2 + DRGNN_H2, HC2, 1);
+    net_row_coefs<KIND>(d.C, rp1, w1, s.dv1, s.sc1);
+    BARRIER();
+    net_aggregate<KIND, DRGNN_H2>(d.C, rp1, col1, w1, s.dv1, s.sc1, s.u2, c2.bias, s.z2);
+    BARRIER();
+    net_cluster_max<DRGNN_H2>(d.C1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, tv.p[DRGNN_TI_MEM1] + d.n0, s.z2,
+                              s.p2, nullptr, a.arg1 + nodeoff * DRGNN_H2);
+    BARRIER();
+    // graph readout: mean over the depth-1 clusters (scatter_mean with count clamp)
+    const int bad = tv.p[DRGNN_TI_ERR][0];
+    const int width = DRGNN_H2 * a.net.n_branch;
+    FOR_TID(c, DRGNN_H2) {
+        float acc = 0.0f;
+        for (int k = 0; k < d.C1; ++k) acc += s.p2[k * DRGNN_H2 + c];
+        acc = acc / (float)(d.C1 > 0 ? d.C1 : 1);
+        a.readout[(long)g * width + br * DRGNN_H2 + c] = bad ? DRGNN_NAN : acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// backward
+// partial layout per workgroup (floats), K x H row-major blocks:
+//   [dW1nbr F*16][dW1self F*16][db1 16][dW2nbr 16*32][dW2self 16*32][db2 32]
+// ---------------------------------------------------------------------------------
+static inline int64_t net_partial_floats(int n_feat) {
+    return 2LL * n_feat * DRGNN_H1 + DRGNN_H1 + 2LL * DRGNN_H1 * DRGNN_H2 + DRGNN_H2;
+}
+
+// dU[j, 0:H]   = sum over CSC entries t of column j : coef * dZ[row(t), :]
+// dU[i, H:2H]  = sc[i] * dZ[i, :]
+template <int KIND, int H>
+DEV void net_aggregate_bwd(int n, const int32_t* rp, const int32_t* cp, const int32_t* ridx,
+                           const int32_t* tslot, const float* w, const float* dv, const float* sc,
+                           const float* dz, float* du) {
+    constexpr int HC = (KIND == DRGNN_GINET) ? H : 2 * H;
+    constexpr int G = H / 4;
+    FOR_TID(item, n * G) {
+        const int j = item / G, c = (item % G) * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int t = cp[j]; t < cp[j + 1]; ++t) {
+            const int i = ridx[t];
+            float cf = 1.0f;
+            if (KIND == DRGNN_SGAT) cf = w[tslot[t]] * dv[i];
+            if (KIND == DRGNN_FOUT) cf = dv[i];
+            const float* di = dz + (long)i * H + c;
+            a0 = fmaf(cf, di[0], a0); a1 = fmaf(cf, di[1], a1);
+            a2 = fmaf(cf, di[2], a2); a3 = fmaf(cf, di[3], a3);
+        }
+        float* uj = du + (long)j * HC + c;
+        uj[0] = a0; uj[1] = a1; uj[2] = a2; uj[3] = a3;
+        if (KIND != DRGNN_GINET) {
+            float s = sc[j];
+            if (KIND == DRGNN_FOUT && rp[j + 1] == rp[j]) s = 0.0f;   // NaN row never wins a max
+            const float* dj = dz + (long)j * H + c;
+            uj[H + 0] = s * dj[0]; uj[H + 1] = s * dj[1];
+            uj[H + 2] = s * dj[2]; uj[H + 3] = s * dj[3];
+        }
+    }
+}
+
+template <int KIND>
+DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int capN, int capC) {
+    constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
+    constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
+    const TopoView& tv = a.tv;
+    const GraphDims d = net_dims(tv, g);
+    const int F = a.net.n_feat;
+    NetScratch s = net_carve(scratch, KIND, capN, capC);
+    const drgnn_conv_params& c1 = a.net.conv1[br];
+    const drgnn_conv_params& c2 = a.net.conv2[br];
+    const float* xg = a.x + (long)d.n0 * F;
+    const int32_t* rp0 = tv.p[DRGNN_TI_ROWPTR0] + d.rowbase;
+    const int32_t* rp1 = tv.p[DRGNN_TI_ROWPTR1] + d.rowbase;
+    const float* w0 = tv.w0 ? tv.w0 + d.e0 : nullptr;
+    const float* w1 = tv.w1 ? tv.w1 + d.e0 : nullptr;
+    const long nodeoff = (long)br * a.n_nodes + d.n0;
+    const float* g_xp = a.xp + nodeoff * DRGNN_H1;
+    const int32_t* g_arg0 = a.arg0 + nodeoff * DRGNN_H1;
+    const int32_t* g_arg1 = a.arg1 + nodeoff * DRGNN_H2;
+    const int width = DRGNN_H2 * a.net.n_branch;
+    const float* dr = a.grad_readout + (long)g * width + br * DRGNN_H2;
+    float* part = a.partials + ((long)g * a.net.n_branch + br) * a.n_partial;
+    float* p_w1n = part;
+    float* p_w1s = p_w1n + (long)F * DRGNN_H1;
+    float* p_b1 = p_w1s + (long)F * DRGNN_H1;
+    float* p_w2n = p_b1 + DRGNN_H1;
+    float* p_w2s = p_w2n + DRGNN_H1 * DRGNN_H2;
+    float* p_b2 = p_w2s + DRGNN_H1 * DRGNN_H2;
+
+    // ---- depth-1 max + mean backward: dZ2 (relu mask folded into arg1 = -1) ------------
+    FOR_TID(item, d.C * DRGNN_H2) { s.z2[item] = 0.0f; }
+    net_row_coefs<KIND>(d.C, rp1, w1, s.dv1, s.sc1);
+    net_row_coefs<KIND>(d.N, rp0, w0, s.dv0, s.sc0);
+    BARRIER();
+    {
+        const float inv = 1.0f / (float)(d.C1 > 0 ? d.C1 : 1);
+        FOR_TID(item, d.C1 * DRGNN_H2) {
+            const int r = g_arg1[item];
+            const int c = item % DRGNN_H2;
+            if (r >= 0) s.z2[(long)r * DRGNN_H2 + c] = dr[c] * inv;
+        }
+    }
+    BARRIER();
+    // ---- conv2 backward ------------------------------------------------------------
+    net_aggregate_bwd<KIND, DRGNN_H2>(d.C, rp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase,
+                                      tv.p[DRGNN_TI_ROWIDX1] + d.e0, tv.p[DRGNN_TI_TSLOT1] + d.e0, w1,
+                                      s.dv1, s.sc1, s.z2, s.u2);
+    FOR_TID(c, DRGNN_H2) {
+        float acc = 0.0f;
+        for (int r = 0; r < d.C; ++r) acc += s.z2[r * DRGNN_H2 + c];
+        p_b2[c] = acc;
+    }
+    BARRIER();
+    // dW2 = XP^T dU2      (A(i=k16, k=r) = xp[r*16 + i])
+    wg_gemm(DRGNN_H1, DRGNN_H2, d.C, g_xp, 1, DRGNN_H1, s.u2, HC2, 1, p_w2n, DRGNN_H2, 1);
+    if (KIND != DRGNN_GINET)
+        wg_gemm(DRGNN_H1, DRGNN_H2, d.C, g_xp, 1, DRGNN_H1, s.u2 + DRGNN_H2, HC2, 1, p_w2s, DRGNN_H2, 1);
+    // dXP = dU2n W2n^T (+ dU2s W2s^T): B(k=h, j=i16) = W2(i16, h) = w[i*sk + h*sh]
+    if (KIND == DRGNN_GINET) {
+        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, c2.w_nbr, (int)c2.nbr_sh, (int)c2.nbr_sk, s.xp,
+                DRGNN_H1, 1);
+    } else {
+        // two products accumulated: first into xp, second into p2 (free here), then added
+        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, c2.w_nbr, (int)c2.nbr_sh, (int)c2.nbr_sk, s.xp,
+                DRGNN_H1, 1);
+        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2 + DRGNN_H2, HC2, 1, c2.w_self, (int)c2.self_sh,
+                (int)c2.self_sk, s.p2, DRGNN_H1, 1);
+    }
+    FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }
+    BARRIER();
+    // ---- depth-0 max backward: dZ1 ----------------------------------------------------
+    FOR_TID(item, d.C * DRGNN_H1) {
+        const int m = g_arg0[item];
+        const int c = item % DRGNN_H1;
+        if (m >= 0) {
+            float v = s.xp[item];
+            if (KIND != DRGNN_GINET) v += s.p2[item];
+            s.z1[(long)m * DRGNN_H1 + c] = v;
+        }
+    }
+    BARRIER();
+    // ---- conv1 backward ------------------------------------------------------------
+    net_aggregate_bwd<KIND, DRGNN_H1>(d.N, rp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase,
+                                      tv.p[DRGNN_TI_ROWIDX0] + d.e0, tv.p[DRGNN_TI_TSLOT0] + d.e0, w0,
+                                      s.dv0, s.sc0, s.z1, s.u1);
+    FOR_TID(c, DRGNN_H1) {
+        float acc = 0.0f;
+        for (int i = 0; i < d.N; ++i) acc += s.z1[i * DRGNN_H1 + c];
+        p_b1[c] = acc;
+    }
+    BARRIER();
+    // dW1 = X^T dU1      (A(i=f, k=node) = x[node*F + f])
+    wg_gemm(F, DRGNN_H1, d.N, xg, 1, F, s.u1, HC1, 1, p_w1n, DRGNN_H1, 1);
+    if (KIND != DRGNN_GINET)
+        wg_gemm(F, DRGNN_H1, d.N, xg, 1, F, s.u1 + DRGNN_H1, HC1, 1, p_w1s, DRGNN_H1, 1);
+    if (a.grad_x != nullptr) {
+        // dX = dU1n W1n^T (+ dU1s W1s^T), written per branch; branches are summed by the reducer
+        float* gx = a.grad_x + nodeoff * F;
+        wg_gemm(d.N, F, DRGNN_H1, s.u1, HC1, 1, c1.w_nbr, (int)c1.nbr_sh, (int)c1.nbr_sk, gx, F, 1);
+        if (KIND != DRGNN_GINET) {
+            BARRIER();
+            // second product accumulated through z1-sized LDS is not possible for F > 16:
+            // add it row by row instead (each thread owns whole (node, f) entries)
+            FOR_TID(item, d.N * F) {
+                const int i = item / F, f = item % F;
+                const float* us = s.u1 + (long)i * HC1 + DRGNN_H1;
+                float acc = 0.0f;
+                for (int h = 0; h < DRGNN_H1; ++h)
+                    acc = fmaf(us[h], c1.w_self[(long)f * c1.self_sk + (long)h * c1.self_sh], acc);
+                gx[item] += acc;
+            }
+        }
+    }
+}

@@ -1,0 +1,107 @@
+// drgnn_rt.h -- execution-model glue shared by all kernels.
+//
+// Kernels are written as a sequence of barrier-separated phases over a workgroup:
+//     FOR_TID(i, n) { ... }   work items i = tid, tid + nthreads, ...
+//     BARRIER();
+// No per-thread value survives a BARRIER except through memory.  That discipline lets the
+// SAME source be compiled twice:
+//   * hipcc --offload-arch=gfx950 : the product (256-thread workgroups, 64-wide waves,
+//     MFMA, LDS);
+//   * g++ -DDRGNN_EMU             : a host emulation used ONLY by the CPU test-suite
+//     (tests/emu), where a "workgroup" is a plain loop that runs every work item of a
+//     phase in order.  It checks index logic without a GPU; it is never loaded by the
+//     package.
+#pragma once
+#include <stdint.h>
+
+#ifdef DRGNN_EMU
+// ---------------------------------------------------------------- host emulation
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <limits.h>
+#define DEV static inline
+#define HD static inline
+#define FOR_TID(i, n) for (int i = 0; i < (int)(n); ++i)
+#define BARRIER() ((void)0)
+#define DRGNN_NTHREADS 256
+struct WG { int block; int nthreads; };
+#define WG_TID0(wg) (true)
+DEV int emu_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
+DEV void emu_atomic_or(int* p, int v) { *p |= v; }
+DEV void emu_atomic_min64(long long* p, long long v) { if (v < *p) *p = v; }
+DEV void emu_atomic_max64(long long* p, long long v) { if (v > *p) *p = v; }
+#define ATOMIC_ADD(p, v) emu_atomic_add((p), (v))
+#define ATOMIC_OR(p, v) emu_atomic_or((p), (v))
+#define ATOMIC_MIN64(p, v) emu_atomic_min64((p), (v))
+#define ATOMIC_MAX64(p, v) emu_atomic_max64((p), (v))
+typedef void* drgnn_stream_t;
+#else
+// ---------------------------------------------------------------- gfx950
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#define DEV __device__ __forceinline__
+#define HD __host__ __device__ static inline
+#define DRGNN_NTHREADS 256
+#define FOR_TID(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += DRGNN_NTHREADS)
+#define BARRIER() __syncthreads()
+struct WG { int block; int nthreads; };
+#define ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#define ATOMIC_OR(p, v) atomicOr((p), (v))
+#define ATOMIC_MIN64(p, v) atomicMin((p), (long long)(v))
+#define ATOMIC_MAX64(p, v) atomicMax((p), (long long)(v))
+typedef hipStream_t drgnn_stream_t;
+#endif
+
+#define DRGNN_WAVE 64
+#define DRGNN_NWAVES (DRGNN_NTHREADS / DRGNN_WAVE)
+
+DEV int imin(int a, int b) { return a < b ? a : b; }
+DEV int imax(int a, int b) { return a > b ? a : b; }
+
+// ---------------------------------------------------------------------------------
+// Workgroup-wide exclusive scan, in place, of a[0..n).  `part` is DRGNN_NTHREADS+1 ints of
+// workgroup-visible scratch.  Returns the total in part[DRGNN_NTHREADS] (valid after the
+// call for every thread).  Three barriers.
+// ---------------------------------------------------------------------------------
+#ifdef DRGNN_EMU
+DEV int wg_exscan(int* a, int n, int* part) {
+    int run = 0;
+    for (int i = 0; i < n; ++i) { int v = a[i]; a[i] = run; run += v; }
+    part[DRGNN_NTHREADS] = run;
+    return run;
+}
+#else
+DEV int wg_exscan(int* a, int n, int* part) {
+    const int t = threadIdx.x;
+    const int chunk = (n + DRGNN_NTHREADS - 1) / DRGNN_NTHREADS;
+    const int lo = imin(t * chunk, n), hi = imin(lo + chunk, n);
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += a[i];
+    part[t] = s;
+    __syncthreads();
+    if (t < DRGNN_WAVE) {
+        constexpr int PER = DRGNN_NTHREADS / DRGNN_WAVE;
+        int v[PER];
+        int loc = 0;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { v[j] = part[t * PER + j]; loc += v[j]; }
+        int inc = loc;
+#pragma unroll
+        for (int d = 1; d < DRGNN_WAVE; d <<= 1) {
+            int o = __shfl_up(inc, d, DRGNN_WAVE);
+            if (t >= d) inc += o;
+        }
+        int run = inc - loc;
+#pragma unroll
+        for (int j = 0; j < PER; ++j) { part[t * PER + j] = run; run += v[j]; }
+        if (t == DRGNN_WAVE - 1) part[DRGNN_NTHREADS] = inc;
+    }
+    __syncthreads();
+    int run = part[t];
+    for (int i = lo; i < hi; ++i) { int v = a[i]; a[i] = run; run += v; }
+    const int total = part[DRGNN_NTHREADS];
+    __syncthreads();
+    return total;
+}
+#endif

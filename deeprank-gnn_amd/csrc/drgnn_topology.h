@@ -1,0 +1,418 @@
+// drgnn_topology.h -- per-graph topology construction (one workgroup per graph).
+//
+// Everything the convolutions and poolings need that depends only on the index tensors:
+//   CSR0/CSC0 of the input graph, consecutive depth-0 clusters + member lists,
+//   pooled graph CSR1/CSC1 (pool_edge: relabel, drop self loops, sort, merge duplicates
+//   with summed edge_attr), consecutive depth-1 clusters + member lists.
+// Deterministic: integer atomics are only used where the result is order-independent
+// (histograms, slot claiming followed by a rank sort on unique keys); every float sum has
+// a fixed order.
+#pragma once
+#include "drgnn_rt.h"
+#include "../../include/drgnn.h"
+
+#ifdef DRGNN_EMU
+#define LAMBDA_DEV
+#else
+#define LAMBDA_DEV __device__
+#endif
+
+// ---- workspace layout (host + device) ---------------------------------------------
+struct TopoLayout {
+    int64_t i32[DRGNN_TI_COUNT + 1];
+    int64_t f32[DRGNN_TF_COUNT + 1];
+};
+
+static inline void topo_layout(int64_t N, int64_t E, int64_t B, TopoLayout* L) {
+    int64_t o = 0;
+    auto take = [&](int which, int64_t n) { L->i32[which] = o; o += (n + 3) & ~(int64_t)3; };
+    take(DRGNN_TI_NPTR, B + 1);
+    take(DRGNN_TI_EPTR, B + 1);
+    take(DRGNN_TI_ROWPTR0, N + B);
+    take(DRGNN_TI_COL0, E);
+    take(DRGNN_TI_EID0, E);
+    take(DRGNN_TI_COLPTR0, N + B);
+    take(DRGNN_TI_ROWIDX0, E);
+    take(DRGNN_TI_TSLOT0, E);
+    take(DRGNN_TI_CL0, N);
+    take(DRGNN_TI_NC0, B);
+    take(DRGNN_TI_MPTR0, N + B);
+    take(DRGNN_TI_MEM0, N);
+    take(DRGNN_TI_ROWPTR1, N + B);
+    take(DRGNN_TI_COL1, E);
+    take(DRGNN_TI_NE1, B);
+    take(DRGNN_TI_COLPTR1, N + B);
+    take(DRGNN_TI_ROWIDX1, E);
+    take(DRGNN_TI_TSLOT1, E);
+    take(DRGNN_TI_CL1, N);
+    take(DRGNN_TI_NC1, B);
+    take(DRGNN_TI_MPTR1, N + B);
+    take(DRGNN_TI_MEM1, N);
+    take(DRGNN_TI_CPTR0, B + 1);
+    take(DRGNN_TI_E1PTR, B + 1);
+    take(DRGNN_TI_CPTR1, B + 1);
+    take(DRGNN_TI_ERR, 4);
+    L->i32[DRGNN_TI_COUNT] = o;
+    int64_t f = 0;
+    L->f32[DRGNN_TF_W0] = f; f += (E + 3) & ~(int64_t)3;
+    L->f32[DRGNN_TF_W1] = f; f += (E + 3) & ~(int64_t)3;
+    L->f32[DRGNN_TF_COUNT] = f;
+}
+
+// Device-side view of the workspace.
+struct TopoView {
+    int32_t* p[DRGNN_TI_COUNT];
+    float* w0;
+    float* w1;
+};
+
+static inline TopoView topo_view(int32_t* ws_i32, float* ws_f32, const TopoLayout& L) {
+    TopoView v;
+    for (int k = 0; k < DRGNN_TI_COUNT; ++k) v.p[k] = ws_i32 + L.i32[k];
+    v.w0 = ws_f32 ? ws_f32 + L.f32[DRGNN_TF_W0] : nullptr;
+    v.w1 = ws_f32 ? ws_f32 + L.f32[DRGNN_TF_W1] : nullptr;
+    return v;
+}
+
+// ---- scratch carving for one graph -------------------------------------------------
+// capT >= max(capN, capE) + 1 ; capF >= capN + capE + 2 (cluster-id flag range)
+struct TopoScratch {
+    long long* mm;   // [2] min / max of the cluster ids
+    int* part;       // [NTHREADS + 1]
+    int* rp;         // [capN+1] rowptr0
+    int* cp;         // [capN+1] colptr (level 0 then level 1)
+    int* cur;        // [capN+1]
+    int* cl;         // [capN]
+    int* mp;         // [capN+1]
+    int* mem;        // [capN]
+    int* pp;         // [capN+1]
+    int* nb;         // [capN]
+    int* rp1;        // [capN+1]
+    int* col;        // [capE]
+    int* seg;        // [capE]
+    int* col1;       // [capE]
+    int* t1;         // [capT] x5
+    int* t2;
+    int* t3;
+    int* t4;
+    int* t5;
+    int* fl;         // [capF]
+    int capF;
+};
+
+#define TOPO_PAD4(n) (((n) + 3) & ~3LL)
+// number of ints: linear in (capN, capE, capT, capF) -- keep in sync with topo_carve
+static inline int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT, int64_t capF) {
+    return 4 + TOPO_PAD4(DRGNN_NTHREADS + 1) + 6 * TOPO_PAD4(capN + 1) + 3 * TOPO_PAD4(capN) +
+           3 * TOPO_PAD4(capE) + 5 * TOPO_PAD4(capT) + TOPO_PAD4(capF);
+}
+
+// Global-memory placement of graph g's scratch when it does not live in LDS.  With
+// capT = N+E+1 and capF = N+E+2 the carve needs at most 15*N + 9*E + TOPO_GSCRATCH_CONST ints
+// (the constant absorbs the fixed arrays and every PAD4 rounding), so regions placed at
+// 15*n0 + 9*e0 + CONST*g (rounded up to even for the 64-bit min/max slot) never overlap.
+#define TOPO_GSCRATCH_CONST 400
+HD int64_t topo_gscratch_base(int64_t n0, int64_t e0, int64_t g) {
+    return ((15 * n0 + 9 * e0 + (int64_t)TOPO_GSCRATCH_CONST * g) + 1) & ~(int64_t)1;
+}
+
+template <class IntPtr>
+DEV TopoScratch topo_carve(IntPtr base, int capN, int capE, int capT, int capF) {
+    TopoScratch s;
+    int o = 0;
+    s.mm = (long long*)(base + o); o += 4;
+    s.part = base + o; o += (int)TOPO_PAD4(DRGNN_NTHREADS + 1);
+    s.rp = base + o;   o += (int)TOPO_PAD4(capN + 1);
+    s.cp = base + o;   o += (int)TOPO_PAD4(capN + 1);
+    s.cur = base + o;  o += (int)TOPO_PAD4(capN + 1);
+    s.mp = base + o;   o += (int)TOPO_PAD4(capN + 1);
+    s.pp = base + o;   o += (int)TOPO_PAD4(capN + 1);
+    s.rp1 = base + o;  o += (int)TOPO_PAD4(capN + 1);
+    s.cl = base + o;   o += (int)TOPO_PAD4(capN);
+    s.mem = base + o;  o += (int)TOPO_PAD4(capN);
+    s.nb = base + o;   o += (int)TOPO_PAD4(capN);
+    s.col = base + o;  o += (int)TOPO_PAD4(capE);
+    s.seg = base + o;  o += (int)TOPO_PAD4(capE);
+    s.col1 = base + o; o += (int)TOPO_PAD4(capE);
+    s.t1 = base + o;   o += (int)TOPO_PAD4(capT);
+    s.t2 = base + o;   o += (int)TOPO_PAD4(capT);
+    s.t3 = base + o;   o += (int)TOPO_PAD4(capT);
+    s.t4 = base + o;   o += (int)TOPO_PAD4(capT);
+    s.t5 = base + o;   o += (int)TOPO_PAD4(capT);
+    s.fl = base + o;   o += (int)TOPO_PAD4(capF);
+    s.capF = capF;
+    return s;
+}
+
+DEV void topo_flag(const TopoView& tv, int bit, int graph) {
+    ATOMIC_OR(&tv.p[DRGNN_TI_ERR][0], bit);
+    tv.p[DRGNN_TI_ERR][1] = graph;
+}
+
+// ---------------------------------------------------------------------------------
+// Stable bucket sort of items 0..n-1 by bucket_of(item) in [0, nb):
+//   ptr[0..nb]   bucket offsets            order[p]  item at sorted position p
+//   slot_bucket[p] bucket of sorted position p
+// Items inside a bucket keep ascending item order (rank sort on the unique item id).
+// tmp: n ints.  cur: nb+1 ints.
+// ---------------------------------------------------------------------------------
+template <class F>
+DEV void wg_bucket_sort(int n, int nb, F bucket_of, int* ptr, int* cur, int* tmp,
+                        int* slot_bucket, int* order, int* part) {
+    FOR_TID(b, nb + 1) { ptr[b] = 0; cur[b] = 0; }
+    BARRIER();
+    FOR_TID(i, n) { ATOMIC_ADD(&ptr[bucket_of(i)], 1); }
+    BARRIER();
+    wg_exscan(ptr, nb + 1, part);
+    FOR_TID(i, n) {
+        const int b = bucket_of(i);
+        const int pos = ptr[b] + ATOMIC_ADD(&cur[b], 1);
+        tmp[pos] = i;
+        slot_bucket[pos] = b;
+    }
+    BARRIER();
+    FOR_TID(p, n) {
+        const int b = slot_bucket[p];
+        const int me = tmp[p];
+        const int lo = ptr[b], hi = ptr[b + 1];
+        int rank = 0;
+        for (int q = lo; q < hi; ++q) rank += (tmp[q] < me) ? 1 : 0;
+        order[lo + rank] = me;
+    }
+    BARRIER();
+}
+
+// ---------------------------------------------------------------------------------
+// consecutive_cluster [3P] for one graph: ids (any int64) -> rank among the distinct ids
+// present (order preserving), plus member lists with ascending member index.
+// Outputs in scratch: s.cl[0..n), s.mp[0..C], s.mem[0..n); returns C.
+// ---------------------------------------------------------------------------------
+DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n, TopoScratch& s) {
+    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+    BARRIER();
+    FOR_TID(i, n) {
+        const long long id = (long long)ids[i];
+        ATOMIC_MIN64(&s.mm[0], id);
+        ATOMIC_MAX64(&s.mm[1], id);
+    }
+    BARRIER();
+    const long long mn = s.mm[0];
+    long long span = (n > 0) ? (s.mm[1] - mn + 1) : 0;
+    if (span > (long long)(s.capF - 1) || span < 0) {
+        FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER_RANGE, graph); }
+        span = s.capF - 1;
+    }
+    const int range = (int)span;
+    FOR_TID(v, range + 1) { s.fl[v] = 0; }
+    BARRIER();
+    FOR_TID(i, n) {
+        long long d = (long long)ids[i] - mn;
+        if (d >= range) d = range - 1;
+        s.fl[(int)d] = 1;
+    }
+    BARRIER();
+    const int C = wg_exscan(s.fl, range + 1, s.part);
+    FOR_TID(i, n) {
+        long long d = (long long)ids[i] - mn;
+        if (d >= range) d = range - 1;
+        s.cl[i] = s.fl[(int)d];
+    }
+    BARRIER();
+    const int* cl = s.cl;
+    wg_bucket_sort(n, C, [cl] LAMBDA_DEV(int i) { return cl[i]; }, s.mp, s.cur, s.t1, s.t2, s.mem,
+                   s.part);
+    return C;
+}
+
+// CSC of a CSR matrix with n rows/cols and m stored entries (slot_row[k] = row of slot k).
+DEV void wg_csc_build(int n, int m, const int* col, const int* slot_row, TopoScratch& s,
+                      int32_t* g_colptr, int32_t* g_rowidx, int32_t* g_tslot) {
+    wg_bucket_sort(m, n, [col] LAMBDA_DEV(int k) { return col[k]; }, s.cp, s.cur, s.t1, s.t2, s.t3,
+                   s.part);
+    FOR_TID(j, m) {
+        const int k = s.t3[j];
+        g_tslot[j] = k;
+        g_rowidx[j] = slot_row[k];
+    }
+    FOR_TID(i, n + 1) { g_colptr[i] = s.cp[i]; }
+    BARRIER();
+}
+
+// ---------------------------------------------------------------------------------
+// The per-graph builder.
+// ---------------------------------------------------------------------------------
+struct TopoArgs {
+    const int64_t* edge_index;   // [2, Etot]
+    const float* edge_attr;      // [Etot] or null
+    const int64_t* cluster0;     // [Ntot]
+    const int64_t* cluster1;     // [L1] or null
+    const int32_t* c1_ptr;       // [B+1] or null (then level 1 is built by topo_graph_level1)
+    int64_t n_edges;
+    int64_t len_cluster1;
+    int n_graphs;
+};
+
+DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int c1_begin, int c1_len,
+                           TopoScratch& s) {
+    const int n0 = tv.p[DRGNN_TI_NPTR][g];
+    const int rowbase = n0 + g;
+    const int C0 = tv.p[DRGNN_TI_NC0][g];
+    if (c1_len != C0) {
+        FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, g); }
+    }
+    const int n = imin(C0, imax(c1_len, 0));
+    const int C1 = wg_cluster_rank(tv, g, a.cluster1 + c1_begin, n, s);
+    int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
+    int32_t* g_mptr1 = tv.p[DRGNN_TI_MPTR1] + rowbase;
+    int32_t* g_mem1 = tv.p[DRGNN_TI_MEM1] + n0;
+    FOR_TID(i, n) { g_cl1[i] = s.cl[i]; g_mem1[i] = s.mem[i]; }
+    FOR_TID(c, C1 + 1) { g_mptr1[c] = s.mp[c]; }
+    FOR_TID(i, 1) { tv.p[DRGNN_TI_NC1][g] = C1; }
+    BARRIER();
+}
+
+DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, TopoScratch& s) {
+    const int n0 = tv.p[DRGNN_TI_NPTR][g], n1 = tv.p[DRGNN_TI_NPTR][g + 1];
+    const int e0 = tv.p[DRGNN_TI_EPTR][g], e1 = tv.p[DRGNN_TI_EPTR][g + 1];
+    const int N = n1 - n0;
+    int E = e1 - e0;
+    const int rowbase = n0 + g;
+    if (N <= 0 && E > 0) {
+        FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_EDGE_RANGE, g); }
+        E = 0;
+    }
+    const int64_t* src_row = a.edge_index + e0;
+    const int64_t* src_col = a.edge_index + a.n_edges + e0;
+    const int Nm1 = N - 1;
+
+    // ---- CSR0: rows ordered by edge id ----------------------------------------------
+    {
+        const TopoView tvc = tv;
+        auto row_of = [src_row, n0, Nm1, tvc, g] LAMBDA_DEV(int e) {
+            long long r = (long long)src_row[e] - n0;
+            if (r < 0 || r > Nm1) { topo_flag(tvc, DRGNN_S_EDGE_RANGE, g); r = 0; }
+            return (int)r;
+        };
+        wg_bucket_sort(E, N, row_of, s.rp, s.cur, s.t1, s.seg, s.t2, s.part);
+    }
+    int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
+    int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
+    int32_t* g_eid0 = tv.p[DRGNN_TI_EID0] + e0;
+    float* g_w0 = tv.w0 ? tv.w0 + e0 : nullptr;
+    float* g_w1 = tv.w1 ? tv.w1 + e0 : nullptr;
+    const bool has_w = (a.edge_attr != nullptr) && (g_w0 != nullptr);
+    FOR_TID(k, E) {
+        const int e = s.t2[k];
+        long long c = (long long)src_col[e] - n0;
+        if (c < 0 || c > Nm1) { topo_flag(tv, DRGNN_S_EDGE_RANGE, g); c = 0; }
+        s.col[k] = (int)c;
+        g_col0[k] = (int)c;
+        g_eid0[k] = e;
+        if (has_w) g_w0[k] = a.edge_attr[e0 + e];
+    }
+    FOR_TID(i, N + 1) { g_rowptr0[i] = s.rp[i]; }
+    BARRIER();
+
+    // ---- CSC0 ----------------------------------------------------------------------
+    wg_csc_build(N, E, s.col, s.seg, s, tv.p[DRGNN_TI_COLPTR0] + rowbase,
+                 tv.p[DRGNN_TI_ROWIDX0] + e0, tv.p[DRGNN_TI_TSLOT0] + e0);
+
+    // ---- depth-0 clusters ------------------------------------------------------------
+    const int C = wg_cluster_rank(tv, g, a.cluster0 + n0, N, s);
+    {
+        int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
+        int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
+        int32_t* g_mem0 = tv.p[DRGNN_TI_MEM0] + n0;
+        FOR_TID(i, N) { g_cl0[i] = s.cl[i]; g_mem0[i] = s.mem[i]; }
+        FOR_TID(c, C + 1) { g_mptr0[c] = s.mp[c]; }
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
+    }
+
+    // ---- pool_edge: candidates of pooled row r = CSR0 rows of its members, in order ----
+    FOR_TID(r, C + 1) {
+        int acc = 0;
+        if (r < C) {
+            for (int p = s.mp[r]; p < s.mp[r + 1]; ++p) {
+                const int m = s.mem[p];
+                s.nb[m] = acc;
+                acc += s.rp[m + 1] - s.rp[m];
+            }
+        }
+        s.pp[r] = acc;
+    }
+    BARRIER();
+    wg_exscan(s.pp, C + 1, s.part);
+    FOR_TID(m, N) {
+        const int r = s.cl[m];
+        const int base = s.pp[r] + s.nb[m];
+        const int lo = s.rp[m], hi = s.rp[m + 1];
+        for (int k = lo; k < hi; ++k) {
+            const int cc = s.cl[s.col[k]];
+            const int j = base + (k - lo);
+            s.t1[j] = (cc == r) ? INT_MAX : cc;   // self loop of the pooled graph: dropped
+            s.t2[j] = k;
+            s.t3[j] = r;
+        }
+    }
+    BARRIER();
+    // rank sort of every pooled row's candidates by (target cluster, position)
+    FOR_TID(j, E) {
+        const int r = s.t3[j];
+        const int key = s.t1[j];
+        const int lo = s.pp[r], hi = s.pp[r + 1];
+        int rank = 0;
+        for (int q = lo; q < hi; ++q) {
+            const int kq = s.t1[q];
+            rank += (kq < key || (kq == key && q < j)) ? 1 : 0;
+        }
+        s.t4[lo + rank] = key;
+        s.t5[lo + rank] = s.t2[j];
+    }
+    BARRIER();
+    // heads of runs of equal target = the coalesced pooled edges, already (row, col) sorted
+    FOR_TID(j, E + 1) {
+        int head = 0;
+        if (j < E) {
+            const int key = s.t4[j];
+            head = (key != INT_MAX && (j == s.pp[s.t3[j]] || s.t4[j - 1] != key)) ? 1 : 0;
+        }
+        s.t1[j] = head;
+    }
+    BARRIER();
+    const int E1 = wg_exscan(s.t1, E + 1, s.part);
+    int32_t* g_rowptr1 = tv.p[DRGNN_TI_ROWPTR1] + rowbase;
+    int32_t* g_col1 = tv.p[DRGNN_TI_COL1] + e0;
+    FOR_TID(j, E) {
+        const int key = s.t4[j];
+        const int r = s.t3[j];
+        if (key != INT_MAX && (j == s.pp[r] || s.t4[j - 1] != key)) {
+            const int slot = s.t1[j];
+            s.col1[slot] = key;
+            s.seg[slot] = r;               // row of pooled CSR slot (s.seg is free again)
+            g_col1[slot] = key;
+            if (has_w) {
+                const int hi = s.pp[r + 1];
+                float w = 0.0f;
+                for (int q = j; q < hi && s.t4[q] == key; ++q) w += g_w0[s.t5[q]];
+                g_w1[slot] = w;
+            }
+        }
+    }
+    FOR_TID(r, C + 1) {
+        const int v = s.t1[s.pp[r]];
+        s.rp1[r] = v;
+        g_rowptr1[r] = v;
+    }
+    FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
+    BARRIER();
+
+    // ---- CSC1 ----------------------------------------------------------------------
+    wg_csc_build(C, E1, s.col1, s.seg, s, tv.p[DRGNN_TI_COLPTR1] + rowbase,
+                 tv.p[DRGNN_TI_ROWIDX1] + e0, tv.p[DRGNN_TI_TSLOT1] + e0);
+
+    // ---- depth-1 clusters (when the caller knows where this graph's ids start) --------
+    if (a.cluster1 != nullptr && a.c1_ptr != nullptr) {
+        const int b = a.c1_ptr[g];
+        topo_graph_level1(tv, a, g, b, a.c1_ptr[g + 1] - b, s);
+    }
+}

@@ -161,7 +161,31 @@ class Batch(Data):
                 out[k] = pieces[k]
         out["batch"] = torch.cat(owner, dim=0)
         out.__dict__["_num_graphs"] = len(graphs)
+        out._record_layout(graphs)
         return out
+
+    def _record_layout(self, graphs):
+        """Per-graph offsets and size bounds, known for free at collate time; they let the
+        device path skip deriving them (and size its LDS) without any host sync.  Stored
+        under underscore names: moved by ``.to()``, invisible to ``keys()``."""
+        nodes = [g.num_nodes for g in graphs]
+        edges = [g.num_edges for g in graphs]
+
+        def ptr(counts):
+            t = torch.zeros(len(counts) + 1, dtype=torch.int32)
+            if counts:
+                t[1:] = torch.tensor(counts, dtype=torch.int64).cumsum(0).to(torch.int32)
+            return t
+        d = self.__dict__
+        d["_node_ptr"] = ptr(nodes)
+        d["_edge_ptr"] = ptr(edges)
+        d["_max_nodes"] = max(nodes) if nodes else 0
+        d["_max_edges"] = max(edges) if edges else 0
+        c1 = [g["cluster1"] for g in graphs]
+        if all(torch.is_tensor(c) for c in c1):
+            lens = [int(c.numel()) for c in c1]
+            d["_c1_ptr"] = ptr(lens)
+            d["_max_c0"] = max(lens) if lens else 0
 
 
 class DataLoader(torch.utils.data.DataLoader):

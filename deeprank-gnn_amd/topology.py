@@ -1,0 +1,126 @@
+"""Per-mini-batch topology workspace (CSR/CSC, consecutive clusters, pooled graph).
+
+Host-side owner of the buffers that ``drgnn_topology_build`` fills (include/drgnn.h).
+It stands in for what the reference recomputes inside every forward pass:
+``get_preloaded_cluster`` (community_pooling.py:25-30), ``consecutive_cluster`` and
+``pool_edge`` [torch_geometric] inside ``community_pooling`` (community_pooling.py:197-201),
+and the COO edge scans of the conv layers.  Nothing here depends on learned parameters,
+so one ``Topology`` serves both GINet branches, forward and backward.
+"""
+import torch
+
+from . import _lib
+
+__all__ = ["Topology"]
+
+
+def _contig(t, dtype):
+    if t is None:
+        return None
+    if t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+class Topology(object):
+    def __init__(self, api, n_nodes, n_edges, n_graphs, device, has_weights):
+        self.api = api
+        self.n_nodes, self.n_edges, self.n_graphs = int(n_nodes), int(n_edges), int(n_graphs)
+        self.off_i32, self.off_f32 = api.topology_layout(self.n_nodes, self.n_edges, self.n_graphs)
+        self.ws_i32 = torch.empty(max(self.off_i32[-1], 4), dtype=torch.int32, device=device)
+        self.ws_f32 = (torch.empty(max(self.off_f32[-1], 4), dtype=torch.float32, device=device)
+                       if has_weights else None)
+        self.max_nodes = 0
+        self.max_edges = 0
+        self.max_c0 = 0
+        self.has_level1 = False
+        self._finalized = False
+
+    # ---------------------------------------------------------------------------
+    @classmethod
+    def from_batch(cls, data, api=None, with_level1=True, check=False):
+        """Build from a ``Batch``-like object (attribute access only)."""
+        api = api or _lib.get()
+        edge_index = _contig(data.edge_index, torch.int64)
+        batch = _contig(data.batch, torch.int64)
+        if api is _lib._API:
+            _lib.require_device(edge_index, batch)
+        device = batch.device
+        n_nodes = batch.numel()
+        n_edges = edge_index.size(1) if edge_index.dim() == 2 else 0
+        edge_attr = getattr(data, "edge_attr", None)
+        if edge_attr is not None:
+            if edge_attr.dim() == 2 and edge_attr.size(1) != 1:
+                raise ValueError("only one edge feature is supported (the reference's layers "
+                                 "broadcast edge_attr [E,1] over the channels, sGAT.py:76)")
+            edge_attr = _contig(edge_attr.reshape(-1), torch.float32)
+        cluster0 = _contig(getattr(data, "cluster0", None), torch.int64)
+        if cluster0 is None:
+            raise ValueError("the batch has no cluster0 (pre-computed communities, DataSet.py:342-357)")
+        cluster1 = _contig(getattr(data, "cluster1", None), torch.int64) if with_level1 else None
+        d = getattr(data, "__dict__", {})
+        n_graphs = d.get("_num_graphs")
+        if n_graphs is None:
+            n_graphs = getattr(data, "num_graphs", None)
+        if n_graphs is None:
+            n_graphs = int(batch.max()) + 1 if n_nodes else 0
+        node_ptr = _contig(d.get("_node_ptr"), torch.int32)
+        edge_ptr = _contig(d.get("_edge_ptr"), torch.int32)
+        c1_ptr = _contig(d.get("_c1_ptr"), torch.int32) if cluster1 is not None else None
+        for t in (node_ptr, edge_ptr, c1_ptr):
+            if t is not None and t.device != device:
+                node_ptr = edge_ptr = c1_ptr = None      # stale host copies: let the device derive them
+                break
+        topo = cls(api, n_nodes, n_edges, n_graphs, device, edge_attr is not None)
+        max_nodes = int(d.get("_max_nodes", 0))
+        max_edges = int(d.get("_max_edges", 0))
+        if max_nodes == 0 and n_nodes:
+            counts = torch.bincount(batch, minlength=n_graphs)
+            max_nodes = int(counts.max())
+            if n_edges:
+                max_edges = int(torch.bincount(batch[edge_index[0]], minlength=n_graphs).max())
+        topo.max_nodes, topo.max_edges = max_nodes, max_edges
+        topo.max_c0 = int(d.get("_max_c0", 0))
+        scratch = None
+        lds_limit = 160 * 1024
+        need = api.topology_lds_bytes(max_nodes, max_edges)
+        if max_nodes == 0 or need > lds_limit:
+            scratch = torch.empty(api.topology_scratch_elems(n_nodes, n_edges, n_graphs),
+                                  dtype=torch.int32, device=device)
+        topo.has_level1 = cluster1 is not None
+        api.topology_build(edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,
+                           n_nodes, n_edges, 0 if cluster1 is None else cluster1.numel(), n_graphs,
+                           max_nodes, max_edges, topo.ws_i32, topo.ws_f32, scratch,
+                           _lib.current_stream(batch))
+        topo._keepalive = (edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch)
+        if check:
+            topo.check()
+        return topo
+
+    # ---------------------------------------------------------------------------
+    def array(self, name):
+        """View of one int32 array of the workspace (enum drgnn_topo_i32)."""
+        k = _lib.TI[name]
+        return self.ws_i32[self.off_i32[k]:self.off_i32[k + 1]]
+
+    def weights(self, name):
+        k = _lib.TF[name]
+        return self.ws_f32[self.off_f32[k]:self.off_f32[k + 1]]
+
+    def status(self):
+        return self.api.topology_status(self.ws_i32, self.n_nodes, self.n_edges, self.n_graphs,
+                                        _lib.current_stream(self.ws_i32))
+
+    def check(self):
+        """Synchronising validity check of the index tensors the workspace was built from."""
+        st = self.status()
+        if st[0]:
+            msgs = [m for bit, m in _lib.STATUS_BITS.items() if st[0] & bit]
+            raise _lib.DrgnnError("malformed batch (graph %d): %s" % (st[1], "; ".join(msgs)))
+
+    def finalize(self):
+        if not self._finalized:
+            self.api.topology_finalize(self.ws_i32, self.n_nodes, self.n_edges, self.n_graphs,
+                                       _lib.current_stream(self.ws_i32))
+            self._finalized = True
+        return self

@@ -1,0 +1,214 @@
+/*
+ * drgnn.h -- C ABI of the MI355X-native Deeprank-GNN message-passing hot path.
+ *
+ * One shared object (deeprank-gnn_amd/csrc/libdrgnn.so, built by hipcc for gfx950).
+ * Every entry point takes raw DEVICE pointers, explicit sizes and a hipStream_t (passed
+ * as void*), never allocates, never synchronises, and is hipGraph-capturable.  Return
+ * value: 0 on success, a positive hipError_t from the launch, or a negative DRGNN_E_*
+ * for argument errors detected on the host.  Data-dependent errors detected on the
+ * device (malformed edge lists, cluster ids out of range ...) are recorded in the
+ * topology workspace (DRGNN_TI_ERR) and poison the outputs with NaN; read them back with
+ * drgnn_topology_status().
+ *
+ * The reference has no C/FFI boundary (it is pure Python on torch_geometric /
+ * torch_scatter / torch_sparse, which are un-vendored).  Each entry point cites the
+ * reference function (file:line under the reference repository) whose arithmetic it
+ * replaces; the Python class protocol above this ABI (GINet / sGAT / FoutNet,
+ * community_pooling ...) lives in deeprank-gnn_amd/ and mirrors the reference names.
+ *
+ * Index tensors arrive as the reference stores them (int64 edge_index [2,E], cluster
+ * ids, batch vector: DataSet.py:268-269,354-357); everything derived is int32.
+ */
+#ifndef DRGNN_H
+#define DRGNN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRGNN_ABI_VERSION 1
+
+/* host-side argument errors */
+#define DRGNN_E_ARG      (-1)   /* null pointer / negative size / bad mode            */
+#define DRGNN_E_CAPACITY (-2)   /* workspace too small for the request                */
+#define DRGNN_E_WIDTH    (-3)   /* feature width not supported by the fused kernels   */
+
+/* device-side status bits (DRGNN_TI_ERR[0]) */
+#define DRGNN_S_EDGE_RANGE    1  /* an edge endpoint lies outside its graph's node range */
+#define DRGNN_S_UNSORTED      2  /* batch vector / edge list not grouped by graph        */
+#define DRGNN_S_CLUSTER_RANGE 4  /* a graph's cluster ids span more than N_g+E_g+1 values*/
+#define DRGNN_S_CLUSTER1_LEN  8  /* len(cluster1) != number of depth-0 clusters          */
+
+/* layer kinds (what "conv" means) */
+#define DRGNN_GINET 0  /* z_i = sum_{e:row=i} W x_col            ginet.py:50-73 (alpha == 1)   */
+#define DRGNN_SGAT  1  /* z_i = mean_e a_e [x_i||x_col] W + b     sGAT.py:62-93                 */
+#define DRGNN_FOUT  2  /* z_i = x_i Wc + mean_e (x Wn)_col + b    foutnet.py:56-82 (NaN if deg 0)*/
+
+/* ---- topology workspace ----------------------------------------------------------
+ * Built once per mini-batch from the index tensors only (no learned quantity), shared
+ * by both GINet branches and by forward and backward.  Layout: "padded per-graph
+ * segments" -- graph g owns node slots [nptr[g], nptr[g+1]) and edge slots
+ * [eptr[g], eptr[g+1]) of every array, pooled levels use a prefix of the same slots
+ * (C0_g <= N_g, E1_g <= E_g), pointer-like arrays of length n+1 start at nptr[g]+g.
+ * All node/cluster ids stored inside are LOCAL to their graph.
+ */
+enum drgnn_topo_i32 {
+    DRGNN_TI_NPTR = 0,   /* [B+1]  node offsets per graph                                   */
+    DRGNN_TI_EPTR,       /* [B+1]  edge offsets per graph                                   */
+    DRGNN_TI_ROWPTR0,    /* [N+B]  CSR by row (edge_index[0]) of the input graph            */
+    DRGNN_TI_COL0,       /* [E]    neighbour (edge_index[1]), rows ordered by edge id       */
+    DRGNN_TI_EID0,       /* [E]    original edge id (local) of every CSR slot               */
+    DRGNN_TI_COLPTR0,    /* [N+B]  CSC (transpose) of the input graph                        */
+    DRGNN_TI_ROWIDX0,    /* [E]                                                              */
+    DRGNN_TI_TSLOT0,     /* [E]    CSR slot of every CSC entry (to look up its weight)      */
+    DRGNN_TI_CL0,        /* [N]    consecutive depth-0 cluster id of every node             */
+    DRGNN_TI_NC0,        /* [B]    number of depth-0 clusters                                */
+    DRGNN_TI_MPTR0,      /* [N+B]  member lists of depth-0 clusters                          */
+    DRGNN_TI_MEM0,       /* [N]    members, ascending node id inside a cluster               */
+    DRGNN_TI_ROWPTR1,    /* [N+B]  CSR of the pooled graph (pool_edge output, sorted)        */
+    DRGNN_TI_COL1,       /* [E]                                                              */
+    DRGNN_TI_NE1,        /* [B]    number of pooled edges                                    */
+    DRGNN_TI_COLPTR1,    /* [N+B]  CSC of the pooled graph                                   */
+    DRGNN_TI_ROWIDX1,    /* [E]                                                              */
+    DRGNN_TI_TSLOT1,     /* [E]                                                              */
+    DRGNN_TI_CL1,        /* [N]    consecutive depth-1 cluster id of every depth-0 cluster   */
+    DRGNN_TI_NC1,        /* [B]                                                              */
+    DRGNN_TI_MPTR1,      /* [N+B]                                                            */
+    DRGNN_TI_MEM1,       /* [N]                                                              */
+    DRGNN_TI_CPTR0,      /* [B+1]  exclusive scan of NC0  (filled by drgnn_topology_finalize)*/
+    DRGNN_TI_E1PTR,      /* [B+1]  exclusive scan of NE1                                     */
+    DRGNN_TI_CPTR1,      /* [B+1]  exclusive scan of NC1                                     */
+    DRGNN_TI_ERR,        /* [4]    [0] status bits, [1] first offending graph                */
+    DRGNN_TI_COUNT
+};
+enum drgnn_topo_f32 {
+    DRGNN_TF_W0 = 0,     /* [E] edge_attr in CSR0 slot order                                 */
+    DRGNN_TF_W1,         /* [E] pooled edge_attr (duplicates summed) in CSR1 slot order      */
+    DRGNN_TF_COUNT
+};
+
+/* Element offsets of every array inside the two workspaces, and their total sizes.
+ * off_i32 has DRGNN_TI_COUNT+1 entries (last = total int32 elements), off_f32 has
+ * DRGNN_TF_COUNT+1 entries. */
+int drgnn_topology_layout(int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                          int64_t* off_i32, int64_t* off_f32);
+
+/* Build the topology workspace.
+ * Replaces, for the whole mini-batch and without host synchronisation:
+ *   - the implicit COO use of edge_index in the conv layers (ginet.py:52, sGAT.py:64,
+ *     foutnet.py:58,71-73)                                      -> CSR0 / CSC0
+ *   - get_preloaded_cluster (community_pooling.py:25-30) + consecutive_cluster [3P]
+ *                                                               -> CL0/CL1, member lists
+ *   - pool_edge [3P] on the external edges (community_pooling.py:200-201): relabel, drop
+ *     self loops, sort by (row,col), merge duplicates with edge_attr summed
+ *                                                               -> CSR1 / CSC1 / W1
+ * edge_index  int64 [2,E] (global node ids, edges grouped by graph)
+ * edge_attr   float [E] or NULL (one edge feature, as the reference supports)
+ * batch       int64 [N] ascending graph id per node
+ * cluster0    int64 [N]  per-graph cluster ids (any integers; made consecutive here)
+ * cluster1    int64 [L1] per-graph ids of the depth-0 clusters; L1 must equal sum C0_g;
+ *             may be NULL (then only depth 0 is built: CL1.. untouched)
+ * node_ptr / edge_ptr / c1_ptr  int32 [B+1] or NULL: per-graph offsets if the caller
+ *             knows them (our DataLoader does); otherwise derived on the device.
+ * max_nodes / max_edges: upper bounds on any single graph's size (used to size LDS);
+ *             pass 0 if unknown (kernels then use their global-memory scratch path,
+ *             scratch_i32 must hold drgnn_topology_scratch_elems() ints).
+ */
+int64_t drgnn_topology_scratch_elems(int64_t n_nodes, int64_t n_edges, int64_t n_graphs);
+/* LDS bytes the builder needs for the given per-graph bounds; it runs out of LDS when this
+ * is <= 160 KiB and max_nodes > 0, else out of scratch_i32. */
+int64_t drgnn_topology_lds_bytes(int32_t max_nodes, int32_t max_edges);
+int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr,
+                         const int64_t* batch, const int64_t* cluster0, const int64_t* cluster1,
+                         const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* c1_ptr,
+                         int64_t n_nodes, int64_t n_edges, int64_t len_cluster1, int64_t n_graphs,
+                         int32_t max_nodes, int32_t max_edges,
+                         int32_t* ws_i32, float* ws_f32, int32_t* scratch_i32, void* stream);
+
+/* Exclusive scans CPTR0 / E1PTR / CPTR1 (only needed to materialise compact pooled
+ * tensors for the function-level API: community_pooling(), max_pool_x()). */
+int drgnn_topology_finalize(int32_t* ws_i32, int64_t n_nodes, int64_t n_edges,
+                            int64_t n_graphs, void* stream);
+
+/* Copy the 4 status words to the host (this one DOES synchronise the stream). */
+int drgnn_topology_status(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edges,
+                          int64_t n_graphs, int32_t* status4, void* stream);
+
+/* ---- fused network body ------------------------------------------------------------
+ * One convolution branch of GINet / sGAT / FoutNet:
+ *   conv1 -> relu -> community_pooling(max) -> conv2 -> relu -> max_pool_x -> graph mean
+ * (ginet.py:103-114,133; sGAT.py:119-133; foutnet.py:108-120), one workgroup per
+ * (graph, branch), intermediates in LDS.  The FC head (fc1/relu/dropout/fc2) stays
+ * outside.  H1 = 16, H2 = 32 as hard-coded in the reference (ginet.py:87-92).
+ *
+ * Weight operands are described as strided [K,H] matrices so that each model's own
+ * parameter layout is used in place: element (k,h) = ptr[k*sk + h*sh].
+ *   GINet   nbr = fc.weight [H,F]           (sk=1, sh=F)   self = NULL   bias = NULL
+ *   sGAT    nbr = weight[F:2F,:], self = weight[0:F,:]     (sk=H, sh=1)  bias [H]
+ *   FoutNet nbr = Wn, self = Wc  [F,H]                     (sk=H, sh=1)  bias [H]
+ */
+typedef struct drgnn_conv_params {
+    const float* w_nbr;  int64_t nbr_sk, nbr_sh;
+    const float* w_self; int64_t self_sk, self_sh;   /* NULL for GINet */
+    const float* bias;                                /* NULL for GINet */
+} drgnn_conv_params;
+
+typedef struct drgnn_conv_grads {       /* same striding as the parameters; NULL = skip */
+    float* w_nbr;
+    float* w_self;
+    float* bias;
+} drgnn_conv_grads;
+
+#define DRGNN_MAX_BRANCH 2
+
+typedef struct drgnn_net_desc {
+    int32_t kind;          /* DRGNN_GINET / DRGNN_SGAT / DRGNN_FOUT                    */
+    int32_t n_branch;      /* 2 for GINet (conv*, conv*_ext), else 1                   */
+    int32_t n_feat;        /* F: input node features                                    */
+    int32_t reserved;
+    drgnn_conv_params conv1[DRGNN_MAX_BRANCH];
+    drgnn_conv_params conv2[DRGNN_MAX_BRANCH];
+} drgnn_net_desc;
+
+/* Saved-for-backward tensors, all in the padded per-graph layout, per branch b:
+ *   xp   float [n_branch][N][16]   pooled node features (input of conv2)
+ *   arg0 int32 [n_branch][N][16]   local node id that won the depth-0 max, -1 = no grad
+ *   arg1 int32 [n_branch][N][32]   local depth-0 cluster that won the depth-1 max, -1 = no grad
+ * readout float [B][32*n_branch]   per-graph mean of the depth-1 pooled features
+ */
+/* max_nodes: upper bound on any graph's node count; max_c0: upper bound on any graph's
+ * number of depth-0 clusters (0 = unknown -> max_nodes).  Both size the LDS carve; when the
+ * carve exceeds 160 KiB (or max_nodes == 0) the kernels run out of `scratch_f32` (global,
+ * drgnn_net_scratch_elems() floats) instead. */
+int64_t drgnn_net_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_c0);
+
+int drgnn_net_forward(const drgnn_net_desc* net, const float* x,
+                      const int32_t* ws_i32, const float* ws_f32,
+                      int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                      int32_t max_nodes, int32_t max_c0,
+                      float* xp, int32_t* arg0, int32_t* arg1, float* readout,
+                      float* scratch_f32, void* stream);
+
+/* Backward of the above.  grad_readout float [B][32*n_branch].  Parameter gradients are
+ * first written per workgroup into `partials` (float [n_graphs*n_branch][P], P =
+ * drgnn_net_partial_elems()) and then reduced deterministically into the strided
+ * gradient tensors (overwritten, not accumulated).  grad_x may be NULL. */
+int64_t drgnn_net_partial_elems(int32_t kind, int32_t n_feat);
+int64_t drgnn_net_scratch_elems(int32_t kind, int32_t n_feat, int64_t n_nodes, int64_t n_edges,
+                                int64_t n_graphs);
+int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* grad_readout,
+                       const int32_t* ws_i32, const float* ws_f32,
+                       int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                       int32_t max_nodes, int32_t max_c0,
+                       const float* xp, const int32_t* arg0, const int32_t* arg1,
+                       drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, float* grad_x,
+                       float* partials, float* scratch_f32, void* stream);
+
+int drgnn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRGNN_H */

@@ -1,0 +1,106 @@
+"""Topology kernels (host-emulation build of the HIP source) vs the oracle.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import fixture_batch, fixture_graphs, syn4_batch
+from emu_api import emu
+from topo_check import check_against_oracle
+from deeprank_gnn_amd.data import Batch, Data
+from deeprank_gnn_amd.topology import Topology
+import deeprank_gnn_amd.synthetic as synth
+
+
+def strip_layout(batch):
+    """Forget the collate-time offsets -> exercises the device-side derivation."""
+    for k in ("_node_ptr", "_edge_ptr", "_c1_ptr", "_max_nodes", "_max_edges", "_max_c0"):
+        batch.__dict__.pop(k, None)
+    return batch
+
+
+def random_graph(rng, n, e, n_c0, n_c1, sym=True, self_loops=False, dup=False):
+    row = rng.integers(0, n, size=e)
+    col = rng.integers(0, n, size=e)
+    if not self_loops:
+        col = np.where(col == row, (col + 1) % max(n, 1), col)
+    if dup and e > 2:
+        row[1], col[1] = row[0], col[0]
+    if sym:
+        row, col = np.concatenate([row, col]), np.concatenate([col, row])
+    ei = torch.from_numpy(np.stack([row, col]).astype(np.int64))
+    ids0 = rng.permutation(np.arange(n) % max(n_c0, 1)) * 3 + 5          # gaps + offset: not consecutive
+    c0 = int(np.unique(ids0).size)
+    ids1 = rng.permutation(np.arange(c0) % max(n_c1, 1)) * 2
+    g = Data(x=torch.from_numpy(rng.standard_normal((n, 5)).astype(np.float32)), edge_index=ei,
+             edge_attr=torch.from_numpy(rng.uniform(0.1, 2.0, size=(ei.size(1), 1)).astype(np.float32)),
+             y=torch.tensor([1.0]), pos=torch.zeros(n, 3))
+    g.cluster0 = torch.from_numpy(ids0.astype(np.int64))
+    g.cluster1 = torch.from_numpy(ids1.astype(np.int64))
+    return g
+
+
+@pytest.mark.parametrize("make", [lambda: fixture_batch(8), lambda: fixture_batch(10), syn4_batch,
+                                  lambda: synth.make_batch(0, 3)])
+@pytest.mark.parametrize("derive", [False, True])
+def test_topology_matches_oracle(make, derive):
+    batch = make()
+    if derive:
+        strip_layout(batch)
+    topo = Topology.from_batch(batch, api=emu())
+    assert topo.status()[0] == 0
+    check_against_oracle(topo, batch)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_topology_random_ragged(seed):
+    rng = np.random.default_rng(seed)
+    graphs = []
+    for k in range(7):
+        n = int(rng.integers(1, 40))
+        e = int(rng.integers(0, 4 * n))
+        graphs.append(random_graph(rng, n, e, int(rng.integers(1, n + 1)), int(rng.integers(1, 5)),
+                                   sym=bool(k % 2), self_loops=(k == 3), dup=(k == 4)))
+    graphs.insert(2, random_graph(rng, 1, 0, 1, 1))              # single node, no edge
+    batch = Batch.from_data_list(graphs)
+    if seed % 2:
+        strip_layout(batch)
+    topo = Topology.from_batch(batch, api=emu())
+    assert topo.status()[0] == 0
+    check_against_oracle(topo, batch)
+
+
+def test_topology_global_scratch_path():
+    """max_nodes unknown / too large for LDS -> the same kernels run out of global scratch."""
+    batch = syn4_batch()
+    batch.__dict__["_max_nodes"] = 100000          # forces the LDS estimate over 160 KiB
+    batch.__dict__["_max_edges"] = 100000
+    topo = Topology.from_batch(batch, api=emu())
+    assert topo.status()[0] == 0
+    check_against_oracle(topo, batch)
+
+
+def test_topology_flags_bad_input():
+    batch = syn4_batch()
+    batch.edge_index[1, 3] = batch.x.size(0) - 1            # endpoint in another graph
+    topo = Topology.from_batch(batch, api=emu())
+    assert topo.status()[0] & 1
+    batch = syn4_batch()
+    batch.cluster1 = batch.cluster1[:-1]                    # wrong length
+    strip_layout(batch)
+    topo = Topology.from_batch(batch, api=emu())
+    assert topo.status()[0] & 8
+    batch = syn4_batch()
+    batch.cluster0[5] = 10 ** 12                            # absurd id range
+    topo = Topology.from_batch(batch, api=emu())
+    assert topo.status()[0] & 4
+
+
+def test_finalize_scans():
+    batch = fixture_batch(8)
+    topo = Topology.from_batch(batch, api=emu()).finalize()
+    nc0 = topo.array("NC0").numpy()[:8]
+    np.testing.assert_array_equal(topo.array("CPTR0").numpy()[:9], np.concatenate([[0], np.cumsum(nc0)]))
+    ne1 = topo.array("NE1").numpy()[:8]
+    np.testing.assert_array_equal(topo.array("E1PTR").numpy()[:9], np.concatenate([[0], np.cumsum(ne1)]))
+    assert topo.array("CPTR0").numpy()[8] == 244 and topo.array("E1PTR").numpy()[8] == 994
+    assert topo.array("CPTR1").numpy()[8] == 83

@@ -1,0 +1,113 @@
+"""Expands a Topology workspace into plain global tensors and compares with the oracle."""
+import numpy as np
+import torch
+
+from oracle import cpu_ref
+
+
+def expand(topo):
+    a = {k: topo.array(k).cpu().numpy() for k in
+         ("NPTR", "EPTR", "ROWPTR0", "COL0", "EID0", "COLPTR0", "ROWIDX0", "TSLOT0", "CL0", "NC0",
+          "MPTR0", "MEM0", "ROWPTR1", "COL1", "NE1", "COLPTR1", "ROWIDX1", "TSLOT1", "CL1", "NC1",
+          "MPTR1", "MEM1")}
+    if topo.ws_f32 is not None:
+        a["W0"] = topo.weights("W0").cpu().numpy()
+        a["W1"] = topo.weights("W1").cpu().numpy()
+    return a
+
+
+def check_against_oracle(topo, batch, level1=True):
+    a = expand(topo)
+    B = topo.n_graphs
+    nptr, eptr = a["NPTR"], a["EPTR"]
+    ei = batch.edge_index.cpu()
+    bvec = batch.batch.cpu()
+    ea = None if getattr(batch, "edge_attr", None) is None else batch.edge_attr.cpu().reshape(-1)
+    # offsets
+    counts = torch.bincount(bvec, minlength=B).numpy() if bvec.numel() else np.zeros(B, int)
+    np.testing.assert_array_equal(nptr[:B + 1], np.concatenate([[0], np.cumsum(counts)]))
+    ecounts = torch.bincount(bvec[ei[0]], minlength=B).numpy() if ei.numel() else np.zeros(B, int)
+    np.testing.assert_array_equal(eptr[:B + 1], np.concatenate([[0], np.cumsum(ecounts)]))
+
+    # oracle global quantities
+    cl0 = cpu_ref.get_preloaded_cluster(batch.cluster0.cpu().clone(), bvec)
+    cons0, perm0 = cpu_ref.consecutive_cluster(cl0)
+    pei, pea = cpu_ref.pool_edge(cons0, ei, None if ea is None else ea.view(-1, 1))
+    pbatch = bvec[perm0]
+    c0counts = torch.bincount(pbatch, minlength=B).numpy() if pbatch.numel() else np.zeros(B, int)
+    np.testing.assert_array_equal(a["NC0"][:B], c0counts)
+    cptr0 = np.concatenate([[0], np.cumsum(c0counts)])
+
+    got_rows, got_cols, got_w = [], [], []
+    for g in range(B):
+        n0, n1, e0, e1 = nptr[g], nptr[g + 1], eptr[g], eptr[g + 1]
+        N, E = n1 - n0, e1 - e0
+        rb = n0 + g
+        # ---- CSR0: neighbours of node i in edge-id order
+        rp = a["ROWPTR0"][rb:rb + N + 1]
+        assert rp[0] == 0 and rp[-1] == E
+        rows = (ei[0, e0:e1] - n0).numpy()
+        cols = (ei[1, e0:e1] - n0).numpy()
+        eid = a["EID0"][e0:e1]
+        order = np.lexsort((np.arange(E), rows))          # stable by row, then edge id
+        np.testing.assert_array_equal(eid, order)
+        np.testing.assert_array_equal(a["COL0"][e0:e1], cols[order])
+        np.testing.assert_array_equal(np.repeat(np.arange(N), np.diff(rp)), rows[order])
+        if ea is not None:
+            np.testing.assert_array_equal(a["W0"][e0:e1], ea[e0:e1].numpy()[order])
+        # ---- CSC0: entries of column j ordered by CSR slot
+        cp = a["COLPTR0"][rb:rb + N + 1]
+        slot_row = np.repeat(np.arange(N), np.diff(rp))
+        slot_col = a["COL0"][e0:e1]
+        corder = np.lexsort((np.arange(E), slot_col))
+        np.testing.assert_array_equal(a["TSLOT0"][e0:e1], corder)
+        np.testing.assert_array_equal(a["ROWIDX0"][e0:e1], slot_row[corder])
+        np.testing.assert_array_equal(np.repeat(np.arange(N), np.diff(cp)), slot_col[corder])
+        # ---- depth-0 clusters
+        C = a["NC0"][g]
+        np.testing.assert_array_equal(a["CL0"][n0:n1] + cptr0[g], cons0[n0:n1].numpy())
+        mp = a["MPTR0"][rb:rb + C + 1]
+        mem = a["MEM0"][n0:n1]
+        assert mp[0] == 0 and mp[-1] == N
+        loc = a["CL0"][n0:n1]
+        np.testing.assert_array_equal(mem, np.lexsort((np.arange(N), loc)))
+        np.testing.assert_array_equal(np.repeat(np.arange(C), np.diff(mp)), loc[mem])
+        # ---- pooled graph
+        E1 = a["NE1"][g]
+        rp1 = a["ROWPTR1"][rb:rb + C + 1]
+        assert rp1[0] == 0 and rp1[-1] == E1
+        r1 = np.repeat(np.arange(C), np.diff(rp1))
+        c1 = a["COL1"][e0:e0 + E1]
+        got_rows.append(r1 + cptr0[g])
+        got_cols.append(c1 + cptr0[g])
+        if ea is not None:
+            got_w.append(a["W1"][e0:e0 + E1])
+        cp1 = a["COLPTR1"][rb:rb + C + 1]
+        corder = np.lexsort((np.arange(E1), c1))
+        np.testing.assert_array_equal(a["TSLOT1"][e0:e0 + E1], corder)
+        np.testing.assert_array_equal(a["ROWIDX1"][e0:e0 + E1], r1[corder])
+        np.testing.assert_array_equal(np.repeat(np.arange(C), np.diff(cp1)), c1[corder])
+    got_rows = np.concatenate(got_rows) if got_rows else np.zeros(0, int)
+    got_cols = np.concatenate(got_cols) if got_cols else np.zeros(0, int)
+    np.testing.assert_array_equal(np.stack([got_rows, got_cols]), pei.numpy().reshape(2, -1))
+    if ea is not None and pea is not None:
+        np.testing.assert_allclose(np.concatenate(got_w), pea.numpy().reshape(-1), rtol=1e-6, atol=1e-6)
+
+    if level1 and getattr(batch, "cluster1", None) is not None:
+        cl1 = cpu_ref.get_preloaded_cluster(batch.cluster1.cpu().clone(), pbatch)
+        cons1, perm1 = cpu_ref.consecutive_cluster(cl1)
+        b2 = pbatch[perm1]
+        c1counts = torch.bincount(b2, minlength=B).numpy() if b2.numel() else np.zeros(B, int)
+        np.testing.assert_array_equal(a["NC1"][:B], c1counts)
+        cptr1 = np.concatenate([[0], np.cumsum(c1counts)])
+        for g in range(B):
+            n0 = nptr[g]
+            C, C1 = a["NC0"][g], a["NC1"][g]
+            rb = n0 + g
+            loc = a["CL1"][n0:n0 + C]
+            np.testing.assert_array_equal(loc + cptr1[g], cons1[cptr0[g]:cptr0[g + 1]].numpy())
+            mp = a["MPTR1"][rb:rb + C1 + 1]
+            mem = a["MEM1"][n0:n0 + C]
+            assert mp[0] == 0 and mp[-1] == C
+            np.testing.assert_array_equal(mem, np.lexsort((np.arange(C), loc)))
+    return a
