@@ -1,0 +1,266 @@
+#!/usr/bin/env python
+"""bench.py -- graphs/s of one GINet training step (topology + forward + MSE + backward
++ gradient all-reduce + Adam) on synthetic residue-level interface graphs, batch 64 per GPU.
+
+Contract (driver):  python bench.py --gpus N --steps K --warmup W
+  N > 1 is launched by torch.distributed.run, one rank per GPU (RCCL); weak scaling: every
+  rank owns 64 graphs (ids 64r .. 64r+63).  Rank 0 prints ONE JSON line.
+
+What a "step" is: everything the reference does per mini-batch inside NeuralNet._epoch
+(NeuralNet.py:489-506) for data already on the device: zero_grad, model(batch) -- including
+the per-batch index work the reference redoes every forward (cluster offsets,
+consecutive_cluster, pool_edge; here: the topology kernel) -- MSE loss, backward, optimizer
+step.  The step is captured once in a hipGraph and replayed (``--mode eager`` runs the same
+Python step without capture).
+
+Extra objects in the JSON line:
+  roofline      HBM roofline of the dominant kernel: algorithmic bytes per launch
+                (SURVEY.md §8(d) per-graph figures x 64 graphs) / its average duration measured
+                here with HIP events over back-to-back launches on the launch stream.
+  cpu_baseline  the CPU oracle (oracle/cpu_ref.py: the reference's algorithm, op for op, in
+                PyTorch) timed on this box's host cores on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+import torch.nn.functional as F
+
+GRAPHS_PER_GPU = 64
+N_FEAT = 32
+# algorithmic HBM bytes per graph (derivation table): GINet
+BYTES_FWD, BYTES_BWD = 67668, 90208
+BYTES_TOPO = 4804 + 1800 + 5808 + 16 * 1000        # read edge_index (int64 [2,E]) + clusters, write CSR0 + pooled CSR
+HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--net", choices=["GINet", "sGAT", "FoutNet"], default="GINet")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd.parallel import FlatGradBucket
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.sGAT import sGAT
+    from deeprank_gnn_amd.foutnet import FoutNet
+    Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[args.net]
+
+    batch_cpu = synth.make_batch(rank * GRAPHS_PER_GPU, GRAPHS_PER_GPU)
+    batch = batch_cpu.clone().to(dev)
+    torch.manual_seed(0)
+    net = Net(N_FEAT, 1, 1).to(dev)            # dropout stays 0.4 for GINet (training mode)
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=(args.mode == "graph"))
+    bucket = FlatGradBucket(net.parameters())
+    loss_out = torch.zeros((), device=dev)
+
+    def fwd_bwd():
+        bucket.zero()
+        topo = Topology.from_batch(batch)
+        pred = net(batch, topo=topo)
+        loss = F.mse_loss(pred.reshape(-1), batch.y)
+        loss.backward()
+        loss_out.copy_(loss.detach())
+
+    def reduce_and_step():
+        opt.step()
+
+    if args.mode == "graph":
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fwd_bwd()
+                bucket.all_reduce()
+                reduce_and_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        g2 = torch.cuda.CUDAGraph()
+        if world == 1:
+            with torch.cuda.graph(g1):
+                fwd_bwd()
+                reduce_and_step()
+
+            def step():
+                g1.replay()
+        else:
+            with torch.cuda.graph(g1):
+                fwd_bwd()
+            with torch.cuda.graph(g2):
+                reduce_and_step()
+
+            def step():
+                g1.replay()
+                bucket.all_reduce()
+                g2.replay()
+    else:
+        def step():
+            fwd_bwd()
+            bucket.all_reduce()
+            reduce_and_step()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    final_loss = float(loss_out.item())
+
+    result = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = GRAPHS_PER_GPU * world * args.steps / elapsed
+        result = {
+            "metric": "interface-graphs/sec (fwd+bwd) %s batch=64 per GPU" % args.net,
+            "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s train step (topology+fwd+MSE+bwd+allreduce+Adam) on SYN graphs: "
+                                   "200 nodes, ~1000 directed edges, 32 node feats, 50->16 clusters "
+                                   "(BASELINE.json configs[1])" % args.net,
+                       "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,
+                       "parallelism": "dp%d" % world, "mode": args.mode, "final_loss": final_loss},
+        }
+        if args.net == "GINet":
+            result["roofline"] = measure_roofline(net, batch, dev, value)
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args.net, batch_cpu, args.cpu_seconds)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
+    """Average duration of each of our kernels (HIP events around `iters` back-to-back launches
+    on torch's current stream = the stream they are launched on), dominant one vs HBM peak."""
+    from deeprank_gnn_amd import _lib, functional
+    from deeprank_gnn_amd.topology import Topology
+    api = _lib.get()
+    topo = Topology.from_batch(batch)
+    convs = (net.conv1, net.conv2, net.conv1_ext, net.conv2_ext)
+    params = tuple(p.detach().contiguous() for c in convs for p in c.live_parameters())
+    x = batch.x.contiguous()
+    n_nodes, n_feat = x.shape
+    B = topo.n_graphs
+    nb = 2
+    xp = torch.empty((nb, n_nodes, 16), device=dev)
+    arg0 = torch.empty((nb, n_nodes, 16), dtype=torch.int32, device=dev)
+    arg1 = torch.empty((nb, n_nodes, 32), dtype=torch.int32, device=dev)
+    readout = torch.empty((B, 64), device=dev)
+    gr = torch.randn((B, 64), device=dev)
+    partials = torch.empty((B * nb, api.net_partial_elems(_lib.GINET, n_feat)), device=dev)
+    desc = functional._describe(_lib.GINET, n_feat, params, nb)
+    stream = _lib.current_stream(x)
+    d = batch.__dict__
+    ei, ea = batch.edge_index.contiguous(), batch.edge_attr.reshape(-1).contiguous()
+
+    def k_topo():
+        api.topology_build(ei, ea, batch.batch, batch.cluster0, batch.cluster1, d["_node_ptr"], d["_edge_ptr"],
+                           d["_c1_ptr"], n_nodes, ei.size(1), batch.cluster1.numel(), B, topo.max_nodes,
+                           topo.max_edges, topo.ws_i32, topo.ws_f32, None, stream)
+
+    def k_fwd():
+        api.net_forward(desc, x, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes,
+                        topo.max_c0, xp, arg0, arg1, readout, None, stream)
+
+    def k_bwd():
+        api.net_backward(desc, x, gr, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes,
+                         topo.max_c0, xp, arg0, arg1, None, partials, None, stream)
+
+    out = {}
+    for name, fn, nbytes in (("k_topo", k_topo, BYTES_TOPO), ("k_net<GINet,fwd>", k_fwd, BYTES_FWD - 5808 - 0),
+                             ("k_net<GINet,bwd>", k_bwd, BYTES_BWD)):
+        for _ in range(10):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / iters
+        out[name] = {"avg_us": us, "alg_bytes_per_launch": nbytes * B,
+                     "achieved_GBs": nbytes * B / (us * 1e-6) / 1e9}
+    dom = max(out, key=lambda k: out[k]["avg_us"])
+    ach = out[dom]["achieved_GBs"]
+    return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "whole_step_frac": graphs_per_s * (BYTES_FWD + BYTES_BWD) / 1e9 / HBM_PEAK_GBS,
+            "kernels": out}
+
+
+def cpu_baseline(net_name, batch_cpu, seconds):
+    """The CPU oracle (reference algorithm restated op for op) on this box's host cores."""
+    from oracle import cpu_ref
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    params = {k: v.clone().requires_grad_(True) for k, v in cpu_ref.init_params(net_name, N_FEAT, 1, 1).items()}
+    opt = torch.optim.Adam(list(params.values()), lr=1e-3)
+    kw = {"dropout": 0.4, "training": True} if net_name == "GINet" else {}
+
+    def step():
+        opt.zero_grad()
+        pred = cpu_ref.FORWARD[net_name](params, batch_cpu, **kw)
+        loss = F.mse_loss(pred.reshape(-1), batch_cpu.y)
+        loss.backward()
+        opt.step()
+    for _ in range(2):
+        step()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        step()
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": GRAPHS_PER_GPU * n / dt, "unit": "graphs/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": "%d train steps of the same 64-graph batch in %.1f s (oracle/cpu_ref.py, "
+            "torch %s CPU kernels)" % (n, dt, torch.__version__)}
+
+
+if __name__ == "__main__":
+    main()

@@ -91,8 +91,9 @@ class Api(object):
         lib.drgnn_net_forward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 3 + [_c_i64] * 3 +
                                           [_c_i32] * 2 + [_vp] * 6)
         lib.drgnn_net_backward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 4 + [_c_i64] * 3 +
-                                           [_c_i32] * 2 + [_vp] * 3 +
-                                           [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 4)
+                                           [_c_i32] * 2 + [_vp] * 3 + [_vp] * 4)
+        lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
+                                               [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
         if lib.drgnn_abi_version() != 1:
             raise DrgnnError("ABI mismatch in %s" % path)
 
@@ -146,11 +147,15 @@ class Api(object):
             "drgnn_net_forward")
 
     def net_backward(self, desc, x, grad_readout, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
-                     max_nodes, max_c0, xp, arg0, arg1, g1, g2, grad_x, partials, scratch, stream):
+                     max_nodes, max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream):
         _check(self.lib.drgnn_net_backward(
             ctypes.byref(desc), _ptr(x), _ptr(grad_readout), _ptr(ws_i32), _ptr(ws_f32), n_nodes,
-            n_edges, n_graphs, max_nodes, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1), g1, g2,
+            n_edges, n_graphs, max_nodes, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1),
             _ptr(grad_x), _ptr(partials), _ptr(scratch), stream), "drgnn_net_backward")
+
+    def net_reduce_grads(self, desc, partials, n_nodes, n_graphs, g1, g2, grad_x, stream):
+        _check(self.lib.drgnn_net_reduce_grads(ctypes.byref(desc), _ptr(partials), n_nodes, n_graphs,
+                                               g1, g2, _ptr(grad_x), stream), "drgnn_net_reduce_grads")
 
 
 _API = None

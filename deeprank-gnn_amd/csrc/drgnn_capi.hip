@@ -460,13 +460,11 @@ int drgnn_net_forward(const drgnn_net_desc* net, const float* x, const int32_t* 
 int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* grad_readout,
                        const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges,
                        int64_t n_graphs, int32_t max_nodes, int32_t max_c0, const float* xp,
-                       const int32_t* arg0, const int32_t* arg1, drgnn_conv_grads* g_conv1,
-                       drgnn_conv_grads* g_conv2, float* grad_x, float* partials, float* scratch_f32,
-                       void* stream_) {
+                       const int32_t* arg0, const int32_t* arg1, float* grad_x, float* partials,
+                       float* scratch_f32, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
-    if (!x || !grad_readout || !ws_i32 || !xp || !arg0 || !arg1 || !g_conv1 || !g_conv2 || !partials)
-        return DRGNN_E_ARG;
+    if (!x || !grad_readout || !ws_i32 || !xp || !arg0 || !arg1 || !partials) return DRGNN_E_ARG;
     TopoLayout lay;
     topo_layout(n_nodes, n_edges, n_graphs, &lay);
     NetLaunch L;
@@ -479,11 +477,18 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
     L.a.arg1 = const_cast<int32_t*>(arg1); L.a.readout = nullptr;
     L.a.grad_readout = grad_readout; L.a.partials = partials; L.a.grad_x = grad_x;
     L.a.n_partial = (int)net_partial_floats(net->n_feat);
-    rc = net_launch<true>(L, max_nodes, max_c0, scratch_f32, stream_);
+    return net_launch<true>(L, max_nodes, max_c0, scratch_f32, stream_);
+}
+
+int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,
+                           int64_t n_graphs, drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2,
+                           float* grad_x, void* stream_) {
+    int rc = net_check(net);
     if (rc) return rc;
+    if (!partials || !g_conv1 || !g_conv2) return DRGNN_E_ARG;
     ReduceArgs r;
     r.partials = partials; r.n_graphs = (int)n_graphs; r.n_branch = net->n_branch;
-    r.n_feat = net->n_feat; r.n_partial = L.a.n_partial; r.kind = net->kind;
+    r.n_feat = net->n_feat; r.n_partial = (int)net_partial_floats(net->n_feat); r.kind = net->kind;
     for (int b = 0; b < DRGNN_MAX_BRANCH; ++b) {
         r.lay1[b] = net->conv1[b]; r.lay2[b] = net->conv2[b];
         if (b < net->n_branch) { r.g1[b] = g_conv1[b]; r.g2[b] = g_conv2[b]; }
@@ -494,6 +499,7 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
     if (grad_x && net->n_branch > 1 && n_nodes * net->n_feat > items) items = n_nodes * net->n_feat;
 #ifdef DRGNN_EMU
     for (int64_t i = 0; i < items; ++i) reduce_item(r, i);
+    (void)stream_;
 #else
     hipLaunchKernelGGL(k_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, r, items);
     HIP_TRY(hipGetLastError());

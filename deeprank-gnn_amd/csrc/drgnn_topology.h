@@ -197,27 +197,44 @@ DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n
     }
     BARRIER();
     const long long mn = s.mm[0];
-    long long span = (n > 0) ? (s.mm[1] - mn + 1) : 0;
-    if (span > (long long)(s.capF - 1) || span < 0) {
-        FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER_RANGE, graph); }
-        span = s.capF - 1;
+    const long long span = (n > 0) ? (s.mm[1] - mn + 1) : 0;
+    int C;
+    if (span >= 0 && span <= (long long)(s.capF - 1)) {
+        // usual case (ids are small labels): presence flags over [min, max] + scan, O(n + span)
+        const int range = (int)span;
+        FOR_TID(v, range + 1) { s.fl[v] = 0; }
+        BARRIER();
+        FOR_TID(i, n) { s.fl[(int)((long long)ids[i] - mn)] = 1; }
+        BARRIER();
+        C = wg_exscan(s.fl, range + 1, s.part);
+        FOR_TID(i, n) { s.cl[i] = s.fl[(int)((long long)ids[i] - mn)]; }
+        BARRIER();
+    } else {
+        // arbitrary ids: rank sort of the members by (id, position), O(n^2) comparisons spread
+        // over the workgroup; rank of an id = number of distinct smaller ids
+        FOR_TID(i, n) {
+            const long long me = (long long)ids[i];
+            int r = 0;
+            for (int j = 0; j < n; ++j) {
+                const long long o = (long long)ids[j];
+                r += (o < me || (o == me && j < i)) ? 1 : 0;
+            }
+            s.t1[r] = i;
+        }
+        BARRIER();
+        FOR_TID(p, n + 1) {
+            int head = 0;
+            if (p < n) head = (p == 0 || ids[s.t1[p]] != ids[s.t1[p - 1]]) ? 1 : 0;
+            s.t2[p] = head;
+        }
+        BARRIER();
+        C = wg_exscan(s.t2, n + 1, s.part);
+        FOR_TID(p, n) {
+            const bool head = (p == 0 || ids[s.t1[p]] != ids[s.t1[p - 1]]);
+            s.cl[s.t1[p]] = s.t2[p] - (head ? 0 : 1);
+        }
+        BARRIER();
     }
-    const int range = (int)span;
-    FOR_TID(v, range + 1) { s.fl[v] = 0; }
-    BARRIER();
-    FOR_TID(i, n) {
-        long long d = (long long)ids[i] - mn;
-        if (d >= range) d = range - 1;
-        s.fl[(int)d] = 1;
-    }
-    BARRIER();
-    const int C = wg_exscan(s.fl, range + 1, s.part);
-    FOR_TID(i, n) {
-        long long d = (long long)ids[i] - mn;
-        if (d >= range) d = range - 1;
-        s.cl[i] = s.fl[(int)d];
-    }
-    BARRIER();
     const int* cl = s.cl;
     wg_bucket_sort(n, C, [cl] LAMBDA_DEV(int i) { return cl[i]; }, s.mp, s.cur, s.t1, s.t2, s.mem,
                    s.part);

@@ -143,9 +143,10 @@ class _NetBody(torch.autograd.Function):
         for b, (l1, l2) in enumerate(_split(kind, grads, n_branch)):
             _fill_grads(g1[b], kind, l1, n_feat, H1)
             _fill_grads(g2[b], kind, l2, H1, H2)
+        stream = _lib.current_stream(x)
         api.net_backward(desc, x, grad_readout, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B,
-                         topo.max_nodes, topo.max_c0, xp, arg0, arg1, g1, g2, grad_x, partials, scratch,
-                         _lib.current_stream(x))
+                         topo.max_nodes, topo.max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream)
+        api.net_reduce_grads(desc, partials, n_nodes, B, g1, g2, grad_x, stream)
         if B == 0:
             grads = tuple(torch.zeros_like(p) for p in params)
         gx = None if grad_x is None else grad_x[0]

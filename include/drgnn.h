@@ -191,10 +191,11 @@ int drgnn_net_forward(const drgnn_net_desc* net, const float* x,
                       float* xp, int32_t* arg0, int32_t* arg1, float* readout,
                       float* scratch_f32, void* stream);
 
-/* Backward of the above.  grad_readout float [B][32*n_branch].  Parameter gradients are
- * first written per workgroup into `partials` (float [n_graphs*n_branch][P], P =
- * drgnn_net_partial_elems()) and then reduced deterministically into the strided
- * gradient tensors (overwritten, not accumulated).  grad_x may be NULL. */
+/* Backward of the above.  grad_readout float [B][32*n_branch].  Every workgroup writes its
+ * graph's parameter-gradient contribution into `partials` (float [n_graphs*n_branch][P],
+ * P = drgnn_net_partial_elems(); K x H row-major blocks
+ * [dW1nbr F*16][dW1self F*16][db1 16][dW2nbr 16*32][dW2self 16*32][db2 32]) and, when grad_x
+ * is given, d loss / d x per branch into grad_x float [n_branch][N][F]. */
 int64_t drgnn_net_partial_elems(int32_t kind, int32_t n_feat);
 int64_t drgnn_net_scratch_elems(int32_t kind, int32_t n_feat, int64_t n_nodes, int64_t n_edges,
                                 int64_t n_graphs);
@@ -203,8 +204,14 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
                        int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
                        int32_t max_nodes, int32_t max_c0,
                        const float* xp, const int32_t* arg0, const int32_t* arg1,
-                       drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, float* grad_x,
-                       float* partials, float* scratch_f32, void* stream);
+                       float* grad_x, float* partials, float* scratch_f32, void* stream);
+
+/* Fixed-order (deterministic) sum of the per-graph partials into the strided gradient
+ * tensors (overwritten, not accumulated); with grad_x, branches 1.. are summed into
+ * branch 0.  Replaces the scatter-add autograd performs for the shared weights. */
+int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,
+                           int64_t n_graphs, drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2,
+                           float* grad_x, void* stream);
 
 int drgnn_abi_version(void);
 

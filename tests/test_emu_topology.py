@@ -89,10 +89,17 @@ def test_topology_flags_bad_input():
     strip_layout(batch)
     topo = Topology.from_batch(batch, api=emu())
     assert topo.status()[0] & 8
+
+
+def test_arbitrary_cluster_ids_take_the_general_path():
+    """Ids far outside any small range (e.g. already offset globally, or hashed labels) are
+    ranked by the O(n^2) rank-sort branch; result identical to torch.unique semantics."""
     batch = syn4_batch()
-    batch.cluster0[5] = 10 ** 12                            # absurd id range
+    batch.cluster0 = batch.cluster0 * 1000003 + 7 * 10 ** 11
+    batch.cluster1 = batch.cluster1 * 99991 + 10 ** 12
     topo = Topology.from_batch(batch, api=emu())
-    assert topo.status()[0] & 4
+    assert topo.status()[0] == 0
+    check_against_oracle(topo, batch)
 
 
 def test_finalize_scans():

