@@ -82,16 +82,16 @@ class Api(object):
         lib.drgnn_topology_build.argtypes = [_vp] * 8 + [_c_i64] * 4 + [_c_i32] * 2 + [_vp] * 4
         lib.drgnn_topology_finalize.argtypes = [_vp, _c_i64, _c_i64, _c_i64, _vp]
         lib.drgnn_topology_status.argtypes = [_vp, _c_i64, _c_i64, _c_i64, ctypes.POINTER(_c_i32), _vp]
-        lib.drgnn_net_lds_bytes.argtypes = [_c_i32] * 4
+        lib.drgnn_net_lds_bytes.argtypes = [_c_i32] * 6
         lib.drgnn_net_lds_bytes.restype = _c_i64
         lib.drgnn_net_partial_elems.argtypes = [_c_i32, _c_i32]
         lib.drgnn_net_partial_elems.restype = _c_i64
         lib.drgnn_net_scratch_elems.argtypes = [_c_i32, _c_i32, _c_i64, _c_i64, _c_i64]
         lib.drgnn_net_scratch_elems.restype = _c_i64
         lib.drgnn_net_forward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 3 + [_c_i64] * 3 +
-                                          [_c_i32] * 2 + [_vp] * 6)
+                                          [_c_i32] * 3 + [_vp] * 6)
         lib.drgnn_net_backward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 4 + [_c_i64] * 3 +
-                                           [_c_i32] * 2 + [_vp] * 3 + [_vp] * 4)
+                                           [_c_i32] * 3 + [_vp] * 3 + [_vp] * 4)
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
                                                [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
         if lib.drgnn_abi_version() != 1:
@@ -130,8 +130,8 @@ class Api(object):
         return list(st)
 
     # -- fused net --------------------------------------------------------------
-    def net_lds_bytes(self, kind, n_feat, max_nodes, max_c0):
-        return int(self.lib.drgnn_net_lds_bytes(kind, n_feat, max_nodes, max_c0))
+    def net_lds_bytes(self, kind, n_feat, max_nodes, max_edges, max_c0, backward):
+        return int(self.lib.drgnn_net_lds_bytes(kind, n_feat, max_nodes, max_edges, max_c0, int(backward)))
 
     def net_partial_elems(self, kind, n_feat):
         return int(self.lib.drgnn_net_partial_elems(kind, n_feat))
@@ -139,18 +139,18 @@ class Api(object):
     def net_scratch_elems(self, kind, n_feat, n_nodes, n_edges, n_graphs):
         return int(self.lib.drgnn_net_scratch_elems(kind, n_feat, n_nodes, n_edges, n_graphs))
 
-    def net_forward(self, desc, x, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, max_nodes, max_c0,
-                    xp, arg0, arg1, readout, scratch, stream):
+    def net_forward(self, desc, x, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, max_nodes, max_edges,
+                    max_c0, xp, arg0, arg1, readout, scratch, stream):
         _check(self.lib.drgnn_net_forward(
             ctypes.byref(desc), _ptr(x), _ptr(ws_i32), _ptr(ws_f32), n_nodes, n_edges, n_graphs,
-            max_nodes, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1), _ptr(readout), _ptr(scratch), stream),
+            max_nodes, max_edges, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1), _ptr(readout), _ptr(scratch), stream),
             "drgnn_net_forward")
 
     def net_backward(self, desc, x, grad_readout, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
-                     max_nodes, max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream):
+                     max_nodes, max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream):
         _check(self.lib.drgnn_net_backward(
             ctypes.byref(desc), _ptr(x), _ptr(grad_readout), _ptr(ws_i32), _ptr(ws_f32), n_nodes,
-            n_edges, n_graphs, max_nodes, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1),
+            n_edges, n_graphs, max_nodes, max_edges, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1),
             _ptr(grad_x), _ptr(partials), _ptr(scratch), stream), "drgnn_net_backward")
 
     def net_reduce_grads(self, desc, partials, n_nodes, n_graphs, g1, g2, grad_x, stream):

@@ -70,11 +70,14 @@ struct TopoLaunch {
     int level1_only;       // second pass: only depth-1 clusters, c1 offsets from NC0
 };
 
+// LDS is a compile-time property so that every scratch access is a ds_* instruction (a
+// run-time choice between LDS and global would make them all flat_* accesses)
+template <bool LDS>
 DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
     TopoScratch s;
     const int n0 = L.tv.p[DRGNN_TI_NPTR][g], N = L.tv.p[DRGNN_TI_NPTR][g + 1] - n0;
     const int e0 = L.tv.p[DRGNN_TI_EPTR][g], E = L.tv.p[DRGNN_TI_EPTR][g + 1] - e0;
-    if (L.capN > 0) {
+    if (LDS) {
         const int capT = imax(L.capN, L.capE) + 1;
         s = topo_carve(lds, L.capN, L.capE, capT, L.capN + L.capE + 2);
         if (N > L.capN || E > L.capE) {   // caller's bound was wrong: refuse loudly
@@ -130,35 +133,51 @@ struct ReduceArgs {
     float* grad_x; int64_t n_nodes;    // [n_branch][Ntot][F] -> summed into branch 0
 };
 
-// one work item per (branch, partial element): fixed-order sum over the graphs
-DEV void reduce_item(const ReduceArgs& a, int64_t item) {
-    const int P = a.n_partial, F = a.n_feat;
-    if (item < (int64_t)a.n_branch * P) {
-        const int br = (int)(item / P), p = (int)(item % P);
-        float acc = 0.0f;
-        for (int g = 0; g < a.n_graphs; ++g) acc += a.partials[((int64_t)g * a.n_branch + br) * P + p];
-        const int o_w1s = F * DRGNN_H1, o_b1 = 2 * F * DRGNN_H1, o_w2n = o_b1 + DRGNN_H1;
-        const int o_w2s = o_w2n + DRGNN_H1 * DRGNN_H2, o_b2 = o_w2s + DRGNN_H1 * DRGNN_H2;
-        if (p < o_w1s) {
-            if (a.g1[br].w_nbr) a.g1[br].w_nbr[(int64_t)(p / DRGNN_H1) * a.lay1[br].nbr_sk + (int64_t)(p % DRGNN_H1) * a.lay1[br].nbr_sh] = acc;
-        } else if (p < o_b1) {
-            const int q = p - o_w1s;
-            if (a.g1[br].w_self) a.g1[br].w_self[(int64_t)(q / DRGNN_H1) * a.lay1[br].self_sk + (int64_t)(q % DRGNN_H1) * a.lay1[br].self_sh] = acc;
-        } else if (p < o_w2n) {
-            if (a.g1[br].bias) a.g1[br].bias[p - o_b1] = acc;
-        } else if (p < o_w2s) {
-            const int q = p - o_w2n;
-            if (a.g2[br].w_nbr) a.g2[br].w_nbr[(int64_t)(q / DRGNN_H2) * a.lay2[br].nbr_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].nbr_sh] = acc;
-        } else if (p < o_b2) {
-            const int q = p - o_w2s;
-            if (a.g2[br].w_self) a.g2[br].w_self[(int64_t)(q / DRGNN_H2) * a.lay2[br].self_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].self_sh] = acc;
-        } else {
-            if (a.g2[br].bias) a.g2[br].bias[p - o_b2] = acc;
-        }
+// scatter one reduced partial element into the model's own (strided) gradient tensor
+DEV void reduce_write(const ReduceArgs& a, int br, int p, float acc) {
+    const int F = a.n_feat;
+    const int o_w1s = F * DRGNN_H1, o_b1 = 2 * F * DRGNN_H1, o_w2n = o_b1 + DRGNN_H1;
+    const int o_w2s = o_w2n + DRGNN_H1 * DRGNN_H2, o_b2 = o_w2s + DRGNN_H1 * DRGNN_H2;
+    if (p < o_w1s) {
+        if (a.g1[br].w_nbr) a.g1[br].w_nbr[(int64_t)(p / DRGNN_H1) * a.lay1[br].nbr_sk + (int64_t)(p % DRGNN_H1) * a.lay1[br].nbr_sh] = acc;
+    } else if (p < o_b1) {
+        const int q = p - o_w1s;
+        if (a.g1[br].w_self) a.g1[br].w_self[(int64_t)(q / DRGNN_H1) * a.lay1[br].self_sk + (int64_t)(q % DRGNN_H1) * a.lay1[br].self_sh] = acc;
+    } else if (p < o_w2n) {
+        if (a.g1[br].bias) a.g1[br].bias[p - o_b1] = acc;
+    } else if (p < o_w2s) {
+        const int q = p - o_w2n;
+        if (a.g2[br].w_nbr) a.g2[br].w_nbr[(int64_t)(q / DRGNN_H2) * a.lay2[br].nbr_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].nbr_sh] = acc;
+    } else if (p < o_b2) {
+        const int q = p - o_w2s;
+        if (a.g2[br].w_self) a.g2[br].w_self[(int64_t)(q / DRGNN_H2) * a.lay2[br].self_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].self_sh] = acc;
+    } else {
+        if (a.g2[br].bias) a.g2[br].bias[p - o_b2] = acc;
     }
-    if (a.grad_x != nullptr && a.n_branch > 1 && item < a.n_nodes * F) {
+}
+
+// is this partial slot ever written by the backward kernel?  (GINet has no self / bias terms)
+DEV bool reduce_live(const ReduceArgs& a, int p) {
+    if (a.kind != DRGNN_GINET) return true;
+    const int F = a.n_feat;
+    const int o_w1s = F * DRGNN_H1, o_w2n = 2 * F * DRGNN_H1 + DRGNN_H1, o_w2s = o_w2n + DRGNN_H1 * DRGNN_H2;
+    return p < o_w1s || (p >= o_w2n && p < o_w2s);
+}
+
+// sum of one partial element over the graphs g = first, first+stride, ... (ascending)
+DEV float reduce_sum(const ReduceArgs& a, int br, int p, int first, int stride) {
+    const float* src = a.partials + (int64_t)br * a.n_partial + p;
+    const int64_t step = (int64_t)a.n_branch * a.n_partial;
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int g = first; g < a.n_graphs; g += stride) acc += src[(int64_t)g * step];
+    return acc;
+}
+
+DEV void reduce_grad_x(const ReduceArgs& a, int64_t item) {
+    if (a.grad_x != nullptr && a.n_branch > 1 && item < a.n_nodes * a.n_feat) {
         float acc = a.grad_x[item];
-        for (int br = 1; br < a.n_branch; ++br) acc += a.grad_x[(int64_t)br * a.n_nodes * F + item];
+        for (int br = 1; br < a.n_branch; ++br) acc += a.grad_x[(int64_t)br * a.n_nodes * a.n_feat + item];
         a.grad_x[item] = acc;
     }
 }
@@ -166,28 +185,44 @@ DEV void reduce_item(const ReduceArgs& a, int64_t item) {
 struct NetLaunch {
     NetArgs a;
     float* gscratch;
-    int capN, capC;      // LDS capacities (0 = global scratch)
-    int64_t gstride_n;   // global scratch: floats per node / per graph constant
+    int capN, capE, capC;   // LDS capacities (capN == 0 -> global scratch)
+    int64_t n_edges;
 };
 
-template <int KIND, bool BWD>
+// global-scratch placement: net_scratch_words is affine in (capN, capE, capC)
+HD int64_t net_gscratch_base(int kind, int F, int64_t n0, int64_t e0, int64_t g, int bwd) {
+    const int64_t c0 = net_scratch_words(kind, F, 0, 0, 0, bwd);
+    return net_scratch_words(kind, F, n0, e0, n0, bwd) - c0 + c0 * g;
+}
+
+template <int KIND, bool BWD, bool LDS>
 DEV void net_block(const NetLaunch& L, int blk, float* lds) {
     const int nb = L.a.net.n_branch;
     const int g = blk / nb, br = blk % nb;
     float* scratch;
-    int capN, capC;
-    if (L.capN > 0) {
-        scratch = lds; capN = L.capN; capC = L.capC;
+    int capN, capE, capC;
+    if (LDS) {
+        scratch = lds; capN = L.capN; capE = L.capE; capC = L.capC;
+        const int n0 = L.a.tv.p[DRGNN_TI_NPTR][g], e0 = L.a.tv.p[DRGNN_TI_EPTR][g];
+        if (L.a.tv.p[DRGNN_TI_NPTR][g + 1] - n0 > capN || L.a.tv.p[DRGNN_TI_EPTR][g + 1] - e0 > capE ||
+            L.a.tv.p[DRGNN_TI_NC0][g] > capC) {
+            // the caller's bounds were wrong: poison the output instead of overrunning LDS
+            if (!BWD) {
+                FOR_TID(c, DRGNN_H2) { L.a.readout[(long)g * DRGNN_H2 * nb + br * DRGNN_H2 + c] = DRGNN_NAN; }
+            }
+            return;
+        }
     } else {
-        const int n0 = L.a.tv.p[DRGNN_TI_NPTR][g];
+        const int n0 = L.a.tv.p[DRGNN_TI_NPTR][g], e0 = L.a.tv.p[DRGNN_TI_EPTR][g];
         capN = L.a.tv.p[DRGNN_TI_NPTR][g + 1] - n0;
+        capE = L.a.tv.p[DRGNN_TI_EPTR][g + 1] - e0;
         capC = capN;
-        const int64_t per_branch = net_scratch_floats(KIND, L.a.n_nodes, L.a.n_nodes) + 64LL * L.a.n_graphs;
-        scratch = L.gscratch + (int64_t)br * per_branch + net_scratch_floats(KIND, n0, n0) + 64LL * g - 64;
-        // net_scratch_floats(n0,n0) includes one +64 constant; remove it and add 64 per graph
+        const int F = L.a.net.n_feat;
+        const int64_t per_branch = net_gscratch_base(KIND, F, L.a.n_nodes, L.n_edges, L.a.n_graphs, BWD);
+        scratch = L.gscratch + (int64_t)br * per_branch + net_gscratch_base(KIND, F, n0, e0, g, BWD);
     }
-    if (BWD) net_backward_graph<KIND>(L.a, g, br, scratch, capN, capC);
-    else net_forward_graph<KIND>(L.a, g, br, scratch, capN, capC);
+    if (BWD) net_backward_graph<KIND>(L.a, g, br, scratch, capN, capE, capC);
+    else net_forward_graph<KIND>(L.a, g, br, scratch, capN, capE, capC);
 }
 
 #ifndef DRGNN_EMU
@@ -195,22 +230,37 @@ __global__ void __launch_bounds__(256) k_ptrs(PtrArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     ptr_item(a, i);
 }
+template <bool LDS>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_topo(TopoLaunch L) {
     extern __shared__ __attribute__((aligned(16))) int smem_i[];
-    topo_block(L, blockIdx.x, smem_i);
+    topo_block<LDS>(L, blockIdx.x, smem_i);
 }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_finalize(ScanArgs a) {
     __shared__ int part[DRGNN_NTHREADS + 4];
     finalize_block(a, part);
 }
+// 64 gradient elements per workgroup; the 4 waves sum interleaved quarters of the graphs, the
+// quarter sums are combined in fixed order -> deterministic, and 4x16 loads in flight per lane
 __global__ void __launch_bounds__(256) k_reduce(ReduceArgs a, int64_t n_items) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_items) reduce_item(a, i);
+    __shared__ float quarter[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = item < (int64_t)a.n_branch * a.n_partial && reduce_live(a, (int)(item % a.n_partial));
+    const int br = live ? (int)(item / a.n_partial) : 0, p = live ? (int)(item % a.n_partial) : 0;
+    quarter[q][lane] = live ? reduce_sum(a, br, p, q, 4) : 0.0f;
+    __syncthreads();
+    if (q == 0) {
+        if (live) reduce_write(a, br, p, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
+    } else {
+        // the other waves fold the per-branch d loss / d x slabs (only when it was requested)
+        for (int64_t e = (int64_t)blockIdx.x * 192 + (threadIdx.x - 64); e < a.n_nodes * a.n_feat && a.grad_x; e += (int64_t)gridDim.x * 192)
+            reduce_grad_x(a, e);
+    }
 }
-template <int KIND, bool BWD>
+template <int KIND, bool BWD, bool LDS>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net(NetLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
-    net_block<KIND, BWD>(L, blockIdx.x, smem_f);
+    net_block<KIND, BWD, LDS>(L, blockIdx.x, smem_f);
 }
 __global__ void k_zero_i32(int32_t* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -224,6 +274,14 @@ __global__ void k_zero_i32(int32_t* p, int n) {
 extern "C" {
 
 int drgnn_abi_version(void) { return DRGNN_ABI_VERSION; }
+
+#if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
+// profiling build only: where phase_mark() writes (device buffer of >= 4002 uint64)
+int drgnn_debug_set_phase_buffer(void* dev_buf) {
+    unsigned long long* p = (unsigned long long*)dev_buf;
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_phase_buf), &p, sizeof(p));
+}
+#endif
 
 int drgnn_topology_layout(int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int64_t* off_i32,
                           int64_t* off_f32) {
@@ -297,10 +355,12 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
         for (int64_t gph = 0; gph <= n_graphs; ++gph) { pa.nptr[gph] = node_ptr[gph]; pa.eptr[gph] = edge_ptr[gph]; }
     }
     std::vector<int> lds_buf((size_t)(lds / 4) + 16);
-    for (int gph = 0; gph < n_graphs; ++gph) topo_block(L, gph, lds_buf.data());
-    if (cluster1 && !c1_ptr) {
-        L.level1_only = 1;
-        for (int gph = 0; gph < n_graphs; ++gph) topo_block(L, gph, lds_buf.data());
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) { if (!(cluster1 && !c1_ptr)) break; L.level1_only = 1; }
+        for (int gph = 0; gph < n_graphs; ++gph) {
+            if (L.capN > 0) topo_block<true>(L, gph, lds_buf.data());
+            else topo_block<false>(L, gph, lds_buf.data());
+        }
     }
     (void)stream;
 #else
@@ -313,11 +373,11 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
         HIP_TRY(hipMemcpyAsync(pa.eptr, edge_ptr, sizeof(int32_t) * (n_graphs + 1), hipMemcpyDeviceToDevice, stream));
     }
     if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void*)k_topo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_topo, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
-    if (cluster1 && !c1_ptr) {
-        L.level1_only = 1;
-        hipLaunchKernelGGL(k_topo, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
+        HIP_TRY(hipFuncSetAttribute((const void*)k_topo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1) { if (!(cluster1 && !c1_ptr)) break; L.level1_only = 1; }
+        if (L.capN > 0) hipLaunchKernelGGL(k_topo<true>, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
+        else hipLaunchKernelGGL(k_topo<false>, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, stream, L);
     }
     HIP_TRY(hipGetLastError());
 #endif
@@ -360,20 +420,21 @@ int drgnn_topology_status(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edge
 }
 
 // ---- fused net ----------------------------------------------------------------------
-int64_t drgnn_net_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_c0) {
-    (void)n_feat;
+int64_t drgnn_net_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
+                            int32_t max_c0, int32_t backward) {
     if (max_nodes <= 0) return 0;
     const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
-    return 4 * net_scratch_floats(kind, max_nodes, capC);
+    return 4 * net_scratch_words(kind, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, backward);
 }
 
 int64_t drgnn_net_partial_elems(int32_t kind, int32_t n_feat) { (void)kind; return net_partial_floats(n_feat); }
 
 int64_t drgnn_net_scratch_elems(int32_t kind, int32_t n_feat, int64_t n_nodes, int64_t n_edges,
                                 int64_t n_graphs) {
-    (void)n_feat; (void)n_edges;
     const int nb = (kind == DRGNN_GINET) ? 2 : 1;
-    return nb * (net_scratch_floats(kind, n_nodes, n_nodes) + 64 * n_graphs) + 64;
+    const int64_t f = net_gscratch_base(kind, n_feat, n_nodes, n_edges, n_graphs, 0);
+    const int64_t b = net_gscratch_base(kind, n_feat, n_nodes, n_edges, n_graphs, 1);
+    return nb * (f > b ? f : b) + 64;
 }
 
 }  // extern "C"
@@ -393,13 +454,15 @@ static int net_check(const drgnn_net_desc* net) {
 }
 
 template <bool BWD>
-static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_c0, float* scratch, void* stream_) {
+static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_edges, int32_t max_c0, float* scratch,
+                      void* stream_) {
     const int kind = L.a.net.kind;
-    const int64_t lds = drgnn_net_lds_bytes(kind, L.a.net.n_feat, max_nodes, max_c0);
-    L.capN = 0; L.capC = 0; L.gscratch = scratch;
+    const int64_t lds = drgnn_net_lds_bytes(kind, L.a.net.n_feat, max_nodes, max_edges, max_c0, BWD ? 1 : 0);
+    L.capN = 0; L.capE = 0; L.capC = 0; L.gscratch = scratch;
     int64_t use_lds = 0;
     if (lds > 0 && lds <= DRGNN_LDS_LIMIT) {
         L.capN = max_nodes;
+        L.capE = max_edges > 0 ? max_edges : 1;
         L.capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
         use_lds = lds;
     } else if (!scratch) {
@@ -410,9 +473,15 @@ static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_c0, float* sc
 #ifdef DRGNN_EMU
     std::vector<float> buf((size_t)(use_lds / 4) + 16);
     for (int b = 0; b < blocks; ++b) {
-        if (kind == DRGNN_GINET) net_block<DRGNN_GINET, BWD>(L, b, buf.data());
-        else if (kind == DRGNN_SGAT) net_block<DRGNN_SGAT, BWD>(L, b, buf.data());
-        else net_block<DRGNN_FOUT, BWD>(L, b, buf.data());
+        if (use_lds) {
+            if (kind == DRGNN_GINET) net_block<DRGNN_GINET, BWD, true>(L, b, buf.data());
+            else if (kind == DRGNN_SGAT) net_block<DRGNN_SGAT, BWD, true>(L, b, buf.data());
+            else net_block<DRGNN_FOUT, BWD, true>(L, b, buf.data());
+        } else {
+            if (kind == DRGNN_GINET) net_block<DRGNN_GINET, BWD, false>(L, b, buf.data());
+            else if (kind == DRGNN_SGAT) net_block<DRGNN_SGAT, BWD, false>(L, b, buf.data());
+            else net_block<DRGNN_FOUT, BWD, false>(L, b, buf.data());
+        }
     }
     (void)stream_;
 #else
@@ -420,10 +489,14 @@ static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_c0, float* sc
 #define DRGNN_NET_LAUNCH(K)                                                                         \
     do {                                                                                            \
         if (use_lds > 64 * 1024)                                                                    \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_net<K, BWD>,                                 \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_net<K, BWD, true>,                           \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)use_lds)); \
-        hipLaunchKernelGGL((k_net<K, BWD>), dim3((unsigned)blocks), dim3(DRGNN_NTHREADS),           \
-                           (size_t)use_lds, stream, L);                                             \
+        if (use_lds)                                                                                \
+            hipLaunchKernelGGL((k_net<K, BWD, true>), dim3((unsigned)blocks), dim3(DRGNN_NTHREADS), \
+                               (size_t)use_lds, stream, L);                                         \
+        else                                                                                        \
+            hipLaunchKernelGGL((k_net<K, BWD, false>), dim3((unsigned)blocks), dim3(DRGNN_NTHREADS),\
+                               0, stream, L);                                                       \
     } while (0)
     if (kind == DRGNN_GINET) DRGNN_NET_LAUNCH(DRGNN_GINET);
     else if (kind == DRGNN_SGAT) DRGNN_NET_LAUNCH(DRGNN_SGAT);
@@ -438,8 +511,8 @@ extern "C" {
 
 int drgnn_net_forward(const drgnn_net_desc* net, const float* x, const int32_t* ws_i32,
                       const float* ws_f32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
-                      int32_t max_nodes, int32_t max_c0, float* xp, int32_t* arg0, int32_t* arg1,
-                      float* readout, float* scratch_f32, void* stream_) {
+                      int32_t max_nodes, int32_t max_edges, int32_t max_c0, float* xp, int32_t* arg0,
+                      int32_t* arg1, float* readout, float* scratch_f32, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
     if (!x || !ws_i32 || !xp || !arg0 || !arg1 || !readout) return DRGNN_E_ARG;
@@ -454,14 +527,15 @@ int drgnn_net_forward(const drgnn_net_desc* net, const float* x, const int32_t* 
     L.a.n_graphs = (int)n_graphs;
     L.a.xp = xp; L.a.arg0 = arg0; L.a.arg1 = arg1; L.a.readout = readout;
     L.a.grad_readout = nullptr; L.a.partials = nullptr; L.a.grad_x = nullptr; L.a.n_partial = 0;
-    return net_launch<false>(L, max_nodes, max_c0, scratch_f32, stream_);
+    L.n_edges = n_edges;
+    return net_launch<false>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
 }
 
 int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* grad_readout,
                        const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges,
-                       int64_t n_graphs, int32_t max_nodes, int32_t max_c0, const float* xp,
-                       const int32_t* arg0, const int32_t* arg1, float* grad_x, float* partials,
-                       float* scratch_f32, void* stream_) {
+                       int64_t n_graphs, int32_t max_nodes, int32_t max_edges, int32_t max_c0,
+                       const float* xp, const int32_t* arg0, const int32_t* arg1, float* grad_x,
+                       float* partials, float* scratch_f32, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
     if (!x || !grad_readout || !ws_i32 || !xp || !arg0 || !arg1 || !partials) return DRGNN_E_ARG;
@@ -477,7 +551,8 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
     L.a.arg1 = const_cast<int32_t*>(arg1); L.a.readout = nullptr;
     L.a.grad_readout = grad_readout; L.a.partials = partials; L.a.grad_x = grad_x;
     L.a.n_partial = (int)net_partial_floats(net->n_feat);
-    return net_launch<true>(L, max_nodes, max_c0, scratch_f32, stream_);
+    L.n_edges = n_edges;
+    return net_launch<true>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
 }
 
 int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,
@@ -498,10 +573,15 @@ int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int
     int64_t items = (int64_t)net->n_branch * r.n_partial;
     if (grad_x && net->n_branch > 1 && n_nodes * net->n_feat > items) items = n_nodes * net->n_feat;
 #ifdef DRGNN_EMU
-    for (int64_t i = 0; i < items; ++i) reduce_item(r, i);
-    (void)stream_;
+    for (int64_t i = 0; i < (int64_t)net->n_branch * r.n_partial; ++i) {
+        const int br = (int)(i / r.n_partial), p = (int)(i % r.n_partial);
+        if (reduce_live(r, p)) reduce_write(r, br, p, reduce_sum(r, br, p, 0, 1));
+    }
+    for (int64_t i = 0; grad_x && i < n_nodes * net->n_feat; ++i) reduce_grad_x(r, i);
+    (void)stream_; (void)items;
 #else
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, r, items);
+    const int64_t pitems = (int64_t)net->n_branch * r.n_partial;
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((pitems + 63) / 64)), dim3(256), 0, (hipStream_t)stream_, r, items);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

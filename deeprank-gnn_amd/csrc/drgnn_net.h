@@ -7,14 +7,22 @@
 //   GINet   s = 0          c_e = 1                       no bias     (ginet.py:50-73, alpha==1)
 //   sGAT    s_i = mean a   c_e = a_e / max(deg_i,1)      bias        (sGAT.py:62-93)
 //   FoutNet s = 1          c_e = 1 / deg_i (NaN if 0)    bias        (foutnet.py:56-82)
-// The dense products run on the f32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32); the
-// neighbour aggregation is a CSR gather out of LDS with a fixed summation order; cluster
-// max keeps the first maximum in ascending member order (torch_scatter CPU tie rule).
+//
+// Data movement: every input of a graph (its x tile, CSR/CSC, member lists, weights, saved
+// activations) is staged into LDS by ONE burst of independent coalesced loads at kernel
+// start; all later phases touch LDS only, and only what autograd must keep (pooled
+// features, argmax indices, readout / per-graph weight-gradient partials) goes back to HBM.
+// The dense products run on the f32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32) with operands
+// read from padded LDS rows; neighbour aggregation is a CSR gather with a fixed summation
+// order; cluster max keeps the first maximum in ascending member order (torch_scatter CPU
+// tie rule).
 #pragma once
 #include "drgnn_topology.h"
 
 #define DRGNN_H1 16
 #define DRGNN_H2 32
+#define DRGNN_W1LD (DRGNN_H1 + 1)   // padded LDS row strides of the staged weights
+#define DRGNN_W2LD (DRGNN_H2 + 1)
 
 #ifdef DRGNN_EMU
 #define DRGNN_NAN (NAN)
@@ -26,13 +34,16 @@
 
 // ---------------------------------------------------------------------------------
 // Workgroup GEMM  C(i,j) = sum_k A(i,k) B(k,j),  i<M, j<N, k<K, fully strided operands.
-// gfx950: 16x16 output tiles spread over the 4 waves, K consumed 4 at a time by
-// v_mfma_f32_16x16x4_f32 (A: lane -> row l&15, k l>>4;  B: lane -> k l>>4, col l&15;
-// D: col l&15, rows 4*(l>>4)+r).  No barrier inside; callers separate phases.
+// gfx950: (16x16 output tile, K slice) units are spread over the 4 waves; K is consumed 4 at
+// a time by v_mfma_f32_16x16x4_f32 (A: lane -> row l&15, k l>>4;  B: lane -> k l>>4, col
+// l&15;  D: col l&15, rows 4*(l>>4)+r), operands of 8 steps are fetched before the MFMA
+// chain so their latencies overlap.  With KS > 1 the K range is cut in KS slices whose
+// partial tiles go to `part` ([KS][M][N] floats) and are summed in slice order afterwards
+// (deterministic); callers put a BARRIER before using C.
 // ---------------------------------------------------------------------------------
 #ifdef DRGNN_EMU
 DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const float* B, int sbk,
-                 int sbj, float* C, int sci, int scj) {
+                 int sbj, float* C, int sci, int scj, int KS = 1, float* part = nullptr) {
     for (int i = 0; i < M; ++i)
         for (int j = 0; j < N; ++j) {
             float acc = 0.0f;
@@ -43,30 +54,51 @@ DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const fl
 #else
 typedef float drgnn_f32x4 __attribute__((ext_vector_type(4)));
 DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const float* B, int sbk,
-                 int sbj, float* C, int sci, int scj) {
+                 int sbj, float* C, int sci, int scj, int KS = 1, float* part = nullptr) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int mt = (M + 15) >> 4, nt = (N + 15) >> 4;
-    for (int tile = wave; tile < mt * nt; tile += DRGNN_NWAVES) {
+    const int kslice = (((K + KS - 1) / KS) + 3) & ~3;
+    for (int unit = wave; unit < mt * nt * KS; unit += DRGNN_NWAVES) {
+        const int ks = unit % KS, tile = unit / KS;
         const int i0 = (tile / nt) << 4, j0 = (tile % nt) << 4;
         const int ai = i0 + lr, bj = j0 + lr;
         const bool a_ok = ai < M, b_ok = bj < N;
         const float* ap = A + (long)ai * sai;
         const float* bp = B + (long)bj * sbj;
+        const int kbeg = ks * kslice, kend = imin(K, kbeg + kslice);
         drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = 0; k0 < K; k0 += 4) {
-            const int k = k0 + lq;
-            const bool k_ok = k < K;
-            const float a = (a_ok && k_ok) ? ap[(long)k * sak] : 0.0f;
-            const float b = (b_ok && k_ok) ? bp[(long)k * sbk] : 0.0f;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            float a[8], b[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                const int k = k0 + 4 * s + lq;
+                const bool k_ok = k < kend;
+                a[s] = (a_ok && k_ok) ? ap[(long)k * sak] : 0.0f;
+                b[s] = (b_ok && k_ok) ? bp[(long)k * sbk] : 0.0f;
+            }
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (k0 + 4 * s < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+            }
         }
         if (b_ok) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ci = i0 + lq * 4 + r;
-                if (ci < M) C[(long)ci * sci + (long)bj * scj] = acc[r];
+                if (ci < M) {
+                    if (KS == 1) C[(long)ci * sci + (long)bj * scj] = acc[r];
+                    else part[((long)ks * M + ci) * N + bj] = acc[r];
+                }
             }
+        }
+    }
+    if (KS > 1) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < M * N; e += DRGNN_NTHREADS) {
+            float s = 0.0f;
+            for (int ks = 0; ks < KS; ++ks) s += part[(long)ks * M * N + e];
+            C[(long)(e / N) * sci + (long)(e % N) * scj] = s;
         }
     }
 }
@@ -91,50 +123,154 @@ struct NetArgs {
     int n_partial;           // P
 };
 
-DEV int net_hc(int kind, int h) { return kind == DRGNN_GINET ? h : 2 * h; }
-
-// scratch floats for one workgroup; capC bounds the number of depth-0 clusters
-HD int64_t net_scratch_floats(int kind, int64_t capN, int64_t capC) {
-    const int64_t hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
-    const int64_t hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
-    return capN * (hc1 + DRGNN_H1 + 2) + capC * (DRGNN_H1 + hc2 + DRGNN_H2 + DRGNN_H2 + 2) + 64;
-}
-
+// ---- scratch (LDS, or a global slab for graphs that do not fit) -------------------------
+// One carve serves forward and backward; sizes in 4-byte words.  capE bounds the edges of a
+// graph, capC its number of depth-0 clusters.
 struct NetScratch {
+    // staged inputs
+    float* xs;                 // [capN][F+1]          x tile, padded rows
+    float* wn1; float* ws1; float* b1;   // [F][17] x2, [16]
+    float* wn2; float* ws2; float* b2;   // [16][33] x2, [32]
+    int* rp0; int* ix0; int* ts0;        // [capN+1], [capE], [capE]  CSR0 (fwd) / CSC0 (bwd)
+    float* ew0;                          // [capE] edge weights in CSR0 slot order (sGAT)
+    int* dg0;                            // [capN+1] CSR0 rowptr when ix0 holds the CSC (bwd)
+    int* mp0; int* mem0;                 // [capN+1], [capN]
+    int* rp1; int* ix1; int* ts1;        // [capC+1], [capE], [capE]
+    float* ew1;                          // [capE]
+    int* dg1;                            // [capC+1]
+    int* mp1; int* mem1;                 // [capC+1], [capC]
+    int* a0; int* a1;                    // [capC][16], [capC][32]   saved argmax (bwd)
+    // compute
     float* u1;    // [capN][hc1]   x W1 (nbr | self)      bwd: dU1
     float* z1;    // [capN][16]    relu(conv1)            bwd: dZ1
-    float* dv0;   // [capN]        1/deg (mode dependent)
-    float* sc0;   // [capN]        self coefficient
-    float* xp;    // [capC][16]    pooled features        bwd: dXP
+    float* dv0;   // [capN]
+    float* sc0;   // [capN]
+    float* xp;    // [capC][16]    pooled features        bwd: saved xp
+    float* dxp;   // [capC][16]    bwd: dXP (nbr part)
     float* u2;    // [capC][hc2]                           bwd: dU2
     float* z2;    // [capC][32]                            bwd: dZ2
-    float* p2;    // [capC][32]    depth-1 pooled
+    float* p2;    // [capC][32]    depth-1 pooled          bwd: dXP (self part)
     float* dv1;   // [capC]
     float* sc1;   // [capC]
+    float* gp;    // [2048]        K-split GEMM partials
     float* misc;  // [64]
 };
 
-DEV NetScratch net_carve(float* base, int kind, int capN, int capC) {
-    const int hc1 = net_hc(kind, DRGNN_H1), hc2 = net_hc(kind, DRGNN_H2);
+// Forward and backward stage different subsets; `bwd` selects the carve.  Keep the two
+// functions below in step: net_scratch_words() is what the host sizes LDS with.
+#define NET_CARVE_LIST(X)                                                                      \
+    X(xs, (long)capN * (F + 1), 1)                                                             \
+    X(wn1, F * DRGNN_W1LD, 1)                                                                  \
+    X(ws1, F * DRGNN_W1LD, !gin)                                                               \
+    X(b1, DRGNN_H1, !gin)                                                                      \
+    X(wn2, DRGNN_H1 * DRGNN_W2LD, 1)                                                           \
+    X(ws2, DRGNN_H1 * DRGNN_W2LD, !gin)                                                        \
+    X(b2, DRGNN_H2, !gin)                                                                      \
+    X(rp0, capN + 1, 1)                                                                        \
+    X(ix0, capE, 1)                                                                            \
+    X(ts0, capE, bwd && sg)                                                                    \
+    X(ew0, capE, sg)                                                                           \
+    X(dg0, capN + 1, bwd && !gin)                                                              \
+    X(mp0, capN + 1, !bwd)                                                                     \
+    X(mem0, capN, !bwd)                                                                        \
+    X(rp1, capC + 1, 1)                                                                        \
+    X(ix1, capE, 1)                                                                            \
+    X(ts1, capE, bwd && sg)                                                                    \
+    X(ew1, capE, sg)                                                                           \
+    X(dg1, capC + 1, bwd && !gin)                                                              \
+    X(mp1, capC + 1, !bwd)                                                                     \
+    X(mem1, capC, !bwd)                                                                        \
+    X(a0, (long)capC * DRGNN_H1, bwd)                                                          \
+    X(a1, (long)capC * DRGNN_H2, bwd)                                                          \
+    X(u1, (long)capN * hc1, 1)                                                                 \
+    X(z1, (long)capN * DRGNN_H1, 1)                                                            \
+    X(dv0, capN, !gin)                                                                         \
+    X(sc0, capN, !gin)                                                                         \
+    X(xp, (long)capC * DRGNN_H1, 1)                                                            \
+    X(dxp, (long)capC * DRGNN_H1, bwd)                                                         \
+    X(u2, (long)capC * hc2, 1)                                                                 \
+    X(z2, (long)capC * DRGNN_H2, 1)                                                            \
+    X(p2, (long)capC * DRGNN_H2, (!bwd) || (!gin))                                             \
+    X(dv1, capC, !gin)                                                                         \
+    X(sc1, capC, !gin)                                                                         \
+    X(gp, 2048, bwd)                                                                           \
+    X(misc, 64, 1)
+
+HD int64_t net_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, int64_t capC, int bwd) {
+    const int64_t hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
+    const int64_t hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
+    const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
+    const int gin = (kind == DRGNN_GINET) ? 1 : 0;
+    int64_t w = 0;
+#define X(name, words, cond) w += (cond) ? (int64_t)(words) : 0;
+    NET_CARVE_LIST(X)
+#undef X
+    return w + 16;
+}
+
+DEV NetScratch net_carve(float* base, int kind, int F, int capN, int capE, int capC, int bwd) {
+    const int hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
+    const int hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
+    const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
+    const int gin = (kind == DRGNN_GINET) ? 1 : 0;
     NetScratch s;
     float* p = base;
-    s.u1 = p;  p += (long)capN * hc1;
-    s.z1 = p;  p += (long)capN * DRGNN_H1;
-    s.dv0 = p; p += capN;
-    s.sc0 = p; p += capN;
-    s.xp = p;  p += (long)capC * DRGNN_H1;
-    s.u2 = p;  p += (long)capC * hc2;
-    s.z2 = p;  p += (long)capC * DRGNN_H2;
-    s.p2 = p;  p += (long)capC * DRGNN_H2;
-    s.dv1 = p; p += capC;
-    s.sc1 = p; p += capC;
-    s.misc = p;
+#define X(name, words, cond) s.name = (decltype(s.name))p; p += (cond) ? (long)(words) : 0;
+    NET_CARVE_LIST(X)
+#undef X
     return s;
+}
+
+struct GraphDims { int n0, N, e0, E, C, E1, C1, rowbase; };
+
+DEV GraphDims net_dims(const TopoView& tv, int g) {
+    GraphDims d;
+    d.n0 = tv.p[DRGNN_TI_NPTR][g];
+    d.N = tv.p[DRGNN_TI_NPTR][g + 1] - d.n0;
+    d.e0 = tv.p[DRGNN_TI_EPTR][g];
+    d.E = tv.p[DRGNN_TI_EPTR][g + 1] - d.e0;
+    d.C = tv.p[DRGNN_TI_NC0][g];
+    d.E1 = tv.p[DRGNN_TI_NE1][g];
+    d.C1 = tv.p[DRGNN_TI_NC1][g];
+    d.rowbase = d.n0 + g;
+    return d;
+}
+
+// strided [K,H] weight -> dense padded LDS rows  dst[k*ld + h]
+DEV void stage_weight(float* dst, int ld, const float* src, long sk, long sh, int K, int H) {
+    if (src == nullptr) return;
+    FOR_TID(e, K * H) {
+        const int k = e / H, h = e % H;
+        dst[k * ld + h] = src[(long)k * sk + (long)h * sh];
+    }
+}
+DEV void stage_i32(int* dst, const int32_t* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
+DEV void stage_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
+
+// weights + x tile
+template <int KIND>
+DEV void net_stage_common(const NetArgs& a, const GraphDims& d, int br, NetScratch& s) {
+    const int F = a.net.n_feat;
+    const drgnn_conv_params& c1 = a.net.conv1[br];
+    const drgnn_conv_params& c2 = a.net.conv2[br];
+    const float* xg = a.x + (long)d.n0 * F;
+    FOR_TID(e, d.N * F) {
+        const int i = e / F, f = e % F;
+        s.xs[i * (F + 1) + f] = xg[e];
+    }
+    stage_weight(s.wn1, DRGNN_W1LD, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
+    stage_weight(s.wn2, DRGNN_W2LD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+    if (KIND != DRGNN_GINET) {
+        stage_weight(s.ws1, DRGNN_W1LD, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
+        stage_weight(s.ws2, DRGNN_W2LD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+        stage_f32(s.b1, c1.bias, DRGNN_H1);
+        stage_f32(s.b2, c2.bias, DRGNN_H2);
+    }
 }
 
 // per-row coefficients of one level:  dv[i] (edge scale), sc[i] (self scale)
 template <int KIND>
-DEV void net_row_coefs(int n, const int32_t* rp, const float* w, float* dv, float* sc) {
+DEV void net_row_coefs(int n, const int* rp, const float* w, float* dv, float* sc) {
     if (KIND == DRGNN_GINET) return;
     FOR_TID(i, n) {
         const int lo = rp[i], hi = rp[i + 1];
@@ -154,7 +290,7 @@ DEV void net_row_coefs(int n, const int32_t* rp, const float* w, float* dv, floa
 
 // z[i, :] = relu( sc[i]*u[i, H:2H] + sum_k coef_k * u[col[k], 0:H] + bias )   (H multiple of 4)
 template <int KIND, int H>
-DEV void net_aggregate(int n, const int32_t* rp, const int32_t* col, const float* w, const float* dv,
+DEV void net_aggregate(int n, const int* rp, const int* col, const float* w, const float* dv,
                        const float* sc, const float* u, const float* bias, float* z) {
     constexpr int HC = (KIND == DRGNN_GINET) ? H : 2 * H;
     constexpr int G = H / 4;
@@ -162,6 +298,7 @@ DEV void net_aggregate(int n, const int32_t* rp, const int32_t* col, const float
         const int i = item / G, c = (item % G) * 4;
         const int lo = rp[i], hi = rp[i + 1];
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
         for (int k = lo; k < hi; ++k) {
             const float* uj = u + (long)col[k] * HC + c;
             float cf = 1.0f;
@@ -188,12 +325,13 @@ DEV void net_aggregate(int n, const int32_t* rp, const int32_t* col, const float
 // cluster max with argmax (first maximum in ascending member order; NaN never wins;
 // empty cluster -> 0).  arg = -1 where no gradient can flow (value <= 0 or empty).
 template <int H>
-DEV void net_cluster_max(int nc, const int32_t* mp, const int32_t* mem, const float* z, float* out,
+DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, float* out,
                          float* g_out, int32_t* g_arg) {
     FOR_TID(item, nc * H) {
         const int r = item / H, c = item % H;
         float best = DRGNN_NEG_INF;
         int arg = -1;
+#pragma unroll 4
         for (int p = mp[r]; p < mp[r + 1]; ++p) {
             const int m = mem[p];
             const float v = z[(long)m * H + c];
@@ -206,65 +344,57 @@ DEV void net_cluster_max(int nc, const int32_t* mp, const int32_t* mem, const fl
     }
 }
 
-struct GraphDims { int n0, N, e0, C, C1, rowbase; };
-
-DEV GraphDims net_dims(const TopoView& tv, int g) {
-    GraphDims d;
-    d.n0 = tv.p[DRGNN_TI_NPTR][g];
-    d.N = tv.p[DRGNN_TI_NPTR][g + 1] - d.n0;
-    d.e0 = tv.p[DRGNN_TI_EPTR][g];
-    d.C = tv.p[DRGNN_TI_NC0][g];
-    d.C1 = tv.p[DRGNN_TI_NC1][g];
-    d.rowbase = d.n0 + g;
-    return d;
-}
-
 // ---------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------
 template <int KIND>
-DEV void net_forward_graph(const NetArgs& a, int g, int br, float* scratch, int capN, int capC) {
+DEV void net_forward_graph(const NetArgs& a, int g, int br, float* scratch, int capN, int capE,
+                           int capC) {
     constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
     constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const TopoView& tv = a.tv;
     const GraphDims d = net_dims(tv, g);
     const int F = a.net.n_feat;
-    NetScratch s = net_carve(scratch, KIND, capN, capC);
-    const drgnn_conv_params& c1 = a.net.conv1[br];
-    const drgnn_conv_params& c2 = a.net.conv2[br];
-    const float* xg = a.x + (long)d.n0 * F;
-    const int32_t* rp0 = tv.p[DRGNN_TI_ROWPTR0] + d.rowbase;
-    const int32_t* col0 = tv.p[DRGNN_TI_COL0] + d.e0;
-    const int32_t* rp1 = tv.p[DRGNN_TI_ROWPTR1] + d.rowbase;
-    const int32_t* col1 = tv.p[DRGNN_TI_COL1] + d.e0;
-    const float* w0 = tv.w0 ? tv.w0 + d.e0 : nullptr;
-    const float* w1 = tv.w1 ? tv.w1 + d.e0 : nullptr;
+    NetScratch s = net_carve(scratch, KIND, F, capN, capE, capC, 0);
     const long nodeoff = (long)br * a.n_nodes + d.n0;
 
+    // ---- one burst of independent loads: everything this graph needs -> LDS ------------
+    PHASE_MARK();
+    net_stage_common<KIND>(a, d, br, s);
+    stage_i32(s.rp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+    stage_i32(s.ix0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
+    stage_i32(s.mp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
+    stage_i32(s.mem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
+    stage_i32(s.rp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+    stage_i32(s.ix1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
+    stage_i32(s.mp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
+    stage_i32(s.mem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+    if (KIND == DRGNN_SGAT) {
+        stage_f32(s.ew0, tv.w0 + d.e0, d.E);
+        stage_f32(s.ew1, tv.w1 + d.e0, d.E1);
+    }
+    BARRIER();
+
     // conv1 dense part:  U1 = X W1
-    wg_gemm(d.N, DRGNN_H1, F, xg, F, 1, c1.w_nbr, (int)c1.nbr_sk, (int)c1.nbr_sh, s.u1, HC1, 1);
+    wg_gemm(d.N, DRGNN_H1, F, s.xs, F + 1, 1, s.wn1, DRGNN_W1LD, 1, s.u1, HC1, 1);
     if (KIND != DRGNN_GINET)
-        wg_gemm(d.N, DRGNN_H1, F, xg, F, 1, c1.w_self, (int)c1.self_sk, (int)c1.self_sh,
-                s.u1 + DRGNN_H1, HC1, 1);
-    net_row_coefs<KIND>(d.N, rp0, w0, s.dv0, s.sc0);
+        wg_gemm(d.N, DRGNN_H1, F, s.xs, F + 1, 1, s.ws1, DRGNN_W1LD, 1, s.u1 + DRGNN_H1, HC1, 1);
+    net_row_coefs<KIND>(d.N, s.rp0, s.ew0, s.dv0, s.sc0);
+    net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
     BARRIER();
-    net_aggregate<KIND, DRGNN_H1>(d.N, rp0, col0, w0, s.dv0, s.sc0, s.u1, c1.bias, s.z1);
+    net_aggregate<KIND, DRGNN_H1>(d.N, s.rp0, s.ix0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
     BARRIER();
-    net_cluster_max<DRGNN_H1>(d.C, tv.p[DRGNN_TI_MPTR0] + d.rowbase, tv.p[DRGNN_TI_MEM0] + d.n0, s.z1,
-                              s.xp, a.xp + nodeoff * DRGNN_H1, a.arg0 + nodeoff * DRGNN_H1);
+    net_cluster_max<DRGNN_H1>(d.C, s.mp0, s.mem0, s.z1, s.xp, a.xp + nodeoff * DRGNN_H1,
+                              a.arg0 + nodeoff * DRGNN_H1);
     BARRIER();
     // conv2 on the pooled graph
-    wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, c2.w_nbr, (int)c2.nbr_sk, (int)c2.nbr_sh, s.u2,
-            HC2, 1);
+    wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.wn2, DRGNN_W2LD, 1, s.u2, HC2, 1);
     if (KIND != DRGNN_GINET)
-        wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, c2.w_self, (int)c2.self_sk, (int)c2.self_sh,
-                s.u2 + DRGNN_H2, HC2, 1);
-    net_row_coefs<KIND>(d.C, rp1, w1, s.dv1, s.sc1);
+        wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.ws2, DRGNN_W2LD, 1, s.u2 + DRGNN_H2, HC2, 1);
     BARRIER();
-    net_aggregate<KIND, DRGNN_H2>(d.C, rp1, col1, w1, s.dv1, s.sc1, s.u2, c2.bias, s.z2);
+    net_aggregate<KIND, DRGNN_H2>(d.C, s.rp1, s.ix1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
     BARRIER();
-    net_cluster_max<DRGNN_H2>(d.C1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, tv.p[DRGNN_TI_MEM1] + d.n0, s.z2,
-                              s.p2, nullptr, a.arg1 + nodeoff * DRGNN_H2);
+    net_cluster_max<DRGNN_H2>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, a.arg1 + nodeoff * DRGNN_H2);
     BARRIER();
     // graph readout: mean over the depth-1 clusters (scatter_mean with count clamp)
     const int bad = tv.p[DRGNN_TI_ERR][0];
@@ -282,21 +412,22 @@ DEV void net_forward_graph(const NetArgs& a, int g, int br, float* scratch, int 
 // partial layout per workgroup (floats), K x H row-major blocks:
 //   [dW1nbr F*16][dW1self F*16][db1 16][dW2nbr 16*32][dW2self 16*32][db2 32]
 // ---------------------------------------------------------------------------------
-static inline int64_t net_partial_floats(int n_feat) {
+HD int64_t net_partial_floats(int n_feat) {
     return 2LL * n_feat * DRGNN_H1 + DRGNN_H1 + 2LL * DRGNN_H1 * DRGNN_H2 + DRGNN_H2;
 }
 
 // dU[j, 0:H]   = sum over CSC entries t of column j : coef * dZ[row(t), :]
 // dU[i, H:2H]  = sc[i] * dZ[i, :]
 template <int KIND, int H>
-DEV void net_aggregate_bwd(int n, const int32_t* rp, const int32_t* cp, const int32_t* ridx,
-                           const int32_t* tslot, const float* w, const float* dv, const float* sc,
-                           const float* dz, float* du) {
+DEV void net_aggregate_bwd(int n, const int* deg_rp, const int* cp, const int* ridx, const int* tslot,
+                           const float* w, const float* dv, const float* sc, const float* dz,
+                           float* du) {
     constexpr int HC = (KIND == DRGNN_GINET) ? H : 2 * H;
     constexpr int G = H / 4;
     FOR_TID(item, n * G) {
         const int j = item / G, c = (item % G) * 4;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
         for (int t = cp[j]; t < cp[j + 1]; ++t) {
             const int i = ridx[t];
             float cf = 1.0f;
@@ -310,7 +441,7 @@ DEV void net_aggregate_bwd(int n, const int32_t* rp, const int32_t* cp, const in
         uj[0] = a0; uj[1] = a1; uj[2] = a2; uj[3] = a3;
         if (KIND != DRGNN_GINET) {
             float s = sc[j];
-            if (KIND == DRGNN_FOUT && rp[j + 1] == rp[j]) s = 0.0f;   // NaN row never wins a max
+            if (KIND == DRGNN_FOUT && deg_rp[j + 1] == deg_rp[j]) s = 0.0f;   // NaN row never wins a max
             const float* dj = dz + (long)j * H + c;
             uj[H + 0] = s * dj[0]; uj[H + 1] = s * dj[1];
             uj[H + 2] = s * dj[2]; uj[H + 3] = s * dj[3];
@@ -319,24 +450,15 @@ DEV void net_aggregate_bwd(int n, const int32_t* rp, const int32_t* cp, const in
 }
 
 template <int KIND>
-DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int capN, int capC) {
+DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int capN, int capE,
+                            int capC) {
     constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
     constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const TopoView& tv = a.tv;
     const GraphDims d = net_dims(tv, g);
     const int F = a.net.n_feat;
-    NetScratch s = net_carve(scratch, KIND, capN, capC);
-    const drgnn_conv_params& c1 = a.net.conv1[br];
-    const drgnn_conv_params& c2 = a.net.conv2[br];
-    const float* xg = a.x + (long)d.n0 * F;
-    const int32_t* rp0 = tv.p[DRGNN_TI_ROWPTR0] + d.rowbase;
-    const int32_t* rp1 = tv.p[DRGNN_TI_ROWPTR1] + d.rowbase;
-    const float* w0 = tv.w0 ? tv.w0 + d.e0 : nullptr;
-    const float* w1 = tv.w1 ? tv.w1 + d.e0 : nullptr;
+    NetScratch s = net_carve(scratch, KIND, F, capN, capE, capC, 1);
     const long nodeoff = (long)br * a.n_nodes + d.n0;
-    const float* g_xp = a.xp + nodeoff * DRGNN_H1;
-    const int32_t* g_arg0 = a.arg0 + nodeoff * DRGNN_H1;
-    const int32_t* g_arg1 = a.arg1 + nodeoff * DRGNN_H2;
     const int width = DRGNN_H2 * a.net.n_branch;
     const float* dr = a.grad_readout + (long)g * width + br * DRGNN_H2;
     float* part = a.partials + ((long)g * a.net.n_branch + br) * a.n_partial;
@@ -347,88 +469,110 @@ DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int
     float* p_w2s = p_w2n + DRGNN_H1 * DRGNN_H2;
     float* p_b2 = p_w2s + DRGNN_H1 * DRGNN_H2;
 
-    // ---- depth-1 max + mean backward: dZ2 (relu mask folded into arg1 = -1) ------------
+    // ---- stage: x tile, weights, transposed graphs, saved activations -------------------
+    PHASE_MARK();
+    net_stage_common<KIND>(a, d, br, s);
+    stage_i32(s.rp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+    stage_i32(s.ix0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+    stage_i32(s.rp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+    stage_i32(s.ix1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+    if (KIND != DRGNN_GINET) {
+        stage_i32(s.dg0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+        stage_i32(s.dg1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+    }
+    if (KIND == DRGNN_SGAT) {
+        stage_i32(s.ts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+        stage_i32(s.ts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+        stage_f32(s.ew0, tv.w0 + d.e0, d.E);
+        stage_f32(s.ew1, tv.w1 + d.e0, d.E1);
+    }
+    stage_i32(s.a0, a.arg0 + nodeoff * DRGNN_H1, d.C * DRGNN_H1);
+    stage_i32(s.a1, a.arg1 + nodeoff * DRGNN_H2, d.C1 * DRGNN_H2);
+    stage_f32(s.xp, a.xp + nodeoff * DRGNN_H1, d.C * DRGNN_H1);
+    stage_f32(s.misc, dr, DRGNN_H2);
     FOR_TID(item, d.C * DRGNN_H2) { s.z2[item] = 0.0f; }
-    net_row_coefs<KIND>(d.C, rp1, w1, s.dv1, s.sc1);
-    net_row_coefs<KIND>(d.N, rp0, w0, s.dv0, s.sc0);
+    FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }
     BARRIER();
+
+    // ---- depth-1 max + mean backward: dZ2 (relu mask folded into arg1 = -1) ------------
+    net_row_coefs<KIND>(d.C, s.dg1, s.ew1, s.dv1, s.sc1);
+    net_row_coefs<KIND>(d.N, s.dg0, s.ew0, s.dv0, s.sc0);
     {
         const float inv = 1.0f / (float)(d.C1 > 0 ? d.C1 : 1);
         FOR_TID(item, d.C1 * DRGNN_H2) {
-            const int r = g_arg1[item];
+            const int r = s.a1[item];
             const int c = item % DRGNN_H2;
-            if (r >= 0) s.z2[(long)r * DRGNN_H2 + c] = dr[c] * inv;
+            if (r >= 0) s.z2[(long)r * DRGNN_H2 + c] = s.misc[c] * inv;
         }
     }
     BARRIER();
     // ---- conv2 backward ------------------------------------------------------------
-    net_aggregate_bwd<KIND, DRGNN_H2>(d.C, rp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase,
-                                      tv.p[DRGNN_TI_ROWIDX1] + d.e0, tv.p[DRGNN_TI_TSLOT1] + d.e0, w1,
-                                      s.dv1, s.sc1, s.z2, s.u2);
-    FOR_TID(c, DRGNN_H2) {
-        float acc = 0.0f;
-        for (int r = 0; r < d.C; ++r) acc += s.z2[r * DRGNN_H2 + c];
-        p_b2[c] = acc;
+    net_aggregate_bwd<KIND, DRGNN_H2>(d.C, s.dg1, s.rp1, s.ix1, s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
+    if (KIND != DRGNN_GINET) {
+        FOR_TID(c, DRGNN_H2) {
+            float acc = 0.0f;
+            for (int r = 0; r < d.C; ++r) acc += s.z2[r * DRGNN_H2 + c];
+            p_b2[c] = acc;
+        }
     }
     BARRIER();
     // dW2 = XP^T dU2      (A(i=k16, k=r) = xp[r*16 + i])
-    wg_gemm(DRGNN_H1, DRGNN_H2, d.C, g_xp, 1, DRGNN_H1, s.u2, HC2, 1, p_w2n, DRGNN_H2, 1);
+    wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2, HC2, 1, p_w2n, DRGNN_H2, 1);
     if (KIND != DRGNN_GINET)
-        wg_gemm(DRGNN_H1, DRGNN_H2, d.C, g_xp, 1, DRGNN_H1, s.u2 + DRGNN_H2, HC2, 1, p_w2s, DRGNN_H2, 1);
-    // dXP = dU2n W2n^T (+ dU2s W2s^T): B(k=h, j=i16) = W2(i16, h) = w[i*sk + h*sh]
-    if (KIND == DRGNN_GINET) {
-        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, c2.w_nbr, (int)c2.nbr_sh, (int)c2.nbr_sk, s.xp,
-                DRGNN_H1, 1);
-    } else {
-        // two products accumulated: first into xp, second into p2 (free here), then added
-        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, c2.w_nbr, (int)c2.nbr_sh, (int)c2.nbr_sk, s.xp,
-                DRGNN_H1, 1);
-        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2 + DRGNN_H2, HC2, 1, c2.w_self, (int)c2.self_sh,
-                (int)c2.self_sk, s.p2, DRGNN_H1, 1);
-    }
-    FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }
+        wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2 + DRGNN_H2, HC2, 1, p_w2s, DRGNN_H2, 1);
+    // dXP = dU2n W2n^T (+ dU2s W2s^T):  B(k=h, j=i16) = W2(i16, h) = wn2[i*33 + h]
+    wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, s.wn2, 1, DRGNN_W2LD, s.dxp, DRGNN_H1, 1);
+    if (KIND != DRGNN_GINET)
+        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2 + DRGNN_H2, HC2, 1, s.ws2, 1, DRGNN_W2LD, s.p2, DRGNN_H1, 1);
     BARRIER();
     // ---- depth-0 max backward: dZ1 ----------------------------------------------------
     FOR_TID(item, d.C * DRGNN_H1) {
-        const int m = g_arg0[item];
+        const int m = s.a0[item];
         const int c = item % DRGNN_H1;
         if (m >= 0) {
-            float v = s.xp[item];
+            float v = s.dxp[item];
             if (KIND != DRGNN_GINET) v += s.p2[item];
             s.z1[(long)m * DRGNN_H1 + c] = v;
         }
     }
     BARRIER();
     // ---- conv1 backward ------------------------------------------------------------
-    net_aggregate_bwd<KIND, DRGNN_H1>(d.N, rp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase,
-                                      tv.p[DRGNN_TI_ROWIDX0] + d.e0, tv.p[DRGNN_TI_TSLOT0] + d.e0, w0,
-                                      s.dv0, s.sc0, s.z1, s.u1);
-    FOR_TID(c, DRGNN_H1) {
-        float acc = 0.0f;
-        for (int i = 0; i < d.N; ++i) acc += s.z1[i * DRGNN_H1 + c];
-        p_b1[c] = acc;
+    net_aggregate_bwd<KIND, DRGNN_H1>(d.N, s.dg0, s.rp0, s.ix0, s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
+    if (KIND != DRGNN_GINET) {
+        FOR_TID(c, DRGNN_H1) {
+            float acc = 0.0f;
+            for (int i = 0; i < d.N; ++i) acc += s.z1[i * DRGNN_H1 + c];
+            p_b1[c] = acc;
+        }
     }
     BARRIER();
-    // dW1 = X^T dU1      (A(i=f, k=node) = x[node*F + f])
-    wg_gemm(F, DRGNN_H1, d.N, xg, 1, F, s.u1, HC1, 1, p_w1n, DRGNN_H1, 1);
-    if (KIND != DRGNN_GINET)
-        wg_gemm(F, DRGNN_H1, d.N, xg, 1, F, s.u1 + DRGNN_H1, HC1, 1, p_w1s, DRGNN_H1, 1);
+    // dW1 = X^T dU1      (A(i=f, k=node) = xs[node*(F+1) + f]); K = N_g is long: split it
+    {
+        const int mtiles = (F + 15) >> 4;
+        int KS = imin(DRGNN_NWAVES / mtiles, 2048 / (F * DRGNN_H1));
+        if (KS < 1) KS = 1;
+        wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, F + 1, s.u1, HC1, 1, p_w1n, DRGNN_H1, 1, KS, s.gp);
+        if (KIND != DRGNN_GINET) {
+            BARRIER();
+            wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, F + 1, s.u1 + DRGNN_H1, HC1, 1, p_w1s, DRGNN_H1, 1, KS, s.gp);
+        }
+    }
     if (a.grad_x != nullptr) {
         // dX = dU1n W1n^T (+ dU1s W1s^T), written per branch; branches are summed by the reducer
         float* gx = a.grad_x + nodeoff * F;
-        wg_gemm(d.N, F, DRGNN_H1, s.u1, HC1, 1, c1.w_nbr, (int)c1.nbr_sh, (int)c1.nbr_sk, gx, F, 1);
+        BARRIER();
+        wg_gemm(d.N, F, DRGNN_H1, s.u1, HC1, 1, s.wn1, 1, DRGNN_W1LD, s.xs, F + 1, 1);
+        BARRIER();
         if (KIND != DRGNN_GINET) {
-            BARRIER();
-            // second product accumulated through z1-sized LDS is not possible for F > 16:
-            // add it row by row instead (each thread owns whole (node, f) entries)
             FOR_TID(item, d.N * F) {
                 const int i = item / F, f = item % F;
                 const float* us = s.u1 + (long)i * HC1 + DRGNN_H1;
-                float acc = 0.0f;
-                for (int h = 0; h < DRGNN_H1; ++h)
-                    acc = fmaf(us[h], c1.w_self[(long)f * c1.self_sk + (long)h * c1.self_sh], acc);
-                gx[item] += acc;
+                float acc = s.xs[i * (F + 1) + f];
+                for (int h = 0; h < DRGNN_H1; ++h) acc = fmaf(us[h], s.ws1[f * DRGNN_W1LD + h], acc);
+                gx[item] = acc;
             }
+        } else {
+            FOR_TID(item, d.N * F) { gx[item] = s.xs[(item / F) * (F + 1) + item % F]; }
         }
     }
 }

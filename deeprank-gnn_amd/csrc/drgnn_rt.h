@@ -24,7 +24,8 @@
 #define HD static inline
 #define FOR_TID(i, n) for (int i = 0; i < (int)(n); ++i)
 #define BARRIER() ((void)0)
-#define DRGNN_NTHREADS 256
+#define PHASE_MARK() ((void)0)
+#define DRGNN_NTHREADS 1024
 struct WG { int block; int nthreads; };
 #define WG_TID0(wg) (true)
 DEV int emu_atomic_add(int* p, int v) { int o = *p; *p = o + v; return o; }
@@ -42,9 +43,24 @@ typedef void* drgnn_stream_t;
 #include <limits.h>
 #define DEV __device__ __forceinline__
 #define HD __host__ __device__ static inline
-#define DRGNN_NTHREADS 256
+#define DRGNN_NTHREADS 1024
 #define FOR_TID(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += DRGNN_NTHREADS)
+#ifdef DRGNN_PHASE_TIMING
+// profiling build only (libdrgnn_prof.so, tools/phase_timing.py): thread 0 of workgroup 0
+// stamps (source line, shader clock) after every barrier into a global buffer.
+__device__ unsigned long long* g_phase_buf = nullptr;
+__device__ __forceinline__ void phase_mark(int line) {
+    if (threadIdx.x == 0 && blockIdx.x == 0 && g_phase_buf != nullptr) {
+        const unsigned long long k = g_phase_buf[0];
+        if (k < 2000) { g_phase_buf[2 + 2 * k] = (unsigned long long)line; g_phase_buf[3 + 2 * k] = clock64(); g_phase_buf[0] = k + 1; }
+    }
+}
+#define BARRIER() do { __syncthreads(); phase_mark(__LINE__); } while (0)
+#define PHASE_MARK() phase_mark(__LINE__)
+#else
 #define BARRIER() __syncthreads()
+#define PHASE_MARK() ((void)0)
+#endif
 struct WG { int block; int nthreads; };
 #define ATOMIC_ADD(p, v) atomicAdd((p), (v))
 #define ATOMIC_OR(p, v) atomicOr((p), (v))

@@ -91,6 +91,9 @@ struct TopoScratch {
     int* col;        // [capE]
     int* seg;        // [capE]
     int* col1;       // [capE]
+    int* er;         // [capE] local row of every edge (staged once from the int64 edge_index)
+    int* ec;         // [capE] local col
+    float* w0;       // [capE] edge_attr in CSR0 slot order
     int* t1;         // [capT] x5
     int* t2;
     int* t3;
@@ -104,16 +107,16 @@ struct TopoScratch {
 // number of ints: linear in (capN, capE, capT, capF) -- keep in sync with topo_carve
 static inline int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT, int64_t capF) {
     return 4 + TOPO_PAD4(DRGNN_NTHREADS + 1) + 6 * TOPO_PAD4(capN + 1) + 3 * TOPO_PAD4(capN) +
-           3 * TOPO_PAD4(capE) + 5 * TOPO_PAD4(capT) + TOPO_PAD4(capF);
+           6 * TOPO_PAD4(capE) + 5 * TOPO_PAD4(capT) + TOPO_PAD4(capF);
 }
 
 // Global-memory placement of graph g's scratch when it does not live in LDS.  With
-// capT = N+E+1 and capF = N+E+2 the carve needs at most 15*N + 9*E + TOPO_GSCRATCH_CONST ints
+// capT = N+E+1 and capF = N+E+2 the carve needs at most 15*N + 12*E + TOPO_GSCRATCH_CONST ints
 // (the constant absorbs the fixed arrays and every PAD4 rounding), so regions placed at
-// 15*n0 + 9*e0 + CONST*g (rounded up to even for the 64-bit min/max slot) never overlap.
-#define TOPO_GSCRATCH_CONST 400
+// 15*n0 + 12*e0 + CONST*g (rounded up to even for the 64-bit min/max slot) never overlap.
+#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 176)
 HD int64_t topo_gscratch_base(int64_t n0, int64_t e0, int64_t g) {
-    return ((15 * n0 + 9 * e0 + (int64_t)TOPO_GSCRATCH_CONST * g) + 1) & ~(int64_t)1;
+    return ((15 * n0 + 12 * e0 + (int64_t)TOPO_GSCRATCH_CONST * g) + 1) & ~(int64_t)1;
 }
 
 template <class IntPtr>
@@ -134,6 +137,9 @@ DEV TopoScratch topo_carve(IntPtr base, int capN, int capE, int capT, int capF) 
     s.col = base + o;  o += (int)TOPO_PAD4(capE);
     s.seg = base + o;  o += (int)TOPO_PAD4(capE);
     s.col1 = base + o; o += (int)TOPO_PAD4(capE);
+    s.er = base + o;   o += (int)TOPO_PAD4(capE);
+    s.ec = base + o;   o += (int)TOPO_PAD4(capE);
+    s.w0 = (float*)(base + o); o += (int)TOPO_PAD4(capE);
     s.t1 = base + o;   o += (int)TOPO_PAD4(capT);
     s.t2 = base + o;   o += (int)TOPO_PAD4(capT);
     s.t3 = base + o;   o += (int)TOPO_PAD4(capT);
@@ -187,15 +193,36 @@ DEV void wg_bucket_sort(int n, int nb, F bucket_of, int* ptr, int* cur, int* tmp
 // present (order preserving), plus member lists with ascending member index.
 // Outputs in scratch: s.cl[0..n), s.mp[0..C], s.mem[0..n); returns C.
 // ---------------------------------------------------------------------------------
-DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n, TopoScratch& s) {
-    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+// min / max of ids[0..n) into mm[0], mm[1]: per-lane running values, a wave butterfly, then
+// ONE atomic per wave (same-address LDS atomics serialise: 2 per element cost ~12k cycles)
+DEV void wg_minmax64(const int64_t* ids, int n, long long* mm) {
+    FOR_TID(i, 1) { mm[0] = LLONG_MAX; mm[1] = LLONG_MIN; }
     BARRIER();
-    FOR_TID(i, n) {
-        const long long id = (long long)ids[i];
-        ATOMIC_MIN64(&s.mm[0], id);
-        ATOMIC_MAX64(&s.mm[1], id);
+#ifdef DRGNN_EMU
+    for (int i = 0; i < n; ++i) {
+        if ((long long)ids[i] < mm[0]) mm[0] = (long long)ids[i];
+        if ((long long)ids[i] > mm[1]) mm[1] = (long long)ids[i];
     }
+#else
+    long long lo = LLONG_MAX, hi = LLONG_MIN;
+    for (int i = threadIdx.x; i < n; i += DRGNN_NTHREADS) {
+        const long long v = (long long)ids[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+#pragma unroll
+    for (int d = DRGNN_WAVE / 2; d >= 1; d >>= 1) {
+        const long long ol = __shfl_xor(lo, d, DRGNN_WAVE), oh = __shfl_xor(hi, d, DRGNN_WAVE);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & (DRGNN_WAVE - 1)) == 0 && lo <= hi) { ATOMIC_MIN64(&mm[0], lo); ATOMIC_MAX64(&mm[1], hi); }
+#endif
     BARRIER();
+}
+
+DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n, TopoScratch& s) {
+    wg_minmax64(ids, n, s.mm);
     const long long mn = s.mm[0];
     const long long span = (n > 0) ? (s.mm[1] - mn + 1) : 0;
     int C;
@@ -298,43 +325,92 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, TopoScratch& s
         FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_EDGE_RANGE, g); }
         E = 0;
     }
+    PHASE_MARK();
     const int64_t* src_row = a.edge_index + e0;
     const int64_t* src_col = a.edge_index + a.n_edges + e0;
     const int Nm1 = N - 1;
-
-    // ---- CSR0: rows ordered by edge id ----------------------------------------------
-    {
-        const TopoView tvc = tv;
-        auto row_of = [src_row, n0, Nm1, tvc, g] LAMBDA_DEV(int e) {
-            long long r = (long long)src_row[e] - n0;
-            if (r < 0 || r > Nm1) { topo_flag(tvc, DRGNN_S_EDGE_RANGE, g); r = 0; }
-            return (int)r;
-        };
-        wg_bucket_sort(E, N, row_of, s.rp, s.cur, s.t1, s.seg, s.t2, s.part);
-    }
     int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
     int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
     int32_t* g_eid0 = tv.p[DRGNN_TI_EID0] + e0;
     float* g_w0 = tv.w0 ? tv.w0 + e0 : nullptr;
     float* g_w1 = tv.w1 ? tv.w1 + e0 : nullptr;
     const bool has_w = (a.edge_attr != nullptr) && (g_w0 != nullptr);
-    FOR_TID(k, E) {
-        const int e = s.t2[k];
-        long long c = (long long)src_col[e] - n0;
-        if (c < 0 || c > Nm1) { topo_flag(tv, DRGNN_S_EDGE_RANGE, g); c = 0; }
-        s.col[k] = (int)c;
-        g_col0[k] = (int)c;
-        g_eid0[k] = e;
-        if (has_w) g_w0[k] = a.edge_attr[e0 + e];
+
+    // ---- stage the edge list once (int64 global ids -> int32 local), clear the histograms ----
+    int* rp = s.rp;             // [N+1]   rows
+    int* cp = s.rp + (N + 1);   // [N+1]   cols, contiguous with rp so ONE scan serves both
+    int* cur_r = s.cur;
+    int* cur_c = s.nb;
+    FOR_TID(e, E) {
+        long long r = (long long)src_row[e] - n0, c = (long long)src_col[e] - n0;
+        if (r < 0 || r > Nm1 || c < 0 || c > Nm1) {
+            topo_flag(tv, DRGNN_S_EDGE_RANGE, g);
+            r = (r < 0 || r > Nm1) ? 0 : r;
+            c = (c < 0 || c > Nm1) ? 0 : c;
+        }
+        s.er[e] = (int)r;
+        s.ec[e] = (int)c;
     }
-    FOR_TID(i, N + 1) { g_rowptr0[i] = s.rp[i]; }
+    FOR_TID(i, 2 * N + 2) { rp[i] = 0; }
+    FOR_TID(i, N + 1) { cur_r[i] = 0; }
+    FOR_TID(i, N) { cur_c[i] = 0; }
     BARRIER();
+    // ---- CSR0 and CSC0 together: histogram, one scan, slot claim, rank sort by edge id ------
+    FOR_TID(e, E) {
+        ATOMIC_ADD(&rp[s.er[e]], 1);
+        ATOMIC_ADD(&cp[s.ec[e]], 1);
+    }
+    BARRIER();
+    wg_exscan(rp, 2 * N + 2, s.part);      // cp[] now carries an extra +E (the row total)
+    FOR_TID(e, E) {
+        const int r = s.er[e], c = s.ec[e];
+        s.t1[rp[r] + ATOMIC_ADD(&cur_r[r], 1)] = e;
+        s.t2[cp[c] - E + ATOMIC_ADD(&cur_c[c], 1)] = e;
+    }
+    BARRIER();
+    FOR_TID(p, E) {
+        {
+            const int e = s.t1[p];
+            const int lo = rp[s.er[e]], hi = rp[s.er[e] + 1];
+            int rank = 0;
+            for (int q = lo; q < hi; ++q) rank += (s.t1[q] < e) ? 1 : 0;
+            s.t3[lo + rank] = e;                       // CSR0 slot -> edge
+        }
+        {
+            const int e = s.t2[p];
+            const int lo = cp[s.ec[e]] - E, hi = cp[s.ec[e] + 1] - E;
+            int rank = 0;
+            for (int q = lo; q < hi; ++q) rank += (s.t2[q] < e) ? 1 : 0;
+            s.t4[lo + rank] = e;                       // CSC0 entry -> edge
+        }
+    }
+    BARRIER();
+    FOR_TID(k, E) {
+        const int e = s.t3[k];
+        const int c = s.ec[e];
+        s.col[k] = c;
+        s.seg[k] = s.er[e];
+        s.t5[e] = k;                                   // edge -> CSR0 slot
+        g_col0[k] = c;
+        g_eid0[k] = e;
+        if (has_w) { const float w = a.edge_attr[e0 + e]; s.w0[k] = w; g_w0[k] = w; }
+    }
+    {
+        int32_t* g_colptr0 = tv.p[DRGNN_TI_COLPTR0] + rowbase;
+        FOR_TID(i, N + 1) { g_rowptr0[i] = rp[i]; g_colptr0[i] = cp[i] - E; }
+    }
+    BARRIER();
+    {
+        int32_t* g_rowidx0 = tv.p[DRGNN_TI_ROWIDX0] + e0;
+        int32_t* g_tslot0 = tv.p[DRGNN_TI_TSLOT0] + e0;
+        FOR_TID(j, E) {
+            const int e = s.t4[j];
+            g_rowidx0[j] = s.er[e];
+            g_tslot0[j] = s.t5[e];
+        }
+    }
 
-    // ---- CSC0 ----------------------------------------------------------------------
-    wg_csc_build(N, E, s.col, s.seg, s, tv.p[DRGNN_TI_COLPTR0] + rowbase,
-                 tv.p[DRGNN_TI_ROWIDX0] + e0, tv.p[DRGNN_TI_TSLOT0] + e0);
-
-    // ---- depth-0 clusters ------------------------------------------------------------
+    // ---- depth-0 clusters (touches t1, t2, cur, fl, cl, mp, mem only) ----------------------
     const int C = wg_cluster_rank(tv, g, a.cluster0 + n0, N, s);
     {
         int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
@@ -352,24 +428,21 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, TopoScratch& s
             for (int p = s.mp[r]; p < s.mp[r + 1]; ++p) {
                 const int m = s.mem[p];
                 s.nb[m] = acc;
-                acc += s.rp[m + 1] - s.rp[m];
+                acc += rp[m + 1] - rp[m];
             }
         }
         s.pp[r] = acc;
     }
     BARRIER();
     wg_exscan(s.pp, C + 1, s.part);
-    FOR_TID(m, N) {
+    FOR_TID(k, E) {                                   // one work item per CSR0 slot
+        const int m = s.seg[k];
         const int r = s.cl[m];
-        const int base = s.pp[r] + s.nb[m];
-        const int lo = s.rp[m], hi = s.rp[m + 1];
-        for (int k = lo; k < hi; ++k) {
-            const int cc = s.cl[s.col[k]];
-            const int j = base + (k - lo);
-            s.t1[j] = (cc == r) ? INT_MAX : cc;   // self loop of the pooled graph: dropped
-            s.t2[j] = k;
-            s.t3[j] = r;
-        }
+        const int cc = s.cl[s.col[k]];
+        const int j = s.pp[r] + s.nb[m] + (k - rp[m]);
+        s.t1[j] = (cc == r) ? INT_MAX : cc;           // self loop of the pooled graph: dropped
+        s.t2[j] = k;
+        s.t3[j] = r;
     }
     BARRIER();
     // rank sort of every pooled row's candidates by (target cluster, position)
@@ -410,7 +483,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, TopoScratch& s
             if (has_w) {
                 const int hi = s.pp[r + 1];
                 float w = 0.0f;
-                for (int q = j; q < hi && s.t4[q] == key; ++q) w += g_w0[s.t5[q]];
+                for (int q = j; q < hi && s.t4[q] == key; ++q) w += s.w0[s.t5[q]];
                 g_w1[slot] = w;
             }
         }

@@ -60,7 +60,7 @@ class FoutNet(nn.Module):
 
     def body(self, data, topo=None):
         if topo is None:
-            topo = Topology.from_batch(data)
+            topo = Topology.from_batch(data, need_weights=False)
         live = self.conv1.live_parameters() + self.conv2.live_parameters()
         return net_body(_lib.FOUT, data.x, topo, live, n_branch=1)
 

@@ -104,13 +104,13 @@ class _NetBody(torch.autograd.Function):
         arg1 = torch.empty((n_branch, n_nodes, H2), dtype=torch.int32, device=dev)
         readout = torch.empty((B, H2 * n_branch), dtype=torch.float32, device=dev)
         scratch = None
-        lds = api.net_lds_bytes(kind, n_feat, topo.max_nodes, topo.max_c0)
+        lds = api.net_lds_bytes(kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, False)
         if lds == 0 or lds > 160 * 1024:
             scratch = torch.empty(api.net_scratch_elems(kind, n_feat, n_nodes, topo.n_edges, B),
                                   dtype=torch.float32, device=dev)
         desc = _describe(kind, n_feat, params, n_branch)
         api.net_forward(desc, x, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes,
-                        topo.max_c0, xp, arg0, arg1, readout, scratch, _lib.current_stream(x))
+                        topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, _lib.current_stream(x))
         ctx.topo, ctx.kind, ctx.n_branch = topo, kind, n_branch
         ctx.save_for_backward(x, xp, arg0, arg1, *params)
         ctx.mark_non_differentiable(arg0, arg1)
@@ -133,7 +133,7 @@ class _NetBody(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             grad_x = torch.empty((n_branch, n_nodes, n_feat), dtype=torch.float32, device=dev)
         scratch = None
-        lds = api.net_lds_bytes(kind, n_feat, topo.max_nodes, topo.max_c0)
+        lds = api.net_lds_bytes(kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, True)
         if lds == 0 or lds > 160 * 1024:
             scratch = torch.empty(api.net_scratch_elems(kind, n_feat, n_nodes, topo.n_edges, B),
                                   dtype=torch.float32, device=dev)
@@ -145,7 +145,8 @@ class _NetBody(torch.autograd.Function):
             _fill_grads(g2[b], kind, l2, H1, H2)
         stream = _lib.current_stream(x)
         api.net_backward(desc, x, grad_readout, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B,
-                         topo.max_nodes, topo.max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream)
+                         topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1, grad_x, partials,
+                         scratch, stream)
         api.net_reduce_grads(desc, partials, n_nodes, B, g1, g2, grad_x, stream)
         if B == 0:
             grads = tuple(torch.zeros_like(p) for p in params)

@@ -81,7 +81,7 @@ class GINet(nn.Module):
     def body(self, data, topo=None):
         """Per-graph readout [B, 64] = [branch(conv1, conv2) | branch(conv1_ext, conv2_ext)]."""
         if topo is None:
-            topo = Topology.from_batch(data)
+            topo = Topology.from_batch(data, need_weights=False)
         convs = (self.conv1, self.conv2, self.conv1_ext, self.conv2_ext)
         live = tuple(p for c in convs for p in c.live_parameters())
         dead = tuple(p for c in convs for p in c.dead_parameters())

@@ -38,8 +38,10 @@ class Topology(object):
 
     # ---------------------------------------------------------------------------
     @classmethod
-    def from_batch(cls, data, api=None, with_level1=True, check=False):
-        """Build from a ``Batch``-like object (attribute access only)."""
+    def from_batch(cls, data, api=None, with_level1=True, check=False, need_weights=True):
+        """Build from a ``Batch``-like object (attribute access only).  ``need_weights=False``
+        skips everything that involves ``edge_attr`` (GINet's attention is identically 1 and
+        FoutLayer never reads it, so only sGAT needs the pooled, summed edge attributes)."""
         api = api or _lib.get()
         edge_index = _contig(data.edge_index, torch.int64)
         batch = _contig(data.batch, torch.int64)
@@ -48,7 +50,7 @@ class Topology(object):
         device = batch.device
         n_nodes = batch.numel()
         n_edges = edge_index.size(1) if edge_index.dim() == 2 else 0
-        edge_attr = getattr(data, "edge_attr", None)
+        edge_attr = getattr(data, "edge_attr", None) if need_weights else None
         if edge_attr is not None:
             if edge_attr.dim() == 2 and edge_attr.size(1) != 1:
                 raise ValueError("only one edge feature is supported (the reference's layers "

@@ -178,16 +178,17 @@ typedef struct drgnn_net_desc {
  *   arg1 int32 [n_branch][N][32]   local depth-0 cluster that won the depth-1 max, -1 = no grad
  * readout float [B][32*n_branch]   per-graph mean of the depth-1 pooled features
  */
-/* max_nodes: upper bound on any graph's node count; max_c0: upper bound on any graph's
- * number of depth-0 clusters (0 = unknown -> max_nodes).  Both size the LDS carve; when the
- * carve exceeds 160 KiB (or max_nodes == 0) the kernels run out of `scratch_f32` (global,
- * drgnn_net_scratch_elems() floats) instead. */
-int64_t drgnn_net_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_c0);
+/* max_nodes / max_edges / max_c0: upper bounds on any single graph's node count, edge count
+ * and number of depth-0 clusters (max_c0 = 0: unknown -> max_nodes).  They size the LDS
+ * carve (forward and backward differ); when it exceeds 160 KiB (or max_nodes == 0) the
+ * kernels run out of `scratch_f32` (global, drgnn_net_scratch_elems() floats) instead. */
+int64_t drgnn_net_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
+                            int32_t max_c0, int32_t backward);
 
 int drgnn_net_forward(const drgnn_net_desc* net, const float* x,
                       const int32_t* ws_i32, const float* ws_f32,
                       int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
-                      int32_t max_nodes, int32_t max_c0,
+                      int32_t max_nodes, int32_t max_edges, int32_t max_c0,
                       float* xp, int32_t* arg0, int32_t* arg1, float* readout,
                       float* scratch_f32, void* stream);
 
@@ -202,7 +203,7 @@ int64_t drgnn_net_scratch_elems(int32_t kind, int32_t n_feat, int64_t n_nodes, i
 int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* grad_readout,
                        const int32_t* ws_i32, const float* ws_f32,
                        int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
-                       int32_t max_nodes, int32_t max_c0,
+                       int32_t max_nodes, int32_t max_edges, int32_t max_c0,
                        const float* xp, const int32_t* arg0, const int32_t* arg1,
                        float* grad_x, float* partials, float* scratch_f32, void* stream);
 

@@ -55,14 +55,14 @@ def check_against_oracle(topo, batch, level1=True):
         np.testing.assert_array_equal(np.repeat(np.arange(N), np.diff(rp)), rows[order])
         if ea is not None:
             np.testing.assert_array_equal(a["W0"][e0:e1], ea[e0:e1].numpy()[order])
-        # ---- CSC0: entries of column j ordered by CSR slot
+        # ---- CSC0: entries of column j ordered by edge id
         cp = a["COLPTR0"][rb:rb + N + 1]
-        slot_row = np.repeat(np.arange(N), np.diff(rp))
-        slot_col = a["COL0"][e0:e1]
-        corder = np.lexsort((np.arange(E), slot_col))
-        np.testing.assert_array_equal(a["TSLOT0"][e0:e1], corder)
-        np.testing.assert_array_equal(a["ROWIDX0"][e0:e1], slot_row[corder])
-        np.testing.assert_array_equal(np.repeat(np.arange(N), np.diff(cp)), slot_col[corder])
+        eorder = np.lexsort((np.arange(E), cols))
+        slot_of_edge = np.empty(E, dtype=np.int64)
+        slot_of_edge[order] = np.arange(E)
+        np.testing.assert_array_equal(a["TSLOT0"][e0:e1], slot_of_edge[eorder])
+        np.testing.assert_array_equal(a["ROWIDX0"][e0:e1], rows[eorder])
+        np.testing.assert_array_equal(np.repeat(np.arange(N), np.diff(cp)), cols[eorder])
         # ---- depth-0 clusters
         C = a["NC0"][g]
         np.testing.assert_array_equal(a["CL0"][n0:n1] + cptr0[g], cons0[n0:n1].numpy())
