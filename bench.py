@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--mode", choices=["graph", "eager"], default="graph")
+    ap.add_argument("--mode", choices=["native", "native-eager", "graph", "eager"], default="native",
+                    help="native: FusedTrainer step (our head/loss/Adam kernels) replayed from a hipGraph; "
+                         "graph/eager: torch autograd + torch.optim.Adam around the fused body")
     ap.add_argument("--net", choices=["GINet", "sGAT", "FoutNet"], default="GINet")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -80,28 +82,48 @@ def main():
     torch.manual_seed(0)
     net = Net(N_FEAT, 1, 1).to(dev)            # dropout stays 0.4 for GINet (training mode)
     net.train()
-    opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=(args.mode == "graph"))
-    bucket = FlatGradBucket(net.parameters())
-    loss_out = torch.zeros((), device=dev)
+    native = args.mode.startswith("native")
+    capture = args.mode in ("native", "graph")
+    need_w = args.net == "sGAT"
+    if native:
+        from deeprank_gnn_amd.trainer import FusedTrainer
+        trainer = FusedTrainer(net, lr=1e-3, task="reg", seed=1234 + rank)
+        loss_out = trainer.loss
 
-    def fwd_bwd():
-        bucket.zero()
-        topo = Topology.from_batch(batch, need_weights=(args.net == "sGAT"))
-        pred = net(batch, topo=topo)
-        loss = F.mse_loss(pred.reshape(-1), batch.y)
-        loss.backward()
-        loss_out.copy_(loss.detach())
+        def fwd_bwd():
+            trainer.compute_gradients(batch)
 
-    def reduce_and_step():
-        opt.step()
+        def all_reduce():
+            trainer.all_reduce_gradients()
 
-    if args.mode == "graph":
+        def reduce_and_step():
+            trainer.apply_update()
+    else:
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=capture)
+        bucket = FlatGradBucket(net.parameters())
+        loss_out = torch.zeros((), device=dev)
+
+        def fwd_bwd():
+            bucket.zero()
+            topo = Topology.from_batch(batch, need_weights=need_w)
+            pred = net(batch, topo=topo)
+            loss = F.mse_loss(pred.reshape(-1), batch.y)
+            loss.backward()
+            loss_out.copy_(loss.detach())
+
+        def all_reduce():
+            bucket.all_reduce()
+
+        def reduce_and_step():
+            opt.step()
+
+    if capture:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
                 fwd_bwd()
-                bucket.all_reduce()
+                all_reduce()
                 reduce_and_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
@@ -122,12 +144,12 @@ def main():
 
             def step():
                 g1.replay()
-                bucket.all_reduce()
+                all_reduce()
                 g2.replay()
     else:
         def step():
             fwd_bwd()
-            bucket.all_reduce()
+            all_reduce()
             reduce_and_step()
 
     for _ in range(args.warmup):
@@ -158,7 +180,7 @@ def main():
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s train step (topology+fwd+MSE+bwd+allreduce+Adam) on SYN graphs: "
+            "config": {"workload": "%s train step (topology + body fwd + FC head/MSE + bwd + grad all-reduce + Adam) on SYN graphs: "
                                    "200 nodes, ~1000 directed edges, 32 node feats, 50->16 clusters "
                                    "(BASELINE.json configs[1])" % args.net,
                        "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,

@@ -50,6 +50,15 @@ class NetDesc(ctypes.Structure):
                 ("conv1", ConvParams * MAX_BRANCH), ("conv2", ConvParams * MAX_BRANCH)]
 
 
+class HeadDesc(ctypes.Structure):
+    _fields_ = [("R", _c_i32), ("H", _c_i32), ("O", _c_i32), ("task", _c_i32), ("train", _c_i32),
+                ("p_drop", ctypes.c_float), ("seed", ctypes.c_uint32), ("reserved", _c_i32),
+                ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("class_w", _vp)]
+
+
+TASK_REG, TASK_CLASS = 0, 1
+
+
 def _ptr(t):
     return None if t is None else t.data_ptr()
 
@@ -94,6 +103,11 @@ class Api(object):
                                            [_c_i32] * 3 + [_vp] * 3 + [_vp] * 4)
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
                                                [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
+        lib.drgnn_head_partial_elems.argtypes = [_c_i32] * 3
+        lib.drgnn_head_partial_elems.restype = _c_i64
+        lib.drgnn_head_step.argtypes = [ctypes.POINTER(HeadDesc), _vp, _vp, _c_i64] + [_vp] * 5
+        lib.drgnn_head_reduce.argtypes = [_vp, _c_i64, _c_i32, _c_i32, _c_i32] + [_vp] * 4
+        lib.drgnn_adam_step.argtypes = [_vp] * 5 + [_c_i64] + [ctypes.c_float] * 5 + [_vp]
         if lib.drgnn_abi_version() != 1:
             raise DrgnnError("ABI mismatch in %s" % path)
 
@@ -156,6 +170,26 @@ class Api(object):
     def net_reduce_grads(self, desc, partials, n_nodes, n_graphs, g1, g2, grad_x, stream):
         _check(self.lib.drgnn_net_reduce_grads(ctypes.byref(desc), _ptr(partials), n_nodes, n_graphs,
                                                g1, g2, _ptr(grad_x), stream), "drgnn_net_reduce_grads")
+
+
+    # -- head / loss / optimiser ------------------------------------------------
+    def head_partial_elems(self, R, H, O):
+        return int(self.lib.drgnn_head_partial_elems(R, H, O))
+
+    def head_step(self, desc, readout, target, n_graphs, step, pred, grad_readout, partials, stream):
+        _check(self.lib.drgnn_head_step(ctypes.byref(desc), _ptr(readout), _ptr(target), n_graphs,
+                                        _ptr(step), _ptr(pred), _ptr(grad_readout), _ptr(partials),
+                                        stream), "drgnn_head_step")
+
+    def head_reduce(self, partials, n_graphs, R, H, O, grad_block_ptr, loss, step, stream):
+        _check(self.lib.drgnn_head_reduce(_ptr(partials), n_graphs, R, H, O, grad_block_ptr, _ptr(loss),
+                                          _ptr(step), stream), "drgnn_head_reduce")
+
+    def adam_step(self, param, grad, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay,
+                  stream):
+        _check(self.lib.drgnn_adam_step(_ptr(param), _ptr(grad), _ptr(exp_avg), _ptr(exp_avg_sq),
+                                        _ptr(step), param.numel(), lr, beta1, beta2, eps, weight_decay,
+                                        stream), "drgnn_adam_step")
 
 
 _API = None

@@ -4,7 +4,7 @@
 //   hipcc --offload-arch=gfx950 -> csrc/libdrgnn.so        (the product)
 //   g++ -x c++ -DDRGNN_EMU      -> tests/emu/build/libdrgnn_emu.so (CPU test-suite only:
 //        every "launch" becomes a loop over workgroups on host pointers)
-#include "drgnn_net.h"
+#include "drgnn_head.h"
 
 #ifdef DRGNN_EMU
 #include <vector>
@@ -262,9 +262,26 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net(NetLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     net_block<KIND, BWD, LDS>(L, blockIdx.x, smem_f);
 }
-__global__ void k_zero_i32(int32_t* p, int n) {
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_head(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_h[];
+    head_block(a, blockIdx.x, smem_h);
+}
+__global__ void __launch_bounds__(256) k_head_reduce(HeadReduceArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0;
+    if (i < a.P - 1) head_reduce_item(a, i);
+}
+__global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
+    adam_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// topology prologue when the caller supplies the per-graph offsets: copy them into the
+// workspace and clear the status words (one launch instead of two copies and a fill)
+__global__ void __launch_bounds__(256) k_topo_begin(const int32_t* node_ptr, const int32_t* edge_ptr,
+                                                    int32_t* nptr, int32_t* eptr, int32_t* err, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        if (node_ptr) { nptr[i] = node_ptr[i]; eptr[i] = edge_ptr[i]; }
+    }
+    if (i < 4) err[i] = 0;
 }
 #endif
 
@@ -364,13 +381,14 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
     }
     (void)stream;
 #else
-    hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, pa.err, 4);
+    {
+        const int n = (int)n_graphs + 1;
+        hipLaunchKernelGGL(k_topo_begin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+                           need_ptrs ? nullptr : node_ptr, edge_ptr, pa.nptr, pa.eptr, pa.err, n);
+    }
     if (need_ptrs) {
         const int64_t items = span > 0 ? span : 1;
         hipLaunchKernelGGL(k_ptrs, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, pa);
-    } else {
-        HIP_TRY(hipMemcpyAsync(pa.nptr, node_ptr, sizeof(int32_t) * (n_graphs + 1), hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(hipMemcpyAsync(pa.eptr, edge_ptr, sizeof(int32_t) * (n_graphs + 1), hipMemcpyDeviceToDevice, stream));
     }
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_topo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -582,6 +600,87 @@ int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int
 #else
     const int64_t pitems = (int64_t)net->n_branch * r.n_partial;
     hipLaunchKernelGGL(k_reduce, dim3((unsigned)((pitems + 63) / 64)), dim3(256), 0, (hipStream_t)stream_, r, items);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+// ---- dense head + loss + optimiser ----------------------------------------------------------
+int64_t drgnn_head_partial_elems(int32_t R, int32_t H, int32_t O) { return head_partial_floats(R, H, O); }
+
+static int head_check(const drgnn_head_desc* hd) {
+    if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2) return DRGNN_E_ARG;
+    if (hd->R < 1 || hd->H < 1 || hd->O < 1 || hd->O > DRGNN_MAX_OUT) return DRGNN_E_WIDTH;
+    if (4 * head_lds_words(hd->R, hd->H, hd->O) > DRGNN_LDS_LIMIT) return DRGNN_E_WIDTH;
+    if (hd->task != DRGNN_TASK_REG && hd->task != DRGNN_TASK_CLASS) return DRGNN_E_ARG;
+    if (!(hd->p_drop >= 0.0f && hd->p_drop < 1.0f)) return DRGNN_E_ARG;
+    return 0;
+}
+
+int drgnn_head_step(const drgnn_head_desc* hd, const float* readout, const void* target,
+                    int64_t n_graphs, const int32_t* step, float* pred, float* grad_readout,
+                    float* partials, void* stream_) {
+    int rc = head_check(hd);
+    if (rc) return rc;
+    if (!readout || !pred || n_graphs < 0) return DRGNN_E_ARG;
+    if (hd->train && (!target || !grad_readout || !partials)) return DRGNN_E_ARG;
+    if (n_graphs == 0) return 0;
+    HeadArgs a;
+    a.readout = readout;
+    a.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
+    a.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
+    a.class_w = hd->class_w;
+    a.w1 = hd->w1; a.b1 = hd->b1; a.w2 = hd->w2; a.b2 = hd->b2;
+    a.step = step; a.pred = pred; a.grad_readout = hd->train ? grad_readout : nullptr;
+    a.partials = partials;
+    a.B = (int)n_graphs; a.R = hd->R; a.H = hd->H; a.O = hd->O;
+    a.task = hd->task; a.train = hd->train; a.p_drop = hd->p_drop; a.seed = hd->seed;
+    const int blocks = (int)((n_graphs + DRGNN_HEAD_TILE - 1) / DRGNN_HEAD_TILE);
+    const int64_t lds = 4 * head_lds_words(hd->R, hd->H, hd->O);
+#ifdef DRGNN_EMU
+    std::vector<float> buf((size_t)(lds / 4) + 16);
+    for (int b = 0; b < blocks; ++b) head_block(a, b, buf.data());
+    (void)stream_;
+#else
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_head, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_head, dim3((unsigned)blocks), dim3(DRGNN_NTHREADS), (size_t)lds, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_head_reduce(const float* partials, int64_t n_graphs, int32_t R, int32_t H, int32_t O,
+                      float* grad_block, float* loss, int32_t* step, void* stream_) {
+    if (!partials || !grad_block) return DRGNN_E_ARG;
+    HeadReduceArgs a;
+    a.partials = partials;
+    a.n_wg = (int)((n_graphs + DRGNN_HEAD_TILE - 1) / DRGNN_HEAD_TILE);
+    a.P = (int)head_partial_floats(R, H, O);
+    a.grad = grad_block; a.loss = loss; a.step = step;
+#ifdef DRGNN_EMU
+    for (int i = 0; i < a.P - 1; ++i) head_reduce_item(a, i);
+    (void)stream_;
+#else
+    hipLaunchKernelGGL(k_head_reduce, dim3((unsigned)((a.P - 1 + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    const int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, void* stream_) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || !step || n < 0) return DRGNN_E_ARG;
+    if (n == 0) return 0;
+    AdamArgs a;
+    a.param = param; a.grad = grad; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.step = step; a.n = n;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
+#ifdef DRGNN_EMU
+    for (int64_t i = 0; i < n; ++i) adam_item(a, i);
+    (void)stream_;
+#else
+    hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

@@ -1,0 +1,245 @@
+// drgnn_head.h -- the dense head of the three nets plus loss, fused forward+backward, and the
+// optimiser update: what the reference trainer runs around the message-passing body for
+// every mini-batch (NeuralNet.py:489-506: model(...) tail, loss, loss.backward(), Adam step).
+//
+//   head   (ginet.py:136-139; sGAT.py:134-135; foutnet.py:121-122)
+//          hid  = dropout(relu(readout W1^T + b1), p)        W1 [H,R]  (R = 64 | 32, H = 128 | 64)
+//          pred = hid W2^T + b2                                W2 [O,H]
+//   loss   MSE on pred.reshape(-1) (regression) or (weighted) cross entropy (classification),
+//          mean reduction                                      (NeuralNet.py:239-263)
+//   update Adam, torch defaults betas (0.9, 0.999), eps 1e-8, no weight decay
+//          (NeuralNet.py:183-184)
+//
+// One workgroup handles a tile of 64 graphs: readout tile and W1 live in LDS (padded rows),
+// the two [64 x H] products run on the f32 MFMA, fc2 / loss are a few hundred FMAs on VALU.
+// Weight-gradient contributions go to a per-workgroup partial slab
+//   [dW1 H*R][db1 H][dW2 O*H][db2 O][loss_sum][weight_sum]
+// which the reducer sums in fixed order (deterministic).
+#pragma once
+#include "drgnn_net.h"
+
+#define DRGNN_HEAD_TILE 64
+#define DRGNN_TASK_REG 0
+#define DRGNN_TASK_CLASS 1
+#define DRGNN_MAX_OUT 16
+
+struct HeadArgs {
+    const float* readout;     // [B, R]
+    const float* y_reg;       // [B]            (regression)
+    const int64_t* y_cls;     // [B] class index (classification)
+    const float* class_w;     // [O] or null
+    const float* w1; const float* b1;   // [H,R], [H]
+    const float* w2; const float* b2;   // [O,H], [O]
+    const int32_t* step;      // device step counter (dropout stream id)
+    float* pred;              // [B, O]
+    float* grad_readout;      // [B, R] or null (inference)
+    float* partials;          // [n_wg][P] or null
+    int B, R, H, O;
+    int task;
+    int train;                // apply dropout, compute gradients
+    float p_drop;
+    uint32_t seed;
+};
+
+HD int64_t head_partial_floats(int R, int H, int O) { return (int64_t)H * R + H + (int64_t)O * H + O + 2; }
+HD int64_t head_lds_words(int R, int H, int O) {
+    return (int64_t)DRGNN_HEAD_TILE * (R + 1) + (int64_t)H * (R + 1) + (int64_t)DRGNN_HEAD_TILE * (H + 1) +
+           H + (int64_t)O * H + O + 4 * DRGNN_HEAD_TILE * DRGNN_MAX_OUT + 64;
+}
+
+// lowbias32-style counter hash -> uniform 32-bit value for (seed, step, element)
+HD uint32_t drgnn_hash(uint32_t seed, uint32_t step, uint32_t idx) {
+    uint32_t h = seed ^ (step * 0x9E3779B9u) ^ (idx * 0x85EBCA6Bu + 0xC2B2AE35u);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+
+DEV void head_block(const HeadArgs& a, int blk, float* lds) {
+    const int R = a.R, H = a.H, O = a.O;
+    const int g0 = blk * DRGNN_HEAD_TILE;
+    const int G = imin(DRGNN_HEAD_TILE, a.B - g0);
+    const int ldx = R + 1, ldh = H + 1;
+    float* xs = lds;                                   // [64][R+1]
+    float* w1p = xs + DRGNN_HEAD_TILE * ldx;           // [H][R+1]
+    float* hid = w1p + (long)H * ldx;                  // [64][H+1]
+    float* b1s = hid + DRGNN_HEAD_TILE * ldh;          // [H]
+    float* w2s = b1s + H;                              // [O][H]
+    float* b2s = w2s + (long)O * H;                    // [O]
+    float* outs = b2s + O;                             // [64][MAX_OUT]   pred tile
+    float* douts = outs + DRGNN_HEAD_TILE * DRGNN_MAX_OUT;   // [64][MAX_OUT]   d loss / d pred
+    float* red = douts + DRGNN_HEAD_TILE * DRGNN_MAX_OUT;    // [64][2] per-graph (loss, weight)
+    const uint32_t step = a.step ? (uint32_t)a.step[0] : 0u;
+
+    FOR_TID(e, DRGNN_HEAD_TILE * R) {
+        const int g = e / R, r = e % R;
+        xs[g * ldx + r] = (g < G) ? a.readout[(long)(g0 + g) * R + r] : 0.0f;
+    }
+    FOR_TID(e, H * R) { w1p[(e / R) * ldx + (e % R)] = a.w1[e]; }
+    FOR_TID(h, H) { b1s[h] = a.b1[h]; }
+    FOR_TID(e, O * H) { w2s[e] = a.w2[e]; }
+    FOR_TID(o, O) { b2s[o] = a.b2[o]; }
+    BARRIER();
+    // hid = X W1^T            B(k=r, j=h) = w1p[h*ldx + r]
+    wg_gemm(DRGNN_HEAD_TILE, H, R, xs, ldx, 1, w1p, 1, ldx, hid, ldh, 1);
+    BARRIER();
+    {
+        const float keep_scale = (a.train && a.p_drop > 0.0f) ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+        const uint32_t thresh = (a.train && a.p_drop > 0.0f)
+                                    ? (uint32_t)((double)a.p_drop * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)a.p_drop * 4294967296.0)
+                                    : 0u;
+        FOR_TID(e, DRGNN_HEAD_TILE * H) {
+            const int g = e / H, h = e % H;
+            float v = hid[g * ldh + h] + b1s[h];
+            v = v > 0.0f ? v : 0.0f;
+            if (thresh) {
+                const uint32_t u = drgnn_hash(a.seed, step, (uint32_t)((g0 + g) * H + h));
+                v = (u >= thresh) ? v * keep_scale : 0.0f;
+            }
+            hid[g * ldh + h] = v;
+        }
+    }
+    BARRIER();
+    FOR_TID(e, DRGNN_HEAD_TILE * O) {
+        const int g = e / O, o = e % O;
+        float acc = b2s[o];
+        for (int h = 0; h < H; ++h) acc = fmaf(hid[g * ldh + h], w2s[o * H + h], acc);
+        outs[g * DRGNN_MAX_OUT + o] = acc;
+        if (g < G) a.pred[(long)(g0 + g) * O + o] = acc;
+    }
+    BARRIER();
+    if (!a.train || a.grad_readout == nullptr) return;
+
+    // ---- loss and d loss / d pred (mean reduction over the WHOLE batch) --------------------
+    FOR_TID(g, DRGNN_HEAD_TILE) {
+        float loss = 0.0f, wsum = 0.0f;
+        if (g < G) {
+            if (a.task == DRGNN_TASK_REG) {
+                // MSELoss()(pred.reshape(-1), y): mean over B*O elements (O == 1 in the reference)
+                const float inv = 1.0f / (float)(a.B * O);
+                for (int o = 0; o < O; ++o) {
+                    const float d = outs[g * DRGNN_MAX_OUT + o] - a.y_reg[g0 + g];
+                    loss += d * d * inv;
+                    douts[g * DRGNN_MAX_OUT + o] = 2.0f * d * inv;
+                }
+                wsum = 1.0f;
+            } else {
+                // CrossEntropyLoss(weight, reduction='mean'): sum_g w[y_g] * nll_g / sum_g w[y_g]
+                float denom = 0.0f;
+                for (int q = 0; q < a.B; ++q) denom += a.class_w ? a.class_w[a.y_cls[q]] : 1.0f;
+                const int yc = (int)a.y_cls[g0 + g];
+                const float wy = a.class_w ? a.class_w[yc] : 1.0f;
+                float mx = outs[g * DRGNN_MAX_OUT];
+                for (int o = 1; o < O; ++o) mx = outs[g * DRGNN_MAX_OUT + o] > mx ? outs[g * DRGNN_MAX_OUT + o] : mx;
+                float se = 0.0f;
+                for (int o = 0; o < O; ++o) se += expf(outs[g * DRGNN_MAX_OUT + o] - mx);
+                const float lse = logf(se) + mx;
+                loss = wy * (lse - outs[g * DRGNN_MAX_OUT + yc]) / denom;
+                for (int o = 0; o < O; ++o) {
+                    const float p = expf(outs[g * DRGNN_MAX_OUT + o] - lse);
+                    douts[g * DRGNN_MAX_OUT + o] = wy * (p - (o == yc ? 1.0f : 0.0f)) / denom;
+                }
+                wsum = wy;
+            }
+        } else {
+            for (int o = 0; o < O; ++o) douts[g * DRGNN_MAX_OUT + o] = 0.0f;
+        }
+        red[2 * g] = loss;
+        red[2 * g + 1] = wsum;
+    }
+    BARRIER();
+    float* part = a.partials + (long)blk * head_partial_floats(R, H, O);
+    float* p_w1 = part;
+    float* p_b1 = p_w1 + (long)H * R;
+    float* p_w2 = p_b1 + H;
+    float* p_b2 = p_w2 + (long)O * H;
+    float* p_loss = p_b2 + O;
+    // dW2[o,h] = sum_g dout[g,o] hid[g,h];  db2;  loss partial
+    FOR_TID(e, O * H) {
+        const int o = e / H, h = e % H;
+        float acc = 0.0f;
+        for (int g = 0; g < DRGNN_HEAD_TILE; ++g) acc = fmaf(douts[g * DRGNN_MAX_OUT + o], hid[g * ldh + h], acc);
+        p_w2[e] = acc;
+    }
+    FOR_TID(o, O) {
+        float acc = 0.0f;
+        for (int g = 0; g < DRGNN_HEAD_TILE; ++g) acc += douts[g * DRGNN_MAX_OUT + o];
+        p_b2[o] = acc;
+    }
+    FOR_TID(i, 1) {
+        float l = 0.0f, w = 0.0f;
+        for (int g = 0; g < DRGNN_HEAD_TILE; ++g) { l += red[2 * g]; w += red[2 * g + 1]; }
+        p_loss[0] = l;
+        p_loss[1] = w;
+    }
+    BARRIER();
+    // d hid (in place): (dout W2) * relu' * dropout mask -- both folded into "hid != 0"
+    {
+        const float keep_scale = (a.p_drop > 0.0f) ? 1.0f / (1.0f - a.p_drop) : 1.0f;
+        FOR_TID(e, DRGNN_HEAD_TILE * H) {
+            const int g = e / H, h = e % H;
+            float acc = 0.0f;
+            for (int o = 0; o < O; ++o) acc = fmaf(douts[g * DRGNN_MAX_OUT + o], w2s[o * H + h], acc);
+            hid[g * ldh + h] = (hid[g * ldh + h] != 0.0f) ? acc * keep_scale : 0.0f;
+        }
+    }
+    BARRIER();
+    // dW1 = dhid^T X   (A(i=h,k=g) = hid[g*ldh + h];  B(k=g,j=r) = xs[g*ldx + r])
+    wg_gemm(H, R, DRGNN_HEAD_TILE, hid, 1, ldh, xs, ldx, 1, p_w1, R, 1);
+    FOR_TID(h, H) {
+        float acc = 0.0f;
+        for (int g = 0; g < DRGNN_HEAD_TILE; ++g) acc += hid[g * ldh + h];
+        p_b1[h] = acc;
+    }
+    // d readout = dhid W1   (B(k=h, j=r) = w1p[h*ldx + r]); rows beyond the batch are skipped
+    wg_gemm(G, R, H, hid, ldh, 1, w1p, ldx, 1, a.grad_readout + (long)g0 * R, R, 1);
+}
+
+// ---- reduction of the head partials + Adam -----------------------------------------------
+struct HeadReduceArgs {
+    const float* partials;    // [n_wg][P]
+    int n_wg, P;              // P = head_partial_floats
+    float* grad;              // contiguous [H*R + H + O*H + O] block of the flat gradient
+    float* loss;              // scalar out
+    int32_t* step;            // incremented once per step by the reducer
+};
+
+DEV void head_reduce_item(const HeadReduceArgs& a, int item) {
+    const int n_grad = a.P - 2;
+    if (item < n_grad) {
+        float acc = 0.0f;
+        for (int w = 0; w < a.n_wg; ++w) acc += a.partials[(long)w * a.P + item];
+        a.grad[item] = acc;
+    } else if (item == n_grad) {
+        float acc = 0.0f;
+        for (int w = 0; w < a.n_wg; ++w) acc += a.partials[(long)w * a.P + n_grad];
+        if (a.loss) a.loss[0] = acc;
+        if (a.step) a.step[0] = a.step[0] + 1;
+    }
+}
+
+struct AdamArgs {
+    float* param; const float* grad; float* exp_avg; float* exp_avg_sq;
+    const int32_t* step;      // already counts this step (>= 1)
+    int64_t n;
+    float lr, beta1, beta2, eps, weight_decay;
+};
+
+// torch.optim.Adam (no amsgrad, maximize=False): identical operation order to the reference
+// implementation (_single_tensor_adam): denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom
+DEV void adam_item(const AdamArgs& a, int64_t i) {
+    if (i >= a.n) return;
+    const float t = (float)a.step[0];
+    float g = a.grad[i];
+    float p = a.param[i];
+    if (a.weight_decay != 0.0f) g = fmaf(a.weight_decay, p, g);
+    const float m = a.exp_avg[i] + (g - a.exp_avg[i]) * (1.0f - a.beta1);          // lerp
+    const float v = a.beta2 * a.exp_avg_sq[i] + (1.0f - a.beta2) * g * g;
+    a.exp_avg[i] = m;
+    a.exp_avg_sq[i] = v;
+    // bias corrections in double, as the Python-side scalars of torch's reference path
+    const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
+    const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
+    const float step_size = (float)((double)a.lr / bc1);
+    const float denom = sqrtf(v) / (float)sqrt(bc2) + a.eps;
+    a.param[i] = p - step_size * (m / denom);
+}

@@ -247,6 +247,12 @@ DEV void stage_weight(float* dst, int ld, const float* src, long sk, long sh, in
 DEV void stage_i32(int* dst, const int32_t* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 DEV void stage_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 
+// sizes for which the register-burst prologue applies (its per-lane element counts are fixed)
+DEV bool net_burst_ok(const float* xg, int F, int N, int E, int C) {
+    return ((((uintptr_t)xg) & 15) == 0) && (F % 4 == 0) && (F * DRGNN_H1 <= DRGNN_NTHREADS) && ((long)N * F <= 16L * DRGNN_NTHREADS) &&
+           (N + 1 <= DRGNN_NTHREADS) && (E <= 2 * DRGNN_NTHREADS) && (C * DRGNN_H1 <= 4 * DRGNN_NTHREADS);
+}
+
 // weights + x tile
 template <int KIND>
 DEV void net_stage_common(const NetArgs& a, const GraphDims& d, int br, NetScratch& s) {
@@ -360,18 +366,64 @@ DEV void net_forward_graph(const NetArgs& a, int g, int br, float* scratch, int 
 
     // ---- one burst of independent loads: everything this graph needs -> LDS ------------
     PHASE_MARK();
-    net_stage_common<KIND>(a, d, br, s);
-    stage_i32(s.rp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
-    stage_i32(s.ix0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
-    stage_i32(s.mp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
-    stage_i32(s.mem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
-    stage_i32(s.rp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
-    stage_i32(s.ix1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
-    stage_i32(s.mp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
-    stage_i32(s.mem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
-    if (KIND == DRGNN_SGAT) {
-        stage_f32(s.ew0, tv.w0 + d.e0, d.E);
-        stage_f32(s.ew1, tv.w1 + d.e0, d.E1);
+    const drgnn_conv_params& c1 = a.net.conv1[br];
+    const drgnn_conv_params& c2 = a.net.conv2[br];
+    const float* xg = a.x + (long)d.n0 * F;
+    const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C);
+    if (burst) {
+        BurstX<4> bx;       burst_load_x(bx, xg, d.N, F);
+        BurstW<1> bw1, bw2, bs1, bs2;
+        burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
+        burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+        Burst<int, 1> brp0, bmp0, bmem0, brp1, bmp1, bmem1;
+        Burst<int, 2> bix0, bix1;
+        burst_load(brp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+        burst_load(bix0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
+        burst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
+        burst_load(bmem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
+        burst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+        burst_load(bix1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
+        burst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
+        burst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+        Burst<float, 1> bb1, bb2;
+        Burst<float, 2> bew0, bew1;
+        if (KIND != DRGNN_GINET) {
+            burst_load_w(bs1, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
+            burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+            burst_load(bb1, c1.bias, DRGNN_H1);
+            burst_load(bb2, c2.bias, DRGNN_H2);
+        }
+        if (KIND == DRGNN_SGAT) {
+            burst_load(bew0, (const float*)(tv.w0 + d.e0), d.E);
+            burst_load(bew1, (const float*)(tv.w1 + d.e0), d.E1);
+        }
+        burst_store_x(bx, s.xs);
+        burst_store_w(bw1, s.wn1, DRGNN_W1LD);
+        burst_store_w(bw2, s.wn2, DRGNN_W2LD);
+        burst_store(brp0, s.rp0); burst_store(bix0, s.ix0);
+        burst_store(bmp0, s.mp0); burst_store(bmem0, s.mem0);
+        burst_store(brp1, s.rp1); burst_store(bix1, s.ix1);
+        burst_store(bmp1, s.mp1); burst_store(bmem1, s.mem1);
+        if (KIND != DRGNN_GINET) {
+            burst_store_w(bs1, s.ws1, DRGNN_W1LD);
+            burst_store_w(bs2, s.ws2, DRGNN_W2LD);
+            burst_store(bb1, s.b1); burst_store(bb2, s.b2);
+        }
+        if (KIND == DRGNN_SGAT) { burst_store(bew0, s.ew0); burst_store(bew1, s.ew1); }
+    } else {
+        net_stage_common<KIND>(a, d, br, s);
+        stage_i32(s.rp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+        stage_i32(s.ix0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
+        stage_i32(s.mp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
+        stage_i32(s.mem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
+        stage_i32(s.rp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+        stage_i32(s.ix1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
+        stage_i32(s.mp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
+        stage_i32(s.mem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+        if (KIND == DRGNN_SGAT) {
+            stage_f32(s.ew0, tv.w0 + d.e0, d.E);
+            stage_f32(s.ew1, tv.w1 + d.e0, d.E1);
+        }
     }
     BARRIER();
 
@@ -471,25 +523,79 @@ DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int
 
     // ---- stage: x tile, weights, transposed graphs, saved activations -------------------
     PHASE_MARK();
-    net_stage_common<KIND>(a, d, br, s);
-    stage_i32(s.rp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
-    stage_i32(s.ix0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
-    stage_i32(s.rp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
-    stage_i32(s.ix1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
-    if (KIND != DRGNN_GINET) {
-        stage_i32(s.dg0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
-        stage_i32(s.dg1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+    const drgnn_conv_params& c1 = a.net.conv1[br];
+    const drgnn_conv_params& c2 = a.net.conv2[br];
+    const float* xg = a.x + (long)d.n0 * F;
+    const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C);
+    if (burst) {
+        BurstX<4> bx;       burst_load_x(bx, xg, d.N, F);
+        BurstW<1> bw1, bw2, bs1, bs2;
+        burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
+        burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+        Burst<int, 1> bcp0, bcp1, bdg0, bdg1;
+        Burst<int, 2> bix0, bix1, bts0, bts1;
+        Burst<int, 4> ba0;
+        Burst<int, 8> ba1;
+        Burst<float, 4> bxp;
+        Burst<float, 1> bdr, bb1, bb2;
+        Burst<float, 2> bew0, bew1;
+        burst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+        burst_load(bix0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+        burst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+        burst_load(bix1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+        burst_load(ba0, (const int*)(a.arg0 + nodeoff * DRGNN_H1), d.C * DRGNN_H1);
+        burst_load(ba1, (const int*)(a.arg1 + nodeoff * DRGNN_H2), d.C1 * DRGNN_H2);
+        burst_load(bxp, (const float*)(a.xp + nodeoff * DRGNN_H1), d.C * DRGNN_H1);
+        burst_load(bdr, dr, DRGNN_H2);
+        if (KIND != DRGNN_GINET) {
+            burst_load_w(bs1, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
+            burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+            burst_load(bdg0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+            burst_load(bdg1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+        }
+        if (KIND == DRGNN_SGAT) {
+            burst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+            burst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+            burst_load(bew0, (const float*)(tv.w0 + d.e0), d.E);
+            burst_load(bew1, (const float*)(tv.w1 + d.e0), d.E1);
+        }
+        burst_store_x(bx, s.xs);
+        burst_store_w(bw1, s.wn1, DRGNN_W1LD);
+        burst_store_w(bw2, s.wn2, DRGNN_W2LD);
+        burst_store(bcp0, s.rp0); burst_store(bix0, s.ix0);
+        burst_store(bcp1, s.rp1); burst_store(bix1, s.ix1);
+        burst_store(ba0, s.a0); burst_store(ba1, s.a1);
+        burst_store(bxp, s.xp); burst_store(bdr, s.misc);
+        if (KIND != DRGNN_GINET) {
+            burst_store_w(bs1, s.ws1, DRGNN_W1LD);
+            burst_store_w(bs2, s.ws2, DRGNN_W2LD);
+            burst_store(bdg0, s.dg0); burst_store(bdg1, s.dg1);
+        }
+        if (KIND == DRGNN_SGAT) {
+            burst_store(bts0, s.ts0); burst_store(bts1, s.ts1);
+            burst_store(bew0, s.ew0); burst_store(bew1, s.ew1);
+        }
+    } else {
+        net_stage_common<KIND>(a, d, br, s);
+        stage_i32(s.rp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+        stage_i32(s.ix0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+        stage_i32(s.rp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+        stage_i32(s.ix1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+        if (KIND != DRGNN_GINET) {
+            stage_i32(s.dg0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+            stage_i32(s.dg1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+        }
+        if (KIND == DRGNN_SGAT) {
+            stage_i32(s.ts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+            stage_i32(s.ts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+            stage_f32(s.ew0, tv.w0 + d.e0, d.E);
+            stage_f32(s.ew1, tv.w1 + d.e0, d.E1);
+        }
+        stage_i32(s.a0, a.arg0 + nodeoff * DRGNN_H1, d.C * DRGNN_H1);
+        stage_i32(s.a1, a.arg1 + nodeoff * DRGNN_H2, d.C1 * DRGNN_H2);
+        stage_f32(s.xp, a.xp + nodeoff * DRGNN_H1, d.C * DRGNN_H1);
+        stage_f32(s.misc, dr, DRGNN_H2);
     }
-    if (KIND == DRGNN_SGAT) {
-        stage_i32(s.ts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
-        stage_i32(s.ts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
-        stage_f32(s.ew0, tv.w0 + d.e0, d.E);
-        stage_f32(s.ew1, tv.w1 + d.e0, d.E1);
-    }
-    stage_i32(s.a0, a.arg0 + nodeoff * DRGNN_H1, d.C * DRGNN_H1);
-    stage_i32(s.a1, a.arg1 + nodeoff * DRGNN_H2, d.C1 * DRGNN_H2);
-    stage_f32(s.xp, a.xp + nodeoff * DRGNN_H1, d.C * DRGNN_H1);
-    stage_f32(s.misc, dr, DRGNN_H2);
     FOR_TID(item, d.C * DRGNN_H2) { s.z2[item] = 0.0f; }
     FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }
     BARRIER();

@@ -121,3 +121,85 @@ DEV int wg_exscan(int* a, int n, int* part) {
     return total;
 }
 #endif
+
+// ---------------------------------------------------------------------------------
+// Burst staging (global -> registers -> LDS).  A kernel prologue that copies a dozen small
+// arrays with one loop each pays one full memory latency PER ARRAY (the store of loop k
+// waits for the load of loop k before loop k+1 may issue).  Instead every array is first
+// loaded into registers (burst_load: J elements per lane, all loads in flight together) and
+// only then written to LDS (burst_store).  Requires n <= J * DRGNN_NTHREADS.
+// ---------------------------------------------------------------------------------
+#ifdef DRGNN_EMU
+template <class T, int J> struct Burst { const T* src; int n; };
+template <class T, int J> DEV void burst_load(Burst<T, J>& b, const T* src, int n) { b.src = src; b.n = src ? n : 0; }
+template <class T, int J> DEV void burst_store(const Burst<T, J>& b, T* dst) { for (int i = 0; i < b.n; ++i) dst[i] = b.src[i]; }
+template <int J> struct BurstW { const float* src; long sk, sh; int K, H; };
+template <int J> DEV void burst_load_w(BurstW<J>& b, const float* src, long sk, long sh, int K, int H) {
+    b.src = src; b.sk = sk; b.sh = sh; b.K = src ? K : 0; b.H = H;
+}
+template <int J> DEV void burst_store_w(const BurstW<J>& b, float* dst, int ld) {
+    for (int k = 0; k < b.K; ++k) for (int h = 0; h < b.H; ++h) dst[k * ld + h] = b.src[k * b.sk + h * b.sh];
+}
+template <int J> struct BurstX { const float* src; int rows, F; };
+template <int J> DEV void burst_load_x(BurstX<J>& b, const float* src, int rows, int F) { b.src = src; b.rows = rows; b.F = F; }
+template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
+    for (int i = 0; i < b.rows; ++i) for (int f = 0; f < b.F; ++f) dst[i * (b.F + 1) + f] = b.src[i * b.F + f];
+}
+#else
+template <class T, int J> struct Burst { T v[J]; int n; };
+template <class T, int J> DEV void burst_load(Burst<T, J>& b, const T* src, int n) {
+    b.n = src ? n : 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int i = threadIdx.x + j * DRGNN_NTHREADS;
+        b.v[j] = (i < b.n) ? src[i] : T(0);
+    }
+}
+template <class T, int J> DEV void burst_store(const Burst<T, J>& b, T* dst) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int i = threadIdx.x + j * DRGNN_NTHREADS;
+        if (i < b.n) dst[i] = b.v[j];
+    }
+}
+// strided [K,H] weight matrix -> dense padded rows dst[k*ld + h]
+template <int J> struct BurstW { float v[J]; int n, H; };
+template <int J> DEV void burst_load_w(BurstW<J>& b, const float* src, long sk, long sh, int K, int H) {
+    b.n = src ? K * H : 0; b.H = H;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int e = threadIdx.x + j * DRGNN_NTHREADS;
+        b.v[j] = (e < b.n) ? src[(long)(e / H) * sk + (long)(e % H) * sh] : 0.0f;
+    }
+}
+template <int J> DEV void burst_store_w(const BurstW<J>& b, float* dst, int ld) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int e = threadIdx.x + j * DRGNN_NTHREADS;
+        if (e < b.n) dst[(e / b.H) * ld + (e % b.H)] = b.v[j];
+    }
+}
+// x tile [rows, F] (F % 4 == 0, 16-byte aligned) -> padded rows dst[i*(F+1) + f], float4 loads
+typedef float drgnn_f4 __attribute__((ext_vector_type(4)));
+template <int J> struct BurstX { drgnn_f4 v[J]; int n4, F; };
+template <int J> DEV void burst_load_x(BurstX<J>& b, const float* src, int rows, int F) {
+    b.n4 = rows * F / 4; b.F = F;
+    const drgnn_f4* s4 = (const drgnn_f4*)src;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int q = threadIdx.x + j * DRGNN_NTHREADS;
+        b.v[j] = (q < b.n4) ? s4[q] : drgnn_f4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int q = threadIdx.x + j * DRGNN_NTHREADS;
+        if (q < b.n4) {
+            const int e = q * 4;
+            float* d = dst + (e / b.F) * (b.F + 1) + (e % b.F);
+            d[0] = b.v[j][0]; d[1] = b.v[j][1]; d[2] = b.v[j][2]; d[3] = b.v[j][3];
+        }
+    }
+}
+#endif

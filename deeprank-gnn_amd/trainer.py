@@ -1,0 +1,195 @@
+"""Native training step: the whole per-mini-batch work of the reference trainer on the device
+path, five kernel launches and no autograd graph.
+
+Counterpart of the inner loop body of ``NeuralNet._epoch`` (reference NeuralNet.py:489-506)
+
+    optimizer.zero_grad(); pred = model(batch); loss = loss_fn(pred, y); loss.backward();
+    optimizer.step()
+
+with the reference's choices: ``MSELoss`` for regression / ``CrossEntropyLoss(weight)`` for
+classification (NeuralNet.py:239-263) and ``torch.optim.Adam(lr)`` (NeuralNet.py:183-184).
+
+    topology  ->  body forward  ->  head (fc1/relu/dropout/fc2 + loss + its backward)
+              ->  body backward ->  gradient reduction  [-> all-reduce]  ->  Adam
+
+The model's parameters become views into one flat fp32 buffer (``state_dict`` / checkpoints
+keep working), their ``.grad`` views into a second one, so the data-parallel exchange is one
+all-reduce of one buffer (deeprank_gnn_amd.parallel) and Adam is one launch.
+Everything is enqueued on torch's current stream and is hipGraph-capturable.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .functional import H1, H2, _describe, _fill_grads, _split
+from .topology import Topology
+
+__all__ = ["FusedTrainer"]
+
+
+def _net_layout(net):
+    """(kind, n_branch, [conv modules in kernel order]) of one of the three reference nets."""
+    name = type(net).__name__
+    if name == "GINet":
+        return _lib.GINET, 2, [net.conv1, net.conv2, net.conv1_ext, net.conv2_ext]
+    if name == "sGAT":
+        return _lib.SGAT, 1, [net.conv1, net.conv2]
+    if name == "FoutNet":
+        return _lib.FOUT, 1, [net.conv1, net.conv2]
+    raise TypeError("FusedTrainer drives GINet / sGAT / FoutNet, not %s" % name)
+
+
+class FusedTrainer(object):
+    def __init__(self, net, lr=0.01, task="reg", class_weights=None, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, seed=0, api=None):
+        self.net = net
+        self.api = api or _lib.get()
+        self.kind, self.n_branch, self.convs = _net_layout(net)
+        self.task = _lib.TASK_REG if task == "reg" else _lib.TASK_CLASS
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        self.seed = int(seed) & 0xFFFFFFFF
+        params = list(net.parameters())
+        dev = params[0].device
+        if self.api is _lib._API:
+            _lib.require_device(*params)
+        total = sum(p.numel() for p in params)
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.offset = {}
+        off = 0
+        with torch.no_grad():
+            for name, p in net.named_parameters():
+                n = p.numel()
+                self.flat_p[off:off + n].copy_(p.detach().reshape(-1))
+                p.data = self.flat_p[off:off + n].view(p.shape)
+                p.grad = self.flat_g[off:off + n].view(p.shape)
+                self.offset[name] = off
+                off += n
+        head = ["fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias"]
+        o0 = self.offset[head[0]]
+        expect = o0
+        for name in head:      # the head reducer writes one contiguous block
+            assert self.offset[name] == expect, "unexpected parameter order for the FC head"
+            expect += dict(net.named_parameters())[name].numel()
+        self.head_grad_offset = o0
+        self.R, self.H, self.O = net.fc1.in_features, net.fc1.out_features, net.fc2.out_features
+        self.class_w = None
+        if class_weights is not None:
+            self.class_w = torch.as_tensor(class_weights, dtype=torch.float32, device=dev).contiguous()
+        self.live = tuple(p for c in self.convs for p in c.live_parameters())
+        self.live_grads = tuple(p.grad for p in self.live)
+
+    # ---------------------------------------------------------------------------
+    def _head_desc(self, train):
+        hd = _lib.HeadDesc()
+        hd.R, hd.H, hd.O, hd.task, hd.train = self.R, self.H, self.O, self.task, int(train)
+        hd.p_drop = float(getattr(self.net, "dropout", 0.0)) if train else 0.0
+        hd.seed = self.seed
+        n = self.net
+        hd.w1, hd.b1 = n.fc1.weight.data_ptr(), n.fc1.bias.data_ptr()
+        hd.w2, hd.b2 = n.fc2.weight.data_ptr(), n.fc2.bias.data_ptr()
+        hd.class_w = None if self.class_w is None else self.class_w.data_ptr()
+        return hd
+
+    def _body_forward(self, batch, topo, stream):
+        api = self.api
+        x = batch.x.contiguous()
+        n_nodes, n_feat = x.shape
+        dev = x.device
+        B = topo.n_graphs
+        nb = self.n_branch
+        xp = torch.empty((nb, n_nodes, H1), dtype=torch.float32, device=dev)
+        arg0 = torch.empty((nb, n_nodes, H1), dtype=torch.int32, device=dev)
+        arg1 = torch.empty((nb, n_nodes, H2), dtype=torch.int32, device=dev)
+        readout = torch.empty((B, H2 * nb), dtype=torch.float32, device=dev)
+        scratch = None
+        need = max(api.net_lds_bytes(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, b)
+                   for b in (False, True))
+        if topo.max_nodes == 0 or need > 160 * 1024:
+            scratch = torch.empty(api.net_scratch_elems(self.kind, n_feat, n_nodes, topo.n_edges, B),
+                                  dtype=torch.float32, device=dev)
+        desc = _describe(self.kind, n_feat, self.live, nb)
+        api.net_forward(desc, x, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes,
+                        topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream)
+        return x, desc, xp, arg0, arg1, readout, scratch
+
+    def compute_gradients(self, batch, topo=None):
+        """topology -> body forward -> head+loss (+ its backward) -> body backward -> reduction.
+        Leaves d(mean loss over THIS batch)/d(params) in ``flat_g`` (= every ``p.grad``), the
+        loss in ``self.loss``, predictions in ``self.last_pred``; increments the step counter."""
+        api = self.api
+        if topo is None:
+            topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
+        stream = _lib.current_stream(batch.x)
+        x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream)
+        B = topo.n_graphs
+        dev = x.device
+        n_nodes, n_feat = x.shape
+        pred = torch.empty((B, self.O), dtype=torch.float32, device=dev)
+        grad_readout = torch.empty_like(readout)
+        n_wg = (B + 63) // 64
+        hp = torch.empty((max(n_wg, 1), api.head_partial_elems(self.R, self.H, self.O)),
+                         dtype=torch.float32, device=dev)
+        y = batch.y
+        y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
+        api.head_step(self._head_desc(True), readout, y, B, self.step, pred, grad_readout, hp, stream)
+        partials = torch.empty((max(B * self.n_branch, 1), api.net_partial_elems(self.kind, n_feat)),
+                               dtype=torch.float32, device=dev)
+        api.net_backward(desc, x, grad_readout, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B,
+                         topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1, None, partials,
+                         scratch, stream)
+        g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+        g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+        for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, self.n_branch)):
+            _fill_grads(g1[b], self.kind, l1, n_feat, H1)
+            _fill_grads(g2[b], self.kind, l2, H1, H2)
+        api.net_reduce_grads(desc, partials, n_nodes, B, g1, g2, None, stream)
+        api.head_reduce(hp, B, self.R, self.H, self.O,
+                        self.flat_g.data_ptr() + 4 * self.head_grad_offset, self.loss, self.step, stream)
+        self.last_pred = pred
+        self.last_batch_size = B
+        return self.loss
+
+    def all_reduce_gradients(self, n_local=None, n_global=None, group=None):
+        """Data parallel exchange: ONE all-reduce of the flat gradient buffer (RCCL over xGMI with
+        the nccl backend).  Each rank holds the gradient of the mean loss over its own shard, so
+        it is weighted by n_local / n_global (equal shards: 1 / world)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(group)
+        if world == 1:
+            return
+        if n_global:
+            self.flat_g.mul_(float(n_local if n_local is not None else self.last_batch_size) / float(n_global))
+        else:
+            self.flat_g.mul_(1.0 / world)
+        dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+
+    def apply_update(self):
+        """Adam on the flat buffers (one launch)."""
+        self.api.adam_step(self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step, self.lr,
+                           self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                           _lib.current_stream(self.flat_p))
+
+    def train_step(self, batch, topo=None, n_global=None, group=None):
+        """One optimisation step on ``batch``; returns the (device) loss of this rank's shard."""
+        loss = self.compute_gradients(batch, topo)
+        self.all_reduce_gradients(n_global=n_global, group=group)
+        self.apply_update()
+        return loss
+
+    @torch.no_grad()
+    def predict(self, batch, topo=None):
+        """Inference (dropout off), fully on the native path; returns pred [B, O]."""
+        api = self.api
+        if topo is None:
+            topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
+        stream = _lib.current_stream(batch.x)
+        x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream)
+        pred = torch.empty((topo.n_graphs, self.O), dtype=torch.float32, device=x.device)
+        api.head_step(self._head_desc(False), readout, None, topo.n_graphs, self.step, pred, None, None, stream)
+        return pred

@@ -214,6 +214,45 @@ int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int
                            int64_t n_graphs, drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2,
                            float* grad_x, void* stream);
 
+/* ---- dense head, loss and optimiser (the rest of one training step) -----------------------
+ * What the reference trainer runs around the message-passing body for every mini-batch
+ * (NeuralNet.py:489-506): the FC head of the nets (ginet.py:136-139, sGAT.py:134-135,
+ * foutnet.py:121-122: fc1 -> relu -> dropout(p) -> fc2), MSELoss / (weighted)
+ * CrossEntropyLoss with mean reduction (NeuralNet.py:239-263), their backward, and the Adam
+ * update (NeuralNet.py:183-184, torch defaults).  torch.nn.Linear layouts: w1 [H,R], b1 [H],
+ * w2 [O,H], b2 [O].
+ */
+#define DRGNN_TASK_REG   0
+#define DRGNN_TASK_CLASS 1
+typedef struct drgnn_head_desc {
+    int32_t R, H, O;          /* readout width, hidden width, outputs (O <= 16)              */
+    int32_t task;             /* DRGNN_TASK_REG: target float [B]; _CLASS: target int64 [B]   */
+    int32_t train;            /* 1: dropout + loss + gradients; 0: predictions only           */
+    float   p_drop;           /* dropout probability (GINet 0.4, others 0)                    */
+    uint32_t seed;            /* dropout stream seed (mixed with the device step counter)     */
+    int32_t reserved;
+    const float* w1; const float* b1; const float* w2; const float* b2;
+    const float* class_w;     /* [O] class weights or NULL                                    */
+} drgnn_head_desc;
+
+/* One workgroup per tile of 64 graphs.  Writes pred [B,O]; when train: grad_readout [B,R]
+ * (d loss / d readout for the mean loss over the B graphs) and one partial slab per workgroup
+ * ([dW1 H*R][db1 H][dW2 O*H][db2 O][loss][weight], drgnn_head_partial_elems() floats).
+ * `step` (device int32) selects the dropout stream; it is NOT modified here. */
+int64_t drgnn_head_partial_elems(int32_t R, int32_t H, int32_t O);
+int drgnn_head_step(const drgnn_head_desc* head, const float* readout, const void* target,
+                    int64_t n_graphs, const int32_t* step, float* pred, float* grad_readout,
+                    float* partials, void* stream);
+/* Fixed-order sum of the head partials into grad_block = [fc1.weight | fc1.bias | fc2.weight |
+ * fc2.bias] (contiguous), the batch loss into *loss, and ++*step (the optimiser step count). */
+int drgnn_head_reduce(const float* partials, int64_t n_graphs, int32_t R, int32_t H, int32_t O,
+                      float* grad_block, float* loss, int32_t* step, void* stream);
+/* torch.optim.Adam single-tensor semantics on flat fp32 buffers; *step must already count
+ * this update (>= 1). */
+int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                    const int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, void* stream);
+
 int drgnn_abi_version(void);
 
 #ifdef __cplusplus

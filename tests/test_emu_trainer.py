@@ -1,0 +1,89 @@
+"""Native training step (head + loss + Adam kernels, emulated) vs the torch reference
+recipe (autograd + torch.nn losses + torch.optim.Adam) on the same model.  CPU only."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import fixture_batch, syn4_batch
+from emu_api import emu
+from deeprank_gnn_amd.topology import Topology
+from deeprank_gnn_amd.trainer import FusedTrainer
+from deeprank_gnn_amd.ginet import GINet
+from deeprank_gnn_amd.sGAT import sGAT
+from deeprank_gnn_amd.foutnet import FoutNet
+from deeprank_gnn_amd import _lib
+
+
+@pytest.mark.parametrize("Net,task", [(GINet, "reg"), (sGAT, "reg"), (FoutNet, "reg"), (GINet, "class")])
+def test_three_steps_match_torch_adam(Net, task):
+    torch.manual_seed(11)
+    batch = syn4_batch()
+    n_out = 1 if task == "reg" else 3
+    ref = Net(12, n_out, 1)
+    if hasattr(ref, "dropout"):
+        ref.dropout = 0.0
+    net = copy.deepcopy(ref)
+    cw = None
+    if task == "class":
+        batch.y = torch.tensor([0, 2, 1, 2])
+        cw = torch.tensor([0.2, 0.5, 0.3])
+    opt = torch.optim.Adam(ref.parameters(), lr=0.01)
+    loss_fn = torch.nn.MSELoss() if task == "reg" else torch.nn.CrossEntropyLoss(weight=cw, reduction="mean")
+    tr = FusedTrainer(net, lr=0.01, task=task, class_weights=cw, api=emu())
+    for it in range(3):
+        opt.zero_grad()
+        topo = Topology.from_batch(batch, api=emu())
+        out = ref(batch, topo=topo)
+        loss = loss_fn(out.reshape(-1), batch.y) if task == "reg" else loss_fn(out, batch.y)
+        loss.backward()
+        opt.step()
+        got = tr.train_step(batch)
+        np.testing.assert_allclose(float(got), float(loss), rtol=2e-5)
+        np.testing.assert_allclose(tr.last_pred.numpy(), out.detach().numpy(), rtol=1e-4, atol=1e-5)
+        for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            np.testing.assert_allclose(p.grad.numpy(), q.grad.numpy(), rtol=1e-4,
+                                       atol=1e-5 * max(1.0, float(q.grad.abs().max())), err_msg="%s grad step %d" % (name, it))
+            np.testing.assert_allclose(p.detach().numpy(), q.detach().numpy(), rtol=1e-5, atol=2e-6,
+                                       err_msg="%s step %d" % (name, it))
+    assert int(tr.step) == 3
+    # state_dict still works and predict() == eval forward of the torch-head model
+    ref.eval()
+    np.testing.assert_allclose(tr.predict(batch).numpy(),
+                               ref(batch, topo=Topology.from_batch(batch, api=emu())).detach().numpy(),
+                               rtol=1e-4, atol=1e-5)
+    assert set(net.state_dict()) == set(ref.state_dict())
+
+
+def test_dropout_statistics_and_reproducibility():
+    """p = 0.4 (GINet default): kept fraction ~0.6, kept activations scaled by 1/0.6,
+    the same (seed, step) reproduces the same mask, a new step draws a new one."""
+    api = emu()
+    B, R, H, O = 64, 64, 128, 1
+    g = torch.Generator().manual_seed(0)
+    readout = torch.rand(B, R, generator=g) + 0.5
+    w1 = torch.rand(H, R, generator=g) * 0.1
+    b1 = torch.zeros(H)
+    w2 = torch.ones(O, H)
+    b2 = torch.zeros(O)
+    y = torch.zeros(B)
+
+    def run(step_val, p):
+        hd = _lib.HeadDesc()
+        hd.R, hd.H, hd.O, hd.task, hd.train, hd.p_drop, hd.seed = R, H, O, 0, 1, p, 1234
+        hd.w1, hd.b1, hd.w2, hd.b2, hd.class_w = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), None
+        step = torch.tensor([step_val], dtype=torch.int32)
+        pred = torch.empty(B, O)
+        gr = torch.empty(B, R)
+        hp = torch.empty(1, api.head_partial_elems(R, H, O))
+        api.head_step(hd, readout, y, B, step, pred, gr, hp, None)
+        return pred
+
+    full = run(0, 0.0)
+    a, a2, b = run(5, 0.4), run(5, 0.4), run(6, 0.4)
+    assert torch.equal(a, a2) and not torch.equal(a, b)
+    # E[dropout(h)] = h: the sum over 128 hidden units stays within a few percent
+    ratio = (a / full).mean().item()
+    assert 0.95 < ratio < 1.05, ratio
