@@ -90,14 +90,24 @@ def main():
         trainer = FusedTrainer(net, lr=1e-3, task="reg", seed=1234 + rank)
         loss_out = trainer.loss
 
-        def fwd_bwd():
-            trainer.compute_gradients(batch)
+        if world == 1:
+            def fwd_bwd():
+                trainer.train_step(batch)          # 5 launches incl. the fused reduce+Adam
 
-        def all_reduce():
-            trainer.all_reduce_gradients()
+            def all_reduce():
+                pass
 
-        def reduce_and_step():
-            trainer.apply_update()
+            def reduce_and_step():
+                pass
+        else:
+            def fwd_bwd():
+                trainer.compute_gradients(batch)
+
+            def all_reduce():
+                trainer.all_reduce_gradients()
+
+            def reduce_and_step():
+                trainer.apply_update()
     else:
         opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=capture)
         bucket = FlatGradBucket(net.parameters())

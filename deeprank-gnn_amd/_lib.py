@@ -20,7 +20,7 @@ MAX_BRANCH = 2
 TI = {name: i for i, name in enumerate([
     "NPTR", "EPTR", "ROWPTR0", "COL0", "EID0", "COLPTR0", "ROWIDX0", "TSLOT0", "CL0", "NC0",
     "MPTR0", "MEM0", "ROWPTR1", "COL1", "NE1", "COLPTR1", "ROWIDX1", "TSLOT1", "CL1", "NC1",
-    "MPTR1", "MEM1", "CPTR0", "E1PTR", "CPTR1", "ERR"])}
+    "MPTR1", "MEM1", "CPTR0", "E1PTR", "CPTR1", "ERR", "GSTAT"])}
 TI_COUNT = len(TI)
 TF = {"W0": 0, "W1": 1}
 TF_COUNT = 2
@@ -100,11 +100,17 @@ class Api(object):
         lib.drgnn_net_forward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 3 + [_c_i64] * 3 +
                                           [_c_i32] * 3 + [_vp] * 6)
         lib.drgnn_net_backward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 4 + [_c_i64] * 3 +
-                                           [_c_i32] * 3 + [_vp] * 3 + [_vp] * 4)
+                                           [_c_i32] * 3 + [_vp] * 3 + [_vp] * 5)
+        lib.drgnn_train_update.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] +
+                                           [ctypes.POINTER(ConvGrads)] * 2 + [_vp] + [_c_i32] * 3 +
+                                           [_c_i64] + [_vp] * 4 + [_c_i64] + [_vp] * 2 +
+                                           [ctypes.c_float] * 4 + [_vp])
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
                                                [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
         lib.drgnn_head_partial_elems.argtypes = [_c_i32] * 3
         lib.drgnn_head_partial_elems.restype = _c_i64
+        lib.drgnn_head_num_slabs.argtypes = [_c_i64]
+        lib.drgnn_head_num_slabs.restype = _c_i64
         lib.drgnn_head_step.argtypes = [ctypes.POINTER(HeadDesc), _vp, _vp, _c_i64] + [_vp] * 5
         lib.drgnn_head_reduce.argtypes = [_vp, _c_i64, _c_i32, _c_i32, _c_i32] + [_vp] * 4
         lib.drgnn_adam_step.argtypes = [_vp] * 5 + [_c_i64] + [ctypes.c_float] * 5 + [_vp]
@@ -161,11 +167,19 @@ class Api(object):
             "drgnn_net_forward")
 
     def net_backward(self, desc, x, grad_readout, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
-                     max_nodes, max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream):
+                     max_nodes, max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream,
+                     step_inc=None):
         _check(self.lib.drgnn_net_backward(
             ctypes.byref(desc), _ptr(x), _ptr(grad_readout), _ptr(ws_i32), _ptr(ws_f32), n_nodes,
             n_edges, n_graphs, max_nodes, max_edges, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1),
-            _ptr(grad_x), _ptr(partials), _ptr(scratch), stream), "drgnn_net_backward")
+            _ptr(grad_x), _ptr(partials), _ptr(scratch), _ptr(step_inc), stream), "drgnn_net_backward")
+
+    def train_update(self, desc, conv_partials, n_graphs, g1, g2, head_partials, R, H, O, head_offset,
+                     flat_p, flat_g, exp_avg, exp_avg_sq, step, loss, lr, beta1, beta2, eps, stream):
+        _check(self.lib.drgnn_train_update(
+            ctypes.byref(desc), _ptr(conv_partials), n_graphs, g1, g2, _ptr(head_partials), R, H, O,
+            head_offset, _ptr(flat_p), _ptr(flat_g), _ptr(exp_avg), _ptr(exp_avg_sq), flat_p.numel(),
+            _ptr(step), _ptr(loss), lr, beta1, beta2, eps, stream), "drgnn_train_update")
 
     def net_reduce_grads(self, desc, partials, n_nodes, n_graphs, g1, g2, grad_x, stream):
         _check(self.lib.drgnn_net_reduce_grads(ctypes.byref(desc), _ptr(partials), n_nodes, n_graphs,
@@ -175,6 +189,9 @@ class Api(object):
     # -- head / loss / optimiser ------------------------------------------------
     def head_partial_elems(self, R, H, O):
         return int(self.lib.drgnn_head_partial_elems(R, H, O))
+
+    def head_num_slabs(self, n_graphs):
+        return int(self.lib.drgnn_head_num_slabs(n_graphs))
 
     def head_step(self, desc, readout, target, n_graphs, step, pred, grad_readout, partials, stream):
         _check(self.lib.drgnn_head_step(ctypes.byref(desc), _ptr(readout), _ptr(target), n_graphs,

@@ -6,8 +6,8 @@
 //        every "launch" becomes a loop over workgroups on host pointers)
 #include "drgnn_head.h"
 
-#ifdef DRGNN_EMU
 #include <vector>
+#ifdef DRGNN_EMU
 #define DRGNN_LDS_LIMIT (160 * 1024)
 #else
 #define DRGNN_LDS_LIMIT (160 * 1024)
@@ -65,6 +65,8 @@ DEV void ptr_item(const PtrArgs& a, int64_t i) {
 struct TopoLaunch {
     TopoView tv;
     TopoArgs args;
+    const int32_t* user_nptr;   // caller-supplied per-graph offsets (null: k_ptrs filled the workspace)
+    const int32_t* user_eptr;
     int32_t* gscratch;     // global scratch (when not in LDS)
     int capN, capE;        // LDS capacities (0 = use global scratch)
     int level1_only;       // second pass: only depth-1 clusters, c1 offsets from NC0
@@ -75,8 +77,21 @@ struct TopoLaunch {
 template <bool LDS>
 DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
     TopoScratch s;
-    const int n0 = L.tv.p[DRGNN_TI_NPTR][g], N = L.tv.p[DRGNN_TI_NPTR][g + 1] - n0;
-    const int e0 = L.tv.p[DRGNN_TI_EPTR][g], E = L.tv.p[DRGNN_TI_EPTR][g + 1] - e0;
+    const int32_t* NP = L.user_nptr ? L.user_nptr : L.tv.p[DRGNN_TI_NPTR];
+    const int32_t* EP = L.user_eptr ? L.user_eptr : L.tv.p[DRGNN_TI_EPTR];
+    const int n0 = NP[g], n1 = NP[g + 1], N = n1 - n0;
+    const int e0 = EP[g], e1 = EP[g + 1], E = e1 - e0;
+    if (!L.level1_only) {
+        FOR_TID(i, 1) {
+            L.tv.p[DRGNN_TI_GSTAT][g] = 0;
+            if (L.user_nptr) {       // publish the offsets for the kernels that follow
+                L.tv.p[DRGNN_TI_NPTR][g] = n0; L.tv.p[DRGNN_TI_NPTR][g + 1] = n1;
+                L.tv.p[DRGNN_TI_EPTR][g] = e0; L.tv.p[DRGNN_TI_EPTR][g + 1] = e1;
+                if (g == 0) L.tv.p[DRGNN_TI_ERR][0] = 0;
+            }
+        }
+        BARRIER();
+    }
     if (LDS) {
         const int capT = imax(L.capN, L.capE) + 1;
         s = topo_carve(lds, L.capN, L.capE, capT, L.capN + L.capE + 2);
@@ -89,7 +104,7 @@ DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
         s = topo_carve(L.gscratch + topo_gscratch_base(n0, e0, g), N, E, N + E + 1, N + E + 2);
     }
     if (!L.level1_only) {
-        topo_graph(L.tv, L.args, g, s);
+        topo_graph(L.tv, L.args, g, n0, n1, e0, e1, s);
     } else {
         // offset of this graph's ids inside cluster1 = number of depth-0 clusters before it
         FOR_TID(i, 1) { s.part[0] = 0; }
@@ -106,7 +121,7 @@ DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
         int len = C0;
         if (g == L.args.n_graphs - 1 && (int64_t)begin + C0 != L.args.len_cluster1) len = -1;
         if ((int64_t)begin + C0 > L.args.len_cluster1) len = -1;
-        topo_graph_level1(L.tv, L.args, g, begin, len, s);
+        topo_graph_level1(L.tv, L.args, g, n0, begin, len, s);
     }
 }
 
@@ -133,27 +148,31 @@ struct ReduceArgs {
     float* grad_x; int64_t n_nodes;    // [n_branch][Ntot][F] -> summed into branch 0
 };
 
-// scatter one reduced partial element into the model's own (strided) gradient tensor
-DEV void reduce_write(const ReduceArgs& a, int br, int p, float acc) {
+// where one reduced partial element lives inside the model's own (strided) gradient tensor
+DEV float* reduce_dst(const ReduceArgs& a, int br, int p) {
     const int F = a.n_feat;
     const int o_w1s = F * DRGNN_H1, o_b1 = 2 * F * DRGNN_H1, o_w2n = o_b1 + DRGNN_H1;
     const int o_w2s = o_w2n + DRGNN_H1 * DRGNN_H2, o_b2 = o_w2s + DRGNN_H1 * DRGNN_H2;
-    if (p < o_w1s) {
-        if (a.g1[br].w_nbr) a.g1[br].w_nbr[(int64_t)(p / DRGNN_H1) * a.lay1[br].nbr_sk + (int64_t)(p % DRGNN_H1) * a.lay1[br].nbr_sh] = acc;
-    } else if (p < o_b1) {
+    if (p < o_w1s)
+        return a.g1[br].w_nbr ? a.g1[br].w_nbr + (int64_t)(p / DRGNN_H1) * a.lay1[br].nbr_sk + (int64_t)(p % DRGNN_H1) * a.lay1[br].nbr_sh : nullptr;
+    if (p < o_b1) {
         const int q = p - o_w1s;
-        if (a.g1[br].w_self) a.g1[br].w_self[(int64_t)(q / DRGNN_H1) * a.lay1[br].self_sk + (int64_t)(q % DRGNN_H1) * a.lay1[br].self_sh] = acc;
-    } else if (p < o_w2n) {
-        if (a.g1[br].bias) a.g1[br].bias[p - o_b1] = acc;
-    } else if (p < o_w2s) {
-        const int q = p - o_w2n;
-        if (a.g2[br].w_nbr) a.g2[br].w_nbr[(int64_t)(q / DRGNN_H2) * a.lay2[br].nbr_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].nbr_sh] = acc;
-    } else if (p < o_b2) {
-        const int q = p - o_w2s;
-        if (a.g2[br].w_self) a.g2[br].w_self[(int64_t)(q / DRGNN_H2) * a.lay2[br].self_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].self_sh] = acc;
-    } else {
-        if (a.g2[br].bias) a.g2[br].bias[p - o_b2] = acc;
+        return a.g1[br].w_self ? a.g1[br].w_self + (int64_t)(q / DRGNN_H1) * a.lay1[br].self_sk + (int64_t)(q % DRGNN_H1) * a.lay1[br].self_sh : nullptr;
     }
+    if (p < o_w2n) return a.g1[br].bias ? a.g1[br].bias + (p - o_b1) : nullptr;
+    if (p < o_w2s) {
+        const int q = p - o_w2n;
+        return a.g2[br].w_nbr ? a.g2[br].w_nbr + (int64_t)(q / DRGNN_H2) * a.lay2[br].nbr_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].nbr_sh : nullptr;
+    }
+    if (p < o_b2) {
+        const int q = p - o_w2s;
+        return a.g2[br].w_self ? a.g2[br].w_self + (int64_t)(q / DRGNN_H2) * a.lay2[br].self_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].self_sh : nullptr;
+    }
+    return a.g2[br].bias ? a.g2[br].bias + (p - o_b2) : nullptr;
+}
+DEV void reduce_write(const ReduceArgs& a, int br, int p, float acc) {
+    float* d = reduce_dst(a, br, p);
+    if (d) *d = acc;
 }
 
 // is this partial slot ever written by the backward kernel?  (GINet has no self / bias terms)
@@ -225,6 +244,32 @@ DEV void net_block(const NetLaunch& L, int blk, float* lds) {
     else net_forward_graph<KIND>(L.a, g, br, scratch, capN, capE, capC);
 }
 
+// ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
+struct UpdateArgs {
+    ReduceArgs r;
+    HeadReduceArgs h;       // h.grad = flat gradient block of the FC head; h.step unused here
+    AdamArgs ad;            // flat buffers; ad.grad = base of the flat gradient
+    int conv_blocks;        // blocks [0, conv_blocks) reduce conv partials, the rest the head's
+};
+
+DEV void update_store(const UpdateArgs& u, float* dst, float g) {
+    *dst = g;                                   // keep p.grad inspectable
+    adam_item(u.ad, (int64_t)(dst - u.ad.grad));
+}
+
+DEV void update_head_item(const UpdateArgs& u, int item) {
+    const int n_grad = u.h.P - 2;
+    if (item < n_grad) {
+        float acc = 0.0f;
+        for (int w = 0; w < u.h.n_wg; ++w) acc += u.h.partials[(long)w * u.h.P + item];
+        update_store(u, u.h.grad + item, acc);
+    } else if (item == n_grad) {
+        float acc = 0.0f;
+        for (int w = 0; w < u.h.n_wg; ++w) acc += u.h.partials[(long)w * u.h.P + n_grad];
+        if (u.h.loss) u.h.loss[0] = acc;
+    }
+}
+
 #ifndef DRGNN_EMU
 __global__ void __launch_bounds__(256) k_ptrs(PtrArgs a) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -269,6 +314,24 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_head(HeadArgs a) {
 __global__ void __launch_bounds__(256) k_head_reduce(HeadReduceArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.P - 1) head_reduce_item(a, i);
+}
+__global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
+    __shared__ float quarter[4][64];
+    if ((int)blockIdx.x < u.conv_blocks) {
+        const ReduceArgs& a = u.r;
+        const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+        const int64_t item = (int64_t)blockIdx.x * 64 + lane;
+        const bool live = item < (int64_t)a.n_branch * a.n_partial && reduce_live(a, (int)(item % a.n_partial));
+        const int br = live ? (int)(item / a.n_partial) : 0, p = live ? (int)(item % a.n_partial) : 0;
+        quarter[q][lane] = live ? reduce_sum(a, br, p, q, 4) : 0.0f;
+        __syncthreads();
+        if (q == 0 && live) {
+            float* d = reduce_dst(a, br, p);
+            if (d) update_store(u, d, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
+        }
+    } else {
+        update_head_item(u, ((int)blockIdx.x - u.conv_blocks) * 256 + (int)threadIdx.x);
+    }
 }
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
     adam_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
@@ -349,6 +412,8 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
     L.args.n_graphs = (int)n_graphs;
     L.gscratch = scratch_i32;
     L.level1_only = 0;
+    L.user_nptr = (node_ptr && edge_ptr) ? node_ptr : nullptr;
+    L.user_eptr = (node_ptr && edge_ptr) ? edge_ptr : nullptr;
     int64_t lds = 0;
     L.capN = 0; L.capE = 0;
     if (max_nodes > 0) {
@@ -365,11 +430,9 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
     const bool need_ptrs = !(node_ptr && edge_ptr);
     const int64_t span = n_nodes > n_edges ? n_nodes : n_edges;
 #ifdef DRGNN_EMU
-    for (int k = 0; k < 4; ++k) pa.err[k] = 0;
     if (need_ptrs) {
+        for (int k = 0; k < 4; ++k) pa.err[k] = 0;
         for (int64_t i = 0; i < (span > 0 ? span : 1); ++i) ptr_item(pa, i);
-    } else {
-        for (int64_t gph = 0; gph <= n_graphs; ++gph) { pa.nptr[gph] = node_ptr[gph]; pa.eptr[gph] = edge_ptr[gph]; }
     }
     std::vector<int> lds_buf((size_t)(lds / 4) + 16);
     for (int pass = 0; pass < 2; ++pass) {
@@ -381,12 +444,10 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
     }
     (void)stream;
 #else
-    {
+    if (need_ptrs) {
         const int n = (int)n_graphs + 1;
         hipLaunchKernelGGL(k_topo_begin, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-                           need_ptrs ? nullptr : node_ptr, edge_ptr, pa.nptr, pa.eptr, pa.err, n);
-    }
-    if (need_ptrs) {
+                           (const int32_t*)nullptr, (const int32_t*)nullptr, pa.nptr, pa.eptr, pa.err, n);
         const int64_t items = span > 0 ? span : 1;
         hipLaunchKernelGGL(k_ptrs, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, stream, pa);
     }
@@ -426,14 +487,27 @@ int drgnn_topology_status(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edge
     if (!ws_i32 || !status4) return DRGNN_E_ARG;
     TopoLayout lay;
     topo_layout(n_nodes, n_edges, n_graphs, &lay);
-    const int32_t* src = ws_i32 + lay.i32[DRGNN_TI_ERR];
+    const int32_t* err = ws_i32 + lay.i32[DRGNN_TI_ERR];
+    const int32_t* gst = ws_i32 + lay.i32[DRGNN_TI_GSTAT];
+    std::vector<int32_t> host((size_t)n_graphs + 4);
 #ifdef DRGNN_EMU
-    for (int k = 0; k < 4; ++k) status4[k] = src[k];
+    for (int k = 0; k < 4; ++k) host[k] = err[k];
+    for (int64_t g = 0; g < n_graphs; ++g) host[4 + g] = gst[g];
     (void)stream_;
 #else
-    HIP_TRY(hipMemcpyAsync(status4, src, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    HIP_TRY(hipMemcpyAsync(host.data(), err, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+    if (n_graphs > 0)
+        HIP_TRY(hipMemcpyAsync(host.data() + 4, gst, n_graphs * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
 #endif
+    status4[0] = host[0]; status4[1] = -1; status4[2] = 0; status4[3] = 0;
+    for (int64_t g = 0; g < n_graphs; ++g) {
+        if (host[4 + g]) {
+            status4[0] |= host[4 + g];
+            if (status4[1] < 0) status4[1] = (int32_t)g;
+            status4[2] += 1;
+        }
+    }
     return 0;
 }
 
@@ -545,6 +619,7 @@ int drgnn_net_forward(const drgnn_net_desc* net, const float* x, const int32_t* 
     L.a.n_graphs = (int)n_graphs;
     L.a.xp = xp; L.a.arg0 = arg0; L.a.arg1 = arg1; L.a.readout = readout;
     L.a.grad_readout = nullptr; L.a.partials = nullptr; L.a.grad_x = nullptr; L.a.n_partial = 0;
+    L.a.step_inc = nullptr;
     L.n_edges = n_edges;
     return net_launch<false>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
 }
@@ -553,7 +628,7 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
                        const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges,
                        int64_t n_graphs, int32_t max_nodes, int32_t max_edges, int32_t max_c0,
                        const float* xp, const int32_t* arg0, const int32_t* arg1, float* grad_x,
-                       float* partials, float* scratch_f32, void* stream_) {
+                       float* partials, float* scratch_f32, int32_t* step_inc, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
     if (!x || !grad_readout || !ws_i32 || !xp || !arg0 || !arg1 || !partials) return DRGNN_E_ARG;
@@ -569,6 +644,7 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
     L.a.arg1 = const_cast<int32_t*>(arg1); L.a.readout = nullptr;
     L.a.grad_readout = grad_readout; L.a.partials = partials; L.a.grad_x = grad_x;
     L.a.n_partial = (int)net_partial_floats(net->n_feat);
+    L.a.step_inc = step_inc;
     L.n_edges = n_edges;
     return net_launch<true>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
 }
@@ -607,11 +683,12 @@ int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int
 
 // ---- dense head + loss + optimiser ----------------------------------------------------------
 int64_t drgnn_head_partial_elems(int32_t R, int32_t H, int32_t O) { return head_partial_floats(R, H, O); }
+int64_t drgnn_head_num_slabs(int64_t n_graphs) { const int t = head_tile(n_graphs); return (n_graphs + t - 1) / t; }
 
 static int head_check(const drgnn_head_desc* hd) {
     if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2) return DRGNN_E_ARG;
     if (hd->R < 1 || hd->H < 1 || hd->O < 1 || hd->O > DRGNN_MAX_OUT) return DRGNN_E_WIDTH;
-    if (4 * head_lds_words(hd->R, hd->H, hd->O) > DRGNN_LDS_LIMIT) return DRGNN_E_WIDTH;
+    if (4 * head_lds_words(hd->R, hd->H, hd->O, DRGNN_HEAD_TILE_LARGE) > DRGNN_LDS_LIMIT) return DRGNN_E_WIDTH;
     if (hd->task != DRGNN_TASK_REG && hd->task != DRGNN_TASK_CLASS) return DRGNN_E_ARG;
     if (!(hd->p_drop >= 0.0f && hd->p_drop < 1.0f)) return DRGNN_E_ARG;
     return 0;
@@ -635,8 +712,9 @@ int drgnn_head_step(const drgnn_head_desc* hd, const float* readout, const void*
     a.partials = partials;
     a.B = (int)n_graphs; a.R = hd->R; a.H = hd->H; a.O = hd->O;
     a.task = hd->task; a.train = hd->train; a.p_drop = hd->p_drop; a.seed = hd->seed;
-    const int blocks = (int)((n_graphs + DRGNN_HEAD_TILE - 1) / DRGNN_HEAD_TILE);
-    const int64_t lds = 4 * head_lds_words(hd->R, hd->H, hd->O);
+    a.T = head_tile(n_graphs);
+    const int blocks = (int)((n_graphs + a.T - 1) / a.T);
+    const int64_t lds = 4 * head_lds_words(hd->R, hd->H, hd->O, a.T);
 #ifdef DRGNN_EMU
     std::vector<float> buf((size_t)(lds / 4) + 16);
     for (int b = 0; b < blocks; ++b) head_block(a, b, buf.data());
@@ -655,7 +733,7 @@ int drgnn_head_reduce(const float* partials, int64_t n_graphs, int32_t R, int32_
     if (!partials || !grad_block) return DRGNN_E_ARG;
     HeadReduceArgs a;
     a.partials = partials;
-    a.n_wg = (int)((n_graphs + DRGNN_HEAD_TILE - 1) / DRGNN_HEAD_TILE);
+    a.n_wg = (int)((n_graphs + head_tile(n_graphs) - 1) / head_tile(n_graphs));
     a.P = (int)head_partial_floats(R, H, O);
     a.grad = grad_block; a.loss = loss; a.step = step;
 #ifdef DRGNN_EMU
@@ -681,6 +759,53 @@ int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
     (void)stream_;
 #else
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+                       drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
+                       int32_t R, int32_t H, int32_t O, int64_t head_offset, float* flat_param,
+                       float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
+                       const int32_t* step, float* loss, float lr, float beta1, float beta2, float eps,
+                       void* stream_) {
+    int rc = net_check(net);
+    if (rc) return rc;
+    if (!conv_partials || !g_conv1 || !g_conv2 || !head_partials || !flat_param || !flat_grad || !exp_avg ||
+        !exp_avg_sq || !step)
+        return DRGNN_E_ARG;
+    UpdateArgs u;
+    ReduceArgs& r = u.r;
+    r.partials = conv_partials; r.n_graphs = (int)n_graphs; r.n_branch = net->n_branch;
+    r.n_feat = net->n_feat; r.n_partial = (int)net_partial_floats(net->n_feat); r.kind = net->kind;
+    for (int b = 0; b < DRGNN_MAX_BRANCH; ++b) {
+        r.lay1[b] = net->conv1[b]; r.lay2[b] = net->conv2[b];
+        if (b < net->n_branch) { r.g1[b] = g_conv1[b]; r.g2[b] = g_conv2[b]; }
+        else { r.g1[b] = drgnn_conv_grads{nullptr, nullptr, nullptr}; r.g2[b] = r.g1[b]; }
+    }
+    r.grad_x = nullptr; r.n_nodes = 0;
+    u.h.partials = head_partials;
+    u.h.n_wg = (int)((n_graphs + head_tile(n_graphs) - 1) / head_tile(n_graphs));
+    u.h.P = (int)head_partial_floats(R, H, O);
+    u.h.grad = flat_grad + head_offset; u.h.loss = loss; u.h.step = nullptr;
+    u.ad.param = flat_param; u.ad.grad = flat_grad; u.ad.exp_avg = exp_avg; u.ad.exp_avg_sq = exp_avg_sq;
+    u.ad.step = step; u.ad.n = n_param;
+    u.ad.lr = lr; u.ad.beta1 = beta1; u.ad.beta2 = beta2; u.ad.eps = eps; u.ad.weight_decay = 0.0f;
+    const int64_t pitems = (int64_t)net->n_branch * r.n_partial;
+    u.conv_blocks = (int)((pitems + 63) / 64);
+    const int head_blocks = (u.h.P - 1 + 255) / 256;
+#ifdef DRGNN_EMU
+    for (int64_t i = 0; i < pitems; ++i) {
+        const int br = (int)(i / r.n_partial), p = (int)(i % r.n_partial);
+        if (!reduce_live(r, p)) continue;
+        float* d = reduce_dst(r, br, p);
+        if (d) update_store(u, d, reduce_sum(r, br, p, 0, 1));
+    }
+    for (int i = 0; i < u.h.P - 1; ++i) update_head_item(u, i);
+    (void)stream_; (void)head_blocks;
+#else
+    hipLaunchKernelGGL(k_update, dim3((unsigned)(u.conv_blocks + head_blocks)), dim3(256), 0, (hipStream_t)stream_, u);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

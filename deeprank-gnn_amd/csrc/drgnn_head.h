@@ -18,10 +18,14 @@
 #pragma once
 #include "drgnn_net.h"
 
-#define DRGNN_HEAD_TILE 64
+#define DRGNN_HEAD_TILE_SMALL 16     // graphs per workgroup for small batches (latency)
+#define DRGNN_HEAD_TILE_LARGE 64     // ... for large batches (fewer partial slabs)
 #define DRGNN_TASK_REG 0
 #define DRGNN_TASK_CLASS 1
 #define DRGNN_MAX_OUT 16
+#define DRGNN_HEAD_TMP 4096          // LDS floats for split sums / K-split GEMM partials
+
+HD int head_tile(int64_t n_graphs) { return n_graphs <= 512 ? DRGNN_HEAD_TILE_SMALL : DRGNN_HEAD_TILE_LARGE; }
 
 struct HeadArgs {
     const float* readout;     // [B, R]
@@ -34,7 +38,7 @@ struct HeadArgs {
     float* pred;              // [B, O]
     float* grad_readout;      // [B, R] or null (inference)
     float* partials;          // [n_wg][P] or null
-    int B, R, H, O;
+    int B, R, H, O, T;        // T = graphs per workgroup
     int task;
     int train;                // apply dropout, compute gradients
     float p_drop;
@@ -42,9 +46,9 @@ struct HeadArgs {
 };
 
 HD int64_t head_partial_floats(int R, int H, int O) { return (int64_t)H * R + H + (int64_t)O * H + O + 2; }
-HD int64_t head_lds_words(int R, int H, int O) {
-    return (int64_t)DRGNN_HEAD_TILE * (R + 1) + (int64_t)H * (R + 1) + (int64_t)DRGNN_HEAD_TILE * (H + 1) +
-           H + (int64_t)O * H + O + 4 * DRGNN_HEAD_TILE * DRGNN_MAX_OUT + 64;
+HD int64_t head_lds_words(int R, int H, int O, int T) {
+    return (int64_t)T * (R + 1) + (int64_t)H * (R + 1) + (int64_t)T * (H + 1) + H + (int64_t)O * H + O +
+           2 * T * DRGNN_MAX_OUT + 2 * T + DRGNN_HEAD_TMP + 64;
 }
 
 // lowbias32-style counter hash -> uniform 32-bit value for (seed, step, element)
@@ -55,40 +59,52 @@ HD uint32_t drgnn_hash(uint32_t seed, uint32_t step, uint32_t idx) {
 }
 
 DEV void head_block(const HeadArgs& a, int blk, float* lds) {
-    const int R = a.R, H = a.H, O = a.O;
-    const int g0 = blk * DRGNN_HEAD_TILE;
-    const int G = imin(DRGNN_HEAD_TILE, a.B - g0);
+    const int R = a.R, H = a.H, O = a.O, T = a.T;
+    const int g0 = blk * T;
+    const int G = imin(T, a.B - g0);
     const int ldx = R + 1, ldh = H + 1;
-    float* xs = lds;                                   // [64][R+1]
-    float* w1p = xs + DRGNN_HEAD_TILE * ldx;           // [H][R+1]
-    float* hid = w1p + (long)H * ldx;                  // [64][H+1]
-    float* b1s = hid + DRGNN_HEAD_TILE * ldh;          // [H]
+    float* xs = lds;                                   // [T][R+1]
+    float* w1p = xs + T * ldx;                         // [H][R+1]
+    float* hid = w1p + (long)H * ldx;                  // [T][H+1]
+    float* b1s = hid + T * ldh;                        // [H]
     float* w2s = b1s + H;                              // [O][H]
     float* b2s = w2s + (long)O * H;                    // [O]
-    float* outs = b2s + O;                             // [64][MAX_OUT]   pred tile
-    float* douts = outs + DRGNN_HEAD_TILE * DRGNN_MAX_OUT;   // [64][MAX_OUT]   d loss / d pred
-    float* red = douts + DRGNN_HEAD_TILE * DRGNN_MAX_OUT;    // [64][2] per-graph (loss, weight)
+    float* outs = b2s + O;                             // [T][MAX_OUT]   pred tile
+    float* douts = outs + T * DRGNN_MAX_OUT;           // [T][MAX_OUT]   d loss / d pred
+    float* red = douts + T * DRGNN_MAX_OUT;            // [T][2] per-graph (loss, weight)
+    float* tmp = red + 2 * T;                          // [DRGNN_HEAD_TMP]
     const uint32_t step = a.step ? (uint32_t)a.step[0] : 0u;
+    const FastDiv dH = fastdiv_make(H), dO = fastdiv_make(O), dR = fastdiv_make(R);
+    PHASE_MARK();
 
-    FOR_TID(e, DRGNN_HEAD_TILE * R) {
-        const int g = e / R, r = e % R;
-        xs[g * ldx + r] = (g < G) ? a.readout[(long)(g0 + g) * R + r] : 0.0f;
+    // ---- stage (all loads in flight together when the sizes allow) ------------------------
+    if (H * R <= 8 * DRGNN_NTHREADS && T * R <= 4 * DRGNN_NTHREADS && O * H <= 2 * DRGNN_NTHREADS &&
+        H <= DRGNN_NTHREADS) {
+        BurstW<8> bw1;  burst_load_w(bw1, a.w1, R, 1, H, R);
+        BurstW<4> bx;   burst_load_w(bx, a.readout + (long)g0 * R, R, 1, G, R);
+        Burst<float, 1> bb1, bb2;  burst_load(bb1, a.b1, H);  burst_load(bb2, a.b2, O);
+        Burst<float, 2> bw2;       burst_load(bw2, a.w2, O * H);
+        burst_store_w(bw1, w1p, ldx);
+        burst_store_w(bx, xs, ldx);
+        burst_store(bb1, b1s); burst_store(bb2, b2s); burst_store(bw2, w2s);
+    } else {
+        FOR_TID(e, G * R) { const int g = fastdiv(dR, e); xs[g * ldx + fastmod(dR, e, g)] = a.readout[(long)g0 * R + e]; }
+        FOR_TID(e, H * R) { const int h = fastdiv(dR, e); w1p[h * ldx + fastmod(dR, e, h)] = a.w1[e]; }
+        FOR_TID(h, H) { b1s[h] = a.b1[h]; }
+        FOR_TID(e, O * H) { w2s[e] = a.w2[e]; }
+        FOR_TID(o, O) { b2s[o] = a.b2[o]; }
     }
-    FOR_TID(e, H * R) { w1p[(e / R) * ldx + (e % R)] = a.w1[e]; }
-    FOR_TID(h, H) { b1s[h] = a.b1[h]; }
-    FOR_TID(e, O * H) { w2s[e] = a.w2[e]; }
-    FOR_TID(o, O) { b2s[o] = a.b2[o]; }
+    FOR_TID(e, (T - G) * R) { const int g = fastdiv(dR, e); xs[(G + g) * ldx + fastmod(dR, e, g)] = 0.0f; }   // rows beyond the batch
     BARRIER();
     // hid = X W1^T            B(k=r, j=h) = w1p[h*ldx + r]
-    wg_gemm(DRGNN_HEAD_TILE, H, R, xs, ldx, 1, w1p, 1, ldx, hid, ldh, 1);
+    wg_gemm(T, H, R, xs, ldx, 1, w1p, 1, ldx, hid, ldh, 1);
     BARRIER();
     {
         const float keep_scale = (a.train && a.p_drop > 0.0f) ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-        const uint32_t thresh = (a.train && a.p_drop > 0.0f)
-                                    ? (uint32_t)((double)a.p_drop * 4294967296.0 > 4294967295.0 ? 4294967295.0 : (double)a.p_drop * 4294967296.0)
-                                    : 0u;
-        FOR_TID(e, DRGNN_HEAD_TILE * H) {
-            const int g = e / H, h = e % H;
+        const double pt = (double)a.p_drop * 4294967296.0;
+        const uint32_t thresh = (a.train && a.p_drop > 0.0f) ? (uint32_t)(pt > 4294967295.0 ? 4294967295.0 : pt) : 0u;
+        FOR_TID(e, T * H) {
+            const int g = fastdiv(dH, e), h = fastmod(dH, e, g);
             float v = hid[g * ldh + h] + b1s[h];
             v = v > 0.0f ? v : 0.0f;
             if (thresh) {
@@ -99,10 +115,19 @@ DEV void head_block(const HeadArgs& a, int blk, float* lds) {
         }
     }
     BARRIER();
-    FOR_TID(e, DRGNN_HEAD_TILE * O) {
-        const int g = e / O, o = e % O;
+    // fc2: 8 interleaved partial dot products per output, combined in fixed order
+    FOR_TID(e, T * O * 8) {
+        const int q = e & 7, go = e >> 3;
+        const int g = fastdiv(dO, go), o = fastmod(dO, go, g);
+        float acc = 0.0f;
+        for (int h = q; h < H; h += 8) acc = fmaf(hid[g * ldh + h], w2s[o * H + h], acc);
+        tmp[e] = acc;
+    }
+    BARRIER();
+    FOR_TID(go, T * O) {
+        const int g = fastdiv(dO, go), o = fastmod(dO, go, g);
         float acc = b2s[o];
-        for (int h = 0; h < H; ++h) acc = fmaf(hid[g * ldh + h], w2s[o * H + h], acc);
+        for (int q = 0; q < 8; ++q) acc += tmp[go * 8 + q];
         outs[g * DRGNN_MAX_OUT + o] = acc;
         if (g < G) a.pred[(long)(g0 + g) * O + o] = acc;
     }
@@ -110,7 +135,7 @@ DEV void head_block(const HeadArgs& a, int blk, float* lds) {
     if (!a.train || a.grad_readout == nullptr) return;
 
     // ---- loss and d loss / d pred (mean reduction over the WHOLE batch) --------------------
-    FOR_TID(g, DRGNN_HEAD_TILE) {
+    FOR_TID(g, T) {
         float loss = 0.0f, wsum = 0.0f;
         if (g < G) {
             if (a.task == DRGNN_TASK_REG) {
@@ -155,19 +180,19 @@ DEV void head_block(const HeadArgs& a, int blk, float* lds) {
     float* p_loss = p_b2 + O;
     // dW2[o,h] = sum_g dout[g,o] hid[g,h];  db2;  loss partial
     FOR_TID(e, O * H) {
-        const int o = e / H, h = e % H;
+        const int o = fastdiv(dH, e), h = fastmod(dH, e, o);
         float acc = 0.0f;
-        for (int g = 0; g < DRGNN_HEAD_TILE; ++g) acc = fmaf(douts[g * DRGNN_MAX_OUT + o], hid[g * ldh + h], acc);
+        for (int g = 0; g < T; ++g) acc = fmaf(douts[g * DRGNN_MAX_OUT + o], hid[g * ldh + h], acc);
         p_w2[e] = acc;
     }
     FOR_TID(o, O) {
         float acc = 0.0f;
-        for (int g = 0; g < DRGNN_HEAD_TILE; ++g) acc += douts[g * DRGNN_MAX_OUT + o];
+        for (int g = 0; g < T; ++g) acc += douts[g * DRGNN_MAX_OUT + o];
         p_b2[o] = acc;
     }
     FOR_TID(i, 1) {
         float l = 0.0f, w = 0.0f;
-        for (int g = 0; g < DRGNN_HEAD_TILE; ++g) { l += red[2 * g]; w += red[2 * g + 1]; }
+        for (int g = 0; g < T; ++g) { l += red[2 * g]; w += red[2 * g + 1]; }
         p_loss[0] = l;
         p_loss[1] = w;
     }
@@ -175,8 +200,8 @@ DEV void head_block(const HeadArgs& a, int blk, float* lds) {
     // d hid (in place): (dout W2) * relu' * dropout mask -- both folded into "hid != 0"
     {
         const float keep_scale = (a.p_drop > 0.0f) ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-        FOR_TID(e, DRGNN_HEAD_TILE * H) {
-            const int g = e / H, h = e % H;
+        FOR_TID(e, T * H) {
+            const int g = fastdiv(dH, e), h = fastmod(dH, e, g);
             float acc = 0.0f;
             for (int o = 0; o < O; ++o) acc = fmaf(douts[g * DRGNN_MAX_OUT + o], w2s[o * H + h], acc);
             hid[g * ldh + h] = (hid[g * ldh + h] != 0.0f) ? acc * keep_scale : 0.0f;
@@ -184,19 +209,25 @@ DEV void head_block(const HeadArgs& a, int blk, float* lds) {
     }
     BARRIER();
     // dW1 = dhid^T X   (A(i=h,k=g) = hid[g*ldh + h];  B(k=g,j=r) = xs[g*ldx + r])
-    wg_gemm(H, R, DRGNN_HEAD_TILE, hid, 1, ldh, xs, ldx, 1, p_w1, R, 1);
+    wg_gemm(H, R, T, hid, 1, ldh, xs, ldx, 1, p_w1, R, 1);
     FOR_TID(h, H) {
         float acc = 0.0f;
-        for (int g = 0; g < DRGNN_HEAD_TILE; ++g) acc += hid[g * ldh + h];
+        for (int g = 0; g < T; ++g) acc += hid[g * ldh + h];
         p_b1[h] = acc;
     }
-    // d readout = dhid W1   (B(k=h, j=r) = w1p[h*ldx + r]); rows beyond the batch are skipped
-    wg_gemm(G, R, H, hid, ldh, 1, w1p, ldx, 1, a.grad_readout + (long)g0 * R, R, 1);
+    // d readout = dhid W1   (B(k=h, j=r) = w1p[h*ldx + r]); rows beyond the batch are skipped.
+    // K = H is long and there are few output tiles: split K over the idle waves
+    {
+        const int tiles = ((G + 15) >> 4) * ((R + 15) >> 4);
+        int KS = imin(DRGNN_NWAVES / imax(tiles, 1), DRGNN_HEAD_TMP / imax(G * R, 1));
+        KS = imax(1, imin(KS, 8));
+        wg_gemm(G, R, H, hid, ldh, 1, w1p, ldx, 1, a.grad_readout + (long)g0 * R, R, 1, KS, tmp);
+    }
 }
 
 // ---- reduction of the head partials + Adam -----------------------------------------------
 struct HeadReduceArgs {
-    const float* partials;    // [n_wg][P]
+    const float* partials;    // [n_wg][P]   n_wg = ceil(B / head_tile(B))
     int n_wg, P;              // P = head_partial_floats
     float* grad;              // contiguous [H*R + H + O*H + O] block of the flat gradient
     float* loss;              // scalar out

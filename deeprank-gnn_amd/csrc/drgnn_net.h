@@ -55,50 +55,57 @@ DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const fl
 typedef float drgnn_f32x4 __attribute__((ext_vector_type(4)));
 DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const float* B, int sbk,
                  int sbj, float* C, int sci, int scj, int KS = 1, float* part = nullptr) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave id as a scalar so that the unit loop below is uniform control flow (SALU only)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
-    const int mt = (M + 15) >> 4, nt = (N + 15) >> 4;
-    const int kslice = (((K + KS - 1) / KS) + 3) & ~3;
-    for (int unit = wave; unit < mt * nt * KS; unit += DRGNN_NWAVES) {
-        const int ks = unit % KS, tile = unit / KS;
-        const int i0 = (tile / nt) << 4, j0 = (tile % nt) << 4;
-        const int ai = i0 + lr, bj = j0 + lr;
-        const bool a_ok = ai < M, b_ok = bj < N;
-        const float* ap = A + (long)ai * sai;
-        const float* bp = B + (long)bj * sbj;
-        const int kbeg = ks * kslice, kend = imin(K, kbeg + kslice);
-        drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int k0 = kbeg; k0 < kend; k0 += 32) {
-            float a[8], b[8];
+    const int kslice = (KS == 1) ? ((K + 3) & ~3) : ((((K + KS - 1) / KS) + 3) & ~3);
+    int unit = 0;      // (tile, K slice) units are dealt round-robin to the waves; all loop
+                       // variables are wave-uniform, no per-lane integer division
+    for (int i0 = 0; i0 < M; i0 += 16) {
+        for (int j0 = 0; j0 < N; j0 += 16) {
+            for (int ks = 0; ks < KS; ++ks, ++unit) {
+                if ((unit & (DRGNN_NWAVES - 1)) != wave) continue;
+                const int ai = i0 + lr, bj = j0 + lr;
+                const bool a_ok = ai < M, b_ok = bj < N;
+                const float* ap = A + (long)ai * sai;
+                const float* bp = B + (long)bj * sbj;
+                const int kbeg = ks * kslice, kend = imin(K, kbeg + kslice);
+                drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                for (int k0 = kbeg; k0 < kend; k0 += 32) {
+                    float a[8], b[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                const int k = k0 + 4 * s + lq;
-                const bool k_ok = k < kend;
-                a[s] = (a_ok && k_ok) ? ap[(long)k * sak] : 0.0f;
-                b[s] = (b_ok && k_ok) ? bp[(long)k * sbk] : 0.0f;
-            }
+                    for (int s = 0; s < 8; ++s) {
+                        const int k = k0 + 4 * s + lq;
+                        const bool k_ok = k < kend;
+                        a[s] = (a_ok && k_ok) ? ap[(long)k * sak] : 0.0f;
+                        b[s] = (b_ok && k_ok) ? bp[(long)k * sbk] : 0.0f;
+                    }
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if (k0 + 4 * s < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
-            }
-        }
-        if (b_ok) {
+                    for (int s = 0; s < 8; ++s) {
+                        if (k0 + 4 * s < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+                    }
+                }
+                if (b_ok) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ci = i0 + lq * 4 + r;
-                if (ci < M) {
-                    if (KS == 1) C[(long)ci * sci + (long)bj * scj] = acc[r];
-                    else part[((long)ks * M + ci) * N + bj] = acc[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int ci = i0 + lq * 4 + r;
+                        if (ci < M) {
+                            if (KS == 1) C[(long)ci * sci + (long)bj * scj] = acc[r];
+                            else part[((long)ks * M + ci) * N + bj] = acc[r];
+                        }
+                    }
                 }
             }
         }
     }
     if (KS > 1) {
         __syncthreads();
+        const FastDiv dn = fastdiv_make(N);
         for (int e = threadIdx.x; e < M * N; e += DRGNN_NTHREADS) {
             float s = 0.0f;
             for (int ks = 0; ks < KS; ++ks) s += part[(long)ks * M * N + e];
-            C[(long)(e / N) * sci + (long)(e % N) * scj] = s;
+            const int i = fastdiv(dn, e);
+            C[(long)i * sci + (long)fastmod(dn, e, i) * scj] = s;
         }
     }
 }
@@ -121,6 +128,7 @@ struct NetArgs {
     float* partials;         // [B*n_branch][P]
     float* grad_x;           // [n_branch][Ntot][F] or null (summed over branches by the reducer)
     int n_partial;           // P
+    int32_t* step_inc;       // optional optimiser step counter, incremented once per backward launch
 };
 
 // ---- scratch (LDS, or a global slab for graphs that do not fit) -------------------------
@@ -449,7 +457,7 @@ DEV void net_forward_graph(const NetArgs& a, int g, int br, float* scratch, int 
     net_cluster_max<DRGNN_H2>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, a.arg1 + nodeoff * DRGNN_H2);
     BARRIER();
     // graph readout: mean over the depth-1 clusters (scatter_mean with count clamp)
-    const int bad = tv.p[DRGNN_TI_ERR][0];
+    const int bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g];
     const int width = DRGNN_H2 * a.net.n_branch;
     FOR_TID(c, DRGNN_H2) {
         float acc = 0.0f;
@@ -521,6 +529,9 @@ DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int
     float* p_w2s = p_w2n + DRGNN_H1 * DRGNN_H2;
     float* p_b2 = p_w2s + DRGNN_H1 * DRGNN_H2;
 
+    if (a.step_inc != nullptr && g == 0 && br == 0) {
+        FOR_TID(i, 1) { a.step_inc[0] = a.step_inc[0] + 1; }
+    }
     // ---- stage: x tile, weights, transposed graphs, saved activations -------------------
     PHASE_MARK();
     const drgnn_conv_params& c1 = a.net.conv1[br];

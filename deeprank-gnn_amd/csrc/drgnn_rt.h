@@ -72,6 +72,24 @@ typedef hipStream_t drgnn_stream_t;
 #define DRGNN_WAVE 64
 #define DRGNN_NWAVES (DRGNN_NTHREADS / DRGNN_WAVE)
 
+// Division by a run-time constant without the ~40-instruction integer divide: one real
+// division per kernel (the magic), then a mul-hi per use.  Exact while n * d < 2^32.
+struct FastDiv {
+    unsigned d, m;
+};
+DEV FastDiv fastdiv_make(int d) {
+    FastDiv f;
+    f.d = (unsigned)(d > 0 ? d : 1);
+    f.m = (unsigned)(0xFFFFFFFFu / f.d) + 1u;
+    return f;
+}
+#ifdef DRGNN_EMU
+DEV int fastdiv(const FastDiv& f, int n) { return (int)((unsigned)n / f.d); }
+#else
+DEV int fastdiv(const FastDiv& f, int n) { return f.d == 1u ? n : (int)__umulhi((unsigned)n, f.m); }
+#endif
+DEV int fastmod(const FastDiv& f, int n, int q) { return n - q * (int)f.d; }
+
 DEV int imin(int a, int b) { return a < b ? a : b; }
 DEV int imax(int a, int b) { return a > b ? a : b; }
 
@@ -166,17 +184,21 @@ template <class T, int J> DEV void burst_store(const Burst<T, J>& b, T* dst) {
 template <int J> struct BurstW { float v[J]; int n, H; };
 template <int J> DEV void burst_load_w(BurstW<J>& b, const float* src, long sk, long sh, int K, int H) {
     b.n = src ? K * H : 0; b.H = H;
+    const FastDiv fd = fastdiv_make(H);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int e = threadIdx.x + j * DRGNN_NTHREADS;
-        b.v[j] = (e < b.n) ? src[(long)(e / H) * sk + (long)(e % H) * sh] : 0.0f;
+        const int k = fastdiv(fd, e), h = fastmod(fd, e, k);
+        b.v[j] = (e < b.n) ? src[(long)k * sk + (long)h * sh] : 0.0f;
     }
 }
 template <int J> DEV void burst_store_w(const BurstW<J>& b, float* dst, int ld) {
+    const FastDiv fd = fastdiv_make(b.H);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int e = threadIdx.x + j * DRGNN_NTHREADS;
-        if (e < b.n) dst[(e / b.H) * ld + (e % b.H)] = b.v[j];
+        const int k = fastdiv(fd, e), h = fastmod(fd, e, k);
+        if (e < b.n) dst[k * ld + h] = b.v[j];
     }
 }
 // x tile [rows, F] (F % 4 == 0, 16-byte aligned) -> padded rows dst[i*(F+1) + f], float4 loads
@@ -192,12 +214,14 @@ template <int J> DEV void burst_load_x(BurstX<J>& b, const float* src, int rows,
     }
 }
 template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
+    const FastDiv fd = fastdiv_make(b.F);
 #pragma unroll
     for (int j = 0; j < J; ++j) {
         const int q = threadIdx.x + j * DRGNN_NTHREADS;
         if (q < b.n4) {
             const int e = q * 4;
-            float* d = dst + (e / b.F) * (b.F + 1) + (e % b.F);
+            const int row = fastdiv(fd, e);
+            float* d = dst + row * (b.F + 1) + fastmod(fd, e, row);
             d[0] = b.v[j][0]; d[1] = b.v[j][1]; d[2] = b.v[j][2]; d[3] = b.v[j][3];
         }
     }

@@ -52,6 +52,7 @@ static inline void topo_layout(int64_t N, int64_t E, int64_t B, TopoLayout* L) {
     take(DRGNN_TI_E1PTR, B + 1);
     take(DRGNN_TI_CPTR1, B + 1);
     take(DRGNN_TI_ERR, 4);
+    take(DRGNN_TI_GSTAT, B);
     L->i32[DRGNN_TI_COUNT] = o;
     int64_t f = 0;
     L->f32[DRGNN_TF_W0] = f; f += (E + 3) & ~(int64_t)3;
@@ -150,10 +151,8 @@ DEV TopoScratch topo_carve(IntPtr base, int capN, int capE, int capT, int capF) 
     return s;
 }
 
-DEV void topo_flag(const TopoView& tv, int bit, int graph) {
-    ATOMIC_OR(&tv.p[DRGNN_TI_ERR][0], bit);
-    tv.p[DRGNN_TI_ERR][1] = graph;
-}
+// per-graph status word: cleared by the graph's own workgroup at the start of every build
+DEV void topo_flag(const TopoView& tv, int bit, int graph) { ATOMIC_OR(&tv.p[DRGNN_TI_GSTAT][graph], bit); }
 
 // ---------------------------------------------------------------------------------
 // Stable bucket sort of items 0..n-1 by bucket_of(item) in [0, nb):
@@ -296,9 +295,8 @@ struct TopoArgs {
     int n_graphs;
 };
 
-DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int c1_begin, int c1_len,
-                           TopoScratch& s) {
-    const int n0 = tv.p[DRGNN_TI_NPTR][g];
+DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0, int c1_begin,
+                           int c1_len, TopoScratch& s) {
     const int rowbase = n0 + g;
     const int C0 = tv.p[DRGNN_TI_NC0][g];
     if (c1_len != C0) {
@@ -315,9 +313,8 @@ DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int c1_
     BARRIER();
 }
 
-DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, TopoScratch& s) {
-    const int n0 = tv.p[DRGNN_TI_NPTR][g], n1 = tv.p[DRGNN_TI_NPTR][g + 1];
-    const int e0 = tv.p[DRGNN_TI_EPTR][g], e1 = tv.p[DRGNN_TI_EPTR][g + 1];
+DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1, int e0, int e1,
+                    TopoScratch& s) {
     const int N = n1 - n0;
     int E = e1 - e0;
     const int rowbase = n0 + g;
@@ -503,6 +500,6 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, TopoScratch& s
     // ---- depth-1 clusters (when the caller knows where this graph's ids start) --------
     if (a.cluster1 != nullptr && a.c1_ptr != nullptr) {
         const int b = a.c1_ptr[g];
-        topo_graph_level1(tv, a, g, b, a.c1_ptr[g + 1] - b, s);
+        topo_graph_level1(tv, a, g, n0, b, a.c1_ptr[g + 1] - b, s);
     }
 }

@@ -117,10 +117,7 @@ class FusedTrainer(object):
                         topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream)
         return x, desc, xp, arg0, arg1, readout, scratch
 
-    def compute_gradients(self, batch, topo=None):
-        """topology -> body forward -> head+loss (+ its backward) -> body backward -> reduction.
-        Leaves d(mean loss over THIS batch)/d(params) in ``flat_g`` (= every ``p.grad``), the
-        loss in ``self.loss``, predictions in ``self.last_pred``; increments the step counter."""
+    def _backward(self, batch, topo, fused_update):
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
@@ -131,7 +128,7 @@ class FusedTrainer(object):
         n_nodes, n_feat = x.shape
         pred = torch.empty((B, self.O), dtype=torch.float32, device=dev)
         grad_readout = torch.empty_like(readout)
-        n_wg = (B + 63) // 64
+        n_wg = api.head_num_slabs(B)
         hp = torch.empty((max(n_wg, 1), api.head_partial_elems(self.R, self.H, self.O)),
                          dtype=torch.float32, device=dev)
         y = batch.y
@@ -141,18 +138,29 @@ class FusedTrainer(object):
                                dtype=torch.float32, device=dev)
         api.net_backward(desc, x, grad_readout, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B,
                          topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1, None, partials,
-                         scratch, stream)
+                         scratch, stream, step_inc=self.step if fused_update else None)
         g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
         g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
         for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, self.n_branch)):
             _fill_grads(g1[b], self.kind, l1, n_feat, H1)
             _fill_grads(g2[b], self.kind, l2, H1, H2)
-        api.net_reduce_grads(desc, partials, n_nodes, B, g1, g2, None, stream)
-        api.head_reduce(hp, B, self.R, self.H, self.O,
-                        self.flat_g.data_ptr() + 4 * self.head_grad_offset, self.loss, self.step, stream)
+        if fused_update:
+            api.train_update(desc, partials, B, g1, g2, hp, self.R, self.H, self.O, self.head_grad_offset,
+                             self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step, self.loss,
+                             self.lr, self.betas[0], self.betas[1], self.eps, stream)
+        else:
+            api.net_reduce_grads(desc, partials, n_nodes, B, g1, g2, None, stream)
+            api.head_reduce(hp, B, self.R, self.H, self.O,
+                            self.flat_g.data_ptr() + 4 * self.head_grad_offset, self.loss, self.step, stream)
         self.last_pred = pred
         self.last_batch_size = B
         return self.loss
+
+    def compute_gradients(self, batch, topo=None):
+        """topology -> body forward -> head+loss (+ its backward) -> body backward -> reduction.
+        Leaves d(mean loss over THIS batch)/d(params) in ``flat_g`` (= every ``p.grad``), the
+        loss in ``self.loss``, predictions in ``self.last_pred``; increments the step counter."""
+        return self._backward(batch, topo, fused_update=False)
 
     def all_reduce_gradients(self, n_local=None, n_global=None, group=None):
         """Data parallel exchange: ONE all-reduce of the flat gradient buffer (RCCL over xGMI with
@@ -176,7 +184,12 @@ class FusedTrainer(object):
                            _lib.current_stream(self.flat_p))
 
     def train_step(self, batch, topo=None, n_global=None, group=None):
-        """One optimisation step on ``batch``; returns the (device) loss of this rank's shard."""
+        """One optimisation step on ``batch``; returns the (device) loss of this rank's shard.
+        Single process: 5 launches (topology, body fwd, head, body bwd, reduce+Adam).  With
+        torch.distributed initialised: reduce, ONE all-reduce of the flat gradient, Adam."""
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        if not distributed and self.weight_decay == 0.0:
+            return self._backward(batch, topo, fused_update=True)
         loss = self.compute_gradients(batch, topo)
         self.all_reduce_gradients(n_global=n_global, group=group)
         self.apply_update()

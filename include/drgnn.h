@@ -6,9 +6,9 @@
  * as void*), never allocates, never synchronises, and is hipGraph-capturable.  Return
  * value: 0 on success, a positive hipError_t from the launch, or a negative DRGNN_E_*
  * for argument errors detected on the host.  Data-dependent errors detected on the
- * device (malformed edge lists, cluster ids out of range ...) are recorded in the
- * topology workspace (DRGNN_TI_ERR) and poison the outputs with NaN; read them back with
- * drgnn_topology_status().
+ * device (malformed edge lists, wrong cluster1 length ...) are recorded per graph in the
+ * topology workspace (DRGNN_TI_GSTAT / DRGNN_TI_ERR) and poison that graph's outputs with
+ * NaN; read them back with drgnn_topology_status().
  *
  * The reference has no C/FFI boundary (it is pure Python on torch_geometric /
  * torch_scatter / torch_sparse, which are un-vendored).  Each entry point cites the
@@ -80,7 +80,8 @@ enum drgnn_topo_i32 {
     DRGNN_TI_CPTR0,      /* [B+1]  exclusive scan of NC0  (filled by drgnn_topology_finalize)*/
     DRGNN_TI_E1PTR,      /* [B+1]  exclusive scan of NE1                                     */
     DRGNN_TI_CPTR1,      /* [B+1]  exclusive scan of NC1                                     */
-    DRGNN_TI_ERR,        /* [4]    [0] status bits, [1] first offending graph                */
+    DRGNN_TI_ERR,        /* [4]    [0] batch-level status bits (offset derivation)           */
+    DRGNN_TI_GSTAT,      /* [B]    per-graph status bits, rewritten by every build           */
     DRGNN_TI_COUNT
 };
 enum drgnn_topo_f32 {
@@ -132,7 +133,8 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr,
 int drgnn_topology_finalize(int32_t* ws_i32, int64_t n_nodes, int64_t n_edges,
                             int64_t n_graphs, void* stream);
 
-/* Copy the 4 status words to the host (this one DOES synchronise the stream). */
+/* status4[0] = OR of all status bits, status4[1] = first offending graph (or -1); this one
+ * DOES synchronise the stream. */
 int drgnn_topology_status(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edges,
                           int64_t n_graphs, int32_t* status4, void* stream);
 
@@ -205,7 +207,8 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
                        int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
                        int32_t max_nodes, int32_t max_edges, int32_t max_c0,
                        const float* xp, const int32_t* arg0, const int32_t* arg1,
-                       float* grad_x, float* partials, float* scratch_f32, void* stream);
+                       float* grad_x, float* partials, float* scratch_f32,
+                       int32_t* step_inc /* optional: ++*step_inc once per launch */, void* stream);
 
 /* Fixed-order (deterministic) sum of the per-graph partials into the strided gradient
  * tensors (overwritten, not accumulated); with grad_x, branches 1.. are summed into
@@ -235,11 +238,12 @@ typedef struct drgnn_head_desc {
     const float* class_w;     /* [O] class weights or NULL                                    */
 } drgnn_head_desc;
 
-/* One workgroup per tile of 64 graphs.  Writes pred [B,O]; when train: grad_readout [B,R]
+/* One workgroup per tile of graphs (16 for B <= 512, else 64; drgnn_head_num_slabs()).  Writes pred [B,O]; when train: grad_readout [B,R]
  * (d loss / d readout for the mean loss over the B graphs) and one partial slab per workgroup
  * ([dW1 H*R][db1 H][dW2 O*H][db2 O][loss][weight], drgnn_head_partial_elems() floats).
  * `step` (device int32) selects the dropout stream; it is NOT modified here. */
 int64_t drgnn_head_partial_elems(int32_t R, int32_t H, int32_t O);
+int64_t drgnn_head_num_slabs(int64_t n_graphs);
 int drgnn_head_step(const drgnn_head_desc* head, const float* readout, const void* target,
                     int64_t n_graphs, const int32_t* step, float* pred, float* grad_readout,
                     float* partials, void* stream);
@@ -252,6 +256,19 @@ int drgnn_head_reduce(const float* partials, int64_t n_graphs, int32_t R, int32_
 int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
                     const int32_t* step, int64_t n, float lr, float beta1, float beta2, float eps,
                     float weight_decay, void* stream);
+
+/* Single-launch parameter update for one process: fixed-order reduction of the conv partials
+ * (as drgnn_net_reduce_grads) and of the head partials (as drgnn_head_reduce, without
+ * touching the step counter), each reduced element immediately followed by its Adam update.
+ * g_conv1/g_conv2 must point INTO flat_grad; head_offset = element offset of fc1.weight in
+ * the flat buffers; *step must already count this update (drgnn_net_backward's step_inc).
+ * weight_decay is not supported here (use reduce + drgnn_adam_step). */
+int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+                       drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2,
+                       const float* head_partials, int32_t R, int32_t H, int32_t O,
+                       int64_t head_offset, float* flat_param, float* flat_grad, float* exp_avg,
+                       float* exp_avg_sq, int64_t n_param, const int32_t* step, float* loss,
+                       float lr, float beta1, float beta2, float eps, void* stream);
 
 int drgnn_abi_version(void);
 

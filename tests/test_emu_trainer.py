@@ -77,7 +77,7 @@ def test_dropout_statistics_and_reproducibility():
         step = torch.tensor([step_val], dtype=torch.int32)
         pred = torch.empty(B, O)
         gr = torch.empty(B, R)
-        hp = torch.empty(1, api.head_partial_elems(R, H, O))
+        hp = torch.empty(api.head_num_slabs(B), api.head_partial_elems(R, H, O))
         api.head_step(hd, readout, y, B, step, pred, gr, hp, None)
         return pred
 
@@ -87,3 +87,38 @@ def test_dropout_statistics_and_reproducibility():
     # E[dropout(h)] = h: the sum over 128 hidden units stays within a few percent
     ratio = (a / full).mean().item()
     assert 0.95 < ratio < 1.05, ratio
+
+
+def test_split_path_equals_fused_path_and_ragged_head_tiles():
+    """compute_gradients + apply_update (the data-parallel path) == the single-launch update;
+    37 graphs = 2 full head tiles of 16 + a ragged one."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.data import Batch
+    graphs = [synth.make_graph(i, n_nodes=10, n_pairs=12, n_feat=8, n_c1=2, n_internal=4) for i in range(37)]
+    batch = Batch.from_data_list(graphs)
+    torch.manual_seed(5)
+    a = sGAT(8, 1, 1)
+    b = copy.deepcopy(a)
+    ta = FusedTrainer(a, lr=0.02, api=emu())
+    tb = FusedTrainer(b, lr=0.02, api=emu())
+    for _ in range(2):
+        la = float(ta.train_step(batch))
+        tb.compute_gradients(batch)
+        lb = float(tb.loss)
+        tb.all_reduce_gradients()          # no process group: no-op
+        tb.apply_update()
+        assert la == lb
+    assert torch.equal(ta.flat_p, tb.flat_p) and torch.equal(ta.flat_g, tb.flat_g)
+    assert int(ta.step) == int(tb.step) == 2
+    # and against torch autograd on the same 37 graphs
+    ref = sGAT(8, 1, 1)
+    torch.manual_seed(5)
+    ref = sGAT(8, 1, 1)
+    opt = torch.optim.Adam(ref.parameters(), lr=0.02)
+    for _ in range(2):
+        opt.zero_grad()
+        out = ref(batch, topo=Topology.from_batch(batch, api=emu()))
+        F.mse_loss(out.reshape(-1), batch.y).backward()
+        opt.step()
+    for (n, p), (_, q) in zip(a.named_parameters(), ref.named_parameters()):
+        np.testing.assert_allclose(p.detach().numpy(), q.detach().numpy(), rtol=1e-5, atol=2e-6, err_msg=n)

@@ -38,3 +38,18 @@ for rep in range(2):
     buf.zero_(); torch.cuda.synchronize()
     out.sum().backward()
     if rep: dump("k_net bwd")
+
+# ---- native training step (head / update kernels) -------------------------------------
+from deeprank_gnn_amd.trainer import FusedTrainer
+net2 = GINet(32, 1, 1).to(dev)
+tr = FusedTrainer(net2, lr=1e-3, api=api)
+for rep in range(2):
+    topo = Topology.from_batch(batch, api=api, need_weights=False)
+    stream = _lib.current_stream(batch.x)
+    x, desc, xp, arg0, arg1, readout, scratch = tr._body_forward(batch, topo, stream)
+    B = topo.n_graphs
+    pred = torch.empty((B, 1), device=dev); gr = torch.empty_like(readout)
+    hp = torch.empty((api.head_num_slabs(B), api.head_partial_elems(tr.R, tr.H, tr.O)), device=dev)
+    torch.cuda.synchronize(); buf.zero_(); torch.cuda.synchronize()
+    api.head_step(tr._head_desc(True), readout, batch.y.contiguous(), B, tr.step, pred, gr, hp, stream)
+    if rep: dump("k_head")
