@@ -107,6 +107,19 @@ class Api(object):
                                            [ctypes.c_float] * 4 + [_vp])
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
                                                [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
+        lib.drgnn_conv_layer_slabs.argtypes = [_c_i64]
+        lib.drgnn_conv_layer_slabs.restype = _c_i64
+        lib.drgnn_conv_layer_partial_elems.argtypes = [_c_i32] * 3
+        lib.drgnn_conv_layer_partial_elems.restype = _c_i64
+        lib.drgnn_conv_layer_forward.argtypes = ([_c_i32, _vp, _c_i64, _c_i32, _c_i32, ctypes.POINTER(ConvParams)] +
+                                                 [_vp] * 2 + [_c_i64] + [_vp] * 3)
+        lib.drgnn_conv_layer_backward.argtypes = ([_c_i32, _vp, _c_i64, _c_i32, _c_i32, ctypes.POINTER(ConvParams)] +
+                                                  [_vp] * 2 + [_c_i64] + [_vp] * 3 +
+                                                  [ctypes.POINTER(ConvGrads)] + [_vp] * 2)
+        lib.drgnn_segpool_forward.argtypes = [_vp, _c_i64, _c_i64, _c_i64, _vp, _c_i32, _c_i32, _vp, _vp, _vp]
+        lib.drgnn_segmax_backward.argtypes = [_vp, _vp, _c_i64, _c_i32, _c_i64, _vp, _vp]
+        lib.drgnn_pooled_edges_export.argtypes = [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp]
+        lib.drgnn_cluster_offset.argtypes = [_vp, _vp, _c_i64, _vp, _vp]
         lib.drgnn_head_partial_elems.argtypes = [_c_i32] * 3
         lib.drgnn_head_partial_elems.restype = _c_i64
         lib.drgnn_head_num_slabs.argtypes = [_c_i64]
@@ -185,6 +198,43 @@ class Api(object):
         _check(self.lib.drgnn_net_reduce_grads(ctypes.byref(desc), _ptr(partials), n_nodes, n_graphs,
                                                g1, g2, _ptr(grad_x), stream), "drgnn_net_reduce_grads")
 
+
+    # -- stand-alone layers / pooling functions ----------------------------------
+    def conv_layer_slabs(self, n_nodes):
+        return int(self.lib.drgnn_conv_layer_slabs(n_nodes))
+
+    def conv_layer_partial_elems(self, kind, F, H):
+        return int(self.lib.drgnn_conv_layer_partial_elems(kind, F, H))
+
+    def conv_layer_forward(self, kind, x, F, H, cp, ws_i32, ws_f32, n_edges, u, out, stream):
+        _check(self.lib.drgnn_conv_layer_forward(kind, _ptr(x), x.size(0), F, H, ctypes.byref(cp), _ptr(ws_i32),
+                                                 _ptr(ws_f32), n_edges, _ptr(u), _ptr(out), stream),
+               "drgnn_conv_layer_forward")
+
+    def conv_layer_backward(self, kind, x, F, H, cp, ws_i32, ws_f32, n_edges, grad_out, du, partials, cg,
+                            grad_x, stream):
+        _check(self.lib.drgnn_conv_layer_backward(kind, _ptr(x), x.size(0), F, H, ctypes.byref(cp), _ptr(ws_i32),
+                                                  _ptr(ws_f32), n_edges, _ptr(grad_out), _ptr(du),
+                                                  _ptr(partials), ctypes.byref(cg), _ptr(grad_x), stream),
+               "drgnn_conv_layer_backward")
+
+    def segpool_forward(self, ws_i32, n_nodes, n_edges, n_graphs, x, H, op, out, arg, stream):
+        _check(self.lib.drgnn_segpool_forward(_ptr(ws_i32), n_nodes, n_edges, n_graphs, _ptr(x), H, op,
+                                              _ptr(out), _ptr(arg), stream), "drgnn_segpool_forward")
+
+    def segmax_backward(self, grad_out, arg, n_clusters, H, n_nodes, grad_x, stream):
+        _check(self.lib.drgnn_segmax_backward(_ptr(grad_out), _ptr(arg), n_clusters, H, n_nodes, _ptr(grad_x),
+                                              stream), "drgnn_segmax_backward")
+
+    def pooled_edges_export(self, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, e1_total, edge_index, edge_attr,
+                            stream):
+        _check(self.lib.drgnn_pooled_edges_export(_ptr(ws_i32), _ptr(ws_f32), n_nodes, n_edges, n_graphs,
+                                                  e1_total, _ptr(edge_index), _ptr(edge_attr), stream),
+               "drgnn_pooled_edges_export")
+
+    def cluster_offset(self, cluster, node_ptr, n_graphs, scratch, stream):
+        _check(self.lib.drgnn_cluster_offset(_ptr(cluster), _ptr(node_ptr), n_graphs, _ptr(scratch), stream),
+               "drgnn_cluster_offset")
 
     # -- head / loss / optimiser ------------------------------------------------
     def head_partial_elems(self, R, H, O):

@@ -1,0 +1,243 @@
+"""Function-level pooling API with the reference's names (deeprank_gnn/community_pooling.py and
+the torch_geometric / torch_scatter helpers its models import), on the device path.
+
+    get_preloaded_cluster(cluster, batch)        community_pooling.py:25-30
+    community_pooling(cluster, data)             community_pooling.py:161-251
+    max_pool_x(cluster, x, batch)                [torch_geometric.nn] used at ginet.py:114
+    scatter_mean / scatter_sum / scatter_max     [torch_scatter] used at ginet.py:133 etc.
+
+These return dynamically-shaped tensors, so -- like the reference -- they synchronise with the
+host; the shipped nets avoid them and run fused (see functional.net_body).  The OFFLINE half of
+the reference module (community_detection: MCL / Louvain on networkx graphs, run once per
+dataset and cached in the HDF5) is not part of the per-step path and is not provided.
+"""
+import types
+
+import torch
+
+from . import _lib
+from .data import Batch, Data
+from .topology import Topology
+
+__all__ = ["get_preloaded_cluster", "community_pooling", "max_pool_x", "scatter_mean", "scatter_sum",
+           "scatter_max", "community_detection", "community_detection_per_batch"]
+
+_API = None      # tests point this at the host-emulation build
+
+
+def _api():
+    return _API or _lib.get()
+
+
+def _num_graphs(batch):
+    return int(batch.max()) + 1 if batch.numel() else 0
+
+
+def _node_ptr(batch, n_graphs):
+    counts = torch.bincount(batch, minlength=n_graphs)
+    ptr = torch.zeros(n_graphs + 1, dtype=torch.int32, device=batch.device)
+    ptr[1:] = counts.cumsum(0).to(torch.int32)
+    return ptr
+
+
+def get_preloaded_cluster(cluster, batch):
+    """Make per-graph cluster ids globally unique with a running offset, IN PLACE (returns the
+    same tensor), like the reference -- but as three small launches instead of a Python loop
+    with two boolean masks and a host sync per graph."""
+    api = _api()
+    if api is _lib._API:
+        _lib.require_device(cluster, batch)
+    if cluster.dtype != torch.int64 or not cluster.is_contiguous():
+        raise TypeError("cluster must be a contiguous int64 tensor (it is updated in place)")
+    B = _num_graphs(batch)
+    if B <= 1:
+        return cluster
+    scratch = torch.empty(B + 1, dtype=torch.int64, device=cluster.device)
+    api.cluster_offset(cluster, _node_ptr(batch, B), B, scratch, _lib.current_stream(cluster))
+    return cluster
+
+
+class _SegMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, topo, n_clusters):
+        api = topo.api
+        x = x.contiguous()
+        H = x.size(1)
+        out = torch.empty((n_clusters, H), dtype=torch.float32, device=x.device)
+        arg = torch.empty((n_clusters, H), dtype=torch.int64, device=x.device)
+        api.segpool_forward(topo.ws_i32, topo.n_nodes, topo.n_edges, topo.n_graphs, x, H, 0, out, arg,
+                            _lib.current_stream(x))
+        ctx.api, ctx.n_nodes = api, x.size(0)
+        ctx.save_for_backward(arg)
+        ctx.mark_non_differentiable(arg)
+        return out, arg
+
+    @staticmethod
+    def backward(ctx, grad_out, _):
+        (arg,) = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        gx = torch.zeros((ctx.n_nodes, grad_out.size(1)), dtype=torch.float32, device=grad_out.device)
+        ctx.api.segmax_backward(grad_out, arg, arg.size(0), grad_out.size(1), ctx.n_nodes, gx,
+                                _lib.current_stream(grad_out))
+        return gx, None, None
+
+
+def _segmean(x, topo, n_clusters):
+    x = x.to(torch.float32).contiguous()
+    out = torch.empty((n_clusters, x.size(1)), dtype=torch.float32, device=x.device)
+    topo.api.segpool_forward(topo.ws_i32, topo.n_nodes, topo.n_edges, topo.n_graphs, x, x.size(1), 1, out, None,
+                             _lib.current_stream(x))
+    return out
+
+
+def _shadow(data, cluster, edge_index, edge_attr):
+    s = types.SimpleNamespace(edge_index=edge_index, edge_attr=edge_attr, cluster0=cluster, cluster1=None)
+    batch = getattr(data, "batch", None)
+    n = cluster.numel()
+    if batch is None:
+        batch = torch.zeros(n, dtype=torch.int64, device=cluster.device)
+        s.__dict__["_num_graphs"] = 1 if n else 0
+    s.batch = batch
+    return s
+
+
+def _pool_edges(topo, e1_total, with_attr):
+    dev = topo.ws_i32.device
+    ei = torch.empty((2, e1_total), dtype=torch.int64, device=dev)
+    ea = torch.empty((e1_total, 1), dtype=torch.float32, device=dev) if with_attr else None
+    topo.api.pooled_edges_export(topo.ws_i32, topo.ws_f32, topo.n_nodes, topo.n_edges, topo.n_graphs, e1_total,
+                                 ei, ea, _lib.current_stream(topo.ws_i32))
+    return ei, ea
+
+
+def community_pooling(cluster, data):
+    """Pools features (max) and edges (relabel, drop self loops, merge duplicates with summed
+    attributes) of all cluster members; positions are averaged.  ``cluster`` must not span
+    graphs and must be graph-major (what get_preloaded_cluster returns)."""
+    api = _api()
+    cluster = cluster.to(torch.int64).contiguous()
+    edge_attr = getattr(data, "edge_attr", None)
+    topo = Topology.from_batch(_shadow(data, cluster, data.edge_index, edge_attr), api=api, with_level1=False)
+    topo.check()
+    c0, e1, _ = topo.totals()
+    x, _ = _SegMax.apply(data.x, topo, c0)
+    edge_index, pooled_attr = _pool_edges(topo, e1, edge_attr is not None)
+    B = topo.n_graphs
+    counts = topo.array("NC0")[:B].to(torch.int64)
+    has_batch = getattr(data, "batch", None) is not None
+    batch = torch.repeat_interleave(torch.arange(B, device=cluster.device), counts) if has_batch else None
+    pos = _segmean(data.pos, topo, c0) if getattr(data, "pos", None) is not None else None
+    if has_batch:
+        out = Batch(batch=batch, x=x, edge_index=edge_index, edge_attr=pooled_attr, pos=pos)
+        out.__dict__["_num_graphs"] = B
+    else:
+        out = Data(x=x, edge_index=edge_index, edge_attr=pooled_attr, pos=pos)
+    iei = getattr(data, "internal_edge_index", None)
+    if iei is not None:
+        iea = getattr(data, "internal_edge_attr", None)
+        t2 = Topology.from_batch(_shadow(data, cluster, iei, iea), api=api, with_level1=False)
+        _, e1i, _ = t2.totals()
+        out.internal_edge_index, out.internal_edge_attr = _pool_edges(t2, e1i, iea is not None)
+    if getattr(data, "pos2D", None) is not None and not has_batch:
+        out.pos2D = _segmean(data.pos2D, topo, c0)
+    if getattr(data, "cluster0", None) is not None:
+        out.cluster0 = data.cluster0
+        out.cluster1 = getattr(data, "cluster1", None)
+    return out
+
+
+def max_pool_x(cluster, x, batch, size=None):
+    """Per-cluster feature maximum + the graph id of every cluster."""
+    if size is not None:
+        raise NotImplementedError("max_pool_x(size=...) is not used by the reference nets")
+    api = _api()
+    cluster = cluster.to(torch.int64).contiguous()
+    s = types.SimpleNamespace(edge_index=torch.zeros((2, 0), dtype=torch.int64, device=x.device), edge_attr=None,
+                              cluster0=cluster, cluster1=None, batch=batch)
+    topo = Topology.from_batch(s, api=api, with_level1=False)
+    c0, _, _ = topo.totals()
+    out, _ = _SegMax.apply(x, topo, c0)
+    B = topo.n_graphs
+    counts = topo.array("NC0")[:B].to(torch.int64)
+    return out, torch.repeat_interleave(torch.arange(B, device=x.device), counts)
+
+
+def _scatter_topology(index, n):
+    return Topology.single_graph(None, None, n, api=_api(), cluster=index.to(torch.int64).contiguous())
+
+
+def _dense_rows(pooled, index, dim_size, fill=0.0):
+    """torch_scatter places segment k at row k (absent ids -> empty rows); the kernels pool the
+    distinct ids in ascending order, so spread them back when ids have gaps."""
+    ids = torch.unique(index)
+    if dim_size is None:
+        dim_size = int(ids[-1]) + 1 if ids.numel() else 0
+    if ids.numel() == dim_size:
+        return pooled, ids
+    out = pooled.new_full((dim_size,) + tuple(pooled.shape[1:]), fill)
+    out[ids] = pooled
+    return out, ids
+
+
+def scatter_max(src, index, dim=0, out=None, dim_size=None):
+    if dim not in (0, -2) or out is not None or src.dim() != 2:
+        raise NotImplementedError("only scatter_max(src [n,h], index [n], dim=0)")
+    topo = _scatter_topology(index, src.size(0))
+    c0, _, _ = topo.totals()
+    pooled, arg = _SegMax.apply(src, topo, c0)
+    dense, ids = _dense_rows(pooled, index, dim_size)
+    if dense is not pooled:
+        full = arg.new_full(dense.shape, src.size(0))
+        full[ids] = arg
+        arg = full
+    return dense, arg
+
+
+class _SegSumMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, topo, n_clusters, mean):
+        out = _segmean(x, topo, n_clusters)
+        B = topo.n_graphs
+        cl = topo.array("CL0")[:x.size(0)].to(torch.int64)
+        counts = torch.bincount(cl, minlength=n_clusters).clamp(min=1).to(torch.float32)
+        if not mean:
+            out = out * counts.view(-1, 1)
+        ctx.save_for_backward(cl, counts)
+        ctx.mean = mean
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cl, counts = ctx.saved_tensors
+        if ctx.mean:
+            g = g / counts.view(-1, 1)
+        return g[cl], None, None, None
+
+
+def _scatter_reduce(src, index, dim, out, dim_size, mean):
+    if dim not in (0, -2) or out is not None:
+        raise NotImplementedError("only scatter over dim 0 without a preallocated out")
+    flat = src if src.dim() == 2 else src.reshape(src.size(0), -1)
+    topo = _scatter_topology(index, flat.size(0))
+    c0, _, _ = topo.totals()
+    pooled = _SegSumMean.apply(flat, topo, c0, mean)
+    dense, _ = _dense_rows(pooled, index, dim_size)
+    return dense if src.dim() == 2 else dense.reshape((dense.size(0),) + tuple(src.shape[1:]))
+
+
+def scatter_mean(src, index, dim=0, out=None, dim_size=None):
+    return _scatter_reduce(src, index, dim, out, dim_size, True)
+
+
+def scatter_sum(src, index, dim=0, out=None, dim_size=None):
+    return _scatter_reduce(src, index, dim, out, dim_size, False)
+
+
+def community_detection(*args, **kwargs):
+    raise NotImplementedError(
+        "community_detection (MCL / Louvain on networkx, reference community_pooling.py:95-158) is the "
+        "offline preprocessing half: it runs once per dataset and its result is stored with the graphs "
+        "(clustering/<method>/depth_{0,1}); it is outside the per-step hot path this package implements.")
+
+
+community_detection_per_batch = community_detection

@@ -5,6 +5,7 @@
 //   g++ -x c++ -DDRGNN_EMU      -> tests/emu/build/libdrgnn_emu.so (CPU test-suite only:
 //        every "launch" becomes a loop over workgroups on host pointers)
 #include "drgnn_head.h"
+#include "drgnn_layers.h"
 
 #include <vector>
 #ifdef DRGNN_EMU
@@ -307,6 +308,31 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net(NetLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     net_block<KIND, BWD, LDS>(L, blockIdx.x, smem_f);
 }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_conv_aggregate(ConvLayerArgs a) {
+    conv_aggregate_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) k_conv_bwd_du(ConvLayerArgs a) {
+    conv_bwd_du_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_bwd_dw(ConvLayerArgs a) { conv_bwd_dw_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_conv_reduce(ConvReduceArgs a) {
+    conv_reduce_item(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) k_conv_bwd_dx(ConvLayerArgs a) {
+    conv_bwd_dx_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_segpool_fwd(SegPoolArgs a) { segpool_fwd_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_segmax_bwd(SegPoolArgs a, int64_t n_items, int64_t n_nodes) {
+    segmax_bwd_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, n_nodes);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_edge_export(EdgeExportArgs a) { edge_export_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_cluster_max(ClusterOffsetArgs a) {
+    __shared__ long long mm[2];
+    cluster_max_block(a, blockIdx.x, mm);
+}
+__global__ void k_cluster_scan(ClusterOffsetArgs a) { cluster_scan_single(a); }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_cluster_add(ClusterOffsetArgs a) { cluster_add_block(a, blockIdx.x); }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_head(HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_h[];
     head_block(a, blockIdx.x, smem_h);
@@ -393,7 +419,8 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
                          int64_t n_edges, int64_t len_cluster1, int64_t n_graphs, int32_t max_nodes,
                          int32_t max_edges, int32_t* ws_i32, float* ws_f32, int32_t* scratch_i32,
                          void* stream_) {
-    if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !ws_i32 || !batch || !cluster0) return DRGNN_E_ARG;
+    if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !ws_i32 || !batch) return DRGNN_E_ARG;
+    if (!cluster0 && cluster1) return DRGNN_E_ARG;
     if (n_edges > 0 && !edge_index) return DRGNN_E_ARG;
     if (edge_attr && !ws_f32) return DRGNN_E_ARG;
     if (n_nodes + n_graphs >= INT32_MAX || n_edges >= INT32_MAX) return DRGNN_E_CAPACITY;
@@ -806,6 +833,156 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
     (void)stream_; (void)head_blocks;
 #else
     hipLaunchKernelGGL(k_update, dim3((unsigned)(u.conv_blocks + head_blocks)), dim3(256), 0, (hipStream_t)stream_, u);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+// ---- stand-alone layers / pooling functions ---------------------------------------------------
+#ifdef DRGNN_EMU
+#define DRGNN_GRID_ITEMS(kern, item_fn, n_items, stream, ...) \
+    do { for (int64_t it_ = 0; it_ < (int64_t)(n_items); ++it_) item_fn(__VA_ARGS__, it_); (void)stream; } while (0)
+#define DRGNN_GRID_BLOCKS(kern, block_fn, n_blocks, stream, ...) \
+    do { for (int b_ = 0; b_ < (int)(n_blocks); ++b_) block_fn(__VA_ARGS__, b_); (void)stream; } while (0)
+#else
+#define DRGNN_GRID_ITEMS(kern, item_fn, n_items, stream, ...)                                              \
+    do { if ((n_items) > 0) hipLaunchKernelGGL(kern, dim3((unsigned)(((n_items) + 255) / 256)), dim3(256), \
+                                               0, (hipStream_t)(stream), __VA_ARGS__); } while (0)
+#define DRGNN_GRID_BLOCKS(kern, block_fn, n_blocks, stream, ...)                                          \
+    do { if ((n_blocks) > 0) hipLaunchKernelGGL(kern, dim3((unsigned)(n_blocks)), dim3(DRGNN_NTHREADS),   \
+                                                0, (hipStream_t)(stream), __VA_ARGS__); } while (0)
+#endif
+
+static int conv_layer_fill(ConvLayerArgs& a, int32_t kind, const float* x, int64_t n_nodes, int32_t F,
+                           int32_t H, const drgnn_conv_params* p, const int32_t* ws_i32,
+                           const float* ws_f32, int64_t n_edges) {
+    if (kind < DRGNN_GINET || kind > DRGNN_FOUT || !x || !p || !p->w_nbr || !ws_i32) return DRGNN_E_ARG;
+    if (kind != DRGNN_GINET && (!p->w_self || !p->bias)) return DRGNN_E_ARG;
+    if (kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
+    if (F < 1 || H < 1 || H > DRGNN_LAYER_MAXH || n_nodes >= INT32_MAX) return DRGNN_E_WIDTH;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, 1, &lay);
+    TopoView tv = topo_view(const_cast<int32_t*>(ws_i32), const_cast<float*>(ws_f32), lay);
+    a.kind = kind; a.x = x; a.F = F; a.H = H; a.p = *p; a.N = (int)n_nodes;
+    a.rowptr = tv.p[DRGNN_TI_ROWPTR0]; a.col = tv.p[DRGNN_TI_COL0]; a.w = tv.w0;
+    a.colptr = tv.p[DRGNN_TI_COLPTR0]; a.ridx = tv.p[DRGNN_TI_ROWIDX0]; a.tslot = tv.p[DRGNN_TI_TSLOT0];
+    a.u = nullptr; a.out = nullptr; a.grad_out = nullptr; a.partials = nullptr; a.grad_x = nullptr;
+    return 0;
+}
+
+int64_t drgnn_conv_layer_slabs(int64_t n_nodes) { return (n_nodes + DRGNN_LAYER_ROWS - 1) / DRGNN_LAYER_ROWS; }
+int64_t drgnn_conv_layer_partial_elems(int32_t kind, int32_t F, int32_t H) { return conv_partial_floats(kind, F, H); }
+
+int drgnn_conv_layer_forward(int32_t kind, const float* x, int64_t n_nodes, int32_t F, int32_t H,
+                             const drgnn_conv_params* p, const int32_t* ws_i32, const float* ws_f32,
+                             int64_t n_edges, float* u, float* out, void* stream) {
+    ConvLayerArgs a;
+    int rc = conv_layer_fill(a, kind, x, n_nodes, F, H, p, ws_i32, ws_f32, n_edges);
+    if (rc) return rc;
+    if (!u || !out) return DRGNN_E_ARG;
+    a.u = u; a.out = out;
+    const int64_t slabs = drgnn_conv_layer_slabs(n_nodes);
+    DRGNN_GRID_BLOCKS(k_conv_gemm, conv_gemm_block, slabs, stream, a);
+    DRGNN_GRID_ITEMS(k_conv_aggregate, conv_aggregate_item, n_nodes * H, stream, a);
+#ifndef DRGNN_EMU
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_conv_layer_backward(int32_t kind, const float* x, int64_t n_nodes, int32_t F, int32_t H,
+                              const drgnn_conv_params* p, const int32_t* ws_i32, const float* ws_f32,
+                              int64_t n_edges, const float* grad_out, float* du, float* partials,
+                              const drgnn_conv_grads* g, float* grad_x, void* stream) {
+    ConvLayerArgs a;
+    int rc = conv_layer_fill(a, kind, x, n_nodes, F, H, p, ws_i32, ws_f32, n_edges);
+    if (rc) return rc;
+    if (!grad_out || !du || !partials || !g) return DRGNN_E_ARG;
+    a.u = du; a.grad_out = grad_out; a.partials = partials; a.grad_x = grad_x;
+    const int64_t slabs = drgnn_conv_layer_slabs(n_nodes);
+    DRGNN_GRID_ITEMS(k_conv_bwd_du, conv_bwd_du_item, n_nodes * H, stream, a);
+    DRGNN_GRID_BLOCKS(k_conv_bwd_dw, conv_bwd_dw_block, slabs, stream, a);
+    ConvReduceArgs r;
+    r.partials = partials; r.n_wg = (int)slabs; r.kind = kind; r.F = F; r.H = H; r.lay = *p; r.g = *g;
+    const int64_t P = conv_partial_floats(kind, F, H);
+#ifdef DRGNN_EMU
+    for (int i = 0; i < (int)P; ++i) conv_reduce_item(r, i);
+#else
+    hipLaunchKernelGGL(k_conv_reduce, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r);
+#endif
+    if (grad_x) DRGNN_GRID_ITEMS(k_conv_bwd_dx, conv_bwd_dx_item, n_nodes * F, stream, a);
+#ifndef DRGNN_EMU
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_segpool_forward(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                          const float* x, int32_t H, int32_t op, float* out, int64_t* arg, void* stream) {
+    if (!ws_i32 || !x || !out || H < 1 || (op != 0 && op != 1)) return DRGNN_E_ARG;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    SegPoolArgs a;
+    a.tv = topo_view(const_cast<int32_t*>(ws_i32), nullptr, lay);
+    a.x = x; a.H = H; a.n_graphs = (int)n_graphs; a.op = op; a.out = out; a.arg = arg;
+    a.grad_out = nullptr; a.grad_x = nullptr; a.arg_in = nullptr;
+    DRGNN_GRID_BLOCKS(k_segpool_fwd, segpool_fwd_block, n_graphs, stream, a);
+#ifndef DRGNN_EMU
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_segmax_backward(const float* grad_out, const int64_t* arg, int64_t n_clusters, int32_t H,
+                          int64_t n_nodes, float* grad_x, void* stream) {
+    if (!grad_out || !arg || !grad_x) return DRGNN_E_ARG;
+    SegPoolArgs a;
+    a.H = H; a.grad_out = grad_out; a.arg_in = arg; a.grad_x = grad_x;
+    a.x = nullptr; a.out = nullptr; a.arg = nullptr; a.n_graphs = 0; a.op = 0;
+    const int64_t n_items = n_clusters * H;
+#ifdef DRGNN_EMU
+    for (int64_t i = 0; i < n_items; ++i) segmax_bwd_item(a, i, n_items, n_nodes);
+    (void)stream;
+#else
+    if (n_items > 0)
+        hipLaunchKernelGGL(k_segmax_bwd, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, n_items, n_nodes);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_pooled_edges_export(const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges,
+                              int64_t n_graphs, int64_t e1_total, int64_t* edge_index, float* edge_attr,
+                              void* stream) {
+    if (!ws_i32 || (e1_total > 0 && !edge_index)) return DRGNN_E_ARG;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    EdgeExportArgs a;
+    a.tv = topo_view(const_cast<int32_t*>(ws_i32), const_cast<float*>(ws_f32), lay);
+    a.n_graphs = (int)n_graphs; a.edge_index = edge_index; a.edge_attr = edge_attr; a.e1_total = e1_total;
+    DRGNN_GRID_BLOCKS(k_edge_export, edge_export_block, n_graphs, stream, a);
+#ifndef DRGNN_EMU
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_cluster_offset(int64_t* cluster, const int32_t* node_ptr, int64_t n_graphs, int64_t* scratch,
+                         void* stream) {
+    if (!cluster || !node_ptr || !scratch || n_graphs < 0) return DRGNN_E_ARG;
+    if (n_graphs == 0) return 0;
+    ClusterOffsetArgs a;
+    a.cluster = cluster; a.nptr = node_ptr; a.n_graphs = (int)n_graphs; a.maxes = (long long*)scratch;
+#ifdef DRGNN_EMU
+    long long mm[2];
+    for (int g = 0; g < n_graphs; ++g) cluster_max_block(a, g, mm);
+    cluster_scan_single(a);
+    for (int g = 0; g < n_graphs; ++g) cluster_add_block(a, g);
+    (void)stream;
+#else
+    hipLaunchKernelGGL(k_cluster_max, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_cluster_scan, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(k_cluster_add, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

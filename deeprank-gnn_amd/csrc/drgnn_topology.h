@@ -407,6 +407,11 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         }
     }
 
+    if (a.cluster0 == nullptr) {          // graph-only build (stand-alone conv layers): no pooling
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = 0; tv.p[DRGNN_TI_NE1][g] = 0; tv.p[DRGNN_TI_NC1][g] = 0; }
+        BARRIER();
+        return;
+    }
     // ---- depth-0 clusters (touches t1, t2, cur, fl, cl, mp, mem only) ----------------------
     const int C = wg_cluster_rank(tv, g, a.cluster0 + n0, N, s);
     {

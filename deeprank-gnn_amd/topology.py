@@ -38,7 +38,7 @@ class Topology(object):
 
     # ---------------------------------------------------------------------------
     @classmethod
-    def from_batch(cls, data, api=None, with_level1=True, check=False, need_weights=True):
+    def from_batch(cls, data, api=None, with_level1=True, check=False, need_weights=True, graph_only=False):
         """Build from a ``Batch``-like object (attribute access only).  ``need_weights=False``
         skips everything that involves ``edge_attr`` (GINet's attention is identically 1 and
         FoutLayer never reads it, so only sGAT needs the pooled, summed edge attributes)."""
@@ -57,8 +57,11 @@ class Topology(object):
                                  "broadcast edge_attr [E,1] over the channels, sGAT.py:76)")
             edge_attr = _contig(edge_attr.reshape(-1), torch.float32)
         cluster0 = _contig(getattr(data, "cluster0", None), torch.int64)
-        if cluster0 is None:
+        if cluster0 is None and not graph_only:
             raise ValueError("the batch has no cluster0 (pre-computed communities, DataSet.py:342-357)")
+        if graph_only:
+            cluster0 = None
+            with_level1 = False
         cluster1 = _contig(getattr(data, "cluster1", None), torch.int64) if with_level1 else None
         d = getattr(data, "__dict__", {})
         n_graphs = d.get("_num_graphs")
@@ -98,6 +101,31 @@ class Topology(object):
         if check:
             topo.check()
         return topo
+
+    @classmethod
+    def single_graph(cls, edge_index, edge_attr, n_nodes, api=None, cluster=None):
+        """Workspace for ONE graph given as bare tensors (the stand-alone layers and the
+        scatter-style functions): CSR/CSC only, or with ``cluster`` also its member lists."""
+        import types
+        dev = edge_index.device if edge_index is not None else cluster.device
+        if edge_index is None:
+            edge_index = torch.zeros((2, 0), dtype=torch.int64, device=dev)
+        shadow = types.SimpleNamespace(
+            edge_index=edge_index, edge_attr=edge_attr,
+            batch=torch.zeros(n_nodes, dtype=torch.int64, device=dev), cluster0=cluster, cluster1=None)
+        shadow.__dict__["_num_graphs"] = 1 if n_nodes > 0 else 0
+        shadow.__dict__["_node_ptr"] = torch.tensor([0, n_nodes], dtype=torch.int32, device=dev)
+        shadow.__dict__["_edge_ptr"] = torch.tensor([0, edge_index.size(1)], dtype=torch.int32, device=dev)
+        shadow.__dict__["_max_nodes"] = n_nodes
+        shadow.__dict__["_max_edges"] = int(edge_index.size(1))
+        return cls.from_batch(shadow, api=api, with_level1=False, graph_only=cluster is None)
+
+    def totals(self):
+        """(C0_total, E1_total, C1_total) -- finalizes and synchronises."""
+        self.finalize()
+        B = self.n_graphs
+        vals = torch.stack([self.array("CPTR0")[B], self.array("E1PTR")[B], self.array("CPTR1")[B]]).tolist()
+        return int(vals[0]), int(vals[1]), int(vals[2])
 
     # ---------------------------------------------------------------------------
     def array(self, name):

@@ -108,7 +108,8 @@ int drgnn_topology_layout(int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
  * edge_index  int64 [2,E] (global node ids, edges grouped by graph)
  * edge_attr   float [E] or NULL (one edge feature, as the reference supports)
  * batch       int64 [N] ascending graph id per node
- * cluster0    int64 [N]  per-graph cluster ids (any integers; made consecutive here)
+ * cluster0    int64 [N]  per-graph cluster ids (any integers; made consecutive here);
+ *             NULL = graph-only build (CSR0/CSC0/W0), used by the stand-alone conv layers
  * cluster1    int64 [L1] per-graph ids of the depth-0 clusters; L1 must equal sum C0_g;
  *             may be NULL (then only depth 0 is built: CL1.. untouched)
  * node_ptr / edge_ptr / c1_ptr  int32 [B+1] or NULL: per-graph offsets if the caller
@@ -216,6 +217,41 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
 int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,
                            int64_t n_graphs, drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2,
                            float* grad_x, void* stream);
+
+/* ---- stand-alone layers and pooling functions (the reference's function-level API) ----------
+ * For custom nets built from the reference's layers (README "custom GNN" snippet).  A single
+ * convolution of arbitrary width H <= 128 on ONE graph described by a graph-only topology
+ * workspace (drgnn_topology_build with n_graphs = 1, cluster0 = NULL):
+ *   GINetConvLayer.forward (ginet.py:50-73), sGraphAttentionLayer.forward (sGAT.py:62-93),
+ *   FoutLayer.forward (foutnet.py:56-82).  `u` / `du` are [N, H] (GINet) or [N, 2H] scratch;
+ *   partials holds drgnn_conv_layer_slabs(N) * drgnn_conv_layer_partial_elems() floats.
+ */
+int64_t drgnn_conv_layer_slabs(int64_t n_nodes);
+int64_t drgnn_conv_layer_partial_elems(int32_t kind, int32_t F, int32_t H);
+int drgnn_conv_layer_forward(int32_t kind, const float* x, int64_t n_nodes, int32_t F, int32_t H,
+                             const drgnn_conv_params* p, const int32_t* ws_i32, const float* ws_f32,
+                             int64_t n_edges, float* u, float* out, void* stream);
+int drgnn_conv_layer_backward(int32_t kind, const float* x, int64_t n_nodes, int32_t F, int32_t H,
+                              const drgnn_conv_params* p, const int32_t* ws_i32, const float* ws_f32,
+                              int64_t n_edges, const float* grad_out, float* du, float* partials,
+                              const drgnn_conv_grads* g, float* grad_x, void* stream);
+/* Cluster pooling over the depth-0 member lists of a FINALIZED topology workspace:
+ * op 0 = max with argmax (scatter_max inside community_pooling.py:197 / max_pool_x [3P]; first
+ * maximum in member order, empty cluster -> 0 / arg = N), op 1 = mean (scatter_mean,
+ * community_pooling.py:212).  out [C0_total, H] compact, arg = GLOBAL node id. */
+int drgnn_segpool_forward(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                          const float* x, int32_t H, int32_t op, float* out, int64_t* arg, void* stream);
+int drgnn_segmax_backward(const float* grad_out, const int64_t* arg, int64_t n_clusters, int32_t H,
+                          int64_t n_nodes, float* grad_x /* zero-filled */, void* stream);
+/* pool_edge [3P] result of a FINALIZED workspace in the reference's form: edge_index int64
+ * [2, e1_total] (consecutive global cluster ids, sorted by (row, col)), edge_attr [e1_total]. */
+int drgnn_pooled_edges_export(const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges,
+                              int64_t n_graphs, int64_t e1_total, int64_t* edge_index, float* edge_attr,
+                              void* stream);
+/* get_preloaded_cluster (community_pooling.py:25-30): cluster[batch == g] += running offset, in
+ * place, no host round trips.  scratch: n_graphs + 1 int64. */
+int drgnn_cluster_offset(int64_t* cluster, const int32_t* node_ptr, int64_t n_graphs, int64_t* scratch,
+                         void* stream);
 
 /* ---- dense head, loss and optimiser (the rest of one training step) -----------------------
  * What the reference trainer runs around the message-passing body for every mini-batch
