@@ -92,7 +92,7 @@ def main():
 
         if world == 1:
             def fwd_bwd():
-                trainer.train_step(batch)          # 5 launches incl. the fused reduce+Adam
+                trainer.train_step(batch)          # 4 launches: topology, fwd, bwd(+head+loss), reduce+Adam
 
             def all_reduce():
                 pass

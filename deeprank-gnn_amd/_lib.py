@@ -98,11 +98,13 @@ class Api(object):
         lib.drgnn_net_scratch_elems.argtypes = [_c_i32, _c_i32, _c_i64, _c_i64, _c_i64]
         lib.drgnn_net_scratch_elems.restype = _c_i64
         lib.drgnn_net_forward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 3 + [_c_i64] * 3 +
-                                          [_c_i32] * 3 + [_vp] * 6)
+                                          [_c_i32] * 3 + [_vp] * 7)
+        lib.drgnn_net_backward_fused_head.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc)] +
+                                                      [_vp] * 6 + [_c_i64] * 3 + [_c_i32] * 3 + [_vp] * 9)
         lib.drgnn_net_backward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 4 + [_c_i64] * 3 +
                                            [_c_i32] * 3 + [_vp] * 3 + [_vp] * 5)
         lib.drgnn_train_update.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] +
-                                           [ctypes.POINTER(ConvGrads)] * 2 + [_vp] + [_c_i32] * 3 +
+                                           [ctypes.POINTER(ConvGrads)] * 2 + [_vp, _c_i64] + [_c_i32] * 3 +
                                            [_c_i64] + [_vp] * 4 + [_c_i64] + [_vp] * 2 +
                                            [ctypes.c_float] * 4 + [_vp])
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
@@ -173,11 +175,20 @@ class Api(object):
         return int(self.lib.drgnn_net_scratch_elems(kind, n_feat, n_nodes, n_edges, n_graphs))
 
     def net_forward(self, desc, x, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, max_nodes, max_edges,
-                    max_c0, xp, arg0, arg1, readout, scratch, stream):
+                    max_c0, xp, arg0, arg1, readout, scratch, stream, step_inc=None):
         _check(self.lib.drgnn_net_forward(
             ctypes.byref(desc), _ptr(x), _ptr(ws_i32), _ptr(ws_f32), n_nodes, n_edges, n_graphs,
-            max_nodes, max_edges, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1), _ptr(readout), _ptr(scratch), stream),
-            "drgnn_net_forward")
+            max_nodes, max_edges, max_c0, _ptr(xp), _ptr(arg0), _ptr(arg1), _ptr(readout), _ptr(scratch),
+            _ptr(step_inc), stream), "drgnn_net_forward")
+
+    def net_backward_fused_head(self, desc, head, x, readout, target, step, ws_i32, ws_f32, n_nodes, n_edges,
+                                n_graphs, max_nodes, max_edges, max_c0, xp, arg0, arg1, pred, head_partials,
+                                grad_x, partials, scratch, stream):
+        _check(self.lib.drgnn_net_backward_fused_head(
+            ctypes.byref(desc), ctypes.byref(head), _ptr(x), _ptr(readout), _ptr(target), _ptr(step),
+            _ptr(ws_i32), _ptr(ws_f32), n_nodes, n_edges, n_graphs, max_nodes, max_edges, max_c0, _ptr(xp),
+            _ptr(arg0), _ptr(arg1), _ptr(pred), _ptr(head_partials), _ptr(grad_x), _ptr(partials),
+            _ptr(scratch), stream), "drgnn_net_backward_fused_head")
 
     def net_backward(self, desc, x, grad_readout, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
                      max_nodes, max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream,
@@ -190,7 +201,8 @@ class Api(object):
     def train_update(self, desc, conv_partials, n_graphs, g1, g2, head_partials, R, H, O, head_offset,
                      flat_p, flat_g, exp_avg, exp_avg_sq, step, loss, lr, beta1, beta2, eps, stream):
         _check(self.lib.drgnn_train_update(
-            ctypes.byref(desc), _ptr(conv_partials), n_graphs, g1, g2, _ptr(head_partials), R, H, O,
+            ctypes.byref(desc), _ptr(conv_partials), n_graphs, g1, g2, _ptr(head_partials),
+            head_partials.size(0), R, H, O,
             head_offset, _ptr(flat_p), _ptr(flat_g), _ptr(exp_avg), _ptr(exp_avg_sq), flat_p.numel(),
             _ptr(step), _ptr(loss), lr, beta1, beta2, eps, stream), "drgnn_train_update")
 

@@ -258,17 +258,18 @@ DEV void update_store(const UpdateArgs& u, float* dst, float g) {
     adam_item(u.ad, (int64_t)(dst - u.ad.grad));
 }
 
-DEV void update_head_item(const UpdateArgs& u, int item) {
+// sum of one head-partial element over the slabs w = first, first+stride, ...
+DEV float update_head_sum(const UpdateArgs& u, int item, int first, int stride) {
+    const float* src = u.h.partials + item;
+    float acc = 0.0f;
+#pragma unroll 4
+    for (int w = first; w < u.h.n_wg; w += stride) acc += src[(long)w * u.h.P];
+    return acc;
+}
+DEV void update_head_store(const UpdateArgs& u, int item, float acc) {
     const int n_grad = u.h.P - 2;
-    if (item < n_grad) {
-        float acc = 0.0f;
-        for (int w = 0; w < u.h.n_wg; ++w) acc += u.h.partials[(long)w * u.h.P + item];
-        update_store(u, u.h.grad + item, acc);
-    } else if (item == n_grad) {
-        float acc = 0.0f;
-        for (int w = 0; w < u.h.n_wg; ++w) acc += u.h.partials[(long)w * u.h.P + n_grad];
-        if (u.h.loss) u.h.loss[0] = acc;
-    }
+    if (item < n_grad) update_store(u, u.h.grad + item, acc);
+    else if (item == n_grad && u.h.loss) u.h.loss[0] = acc;
 }
 
 #ifndef DRGNN_EMU
@@ -341,11 +342,13 @@ __global__ void __launch_bounds__(256) k_head_reduce(HeadReduceArgs a) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.P - 1) head_reduce_item(a, i);
 }
+// 64 gradient elements per workgroup; the 4 waves sum interleaved quarters of the partial
+// slabs, the quarter sums are combined in fixed order, then Adam is applied to that element
 __global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
     __shared__ float quarter[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
     if ((int)blockIdx.x < u.conv_blocks) {
         const ReduceArgs& a = u.r;
-        const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
         const int64_t item = (int64_t)blockIdx.x * 64 + lane;
         const bool live = item < (int64_t)a.n_branch * a.n_partial && reduce_live(a, (int)(item % a.n_partial));
         const int br = live ? (int)(item / a.n_partial) : 0, p = live ? (int)(item % a.n_partial) : 0;
@@ -356,7 +359,12 @@ __global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
             if (d) update_store(u, d, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
         }
     } else {
-        update_head_item(u, ((int)blockIdx.x - u.conv_blocks) * 256 + (int)threadIdx.x);
+        const int item = ((int)blockIdx.x - u.conv_blocks) * 64 + lane;
+        const bool live = item < u.h.P - 1;
+        quarter[q][lane] = live ? update_head_sum(u, item, q, 4) : 0.0f;
+        __syncthreads();
+        if (q == 0 && live)
+            update_head_store(u, item, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
     }
 }
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
@@ -579,11 +587,16 @@ static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_edges, int32_
     const int64_t lds = drgnn_net_lds_bytes(kind, L.a.net.n_feat, max_nodes, max_edges, max_c0, BWD ? 1 : 0);
     L.capN = 0; L.capE = 0; L.capC = 0; L.gscratch = scratch;
     int64_t use_lds = 0;
+    L.a.hf.stage = 0;
     if (lds > 0 && lds <= DRGNN_LDS_LIMIT) {
         L.capN = max_nodes;
         L.capE = max_edges > 0 ? max_edges : 1;
         L.capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
         use_lds = lds;
+        if (BWD && L.a.hf.enabled) {    // room to keep the head's weights in LDS as well?
+            const int64_t extra = 4 * head_stage_words(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+            if (use_lds + extra <= DRGNN_LDS_LIMIT) { use_lds += extra; L.a.hf.stage = 1; }
+        }
     } else if (!scratch) {
         return DRGNN_E_CAPACITY;
     }
@@ -631,7 +644,7 @@ extern "C" {
 int drgnn_net_forward(const drgnn_net_desc* net, const float* x, const int32_t* ws_i32,
                       const float* ws_f32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
                       int32_t max_nodes, int32_t max_edges, int32_t max_c0, float* xp, int32_t* arg0,
-                      int32_t* arg1, float* readout, float* scratch_f32, void* stream_) {
+                      int32_t* arg1, float* readout, float* scratch_f32, int32_t* step_inc, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
     if (!x || !ws_i32 || !xp || !arg0 || !arg1 || !readout) return DRGNN_E_ARG;
@@ -646,19 +659,21 @@ int drgnn_net_forward(const drgnn_net_desc* net, const float* x, const int32_t* 
     L.a.n_graphs = (int)n_graphs;
     L.a.xp = xp; L.a.arg0 = arg0; L.a.arg1 = arg1; L.a.readout = readout;
     L.a.grad_readout = nullptr; L.a.partials = nullptr; L.a.grad_x = nullptr; L.a.n_partial = 0;
-    L.a.step_inc = nullptr;
+    L.a.step_inc = step_inc;
+    L.a.hf.enabled = 0;
     L.n_edges = n_edges;
     return net_launch<false>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
 }
 
-int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* grad_readout,
-                       const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges,
-                       int64_t n_graphs, int32_t max_nodes, int32_t max_edges, int32_t max_c0,
-                       const float* xp, const int32_t* arg0, const int32_t* arg1, float* grad_x,
-                       float* partials, float* scratch_f32, int32_t* step_inc, void* stream_) {
+static int net_backward_impl(const drgnn_net_desc* net, const float* x, const float* grad_readout,
+                             const HeadFused* hf, const int32_t* ws_i32, const float* ws_f32,
+                             int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
+                             int32_t max_edges, int32_t max_c0, const float* xp, const int32_t* arg0,
+                             const int32_t* arg1, float* grad_x, float* partials, float* scratch_f32,
+                             int32_t* step_inc, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
-    if (!x || !grad_readout || !ws_i32 || !xp || !arg0 || !arg1 || !partials) return DRGNN_E_ARG;
+    if (!x || (!grad_readout && !hf) || !ws_i32 || !xp || !arg0 || !arg1 || !partials) return DRGNN_E_ARG;
     TopoLayout lay;
     topo_layout(n_nodes, n_edges, n_graphs, &lay);
     NetLaunch L;
@@ -672,8 +687,44 @@ int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* g
     L.a.grad_readout = grad_readout; L.a.partials = partials; L.a.grad_x = grad_x;
     L.a.n_partial = (int)net_partial_floats(net->n_feat);
     L.a.step_inc = step_inc;
+    if (hf) L.a.hf = *hf; else L.a.hf.enabled = 0;
     L.n_edges = n_edges;
     return net_launch<true>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
+}
+
+}  // extern "C"
+extern "C" {
+
+int drgnn_net_backward(const drgnn_net_desc* net, const float* x, const float* grad_readout,
+                       const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges,
+                       int64_t n_graphs, int32_t max_nodes, int32_t max_edges, int32_t max_c0,
+                       const float* xp, const int32_t* arg0, const int32_t* arg1, float* grad_x,
+                       float* partials, float* scratch_f32, int32_t* step_inc, void* stream_) {
+    return net_backward_impl(net, x, grad_readout, nullptr, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
+                             max_nodes, max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch_f32,
+                             step_inc, stream_);
+}
+
+int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_desc* hd, const float* x,
+                                  const float* readout, const void* target, const int32_t* step,
+                                  const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes,
+                                  int64_t n_edges, int64_t n_graphs, int32_t max_nodes, int32_t max_edges,
+                                  int32_t max_c0, const float* xp, const int32_t* arg0, const int32_t* arg1,
+                                  float* pred, float* head_partials, float* grad_x, float* partials,
+                                  float* scratch_f32, void* stream_) {
+    if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2 || !readout || !target || !pred || !head_partials)
+        return DRGNN_E_ARG;
+    if (!net || hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
+        return DRGNN_E_WIDTH;
+    HeadFused hf;
+    hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
+    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = -1;
+    hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
+    hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
+    hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
+    hf.readout = readout; hf.step = step; hf.pred = pred; hf.partials = head_partials;
+    return net_backward_impl(net, x, nullptr, &hf, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, max_nodes,
+                             max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch_f32, nullptr, stream_);
 }
 
 int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,
@@ -793,7 +844,8 @@ int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
 
 int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
                        drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
-                       int32_t R, int32_t H, int32_t O, int64_t head_offset, float* flat_param,
+                       int64_t head_slabs, int32_t R, int32_t H, int32_t O, int64_t head_offset,
+                       float* flat_param,
                        float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
                        const int32_t* step, float* loss, float lr, float beta1, float beta2, float eps,
                        void* stream_) {
@@ -813,7 +865,7 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
     }
     r.grad_x = nullptr; r.n_nodes = 0;
     u.h.partials = head_partials;
-    u.h.n_wg = (int)((n_graphs + head_tile(n_graphs) - 1) / head_tile(n_graphs));
+    u.h.n_wg = (int)head_slabs;
     u.h.P = (int)head_partial_floats(R, H, O);
     u.h.grad = flat_grad + head_offset; u.h.loss = loss; u.h.step = nullptr;
     u.ad.param = flat_param; u.ad.grad = flat_grad; u.ad.exp_avg = exp_avg; u.ad.exp_avg_sq = exp_avg_sq;
@@ -821,7 +873,7 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
     u.ad.lr = lr; u.ad.beta1 = beta1; u.ad.beta2 = beta2; u.ad.eps = eps; u.ad.weight_decay = 0.0f;
     const int64_t pitems = (int64_t)net->n_branch * r.n_partial;
     u.conv_blocks = (int)((pitems + 63) / 64);
-    const int head_blocks = (u.h.P - 1 + 255) / 256;
+    const int head_blocks = (u.h.P - 1 + 63) / 64;
 #ifdef DRGNN_EMU
     for (int64_t i = 0; i < pitems; ++i) {
         const int br = (int)(i / r.n_partial), p = (int)(i % r.n_partial);
@@ -829,7 +881,7 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
         float* d = reduce_dst(r, br, p);
         if (d) update_store(u, d, reduce_sum(r, br, p, 0, 1));
     }
-    for (int i = 0; i < u.h.P - 1; ++i) update_head_item(u, i);
+    for (int i = 0; i < u.h.P - 1; ++i) update_head_store(u, i, update_head_sum(u, i, 0, 1));
     (void)stream_; (void)head_blocks;
 #else
     hipLaunchKernelGGL(k_update, dim3((unsigned)(u.conv_blocks + head_blocks)), dim3(256), 0, (hipStream_t)stream_, u);

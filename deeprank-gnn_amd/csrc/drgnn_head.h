@@ -20,9 +20,6 @@
 
 #define DRGNN_HEAD_TILE_SMALL 16     // graphs per workgroup for small batches (latency)
 #define DRGNN_HEAD_TILE_LARGE 64     // ... for large batches (fewer partial slabs)
-#define DRGNN_TASK_REG 0
-#define DRGNN_TASK_CLASS 1
-#define DRGNN_MAX_OUT 16
 #define DRGNN_HEAD_TMP 4096          // LDS floats for split sums / K-split GEMM partials
 
 HD int head_tile(int64_t n_graphs) { return n_graphs <= 512 ? DRGNN_HEAD_TILE_SMALL : DRGNN_HEAD_TILE_LARGE; }
@@ -45,17 +42,9 @@ struct HeadArgs {
     uint32_t seed;
 };
 
-HD int64_t head_partial_floats(int R, int H, int O) { return (int64_t)H * R + H + (int64_t)O * H + O + 2; }
 HD int64_t head_lds_words(int R, int H, int O, int T) {
     return (int64_t)T * (R + 1) + (int64_t)H * (R + 1) + (int64_t)T * (H + 1) + H + (int64_t)O * H + O +
            2 * T * DRGNN_MAX_OUT + 2 * T + DRGNN_HEAD_TMP + 64;
-}
-
-// lowbias32-style counter hash -> uniform 32-bit value for (seed, step, element)
-HD uint32_t drgnn_hash(uint32_t seed, uint32_t step, uint32_t idx) {
-    uint32_t h = seed ^ (step * 0x9E3779B9u) ^ (idx * 0x85EBCA6Bu + 0xC2B2AE35u);
-    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
-    return h;
 }
 
 DEV void head_block(const HeadArgs& a, int blk, float* lds) {

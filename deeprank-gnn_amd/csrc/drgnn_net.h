@@ -111,6 +111,156 @@ DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const fl
 }
 #endif
 
+// ---------------------------------------------------------------------------------
+// Per-graph FC head + loss + its backward, run INSIDE the body-backward workgroups (the head
+// is row-wise: pred_g = fc2(dropout(relu(fc1(readout_g)))) and d loss / d pred_g only needs
+// the batch size), so a training step needs no separate head launch.  Both branch workgroups
+// of a graph evaluate it redundantly (8k MACs); branch 0 alone writes predictions and the
+// head's weight-gradient partial slab  [dW1 H*R][db1 H][dW2 O*H][db2 O][loss][weight].
+// ---------------------------------------------------------------------------------
+#define DRGNN_MAX_OUT 16
+#define DRGNN_TASK_REG 0
+#define DRGNN_TASK_CLASS 1
+
+// lowbias32-style counter hash -> uniform 32-bit value for (seed, step, element)
+HD uint32_t drgnn_hash(uint32_t seed, uint32_t step, uint32_t idx) {
+    uint32_t h = seed ^ (step * 0x9E3779B9u) ^ (idx * 0x85EBCA6Bu + 0xC2B2AE35u);
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    return h;
+}
+HD int64_t head_partial_floats(int R, int H, int O) { return (int64_t)H * R + H + (int64_t)O * H + O + 2; }
+
+struct HeadFused {
+    int enabled;
+    int B, R, H, O, task;
+    float p_drop; uint32_t seed; int step_bias;
+    const float* w1; const float* b1; const float* w2; const float* b2; const float* class_w;
+    const float* y_reg; const int64_t* y_cls;
+    const float* readout;        // [B, R] (forward output)
+    const int32_t* step;
+    float* pred;                 // [B, O]
+    float* partials;             // [B][head_partial_floats]
+    int stage;                   // 1: the launch reserved LDS for W1/b1/W2/b2/readout row
+};
+HD int64_t head_stage_words(int R, int H, int O) { return (int64_t)H * (R + 1) + H + (int64_t)O * H + O + R + 16; }
+
+// scratch `gp`: >= 1024 + H + R + 2*DRGNN_MAX_OUT floats; dr_out: this branch's 32 columns
+// w1/b1/w2/b2/xrow: either the model's tensors in global memory (ldw = R) or their LDS copies
+// made by the prologue burst (ldw = R + 1, padded rows)
+DEV void head_graph(const HeadFused& hf, int g, int br, float* gp, float* dr_out, const float* w1, int ldw,
+                    const float* b1, const float* w2, const float* b2, const float* xrow) {
+    const int R = hf.R, H = hf.H, O = hf.O;
+    float* tmp = gp;
+    float* hid = gp + 1024;
+    float* xr = hid + H;
+    float* outs = xr + R;
+    float* douts = outs + DRGNN_MAX_OUT;
+    const uint32_t step = hf.step ? (uint32_t)(hf.step[0] + hf.step_bias) : 0u;
+    const float keep_scale = (hf.p_drop > 0.0f) ? 1.0f / (1.0f - hf.p_drop) : 1.0f;
+    const double pt = (double)hf.p_drop * 4294967296.0;
+    const uint32_t thresh = (hf.p_drop > 0.0f) ? (uint32_t)(pt > 4294967295.0 ? 4294967295.0 : pt) : 0u;
+    float* part = hf.partials + (long)g * head_partial_floats(R, H, O);
+    float* p_w1 = part;
+    float* p_b1 = p_w1 + (long)H * R;
+    float* p_w2 = p_b1 + H;
+    float* p_b2 = p_w2 + (long)O * H;
+    float* p_loss = p_b2 + O;
+
+    FOR_TID(r, R) { xr[r] = xrow[r]; }
+    BARRIER();
+    {   // fc1: 8 lanes per hidden unit, each a contiguous slice of the row (coalesced W1 read)
+        const int per = (R + 7) >> 3;
+        FOR_TID(t, H * 8) {
+            const int h = t >> 3, q = t & 7;
+            const int lo = q * per, hi = imin(R, lo + per);
+            float acc = 0.0f;
+            for (int r = lo; r < hi; ++r) acc = fmaf(w1[h * ldw + r], xr[r], acc);
+            tmp[t] = acc;
+        }
+    }
+    BARRIER();
+    FOR_TID(h, H) {
+        float v = b1[h];
+        for (int q = 0; q < 8; ++q) v += tmp[h * 8 + q];
+        v = v > 0.0f ? v : 0.0f;
+        if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
+        hid[h] = v;
+    }
+    BARRIER();
+    FOR_TID(t, O * 16) {
+        const int o = t >> 4, q = t & 15;
+        float acc = 0.0f;
+        for (int h = q; h < H; h += 16) acc = fmaf(hid[h], w2[o * H + h], acc);
+        tmp[t] = acc;
+    }
+    BARRIER();
+    FOR_TID(i, 1) {
+        for (int o = 0; o < O; ++o) {
+            float acc = b2[o];
+            for (int q = 0; q < 16; ++q) acc += tmp[o * 16 + q];
+            outs[o] = acc;
+            if (br == 0) hf.pred[(long)g * O + o] = acc;
+        }
+        float loss = 0.0f, wsum = 1.0f;
+        if (hf.task == DRGNN_TASK_REG) {
+            const float inv = 1.0f / (float)(hf.B * O);
+            for (int o = 0; o < O; ++o) {
+                const float d = outs[o] - hf.y_reg[g];
+                loss += d * d * inv;
+                douts[o] = 2.0f * d * inv;
+            }
+        } else {
+            float denom = 0.0f;
+            for (int q = 0; q < hf.B; ++q) denom += hf.class_w ? hf.class_w[hf.y_cls[q]] : 1.0f;
+            const int yc = (int)hf.y_cls[g];
+            const float wy = hf.class_w ? hf.class_w[yc] : 1.0f;
+            float mx = outs[0];
+            for (int o = 1; o < O; ++o) mx = outs[o] > mx ? outs[o] : mx;
+            float se = 0.0f;
+            for (int o = 0; o < O; ++o) se += expf(outs[o] - mx);
+            const float lse = logf(se) + mx;
+            loss = wy * (lse - outs[yc]) / denom;
+            for (int o = 0; o < O; ++o) douts[o] = wy * (expf(outs[o] - lse) - (o == yc ? 1.0f : 0.0f)) / denom;
+            wsum = wy;
+        }
+        if (br == 0) { p_loss[0] = loss; p_loss[1] = wsum; }
+    }
+    BARRIER();
+    FOR_TID(h, H) {
+        float acc = 0.0f;
+        for (int o = 0; o < O; ++o) acc = fmaf(douts[o], w2[o * H + h], acc);
+        const float hv = hid[h];
+        const float d = (hv != 0.0f) ? acc * keep_scale : 0.0f;     // relu' and dropout mask
+        if (br == 0) {
+            for (int o = 0; o < O; ++o) p_w2[(long)o * H + h] = douts[o] * hv;
+            p_b1[h] = d;
+        }
+        hid[h] = d;
+    }
+    if (br == 0) { FOR_TID(o, O) { p_b2[o] = douts[o]; } }
+    BARRIER();
+    if (br == 0) {
+        const FastDiv dR = fastdiv_make(R);
+        FOR_TID(e, H * R) {
+            const int h = fastdiv(dR, e);
+            p_w1[e] = hid[h] * xr[fastmod(dR, e, h)];
+        }
+    }
+    FOR_TID(t, DRGNN_H2 * 32) {     // d readout, this branch's 32 columns: 32 partial sums per column
+        const int r = t & 31, q = t >> 5;
+        float acc = 0.0f;
+        for (int h = q; h < H; h += 32) acc = fmaf(hid[h], w1[h * ldw + br * DRGNN_H2 + r], acc);
+        tmp[t] = acc;
+    }
+    BARRIER();
+    FOR_TID(r, DRGNN_H2) {
+        float acc = 0.0f;
+        for (int q = 0; q < 32; ++q) acc += tmp[q * 32 + r];
+        dr_out[r] = acc;
+    }
+    BARRIER();
+}
+
 // ---- per-launch description ----------------------------------------------------------
 struct NetArgs {
     drgnn_net_desc net;
@@ -128,7 +278,8 @@ struct NetArgs {
     float* partials;         // [B*n_branch][P]
     float* grad_x;           // [n_branch][Ntot][F] or null (summed over branches by the reducer)
     int n_partial;           // P
-    int32_t* step_inc;       // optional optimiser step counter, incremented once per backward launch
+    int32_t* step_inc;       // optional optimiser step counter, incremented once per launch
+    HeadFused hf;            // backward: per-graph FC head + loss instead of grad_readout
 };
 
 // ---- scratch (LDS, or a global slab for graphs that do not fit) -------------------------
@@ -162,6 +313,7 @@ struct NetScratch {
     float* sc1;   // [capC]
     float* gp;    // [2048]        K-split GEMM partials
     float* misc;  // [64]
+    float* end;   // first word after the carve (head staging area of the fused backward)
 };
 
 // Forward and backward stage different subsets; `bwd` selects the carve.  Keep the two
@@ -226,6 +378,7 @@ DEV NetScratch net_carve(float* base, int kind, int F, int capN, int capE, int c
 #define X(name, words, cond) s.name = (decltype(s.name))p; p += (cond) ? (long)(words) : 0;
     NET_CARVE_LIST(X)
 #undef X
+    s.end = p;
     return s;
 }
 
@@ -372,6 +525,9 @@ DEV void net_forward_graph(const NetArgs& a, int g, int br, float* scratch, int 
     NetScratch s = net_carve(scratch, KIND, F, capN, capE, capC, 0);
     const long nodeoff = (long)br * a.n_nodes + d.n0;
 
+    if (a.step_inc != nullptr && g == 0 && br == 0) {
+        FOR_TID(i, 1) { a.step_inc[0] = a.step_inc[0] + 1; }
+    }
     // ---- one burst of independent loads: everything this graph needs -> LDS ------------
     PHASE_MARK();
     const drgnn_conv_params& c1 = a.net.conv1[br];
@@ -520,7 +676,7 @@ DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int
     NetScratch s = net_carve(scratch, KIND, F, capN, capE, capC, 1);
     const long nodeoff = (long)br * a.n_nodes + d.n0;
     const int width = DRGNN_H2 * a.net.n_branch;
-    const float* dr = a.grad_readout + (long)g * width + br * DRGNN_H2;
+    const float* dr = a.hf.enabled ? nullptr : a.grad_readout + (long)g * width + br * DRGNN_H2;
     float* part = a.partials + ((long)g * a.net.n_branch + br) * a.n_partial;
     float* p_w1n = part;
     float* p_w1s = p_w1n + (long)F * DRGNN_H1;
@@ -538,11 +694,23 @@ DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int
     const drgnn_conv_params& c2 = a.net.conv2[br];
     const float* xg = a.x + (long)d.n0 * F;
     const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C);
+    const bool head_staged = burst && a.hf.enabled && a.hf.stage && a.hf.H * a.hf.R <= 8 * DRGNN_NTHREADS &&
+                             a.hf.O * a.hf.H <= 2 * DRGNN_NTHREADS && a.hf.H <= DRGNN_NTHREADS;
     if (burst) {
         BurstX<4> bx;       burst_load_x(bx, xg, d.N, F);
         BurstW<1> bw1, bw2, bs1, bs2;
         burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
         burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+        BurstW<8> bhw1;
+        Burst<float, 1> bhb1, bhb2, bhx;
+        Burst<float, 2> bhw2;
+        if (head_staged) {
+            burst_load_w(bhw1, a.hf.w1, a.hf.R, 1, a.hf.H, a.hf.R);
+            burst_load(bhb1, a.hf.b1, a.hf.H);
+            burst_load(bhw2, a.hf.w2, a.hf.O * a.hf.H);
+            burst_load(bhb2, a.hf.b2, a.hf.O);
+            burst_load(bhx, a.hf.readout + (long)g * a.hf.R, a.hf.R);
+        }
         Burst<int, 1> bcp0, bcp1, bdg0, bdg1;
         Burst<int, 2> bix0, bix1, bts0, bts1;
         Burst<int, 4> ba0;
@@ -577,6 +745,15 @@ DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int
         burst_store(bcp1, s.rp1); burst_store(bix1, s.ix1);
         burst_store(ba0, s.a0); burst_store(ba1, s.a1);
         burst_store(bxp, s.xp); burst_store(bdr, s.misc);
+        if (head_staged) {
+            float* hw1 = s.end;
+            float* hb1 = hw1 + (long)a.hf.H * (a.hf.R + 1);
+            float* hw2 = hb1 + a.hf.H;
+            float* hb2 = hw2 + (long)a.hf.O * a.hf.H;
+            burst_store_w(bhw1, hw1, a.hf.R + 1);
+            burst_store(bhb1, hb1); burst_store(bhw2, hw2); burst_store(bhb2, hb2);
+            burst_store(bhx, hb2 + a.hf.O);
+        }
         if (KIND != DRGNN_GINET) {
             burst_store_w(bs1, s.ws1, DRGNN_W1LD);
             burst_store_w(bs2, s.ws2, DRGNN_W2LD);
@@ -605,11 +782,24 @@ DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int
         stage_i32(s.a0, a.arg0 + nodeoff * DRGNN_H1, d.C * DRGNN_H1);
         stage_i32(s.a1, a.arg1 + nodeoff * DRGNN_H2, d.C1 * DRGNN_H2);
         stage_f32(s.xp, a.xp + nodeoff * DRGNN_H1, d.C * DRGNN_H1);
-        stage_f32(s.misc, dr, DRGNN_H2);
+        if (dr != nullptr) stage_f32(s.misc, dr, DRGNN_H2);
     }
     FOR_TID(item, d.C * DRGNN_H2) { s.z2[item] = 0.0f; }
     FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }
     BARRIER();
+    if (a.hf.enabled) {      // FC head + loss + their backward for this graph: d loss / d readout -> s.misc
+        const HeadFused& hf = a.hf;
+        if (head_staged) {
+            float* hw1 = s.end;
+            float* hb1 = hw1 + (long)hf.H * (hf.R + 1);
+            float* hw2 = hb1 + hf.H;
+            float* hb2 = hw2 + (long)hf.O * hf.H;
+            float* hx = hb2 + hf.O;
+            head_graph(hf, g, br, s.gp, s.misc, hw1, hf.R + 1, hb1, hw2, hb2, hx);
+        } else {
+            head_graph(hf, g, br, s.gp, s.misc, hf.w1, hf.R, hf.b1, hf.w2, hf.b2, hf.readout + (long)g * hf.R);
+        }
+    }
 
     // ---- depth-1 max + mean backward: dZ2 (relu mask folded into arg1 = -1) ------------
     net_row_coefs<KIND>(d.C, s.dg1, s.ew1, s.dv1, s.sc1);

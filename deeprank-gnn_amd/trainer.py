@@ -95,7 +95,7 @@ class FusedTrainer(object):
         hd.class_w = None if self.class_w is None else self.class_w.data_ptr()
         return hd
 
-    def _body_forward(self, batch, topo, stream):
+    def _body_forward(self, batch, topo, stream, step_inc=None):
         api = self.api
         x = batch.x.contiguous()
         n_nodes, n_feat = x.shape
@@ -114,7 +114,7 @@ class FusedTrainer(object):
                                   dtype=torch.float32, device=dev)
         desc = _describe(self.kind, n_feat, self.live, nb)
         api.net_forward(desc, x, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes,
-                        topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream)
+                        topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream, step_inc=step_inc)
         return x, desc, xp, arg0, arg1, readout, scratch
 
     def _backward(self, batch, topo, fused_update):
@@ -122,33 +122,40 @@ class FusedTrainer(object):
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
         stream = _lib.current_stream(batch.x)
-        x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream)
+        x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(
+            batch, topo, stream, step_inc=self.step if fused_update else None)
         B = topo.n_graphs
         dev = x.device
         n_nodes, n_feat = x.shape
         pred = torch.empty((B, self.O), dtype=torch.float32, device=dev)
-        grad_readout = torch.empty_like(readout)
-        n_wg = api.head_num_slabs(B)
-        hp = torch.empty((max(n_wg, 1), api.head_partial_elems(self.R, self.H, self.O)),
-                         dtype=torch.float32, device=dev)
         y = batch.y
         y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
-        api.head_step(self._head_desc(True), readout, y, B, self.step, pred, grad_readout, hp, stream)
         partials = torch.empty((max(B * self.n_branch, 1), api.net_partial_elems(self.kind, n_feat)),
                                dtype=torch.float32, device=dev)
-        api.net_backward(desc, x, grad_readout, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B,
-                         topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1, None, partials,
-                         scratch, stream, step_inc=self.step if fused_update else None)
         g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
         g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
         for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, self.n_branch)):
             _fill_grads(g1[b], self.kind, l1, n_feat, H1)
             _fill_grads(g2[b], self.kind, l2, H1, H2)
         if fused_update:
+            # 3 launches after the topology: forward (++step), backward with the per-graph head
+            # + loss inside, reduce + Adam
+            hp = torch.empty((max(B, 1), api.head_partial_elems(self.R, self.H, self.O)),
+                             dtype=torch.float32, device=dev)
+            api.net_backward_fused_head(desc, self._head_desc(True), x, readout, y, self.step, topo.ws_i32,
+                                        topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes, topo.max_edges,
+                                        topo.max_c0, xp, arg0, arg1, pred, hp, None, partials, scratch, stream)
             api.train_update(desc, partials, B, g1, g2, hp, self.R, self.H, self.O, self.head_grad_offset,
                              self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step, self.loss,
                              self.lr, self.betas[0], self.betas[1], self.eps, stream)
         else:
+            grad_readout = torch.empty_like(readout)
+            hp = torch.empty((max(api.head_num_slabs(B), 1), api.head_partial_elems(self.R, self.H, self.O)),
+                             dtype=torch.float32, device=dev)
+            api.head_step(self._head_desc(True), readout, y, B, self.step, pred, grad_readout, hp, stream)
+            api.net_backward(desc, x, grad_readout, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B,
+                             topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1, None, partials,
+                             scratch, stream)
             api.net_reduce_grads(desc, partials, n_nodes, B, g1, g2, None, stream)
             api.head_reduce(hp, B, self.R, self.H, self.O,
                             self.flat_g.data_ptr() + 4 * self.head_grad_offset, self.loss, self.step, stream)
@@ -185,7 +192,7 @@ class FusedTrainer(object):
 
     def train_step(self, batch, topo=None, n_global=None, group=None):
         """One optimisation step on ``batch``; returns the (device) loss of this rank's shard.
-        Single process: 5 launches (topology, body fwd, head, body bwd, reduce+Adam).  With
+        Single process: 4 launches (topology, body fwd, body bwd incl. head + loss, reduce+Adam).  With
         torch.distributed initialised: reduce, ONE all-reduce of the flat gradient, Adam."""
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if not distributed and self.weight_decay == 0.0:

@@ -193,7 +193,8 @@ int drgnn_net_forward(const drgnn_net_desc* net, const float* x,
                       int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
                       int32_t max_nodes, int32_t max_edges, int32_t max_c0,
                       float* xp, int32_t* arg0, int32_t* arg1, float* readout,
-                      float* scratch_f32, void* stream);
+                      float* scratch_f32, int32_t* step_inc /* optional: ++*step_inc once */,
+                      void* stream);
 
 /* Backward of the above.  grad_readout float [B][32*n_branch].  Every workgroup writes its
  * graph's parameter-gradient contribution into `partials` (float [n_graphs*n_branch][P],
@@ -274,6 +275,19 @@ typedef struct drgnn_head_desc {
     const float* class_w;     /* [O] class weights or NULL                                    */
 } drgnn_head_desc;
 
+/* Backward of the body with the FC head, loss and their backward evaluated per graph INSIDE the
+ * same launch (the head is row-wise), instead of taking grad_readout from drgnn_head_step:
+ * reads readout [B,32*n_branch] (forward output) and the targets, writes pred [B,O], one head
+ * partial slab per GRAPH (head_partials [B][drgnn_head_partial_elems]) and the conv partials.
+ * Dropout stream id = *step - 1 (the forward launch of the same step has incremented it). */
+int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_desc* head, const float* x,
+                                  const float* readout, const void* target, const int32_t* step,
+                                  const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes,
+                                  int64_t n_edges, int64_t n_graphs, int32_t max_nodes, int32_t max_edges,
+                                  int32_t max_c0, const float* xp, const int32_t* arg0, const int32_t* arg1,
+                                  float* pred, float* head_partials, float* grad_x, float* partials,
+                                  float* scratch_f32, void* stream);
+
 /* One workgroup per tile of graphs (16 for B <= 512, else 64; drgnn_head_num_slabs()).  Writes pred [B,O]; when train: grad_readout [B,R]
  * (d loss / d readout for the mean loss over the B graphs) and one partial slab per workgroup
  * ([dW1 H*R][db1 H][dW2 O*H][db2 O][loss][weight], drgnn_head_partial_elems() floats).
@@ -301,8 +315,8 @@ int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * weight_decay is not supported here (use reduce + drgnn_adam_step). */
 int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
                        drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2,
-                       const float* head_partials, int32_t R, int32_t H, int32_t O,
-                       int64_t head_offset, float* flat_param, float* flat_grad, float* exp_avg,
+                       const float* head_partials, int64_t head_slabs /* rows of head_partials */,
+                       int32_t R, int32_t H, int32_t O, int64_t head_offset, float* flat_param, float* flat_grad, float* exp_avg,
                        float* exp_avg_sq, int64_t n_param, const int32_t* step, float* loss,
                        float lr, float beta1, float beta2, float eps, void* stream);
 

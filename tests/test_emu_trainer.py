@@ -107,8 +107,9 @@ def test_split_path_equals_fused_path_and_ragged_head_tiles():
         lb = float(tb.loss)
         tb.all_reduce_gradients()          # no process group: no-op
         tb.apply_update()
-        assert la == lb
-    assert torch.equal(ta.flat_p, tb.flat_p) and torch.equal(ta.flat_g, tb.flat_g)
+        np.testing.assert_allclose(la, lb, rtol=1e-6)     # per-graph head vs 16-graph tiles: same math,
+    np.testing.assert_allclose(ta.flat_p.numpy(), tb.flat_p.numpy(), rtol=1e-5, atol=1e-6)   # different summation order
+    np.testing.assert_allclose(ta.flat_g.numpy(), tb.flat_g.numpy(), rtol=1e-4, atol=1e-5)
     assert int(ta.step) == int(tb.step) == 2
     # and against torch autograd on the same 37 graphs
     ref = sGAT(8, 1, 1)
