@@ -49,6 +49,11 @@ def parse():
                     help="native: FusedTrainer step (our head/loss/Adam kernels) replayed from a hipGraph; "
                          "graph/eager: torch autograd + torch.optim.Adam around the fused body")
     ap.add_argument("--net", choices=["GINet", "sGAT", "FoutNet"], default="GINet")
+    ap.add_argument("--overlap", action="store_true",
+                    help="native mode (experimental): build the next step's topology on a second stream "
+                         "concurrently with the current step (double-buffered).  Measured SLOWER under "
+                         "hipGraph replay on MI355X (78.9 vs 67.2 us/step): the fork/join edges cost more "
+                         "than the overlap gains, so it is off by default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -85,14 +90,37 @@ def main():
     native = args.mode.startswith("native")
     capture = args.mode in ("native", "graph")
     need_w = args.net == "sGAT"
+    overlap = native and capture and args.overlap
+    steps_per_call = 2 if overlap else 1
     if native:
         from deeprank_gnn_amd.trainer import FusedTrainer
         trainer = FusedTrainer(net, lr=1e-3, task="reg", seed=1234 + rank)
         loss_out = trainer.loss
+        # two persistent topology workspaces: while step t trains out of one, the topology of step
+        # t+1 is (re)built into the other on a second stream -- it depends on index tensors only
+        topos = [Topology.from_batch(batch, need_weights=need_w) for _ in range(2)]
+        side_build = torch.cuda.Stream()
+
+        def half_step(k, fused):
+            main = torch.cuda.current_stream()
+            if overlap:
+                side_build.wait_stream(main)                 # fork
+                with torch.cuda.stream(side_build):
+                    topos[1 - k].rebuild()
+                cur = topos[k]
+            else:
+                cur = topos[0].rebuild()
+            if fused:
+                trainer.train_step(batch, topo=cur)          # fwd, bwd(+head+loss), reduce+Adam
+            else:
+                trainer.compute_gradients(batch, topo=cur)
+            if overlap:
+                main.wait_stream(side_build)                 # join
 
         if world == 1:
             def fwd_bwd():
-                trainer.train_step(batch)          # 4 launches: topology, fwd, bwd(+head+loss), reduce+Adam
+                for k in range(steps_per_call):
+                    half_step(k, True)
 
             def all_reduce():
                 pass
@@ -100,8 +128,11 @@ def main():
             def reduce_and_step():
                 pass
         else:
+            steps_per_call = 1
+            state = {"k": 0}
+
             def fwd_bwd():
-                trainer.compute_gradients(batch)
+                half_step(state["k"], False)
 
             def all_reduce():
                 trainer.all_reduce_gradients()
@@ -137,39 +168,66 @@ def main():
                 reduce_and_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        g1 = torch.cuda.CUDAGraph()
-        g2 = torch.cuda.CUDAGraph()
         if world == 1:
+            g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 fwd_bwd()
                 reduce_and_step()
 
-            def step():
+            def call():
                 g1.replay()
+        elif native and overlap:
+            # data parallel + overlap: even / odd half-steps are separate graphs, the all-reduce
+            # (RCCL) runs eagerly between the gradient graph and the Adam graph
+            gk = []
+            for k in (0, 1):
+                state["k"] = k
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fwd_bwd()
+                gk.append(g)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                reduce_and_step()
+            steps_per_call = 2
+
+            def call():
+                for k in (0, 1):
+                    gk[k].replay()
+                    all_reduce()
+                    g2.replay()
         else:
+            g1 = torch.cuda.CUDAGraph()
+            g2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 fwd_bwd()
             with torch.cuda.graph(g2):
                 reduce_and_step()
 
-            def step():
+            def call():
                 g1.replay()
                 all_reduce()
                 g2.replay()
     else:
-        def step():
+        def call():
             fwd_bwd()
             all_reduce()
             reduce_and_step()
 
-    for _ in range(args.warmup):
-        step()
+    if args.steps % steps_per_call or args.warmup % steps_per_call:
+        raise SystemExit("--steps and --warmup must be multiples of %d in this mode" % steps_per_call)
+    n_calls, n_warm = args.steps // steps_per_call, args.warmup // steps_per_call
+
+    def step_calls(n):
+        for _ in range(n):
+            call()
+
+    step_calls(n_warm)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    step_calls(n_calls)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -194,7 +252,10 @@ def main():
                                    "200 nodes, ~1000 directed edges, 32 node feats, 50->16 clusters "
                                    "(BASELINE.json configs[1])" % args.net,
                        "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,
-                       "parallelism": "dp%d" % world, "mode": args.mode, "final_loss": final_loss},
+                       "parallelism": "dp%d" % world, "mode": args.mode,
+                       "topology": ("rebuilt every step on a second stream, overlapped with the previous step "
+                                    "(double-buffered)" if overlap else "rebuilt every step, in line"),
+                       "final_loss": final_loss},
         }
         if args.net == "GINet":
             result["roofline"] = measure_roofline(net, batch, dev, value)

@@ -108,6 +108,30 @@ DEV int wg_exscan(int* a, int n, int* part) {
 #else
 DEV int wg_exscan(int* a, int n, int* part) {
     const int t = threadIdx.x;
+    if (n <= DRGNN_NTHREADS) {
+        // one element per lane: wave-level inclusive scan (DPP shuffles), the 16 wave totals go
+        // through LDS and every lane adds the totals of the waves before its own -> 2 barriers
+        const int lane = t & (DRGNN_WAVE - 1), wave = t >> 6;
+        const int v = (t < n) ? a[t] : 0;
+        int inc = v;
+#pragma unroll
+        for (int d = 1; d < DRGNN_WAVE; d <<= 1) {
+            const int o = __shfl_up(inc, d, DRGNN_WAVE);
+            if (lane >= d) inc += o;
+        }
+        if (lane == DRGNN_WAVE - 1) part[wave] = inc;
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < DRGNN_NWAVES; ++w) {
+            const int tw = part[w];
+            base += (w < wave) ? tw : 0;
+            total += tw;
+        }
+        if (t < n) a[t] = base + inc - v;
+        __syncthreads();
+        return total;
+    }
     const int chunk = (n + DRGNN_NTHREADS - 1) / DRGNN_NTHREADS;
     const int lo = imin(t * chunk, n), hi = imin(lo + chunk, n);
     int s = 0;

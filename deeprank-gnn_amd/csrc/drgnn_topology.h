@@ -163,9 +163,11 @@ DEV void topo_flag(const TopoView& tv, int bit, int graph) { ATOMIC_OR(&tv.p[DRG
 // ---------------------------------------------------------------------------------
 template <class F>
 DEV void wg_bucket_sort(int n, int nb, F bucket_of, int* ptr, int* cur, int* tmp,
-                        int* slot_bucket, int* order, int* part) {
-    FOR_TID(b, nb + 1) { ptr[b] = 0; cur[b] = 0; }
-    BARRIER();
+                        int* slot_bucket, int* order, int* part, bool prezeroed = false) {
+    if (!prezeroed) {      // callers that can clear ptr/cur in an earlier phase save this barrier
+        FOR_TID(b, nb + 1) { ptr[b] = 0; cur[b] = 0; }
+        BARRIER();
+    }
     FOR_TID(i, n) { ATOMIC_ADD(&ptr[bucket_of(i)], 1); }
     BARRIER();
     wg_exscan(ptr, nb + 1, part);
@@ -194,9 +196,11 @@ DEV void wg_bucket_sort(int n, int nb, F bucket_of, int* ptr, int* cur, int* tmp
 // ---------------------------------------------------------------------------------
 // min / max of ids[0..n) into mm[0], mm[1]: per-lane running values, a wave butterfly, then
 // ONE atomic per wave (same-address LDS atomics serialise: 2 per element cost ~12k cycles)
-DEV void wg_minmax64(const int64_t* ids, int n, long long* mm) {
-    FOR_TID(i, 1) { mm[0] = LLONG_MAX; mm[1] = LLONG_MIN; }
-    BARRIER();
+DEV void wg_minmax64(const int64_t* ids, int n, long long* mm, bool preinit = false) {
+    if (!preinit) {
+        FOR_TID(i, 1) { mm[0] = LLONG_MAX; mm[1] = LLONG_MIN; }
+        BARRIER();
+    }
 #ifdef DRGNN_EMU
     for (int i = 0; i < n; ++i) {
         if ((long long)ids[i] < mm[0]) mm[0] = (long long)ids[i];
@@ -220,20 +224,25 @@ DEV void wg_minmax64(const int64_t* ids, int n, long long* mm) {
     BARRIER();
 }
 
-DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n, TopoScratch& s) {
-    wg_minmax64(ids, n, s.mm);
+// `prepared`: the caller has, in an earlier phase, set mm = {MAX, MIN} and cleared fl[0..capF)
+DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n, TopoScratch& s,
+                        bool prepared = false) {
+    wg_minmax64(ids, n, s.mm, prepared);
     const long long mn = s.mm[0];
     const long long span = (n > 0) ? (s.mm[1] - mn + 1) : 0;
     int C;
     if (span >= 0 && span <= (long long)(s.capF - 1)) {
         // usual case (ids are small labels): presence flags over [min, max] + scan, O(n + span)
         const int range = (int)span;
-        FOR_TID(v, range + 1) { s.fl[v] = 0; }
-        BARRIER();
+        if (!prepared) {
+            FOR_TID(v, range + 1) { s.fl[v] = 0; }
+            BARRIER();
+        }
         FOR_TID(i, n) { s.fl[(int)((long long)ids[i] - mn)] = 1; }
         BARRIER();
         C = wg_exscan(s.fl, range + 1, s.part);
         FOR_TID(i, n) { s.cl[i] = s.fl[(int)((long long)ids[i] - mn)]; }
+        FOR_TID(b, n + 1) { s.mp[b] = 0; s.cur[b] = 0; }       // for the member bucket sort below
         BARRIER();
     } else {
         // arbitrary ids: rank sort of the members by (id, position), O(n^2) comparisons spread
@@ -259,19 +268,20 @@ DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n
             const bool head = (p == 0 || ids[s.t1[p]] != ids[s.t1[p - 1]]);
             s.cl[s.t1[p]] = s.t2[p] - (head ? 0 : 1);
         }
+        FOR_TID(b, n + 1) { s.mp[b] = 0; s.cur[b] = 0; }
         BARRIER();
     }
     const int* cl = s.cl;
     wg_bucket_sort(n, C, [cl] LAMBDA_DEV(int i) { return cl[i]; }, s.mp, s.cur, s.t1, s.t2, s.mem,
-                   s.part);
+                   s.part, true);
     return C;
 }
 
 // CSC of a CSR matrix with n rows/cols and m stored entries (slot_row[k] = row of slot k).
 DEV void wg_csc_build(int n, int m, const int* col, const int* slot_row, TopoScratch& s,
-                      int32_t* g_colptr, int32_t* g_rowidx, int32_t* g_tslot) {
+                      int32_t* g_colptr, int32_t* g_rowidx, int32_t* g_tslot, bool prezeroed = false) {
     wg_bucket_sort(m, n, [col] LAMBDA_DEV(int k) { return col[k]; }, s.cp, s.cur, s.t1, s.t2, s.t3,
-                   s.part);
+                   s.part, prezeroed);
     FOR_TID(j, m) {
         const int k = s.t3[j];
         g_tslot[j] = k;
@@ -296,14 +306,14 @@ struct TopoArgs {
 };
 
 DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0, int c1_begin,
-                           int c1_len, TopoScratch& s) {
+                           int c1_len, TopoScratch& s, bool prepared = false) {
     const int rowbase = n0 + g;
     const int C0 = tv.p[DRGNN_TI_NC0][g];
     if (c1_len != C0) {
         FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, g); }
     }
     const int n = imin(C0, imax(c1_len, 0));
-    const int C1 = wg_cluster_rank(tv, g, a.cluster1 + c1_begin, n, s);
+    const int C1 = wg_cluster_rank(tv, g, a.cluster1 + c1_begin, n, s, prepared);
     int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
     int32_t* g_mptr1 = tv.p[DRGNN_TI_MPTR1] + rowbase;
     int32_t* g_mem1 = tv.p[DRGNN_TI_MEM1] + n0;
@@ -351,6 +361,8 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     FOR_TID(i, 2 * N + 2) { rp[i] = 0; }
     FOR_TID(i, N + 1) { cur_r[i] = 0; }
     FOR_TID(i, N) { cur_c[i] = 0; }
+    FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-0 cluster ranks
+    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
     BARRIER();
     // ---- CSR0 and CSC0 together: histogram, one scan, slot claim, rank sort by edge id ------
     FOR_TID(e, E) {
@@ -413,7 +425,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         return;
     }
     // ---- depth-0 clusters (touches t1, t2, cur, fl, cl, mp, mem only) ----------------------
-    const int C = wg_cluster_rank(tv, g, a.cluster0 + n0, N, s);
+    const int C = wg_cluster_rank(tv, g, a.cluster0 + n0, N, s, true);
     {
         int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
         int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
@@ -446,6 +458,8 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         s.t2[j] = k;
         s.t3[j] = r;
     }
+    FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-1 cluster ranks
+    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
     BARRIER();
     // rank sort of every pooled row's candidates by (target cluster, position)
     FOR_TID(j, E) {
@@ -494,17 +508,19 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         const int v = s.t1[s.pp[r]];
         s.rp1[r] = v;
         g_rowptr1[r] = v;
+        s.cp[r] = 0;                                          // histogram / cursors of the CSC1 build
+        s.cur[r] = 0;
     }
     FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
     BARRIER();
 
     // ---- CSC1 ----------------------------------------------------------------------
     wg_csc_build(C, E1, s.col1, s.seg, s, tv.p[DRGNN_TI_COLPTR1] + rowbase,
-                 tv.p[DRGNN_TI_ROWIDX1] + e0, tv.p[DRGNN_TI_TSLOT1] + e0);
+                 tv.p[DRGNN_TI_ROWIDX1] + e0, tv.p[DRGNN_TI_TSLOT1] + e0, true);
 
     // ---- depth-1 clusters (when the caller knows where this graph's ids start) --------
     if (a.cluster1 != nullptr && a.c1_ptr != nullptr) {
         const int b = a.c1_ptr[g];
-        topo_graph_level1(tv, a, g, n0, b, a.c1_ptr[g + 1] - b, s);
+        topo_graph_level1(tv, a, g, n0, b, a.c1_ptr[g + 1] - b, s, true);
     }
 }

@@ -93,14 +93,24 @@ class Topology(object):
             scratch = torch.empty(api.topology_scratch_elems(n_nodes, n_edges, n_graphs),
                                   dtype=torch.int32, device=device)
         topo.has_level1 = cluster1 is not None
-        api.topology_build(edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,
-                           n_nodes, n_edges, 0 if cluster1 is None else cluster1.numel(), n_graphs,
-                           max_nodes, max_edges, topo.ws_i32, topo.ws_f32, scratch,
-                           _lib.current_stream(batch))
-        topo._keepalive = (edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch)
+        topo._inputs = (edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch)
+        topo.rebuild()
         if check:
             topo.check()
         return topo
+
+    def rebuild(self):
+        """(Re)run the builder into this object's existing buffers, on torch's current stream --
+        e.g. on a side stream while the previous mini-batch is still training (the build only
+        depends on index tensors, never on parameters).  The input tensors captured at
+        construction are re-read, so refreshing them in place refreshes the topology."""
+        edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch = self._inputs
+        self.api.topology_build(edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,
+                                self.n_nodes, self.n_edges, 0 if cluster1 is None else cluster1.numel(),
+                                self.n_graphs, self.max_nodes, self.max_edges, self.ws_i32, self.ws_f32,
+                                scratch, _lib.current_stream(batch))
+        self._finalized = False
+        return self
 
     @classmethod
     def single_graph(cls, edge_index, edge_attr, n_nodes, api=None, cluster=None):
