@@ -1,0 +1,230 @@
+"""Trainer counterpart of the reference's ``deeprank_gnn.NeuralNet`` (NeuralNet.py) for images
+without torch_geometric / h5py: same constructor vocabulary, ``train`` / ``eval`` / ``test`` /
+``save_model`` / ``pretrained_model=`` flow and the same checkpoint dictionary
+(NeuralNet.py:775-790), with the per-batch body executed by ``FusedTrainer`` (native step).
+
+What is NOT reproduced: ``PreCluster`` (community detection is offline preprocessing; the
+graphs must already carry ``clustering/<method>/depth_{0,1}``, as the reference's fixture does),
+``Metrics`` / plots, and the HDF5 epoch export (written as ``.npz`` with the same group names
+because h5py is absent on the target image).
+"""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import _lib
+from .data import Batch
+from .dataset import GraphDataSet
+from .trainer import FusedTrainer
+
+__all__ = ["NeuralNet"]
+
+
+def _divide(n, percent, shuffle):
+    """reference DivideDataSet (DataSet.py:14-42): shuffled index split."""
+    index = np.arange(n)
+    if shuffle:
+        np.random.shuffle(index)
+    n1 = int(percent[0] * n)
+    return index[:n1], index[n1:]
+
+
+class NeuralNet(object):
+    def __init__(self, database, Net, node_feature=['type', 'polarity', 'bsa'], edge_feature=['dist'],
+                 target='irmsd', lr=0.01, batch_size=32, percent=[1.0, 0.0], database_eval=None, index=None,
+                 class_weights=None, task=None, classes=[0, 1], threshold=None, pretrained_model=None,
+                 shuffle=True, outdir='./', cluster_nodes='mcl', transform_sigmoid=False, device=None,
+                 _api=None):
+        self._api = _api
+        self.device = torch.device(device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu'))
+        if self.device.type != 'cuda' and _api is None:
+            raise _lib.DrgnnError("deeprank_gnn_amd.NeuralNet needs an MI355X: there is no CPU path")
+        self.outdir = outdir
+        if pretrained_model is None:
+            self.node_feature, self.edge_feature, self.target = node_feature, edge_feature, target
+            self.lr, self.batch_size, self.percent, self.index = lr, batch_size, percent, index
+            self.class_weights, self.task, self.classes, self.threshold = class_weights, task, classes, threshold
+            self.shuffle, self.cluster_nodes, self.transform_sigmoid = shuffle, cluster_nodes, transform_sigmoid
+            if self.task is None:                      # NeuralNet.py:64-78
+                if self.target in ['irmsd', 'lrmsd', 'fnat', 'dockQ']:
+                    self.task = 'reg'
+                elif self.target in ['bin_class', 'capri_classes']:
+                    self.task = 'class'
+                else:
+                    raise ValueError("User target detected -> The task argument is required ('class' or 'reg').")
+            if self.threshold is None:
+                self.threshold = self.classes[1] if self.task == 'class' else 0.3
+            opt_state = model_state = None
+        else:
+            state = torch.load(pretrained_model, map_location='cpu', weights_only=False)
+            for dst, src in (('node_feature', 'node'), ('edge_feature', 'edge'), ('target', 'target'),
+                             ('batch_size', 'batch_size'), ('percent', 'percent'), ('lr', 'lr'), ('index', 'index'),
+                             ('class_weights', 'class_weight'), ('task', 'task'), ('classes', 'classes'),
+                             ('threshold', 'threshold'), ('shuffle', 'shuffle'), ('cluster_nodes', 'cluster_nodes'),
+                             ('transform_sigmoid', 'transform_sigmoid')):
+                setattr(self, dst, state[src])
+            opt_state, model_state = state['optimizer'], state['model']
+        if self.transform_sigmoid:
+            raise NotImplementedError("transform_sigmoid is not on the native path")
+
+        self.dataset = GraphDataSet(database, node_feature=self.node_feature, edge_feature=self.edge_feature,
+                                    target=self.target, clustering_method=self.cluster_nodes or 'mcl', index=self.index)
+        first = self.dataset[0]
+        if getattr(first, "cluster0", None) is None:
+            raise ValueError("the graphs carry no clustering/%s/depth_0|1: run the reference's PreCluster "
+                             "(offline community detection) once on the dataset" % self.cluster_nodes)
+        if pretrained_model is None:
+            i_train, i_valid = _divide(len(self.dataset), self.percent, True)
+        else:
+            i_train, i_valid = np.arange(len(self.dataset)), np.arange(0)
+        self.train_index, self.valid_index = list(i_train), list(i_valid)
+        self.eval_dataset = None
+        if database_eval is not None:
+            self.eval_dataset = GraphDataSet(database_eval, node_feature=self.node_feature,
+                                             edge_feature=self.edge_feature, target=self.target,
+                                             clustering_method=self.cluster_nodes or 'mcl', index=self.index)
+
+        n_out = 1 if self.task == 'reg' else len(self.classes)
+        self.classes_to_idx = {c: i for i, c in enumerate(self.classes)}
+        self.idx_to_classes = {i: c for i, c in enumerate(self.classes)}
+        self.model = Net(first.num_features, n_out, len(self.edge_feature)).to(self.device)
+        if model_state is not None:
+            self.model.load_state_dict(model_state)
+        weights = None
+        if self.task == 'class' and self.class_weights is True:      # NeuralNet.py:247-258
+            ys = [int(self.dataset[i].y) for i in self.train_index]
+            w = torch.tensor([ys.count(c) for c in self.classes], dtype=torch.float32)
+            w = 1.0 / w
+            weights = w / w.sum()
+        elif self.task == 'class' and isinstance(self.class_weights, (list, tuple)):
+            weights = torch.tensor(self.class_weights, dtype=torch.float32)
+        self.trainer = FusedTrainer(self.model, lr=self.lr, task=self.task, class_weights=weights, api=_api)
+        if opt_state is not None:
+            self.trainer.load_optimizer_state_dict(opt_state)
+        self.train_loss, self.valid_loss, self.train_acc, self.valid_acc = [], [], [], []
+        self.data = {}
+
+    # ------------------------------------------------------------------------------
+    def _batches(self, dataset, indices, shuffle):
+        order = list(indices)
+        if shuffle:
+            order = [order[i] for i in torch.randperm(len(order)).tolist()]
+        for lo in range(0, len(order), self.batch_size):
+            graphs = [dataset[i] for i in order[lo:lo + self.batch_size]]
+            batch = Batch.from_data_list(graphs)
+            yield self._targets(batch).to(self.device)
+
+    def _targets(self, batch):
+        """format_output's target half (NeuralNet.py:616-631): class labels -> class indices."""
+        if self.task == 'class' and batch.y is not None:
+            batch.y = torch.tensor([self.classes_to_idx[int(v)] for v in batch.y])
+        return batch
+
+    def _collect(self, pred, batch, store):
+        if self.task == 'class':
+            prob = torch.softmax(pred.detach().cpu(), dim=1)
+            store['raw_outputs'] += prob.tolist()
+            out = prob.argmax(dim=1).tolist()
+            store['outputs'] += [self.idx_to_classes[i] for i in out]
+            if batch.y is not None:
+                store['targets'] += [self.idx_to_classes[int(i)] for i in batch.y.tolist()]
+        else:
+            out = pred.detach().cpu().reshape(-1).tolist()
+            store['raw_outputs'] += out
+            store['outputs'] += out
+            if batch.y is not None:
+                store['targets'] += batch.y.tolist()
+        store['mol'] += list(batch['mol'])
+
+    def _accuracy(self, store):
+        if not store['targets']:
+            return None
+        if self.task == 'class':
+            return float(np.mean(np.asarray(store['outputs']) == np.asarray(store['targets'])))
+        t, o = np.asarray(store['targets']), np.asarray(store['outputs'])
+        return float(np.mean((t < self.threshold) == (o < self.threshold)))
+
+    def _epoch(self, epoch):
+        """One pass over the training set (NeuralNet.py:477-537) on the native step."""
+        store = {'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': []}
+        running = 0.0
+        for batch in self._batches(self.dataset, self.train_index, self.shuffle):
+            loss = self.trainer.train_step(batch)
+            running += float(loss)                      # host sync per batch, as the reference's .item()
+            self._collect(self.trainer.last_pred, batch, store)
+        return running, store
+
+    def eval(self, dataset=None, indices=None):
+        """Forward only (NeuralNet.py:414-475); returns (loss_sum, store)."""
+        dataset = dataset or self.dataset
+        indices = self.valid_index if indices is None else indices
+        store = {'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': []}
+        total = 0.0
+        for batch in self._batches(dataset, indices, False):
+            pred = self.trainer.predict(batch)
+            if batch.y is not None:
+                if self.task == 'reg':
+                    total += float(torch.nn.functional.mse_loss(pred.reshape(-1), batch.y))
+                else:
+                    total += float(torch.nn.functional.cross_entropy(pred, batch.y, weight=self.trainer.class_w))
+            self._collect(pred, batch, store)
+        return total, store
+
+    def train(self, nepoch=1, validate=False, save_model='last', hdf5='train_data.npz', save_epoch='intermediate',
+              save_every=5):
+        best = None
+        for epoch in range(1, nepoch + 1):
+            t0 = time.time()
+            loss, store = self._epoch(epoch)
+            self.train_loss.append(loss)
+            self.train_acc.append(self._accuracy(store))
+            self.data['epoch_%04d/train' % epoch] = store
+            line = "Epoch [%04d] : train loss %e" % (epoch, loss)
+            if validate and (self.valid_index or self.eval_dataset is not None):
+                ds = self.eval_dataset or self.dataset
+                idx = range(len(ds)) if self.eval_dataset is not None else self.valid_index
+                vloss, vstore = self.eval(ds, list(idx))
+                self.valid_loss.append(vloss)
+                self.valid_acc.append(self._accuracy(vstore))
+                self.data['epoch_%04d/eval' % epoch] = vstore
+                line += " | valid loss %e" % vloss
+                if save_model == 'best' and (best is None or vloss < best):
+                    best = vloss
+                    self.save_model(os.path.join(self.outdir, 'best_model.pth.tar'))
+            print(line + " | time %.3f s" % (time.time() - t0))
+        if save_model == 'last':
+            self.save_model(os.path.join(self.outdir, 'last_model.pth.tar'))
+        if hdf5:
+            self.export(os.path.join(self.outdir, hdf5))
+
+    def test(self, database_test=None, threshold=4, hdf5='test_data.npz'):
+        ds = self.dataset if database_test is None else GraphDataSet(
+            database_test, node_feature=self.node_feature, edge_feature=self.edge_feature, target=self.target,
+            clustering_method=self.cluster_nodes or 'mcl')
+        loss, store = self.eval(ds, list(range(len(ds))))
+        self.data['epoch_0000/test'] = store
+        self.test_loss, self.test_acc = loss, self._accuracy(store)
+        if hdf5:
+            self.export(os.path.join(self.outdir, hdf5))
+        return store
+
+    def export(self, fname):
+        """Per-epoch outputs/targets/mol, same group names as the reference's HDF5 export
+        (NeuralNet.py:827-872; tests/data/train_ref/train_data.hdf5), written as .npz."""
+        flat = {}
+        for grp, store in self.data.items():
+            for k, v in store.items():
+                flat["%s/%s" % (grp, k)] = np.asarray(v)
+        np.savez_compressed(fname, **flat)
+
+    def save_model(self, filename='model.pth.tar'):
+        state = {'model': {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
+                 'optimizer': self.trainer.optimizer_state_dict(),
+                 'node': self.node_feature, 'edge': self.edge_feature, 'target': self.target, 'task': self.task,
+                 'classes': self.classes, 'class_weight': self.class_weights, 'batch_size': self.batch_size,
+                 'percent': self.percent, 'lr': self.lr, 'index': self.index, 'shuffle': self.shuffle,
+                 'threshold': self.threshold, 'cluster_nodes': self.cluster_nodes,
+                 'transform_sigmoid': self.transform_sigmoid}
+        torch.save(state, filename)

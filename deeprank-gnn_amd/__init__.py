@@ -6,5 +6,8 @@ needs a kernel loads ``csrc/libdrgnn.so`` and raises if it (or a GPU) is missing
 there is no CPU fallback in the product path.
 """
 from .data import Batch, Data, DataLoader  # noqa: F401
+from .ginet import GINet  # noqa: F401
+from .sGAT import sGAT  # noqa: F401
+from .foutnet import FoutNet  # noqa: F401
 
 __version__ = "0.1.0"

@@ -202,6 +202,40 @@ class FusedTrainer(object):
         self.apply_update()
         return loss
 
+    # -- torch.optim.Adam compatible optimiser state --------------------------------------
+    def optimizer_state_dict(self):
+        """Same structure as ``torch.optim.Adam(...).state_dict()`` over ``net.parameters()`` (what the
+        reference stores under 'optimizer', NeuralNet.py:776), so either side can resume the other."""
+        state = {}
+        step = int(self.step)
+        for i, (name, p) in enumerate(self.net.named_parameters()):
+            off, n = self.offset[name], p.numel()
+            if step > 0:
+                state[i] = {'step': torch.tensor(float(step)),
+                            'exp_avg': self.exp_avg[off:off + n].view(p.shape).detach().cpu().clone(),
+                            'exp_avg_sq': self.exp_avg_sq[off:off + n].view(p.shape).detach().cpu().clone()}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.weight_decay,
+                 'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
+                 'fused': None, 'params': list(range(len(self.offset)))}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_optimizer_state_dict(self, sd):
+        group = sd['param_groups'][0]
+        self.lr, self.betas, self.eps = float(group['lr']), tuple(group['betas']), float(group['eps'])
+        self.weight_decay = float(group.get('weight_decay', 0.0))
+        steps = set()
+        with torch.no_grad():
+            for i, (name, p) in enumerate(self.net.named_parameters()):
+                st = sd['state'].get(i)
+                if st is None:
+                    continue
+                off, n = self.offset[name], p.numel()
+                self.exp_avg[off:off + n].copy_(st['exp_avg'].reshape(-1).to(self.exp_avg.device))
+                self.exp_avg_sq[off:off + n].copy_(st['exp_avg_sq'].reshape(-1).to(self.exp_avg.device))
+                steps.add(int(float(st['step'])))
+            if steps:
+                self.step.fill_(max(steps))
+
     @torch.no_grad()
     def predict(self, batch, topo=None):
         """Inference (dropout off), fully on the native path; returns pred [B, O]."""

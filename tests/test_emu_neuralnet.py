@@ -1,0 +1,57 @@
+"""Trainer counterpart (deeprank_gnn_amd.NeuralNet) on the fixture, kernels emulated on CPU --
+mirrors what the reference's tests/test_nn.py exercises (train 5 epochs, save, reload)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import GOLDEN, NODE_FEATURES
+from emu_api import emu
+from deeprank_gnn_amd.NeuralNet import NeuralNet
+from deeprank_gnn_amd.ginet import GINet
+from deeprank_gnn_amd.sGAT import sGAT
+from deeprank_gnn_amd.foutnet import FoutNet
+
+DB = os.path.join(GOLDEN, "fixture_1ATN.npz")
+REF_KEYS = {'model', 'optimizer', 'node', 'edge', 'target', 'task', 'classes', 'class_weight', 'batch_size',
+            'percent', 'lr', 'index', 'shuffle', 'threshold', 'cluster_nodes', 'transform_sigmoid'}
+
+
+@pytest.mark.parametrize("Net,task,target", [(GINet, None, 'irmsd'), (FoutNet, None, 'irmsd'), (sGAT, None, 'irmsd'),
+                                            (GINet, 'class', 'binclass')])
+def test_train_save_reload(Net, task, target, tmp_path):
+    torch.manual_seed(0)
+    np.random.seed(0)
+    nn = NeuralNet(DB, Net, node_feature=NODE_FEATURES, edge_feature=['dist'], target=target, task=task,
+                   batch_size=64, percent=[0.8, 0.2], outdir=str(tmp_path), _api=emu(), device='cpu')
+    nn.train(nepoch=3, validate=True)
+    assert len(nn.train_loss) == 3 and len(nn.valid_loss) == 3 and all(np.isfinite(nn.train_loss))
+    if task is None:
+        assert nn.train_loss[-1] < nn.train_loss[0]              # it learns
+    ck = os.path.join(str(tmp_path), 'test.pth.tar')
+    nn.save_model(ck)
+    state = torch.load(ck, weights_only=False)
+    assert set(state) == REF_KEYS                                  # reference checkpoint schema (NeuralNet.py:775-790)
+    assert set(state['optimizer']) == {'state', 'param_groups'}
+    # a torch Adam over the same parameter list accepts the optimiser state
+    ref_net = Net(28, 1 if task is None else 2, 1)
+    ref_net.load_state_dict(state['model'], strict=True)
+    torch.optim.Adam(ref_net.parameters(), lr=0.01).load_state_dict(state['optimizer'])
+    # reload and test: identical predictions
+    cpy = NeuralNet(DB, Net, pretrained_model=ck, outdir=str(tmp_path), _api=emu(), device='cpu')
+    assert int(cpy.trainer.step) == int(nn.trainer.step)
+    a = cpy.test(hdf5=None)
+    b = nn.test(hdf5=None)
+    np.testing.assert_allclose(a['raw_outputs'], b['raw_outputs'], rtol=1e-6)
+    assert a['mol'] == b['mol'] and len(a['mol']) == 10
+    exp = np.load(os.path.join(str(tmp_path), 'train_data.npz'))
+    assert 'epoch_0003/train/outputs' in exp.files and 'epoch_0003/eval/targets' in exp.files
+
+
+def test_needs_gpu_without_emulation():
+    from deeprank_gnn_amd import _lib
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.DrgnnError):
+        NeuralNet(DB, GINet, node_feature=NODE_FEATURES, target='irmsd')

@@ -65,3 +65,22 @@ def test_native_step_is_graph_capturable_and_deterministic():
         assert int(tr.step) == 5          # 1 eager warm-up + 4 replays (capture itself does not execute)
         results.append(tr.flat_p.clone())
     assert torch.equal(results[0], results[1])
+
+
+def test_neuralnet_counterpart_on_gpu(tmp_path):
+    """reference tests/test_nn.py flow (train, save, reload) on the device."""
+    import os
+    from helpers import GOLDEN, NODE_FEATURES
+    from deeprank_gnn_amd.NeuralNet import NeuralNet
+    from deeprank_gnn_amd.ginet import GINet
+    db = os.path.join(GOLDEN, "fixture_1ATN.npz")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    nn = NeuralNet(db, GINet, node_feature=NODE_FEATURES, edge_feature=['dist'], target='irmsd',
+                   batch_size=64, percent=[0.8, 0.2], outdir=str(tmp_path))
+    nn.train(nepoch=5, validate=True)
+    assert nn.train_loss[-1] < nn.train_loss[0]
+    ck = os.path.join(str(tmp_path), 'test.pth.tar')
+    nn.save_model(ck)
+    cpy = NeuralNet(db, GINet, pretrained_model=ck, outdir=str(tmp_path))
+    np.testing.assert_allclose(cpy.test(hdf5=None)['raw_outputs'], nn.test(hdf5=None)['raw_outputs'], rtol=1e-6)
