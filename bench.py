@@ -49,11 +49,9 @@ def parse():
                     help="native: FusedTrainer step (our head/loss/Adam kernels) replayed from a hipGraph; "
                          "graph/eager: torch autograd + torch.optim.Adam around the fused body")
     ap.add_argument("--net", choices=["GINet", "sGAT", "FoutNet"], default="GINet")
-    ap.add_argument("--overlap", action="store_true",
-                    help="native mode (experimental): build the next step's topology on a second stream "
-                         "concurrently with the current step (double-buffered).  Measured SLOWER under "
-                         "hipGraph replay on MI355X (78.9 vs 67.2 us/step): the fork/join edges cost more "
-                         "than the overlap gains, so it is off by default")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="native mode: build each step's topology with its own launch at the start of the step "
+                         "instead of inside the previous step's backward launch (double-buffered workspaces)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -90,37 +88,25 @@ def main():
     native = args.mode.startswith("native")
     capture = args.mode in ("native", "graph")
     need_w = args.net == "sGAT"
-    overlap = native and capture and args.overlap
-    steps_per_call = 2 if overlap else 1
+    pipeline = native and world == 1 and not args.no_pipeline
+    steps_per_call = 2 if pipeline else 1
     if native:
         from deeprank_gnn_amd.trainer import FusedTrainer
         trainer = FusedTrainer(net, lr=1e-3, task="reg", seed=1234 + rank)
         loss_out = trainer.loss
-        # two persistent topology workspaces: while step t trains out of one, the topology of step
-        # t+1 is (re)built into the other on a second stream -- it depends on index tensors only
-        topos = [Topology.from_batch(batch, need_weights=need_w) for _ in range(2)]
-        side_build = torch.cuda.Stream()
-
-        def half_step(k, fused):
-            main = torch.cuda.current_stream()
-            if overlap:
-                side_build.wait_stream(main)                 # fork
-                with torch.cuda.stream(side_build):
-                    topos[1 - k].rebuild()
-                cur = topos[k]
-            else:
-                cur = topos[0].rebuild()
-            if fused:
-                trainer.train_step(batch, topo=cur)          # fwd, bwd(+head+loss), reduce+Adam
-            else:
-                trainer.compute_gradients(batch, topo=cur)
-            if overlap:
-                main.wait_stream(side_build)                 # join
+        # Two persistent topology workspaces.  Pipelined: while step t trains out of one, the
+        # topology of step t+1 is built into the other INSIDE step t's backward launch (the builder
+        # only depends on index tensors).  Every step still builds one topology and consumes one.
+        topos = [Topology.from_batch(batch, need_weights=need_w),
+                 Topology.from_batch(batch, need_weights=need_w, build=not pipeline)]
 
         if world == 1:
             def fwd_bwd():
-                for k in range(steps_per_call):
-                    half_step(k, True)
+                if pipeline:
+                    trainer.train_step(batch, topo=topos[0], next_topo=topos[1])
+                    trainer.train_step(batch, topo=topos[1], next_topo=topos[0])
+                else:
+                    trainer.train_step(batch, topo=topos[0].rebuild())   # topology, fwd, bwd(+head+loss), reduce+Adam
 
             def all_reduce():
                 pass
@@ -128,11 +114,8 @@ def main():
             def reduce_and_step():
                 pass
         else:
-            steps_per_call = 1
-            state = {"k": 0}
-
             def fwd_bwd():
-                half_step(state["k"], False)
+                trainer.compute_gradients(batch, topo=topos[0].rebuild())
 
             def all_reduce():
                 trainer.all_reduce_gradients()
@@ -176,26 +159,6 @@ def main():
 
             def call():
                 g1.replay()
-        elif native and overlap:
-            # data parallel + overlap: even / odd half-steps are separate graphs, the all-reduce
-            # (RCCL) runs eagerly between the gradient graph and the Adam graph
-            gk = []
-            for k in (0, 1):
-                state["k"] = k
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    fwd_bwd()
-                gk.append(g)
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                reduce_and_step()
-            steps_per_call = 2
-
-            def call():
-                for k in (0, 1):
-                    gk[k].replay()
-                    all_reduce()
-                    g2.replay()
         else:
             g1 = torch.cuda.CUDAGraph()
             g2 = torch.cuda.CUDAGraph()
@@ -253,8 +216,8 @@ def main():
                                    "(BASELINE.json configs[1])" % args.net,
                        "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,
                        "parallelism": "dp%d" % world, "mode": args.mode,
-                       "topology": ("rebuilt every step on a second stream, overlapped with the previous step "
-                                    "(double-buffered)" if overlap else "rebuilt every step, in line"),
+                       "topology": ("rebuilt every step; the build of step t+1 shares step t's backward launch "
+                                    "(double-buffered)" if pipeline else "rebuilt every step, own launch"),
                        "final_loss": final_loss},
         }
         if args.net == "GINet":

@@ -50,6 +50,14 @@ class NetDesc(ctypes.Structure):
                 ("conv1", ConvParams * MAX_BRANCH), ("conv2", ConvParams * MAX_BRANCH)]
 
 
+class TopologyRequest(ctypes.Structure):
+    _fields_ = [("edge_index", _vp), ("edge_attr", _vp), ("batch", _vp), ("cluster0", _vp), ("cluster1", _vp),
+                ("node_ptr", _vp), ("edge_ptr", _vp), ("c1_ptr", _vp),
+                ("n_nodes", _c_i64), ("n_edges", _c_i64), ("len_cluster1", _c_i64), ("n_graphs", _c_i64),
+                ("max_nodes", _c_i32), ("max_edges", _c_i32),
+                ("ws_i32", _vp), ("ws_f32", _vp), ("scratch_i32", _vp)]
+
+
 class HeadDesc(ctypes.Structure):
     _fields_ = [("R", _c_i32), ("H", _c_i32), ("O", _c_i32), ("task", _c_i32), ("train", _c_i32),
                 ("p_drop", ctypes.c_float), ("seed", ctypes.c_uint32), ("reserved", _c_i32),
@@ -100,7 +108,8 @@ class Api(object):
         lib.drgnn_net_forward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 3 + [_c_i64] * 3 +
                                           [_c_i32] * 3 + [_vp] * 7)
         lib.drgnn_net_backward_fused_head.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc)] +
-                                                      [_vp] * 6 + [_c_i64] * 3 + [_c_i32] * 3 + [_vp] * 9)
+                                                      [_vp] * 6 + [_c_i64] * 3 + [_c_i32] * 3 + [_vp] * 8 +
+                                                      [ctypes.POINTER(TopologyRequest), _vp])
         lib.drgnn_net_backward.argtypes = ([ctypes.POINTER(NetDesc)] + [_vp] * 4 + [_c_i64] * 3 +
                                            [_c_i32] * 3 + [_vp] * 3 + [_vp] * 5)
         lib.drgnn_train_update.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] +
@@ -183,12 +192,13 @@ class Api(object):
 
     def net_backward_fused_head(self, desc, head, x, readout, target, step, ws_i32, ws_f32, n_nodes, n_edges,
                                 n_graphs, max_nodes, max_edges, max_c0, xp, arg0, arg1, pred, head_partials,
-                                grad_x, partials, scratch, stream):
+                                grad_x, partials, scratch, stream, next_topology=None):
         _check(self.lib.drgnn_net_backward_fused_head(
             ctypes.byref(desc), ctypes.byref(head), _ptr(x), _ptr(readout), _ptr(target), _ptr(step),
             _ptr(ws_i32), _ptr(ws_f32), n_nodes, n_edges, n_graphs, max_nodes, max_edges, max_c0, _ptr(xp),
             _ptr(arg0), _ptr(arg1), _ptr(pred), _ptr(head_partials), _ptr(grad_x), _ptr(partials),
-            _ptr(scratch), stream), "drgnn_net_backward_fused_head")
+            _ptr(scratch), None if next_topology is None else ctypes.byref(next_topology), stream),
+            "drgnn_net_backward_fused_head")
 
     def net_backward(self, desc, x, grad_readout, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
                      max_nodes, max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch, stream,

@@ -209,6 +209,16 @@ struct NetLaunch {
     int64_t n_edges;
 };
 
+// A body launch that ALSO builds the topology of the next mini-batch: workgroups
+// [0, n_net) run the body, [n_net, n_net + n_graphs_next) the topology builder.  The two jobs
+// are independent (the builder reads index tensors only), so this hides one of them behind
+// the other and saves a kernel boundary -- software pipelining across training steps.
+struct CoLaunch {
+    NetLaunch net;
+    TopoLaunch topo;
+    int n_net;
+};
+
 // global-scratch placement: net_scratch_words is affine in (capN, capE, capC)
 HD int64_t net_gscratch_base(int kind, int F, int64_t n0, int64_t e0, int64_t g, int bwd) {
     const int64_t c0 = net_scratch_words(kind, F, 0, 0, 0, bwd);
@@ -308,6 +318,12 @@ template <int KIND, bool BWD, bool LDS>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net(NetLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
     net_block<KIND, BWD, LDS>(L, blockIdx.x, smem_f);
+}
+template <int KIND, bool BWD>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_net_co_topo(CoLaunch C) {
+    extern __shared__ __attribute__((aligned(16))) float smem_c[];
+    if ((int)blockIdx.x < C.n_net) net_block<KIND, BWD, true>(C.net, blockIdx.x, smem_c);
+    else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_c);
 }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
 __global__ void __launch_bounds__(256) k_conv_aggregate(ConvLayerArgs a) {
@@ -421,21 +437,22 @@ int64_t drgnn_topology_lds_bytes(int32_t max_nodes, int32_t max_edges) {
     return topo_lds_bytes(max_nodes, max_edges > 0 ? max_edges : 1);
 }
 
-int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, const int64_t* batch,
-                         const int64_t* cluster0, const int64_t* cluster1, const int32_t* node_ptr,
-                         const int32_t* edge_ptr, const int32_t* c1_ptr, int64_t n_nodes,
-                         int64_t n_edges, int64_t len_cluster1, int64_t n_graphs, int32_t max_nodes,
-                         int32_t max_edges, int32_t* ws_i32, float* ws_f32, int32_t* scratch_i32,
-                         void* stream_) {
+}  // extern "C"
+
+// fills a TopoLaunch from the public arguments; *lds_out = LDS bytes (0: global scratch path)
+static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_index, const float* edge_attr,
+                        const int64_t* batch, const int64_t* cluster0, const int64_t* cluster1,
+                        const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* c1_ptr,
+                        int64_t n_nodes, int64_t n_edges, int64_t len_cluster1, int64_t n_graphs,
+                        int32_t max_nodes, int32_t max_edges, int32_t* ws_i32, float* ws_f32,
+                        int32_t* scratch_i32) {
     if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !ws_i32 || !batch) return DRGNN_E_ARG;
     if (!cluster0 && cluster1) return DRGNN_E_ARG;
     if (n_edges > 0 && !edge_index) return DRGNN_E_ARG;
     if (edge_attr && !ws_f32) return DRGNN_E_ARG;
     if (n_nodes + n_graphs >= INT32_MAX || n_edges >= INT32_MAX) return DRGNN_E_CAPACITY;
-    drgnn_stream_t stream = (drgnn_stream_t)stream_;
     TopoLayout lay;
     topo_layout(n_nodes, n_edges, n_graphs, &lay);
-    TopoLaunch L;
     L.tv = topo_view(ws_i32, ws_f32, lay);
     L.args.edge_index = edge_index;
     L.args.edge_attr = edge_attr;
@@ -456,6 +473,25 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
         if (lds <= DRGNN_LDS_LIMIT) { L.capN = max_nodes; L.capE = max_edges > 0 ? max_edges : 1; }
         else lds = 0;
     }
+    *lds_out = lds;
+    return 0;
+}
+
+extern "C" {
+
+int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, const int64_t* batch,
+                         const int64_t* cluster0, const int64_t* cluster1, const int32_t* node_ptr,
+                         const int32_t* edge_ptr, const int32_t* c1_ptr, int64_t n_nodes,
+                         int64_t n_edges, int64_t len_cluster1, int64_t n_graphs, int32_t max_nodes,
+                         int32_t max_edges, int32_t* ws_i32, float* ws_f32, int32_t* scratch_i32,
+                         void* stream_) {
+    drgnn_stream_t stream = (drgnn_stream_t)stream_;
+    TopoLaunch L;
+    int64_t lds = 0;
+    int rc0 = topo_prepare(L, &lds, edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,
+                           n_nodes, n_edges, len_cluster1, n_graphs, max_nodes, max_edges, ws_i32, ws_f32,
+                           scratch_i32);
+    if (rc0) return rc0;
     if (L.capN == 0 && !scratch_i32) return DRGNN_E_CAPACITY;
     if (n_graphs == 0) return 0;
     PtrArgs pa;
@@ -582,7 +618,7 @@ static int net_check(const drgnn_net_desc* net) {
 
 template <bool BWD>
 static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_edges, int32_t max_c0, float* scratch,
-                      void* stream_) {
+                      void* stream_, const TopoLaunch* co = nullptr, int64_t co_lds = 0) {
     const int kind = L.a.net.kind;
     const int64_t lds = drgnn_net_lds_bytes(kind, L.a.net.n_feat, max_nodes, max_edges, max_c0, BWD ? 1 : 0);
     L.capN = 0; L.capE = 0; L.capC = 0; L.gscratch = scratch;
@@ -601,9 +637,14 @@ static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_edges, int32_
         return DRGNN_E_CAPACITY;
     }
     const int blocks = L.a.n_graphs * L.a.net.n_branch;
-    if (blocks == 0) return 0;
+    // co-launched topology build of the next mini-batch: only when both jobs run out of LDS and the
+    // builder needs no helper passes (offsets supplied, depth-1 ids located)
+    const bool co_ok = co != nullptr && use_lds > 0 && co->capN > 0 && co->user_nptr != nullptr &&
+                       !(co->args.cluster1 != nullptr && co->args.c1_ptr == nullptr) && co->args.n_graphs > 0 &&
+                       blocks > 0;
+    if (blocks == 0 && !co) return 0;
 #ifdef DRGNN_EMU
-    std::vector<float> buf((size_t)(use_lds / 4) + 16);
+    std::vector<float> buf((size_t)((use_lds > co_lds ? use_lds : co_lds) / 4) + 16);
     for (int b = 0; b < blocks; ++b) {
         if (use_lds) {
             if (kind == DRGNN_GINET) net_block<DRGNN_GINET, BWD, true>(L, b, buf.data());
@@ -615,9 +656,32 @@ static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_edges, int32_
             else net_block<DRGNN_FOUT, BWD, false>(L, b, buf.data());
         }
     }
+    if (co_ok)
+        for (int g = 0; g < co->args.n_graphs; ++g) topo_block<true>(*co, g, (int*)buf.data());
     (void)stream_;
+    return co_ok ? 1 : 0;       // 1: the co-launched topology has been built as well
 #else
     hipStream_t stream = (hipStream_t)stream_;
+    if (co_ok) {
+        CoLaunch C;
+        C.net = L; C.topo = *co; C.n_net = blocks;
+        const int64_t both = use_lds > co_lds ? use_lds : co_lds;
+#define DRGNN_CO_LAUNCH(K)                                                                               \
+    do {                                                                                                 \
+        if (both > 64 * 1024)                                                                            \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_net_co_topo<K, BWD>,                              \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));         \
+        hipLaunchKernelGGL((k_net_co_topo<K, BWD>), dim3((unsigned)(blocks + co->args.n_graphs)),        \
+                           dim3(DRGNN_NTHREADS), (size_t)both, stream, C);                               \
+    } while (0)
+        if (kind == DRGNN_GINET) DRGNN_CO_LAUNCH(DRGNN_GINET);
+        else if (kind == DRGNN_SGAT) DRGNN_CO_LAUNCH(DRGNN_SGAT);
+        else DRGNN_CO_LAUNCH(DRGNN_FOUT);
+#undef DRGNN_CO_LAUNCH
+        HIP_TRY(hipGetLastError());
+        return 1;
+    }
+    if (blocks == 0) return 0;
 #define DRGNN_NET_LAUNCH(K)                                                                         \
     do {                                                                                            \
         if (use_lds > 64 * 1024)                                                                    \
@@ -635,8 +699,8 @@ static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_edges, int32_
     else DRGNN_NET_LAUNCH(DRGNN_FOUT);
 #undef DRGNN_NET_LAUNCH
     HIP_TRY(hipGetLastError());
-#endif
     return 0;
+#endif
 }
 
 extern "C" {
@@ -662,7 +726,8 @@ int drgnn_net_forward(const drgnn_net_desc* net, const float* x, const int32_t* 
     L.a.step_inc = step_inc;
     L.a.hf.enabled = 0;
     L.n_edges = n_edges;
-    return net_launch<false>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
+    const int rc2 = net_launch<false>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
+    return rc2 < 0 ? rc2 : (rc2 > 1 ? rc2 : 0);
 }
 
 static int net_backward_impl(const drgnn_net_desc* net, const float* x, const float* grad_readout,
@@ -670,7 +735,7 @@ static int net_backward_impl(const drgnn_net_desc* net, const float* x, const fl
                              int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
                              int32_t max_edges, int32_t max_c0, const float* xp, const int32_t* arg0,
                              const int32_t* arg1, float* grad_x, float* partials, float* scratch_f32,
-                             int32_t* step_inc, void* stream_) {
+                             int32_t* step_inc, void* stream_, const drgnn_topology_request* next = nullptr) {
     int rc = net_check(net);
     if (rc) return rc;
     if (!x || (!grad_readout && !hf) || !ws_i32 || !xp || !arg0 || !arg1 || !partials) return DRGNN_E_ARG;
@@ -689,7 +754,25 @@ static int net_backward_impl(const drgnn_net_desc* net, const float* x, const fl
     L.a.step_inc = step_inc;
     if (hf) L.a.hf = *hf; else L.a.hf.enabled = 0;
     L.n_edges = n_edges;
-    return net_launch<true>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
+    if (!next) {
+        const int rc2 = net_launch<true>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_);
+        return rc2 < 0 ? rc2 : (rc2 > 1 ? rc2 : 0);
+    }
+    TopoLaunch T;
+    int64_t tlds = 0;
+    rc = topo_prepare(T, &tlds, next->edge_index, next->edge_attr, next->batch, next->cluster0, next->cluster1,
+                      next->node_ptr, next->edge_ptr, next->c1_ptr, next->n_nodes, next->n_edges,
+                      next->len_cluster1, next->n_graphs, next->max_nodes, next->max_edges, next->ws_i32,
+                      next->ws_f32, next->scratch_i32);
+    if (rc) return rc;
+    const int rc2 = net_launch<true>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_, &T, tlds);
+    if (rc2 < 0 || rc2 > 1) return rc2;
+    if (rc2 == 1) return 0;
+    // could not share the launch: build the next topology with its own launches
+    return drgnn_topology_build(next->edge_index, next->edge_attr, next->batch, next->cluster0, next->cluster1,
+                                next->node_ptr, next->edge_ptr, next->c1_ptr, next->n_nodes, next->n_edges,
+                                next->len_cluster1, next->n_graphs, next->max_nodes, next->max_edges,
+                                next->ws_i32, next->ws_f32, next->scratch_i32, stream_);
 }
 
 }  // extern "C"
@@ -711,7 +794,8 @@ int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_de
                                   int64_t n_edges, int64_t n_graphs, int32_t max_nodes, int32_t max_edges,
                                   int32_t max_c0, const float* xp, const int32_t* arg0, const int32_t* arg1,
                                   float* pred, float* head_partials, float* grad_x, float* partials,
-                                  float* scratch_f32, void* stream_) {
+                                  float* scratch_f32, const drgnn_topology_request* next_topology,
+                                  void* stream_) {
     if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2 || !readout || !target || !pred || !head_partials)
         return DRGNN_E_ARG;
     if (!net || hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
@@ -724,7 +808,8 @@ int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_de
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
     hf.readout = readout; hf.step = step; hf.pred = pred; hf.partials = head_partials;
     return net_backward_impl(net, x, nullptr, &hf, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, max_nodes,
-                             max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch_f32, nullptr, stream_);
+                             max_edges, max_c0, xp, arg0, arg1, grad_x, partials, scratch_f32, nullptr, stream_,
+                             next_topology);
 }
 
 int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,

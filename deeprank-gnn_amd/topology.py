@@ -38,7 +38,8 @@ class Topology(object):
 
     # ---------------------------------------------------------------------------
     @classmethod
-    def from_batch(cls, data, api=None, with_level1=True, check=False, need_weights=True, graph_only=False):
+    def from_batch(cls, data, api=None, with_level1=True, check=False, need_weights=True, graph_only=False,
+                   build=True):
         """Build from a ``Batch``-like object (attribute access only).  ``need_weights=False``
         skips everything that involves ``edge_attr`` (GINet's attention is identically 1 and
         FoutLayer never reads it, so only sGAT needs the pooled, summed edge attributes)."""
@@ -94,10 +95,26 @@ class Topology(object):
                                   dtype=torch.int32, device=device)
         topo.has_level1 = cluster1 is not None
         topo._inputs = (edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch)
-        topo.rebuild()
-        if check:
-            topo.check()
+        if build:
+            topo.rebuild()
+            if check:
+                topo.check()
         return topo
+
+    def request(self):
+        """The builder's arguments as a ``drgnn_topology_request`` (to have a body launch of the
+        PREVIOUS mini-batch build this topology in the same launch)."""
+        edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch = self._inputs
+        r = _lib.TopologyRequest()
+        p = _lib._ptr
+        r.edge_index, r.edge_attr, r.batch, r.cluster0, r.cluster1 = p(edge_index), p(edge_attr), p(batch), p(cluster0), p(cluster1)
+        r.node_ptr, r.edge_ptr, r.c1_ptr = p(node_ptr), p(edge_ptr), p(c1_ptr)
+        r.n_nodes, r.n_edges, r.n_graphs = self.n_nodes, self.n_edges, self.n_graphs
+        r.len_cluster1 = 0 if cluster1 is None else cluster1.numel()
+        r.max_nodes, r.max_edges = self.max_nodes, self.max_edges
+        r.ws_i32, r.ws_f32, r.scratch_i32 = p(self.ws_i32), p(self.ws_f32), p(scratch)
+        self._finalized = False
+        return r
 
     def rebuild(self):
         """(Re)run the builder into this object's existing buffers, on torch's current stream --

@@ -117,7 +117,7 @@ class FusedTrainer(object):
                         topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream, step_inc=step_inc)
         return x, desc, xp, arg0, arg1, readout, scratch
 
-    def _backward(self, batch, topo, fused_update):
+    def _backward(self, batch, topo, fused_update, next_topo=None):
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
@@ -144,7 +144,8 @@ class FusedTrainer(object):
                              dtype=torch.float32, device=dev)
             api.net_backward_fused_head(desc, self._head_desc(True), x, readout, y, self.step, topo.ws_i32,
                                         topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes, topo.max_edges,
-                                        topo.max_c0, xp, arg0, arg1, pred, hp, None, partials, scratch, stream)
+                                        topo.max_c0, xp, arg0, arg1, pred, hp, None, partials, scratch, stream,
+                                        next_topology=None if next_topo is None else next_topo.request())
             api.train_update(desc, partials, B, g1, g2, hp, self.R, self.H, self.O, self.head_grad_offset,
                              self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step, self.loss,
                              self.lr, self.betas[0], self.betas[1], self.eps, stream)
@@ -190,14 +191,20 @@ class FusedTrainer(object):
                            self.betas[0], self.betas[1], self.eps, self.weight_decay,
                            _lib.current_stream(self.flat_p))
 
-    def train_step(self, batch, topo=None, n_global=None, group=None):
+    def train_step(self, batch, topo=None, n_global=None, group=None, next_topo=None):
         """One optimisation step on ``batch``; returns the (device) loss of this rank's shard.
+        ``next_topo``: an allocated-but-unbuilt ``Topology`` of the NEXT mini-batch
+        (``Topology.from_batch(next_batch, build=False)``): it is built inside this step's backward
+        launch (independent work sharing the launch), so the next step starts without a builder
+        launch.
         Single process: 4 launches (topology, body fwd, body bwd incl. head + loss, reduce+Adam).  With
         torch.distributed initialised: reduce, ONE all-reduce of the flat gradient, Adam."""
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if not distributed and self.weight_decay == 0.0:
-            return self._backward(batch, topo, fused_update=True)
+            return self._backward(batch, topo, fused_update=True, next_topo=next_topo)
         loss = self.compute_gradients(batch, topo)
+        if next_topo is not None:
+            next_topo.rebuild()
         self.all_reduce_gradients(n_global=n_global, group=group)
         self.apply_update()
         return loss

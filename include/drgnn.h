@@ -275,6 +275,20 @@ typedef struct drgnn_head_desc {
     const float* class_w;     /* [O] class weights or NULL                                    */
 } drgnn_head_desc;
 
+/* The arguments of drgnn_topology_build bundled, to ask a body launch to ALSO build the topology
+ * of the NEXT mini-batch in the same launch (its workgroups are appended to the grid).  The two
+ * jobs are independent -- the builder only reads index tensors -- so one hides behind the other and
+ * a kernel boundary disappears (software pipelining across training steps).  Falls back to
+ * separate launches when LDS does not fit or the per-graph offsets are not supplied. */
+typedef struct drgnn_topology_request {
+    const int64_t* edge_index; const float* edge_attr; const int64_t* batch;
+    const int64_t* cluster0; const int64_t* cluster1;
+    const int32_t* node_ptr; const int32_t* edge_ptr; const int32_t* c1_ptr;
+    int64_t n_nodes, n_edges, len_cluster1, n_graphs;
+    int32_t max_nodes, max_edges;
+    int32_t* ws_i32; float* ws_f32; int32_t* scratch_i32;
+} drgnn_topology_request;
+
 /* Backward of the body with the FC head, loss and their backward evaluated per graph INSIDE the
  * same launch (the head is row-wise), instead of taking grad_readout from drgnn_head_step:
  * reads readout [B,32*n_branch] (forward output) and the targets, writes pred [B,O], one head
@@ -286,7 +300,9 @@ int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_de
                                   int64_t n_edges, int64_t n_graphs, int32_t max_nodes, int32_t max_edges,
                                   int32_t max_c0, const float* xp, const int32_t* arg0, const int32_t* arg1,
                                   float* pred, float* head_partials, float* grad_x, float* partials,
-                                  float* scratch_f32, void* stream);
+                                  float* scratch_f32,
+                                  const drgnn_topology_request* next_topology /* optional */,
+                                  void* stream);
 
 /* One workgroup per tile of graphs (16 for B <= 512, else 64; drgnn_head_num_slabs()).  Writes pred [B,O]; when train: grad_readout [B,R]
  * (d loss / d readout for the mean loss over the B graphs) and one partial slab per workgroup

@@ -123,3 +123,26 @@ def test_split_path_equals_fused_path_and_ragged_head_tiles():
         opt.step()
     for (n, p), (_, q) in zip(a.named_parameters(), ref.named_parameters()):
         np.testing.assert_allclose(p.detach().numpy(), q.detach().numpy(), rtol=1e-5, atol=2e-6, err_msg=n)
+
+
+def test_pipelined_topology_build_is_equivalent():
+    """next_topo: the next mini-batch's topology is built inside this step's backward launch."""
+    from helpers import fixture_graphs
+    from deeprank_gnn_amd.data import Batch
+    graphs = fixture_graphs(count=10)
+    batches = [Batch.from_data_list(graphs[0:4]), Batch.from_data_list(graphs[4:7]), Batch.from_data_list(graphs[7:10])]
+    torch.manual_seed(2)
+    a = GINet(28, 1, 1)
+    a.dropout = 0.0
+    b = copy.deepcopy(a)
+    ta, tb = FusedTrainer(a, lr=0.01, api=emu()), FusedTrainer(b, lr=0.01, api=emu())
+    topo = Topology.from_batch(batches[0], api=emu(), need_weights=False)
+    for i, batch in enumerate(batches):
+        nxt = None
+        if i + 1 < len(batches):
+            nxt = Topology.from_batch(batches[i + 1], api=emu(), need_weights=False, build=False)
+        la = float(ta.train_step(batch, topo=topo, next_topo=nxt))
+        lb = float(tb.train_step(batch))
+        assert la == lb
+        topo = nxt
+    assert torch.equal(ta.flat_p, tb.flat_p)

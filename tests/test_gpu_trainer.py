@@ -84,3 +84,32 @@ def test_neuralnet_counterpart_on_gpu(tmp_path):
     nn.save_model(ck)
     cpy = NeuralNet(db, GINet, pretrained_model=ck, outdir=str(tmp_path))
     np.testing.assert_allclose(cpy.test(hdf5=None)['raw_outputs'], nn.test(hdf5=None)['raw_outputs'], rtol=1e-6)
+
+
+def test_pipelined_topology_co_launch_matches_plain_training():
+    """The next batch's topology built inside this step's backward launch (co-launched workgroups)."""
+    from helpers import fixture_graphs
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    import copy
+    dev = torch.device("cuda:0")
+    graphs = fixture_graphs(count=10)
+    batches = [Batch.from_data_list(graphs[0:4]).to(dev), Batch.from_data_list(graphs[4:7]).to(dev),
+               Batch.from_data_list(graphs[7:10]).to(dev)]
+    torch.manual_seed(2)
+    a = GINet(28, 1, 1).to(dev)
+    a.dropout = 0.0
+    b = copy.deepcopy(a)
+    ta, tb = FusedTrainer(a, lr=0.01), FusedTrainer(b, lr=0.01)
+    topo = Topology.from_batch(batches[0], need_weights=False)
+    for i, batch in enumerate(batches):
+        nxt = Topology.from_batch(batches[i + 1], need_weights=False, build=False) if i + 1 < len(batches) else None
+        la = float(ta.train_step(batch, topo=topo, next_topo=nxt))
+        lb = float(tb.train_step(batch))
+        assert la == lb
+        if nxt is not None:
+            assert nxt.status()[0] == 0
+        topo = nxt
+    assert torch.equal(ta.flat_p, tb.flat_p)
