@@ -52,6 +52,9 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="native mode: build each step's topology with its own launch at the start of the step "
                          "instead of inside the previous step's backward launch (double-buffered workspaces)")
+    ap.add_argument("--force-dp-path", action="store_true",
+                    help="run the data-parallel code path (gradient graph, eager all-reduce, Adam graph) even "
+                         "with one process -- for testing on a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -88,7 +91,8 @@ def main():
     native = args.mode.startswith("native")
     capture = args.mode in ("native", "graph")
     need_w = args.net == "sGAT"
-    pipeline = native and world == 1 and not args.no_pipeline
+    pipeline = native and not args.no_pipeline
+    dp_path = world > 1 or args.force_dp_path
     steps_per_call = 2 if pipeline else 1
     if native:
         from deeprank_gnn_amd.trainer import FusedTrainer
@@ -100,13 +104,20 @@ def main():
         topos = [Topology.from_batch(batch, need_weights=need_w),
                  Topology.from_batch(batch, need_weights=need_w, build=not pipeline)]
 
-        if world == 1:
-            def fwd_bwd():
-                if pipeline:
-                    trainer.train_step(batch, topo=topos[0], next_topo=topos[1])
-                    trainer.train_step(batch, topo=topos[1], next_topo=topos[0])
-                else:
-                    trainer.train_step(batch, topo=topos[0].rebuild())   # topology, fwd, bwd(+head+loss), reduce+Adam
+        state = {"k": 0}
+
+        def one_step(fn):
+            k = state["k"]
+            if pipeline:
+                fn(batch, topo=topos[k], next_topo=topos[1 - k])
+                state["k"] = 1 - k
+            else:
+                fn(batch, topo=topos[0].rebuild())
+
+        if not dp_path:
+            def fwd_bwd():                      # fwd, bwd(+head+loss [+next topology]), reduce+Adam
+                for _ in range(steps_per_call):
+                    one_step(trainer.train_step)
 
             def all_reduce():
                 pass
@@ -114,11 +125,16 @@ def main():
             def reduce_and_step():
                 pass
         else:
+            steps_per_call = 1
+
             def fwd_bwd():
-                trainer.compute_gradients(batch, topo=topos[0].rebuild())
+                one_step(trainer.compute_gradients)
 
             def all_reduce():
-                trainer.all_reduce_gradients()
+                if world > 1:
+                    trainer.all_reduce_gradients()
+                elif args.force_dp_path:
+                    trainer.flat_g.mul_(1.0)
 
             def reduce_and_step():
                 trainer.apply_update()
@@ -151,7 +167,7 @@ def main():
                 reduce_and_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if world == 1:
+        if not (native and dp_path) and world == 1:
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
                 fwd_bwd()
@@ -159,6 +175,27 @@ def main():
 
             def call():
                 g1.replay()
+        elif native and pipeline:
+            # data parallel + pipelined topology: the gradient graph exists in an even and an odd
+            # flavour (which workspace it trains from / builds into); the all-reduce (RCCL) runs
+            # eagerly between the gradient graph and the Adam graph
+            gk = []
+            state["k"] = 0
+            for k in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    fwd_bwd()
+                gk.append(g)
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                reduce_and_step()
+            steps_per_call = 2
+
+            def call():
+                for k in (0, 1):
+                    gk[k].replay()
+                    all_reduce()
+                    g2.replay()
         else:
             g1 = torch.cuda.CUDAGraph()
             g2 = torch.cuda.CUDAGraph()

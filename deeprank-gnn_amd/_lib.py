@@ -115,7 +115,7 @@ class Api(object):
         lib.drgnn_train_update.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] +
                                            [ctypes.POINTER(ConvGrads)] * 2 + [_vp, _c_i64] + [_c_i32] * 3 +
                                            [_c_i64] + [_vp] * 4 + [_c_i64] + [_vp] * 2 +
-                                           [ctypes.c_float] * 4 + [_vp])
+                                           [ctypes.c_float] * 4 + [_c_i32, _vp])
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
                                                [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
         lib.drgnn_conv_layer_slabs.argtypes = [_c_i64]
@@ -209,12 +209,14 @@ class Api(object):
             _ptr(grad_x), _ptr(partials), _ptr(scratch), _ptr(step_inc), stream), "drgnn_net_backward")
 
     def train_update(self, desc, conv_partials, n_graphs, g1, g2, head_partials, R, H, O, head_offset,
-                     flat_p, flat_g, exp_avg, exp_avg_sq, step, loss, lr, beta1, beta2, eps, stream):
+                     flat_p, flat_g, exp_avg, exp_avg_sq, step, loss, lr, beta1, beta2, eps, stream,
+                     apply_adam=True):
         _check(self.lib.drgnn_train_update(
             ctypes.byref(desc), _ptr(conv_partials), n_graphs, g1, g2, _ptr(head_partials),
             head_partials.size(0), R, H, O,
             head_offset, _ptr(flat_p), _ptr(flat_g), _ptr(exp_avg), _ptr(exp_avg_sq), flat_p.numel(),
-            _ptr(step), _ptr(loss), lr, beta1, beta2, eps, stream), "drgnn_train_update")
+            _ptr(step), _ptr(loss), lr, beta1, beta2, eps, 1 if apply_adam else 0, stream),
+            "drgnn_train_update")
 
     def net_reduce_grads(self, desc, partials, n_nodes, n_graphs, g1, g2, grad_x, stream):
         _check(self.lib.drgnn_net_reduce_grads(ctypes.byref(desc), _ptr(partials), n_nodes, n_graphs,

@@ -261,11 +261,12 @@ struct UpdateArgs {
     HeadReduceArgs h;       // h.grad = flat gradient block of the FC head; h.step unused here
     AdamArgs ad;            // flat buffers; ad.grad = base of the flat gradient
     int conv_blocks;        // blocks [0, conv_blocks) reduce conv partials, the rest the head's
+    int apply_adam;         // 0: only produce the flat gradient (data parallel: all-reduce comes next)
 };
 
 DEV void update_store(const UpdateArgs& u, float* dst, float g) {
     *dst = g;                                   // keep p.grad inspectable
-    adam_item(u.ad, (int64_t)(dst - u.ad.grad));
+    if (u.apply_adam) adam_item(u.ad, (int64_t)(dst - u.ad.grad));
 }
 
 // sum of one head-partial element over the slabs w = first, first+stride, ...
@@ -933,12 +934,11 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
                        float* flat_param,
                        float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
                        const int32_t* step, float* loss, float lr, float beta1, float beta2, float eps,
-                       void* stream_) {
+                       int32_t apply_adam, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
-    if (!conv_partials || !g_conv1 || !g_conv2 || !head_partials || !flat_param || !flat_grad || !exp_avg ||
-        !exp_avg_sq || !step)
-        return DRGNN_E_ARG;
+    if (!conv_partials || !g_conv1 || !g_conv2 || !head_partials || !flat_grad) return DRGNN_E_ARG;
+    if (apply_adam && (!flat_param || !exp_avg || !exp_avg_sq || !step)) return DRGNN_E_ARG;
     UpdateArgs u;
     ReduceArgs& r = u.r;
     r.partials = conv_partials; r.n_graphs = (int)n_graphs; r.n_branch = net->n_branch;
@@ -956,6 +956,7 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
     u.ad.param = flat_param; u.ad.grad = flat_grad; u.ad.exp_avg = exp_avg; u.ad.exp_avg_sq = exp_avg_sq;
     u.ad.step = step; u.ad.n = n_param;
     u.ad.lr = lr; u.ad.beta1 = beta1; u.ad.beta2 = beta2; u.ad.eps = eps; u.ad.weight_decay = 0.0f;
+    u.apply_adam = apply_adam ? 1 : 0;
     const int64_t pitems = (int64_t)net->n_branch * r.n_partial;
     u.conv_blocks = (int)((pitems + 63) / 64);
     const int head_blocks = (u.h.P - 1 + 63) / 64;

@@ -117,13 +117,15 @@ class FusedTrainer(object):
                         topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream, step_inc=step_inc)
         return x, desc, xp, arg0, arg1, readout, scratch
 
-    def _backward(self, batch, topo, fused_update, next_topo=None):
+    def _backward(self, batch, topo, apply_adam, next_topo=None):
+        """fwd (++step) -> bwd with the per-graph head + loss inside (and, when given, the NEXT
+        mini-batch's topology build sharing that launch) -> fixed-order reduction of the partials,
+        with Adam applied in the same launch when ``apply_adam``."""
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
         stream = _lib.current_stream(batch.x)
-        x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(
-            batch, topo, stream, step_inc=self.step if fused_update else None)
+        x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream, step_inc=self.step)
         B = topo.n_graphs
         dev = x.device
         n_nodes, n_feat = x.shape
@@ -137,38 +139,24 @@ class FusedTrainer(object):
         for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, self.n_branch)):
             _fill_grads(g1[b], self.kind, l1, n_feat, H1)
             _fill_grads(g2[b], self.kind, l2, H1, H2)
-        if fused_update:
-            # 3 launches after the topology: forward (++step), backward with the per-graph head
-            # + loss inside, reduce + Adam
-            hp = torch.empty((max(B, 1), api.head_partial_elems(self.R, self.H, self.O)),
-                             dtype=torch.float32, device=dev)
-            api.net_backward_fused_head(desc, self._head_desc(True), x, readout, y, self.step, topo.ws_i32,
-                                        topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes, topo.max_edges,
-                                        topo.max_c0, xp, arg0, arg1, pred, hp, None, partials, scratch, stream,
-                                        next_topology=None if next_topo is None else next_topo.request())
-            api.train_update(desc, partials, B, g1, g2, hp, self.R, self.H, self.O, self.head_grad_offset,
-                             self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step, self.loss,
-                             self.lr, self.betas[0], self.betas[1], self.eps, stream)
-        else:
-            grad_readout = torch.empty_like(readout)
-            hp = torch.empty((max(api.head_num_slabs(B), 1), api.head_partial_elems(self.R, self.H, self.O)),
-                             dtype=torch.float32, device=dev)
-            api.head_step(self._head_desc(True), readout, y, B, self.step, pred, grad_readout, hp, stream)
-            api.net_backward(desc, x, grad_readout, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B,
-                             topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1, None, partials,
-                             scratch, stream)
-            api.net_reduce_grads(desc, partials, n_nodes, B, g1, g2, None, stream)
-            api.head_reduce(hp, B, self.R, self.H, self.O,
-                            self.flat_g.data_ptr() + 4 * self.head_grad_offset, self.loss, self.step, stream)
+        hp = torch.empty((max(B, 1), api.head_partial_elems(self.R, self.H, self.O)),
+                         dtype=torch.float32, device=dev)
+        api.net_backward_fused_head(desc, self._head_desc(True), x, readout, y, self.step, topo.ws_i32,
+                                    topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes, topo.max_edges,
+                                    topo.max_c0, xp, arg0, arg1, pred, hp, None, partials, scratch, stream,
+                                    next_topology=None if next_topo is None else next_topo.request())
+        api.train_update(desc, partials, B, g1, g2, hp, self.R, self.H, self.O, self.head_grad_offset,
+                         self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step, self.loss,
+                         self.lr, self.betas[0], self.betas[1], self.eps, stream, apply_adam=apply_adam)
         self.last_pred = pred
         self.last_batch_size = B
         return self.loss
 
-    def compute_gradients(self, batch, topo=None):
-        """topology -> body forward -> head+loss (+ its backward) -> body backward -> reduction.
-        Leaves d(mean loss over THIS batch)/d(params) in ``flat_g`` (= every ``p.grad``), the
-        loss in ``self.loss``, predictions in ``self.last_pred``; increments the step counter."""
-        return self._backward(batch, topo, fused_update=False)
+    def compute_gradients(self, batch, topo=None, next_topo=None):
+        """Everything of a step except the parameter update: leaves d(mean loss over THIS
+        batch)/d(params) in ``flat_g`` (= every ``p.grad``), the loss in ``self.loss``, predictions in
+        ``self.last_pred``; the step counter already counts this step."""
+        return self._backward(batch, topo, False, next_topo)
 
     def all_reduce_gradients(self, n_local=None, n_global=None, group=None):
         """Data parallel exchange: ONE all-reduce of the flat gradient buffer (RCCL over xGMI with
@@ -197,14 +185,13 @@ class FusedTrainer(object):
         (``Topology.from_batch(next_batch, build=False)``): it is built inside this step's backward
         launch (independent work sharing the launch), so the next step starts without a builder
         launch.
-        Single process: 4 launches (topology, body fwd, body bwd incl. head + loss, reduce+Adam).  With
-        torch.distributed initialised: reduce, ONE all-reduce of the flat gradient, Adam."""
+        Single process: 3 launches (+1 for the topology unless it was co-built by the previous step):
+        body fwd, body bwd incl. head + loss, reduce+Adam.  With torch.distributed initialised:
+        reduce, ONE all-reduce of the flat gradient, Adam."""
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
         if not distributed and self.weight_decay == 0.0:
-            return self._backward(batch, topo, fused_update=True, next_topo=next_topo)
-        loss = self.compute_gradients(batch, topo)
-        if next_topo is not None:
-            next_topo.rebuild()
+            return self._backward(batch, topo, True, next_topo)
+        loss = self.compute_gradients(batch, topo, next_topo)
         self.all_reduce_gradients(n_global=n_global, group=group)
         self.apply_update()
         return loss

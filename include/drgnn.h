@@ -327,14 +327,15 @@ int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * (as drgnn_net_reduce_grads) and of the head partials (as drgnn_head_reduce, without
  * touching the step counter), each reduced element immediately followed by its Adam update.
  * g_conv1/g_conv2 must point INTO flat_grad; head_offset = element offset of fc1.weight in
- * the flat buffers; *step must already count this update (drgnn_net_backward's step_inc).
- * weight_decay is not supported here (use reduce + drgnn_adam_step). */
+ * the flat buffers; *step must already count this update (the forward launch's step_inc).
+ * apply_adam = 0 only produces the flat gradient + loss (data parallel: all-reduce, then
+ * drgnn_adam_step).  weight_decay is not supported here (use drgnn_adam_step). */
 int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
                        drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2,
                        const float* head_partials, int64_t head_slabs /* rows of head_partials */,
                        int32_t R, int32_t H, int32_t O, int64_t head_offset, float* flat_param, float* flat_grad, float* exp_avg,
                        float* exp_avg_sq, int64_t n_param, const int32_t* step, float* loss,
-                       float lr, float beta1, float beta2, float eps, void* stream);
+                       float lr, float beta1, float beta2, float eps, int32_t apply_adam, void* stream);
 
 int drgnn_abi_version(void);
 
