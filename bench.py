@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="native mode: build each step's topology with its own launch at the start of the step "
                          "instead of inside the previous step's backward launch (double-buffered workspaces)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
+                    "exercising the multi-process path on a single GPU)")
     ap.add_argument("--force-dp-path", action="store_true",
                     help="run the data-parallel code path (gradient graph, eager all-reduce, Adam graph) even "
                          "with one process -- for testing on a single GPU")
@@ -68,11 +70,16 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd import _lib

@@ -71,21 +71,26 @@ struct TopoLaunch {
     int32_t* gscratch;     // global scratch (when not in LDS)
     int capN, capE;        // LDS capacities (0 = use global scratch)
     int level1_only;       // second pass: only depth-1 clusters, c1 offsets from NC0
+    int roles;             // 1: one workgroup per graph; 2: edge structures / member lists split
 };
 
 // LDS is a compile-time property so that every scratch access is a ds_* instruction (a
 // run-time choice between LDS and global would make them all flat_* accesses)
 template <bool LDS>
-DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
+DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
     TopoScratch s;
+    const int g = (L.roles == 2) ? (blk >> 1) : blk;
+    const int role = (L.roles == 2) ? ((blk & 1) ? TOPO_ROLE_MEMBERS : TOPO_ROLE_EDGES) : TOPO_ROLE_ALL;
+    const int sidx = (role == TOPO_ROLE_MEMBERS) ? L.args.n_graphs + g : g;
     const int32_t* NP = L.user_nptr ? L.user_nptr : L.tv.p[DRGNN_TI_NPTR];
     const int32_t* EP = L.user_eptr ? L.user_eptr : L.tv.p[DRGNN_TI_EPTR];
     const int n0 = NP[g], n1 = NP[g + 1], N = n1 - n0;
     const int e0 = EP[g], e1 = EP[g + 1], E = e1 - e0;
     if (!L.level1_only) {
         FOR_TID(i, 1) {
-            L.tv.p[DRGNN_TI_GSTAT][g] = 0;
-            if (L.user_nptr) {       // publish the offsets for the kernels that follow
+            L.tv.p[DRGNN_TI_GSTAT][sidx] = 0;
+            if (role == TOPO_ROLE_ALL) L.tv.p[DRGNN_TI_GSTAT][L.args.n_graphs + g] = 0;
+            if (L.user_nptr && role != TOPO_ROLE_MEMBERS) {       // publish the offsets for the kernels that follow
                 L.tv.p[DRGNN_TI_NPTR][g] = n0; L.tv.p[DRGNN_TI_NPTR][g + 1] = n1;
                 L.tv.p[DRGNN_TI_EPTR][g] = e0; L.tv.p[DRGNN_TI_EPTR][g + 1] = e1;
                 if (g == 0) L.tv.p[DRGNN_TI_ERR][0] = 0;
@@ -97,7 +102,7 @@ DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
         const int capT = imax(L.capN, L.capE) + 1;
         s = topo_carve(lds, L.capN, L.capE, capT, L.capN + L.capE + 2);
         if (N > L.capN || E > L.capE) {   // caller's bound was wrong: refuse loudly
-            FOR_TID(i, 1) { topo_flag(L.tv, DRGNN_S_EDGE_RANGE, g); }
+            FOR_TID(i, 1) { topo_flag(L.tv, DRGNN_S_EDGE_RANGE, sidx); }
             return;
         }
     } else {
@@ -105,7 +110,7 @@ DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
         s = topo_carve(L.gscratch + topo_gscratch_base(n0, e0, g), N, E, N + E + 1, N + E + 2);
     }
     if (!L.level1_only) {
-        topo_graph(L.tv, L.args, g, n0, n1, e0, e1, s);
+        topo_graph(L.tv, L.args, g, n0, n1, e0, e1, s, role);
     } else {
         // offset of this graph's ids inside cluster1 = number of depth-0 clusters before it
         FOR_TID(i, 1) { s.part[0] = 0; }
@@ -122,7 +127,7 @@ DEV void topo_block(const TopoLaunch& L, int g, int* lds) {
         int len = C0;
         if (g == L.args.n_graphs - 1 && (int64_t)begin + C0 != L.args.len_cluster1) len = -1;
         if ((int64_t)begin + C0 > L.args.len_cluster1) len = -1;
-        topo_graph_level1(L.tv, L.args, g, n0, begin, len, s);
+        topo_graph_level1(L.tv, L.args, g, n0, C0, begin, len, s, g);
     }
 }
 
@@ -465,6 +470,7 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     L.args.n_graphs = (int)n_graphs;
     L.gscratch = scratch_i32;
     L.level1_only = 0;
+    L.roles = 1;
     L.user_nptr = (node_ptr && edge_ptr) ? node_ptr : nullptr;
     L.user_eptr = (node_ptr && edge_ptr) ? edge_ptr : nullptr;
     int64_t lds = 0;
@@ -474,6 +480,10 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
         if (lds <= DRGNN_LDS_LIMIT) { L.capN = max_nodes; L.capE = max_edges > 0 ? max_edges : 1; }
         else lds = 0;
     }
+    // two independent workgroups per graph (edge structures / member lists) when nothing forces the
+    // single-chain order: LDS path, clusters present, depth-1 ids located by the caller
+    if (L.capN > 0 && cluster0 != nullptr && L.user_nptr != nullptr && !(cluster1 != nullptr && c1_ptr == nullptr))
+        L.roles = 2;
     *lds_out = lds;
     return 0;
 }
@@ -508,8 +518,8 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
     }
     std::vector<int> lds_buf((size_t)(lds / 4) + 16);
     for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) { if (!(cluster1 && !c1_ptr)) break; L.level1_only = 1; }
-        for (int gph = 0; gph < n_graphs; ++gph) {
+        if (pass == 1) { if (!(cluster1 && !c1_ptr)) break; L.level1_only = 1; L.roles = 1; }
+        for (int gph = 0; gph < n_graphs * (pass == 0 ? L.roles : 1); ++gph) {
             if (L.capN > 0) topo_block<true>(L, gph, lds_buf.data());
             else topo_block<false>(L, gph, lds_buf.data());
         }
@@ -526,8 +536,8 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void*)k_topo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     for (int pass = 0; pass < 2; ++pass) {
-        if (pass == 1) { if (!(cluster1 && !c1_ptr)) break; L.level1_only = 1; }
-        if (L.capN > 0) hipLaunchKernelGGL(k_topo<true>, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
+        if (pass == 1) { if (!(cluster1 && !c1_ptr)) break; L.level1_only = 1; L.roles = 1; }
+        if (L.capN > 0) hipLaunchKernelGGL(k_topo<true>, dim3((unsigned)(n_graphs * L.roles)), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
         else hipLaunchKernelGGL(k_topo<false>, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, stream, L);
     }
     HIP_TRY(hipGetLastError());
@@ -561,19 +571,20 @@ int drgnn_topology_status(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edge
     topo_layout(n_nodes, n_edges, n_graphs, &lay);
     const int32_t* err = ws_i32 + lay.i32[DRGNN_TI_ERR];
     const int32_t* gst = ws_i32 + lay.i32[DRGNN_TI_GSTAT];
-    std::vector<int32_t> host((size_t)n_graphs + 4);
+    std::vector<int32_t> host((size_t)(2 * n_graphs) + 4);
 #ifdef DRGNN_EMU
     for (int k = 0; k < 4; ++k) host[k] = err[k];
-    for (int64_t g = 0; g < n_graphs; ++g) host[4 + g] = gst[g];
+    for (int64_t g = 0; g < 2 * n_graphs; ++g) host[4 + g] = gst[g];
     (void)stream_;
 #else
     HIP_TRY(hipMemcpyAsync(host.data(), err, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     if (n_graphs > 0)
-        HIP_TRY(hipMemcpyAsync(host.data() + 4, gst, n_graphs * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
+        HIP_TRY(hipMemcpyAsync(host.data() + 4, gst, 2 * n_graphs * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream_));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream_));
 #endif
     status4[0] = host[0]; status4[1] = -1; status4[2] = 0; status4[3] = 0;
     for (int64_t g = 0; g < n_graphs; ++g) {
+        host[4 + g] |= host[4 + n_graphs + g];       // edge-structure and member-list workgroups
         if (host[4 + g]) {
             status4[0] |= host[4 + g];
             if (status4[1] < 0) status4[1] = (int32_t)g;
@@ -658,7 +669,7 @@ static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_edges, int32_
         }
     }
     if (co_ok)
-        for (int g = 0; g < co->args.n_graphs; ++g) topo_block<true>(*co, g, (int*)buf.data());
+        for (int g = 0; g < co->args.n_graphs * co->roles; ++g) topo_block<true>(*co, g, (int*)buf.data());
     (void)stream_;
     return co_ok ? 1 : 0;       // 1: the co-launched topology has been built as well
 #else
@@ -672,7 +683,7 @@ static int net_launch(NetLaunch& L, int32_t max_nodes, int32_t max_edges, int32_
         if (both > 64 * 1024)                                                                            \
             HIP_TRY(hipFuncSetAttribute((const void*)k_net_co_topo<K, BWD>,                              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));         \
-        hipLaunchKernelGGL((k_net_co_topo<K, BWD>), dim3((unsigned)(blocks + co->args.n_graphs)),        \
+        hipLaunchKernelGGL((k_net_co_topo<K, BWD>), dim3((unsigned)(blocks + co->args.n_graphs * co->roles)), \
                            dim3(DRGNN_NTHREADS), (size_t)both, stream, C);                               \
     } while (0)
         if (kind == DRGNN_GINET) DRGNN_CO_LAUNCH(DRGNN_GINET);

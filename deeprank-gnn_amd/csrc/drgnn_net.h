@@ -613,7 +613,7 @@ DEV void net_forward_graph(const NetArgs& a, int g, int br, float* scratch, int 
     net_cluster_max<DRGNN_H2>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, a.arg1 + nodeoff * DRGNN_H2);
     BARRIER();
     // graph readout: mean over the depth-1 clusters (scatter_mean with count clamp)
-    const int bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g];
+    const int bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g] | tv.p[DRGNN_TI_GSTAT][a.n_graphs + g];
     const int width = DRGNN_H2 * a.net.n_branch;
     FOR_TID(c, DRGNN_H2) {
         float acc = 0.0f;

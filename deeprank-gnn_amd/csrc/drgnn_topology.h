@@ -52,7 +52,7 @@ static inline void topo_layout(int64_t N, int64_t E, int64_t B, TopoLayout* L) {
     take(DRGNN_TI_E1PTR, B + 1);
     take(DRGNN_TI_CPTR1, B + 1);
     take(DRGNN_TI_ERR, 4);
-    take(DRGNN_TI_GSTAT, B);
+    take(DRGNN_TI_GSTAT, 2 * B);
     L->i32[DRGNN_TI_COUNT] = o;
     int64_t f = 0;
     L->f32[DRGNN_TF_W0] = f; f += (E + 3) & ~(int64_t)3;
@@ -226,7 +226,7 @@ DEV void wg_minmax64(const int64_t* ids, int n, long long* mm, bool preinit = fa
 
 // `prepared`: the caller has, in an earlier phase, set mm = {MAX, MIN} and cleared fl[0..capF)
 DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n, TopoScratch& s,
-                        bool prepared = false) {
+                        bool prepared = false, bool with_members = true) {
     wg_minmax64(ids, n, s.mm, prepared);
     const long long mn = s.mm[0];
     const long long span = (n > 0) ? (s.mm[1] - mn + 1) : 0;
@@ -271,9 +271,11 @@ DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n
         FOR_TID(b, n + 1) { s.mp[b] = 0; s.cur[b] = 0; }
         BARRIER();
     }
-    const int* cl = s.cl;
-    wg_bucket_sort(n, C, [cl] LAMBDA_DEV(int i) { return cl[i]; }, s.mp, s.cur, s.t1, s.t2, s.mem,
-                   s.part, true);
+    if (with_members) {
+        const int* cl = s.cl;
+        wg_bucket_sort(n, C, [cl] LAMBDA_DEV(int i) { return cl[i]; }, s.mp, s.cur, s.t1, s.t2, s.mem,
+                       s.part, true);
+    }
     return C;
 }
 
@@ -305,15 +307,15 @@ struct TopoArgs {
     int n_graphs;
 };
 
-DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0, int c1_begin,
-                           int c1_len, TopoScratch& s, bool prepared = false) {
+// C0 = number of depth-0 clusters of the graph; sidx = this workgroup's status word
+DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0, int C0, int c1_begin,
+                           int c1_len, TopoScratch& s, int sidx, bool prepared = false) {
     const int rowbase = n0 + g;
-    const int C0 = tv.p[DRGNN_TI_NC0][g];
     if (c1_len != C0) {
-        FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, g); }
+        FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, sidx); }
     }
     const int n = imin(C0, imax(c1_len, 0));
-    const int C1 = wg_cluster_rank(tv, g, a.cluster1 + c1_begin, n, s, prepared);
+    const int C1 = wg_cluster_rank(tv, sidx, a.cluster1 + c1_begin, n, s, prepared);
     int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
     int32_t* g_mptr1 = tv.p[DRGNN_TI_MPTR1] + rowbase;
     int32_t* g_mem1 = tv.p[DRGNN_TI_MEM1] + n0;
@@ -323,11 +325,44 @@ DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0,
     BARRIER();
 }
 
+// role 0: everything in one workgroup.  With two workgroups per graph the work splits into two
+// INDEPENDENT chains: role 1 = edge structures (CSR0/CSC0, pooled graph, CSC1; it recomputes the
+// cluster ranks it needs, 5 cheap phases), role 2 = the cluster member lists of both depths.
+#define TOPO_ROLE_ALL 0
+#define TOPO_ROLE_EDGES 1
+#define TOPO_ROLE_MEMBERS 2
+
+DEV void topo_members(const TopoView& tv, const TopoArgs& a, int g, int n0, int N, TopoScratch& s, int sidx) {
+    const int rowbase = n0 + g;
+    FOR_TID(v, s.capF) { s.fl[v] = 0; }
+    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+    BARRIER();
+    const int C = wg_cluster_rank(tv, sidx, a.cluster0 + n0, N, s, true);
+    int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
+    int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
+    int32_t* g_mem0 = tv.p[DRGNN_TI_MEM0] + n0;
+    FOR_TID(i, N) { g_cl0[i] = s.cl[i]; g_mem0[i] = s.mem[i]; }
+    FOR_TID(c, C + 1) { g_mptr0[c] = s.mp[c]; }
+    FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
+    FOR_TID(v, s.capF) { s.fl[v] = 0; }
+    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+    BARRIER();
+    if (a.cluster1 != nullptr && a.c1_ptr != nullptr) {
+        const int b = a.c1_ptr[g];
+        topo_graph_level1(tv, a, g, n0, C, b, a.c1_ptr[g + 1] - b, s, sidx, true);
+    }
+}
+
 DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1, int e0, int e1,
-                    TopoScratch& s) {
+                    TopoScratch& s, int role = TOPO_ROLE_ALL) {
     const int N = n1 - n0;
     int E = e1 - e0;
     const int rowbase = n0 + g;
+    const int sidx = (role == TOPO_ROLE_MEMBERS) ? a.n_graphs + g : g;
+    if (role == TOPO_ROLE_MEMBERS) {
+        if (a.cluster0 != nullptr) topo_members(tv, a, g, n0, N, s, sidx);
+        return;
+    }
     if (N <= 0 && E > 0) {
         FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_EDGE_RANGE, g); }
         E = 0;
@@ -425,8 +460,9 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         return;
     }
     // ---- depth-0 clusters (touches t1, t2, cur, fl, cl, mp, mem only) ----------------------
-    const int C = wg_cluster_rank(tv, g, a.cluster0 + n0, N, s, true);
-    {
+    const bool members = (role == TOPO_ROLE_ALL);
+    const int C = wg_cluster_rank(tv, g, a.cluster0 + n0, N, s, true, members);
+    if (members) {
         int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
         int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
         int32_t* g_mem0 = tv.p[DRGNN_TI_MEM0] + n0;
@@ -435,44 +471,36 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
     }
 
-    // ---- pool_edge: candidates of pooled row r = CSR0 rows of its members, in order ----
-    FOR_TID(r, C + 1) {
-        int acc = 0;
-        if (r < C) {
-            for (int p = s.mp[r]; p < s.mp[r + 1]; ++p) {
-                const int m = s.mem[p];
-                s.nb[m] = acc;
-                acc += rp[m + 1] - rp[m];
-            }
-        }
-        s.pp[r] = acc;
-    }
+    // ---- pool_edge: bucket the CSR0 slots by the pooled row of their source node (stable:
+    // slot order = (member, edge) order), then rank every bucket by (target cluster, slot) ------
+    FOR_TID(r, C + 1) { s.pp[r] = 0; s.cur[r] = 0; }
+    FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-1 cluster ranks
+    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+    BARRIER();
+    FOR_TID(k, E) { ATOMIC_ADD(&s.pp[s.cl[s.seg[k]]], 1); }
     BARRIER();
     wg_exscan(s.pp, C + 1, s.part);
     FOR_TID(k, E) {                                   // one work item per CSR0 slot
-        const int m = s.seg[k];
-        const int r = s.cl[m];
+        const int r = s.cl[s.seg[k]];
         const int cc = s.cl[s.col[k]];
-        const int j = s.pp[r] + s.nb[m] + (k - rp[m]);
+        const int j = s.pp[r] + ATOMIC_ADD(&s.cur[r], 1);
         s.t1[j] = (cc == r) ? INT_MAX : cc;           // self loop of the pooled graph: dropped
         s.t2[j] = k;
         s.t3[j] = r;
     }
-    FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-1 cluster ranks
-    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
     BARRIER();
-    // rank sort of every pooled row's candidates by (target cluster, position)
+    // rank sort of every pooled row's candidates by (target cluster, CSR0 slot)
     FOR_TID(j, E) {
         const int r = s.t3[j];
-        const int key = s.t1[j];
+        const int key = s.t1[j], slot = s.t2[j];
         const int lo = s.pp[r], hi = s.pp[r + 1];
         int rank = 0;
         for (int q = lo; q < hi; ++q) {
             const int kq = s.t1[q];
-            rank += (kq < key || (kq == key && q < j)) ? 1 : 0;
+            rank += (kq < key || (kq == key && s.t2[q] < slot)) ? 1 : 0;
         }
         s.t4[lo + rank] = key;
-        s.t5[lo + rank] = s.t2[j];
+        s.t5[lo + rank] = slot;
     }
     BARRIER();
     // heads of runs of equal target = the coalesced pooled edges, already (row, col) sorted
@@ -519,8 +547,8 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
                  tv.p[DRGNN_TI_ROWIDX1] + e0, tv.p[DRGNN_TI_TSLOT1] + e0, true);
 
     // ---- depth-1 clusters (when the caller knows where this graph's ids start) --------
-    if (a.cluster1 != nullptr && a.c1_ptr != nullptr) {
+    if (role == TOPO_ROLE_ALL && a.cluster1 != nullptr && a.c1_ptr != nullptr) {
         const int b = a.c1_ptr[g];
-        topo_graph_level1(tv, a, g, n0, b, a.c1_ptr[g + 1] - b, s, true);
+        topo_graph_level1(tv, a, g, n0, C, b, a.c1_ptr[g + 1] - b, s, g, true);
     }
 }

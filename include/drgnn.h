@@ -81,7 +81,7 @@ enum drgnn_topo_i32 {
     DRGNN_TI_E1PTR,      /* [B+1]  exclusive scan of NE1                                     */
     DRGNN_TI_CPTR1,      /* [B+1]  exclusive scan of NC1                                     */
     DRGNN_TI_ERR,        /* [4]    [0] batch-level status bits (offset derivation)           */
-    DRGNN_TI_GSTAT,      /* [B]    per-graph status bits, rewritten by every build           */
+    DRGNN_TI_GSTAT,      /* [2B]   per-graph status bits (edge half, member half), rewritten by every build */
     DRGNN_TI_COUNT
 };
 enum drgnn_topo_f32 {
