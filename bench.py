@@ -276,45 +276,64 @@ def main():
 
 
 def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
-    """Average duration of each of our kernels (HIP events around `iters` back-to-back launches
-    on torch's current stream = the stream they are launched on), dominant one vs HBM peak."""
-    from deeprank_gnn_amd import _lib, functional
+    """Average duration of each launch of the native step, measured with HIP events around
+    `iters` back-to-back launches on torch's current stream (= the stream the kernels are launched
+    on), and the dominant one against the HBM roofline.  Algorithmic bytes: SURVEY.md §8(d)
+    per-graph figures x 64 graphs."""
+    import copy
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.functional import H1, H2, _fill_grads, _split
     from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd.trainer import FusedTrainer
     api = _lib.get()
+    tr = FusedTrainer(copy.deepcopy(net), lr=1e-3, task="reg", seed=99)
     topo = Topology.from_batch(batch, need_weights=False)
-    convs = (net.conv1, net.conv2, net.conv1_ext, net.conv2_ext)
-    params = tuple(p.detach().contiguous() for c in convs for p in c.live_parameters())
-    x = batch.x.contiguous()
+    nxt = Topology.from_batch(batch, need_weights=False, build=False)
+    stream = _lib.current_stream(batch.x)
+    x, desc, xp, arg0, arg1, readout, scratch = tr._body_forward(batch, topo, stream)
     n_nodes, n_feat = x.shape
     B = topo.n_graphs
-    nb = 2
-    xp = torch.empty((nb, n_nodes, 16), device=dev)
-    arg0 = torch.empty((nb, n_nodes, 16), dtype=torch.int32, device=dev)
-    arg1 = torch.empty((nb, n_nodes, 32), dtype=torch.int32, device=dev)
-    readout = torch.empty((B, 64), device=dev)
-    gr = torch.randn((B, 64), device=dev)
-    partials = torch.empty((B * nb, api.net_partial_elems(_lib.GINET, n_feat)), device=dev)
-    desc = functional._describe(_lib.GINET, n_feat, params, nb)
-    stream = _lib.current_stream(x)
-    d = batch.__dict__
-    ei, ea = batch.edge_index.contiguous(), batch.edge_attr.reshape(-1).contiguous()
+    pred = torch.empty((B, 1), device=dev)
+    y = batch.y.contiguous()
+    partials = torch.empty((B * 2, api.net_partial_elems(_lib.GINET, n_feat)), device=dev)
+    hp = torch.empty((B, api.head_partial_elems(tr.R, tr.H, tr.O)), device=dev)
+    g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+    g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+    for b, (l1, l2) in enumerate(_split(tr.kind, tr.live_grads, tr.n_branch)):
+        _fill_grads(g1[b], tr.kind, l1, n_feat, H1)
+        _fill_grads(g2[b], tr.kind, l2, H1, H2)
+    head = tr._head_desc(True)
+    req = nxt.request()
 
     def k_topo():
-        api.topology_build(ei, None, batch.batch, batch.cluster0, batch.cluster1, d["_node_ptr"], d["_edge_ptr"],
-                           d["_c1_ptr"], n_nodes, ei.size(1), batch.cluster1.numel(), B, topo.max_nodes,
-                           topo.max_edges, topo.ws_i32, topo.ws_f32, None, stream)
+        topo.rebuild()
 
     def k_fwd():
         api.net_forward(desc, x, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes,
-                        topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, None, stream)
+                        topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream)
+
+    def k_bwd_co():
+        api.net_backward_fused_head(desc, head, x, readout, y, tr.step, topo.ws_i32, topo.ws_f32, n_nodes,
+                                    topo.n_edges, B, topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1,
+                                    pred, hp, None, partials, scratch, stream, next_topology=req)
 
     def k_bwd():
-        api.net_backward(desc, x, gr, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes,
-                         topo.max_edges, topo.max_c0, xp, arg0, arg1, None, partials, None, stream)
+        api.net_backward_fused_head(desc, head, x, readout, y, tr.step, topo.ws_i32, topo.ws_f32, n_nodes,
+                                    topo.n_edges, B, topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1,
+                                    pred, hp, None, partials, scratch, stream)
 
+    def k_update():
+        api.train_update(desc, partials, B, g1, g2, hp, tr.R, tr.H, tr.O, tr.head_grad_offset, tr.flat_p,
+                         tr.flat_g, tr.exp_avg, tr.exp_avg_sq, tr.step, tr.loss, 0.0, 0.9, 0.999, 1e-8, stream)
+
+    upd_bytes = (partials.numel() + hp.numel() + 7 * tr.flat_p.numel()) * 4 / B
     out = {}
-    for name, fn, nbytes in (("k_topo", k_topo, BYTES_TOPO), ("k_net<GINet,fwd>", k_fwd, BYTES_FWD - 5808 - 0),
-                             ("k_net<GINet,bwd>", k_bwd, BYTES_BWD)):
+    for name, fn, nbytes in (
+            ("k_net<GINet,fwd>", k_fwd, BYTES_FWD - 5808),
+            ("k_net_co_topo<GINet,bwd+head> (+ topology of the next batch)", k_bwd_co, BYTES_BWD + BYTES_TOPO),
+            ("k_update (partials reduction + Adam)", k_update, upd_bytes),
+            ("k_topo (own launch; not on the pipelined path)", k_topo, BYTES_TOPO),
+            ("k_net<GINet,bwd+head> (own launch; not on the pipelined path)", k_bwd, BYTES_BWD)):
         for _ in range(10):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -327,10 +346,20 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
         us = e0.elapsed_time(e1) * 1e3 / iters
         out[name] = {"avg_us": us, "alg_bytes_per_launch": nbytes * B,
                      "achieved_GBs": nbytes * B / (us * 1e-6) / 1e9}
-    dom = max(out, key=lambda k: out[k]["avg_us"])
+    on_path = list(out)[:3]
+    dom = max(on_path, key=lambda k: out[k]["avg_us"])
     ach = out[dom]["achieved_GBs"]
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "r01_bench_native_v2_pmc.json")
+    if os.path.exists(pmc_path):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (offline passes)
+        pmc = json.load(open(pmc_path))
+        for k, v in pmc.items():
+            if "k_net_co_topo" in k and "co_topo" in dom:
+                traffic = v["hbm_bytes_per_launch"]
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_note": "bytes/launch from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, profiles/"
+                            "r01_bench_native_v2_pmc.json); FETCH doubled per MI355X_MICROARCH.md",
             "whole_step_frac": graphs_per_s * (BYTES_FWD + BYTES_BWD) / 1e9 / HBM_PEAK_GBS,
             "kernels": out}
 
