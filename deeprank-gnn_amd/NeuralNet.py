@@ -17,6 +17,7 @@ import torch
 from . import _lib
 from .data import Batch
 from .dataset import GraphDataSet
+from .topology import Topology
 from .trainer import FusedTrainer
 
 __all__ = ["NeuralNet"]
@@ -150,10 +151,21 @@ class NeuralNet(object):
         """One pass over the training set (NeuralNet.py:477-537) on the native step."""
         store = {'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': []}
         running = 0.0
-        for batch in self._batches(self.dataset, self.train_index, self.shuffle):
-            loss = self.trainer.train_step(batch)
+        need_w = self.trainer.kind == _lib.SGAT
+        it = self._batches(self.dataset, self.train_index, self.shuffle)
+        batch = next(it, None)
+        topo = None if batch is None else Topology.from_batch(batch, api=self.trainer.api, need_weights=need_w)
+        while batch is not None:
+            # one-batch look-ahead: the next mini-batch's topology is built inside this step's
+            # backward launch (index tensors only), so only the first batch of an epoch pays a
+            # builder launch of its own
+            nxt = next(it, None)
+            nxt_topo = None if nxt is None else Topology.from_batch(nxt, api=self.trainer.api,
+                                                                    need_weights=need_w, build=False)
+            loss = self.trainer.train_step(batch, topo=topo, next_topo=nxt_topo)
             running += float(loss)                      # host sync per batch, as the reference's .item()
             self._collect(self.trainer.last_pred, batch, store)
+            batch, topo = nxt, nxt_topo
         return running, store
 
     def eval(self, dataset=None, indices=None):

@@ -55,3 +55,38 @@ def test_needs_gpu_without_emulation():
         pytest.skip("GPU present")
     with pytest.raises(_lib.DrgnnError):
         NeuralNet(DB, GINet, node_feature=NODE_FEATURES, target='irmsd')
+
+
+def test_epoch_with_several_batches_uses_the_lookahead(tmp_path):
+    """batch_size 3 -> three mini-batches per epoch: the topology of batch k+1 is built inside
+    the backward launch of batch k.  Same losses as stepping every batch with its own build."""
+    from deeprank_gnn_amd.topology import Topology
+    built = {"n": 0}
+    orig = Topology.rebuild
+
+    def counting(self):
+        built["n"] += 1
+        return orig(self)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    nn = NeuralNet(DB, sGAT, node_feature=NODE_FEATURES, edge_feature=['dist'], target='irmsd',
+                   batch_size=3, percent=[0.8, 0.2], shuffle=False, outdir=str(tmp_path), _api=emu(), device='cpu')
+    Topology.rebuild = counting
+    try:
+        nn.train(nepoch=2, validate=False, save_model=None, hdf5=None)
+    finally:
+        Topology.rebuild = orig
+    assert built["n"] == 2                     # one explicit build per epoch (first batch); the rest rode along
+    assert np.isfinite(nn.train_loss).all() and nn.train_loss[1] < nn.train_loss[0]
+    # reference run: every batch builds its own topology
+    torch.manual_seed(0)
+    np.random.seed(0)
+    ref = NeuralNet(DB, sGAT, node_feature=NODE_FEATURES, edge_feature=['dist'], target='irmsd',
+                    batch_size=3, percent=[0.8, 0.2], shuffle=False, outdir=str(tmp_path), _api=emu(), device='cpu')
+    total = []
+    for _ in range(2):
+        run = 0.0
+        for batch in ref._batches(ref.dataset, ref.train_index, False):
+            run += float(ref.trainer.train_step(batch))
+        total.append(run)
+    np.testing.assert_allclose(nn.train_loss, total, rtol=1e-6)
