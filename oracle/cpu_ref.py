@@ -59,10 +59,12 @@ class _SegMax(torch.autograd.Function):
     def forward(ctx, src, index, dim_size):
         n, h = src.shape
         idx = index.view(-1, 1).expand(n, h)
+        # the CPU kernel compares with '>' : a NaN source never replaces the running maximum
+        clean = torch.where(torch.isnan(src), torch.full_like(src, -math.inf), src)
         best = torch.full((dim_size, h), -math.inf, dtype=src.dtype)
-        best = best.scatter_reduce(0, idx, src, reduce="amax", include_self=True)
+        best = best.scatter_reduce(0, idx, clean, reduce="amax", include_self=True)
         pos = torch.arange(n).view(-1, 1).expand(n, h)
-        is_best = src == best.gather(0, idx)
+        is_best = (clean == best.gather(0, idx)) & (clean > -math.inf)
         cand = torch.where(is_best, pos, torch.full_like(pos, n))
         arg = torch.full((dim_size, h), n, dtype=torch.long)
         arg = arg.scatter_reduce(0, idx, cand, reduce="amin", include_self=True)

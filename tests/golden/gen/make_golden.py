@@ -155,6 +155,13 @@ def main():
     for name in NETS:
         run_case(name, syn, 12, 1, ys, "reg", "syn4_%s.npz" % name, seed=2)
 
+    # -- nets on a batch that contains an isolated node (FoutLayer: NaN row, dropped by the max-pool) --
+    iso = [to_shim(synth.make_graph(i, n_nodes=40, n_pairs=70, n_feat=12, n_c1=4, n_internal=40,
+                                    isolate_node=(7 if i == 1 else None))) for i in range(3)]
+    yi = torch.cat([g.y for g in iso])
+    for name in NETS:
+        run_case(name, iso, 12, 1, yi, "reg", "iso3_%s.npz" % name, seed=4)
+
     # -- conv layers with an isolated node ----------------------------------
     g = synth.make_graph(7, n_nodes=24, n_pairs=40, n_feat=6, n_c1=3, n_internal=10, isolate_node=5)
     torch.manual_seed(3)

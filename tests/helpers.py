@@ -41,6 +41,13 @@ def syn4_batch():
     return Batch.from_data_list(syn4_graphs())
 
 
+def iso3_batch():
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.data import Batch
+    return Batch.from_data_list([synth.make_graph(i, n_nodes=40, n_pairs=70, n_feat=12, n_c1=4, n_internal=40,
+                                                  isolate_node=(7 if i == 1 else None)) for i in range(3)])
+
+
 CASES = {
     # golden file            net       batch factory                task
     "fix8_GINet.npz": ("GINet", lambda: fixture_batch(8), "reg"),
@@ -50,4 +57,8 @@ CASES = {
     "syn4_GINet.npz": ("GINet", syn4_batch, "reg"),
     "syn4_sGAT.npz": ("sGAT", syn4_batch, "reg"),
     "syn4_FoutNet.npz": ("FoutNet", syn4_batch, "reg"),
+    # one graph has an isolated node: GINet row 0, sGAT row = bias, FoutLayer row NaN (dropped by the pooling)
+    "iso3_GINet.npz": ("GINet", iso3_batch, "reg"),
+    "iso3_sGAT.npz": ("sGAT", iso3_batch, "reg"),
+    "iso3_FoutNet.npz": ("FoutNet", iso3_batch, "reg"),
 }
