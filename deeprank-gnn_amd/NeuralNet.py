@@ -3,8 +3,8 @@ without torch_geometric / h5py: same constructor vocabulary, ``train`` / ``eval`
 ``save_model`` / ``pretrained_model=`` flow and the same checkpoint dictionary
 (NeuralNet.py:775-790), with the per-batch body executed by ``FusedTrainer`` (native step).
 
-What is NOT reproduced: ``PreCluster`` (community detection is offline preprocessing; the
-graphs must already carry ``clustering/<method>/depth_{0,1}``, as the reference's fixture does),
+``PreCluster`` (MCL) runs on the device when the graphs do not carry
+``clustering/<method>/depth_{0,1}`` yet.  What is NOT reproduced: Louvain clustering,
 ``Metrics`` / plots, and the HDF5 epoch export (written as ``.npz`` with the same group names
 because h5py is absent on the target image).
 """
@@ -74,8 +74,12 @@ class NeuralNet(object):
                                     target=self.target, clustering_method=self.cluster_nodes or 'mcl', index=self.index)
         first = self.dataset[0]
         if getattr(first, "cluster0", None) is None:
-            raise ValueError("the graphs carry no clustering/%s/depth_0|1: run the reference's PreCluster "
-                             "(offline community detection) once on the dataset" % self.cluster_nodes)
+            # the reference runs PreCluster at every construction (NeuralNet.py:139-143); here only
+            # when the graphs do not carry the labels yet (same result: MCL is deterministic)
+            from .clustering import PreCluster
+            print("Loading clusters")
+            PreCluster(self.dataset, method=self.cluster_nodes or 'mcl', api=_api, device=self.device)
+            first = self.dataset[0]
         if pretrained_model is None:
             i_train, i_valid = _divide(len(self.dataset), self.percent, True)
         else:

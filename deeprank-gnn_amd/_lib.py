@@ -131,6 +131,7 @@ class Api(object):
         lib.drgnn_segmax_backward.argtypes = [_vp, _vp, _c_i64, _c_i32, _c_i64, _vp, _vp]
         lib.drgnn_pooled_edges_export.argtypes = [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp]
         lib.drgnn_cluster_offset.argtypes = [_vp, _vp, _c_i64, _vp, _vp]
+        lib.drgnn_mcl.argtypes = [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp]
         lib.drgnn_head_partial_elems.argtypes = [_c_i32] * 3
         lib.drgnn_head_partial_elems.restype = _c_i64
         lib.drgnn_head_num_slabs.argtypes = [_c_i64]
@@ -259,6 +260,11 @@ class Api(object):
     def cluster_offset(self, cluster, node_ptr, n_graphs, scratch, stream):
         _check(self.lib.drgnn_cluster_offset(_ptr(cluster), _ptr(node_ptr), n_graphs, _ptr(scratch), stream),
                "drgnn_cluster_offset")
+
+    def mcl(self, edge_index, n_edges, node_ptr, edge_ptr, mat_ptr, n_graphs, mat_scratch, int_scratch, labels,
+            info, stream):
+        _check(self.lib.drgnn_mcl(_ptr(edge_index), n_edges, _ptr(node_ptr), _ptr(edge_ptr), _ptr(mat_ptr), n_graphs,
+                                  _ptr(mat_scratch), _ptr(int_scratch), _ptr(labels), _ptr(info), stream), "drgnn_mcl")
 
     # -- head / loss / optimiser ------------------------------------------------
     def head_partial_elems(self, R, H, O):

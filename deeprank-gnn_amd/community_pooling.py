@@ -8,8 +8,8 @@ the torch_geometric / torch_scatter helpers its models import), on the device pa
 
 These return dynamically-shaped tensors, so -- like the reference -- they synchronise with the
 host; the shipped nets avoid them and run fused (see functional.net_body).  The OFFLINE half of
-the reference module (community_detection: MCL / Louvain on networkx graphs, run once per
-dataset and cached in the HDF5) is not part of the per-step path and is not provided.
+the reference module (community_detection with method 'mcl', run once per dataset and cached with
+the graphs) is provided on the device through deeprank_gnn_amd.clustering; Louvain is not.
 """
 import types
 
@@ -233,11 +233,29 @@ def scatter_sum(src, index, dim=0, out=None, dim_size=None):
     return _scatter_reduce(src, index, dim, out, dim_size, False)
 
 
-def community_detection(*args, **kwargs):
-    raise NotImplementedError(
-        "community_detection (MCL / Louvain on networkx, reference community_pooling.py:95-158) is the "
-        "offline preprocessing half: it runs once per dataset and its result is stored with the graphs "
-        "(clustering/<method>/depth_{0,1}); it is outside the per-step hot path this package implements.")
+def community_detection(edge_index, num_nodes, edge_attr=None, method='mcl'):
+    """Cluster labels of ONE graph (reference community_pooling.py:95-158).  'mcl' runs on the device
+    (unweighted, like the reference's PreCluster call); 'louvain' (python-louvain, randomised, so
+    without a reproducible answer to match) is not provided."""
+    if method != 'mcl':
+        raise ValueError('Clustering method %s not supported' % method)
+    if edge_attr is not None:
+        raise NotImplementedError("weighted MCL is never used by the reference's PreCluster")
+    from .clustering import community_detection_mcl
+    return community_detection_mcl(edge_index, num_nodes, api=_api())
 
 
-community_detection_per_batch = community_detection
+def community_detection_per_batch(edge_index, batch, num_nodes, edge_attr=None, method='mcl'):
+    """Per-graph MCL with the reference's running label offset (community_pooling.py:33-92:
+    ``ncluster = max(cluster)`` after every graph, i.e. consecutive graphs SHARE one id)."""
+    if method != 'mcl':
+        raise ValueError('Clustering method %s not supported' % method)
+    from .clustering import mcl_labels, _ptr_from_counts
+    batch = torch.as_tensor(batch, device=edge_index.device)
+    B = int(batch.max()) + 1
+    node_ptr = _ptr_from_counts(torch.bincount(batch, minlength=B), edge_index.device)
+    edge_ptr = _ptr_from_counts(torch.bincount(batch[edge_index[0]], minlength=B), edge_index.device)
+    labels, _ = mcl_labels(edge_index, node_ptr, edge_ptr, api=_api())
+    tops = torch.stack([labels[batch == g].max() for g in range(B)])
+    offset = torch.cat([tops.new_zeros(1), tops.cumsum(0)[:-1]])
+    return labels + offset[batch]

@@ -6,6 +6,7 @@
 //        every "launch" becomes a loop over workgroups on host pointers)
 #include "drgnn_head.h"
 #include "drgnn_layers.h"
+#include "drgnn_mcl.h"
 
 #include <vector>
 #ifdef DRGNN_EMU
@@ -356,6 +357,11 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_cluster_max(ClusterOffsetArg
 }
 __global__ void k_cluster_scan(ClusterOffsetArgs a) { cluster_scan_single(a); }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_cluster_add(ClusterOffsetArgs a) { cluster_add_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_mcl(MclArgs a) {
+    __shared__ double red[DRGNN_NTHREADS];
+    __shared__ int flag[2];
+    mcl_graph(a, blockIdx.x, flag, red);
+}
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_head(HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_h[];
     head_block(a, blockIdx.x, smem_h);
@@ -1132,6 +1138,30 @@ int drgnn_cluster_offset(int64_t* cluster, const int32_t* node_ptr, int64_t n_gr
     hipLaunchKernelGGL(k_cluster_max, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_cluster_scan, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_cluster_add, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+// ---- offline clustering ---------------------------------------------------------------------------
+int drgnn_mcl(const int64_t* edge_index, int64_t n_edges, const int32_t* node_ptr, const int32_t* edge_ptr,
+              const int64_t* mat_ptr, int64_t n_graphs, double* mat_scratch, int32_t* int_scratch,
+              int64_t* labels, int32_t* info, void* stream) {
+    if (!node_ptr || !edge_ptr || !mat_ptr || !mat_scratch || !int_scratch || !labels || !info || n_graphs < 0)
+        return DRGNN_E_ARG;
+    if (n_edges > 0 && !edge_index) return DRGNN_E_ARG;
+    if (n_graphs == 0) return 0;
+    MclArgs a;
+    a.edge_index = edge_index; a.n_edges = n_edges; a.node_ptr = node_ptr; a.edge_ptr = edge_ptr;
+    a.mat_ptr = mat_ptr; a.n_graphs = (int)n_graphs; a.mat = mat_scratch; a.iscr = int_scratch;
+    a.labels = labels; a.info = info; a.iterations = 100; a.prune_threshold = 1e-3;
+#ifdef DRGNN_EMU
+    std::vector<double> red(DRGNN_NTHREADS);
+    int flag[2];
+    for (int g = 0; g < n_graphs; ++g) mcl_graph(a, g, flag, red.data());
+    (void)stream;
+#else
+    hipLaunchKernelGGL(k_mcl, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

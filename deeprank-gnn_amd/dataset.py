@@ -64,6 +64,17 @@ class GraphStore(object):
     def get(self, mol, path):
         return self._mols[mol][path]
 
+    def set(self, mol, path, array):
+        """Add / replace one dataset in memory (used by PreCluster to attach clustering/<method>/depth_k)."""
+        self._mols[mol][path] = np.asarray(array)
+
+    def save_npz(self, path):
+        flat = {"__mols__": np.array(self.mols())}
+        for mol, tree in self._mols.items():
+            for k, v in tree.items():
+                flat["%s/%s" % (mol, k)] = v
+        np.savez_compressed(path, **flat)
+
     def children(self, mol, prefix):
         prefix = prefix.rstrip("/") + "/"
         return sorted({k[len(prefix):].split("/")[0] for k in self._mols[mol] if k.startswith(prefix)})

@@ -337,6 +337,17 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
                        float* exp_avg_sq, int64_t n_param, const int32_t* step, float* loss,
                        float lr, float beta1, float beta2, float eps, int32_t apply_adam, void* stream);
 
+/* ---- offline clustering --------------------------------------------------------
+ * Markov clustering of every graph of a batch: community_detection(edge_index, num_nodes,
+ * method='mcl') (community_pooling.py:95-158; markov_clustering.run_mcl defaults), as PreCluster
+ * runs it on the internal-contact graph (DataSet.py:77-86).  One workgroup per graph, dense fp64.
+ * mat_ptr int64 [B+1] = prefix sums of N_g^2; mat_scratch 3 * mat_ptr[B] doubles; int_scratch
+ * 4 * N ints; labels int64 [N] (per-graph cluster ids, the reference's numbering); info int32 [B]
+ * = iterations used (negative: no convergence within 100). */
+int drgnn_mcl(const int64_t* edge_index, int64_t n_edges, const int32_t* node_ptr, const int32_t* edge_ptr,
+              const int64_t* mat_ptr, int64_t n_graphs, double* mat_scratch, int32_t* int_scratch,
+              int64_t* labels, int32_t* info, void* stream);
+
 int drgnn_abi_version(void);
 
 #ifdef __cplusplus

@@ -99,3 +99,14 @@ def test_custom_net_from_layers_trains():
         opt.step()
         losses.append(float(loss))
     assert losses[-1] < losses[0]
+
+
+def test_precluster_on_device_reproduces_the_fixture_labels():
+    """Offline MCL (fp64, one workgroup per graph) + pooling on the MI355X == the reference's stored
+    clustering/mcl/depth_0 and depth_1 for all 10 fixture graphs."""
+    from test_mcl import _fixture_batch_without_clusters
+    from deeprank_gnn_amd.clustering import precluster
+    batch, expect0, expect1 = _fixture_batch_without_clusters()
+    d0, d1 = precluster(batch.to(DEV))
+    np.testing.assert_array_equal(d0.cpu().numpy(), expect0)
+    np.testing.assert_array_equal(d1.cpu().numpy(), expect1)
