@@ -100,7 +100,7 @@ def main():
     need_w = args.net == "sGAT"
     pipeline = native and not args.no_pipeline
     dp_path = world > 1 or args.force_dp_path
-    steps_per_call = 2 if pipeline else 1
+    state = {"k": 0}       # which of the two topology workspaces the next step trains from
     if native:
         from deeprank_gnn_amd.trainer import FusedTrainer
         trainer = FusedTrainer(net, lr=1e-3, task="reg", seed=1234 + rank)
@@ -109,9 +109,7 @@ def main():
         # topology of step t+1 is built into the other INSIDE step t's backward launch (the builder
         # only depends on index tensors).  Every step still builds one topology and consumes one.
         topos = [Topology.from_batch(batch, need_weights=need_w),
-                 Topology.from_batch(batch, need_weights=need_w, build=not pipeline)]
-
-        state = {"k": 0}
+                 Topology.from_batch(batch, need_weights=need_w)]
 
         def one_step(fn):
             k = state["k"]
@@ -122,19 +120,16 @@ def main():
                 fn(batch, topo=topos[0].rebuild())
 
         if not dp_path:
-            def fwd_bwd():                      # fwd, bwd(+head+loss [+next topology]), reduce+Adam
-                for _ in range(steps_per_call):
-                    one_step(trainer.train_step)
+            def grad_part():                    # fwd, bwd(+head+loss [+next topology]), reduce+Adam
+                one_step(trainer.train_step)
 
             def all_reduce():
                 pass
 
-            def reduce_and_step():
+            def update_part():
                 pass
         else:
-            steps_per_call = 1
-
-            def fwd_bwd():
+            def grad_part():
                 one_step(trainer.compute_gradients)
 
             def all_reduce():
@@ -143,14 +138,14 @@ def main():
                 elif args.force_dp_path:
                     trainer.flat_g.mul_(1.0)
 
-            def reduce_and_step():
+            def update_part():
                 trainer.apply_update()
     else:
         opt = torch.optim.Adam(net.parameters(), lr=1e-3, fused=True, capturable=capture)
         bucket = FlatGradBucket(net.parameters())
         loss_out = torch.zeros((), device=dev)
 
-        def fwd_bwd():
+        def grad_part():
             bucket.zero()
             topo = Topology.from_batch(batch, need_weights=need_w)
             pred = net(batch, topo=topo)
@@ -161,80 +156,86 @@ def main():
         def all_reduce():
             bucket.all_reduce()
 
-        def reduce_and_step():
+        def update_part():
             opt.step()
+
+    split = dp_path or (world > 1)            # eager collective between the gradient and the update part
+    two_flavours = native and pipeline        # steps alternate between the two topology workspaces
+
+    def eager_step():
+        grad_part()
+        all_reduce()
+        update_part()
 
     if capture:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(3):
-                fwd_bwd()
-                all_reduce()
-                reduce_and_step()
+            for _ in range(4):                # even: the workspace parity is back to 0 afterwards
+                eager_step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        if not (native and dp_path) and world == 1:
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                fwd_bwd()
-                reduce_and_step()
 
-            def call():
-                g1.replay()
-        elif native and pipeline:
-            # data parallel + pipelined topology: the gradient graph exists in an even and an odd
-            # flavour (which workspace it trains from / builds into); the all-reduce (RCCL) runs
-            # eagerly between the gradient graph and the Adam graph
-            gk = []
+        def graph_of(fn):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            return g
+
+        state["k"] = 0
+        if split:
+            # [gradient graph (one per workspace parity)] -> eager all-reduce (RCCL) -> [Adam graph]
+            g_grad = [graph_of(grad_part) for _ in range(2 if two_flavours else 1)]
+            g_upd = graph_of(update_part)
             state["k"] = 0
-            for k in (0, 1):
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    fwd_bwd()
-                gk.append(g)
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                reduce_and_step()
-            steps_per_call = 2
 
-            def call():
-                for k in (0, 1):
-                    gk[k].replay()
+            def run_steps(n):
+                for _ in range(n):
+                    g_grad[state["k"] if two_flavours else 0].replay()
                     all_reduce()
-                    g2.replay()
+                    g_upd.replay()
+                    if two_flavours:
+                        state["k"] ^= 1
         else:
-            g1 = torch.cuda.CUDAGraph()
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                fwd_bwd()
-            with torch.cuda.graph(g2):
-                reduce_and_step()
+            def whole_step():
+                grad_part()
+                update_part()
 
-            def call():
-                g1.replay()
-                all_reduce()
-                g2.replay()
+            if two_flavours:
+                def pair():
+                    whole_step()
+                    whole_step()
+                g_pair = graph_of(pair)                         # parity 0 -> 0
+                g_one = [graph_of(whole_step), graph_of(whole_step)]   # parity 0 -> 1, then 1 -> 0
+                state["k"] = 0
+
+                def run_steps(n):
+                    if n > 0 and state["k"] == 1:
+                        g_one[1].replay()
+                        state["k"] = 0
+                        n -= 1
+                    for _ in range(n // 2):
+                        g_pair.replay()
+                    if n % 2:
+                        g_one[0].replay()
+                        state["k"] = 1
+            else:
+                g_step = graph_of(whole_step)
+
+                def run_steps(n):
+                    for _ in range(n):
+                        g_step.replay()
     else:
-        def call():
-            fwd_bwd()
-            all_reduce()
-            reduce_and_step()
+        def run_steps(n):
+            for _ in range(n):
+                eager_step()
 
-    if args.steps % steps_per_call or args.warmup % steps_per_call:
-        raise SystemExit("--steps and --warmup must be multiples of %d in this mode" % steps_per_call)
-    n_calls, n_warm = args.steps // steps_per_call, args.warmup // steps_per_call
-
-    def step_calls(n):
-        for _ in range(n):
-            call()
-
-    step_calls(n_warm)
+    run_steps(args.warmup)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    step_calls(n_calls)
+    run_steps(args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
