@@ -37,6 +37,7 @@ N_FEAT = 32
 # algorithmic HBM bytes per graph (derivation table): GINet
 BYTES_FWD, BYTES_BWD = 67668, 90208
 BYTES_TOPO = 4804 + 1800 + 5808 + 16 * 1000        # read edge_index (int64 [2,E]) + clusters, write CSR0 + pooled CSR
+PMC_FILE = "r01_bench_native_v3_pmc.json"
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -282,59 +283,38 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
     on), and the dominant one against the HBM roofline.  Algorithmic bytes: SURVEY.md §8(d)
     per-graph figures x 64 graphs."""
     import copy
-    from deeprank_gnn_amd import _lib
-    from deeprank_gnn_amd.functional import H1, H2, _fill_grads, _split
     from deeprank_gnn_amd.topology import Topology
     from deeprank_gnn_amd.trainer import FusedTrainer
-    api = _lib.get()
     tr = FusedTrainer(copy.deepcopy(net), lr=1e-3, task="reg", seed=99)
     topo = Topology.from_batch(batch, need_weights=False)
     nxt = Topology.from_batch(batch, need_weights=False, build=False)
-    stream = _lib.current_stream(batch.x)
-    x, desc, xp, arg0, arg1, readout, scratch = tr._body_forward(batch, topo, stream)
-    n_nodes, n_feat = x.shape
-    B = topo.n_graphs
-    pred = torch.empty((B, 1), device=dev)
-    y = batch.y.contiguous()
-    partials = torch.empty((B * 2, api.net_partial_elems(_lib.GINET, n_feat)), device=dev)
-    hp = torch.empty((B, api.head_partial_elems(tr.R, tr.H, tr.O)), device=dev)
-    g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-    g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-    for b, (l1, l2) in enumerate(_split(tr.kind, tr.live_grads, tr.n_branch)):
-        _fill_grads(g1[b], tr.kind, l1, n_feat, H1)
-        _fill_grads(g2[b], tr.kind, l2, H1, H2)
-    head = tr._head_desc(True)
-    req = nxt.request()
+    assert tr._can_fuse(topo, batch.x.shape[1]), "SYN graphs must take the fused-step path"
+    c = tr._fused_prepare(batch, topo)
+    B = c["B"]
 
     def k_topo():
         topo.rebuild()
 
-    def k_fwd():
-        api.net_forward(desc, x, topo.ws_i32, topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes,
-                        topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream)
+    def k_step_co():
+        tr._fused_launch_step(c, nxt)
 
-    def k_bwd_co():
-        api.net_backward_fused_head(desc, head, x, readout, y, tr.step, topo.ws_i32, topo.ws_f32, n_nodes,
-                                    topo.n_edges, B, topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1,
-                                    pred, hp, None, partials, scratch, stream, next_topology=req)
-
-    def k_bwd():
-        api.net_backward_fused_head(desc, head, x, readout, y, tr.step, topo.ws_i32, topo.ws_f32, n_nodes,
-                                    topo.n_edges, B, topo.max_nodes, topo.max_edges, topo.max_c0, xp, arg0, arg1,
-                                    pred, hp, None, partials, scratch, stream)
+    def k_step():
+        tr._fused_launch_step(c, None)
 
     def k_update():
-        api.train_update(desc, partials, B, g1, g2, hp, tr.R, tr.H, tr.O, tr.head_grad_offset, tr.flat_p,
-                         tr.flat_g, tr.exp_avg, tr.exp_avg_sq, tr.step, tr.loss, 0.0, 0.9, 0.999, 1e-8, stream)
+        tr._fused_launch_update(c, True, lr=0.0)
 
-    upd_bytes = (partials.numel() + hp.numel() + 7 * tr.flat_p.numel()) * 4 / B
+    upd_bytes = (c["partials"].numel() + c["hp"].numel() + c["readout"].numel() + 7 * tr.flat_p.numel()) * 4 / B
+    # SURVEY figures of forward + backward (the fused launch moves less: xp/arg0/arg1 stay in LDS)
+    step_bytes = BYTES_FWD - 5808 + BYTES_BWD
     out = {}
     for name, fn, nbytes in (
-            ("k_net<GINet,fwd>", k_fwd, BYTES_FWD - 5808),
-            ("k_net_co_topo<GINet,bwd+head> (+ topology of the next batch)", k_bwd_co, BYTES_BWD + BYTES_TOPO),
+            ("k_step_co_topo<GINet> (fwd + head/loss + bwd, + topology of the next batch)", k_step_co,
+             step_bytes + BYTES_TOPO),
             ("k_update (partials reduction + Adam)", k_update, upd_bytes),
             ("k_topo (own launch; not on the pipelined path)", k_topo, BYTES_TOPO),
-            ("k_net<GINet,bwd+head> (own launch; not on the pipelined path)", k_bwd, BYTES_BWD)):
+            ("k_step_co_topo<GINet> without the co-launched topology (not on the pipelined path)", k_step,
+             step_bytes)):
         for _ in range(10):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -347,20 +327,20 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
         us = e0.elapsed_time(e1) * 1e3 / iters
         out[name] = {"avg_us": us, "alg_bytes_per_launch": nbytes * B,
                      "achieved_GBs": nbytes * B / (us * 1e-6) / 1e9}
-    on_path = list(out)[:3]
+    on_path = list(out)[:2]
     dom = max(on_path, key=lambda k: out[k]["avg_us"])
     ach = out[dom]["achieved_GBs"]
     traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", "r01_bench_native_v2_pmc.json")
+    pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
     if os.path.exists(pmc_path):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (offline passes)
         pmc = json.load(open(pmc_path))
         for k, v in pmc.items():
-            if "k_net_co_topo" in k and "co_topo" in dom:
+            if "k_step_co_topo" in k and "k_step_co_topo" in dom:
                 traffic = v["hbm_bytes_per_launch"]
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_note": "bytes/launch from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, profiles/"
-                            "r01_bench_native_v2_pmc.json); FETCH doubled per MI355X_MICROARCH.md",
+                            "%s); FETCH doubled per MI355X_MICROARCH.md" % PMC_FILE,
             "whole_step_frac": graphs_per_s * (BYTES_FWD + BYTES_BWD) / 1e9 / HBM_PEAK_GBS,
             "kernels": out}
 

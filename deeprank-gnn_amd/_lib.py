@@ -116,6 +116,17 @@ class Api(object):
                                            [ctypes.POINTER(ConvGrads)] * 2 + [_vp, _c_i64] + [_c_i32] * 3 +
                                            [_c_i64] + [_vp] * 4 + [_c_i64] + [_vp] * 2 +
                                            [ctypes.c_float] * 4 + [_c_i32, _vp])
+        lib.drgnn_net_step_lds_bytes.argtypes = [_c_i32] * 8
+        lib.drgnn_net_step_lds_bytes.restype = _c_i64
+        lib.drgnn_head_compact_elems.argtypes = [_c_i32] * 3
+        lib.drgnn_head_compact_elems.restype = _c_i64
+        lib.drgnn_net_train_step.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc)] + [_vp] * 5 +
+                                             [_c_i64] * 3 + [_c_i32] * 3 + [_vp] * 5 +
+                                             [ctypes.POINTER(TopologyRequest), _vp])
+        lib.drgnn_step_update.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] +
+                                          [ctypes.POINTER(ConvGrads)] * 2 + [_vp, _vp] + [_c_i32] * 3 +
+                                          [_c_i64] + [_vp] * 4 + [_c_i64] + [_vp] * 2 +
+                                          [ctypes.c_float] * 4 + [_c_i32, _vp])
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
                                                [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
         lib.drgnn_conv_layer_slabs.argtypes = [_c_i64]
@@ -218,6 +229,31 @@ class Api(object):
             head_offset, _ptr(flat_p), _ptr(flat_g), _ptr(exp_avg), _ptr(exp_avg_sq), flat_p.numel(),
             _ptr(step), _ptr(loss), lr, beta1, beta2, eps, 1 if apply_adam else 0, stream),
             "drgnn_train_update")
+
+    # -- fused training step ------------------------------------------------------
+    def net_step_lds_bytes(self, kind, n_feat, max_nodes, max_edges, max_c0, R, H, O):
+        return int(self.lib.drgnn_net_step_lds_bytes(kind, n_feat, max_nodes, max_edges, max_c0, R, H, O))
+
+    def head_compact_elems(self, R, H, O):
+        return int(self.lib.drgnn_head_compact_elems(R, H, O))
+
+    def net_train_step(self, desc, head, x, target, step2, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
+                       max_nodes, max_edges, max_c0, pred, readout, head_partials, partials, xchg, stream,
+                       next_topology=None):
+        _check(self.lib.drgnn_net_train_step(
+            ctypes.byref(desc), ctypes.byref(head), _ptr(x), _ptr(target), _ptr(step2), _ptr(ws_i32),
+            _ptr(ws_f32), n_nodes, n_edges, n_graphs, max_nodes, max_edges, max_c0, _ptr(pred), _ptr(readout),
+            _ptr(head_partials), _ptr(partials), _ptr(xchg),
+            None if next_topology is None else ctypes.byref(next_topology), stream), "drgnn_net_train_step")
+
+    def step_update(self, desc, conv_partials, n_graphs, g1, g2, head_partials, readout, R, H, O, head_offset,
+                    flat_p, flat_g, exp_avg, exp_avg_sq, step2, loss, lr, beta1, beta2, eps, stream,
+                    apply_adam=True):
+        _check(self.lib.drgnn_step_update(
+            ctypes.byref(desc), _ptr(conv_partials), n_graphs, g1, g2, _ptr(head_partials), _ptr(readout),
+            R, H, O, head_offset, _ptr(flat_p), _ptr(flat_g), _ptr(exp_avg), _ptr(exp_avg_sq), flat_p.numel(),
+            _ptr(step2), _ptr(loss), lr, beta1, beta2, eps, 1 if apply_adam else 0, stream),
+            "drgnn_step_update")
 
     def net_reduce_grads(self, desc, partials, n_nodes, n_graphs, g1, g2, grad_x, stream):
         _check(self.lib.drgnn_net_reduce_grads(ctypes.byref(desc), _ptr(partials), n_nodes, n_graphs,

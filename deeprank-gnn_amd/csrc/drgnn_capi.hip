@@ -5,6 +5,7 @@
 //   g++ -x c++ -DDRGNN_EMU      -> tests/emu/build/libdrgnn_emu.so (CPU test-suite only:
 //        every "launch" becomes a loop over workgroups on host pointers)
 #include "drgnn_head.h"
+#include "drgnn_step.h"
 #include "drgnn_layers.h"
 #include "drgnn_mcl.h"
 
@@ -261,6 +262,44 @@ DEV void net_block(const NetLaunch& L, int blk, float* lds) {
     else net_forward_graph<KIND>(L.a, g, br, scratch, capN, capE, capC);
 }
 
+// ---- fused training step (drgnn_step.h): one launch for body fwd + head/loss + body bwd, sharing the
+// grid with the topology builder of the next mini-batch exactly like CoLaunch above ---------------
+struct StepLaunch {
+    StepArgs a;
+    int capN, capE, capC;
+    int64_t words;          // scratch words per workgroup (emulation: one persistent slab each)
+};
+struct StepCoLaunch {
+    StepLaunch step;
+    TopoLaunch topo;
+    int n_net;
+};
+
+template <int KIND>
+DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
+    const int nb = L.a.net.n_branch;
+    const int g = blk / nb, br = blk % nb;
+    const int n0 = L.a.tv.p[DRGNN_TI_NPTR][g], e0 = L.a.tv.p[DRGNN_TI_EPTR][g];
+    if (L.a.tv.p[DRGNN_TI_NPTR][g + 1] - n0 > L.capN || L.a.tv.p[DRGNN_TI_EPTR][g + 1] - e0 > L.capE ||
+        L.a.tv.p[DRGNN_TI_NC0][g] > L.capC) {
+        // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
+        if (part != 2) {
+            const uint32_t tag = (uint32_t)L.a.step2[0] + 1u;
+            FOR_TID(c, DRGNN_H2) {
+                const long slot = (long)g * L.a.hf.R + br * DRGNN_H2 + c;
+                const_cast<float*>(L.a.hf.readout)[slot] = DRGNN_NAN;
+                if (nb > 1) xchg_publish(L.a.xchg + slot, tag, DRGNN_NAN);
+            }
+        }
+        if (part != 1 && br == 0) {
+            float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+            FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+        }
+        return;
+    }
+    net_step_graph<KIND>(L.a, g, br, lds, L.capN, L.capE, L.capC, part);
+}
+
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
 struct UpdateArgs {
     ReduceArgs r;
@@ -268,6 +307,11 @@ struct UpdateArgs {
     AdamArgs ad;            // flat buffers; ad.grad = base of the flat gradient
     int conv_blocks;        // blocks [0, conv_blocks) reduce conv partials, the rest the head's
     int apply_adam;         // 0: only produce the flat gradient (data parallel: all-reduce comes next)
+    // fused-step mode: head slabs are compact ([dhid H][dW2][db2][loss][weight], u.h.P floats each) and
+    // dW_fc1[h][r] = sum_g dhid[g][h] * readout[g][r] is formed here
+    const float* readout;   // [n_wg][R] or null (legacy slabs that already hold dW_fc1)
+    int hR, hH;
+    int32_t* step2;         // non-null: commit step2[0] = step2[1] (the step index Adam just used)
 };
 
 DEV void update_store(const UpdateArgs& u, float* dst, float g) {
@@ -275,16 +319,30 @@ DEV void update_store(const UpdateArgs& u, float* dst, float g) {
     if (u.apply_adam) adam_item(u.ad, (int64_t)(dst - u.ad.grad));
 }
 
+// number of head items one update launch produces: the gradient block + the loss
+DEV int update_head_items(const UpdateArgs& u) { return (u.readout ? u.hH * u.hR : 0) + u.h.P - 1; }
 // sum of one head-partial element over the slabs w = first, first+stride, ...
 DEV float update_head_sum(const UpdateArgs& u, int item, int first, int stride) {
-    const float* src = u.h.partials + item;
     float acc = 0.0f;
+    if (u.readout) {
+        const int HR = u.hH * u.hR;
+        if (item < HR) {
+            const int h = item / u.hR, r = item - h * u.hR;
+            const float* dh = u.h.partials + h;
+            const float* xr = u.readout + r;
+#pragma unroll 4
+            for (int w = first; w < u.h.n_wg; w += stride) acc = fmaf(dh[(long)w * u.h.P], xr[(long)w * u.hR], acc);
+            return acc;
+        }
+        item -= HR;
+    }
+    const float* src = u.h.partials + item;
 #pragma unroll 4
     for (int w = first; w < u.h.n_wg; w += stride) acc += src[(long)w * u.h.P];
     return acc;
 }
 DEV void update_head_store(const UpdateArgs& u, int item, float acc) {
-    const int n_grad = u.h.P - 2;
+    const int n_grad = update_head_items(u) - 1;
     if (item < n_grad) update_store(u, u.h.grad + item, acc);
     else if (item == n_grad && u.h.loss) u.h.loss[0] = acc;
 }
@@ -297,6 +355,7 @@ __global__ void __launch_bounds__(256) k_ptrs(PtrArgs a) {
 template <bool LDS>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_topo(TopoLaunch L) {
     extern __shared__ __attribute__((aligned(16))) int smem_i[];
+    PHASE_BEGIN();
     topo_block<LDS>(L, blockIdx.x, smem_i);
 }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_finalize(ScanArgs a) {
@@ -324,13 +383,22 @@ __global__ void __launch_bounds__(256) k_reduce(ReduceArgs a, int64_t n_items) {
 template <int KIND, bool BWD, bool LDS>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net(NetLaunch L) {
     extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    PHASE_BEGIN();
     net_block<KIND, BWD, LDS>(L, blockIdx.x, smem_f);
 }
 template <int KIND, bool BWD>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net_co_topo(CoLaunch C) {
     extern __shared__ __attribute__((aligned(16))) float smem_c[];
+    PHASE_BEGIN();
     if ((int)blockIdx.x < C.n_net) net_block<KIND, BWD, true>(C.net, blockIdx.x, smem_c);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_c);
+}
+template <int KIND>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C) {
+    extern __shared__ __attribute__((aligned(16))) float smem_s[];
+    PHASE_BEGIN();
+    if ((int)blockIdx.x < C.n_net) step_block<KIND>(C.step, blockIdx.x, smem_s, 0);
+    else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);
 }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
 __global__ void __launch_bounds__(256) k_conv_aggregate(ConvLayerArgs a) {
@@ -388,12 +456,14 @@ __global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
         }
     } else {
         const int item = ((int)blockIdx.x - u.conv_blocks) * 64 + lane;
-        const bool live = item < u.h.P - 1;
+        const bool live = item < update_head_items(u);
         quarter[q][lane] = live ? update_head_sum(u, item, q, 4) : 0.0f;
         __syncthreads();
         if (q == 0 && live)
             update_head_store(u, item, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
     }
+    // nobody reads step2[0] in this launch (Adam reads step2[1]): safe to commit it here
+    if (u.step2 && blockIdx.x == 0 && threadIdx.x == 0) u.step2[0] = u.step2[1];
 }
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
     adam_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
@@ -830,6 +900,120 @@ int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_de
                              next_topology);
 }
 
+// ---- fused training step ---------------------------------------------------------------------
+static int64_t step_lds_bytes(int kind, int F, int capN, int capE, int capC, int R, int H, int O) {
+    return 4 * step_scratch_words(kind, F, capN, capE, capC, R, H, O);
+}
+
+int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
+                                 int32_t max_c0, int32_t R, int32_t H, int32_t O) {
+    if (max_nodes <= 0) return 0;
+    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    return step_lds_bytes(kind, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, R, H, O);
+}
+
+int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O) { return head_compact_floats(R, H, O); }
+
+int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, const float* x,
+                         const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
+                         int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
+                         int32_t max_edges, int32_t max_c0, float* pred, float* readout,
+                         float* head_partials, float* partials, uint64_t* xchg,
+                         const drgnn_topology_request* next, void* stream_) {
+    int rc = net_check(net);
+    if (rc) return rc;
+    if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2 || !x || !target || !step2 || !ws_i32 || !pred ||
+        !readout || !head_partials || !partials)
+        return DRGNN_E_ARG;
+    if (net->n_branch > 1 && !xchg) return DRGNN_E_ARG;
+    if (net->kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
+    if (hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
+        return DRGNN_E_WIDTH;
+    if (max_nodes <= 0) return DRGNN_E_CAPACITY;
+    StepLaunch L;
+    L.capN = max_nodes;
+    L.capE = max_edges > 0 ? max_edges : 1;
+    L.capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    const int kind = net->kind, F = net->n_feat;
+    const int64_t lds = step_lds_bytes(kind, F, L.capN, L.capE, L.capC, hd->R, hd->H, hd->O);
+    if (lds > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
+    L.words = lds / 4;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    StepArgs& a = L.a;
+    a.net = *net; a.x = x;
+    a.tv = topo_view(const_cast<int32_t*>(ws_i32), const_cast<float*>(ws_f32), lay);
+    a.n_nodes = n_nodes; a.n_graphs = (int)n_graphs;
+    a.partials = partials; a.n_partial = (int)net_partial_floats(F);
+    a.xchg = (unsigned long long*)xchg; a.step2 = step2;
+    HeadFused& hf = a.hf;
+    hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
+    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0;
+    hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
+    hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
+    hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
+    hf.readout = readout; hf.step = step2; hf.pred = pred; hf.partials = head_partials; hf.stage = 0;
+
+    const int blocks = (int)n_graphs * net->n_branch;
+    TopoLaunch T;
+    int64_t tlds = 0;
+    bool co_ok = false;
+    if (next) {
+        rc = topo_prepare(T, &tlds, next->edge_index, next->edge_attr, next->batch, next->cluster0, next->cluster1,
+                          next->node_ptr, next->edge_ptr, next->c1_ptr, next->n_nodes, next->n_edges,
+                          next->len_cluster1, next->n_graphs, next->max_nodes, next->max_edges, next->ws_i32,
+                          next->ws_f32, next->scratch_i32);
+        if (rc) return rc;
+        co_ok = T.capN > 0 && T.user_nptr != nullptr && !(T.args.cluster1 != nullptr && T.args.c1_ptr == nullptr) &&
+                T.args.n_graphs > 0 && blocks > 0;
+    }
+    if (blocks > 0) {
+#ifdef DRGNN_EMU
+        // workgroups run one after the other here: two passes (up to the readout exchange, then the
+        // rest), each workgroup keeping its "LDS" in a slab of its own between the passes
+        std::vector<float> slabs((size_t)blocks * (size_t)(L.words + 16));
+        for (int pass = 1; pass <= 2; ++pass)
+            for (int b = 0; b < blocks; ++b) {
+                float* lds_b = slabs.data() + (size_t)b * (size_t)(L.words + 16);
+                if (kind == DRGNN_GINET) step_block<DRGNN_GINET>(L, b, lds_b, pass);
+                else if (kind == DRGNN_SGAT) step_block<DRGNN_SGAT>(L, b, lds_b, pass);
+                else step_block<DRGNN_FOUT>(L, b, lds_b, pass);
+            }
+        if (co_ok) {
+            std::vector<int> tbuf((size_t)(tlds / 4) + 16);
+            for (int g = 0; g < T.args.n_graphs * T.roles; ++g) topo_block<true>(T, g, tbuf.data());
+        }
+        (void)stream_;
+#else
+        hipStream_t stream = (hipStream_t)stream_;
+        StepCoLaunch C;
+        C.step = L; C.n_net = blocks;
+        int64_t both = lds;
+        int extra = 0;
+        if (co_ok) { C.topo = T; both = lds > tlds ? lds : tlds; extra = T.args.n_graphs * T.roles; }
+#define DRGNN_STEP_LAUNCH(K)                                                                                \
+    do {                                                                                                    \
+        if (both > 64 * 1024)                                                                               \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_step_co_topo<K>,                                     \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));            \
+        hipLaunchKernelGGL((k_step_co_topo<K>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),    \
+                           (size_t)both, stream, C);                                                        \
+    } while (0)
+        if (kind == DRGNN_GINET) DRGNN_STEP_LAUNCH(DRGNN_GINET);
+        else if (kind == DRGNN_SGAT) DRGNN_STEP_LAUNCH(DRGNN_SGAT);
+        else DRGNN_STEP_LAUNCH(DRGNN_FOUT);
+#undef DRGNN_STEP_LAUNCH
+        HIP_TRY(hipGetLastError());
+#endif
+    }
+    if (next && (!co_ok || blocks == 0))
+        return drgnn_topology_build(next->edge_index, next->edge_attr, next->batch, next->cluster0, next->cluster1,
+                                    next->node_ptr, next->edge_ptr, next->c1_ptr, next->n_nodes, next->n_edges,
+                                    next->len_cluster1, next->n_graphs, next->max_nodes, next->max_edges,
+                                    next->ws_i32, next->ws_f32, next->scratch_i32, stream_);
+    return 0;
+}
+
 int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,
                            int64_t n_graphs, drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2,
                            float* grad_x, void* stream_) {
@@ -945,12 +1129,17 @@ int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
     return 0;
 }
 
-int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+}  // extern "C"
+
+// `readout` null: legacy head slabs [head_slabs][head_partial_floats] (dW_fc1 inside), Adam reads step[0].
+// `readout` given (fused step): compact slabs [n_graphs][head_compact_floats] + readout [n_graphs][R];
+// `step` is then the 2-word counter of drgnn_net_train_step: Adam reads step[1], step[0] is committed.
+static int update_impl(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
                        drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
-                       int64_t head_slabs, int32_t R, int32_t H, int32_t O, int64_t head_offset,
-                       float* flat_param,
+                       int64_t head_slabs, const float* readout, int32_t R, int32_t H, int32_t O,
+                       int64_t head_offset, float* flat_param,
                        float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
-                       const int32_t* step, float* loss, float lr, float beta1, float beta2, float eps,
+                       int32_t* step, float* loss, float lr, float beta1, float beta2, float eps,
                        int32_t apply_adam, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
@@ -968,15 +1157,18 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
     r.grad_x = nullptr; r.n_nodes = 0;
     u.h.partials = head_partials;
     u.h.n_wg = (int)head_slabs;
-    u.h.P = (int)head_partial_floats(R, H, O);
+    u.h.P = (int)(readout ? head_compact_floats(R, H, O) : head_partial_floats(R, H, O));
     u.h.grad = flat_grad + head_offset; u.h.loss = loss; u.h.step = nullptr;
+    u.readout = readout; u.hR = R; u.hH = H;
+    u.step2 = readout ? step : nullptr;
     u.ad.param = flat_param; u.ad.grad = flat_grad; u.ad.exp_avg = exp_avg; u.ad.exp_avg_sq = exp_avg_sq;
-    u.ad.step = step; u.ad.n = n_param;
+    u.ad.step = (readout && step) ? step + 1 : step; u.ad.n = n_param;
     u.ad.lr = lr; u.ad.beta1 = beta1; u.ad.beta2 = beta2; u.ad.eps = eps; u.ad.weight_decay = 0.0f;
     u.apply_adam = apply_adam ? 1 : 0;
     const int64_t pitems = (int64_t)net->n_branch * r.n_partial;
     u.conv_blocks = (int)((pitems + 63) / 64);
-    const int head_blocks = (u.h.P - 1 + 63) / 64;
+    const int head_items = (readout ? H * R : 0) + u.h.P - 1;
+    const int head_blocks = (head_items + 63) / 64;
 #ifdef DRGNN_EMU
     for (int64_t i = 0; i < pitems; ++i) {
         const int br = (int)(i / r.n_partial), p = (int)(i % r.n_partial);
@@ -984,13 +1176,41 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
         float* d = reduce_dst(r, br, p);
         if (d) update_store(u, d, reduce_sum(r, br, p, 0, 1));
     }
-    for (int i = 0; i < u.h.P - 1; ++i) update_head_store(u, i, update_head_sum(u, i, 0, 1));
+    for (int i = 0; i < head_items; ++i) update_head_store(u, i, update_head_sum(u, i, 0, 1));
+    if (u.step2) u.step2[0] = u.step2[1];
     (void)stream_; (void)head_blocks;
 #else
     hipLaunchKernelGGL(k_update, dim3((unsigned)(u.conv_blocks + head_blocks)), dim3(256), 0, (hipStream_t)stream_, u);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;
+}
+
+extern "C" {
+
+int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+                       drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
+                       int64_t head_slabs, int32_t R, int32_t H, int32_t O, int64_t head_offset,
+                       float* flat_param,
+                       float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
+                       const int32_t* step, float* loss, float lr, float beta1, float beta2, float eps,
+                       int32_t apply_adam, void* stream_) {
+    if (!head_partials) return DRGNN_E_ARG;
+    return update_impl(net, conv_partials, n_graphs, g_conv1, g_conv2, head_partials, head_slabs, nullptr, R, H, O,
+                       head_offset, flat_param, flat_grad, exp_avg, exp_avg_sq, n_param,
+                       const_cast<int32_t*>(step), loss, lr, beta1, beta2, eps, apply_adam, stream_);
+}
+
+int drgnn_step_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+                      drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
+                      const float* readout, int32_t R, int32_t H, int32_t O, int64_t head_offset,
+                      float* flat_param, float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
+                      int32_t* step2, float* loss, float lr, float beta1, float beta2, float eps,
+                      int32_t apply_adam, void* stream_) {
+    if (!head_partials || !readout || !step2) return DRGNN_E_ARG;
+    return update_impl(net, conv_partials, n_graphs, g_conv1, g_conv2, head_partials, n_graphs, readout, R, H, O,
+                       head_offset, flat_param, flat_grad, exp_avg, exp_avg_sq, n_param, step2, loss, lr, beta1,
+                       beta2, eps, apply_adam, stream_);
 }
 
 // ---- stand-alone layers / pooling functions ---------------------------------------------------

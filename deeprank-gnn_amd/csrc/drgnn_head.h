@@ -67,8 +67,8 @@ DEV void head_block(const HeadArgs& a, int blk, float* lds) {
     PHASE_MARK();
 
     // ---- stage (all loads in flight together when the sizes allow) ------------------------
-    if (H * R <= 8 * DRGNN_NTHREADS && T * R <= 4 * DRGNN_NTHREADS && O * H <= 2 * DRGNN_NTHREADS &&
-        H <= DRGNN_NTHREADS) {
+    if (H * R <= 8 * DRGNN_BCAP && T * R <= 4 * DRGNN_BCAP && O * H <= 2 * DRGNN_BCAP &&
+        H <= DRGNN_BCAP) {
         BurstW<8> bw1;  burst_load_w(bw1, a.w1, R, 1, H, R);
         BurstW<4> bx;   burst_load_w(bx, a.readout + (long)g0 * R, R, 1, G, R);
         Burst<float, 1> bb1, bb2;  burst_load(bb1, a.b1, H);  burst_load(bb2, a.b2, O);

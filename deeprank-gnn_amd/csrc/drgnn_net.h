@@ -410,8 +410,8 @@ DEV void stage_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i]
 
 // sizes for which the register-burst prologue applies (its per-lane element counts are fixed)
 DEV bool net_burst_ok(const float* xg, int F, int N, int E, int C) {
-    return ((((uintptr_t)xg) & 15) == 0) && (F % 4 == 0) && (F * DRGNN_H1 <= DRGNN_NTHREADS) && ((long)N * F <= 16L * DRGNN_NTHREADS) &&
-           (N + 1 <= DRGNN_NTHREADS) && (E <= 2 * DRGNN_NTHREADS) && (C * DRGNN_H1 <= 4 * DRGNN_NTHREADS);
+    return ((((uintptr_t)xg) & 15) == 0) && (F % 4 == 0) && (F * DRGNN_H1 <= DRGNN_BCAP) && ((long)N * F <= 16L * DRGNN_BCAP) &&
+           (N + 1 <= DRGNN_BCAP) && (E <= 2 * DRGNN_BCAP) && (C * DRGNN_H1 <= 4 * DRGNN_BCAP);
 }
 
 // weights + x tile
@@ -456,7 +456,23 @@ DEV void net_row_coefs(int n, const int* rp, const float* w, float* dv, float* s
 }
 
 // z[i, :] = relu( sc[i]*u[i, H:2H] + sum_k coef_k * u[col[k], 0:H] + bias )   (H multiple of 4)
-template <int KIND, int H>
+// A16: u / z rows are 16-byte aligned (LDS carve of the fused step) -> 128-bit LDS accesses
+#ifdef DRGNN_EMU
+#define NET_LD4(A16, p, v0, v1, v2, v3) do { v0 = (p)[0]; v1 = (p)[1]; v2 = (p)[2]; v3 = (p)[3]; } while (0)
+#define NET_ST4(A16, p, v0, v1, v2, v3) do { (p)[0] = v0; (p)[1] = v1; (p)[2] = v2; (p)[3] = v3; } while (0)
+#else
+#define NET_LD4(A16, p, v0, v1, v2, v3)                                                        \
+    do {                                                                                       \
+        if (A16) { const drgnn_f4 t_ = *(const drgnn_f4*)(p); v0 = t_[0]; v1 = t_[1]; v2 = t_[2]; v3 = t_[3]; } \
+        else { v0 = (p)[0]; v1 = (p)[1]; v2 = (p)[2]; v3 = (p)[3]; }                           \
+    } while (0)
+#define NET_ST4(A16, p, v0, v1, v2, v3)                                                        \
+    do {                                                                                       \
+        if (A16) { drgnn_f4 t_ = {v0, v1, v2, v3}; *(drgnn_f4*)(p) = t_; }                     \
+        else { (p)[0] = v0; (p)[1] = v1; (p)[2] = v2; (p)[3] = v3; }                           \
+    } while (0)
+#endif
+template <int KIND, int H, bool A16 = false>
 DEV void net_aggregate(int n, const int* rp, const int* col, const float* w, const float* dv,
                        const float* sc, const float* u, const float* bias, float* z) {
     constexpr int HC = (KIND == DRGNN_GINET) ? H : 2 * H;
@@ -467,25 +483,29 @@ DEV void net_aggregate(int n, const int* rp, const int* col, const float* w, con
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 4
         for (int k = lo; k < hi; ++k) {
-            const float* uj = u + (long)col[k] * HC + c;
-            float cf = 1.0f;
+            const float* uj = u + col[k] * HC + c;
+            float cf = 1.0f, v0, v1, v2, v3;
             if (KIND == DRGNN_SGAT) cf = w[k];
-            a0 = fmaf(cf, uj[0], a0); a1 = fmaf(cf, uj[1], a1);
-            a2 = fmaf(cf, uj[2], a2); a3 = fmaf(cf, uj[3], a3);
+            NET_LD4(A16, uj, v0, v1, v2, v3);
+            a0 = fmaf(cf, v0, a0); a1 = fmaf(cf, v1, a1);
+            a2 = fmaf(cf, v2, a2); a3 = fmaf(cf, v3, a3);
         }
         if (KIND != DRGNN_GINET) {
             const float d = dv[i], s = sc[i];
-            const float* us = u + (long)i * HC + H + c;
-            a0 = fmaf(s, us[0], a0 * d) + bias[c + 0];
-            a1 = fmaf(s, us[1], a1 * d) + bias[c + 1];
-            a2 = fmaf(s, us[2], a2 * d) + bias[c + 2];
-            a3 = fmaf(s, us[3], a3 * d) + bias[c + 3];
+            const float* us = u + i * HC + H + c;
+            float s0, s1, s2, s3;
+            NET_LD4(A16, us, s0, s1, s2, s3);
+            a0 = fmaf(s, s0, a0 * d) + bias[c + 0];
+            a1 = fmaf(s, s1, a1 * d) + bias[c + 1];
+            a2 = fmaf(s, s2, a2 * d) + bias[c + 2];
+            a3 = fmaf(s, s3, a3 * d) + bias[c + 3];
             if (KIND == DRGNN_FOUT && hi == lo) { a0 = a1 = a2 = a3 = DRGNN_NAN; }
         }
-        float* zi = z + (long)i * H + c;
+        float* zi = z + i * H + c;
         // relu that lets NaN through, like torch (max(x,0) would swallow it)
-        zi[0] = (a0 < 0.f) ? 0.f : a0; zi[1] = (a1 < 0.f) ? 0.f : a1;
-        zi[2] = (a2 < 0.f) ? 0.f : a2; zi[3] = (a3 < 0.f) ? 0.f : a3;
+        a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
+        a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
+        NET_ST4(A16, zi, a0, a1, a2, a3);
     }
 }
 
@@ -634,7 +654,7 @@ HD int64_t net_partial_floats(int n_feat) {
 
 // dU[j, 0:H]   = sum over CSC entries t of column j : coef * dZ[row(t), :]
 // dU[i, H:2H]  = sc[i] * dZ[i, :]
-template <int KIND, int H>
+template <int KIND, int H, bool A16 = false>
 DEV void net_aggregate_bwd(int n, const int* deg_rp, const int* cp, const int* ridx, const int* tslot,
                            const float* w, const float* dv, const float* sc, const float* dz,
                            float* du) {
@@ -649,18 +669,22 @@ DEV void net_aggregate_bwd(int n, const int* deg_rp, const int* cp, const int* r
             float cf = 1.0f;
             if (KIND == DRGNN_SGAT) cf = w[tslot[t]] * dv[i];
             if (KIND == DRGNN_FOUT) cf = dv[i];
-            const float* di = dz + (long)i * H + c;
-            a0 = fmaf(cf, di[0], a0); a1 = fmaf(cf, di[1], a1);
-            a2 = fmaf(cf, di[2], a2); a3 = fmaf(cf, di[3], a3);
+            const float* di = dz + i * H + c;
+            float v0, v1, v2, v3;
+            NET_LD4(A16, di, v0, v1, v2, v3);
+            a0 = fmaf(cf, v0, a0); a1 = fmaf(cf, v1, a1);
+            a2 = fmaf(cf, v2, a2); a3 = fmaf(cf, v3, a3);
         }
-        float* uj = du + (long)j * HC + c;
-        uj[0] = a0; uj[1] = a1; uj[2] = a2; uj[3] = a3;
+        float* uj = du + j * HC + c;
+        NET_ST4(A16, uj, a0, a1, a2, a3);
         if (KIND != DRGNN_GINET) {
             float s = sc[j];
             if (KIND == DRGNN_FOUT && deg_rp[j + 1] == deg_rp[j]) s = 0.0f;   // NaN row never wins a max
-            const float* dj = dz + (long)j * H + c;
-            uj[H + 0] = s * dj[0]; uj[H + 1] = s * dj[1];
-            uj[H + 2] = s * dj[2]; uj[H + 3] = s * dj[3];
+            const float* dj = dz + j * H + c;
+            float d0, d1, d2, d3;
+            NET_LD4(A16, dj, d0, d1, d2, d3);
+            d0 *= s; d1 *= s; d2 *= s; d3 *= s;
+            NET_ST4(A16, uj + H, d0, d1, d2, d3);
         }
     }
 }
@@ -694,8 +718,8 @@ DEV void net_backward_graph(const NetArgs& a, int g, int br, float* scratch, int
     const drgnn_conv_params& c2 = a.net.conv2[br];
     const float* xg = a.x + (long)d.n0 * F;
     const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C);
-    const bool head_staged = burst && a.hf.enabled && a.hf.stage && a.hf.H * a.hf.R <= 8 * DRGNN_NTHREADS &&
-                             a.hf.O * a.hf.H <= 2 * DRGNN_NTHREADS && a.hf.H <= DRGNN_NTHREADS;
+    const bool head_staged = burst && a.hf.enabled && a.hf.stage && a.hf.H * a.hf.R <= 8 * DRGNN_BCAP &&
+                             a.hf.O * a.hf.H <= 2 * DRGNN_BCAP && a.hf.H <= DRGNN_BCAP;
     if (burst) {
         BurstX<4> bx;       burst_load_x(bx, xg, d.N, F);
         BurstW<1> bw1, bw2, bs1, bs2;

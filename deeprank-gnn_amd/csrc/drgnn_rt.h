@@ -25,6 +25,7 @@
 #define FOR_TID(i, n) for (int i = 0; i < (int)(n); ++i)
 #define BARRIER() ((void)0)
 #define PHASE_MARK() ((void)0)
+#define PHASE_BEGIN() ((void)0)
 #define DRGNN_NTHREADS 1024
 struct WG { int block; int nthreads; };
 #define WG_TID0(wg) (true)
@@ -43,23 +44,35 @@ typedef void* drgnn_stream_t;
 #include <limits.h>
 #define DEV __device__ __forceinline__
 #define HD __host__ __device__ static inline
+#ifndef DRGNN_NTHREADS
 #define DRGNN_NTHREADS 1024
+#endif
 #define FOR_TID(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += DRGNN_NTHREADS)
 #ifdef DRGNN_PHASE_TIMING
 // profiling build only (libdrgnn_prof.so, tools/phase_timing.py): thread 0 of workgroup 0
 // stamps (source line, shader clock) after every barrier into a global buffer.
 __device__ unsigned long long* g_phase_buf = nullptr;
+// the mark counter lives in LDS (set by PHASE_BEGIN at kernel entry) so that a mark costs one
+// scalar pointer load + s_memtime + a fire-and-forget store, not two global round trips
+__shared__ unsigned int drgnn_phase_k;
 __device__ __forceinline__ void phase_mark(int line) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && g_phase_buf != nullptr) {
-        const unsigned long long k = g_phase_buf[0];
-        if (k < 2000) { g_phase_buf[2 + 2 * k] = (unsigned long long)line; g_phase_buf[3 + 2 * k] = clock64(); g_phase_buf[0] = k + 1; }
+        const unsigned int k = drgnn_phase_k;
+        if (k < 2000) {
+            g_phase_buf[2 + 2 * k] = (unsigned long long)line;
+            g_phase_buf[3 + 2 * k] = clock64();
+            g_phase_buf[0] = k + 1;
+            drgnn_phase_k = k + 1;
+        }
     }
 }
+#define PHASE_BEGIN() do { if (threadIdx.x == 0) drgnn_phase_k = 0; } while (0)
 #define BARRIER() do { __syncthreads(); phase_mark(__LINE__); } while (0)
 #define PHASE_MARK() phase_mark(__LINE__)
 #else
 #define BARRIER() __syncthreads()
 #define PHASE_MARK() ((void)0)
+#define PHASE_BEGIN() ((void)0)
 #endif
 struct WG { int block; int nthreads; };
 #define ATOMIC_ADD(p, v) atomicAdd((p), (v))
@@ -70,6 +83,8 @@ typedef hipStream_t drgnn_stream_t;
 #endif
 
 #define DRGNN_WAVE 64
+#define DRGNN_BSCALE (1024 / DRGNN_NTHREADS)   // burst capacities are quoted per 1024 lanes
+#define DRGNN_BCAP 1024
 #define DRGNN_NWAVES (DRGNN_NTHREADS / DRGNN_WAVE)
 
 // Division by a run-time constant without the ~40-instruction integer divide: one real
@@ -188,29 +203,29 @@ template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
     for (int i = 0; i < b.rows; ++i) for (int f = 0; f < b.F; ++f) dst[i * (b.F + 1) + f] = b.src[i * b.F + f];
 }
 #else
-template <class T, int J> struct Burst { T v[J]; int n; };
+template <class T, int J> struct Burst { T v[J * DRGNN_BSCALE]; int n; };
 template <class T, int J> DEV void burst_load(Burst<T, J>& b, const T* src, int n) {
     b.n = src ? n : 0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
         const int i = threadIdx.x + j * DRGNN_NTHREADS;
         b.v[j] = (i < b.n) ? src[i] : T(0);
     }
 }
 template <class T, int J> DEV void burst_store(const Burst<T, J>& b, T* dst) {
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
         const int i = threadIdx.x + j * DRGNN_NTHREADS;
         if (i < b.n) dst[i] = b.v[j];
     }
 }
 // strided [K,H] weight matrix -> dense padded rows dst[k*ld + h]
-template <int J> struct BurstW { float v[J]; int n, H; };
+template <int J> struct BurstW { float v[J * DRGNN_BSCALE]; int n, H; };
 template <int J> DEV void burst_load_w(BurstW<J>& b, const float* src, long sk, long sh, int K, int H) {
     b.n = src ? K * H : 0; b.H = H;
     const FastDiv fd = fastdiv_make(H);
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
         const int e = threadIdx.x + j * DRGNN_NTHREADS;
         const int k = fastdiv(fd, e), h = fastmod(fd, e, k);
         b.v[j] = (e < b.n) ? src[(long)k * sk + (long)h * sh] : 0.0f;
@@ -219,7 +234,7 @@ template <int J> DEV void burst_load_w(BurstW<J>& b, const float* src, long sk, 
 template <int J> DEV void burst_store_w(const BurstW<J>& b, float* dst, int ld) {
     const FastDiv fd = fastdiv_make(b.H);
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
         const int e = threadIdx.x + j * DRGNN_NTHREADS;
         const int k = fastdiv(fd, e), h = fastmod(fd, e, k);
         if (e < b.n) dst[k * ld + h] = b.v[j];
@@ -227,12 +242,12 @@ template <int J> DEV void burst_store_w(const BurstW<J>& b, float* dst, int ld) 
 }
 // x tile [rows, F] (F % 4 == 0, 16-byte aligned) -> padded rows dst[i*(F+1) + f], float4 loads
 typedef float drgnn_f4 __attribute__((ext_vector_type(4)));
-template <int J> struct BurstX { drgnn_f4 v[J]; int n4, F; };
+template <int J> struct BurstX { drgnn_f4 v[J * DRGNN_BSCALE]; int n4, F; };
 template <int J> DEV void burst_load_x(BurstX<J>& b, const float* src, int rows, int F) {
     b.n4 = rows * F / 4; b.F = F;
     const drgnn_f4* s4 = (const drgnn_f4*)src;
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
         const int q = threadIdx.x + j * DRGNN_NTHREADS;
         b.v[j] = (q < b.n4) ? s4[q] : drgnn_f4{0.f, 0.f, 0.f, 0.f};
     }
@@ -240,7 +255,7 @@ template <int J> DEV void burst_load_x(BurstX<J>& b, const float* src, int rows,
 template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
     const FastDiv fd = fastdiv_make(b.F);
 #pragma unroll
-    for (int j = 0; j < J; ++j) {
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
         const int q = threadIdx.x + j * DRGNN_NTHREADS;
         if (q < b.n4) {
             const int e = q * 4;
@@ -249,5 +264,57 @@ template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
             d[0] = b.v[j][0]; d[1] = b.v[j][1]; d[2] = b.v[j][2]; d[3] = b.v[j][3];
         }
     }
+}
+#endif
+
+// x tile with rows padded to ld = F + 4 floats (16-byte aligned rows: one 128-bit LDS store per
+// float4; 36-float rows keep the 16 row lanes of an MFMA A-operand read on distinct banks)
+#ifdef DRGNN_EMU
+template <int J> DEV void burst_store_x4(const BurstX<J>& b, float* dst) {
+    for (int i = 0; i < b.rows; ++i) for (int f = 0; f < b.F; ++f) dst[i * (b.F + 4) + f] = b.src[i * b.F + f];
+}
+#else
+template <int J> DEV void burst_store_x4(const BurstX<J>& b, float* dst) {
+    const FastDiv fd = fastdiv_make(b.F >> 2);
+#pragma unroll
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        const int q = threadIdx.x + j * DRGNN_NTHREADS;
+        if (q < b.n4) {
+            const int row = fastdiv(fd, q);
+            *(drgnn_f4*)(dst + row * (b.F + 4) + 4 * fastmod(fd, q, row)) = b.v[j];
+        }
+    }
+}
+
+// ---- cross-lane sums on the DPP path (no LDS round trip): fixed combination order ---------------
+template <int CTRL> DEV float dpp_take(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// sum over aligned groups of 8 / 16 lanes, every lane of the group gets the result
+DEV float lanes8_sum(float v) {
+    v += dpp_take<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E>(v);     // quad_perm [2,3,0,1]
+    v += dpp_take<0x141>(v);    // row_half_mirror
+    return v;
+}
+DEV float lanes16_sum(float v) {
+    v = lanes8_sum(v);
+    v += dpp_take<0x140>(v);    // row_mirror
+    return v;
+}
+DEV float lane_get(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+DEV float lanes32_sum(float v) {
+    v = lanes16_sum(v);
+    const float lo = lane_get(v, 0) + lane_get(v, 16), hi = lane_get(v, 32) + lane_get(v, 48);
+    return (threadIdx.x & 32) ? hi : lo;
+}
+DEV float lanes64_sum(float v) {
+    v = lanes16_sum(v);
+    return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
+}
+DEV float lanes64_max(float v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { const float o = __shfl_xor(v, m, 64); v = o > v ? o : v; }
+    return v;
 }
 #endif

@@ -1,0 +1,641 @@
+// Fused training step of one (graph, branch) workgroup: body forward, FC head + loss, body
+// backward in ONE launch, every intermediate kept in LDS.
+//
+// Same math as net_forward_graph + head + net_backward_graph (drgnn_net.h; reference
+// ginet.py:103-139, sGAT.py:119-137, foutnet.py:108-124 and their autograd), but
+//   * the graph is staged once (CSR and CSC of both levels, member lists, x tile, weights),
+//   * pooled features / argmax indices never leave LDS (no xp / arg0 / arg1 round trip),
+//   * the per-graph head needs the readout of BOTH branches of a GINet: the two branch
+//     workgroups of a graph exchange their 32 readout columns through tagged 64-bit words in
+//     global memory (one relaxed agent-scope atomic per value; tag = index of this step, so a
+//     word is valid exactly when its tag matches -- no fence, no flag),
+//   * dW_fc1 = dhid^T readout is left to the update kernel (it only needs dhid [B,H] and the
+//     readout [B,R]), so the head writes a compact slab  [dhid H][dW2 O*H][db2 O][loss][weight].
+// Phases are separated by BARRIER(); the host emulation (tests) runs the two halves of the
+// kernel as two passes over all workgroups (`part` 1 then 2) because it executes workgroups one
+// after the other and cannot wait for a partner.
+#ifndef DRGNN_STEP_H
+#define DRGNN_STEP_H
+
+#include "drgnn_net.h"
+
+struct StepArgs {
+    drgnn_net_desc net;
+    const float* x;              // [Ntot, F]
+    TopoView tv;
+    int64_t n_nodes;
+    int n_graphs;
+    float* partials;             // [B*n_branch][P] conv weight-gradient slabs (net_partial_floats)
+    int n_partial;
+    HeadFused hf;                // hf.readout: [B][R] OUTPUT; hf.partials: [B][head_compact_floats]
+    unsigned long long* xchg;    // [B][R] tagged readout words (zero-initialised once by the owner)
+    int32_t* step2;              // [0] steps completed so far (read)   [1] index of this step (written)
+};
+
+HD int64_t head_compact_floats(int R, int H, int O) { (void)R; return (int64_t)H + (int64_t)O * H + O + 2; }
+
+// ---- scratch ---------------------------------------------------------------------------------
+struct StepScratch {
+    float* xs; float* wn1; float* ws1; float* b1; float* wn2; float* ws2; float* b2;
+    int* rp0; int* cx0; float* ew0; int* cp0; int* rx0; int* ts0; int* mp0; int* mem0;
+    int* rp1; int* cx1; float* ew1; int* cp1; int* rx1; int* ts1; int* mp1; int* mem1;
+    int* a0; int* a1;
+    float* u1; float* z1; float* dv0; float* sc0;
+    float* xp; float* dxp; float* u2; float* z2; float* p2; float* dv1; float* sc1;
+    float* gp; float* misc;
+    float* xr; float* hid; float* dhid;
+    float* hb1; float* hw2; float* hb2;
+    float* end;
+};
+
+#define STEP_CARVE_LIST(X)                                                                     \
+    X(xs, (long)capN * (F + 4), 1)                                                             \
+    X(wn1, F * DRGNN_W1LD, 1)                                                                  \
+    X(ws1, F * DRGNN_W1LD, !gin)                                                               \
+    X(b1, DRGNN_H1, !gin)                                                                      \
+    X(wn2, DRGNN_H1 * DRGNN_W2LD, 1)                                                           \
+    X(ws2, DRGNN_H1 * DRGNN_W2LD, !gin)                                                        \
+    X(b2, DRGNN_H2, !gin)                                                                      \
+    X(rp0, capN + 1, 1)                                                                        \
+    X(cx0, capE, 1)                                                                            \
+    X(ew0, capE, sg)                                                                           \
+    X(cp0, capN + 1, 1)                                                                        \
+    X(rx0, capE, 1)                                                                            \
+    X(ts0, capE, sg)                                                                           \
+    X(mp0, capC + 1, 1)                                                                        \
+    X(mem0, capN, 1)                                                                           \
+    X(rp1, capC + 1, 1)                                                                        \
+    X(cx1, capE, 1)                                                                            \
+    X(ew1, capE, sg)                                                                           \
+    X(cp1, capC + 1, 1)                                                                        \
+    X(rx1, capE, 1)                                                                            \
+    X(ts1, capE, sg)                                                                           \
+    X(mp1, capC + 1, 1)                                                                        \
+    X(mem1, capC, 1)                                                                           \
+    X(a0, (long)capC * DRGNN_H1, 1)                                                            \
+    X(a1, (long)capC * DRGNN_H2, 1)                                                            \
+    X(u1, (long)capN * hc1, 1)                                                                 \
+    X(z1, (long)capN * DRGNN_H1, 1)                                                            \
+    X(dv0, capN, !gin)                                                                         \
+    X(sc0, capN, !gin)                                                                         \
+    X(xp, (long)capC * DRGNN_H1, 1)                                                            \
+    X(dxp, (long)capC * DRGNN_H1, 1)                                                           \
+    X(u2, (long)capC * hc2, 1)                                                                 \
+    X(z2, (long)capC * DRGNN_H2, 1)                                                            \
+    X(p2, (long)capC * DRGNN_H2, 1)                                                            \
+    X(dv1, capC, !gin)                                                                         \
+    X(sc1, capC, !gin)                                                                         \
+    X(gp, 2048, 1)                                                                             \
+    X(misc, 64, 1)                                                                             \
+    X(xr, R, 1)                                                                                \
+    X(hid, H, 1)                                                                               \
+    X(dhid, H, 1)                                                                              \
+    X(hb1, H, 1)                                                                               \
+    X(hw2, (long)O * H, 1)                                                                     \
+    X(hb2, O, 1)
+
+HD int64_t step_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t R,
+                              int64_t H, int64_t O) {
+    const int64_t hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
+    const int64_t hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
+    const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
+    const int gin = (kind == DRGNN_GINET) ? 1 : 0;
+    int64_t w = 0;
+#define X(name, words, cond) w += (cond) ? (((int64_t)(words) + 3) & ~(int64_t)3) : 0;   /* 16-byte aligned arrays */
+    STEP_CARVE_LIST(X)
+#undef X
+    return w + 16;
+}
+
+DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int capC, int R, int H, int O) {
+    const int hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
+    const int hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
+    const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
+    const int gin = (kind == DRGNN_GINET) ? 1 : 0;
+    StepScratch s;
+    float* p = base;
+#define X(name, words, cond) s.name = (decltype(s.name))p; p += (cond) ? (((long)(words) + 3) & ~3L) : 0;
+    STEP_CARVE_LIST(X)
+#undef X
+    s.end = p;
+    return s;
+}
+
+// ---- readout exchange between the branch workgroups of a graph -----------------------------------
+#ifdef DRGNN_EMU
+DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v) {
+    uint32_t bits; memcpy(&bits, &v, 4);
+    *slot = ((unsigned long long)tag << 32) | bits;
+}
+#else
+DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v) {
+    const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+    __hip_atomic_store(slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Spins until the partner has published its value of THIS step.  Both branch workgroups of a graph
+// are adjacent in the grid and the launch fits the device in one wave, so the partner is resident;
+// the wait is nevertheless bounded (~0.3 s of the 100 MHz wall clock): on expiry the value is NaN,
+// which surfaces as a NaN loss instead of a hung queue.
+DEV float xchg_wait(unsigned long long* slot, uint32_t tag) {
+    const unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(w >> 32) == tag) return __uint_as_float((uint32_t)w);
+        if (wall_clock64() - t0 > 30000000ull) return DRGNN_NAN;
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+#endif
+
+// ---- head pieces -----------------------------------------------------------------------------
+// fc1.weight [H][R] is read twice by a workgroup: row slices for hid = W1 xr (8 lanes per hidden
+// unit) and the column block of this branch for d readout = dhid W1 (32 lanes per column).  With
+// H <= 128 each of the 1024 lanes needs 8 + 4 values: they are fetched into registers in the
+// staging burst and never touch LDS.
+struct HeadRegs { float wf[8]; float wd[4]; int on; };
+
+DEV void step_head_prefetch(HeadRegs& hr, const HeadFused& hf, int br) {
+#ifdef DRGNN_EMU
+    hr.on = 0; (void)hf; (void)br;
+#else
+    const int R = hf.R, H = hf.H;
+    hr.on = (DRGNN_NTHREADS == 1024) && H <= 128 && R <= 64;
+    if (!hr.on) return;
+    const int t = threadIdx.x;
+    const int per = (R + 7) >> 3;
+    {
+        const int h = t >> 3, q = t & 7;
+        const float* wr = hf.w1 + (long)(h < H ? h : 0) * R;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = q * per + j;
+            hr.wf[j] = (h < H && j < per && r < R) ? wr[r] : 0.0f;
+        }
+    }
+    {
+        const int c = t >> 5, q = t & 31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int h = q + 32 * j;
+            hr.wd[j] = (h < H) ? hf.w1[(long)h * R + br * DRGNN_H2 + c] : 0.0f;
+        }
+    }
+#endif
+}
+
+// hid = dropout(relu(W1 xr + b1)):  8 lanes per hidden unit, DPP sum inside the lane group
+DEV void step_head_fc1(const HeadFused& hf, const HeadRegs& hr, int g, const float* b1, const float* xr,
+                       float* hid, uint32_t step, uint32_t thresh, float keep_scale) {
+    const int R = hf.R, H = hf.H;
+#ifdef DRGNN_EMU
+    (void)hr;
+    for (int h = 0; h < H; ++h) {
+        float v = b1[h];
+        for (int r = 0; r < R; ++r) v = fmaf(hf.w1[h * R + r], xr[r], v);
+        v = v > 0.0f ? v : 0.0f;
+        if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
+        hid[h] = v;
+    }
+#else
+    const int per = (R + 7) >> 3;
+    const int items = (H * 8 + 63) & ~63;         // whole waves: the lane-group sums need every lane
+    for (int t = threadIdx.x; t < items; t += DRGNN_NTHREADS) {
+        const int h = t >> 3, q = t & 7;
+        float acc = 0.0f;
+        if (hr.on) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = q * per + j;
+                acc = fmaf(hr.wf[j], xr[r < R ? r : 0], acc);      // wf is 0 past the slice
+            }
+        } else if (h < H) {
+            const int lo = q * per, hi = imin(R, lo + per);
+            const float* wr = hf.w1 + (long)h * R;
+            for (int r = lo; r < hi; ++r) acc = fmaf(wr[r], xr[r], acc);
+        }
+        acc = lanes8_sum(acc);
+        if (q == 0 && h < H) {
+            float v = acc + b1[h];
+            v = v > 0.0f ? v : 0.0f;
+            if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
+            hid[h] = v;
+        }
+    }
+#endif
+}
+
+// per-graph scalars of the loss, fetched during staging:  misc = [bad (int)][y or class id][wy][denom]
+#define STEP_M_BAD 0
+#define STEP_M_Y 1
+#define STEP_M_WY 2
+#define STEP_M_DENOM 3
+
+// outs = W2 hid + b2, loss, d loss / d outs, then dhid = relu'/dropout' (W2^T douts).  Device: every
+// wave evaluates outs redundantly (lane o keeps outs[o] / douts[o]) so that no barrier separates
+// them from their consumers.  Branch 0 writes predictions and the head slab.
+DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
+                        const float* misc, float keep_scale, float* dhid, float* p_dhid, float* p_hw2,
+                        float* p_hb2, float* p_loss) {
+    const int H = hf.H, O = hf.O;
+    const float denom = misc[STEP_M_DENOM], wy = misc[STEP_M_WY];
+#ifdef DRGNN_EMU
+    float outs[DRGNN_MAX_OUT], douts[DRGNN_MAX_OUT];
+    for (int o = 0; o < O; ++o) {
+        float acc = 0.0f;
+        for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
+        outs[o] = acc + b2[o];
+    }
+    float loss = 0.0f, wsum = 1.0f;
+    if (hf.task == DRGNN_TASK_REG) {
+        const float inv = 1.0f / (float)(hf.B * O);
+        for (int o = 0; o < O; ++o) {
+            const float d = outs[o] - misc[STEP_M_Y];
+            loss += d * d * inv;
+            douts[o] = 2.0f * d * inv;
+        }
+    } else {
+        int yc; memcpy(&yc, &misc[STEP_M_Y], 4);
+        float mx = outs[0];
+        for (int o = 1; o < O; ++o) mx = outs[o] > mx ? outs[o] : mx;
+        float se = 0.0f;
+        for (int o = 0; o < O; ++o) se += expf(outs[o] - mx);
+        const float lse = logf(se) + mx;
+        loss = wy * (lse - outs[yc]) / denom;
+        for (int o = 0; o < O; ++o) douts[o] = wy * (expf(outs[o] - lse) - (o == yc ? 1.0f : 0.0f)) / denom;
+        wsum = wy;
+    }
+    if (br == 0) {
+        for (int o = 0; o < O; ++o) { hf.pred[(long)g * O + o] = outs[o]; p_hb2[o] = douts[o]; }
+        p_loss[0] = loss; p_loss[1] = wsum;
+    }
+    for (int h = 0; h < H; ++h) {
+        float acc = 0.0f;
+        const float hv = hid[h];
+        for (int o = 0; o < O; ++o) {
+            acc = fmaf(douts[o], w2[o * H + h], acc);
+            if (br == 0) p_hw2[(long)o * H + h] = douts[o] * hv;
+        }
+        const float dh = (hv != 0.0f) ? acc * keep_scale : 0.0f;
+        dhid[h] = dh;
+        if (br == 0) p_dhid[h] = dh;
+    }
+#else
+    const int lane = threadIdx.x & 63;
+    float my_out = 0.0f;
+    for (int o = 0; o < O; ++o) {
+        float acc = 0.0f;
+        for (int h = lane; h < H; h += 64) acc = fmaf(hid[h], w2[o * H + h], acc);
+        acc = lanes64_sum(acc) + b2[o];
+        if (lane == o) my_out = acc;
+    }
+    float my_dout = 0.0f, loss, wsum = 1.0f;
+    if (hf.task == DRGNN_TASK_REG) {
+        const float inv = 1.0f / (float)(hf.B * O);
+        const float d = my_out - misc[STEP_M_Y];
+        loss = lanes64_sum(lane < O ? d * d * inv : 0.0f);
+        my_dout = lane < O ? 2.0f * d * inv : 0.0f;
+    } else {
+        const int yc = __builtin_amdgcn_readfirstlane(__float_as_int(misc[STEP_M_Y]));
+        const float mx = lanes64_max(lane < O ? my_out : DRGNN_NEG_INF);
+        const float se = lanes64_sum(lane < O ? expf(my_out - mx) : 0.0f);
+        const float lse = logf(se) + mx;
+        loss = wy * (lse - lane_get(my_out, yc)) / denom;
+        my_dout = lane < O ? wy * (expf(my_out - lse) - (lane == yc ? 1.0f : 0.0f)) / denom : 0.0f;
+        wsum = wy;
+    }
+    if (br == 0 && (int)threadIdx.x < O) {
+        hf.pred[(long)g * O + threadIdx.x] = my_out;
+        p_hb2[threadIdx.x] = my_dout;
+    }
+    if (br == 0 && threadIdx.x == 0) { p_loss[0] = loss; p_loss[1] = wsum; }
+    for (int h0 = 0; h0 < H; h0 += DRGNN_NTHREADS) {      // uniform trip count: lane_get below is wave-wide
+        const int h = h0 + (int)threadIdx.x;
+        const bool ok = h < H;
+        const float hv = ok ? hid[h] : 0.0f;
+        float acc = 0.0f;
+        for (int o = 0; o < O; ++o) {
+            const float dout = lane_get(my_dout, o);
+            if (ok) {
+                acc = fmaf(dout, w2[o * H + h], acc);
+                if (br == 0) p_hw2[(long)o * H + h] = dout * hv;
+            }
+        }
+        if (ok) {
+            const float dh = (hv != 0.0f) ? acc * keep_scale : 0.0f;     // relu' and dropout mask
+            dhid[h] = dh;
+            if (br == 0) p_dhid[h] = dh;
+        }
+    }
+#endif
+}
+
+// d readout (this branch's 32 columns) = dhid W1[:, br*32 : br*32+32], scattered straight into
+// dZ2 through the depth-1 argmax (mean over the C1 clusters -> factor inv)
+DEV void step_head_dreadout(const HeadFused& hf, const HeadRegs& hr, int br, const float* dhid, const int* a1,
+                            int C1, float* z2) {
+    const int H = hf.H, R = hf.R;
+    const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
+#ifdef DRGNN_EMU
+    (void)hr;
+    for (int c = 0; c < DRGNN_H2; ++c) {
+        float acc = 0.0f;
+        for (int h = 0; h < H; ++h) acc = fmaf(dhid[h], hf.w1[h * R + br * DRGNN_H2 + c], acc);
+        for (int k = 0; k < C1; ++k) {
+            const int r = a1[k * DRGNN_H2 + c];
+            if (r >= 0) z2[r * DRGNN_H2 + c] = acc * inv;
+        }
+    }
+#else
+    for (int t = threadIdx.x; t < DRGNN_H2 * 32; t += DRGNN_NTHREADS) {
+        const int c = t >> 5, q = t & 31;
+        float acc = 0.0f;
+        if (hr.on) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int h = q + 32 * j;
+                acc = fmaf(hr.wd[j], dhid[h < H ? h : 0], acc);       // wd is 0 past H
+            }
+        } else {
+            for (int h = q; h < H; h += 32) acc = fmaf(dhid[h], hf.w1[(long)h * R + br * DRGNN_H2 + c], acc);
+        }
+        const float v = lanes32_sum(acc) * inv;
+        for (int k = q; k < C1; k += 32) {
+            const int r = a1[k * DRGNN_H2 + c];
+            if (r >= 0) z2[r * DRGNN_H2 + c] = v;
+        }
+    }
+#endif
+}
+
+DEV void step_copy_i32(int* dst, const int32_t* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
+DEV void step_copy_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
+
+// `part`: 0 = whole step (device), 1 = up to the readout publication, 2 = from the head on
+template <int KIND>
+DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int capN, int capE, int capC,
+                        int part) {
+    constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
+    constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
+    const TopoView& tv = a.tv;
+    const HeadFused& hf = a.hf;
+    const GraphDims d = net_dims(tv, g);
+    const int F = a.net.n_feat;
+    const int nb = a.net.n_branch;
+    const int R = hf.R, H = hf.H, O = hf.O;
+    const int XLD = F + 4;
+    StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
+    HeadRegs hr;
+    step_head_prefetch(hr, hf, br);
+    const uint32_t done = (uint32_t)a.step2[0];
+    const uint32_t tag = done + 1u;
+    const drgnn_conv_params& c1 = a.net.conv1[br];
+    const drgnn_conv_params& c2 = a.net.conv2[br];
+    const float* b1 = s.hb1;
+    const float* w2 = s.hw2;
+    const float* b2 = s.hb2;
+
+    if (part != 2) {
+        if (g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }
+        // ---- one burst of independent loads: everything this graph needs -> LDS ------------
+        PHASE_MARK();
+        const float* xg = a.x + (long)d.n0 * F;
+        const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C) && O * H <= 2 * DRGNN_BCAP && H <= DRGNN_BCAP;
+        if (burst) {
+            BurstX<4> bx;       burst_load_x(bx, xg, d.N, F);
+            BurstW<1> bw1, bw2, bs1, bs2;
+            burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
+            burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+            Burst<int, 1> brp0, bcp0, bmp0, bmem0, brp1, bcp1, bmp1, bmem1;
+            Burst<int, 2> bcx0, brx0, bcx1, brx1, bts0, bts1;
+            Burst<float, 2> bew0, bew1;
+            Burst<float, 1> bb1, bb2, bhb1, bhb2;
+            Burst<float, 2> bhw2;
+            burst_load(brp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+            burst_load(bcx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
+            burst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+            burst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+            burst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
+            burst_load(bmem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
+            burst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+            burst_load(bcx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
+            burst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+            burst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            burst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
+            burst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+            burst_load(bhb1, hf.b1, H);
+            burst_load(bhw2, hf.w2, O * H);
+            burst_load(bhb2, hf.b2, O);
+            if (KIND != DRGNN_GINET) {
+                burst_load_w(bs1, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
+                burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+                burst_load(bb1, c1.bias, DRGNN_H1);
+                burst_load(bb2, c2.bias, DRGNN_H2);
+            }
+            if (KIND == DRGNN_SGAT) {
+                burst_load(bew0, (const float*)(tv.w0 + d.e0), d.E);
+                burst_load(bew1, (const float*)(tv.w1 + d.e0), d.E1);
+                burst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+                burst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+            }
+            burst_store_x4(bx, s.xs);
+            burst_store_w(bw1, s.wn1, DRGNN_W1LD);
+            burst_store_w(bw2, s.wn2, DRGNN_W2LD);
+            burst_store(brp0, s.rp0); burst_store(bcx0, s.cx0);
+            burst_store(bcp0, s.cp0); burst_store(brx0, s.rx0);
+            burst_store(bmp0, s.mp0); burst_store(bmem0, s.mem0);
+            burst_store(brp1, s.rp1); burst_store(bcx1, s.cx1);
+            burst_store(bcp1, s.cp1); burst_store(brx1, s.rx1);
+            burst_store(bmp1, s.mp1); burst_store(bmem1, s.mem1);
+            burst_store(bhb1, s.hb1); burst_store(bhw2, s.hw2); burst_store(bhb2, s.hb2);
+            if (KIND != DRGNN_GINET) {
+                burst_store_w(bs1, s.ws1, DRGNN_W1LD);
+                burst_store_w(bs2, s.ws2, DRGNN_W2LD);
+                burst_store(bb1, s.b1); burst_store(bb2, s.b2);
+            }
+            if (KIND == DRGNN_SGAT) {
+                burst_store(bew0, s.ew0); burst_store(bew1, s.ew1);
+                burst_store(bts0, s.ts0); burst_store(bts1, s.ts1);
+            }
+        } else {
+            FOR_TID(e, d.N * F) { s.xs[(e / F) * XLD + e % F] = xg[e]; }
+            stage_weight(s.wn1, DRGNN_W1LD, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
+            stage_weight(s.wn2, DRGNN_W2LD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+            step_copy_i32(s.rp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+            step_copy_i32(s.cx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
+            step_copy_i32(s.cp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+            step_copy_i32(s.rx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+            step_copy_i32(s.mp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
+            step_copy_i32(s.mem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
+            step_copy_i32(s.rp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+            step_copy_i32(s.cx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
+            step_copy_i32(s.cp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+            step_copy_i32(s.rx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            step_copy_i32(s.mp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
+            step_copy_i32(s.mem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+            step_copy_f32(s.hb1, hf.b1, H);
+            step_copy_f32(s.hw2, hf.w2, O * H);
+            step_copy_f32(s.hb2, hf.b2, O);
+            if (KIND != DRGNN_GINET) {
+                stage_weight(s.ws1, DRGNN_W1LD, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
+                stage_weight(s.ws2, DRGNN_W2LD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+                step_copy_f32(s.b1, c1.bias, DRGNN_H1);
+                step_copy_f32(s.b2, c2.bias, DRGNN_H2);
+            }
+            if (KIND == DRGNN_SGAT) {
+                step_copy_f32(s.ew0, tv.w0 + d.e0, d.E);
+                step_copy_f32(s.ew1, tv.w1 + d.e0, d.E1);
+                step_copy_i32(s.ts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+                step_copy_i32(s.ts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+            }
+        }
+        // per-graph scalars of the readout / loss phases (their global latency hides in the burst)
+        FOR_TID(i, 1) {
+            const int bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g] | tv.p[DRGNN_TI_GSTAT][a.n_graphs + g];
+            memcpy(&s.misc[STEP_M_BAD], &bad, 4);
+            if (hf.task == DRGNN_TASK_REG) {
+                s.misc[STEP_M_Y] = hf.y_reg[g];
+                s.misc[STEP_M_WY] = 1.0f;
+            } else {
+                const int yc = (int)hf.y_cls[g];
+                memcpy(&s.misc[STEP_M_Y], &yc, 4);
+                s.misc[STEP_M_WY] = hf.class_w ? hf.class_w[yc] : 1.0f;
+            }
+        }
+        if (hf.task == DRGNN_TASK_CLASS) {      // CrossEntropyLoss(weight): mean over sum of target weights
+#ifdef DRGNN_EMU
+            float denom = 0.0f;
+            for (int q = 0; q < hf.B; ++q) denom += hf.class_w ? hf.class_w[hf.y_cls[q]] : 1.0f;
+            s.misc[STEP_M_DENOM] = denom;
+#else
+            if (threadIdx.x < 64) {
+                float part_sum = 0.0f;
+                for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w ? hf.class_w[hf.y_cls[q]] : 1.0f;
+                part_sum = lanes64_sum(part_sum);
+                if (threadIdx.x == 0) s.misc[STEP_M_DENOM] = part_sum;
+            }
+#endif
+        } else {
+            FOR_TID(i, 1) { s.misc[STEP_M_DENOM] = 1.0f; }
+        }
+        BARRIER();
+
+        // ---- forward ------------------------------------------------------------------
+        wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.wn1, DRGNN_W1LD, 1, s.u1, HC1, 1);
+        if (KIND != DRGNN_GINET)
+            wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.ws1, DRGNN_W1LD, 1, s.u1 + DRGNN_H1, HC1, 1);
+        net_row_coefs<KIND>(d.N, s.rp0, s.ew0, s.dv0, s.sc0);
+        net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
+        BARRIER();
+        net_aggregate<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
+        BARRIER();
+        net_cluster_max<DRGNN_H1>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
+        BARRIER();
+        wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.wn2, DRGNN_W2LD, 1, s.u2, HC2, 1);
+        if (KIND != DRGNN_GINET)
+            wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.ws2, DRGNN_W2LD, 1, s.u2 + DRGNN_H2, HC2, 1);
+        FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }      // Z1 is consumed: becomes dZ1
+        BARRIER();
+        net_aggregate<KIND, DRGNN_H2, true>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+        BARRIER();
+        net_cluster_max<DRGNN_H2>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
+        BARRIER();
+        // graph readout: mean over the depth-1 clusters; publish this branch's 32 columns
+        FOR_TID(c, DRGNN_H2) {
+            int bad; memcpy(&bad, &s.misc[STEP_M_BAD], 4);
+            float acc = 0.0f;
+            for (int k = 0; k < d.C1; ++k) acc += s.p2[k * DRGNN_H2 + c];
+            acc = acc / (float)(d.C1 > 0 ? d.C1 : 1);
+            if (bad) acc = DRGNN_NAN;
+            const long slot = (long)g * R + br * DRGNN_H2 + c;
+            s.xr[br * DRGNN_H2 + c] = acc;
+            const_cast<float*>(hf.readout)[slot] = acc;
+            if (nb > 1) xchg_publish(a.xchg + slot, tag, acc);
+        }
+        FOR_TID(item, d.C * DRGNN_H2) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2
+    }
+    if (part == 1) return;
+    if (nb > 1) {
+        FOR_TID(t, DRGNN_H2 * (nb - 1)) {
+            const int ob = (br + 1 + t / DRGNN_H2) % nb, c = t % DRGNN_H2;
+            const long slot = (long)g * R + ob * DRGNN_H2 + c;
+#ifdef DRGNN_EMU
+            s.xr[ob * DRGNN_H2 + c] = hf.readout[slot];
+#else
+            s.xr[ob * DRGNN_H2 + c] = xchg_wait(a.xchg + slot, tag);
+#endif
+        }
+    }
+    BARRIER();
+
+    // ---- FC head + loss + their backward ---------------------------------------------------
+    const float keep_scale = (hf.p_drop > 0.0f) ? 1.0f / (1.0f - hf.p_drop) : 1.0f;
+    const double pt = (double)hf.p_drop * 4294967296.0;
+    const uint32_t thresh = (hf.p_drop > 0.0f) ? (uint32_t)(pt > 4294967295.0 ? 4294967295.0 : pt) : 0u;
+    float* hp = hf.partials + (long)g * head_compact_floats(R, H, O);
+    float* p_dhid = hp;
+    float* p_hw2 = p_dhid + H;
+    float* p_hb2 = p_hw2 + (long)O * H;
+    float* p_loss = p_hb2 + O;
+    step_head_fc1(hf, hr, g, b1, s.xr, s.hid, done, thresh, keep_scale);
+    BARRIER();
+    step_head_loss(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    BARRIER();
+    step_head_dreadout(hf, hr, br, s.dhid, s.a1, d.C1, s.z2);
+    BARRIER();
+
+    // ---- backward body ---------------------------------------------------------------------
+    float* part_w = a.partials + ((long)g * nb + br) * a.n_partial;
+    float* p_w1n = part_w;
+    float* p_w1s = p_w1n + (long)F * DRGNN_H1;
+    float* p_b1 = p_w1s + (long)F * DRGNN_H1;
+    float* p_w2n = p_b1 + DRGNN_H1;
+    float* p_w2s = p_w2n + DRGNN_H1 * DRGNN_H2;
+    float* p_b2 = p_w2s + DRGNN_H1 * DRGNN_H2;
+    net_aggregate_bwd<KIND, DRGNN_H2, true>(d.C, s.rp1, s.cp1, s.rx1, s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
+    if (KIND != DRGNN_GINET) {
+        FOR_TID(c, DRGNN_H2) {
+            float acc = 0.0f;
+            for (int r = 0; r < d.C; ++r) acc += s.z2[r * DRGNN_H2 + c];
+            p_b2[c] = acc;
+        }
+    }
+    BARRIER();
+    wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2, HC2, 1, p_w2n, DRGNN_H2, 1);
+    if (KIND != DRGNN_GINET)
+        wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2 + DRGNN_H2, HC2, 1, p_w2s, DRGNN_H2, 1);
+    wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, s.wn2, 1, DRGNN_W2LD, s.dxp, DRGNN_H1, 1);
+    if (KIND != DRGNN_GINET)
+        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2 + DRGNN_H2, HC2, 1, s.ws2, 1, DRGNN_W2LD, s.p2, DRGNN_H1, 1);
+    BARRIER();
+    FOR_TID(item, d.C * DRGNN_H1) {
+        const int m = s.a0[item];
+        const int c = item % DRGNN_H1;
+        if (m >= 0) {
+            float v = s.dxp[item];
+            if (KIND != DRGNN_GINET) v += s.p2[item];
+            s.z1[m * DRGNN_H1 + c] = v;
+        }
+    }
+    BARRIER();
+    net_aggregate_bwd<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cp0, s.rx0, s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
+    if (KIND != DRGNN_GINET) {
+        FOR_TID(c, DRGNN_H1) {
+            float acc = 0.0f;
+            for (int i = 0; i < d.N; ++i) acc += s.z1[i * DRGNN_H1 + c];
+            p_b1[c] = acc;
+        }
+    }
+    BARRIER();
+    {
+        const int mtiles = (F + 15) >> 4;
+        int KS = imin(DRGNN_NWAVES / mtiles, 2048 / (F * DRGNN_H1));
+        if (KS < 1) KS = 1;
+        wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, XLD, s.u1, HC1, 1, p_w1n, DRGNN_H1, 1, KS, s.gp);
+        if (KIND != DRGNN_GINET) {
+            BARRIER();
+            wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, XLD, s.u1 + DRGNN_H1, HC1, 1, p_w1s, DRGNN_H1, 1, KS, s.gp);
+        }
+    }
+}
+
+#endif

@@ -57,7 +57,12 @@ class FusedTrainer(object):
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
-        self.step = torch.zeros(1, dtype=torch.int32, device=dev)
+        # [0] optimiser steps completed, [1] index of the step in flight (fused step launch writes it,
+        # the update launch reads it for Adam and commits [0]); `step` is the public 1-element view
+        self.step2 = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.step = self.step2[:1]
+        self.fused_step = True       # one launch for fwd + head + bwd whenever a graph fits LDS
+        self._xchg = {}              # readout exchange words of the fused step, per batch size
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.offset = {}
         off = 0
@@ -117,13 +122,75 @@ class FusedTrainer(object):
                         topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream, step_inc=step_inc)
         return x, desc, xp, arg0, arg1, readout, scratch
 
+    def _can_fuse(self, topo, n_feat):
+        if not self.fused_step or topo.max_nodes <= 0:
+            return False
+        need = self.api.net_step_lds_bytes(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0,
+                                           self.R, self.H, self.O)
+        return 0 < need <= 160 * 1024
+
+    def _fused_prepare(self, batch, topo):
+        """Buffers and descriptors of one fused step (allocation only, no launch)."""
+        api = self.api
+        x = batch.x.contiguous()
+        n_nodes, n_feat = x.shape
+        dev = x.device
+        B, nb = topo.n_graphs, self.n_branch
+        y = batch.y
+        y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
+        xchg = None
+        if nb > 1:
+            xchg = self._xchg.get(B)
+            if xchg is None:
+                xchg = self._xchg[B] = torch.zeros((max(B, 1), H2 * nb), dtype=torch.int64, device=dev)
+        g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+        g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+        for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, nb)):
+            _fill_grads(g1[b], self.kind, l1, n_feat, H1)
+            _fill_grads(g2[b], self.kind, l2, H1, H2)
+        return dict(
+            x=x, y=y, topo=topo, B=B, n_nodes=n_nodes, xchg=xchg, g1=g1, g2=g2,
+            desc=_describe(self.kind, n_feat, self.live, nb), stream=_lib.current_stream(x),
+            pred=torch.empty((B, self.O), dtype=torch.float32, device=dev),
+            readout=torch.empty((B, H2 * nb), dtype=torch.float32, device=dev),
+            partials=torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)),
+                                 dtype=torch.float32, device=dev),
+            hp=torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)),
+                           dtype=torch.float32, device=dev))
+
+    def _fused_launch_step(self, c, next_topo=None):
+        """ONE launch: body fwd + head/loss + body bwd (+ the next mini-batch's topology)."""
+        t = c["topo"]
+        self.api.net_train_step(c["desc"], self._head_desc(True), c["x"], c["y"], self.step2, t.ws_i32, t.ws_f32,
+                                c["n_nodes"], t.n_edges, c["B"], t.max_nodes, t.max_edges, t.max_c0, c["pred"],
+                                c["readout"], c["hp"], c["partials"], c["xchg"], c["stream"],
+                                next_topology=None if next_topo is None else next_topo.request())
+
+    def _fused_launch_update(self, c, apply_adam=True, lr=None):
+        """Second launch: fixed-order reduction of the slabs (+ dW_fc1 = dhid^T readout) and Adam."""
+        self.api.step_update(c["desc"], c["partials"], c["B"], c["g1"], c["g2"], c["hp"], c["readout"], self.R,
+                             self.H, self.O, self.head_grad_offset, self.flat_p, self.flat_g, self.exp_avg,
+                             self.exp_avg_sq, self.step2, self.loss, self.lr if lr is None else lr,
+                             self.betas[0], self.betas[1], self.eps, c["stream"], apply_adam=apply_adam)
+
+    def _fused(self, batch, topo, apply_adam, next_topo):
+        c = self._fused_prepare(batch, topo)
+        self._fused_launch_step(c, next_topo)
+        self._fused_launch_update(c, apply_adam)
+        self.last_pred = c["pred"]
+        self.last_batch_size = c["B"]
+        return self.loss
+
     def _backward(self, batch, topo, apply_adam, next_topo=None):
-        """fwd (++step) -> bwd with the per-graph head + loss inside (and, when given, the NEXT
-        mini-batch's topology build sharing that launch) -> fixed-order reduction of the partials,
-        with Adam applied in the same launch when ``apply_adam``."""
+        """Fused step when every graph fits LDS (see _fused); else fwd (++step) -> bwd with the per-graph
+        head + loss inside (and, when given, the NEXT mini-batch's topology build sharing that launch)
+        -> fixed-order reduction of the partials, with Adam applied in the same launch when
+        ``apply_adam``."""
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
+        if self._can_fuse(topo, batch.x.shape[1]):
+            return self._fused(batch, topo, apply_adam, next_topo)
         stream = _lib.current_stream(batch.x)
         x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream, step_inc=self.step)
         B = topo.n_graphs
@@ -229,6 +296,8 @@ class FusedTrainer(object):
                 steps.add(int(float(st['step'])))
             if steps:
                 self.step.fill_(max(steps))
+            for buf in self._xchg.values():      # tags of an earlier run must not match again
+                buf.zero_()
 
     @torch.no_grad()
     def predict(self, batch, topo=None):

@@ -337,6 +337,43 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
                        float* exp_avg_sq, int64_t n_param, const int32_t* step, float* loss,
                        float lr, float beta1, float beta2, float eps, int32_t apply_adam, void* stream);
 
+/* ---- fused training step --------------------------------------------------------------------
+ * Body forward + FC head + loss + body backward of one mini-batch in ONE launch (every workgroup
+ * keeps its graph, activations and argmax indices in LDS between the forward and the backward
+ * half), optionally sharing the grid with the topology build of the NEXT mini-batch.  Replaces,
+ * together with drgnn_step_update, the whole loop body of NeuralNet._epoch (NeuralNet.py:489-506:
+ * zero_grad, model(batch), loss, backward, optimizer.step) for GINet / sGAT / FoutNet.
+ *   step2     device int32[2]: [0] = optimiser steps completed (selects the dropout stream, read
+ *             only); [1] = index of this step, written here.  drgnn_step_update commits [0] = [1].
+ *   readout   OUT [B, 32*n_branch]; pred OUT [B, O]
+ *   head_partials OUT [B][drgnn_head_compact_elems]: [dhid H][dW_fc2 O*H][db_fc2 O][loss][weight]
+ *             (dW_fc1 = dhid^T readout is formed by drgnn_step_update)
+ *   partials  OUT [B*n_branch][drgnn_net_partial_elems]
+ *   xchg      uint64 [B, 32*n_branch], zero-filled ONCE by the caller and then left alone: the two
+ *             branch workgroups of a GINet graph exchange their readout halves through it
+ *             (may be NULL when n_branch == 1)
+ * Needs max_nodes/max_edges/max_c0 bounds; returns DRGNN_E_CAPACITY when a graph of that size does
+ * not fit the 160 KiB LDS (drgnn_net_step_lds_bytes): use drgnn_net_forward +
+ * drgnn_net_backward_fused_head + drgnn_train_update then. */
+int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
+                                 int32_t max_c0, int32_t R, int32_t H, int32_t O);
+int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O);
+int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head, const float* x,
+                         const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
+                         int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
+                         int32_t max_edges, int32_t max_c0, float* pred, float* readout,
+                         float* head_partials, float* partials, uint64_t* xchg,
+                         const drgnn_topology_request* next_topology /* optional */, void* stream);
+/* drgnn_train_update for the slabs of drgnn_net_train_step: also forms dW_fc1 from head_partials'
+ * dhid rows and readout, applies Adam with step index step2[1] and commits step2[0] = step2[1]
+ * (also when apply_adam = 0: data parallel, all-reduce + drgnn_adam_step(step2) follow). */
+int drgnn_step_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+                      drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
+                      const float* readout, int32_t R, int32_t H, int32_t O, int64_t head_offset,
+                      float* flat_param, float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
+                      int32_t* step2, float* loss, float lr, float beta1, float beta2, float eps,
+                      int32_t apply_adam, void* stream);
+
 /* ---- offline clustering --------------------------------------------------------
  * Markov clustering of every graph of a batch: community_detection(edge_index, num_nodes,
  * method='mcl') (community_pooling.py:95-158; markov_clustering.run_mcl defaults), as PreCluster

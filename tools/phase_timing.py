@@ -53,3 +53,16 @@ for rep in range(2):
     torch.cuda.synchronize(); buf.zero_(); torch.cuda.synchronize()
     api.head_step(tr._head_desc(True), readout, batch.y.contiguous(), B, tr.step, pred, gr, hp, stream)
     if rep: dump("k_head")
+
+# ---- the pipelined step's launches: forward, backward with fused head (+ next topology) ---------
+for rep in range(2):
+    topo = Topology.from_batch(batch, api=api, need_weights=False)
+    nxt = Topology.from_batch(batch, api=api, need_weights=False, build=False)
+    stream = _lib.current_stream(batch.x)
+    torch.cuda.synchronize(); buf.zero_(); torch.cuda.synchronize()
+    tr._body_forward(batch, topo, stream)
+    if rep: dump("k_net fwd (trainer)")
+    torch.cuda.synchronize(); buf.zero_(); torch.cuda.synchronize()
+    tr.step.zero_()
+    tr.train_step(batch, topo=topo, next_topo=nxt)
+    if rep: dump("k_net_co_topo bwd + fused head (train_step)")
