@@ -11,7 +11,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdrgnn.so")
+# DRGNN_LIB: use another build of the same library (profiling / ablation builds under tools/)
+LIB_PATH = os.environ.get("DRGNN_LIB") or os.path.join(_HERE, "csrc", "libdrgnn.so")
 
 GINET, SGAT, FOUT = 0, 1, 2
 MAX_BRANCH = 2

@@ -285,10 +285,9 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
         // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
         if (part != 2) {
             const uint32_t tag = (uint32_t)L.a.step2[0] + 1u;
-            FOR_TID(c, DRGNN_H2) {
-                const long slot = (long)g * L.a.hf.R + br * DRGNN_H2 + c;
-                const_cast<float*>(L.a.hf.readout)[slot] = DRGNN_NAN;
-                if (nb > 1) xchg_publish(L.a.xchg + slot, tag, DRGNN_NAN);
+            FOR_TID(c, DRGNN_H2) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + br * DRGNN_H2 + c] = DRGNN_NAN; }
+            if (nb > 1) {
+                FOR_TID(h, L.a.hf.H) { xchg_publish(L.a.xchg + ((long)g * nb + br) * L.a.hf.H + h, tag, DRGNN_NAN); }
             }
         }
         if (part != 1 && br == 0) {

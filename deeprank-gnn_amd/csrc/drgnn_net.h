@@ -77,15 +77,27 @@ DEV void wg_gemm(int M, int N, int K, const float* A, int sai, int sak, const fl
                     for (int s = 0; s < 8; ++s) {
                         const int k = k0 + 4 * s + lq;
                         const bool k_ok = k < kend;
+#if defined(DRGNN_SKIP) && DRGNN_SKIP == 31
+                        a[s] = 1.0f; b[s] = 1.0f;
+#else
                         a[s] = (a_ok && k_ok) ? ap[(long)k * sak] : 0.0f;
                         b[s] = (b_ok && k_ok) ? bp[(long)k * sbk] : 0.0f;
+#endif
                     }
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
+#if defined(DRGNN_SKIP) && DRGNN_SKIP == 30
+                        acc[0] += a[s] * b[s];
+#else
                         if (k0 + 4 * s < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc, 0, 0, 0);
+#endif
                     }
                 }
+#if defined(DRGNN_SKIP) && DRGNN_SKIP == 32
+                if (b_ok && acc[0] == 12345.0f) {
+#else
                 if (b_ok) {
+#endif
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int ci = i0 + lq * 4 + r;

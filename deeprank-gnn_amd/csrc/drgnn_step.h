@@ -5,8 +5,10 @@
 // ginet.py:103-139, sGAT.py:119-137, foutnet.py:108-124 and their autograd), but
 //   * the graph is staged once (CSR and CSC of both levels, member lists, x tile, weights),
 //   * pooled features / argmax indices never leave LDS (no xp / arg0 / arg1 round trip),
-//   * the per-graph head needs the readout of BOTH branches of a GINet: the two branch
-//     workgroups of a graph exchange their 32 readout columns through tagged 64-bit words in
+//   * the per-graph head needs the readout of BOTH branches of a GINet.  fc1 is linear, so each
+//     branch workgroup multiplies ITS 32 readout columns with ITS column block of fc1.weight (the
+//     only part of that matrix it ever touches: 16 KB in LDS, also used by the head's backward) and
+//     the two workgroups of a graph exchange the H half-products through tagged 64-bit words in
 //     global memory (one relaxed agent-scope atomic per value; tag = index of this step, so a
 //     word is valid exactly when its tag matches -- no fence, no flag),
 //   * dW_fc1 = dhid^T readout is left to the update kernel (it only needs dhid [B,H] and the
@@ -19,6 +21,18 @@
 
 #include "drgnn_net.h"
 
+// ablation profiling (tools/ablate_step.sh): -DDRGNN_SKIP=k compiles the step kernel WITHOUT the work
+// of phase k (barriers stay); the drop in kernel time is what that phase costs.  Never set in the product.
+#ifndef DRGNN_SKIP
+#define DRGNN_SKIP (-1)
+#endif
+#define PH(k) if (DRGNN_SKIP != (k))
+// -DDRGNN_EXIT_AFTER=k: every workgroup returns after barrier k (cumulative timeline of the phases)
+#ifndef DRGNN_EXIT_AFTER
+#define DRGNN_EXIT_AFTER (-1)
+#endif
+#define EXIT_AFTER(k) do { if (DRGNN_EXIT_AFTER == (k)) return; } while (0)
+
 struct StepArgs {
     drgnn_net_desc net;
     const float* x;              // [Ntot, F]
@@ -28,11 +42,13 @@ struct StepArgs {
     float* partials;             // [B*n_branch][P] conv weight-gradient slabs (net_partial_floats)
     int n_partial;
     HeadFused hf;                // hf.readout: [B][R] OUTPUT; hf.partials: [B][head_compact_floats]
-    unsigned long long* xchg;    // [B][R] tagged readout words (zero-initialised once by the owner)
+    unsigned long long* xchg;    // [B][n_branch][H] tagged fc1 half-products (zero-initialised once by the owner)
     int32_t* step2;              // [0] steps completed so far (read)   [1] index of this step (written)
 };
 
 HD int64_t head_compact_floats(int R, int H, int O) { (void)R; return (int64_t)H + (int64_t)O * H + O + 2; }
+
+#define STEP_WBLD (DRGNN_H2 + 4)     // row stride of the fc1.weight column block in LDS (16-byte aligned rows)
 
 // ---- scratch ---------------------------------------------------------------------------------
 struct StepScratch {
@@ -44,7 +60,7 @@ struct StepScratch {
     float* xp; float* dxp; float* u2; float* z2; float* p2; float* dv1; float* sc1;
     float* gp; float* misc;
     float* xr; float* hid; float* dhid;
-    float* hb1; float* hw2; float* hb2;
+    float* wb; float* hb1; float* hw2; float* hb2;
     float* end;
 };
 
@@ -90,6 +106,7 @@ struct StepScratch {
     X(xr, R, 1)                                                                                \
     X(hid, H, 1)                                                                               \
     X(dhid, H, 1)                                                                              \
+    X(wb, (long)H * STEP_WBLD, 1)                                                              \
     X(hb1, H, 1)                                                                               \
     X(hw2, (long)O * H, 1)                                                                     \
     X(hb2, O, 1)
@@ -127,6 +144,12 @@ DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v) {
     uint32_t bits; memcpy(&bits, &v, 4);
     *slot = ((unsigned long long)tag << 32) | bits;
 }
+DEV float xchg_wait(unsigned long long* slot, uint32_t tag) {      // emulation: the partner's pass 1 is complete
+    (void)tag;
+    const uint32_t bits = (uint32_t)*slot;
+    float v; memcpy(&v, &bits, 4);
+    return v;
+}
 #else
 DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v) {
     const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
@@ -148,74 +171,90 @@ DEV float xchg_wait(unsigned long long* slot, uint32_t tag) {
 #endif
 
 // ---- head pieces -----------------------------------------------------------------------------
-// fc1.weight [H][R] is read twice by a workgroup: row slices for hid = W1 xr (8 lanes per hidden
-// unit) and the column block of this branch for d readout = dhid W1 (32 lanes per column).  With
-// H <= 128 each of the 1024 lanes needs 8 + 4 values: they are fetched into registers in the
-// staging burst and never touch LDS.
-struct HeadRegs { float wf[8]; float wd[4]; int on; };
-
-DEV void step_head_prefetch(HeadRegs& hr, const HeadFused& hf, int br) {
+// Column block of fc1.weight owned by this branch: wb[h][c] = W1[h][br*32 + c]  (LDS, rows of
+// STEP_WBLD floats).  Loaded as float4 (8 lanes cover the 128 contiguous bytes of a row).
+#define STEP_WB_J 4        // float4 per lane: H * 8 <= STEP_WB_J * 1024  (H <= 512)
 #ifdef DRGNN_EMU
-    hr.on = 0; (void)hf; (void)br;
-#else
-    const int R = hf.R, H = hf.H;
-    hr.on = (DRGNN_NTHREADS == 1024) && H <= 128 && R <= 64;
-    if (!hr.on) return;
-    const int t = threadIdx.x;
-    const int per = (R + 7) >> 3;
-    {
-        const int h = t >> 3, q = t & 7;
-        const float* wr = hf.w1 + (long)(h < H ? h : 0) * R;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int r = q * per + j;
-            hr.wf[j] = (h < H && j < per && r < R) ? wr[r] : 0.0f;
-        }
-    }
-    {
-        const int c = t >> 5, q = t & 31;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int h = q + 32 * j;
-            hr.wd[j] = (h < H) ? hf.w1[(long)h * R + br * DRGNN_H2 + c] : 0.0f;
-        }
-    }
-#endif
+struct WBlockRegs { int dummy; };
+DEV void step_wblock_load(WBlockRegs&, const HeadFused&, int) {}
+DEV void step_wblock_store(const WBlockRegs&, const HeadFused& hf, int br, float* wb) {
+    for (int h = 0; h < hf.H; ++h)
+        for (int c = 0; c < DRGNN_H2; ++c) wb[h * STEP_WBLD + c] = hf.w1[(long)h * hf.R + br * DRGNN_H2 + c];
 }
+#else
+struct WBlockRegs { drgnn_f4 v[STEP_WB_J * DRGNN_BSCALE]; };
+DEV void step_wblock_load(WBlockRegs& wr, const HeadFused& hf, int br) {
+    const bool vec = ((((uintptr_t)hf.w1) & 15) == 0);       // R = 32*n_branch floats: rows stay 16-byte aligned
+#pragma unroll
+    for (int j = 0; j < STEP_WB_J * DRGNN_BSCALE; ++j) {
+        const int t = threadIdx.x + j * DRGNN_NTHREADS;
+        const int h = t >> 3, q = t & 7;
+        drgnn_f4 v = {0.f, 0.f, 0.f, 0.f};
+        if (h < hf.H) {
+            const float* src = hf.w1 + (long)h * hf.R + br * DRGNN_H2 + 4 * q;
+            if (vec) v = *(const drgnn_f4*)src;
+            else { v[0] = src[0]; v[1] = src[1]; v[2] = src[2]; v[3] = src[3]; }
+        }
+        wr.v[j] = v;
+    }
+}
+DEV void step_wblock_store(const WBlockRegs& wr, const HeadFused& hf, int br, float* wb) {
+    (void)br;
+#pragma unroll
+    for (int j = 0; j < STEP_WB_J * DRGNN_BSCALE; ++j) {
+        const int t = threadIdx.x + j * DRGNN_NTHREADS;
+        const int h = t >> 3, q = t & 7;
+        if (h < hf.H) *(drgnn_f4*)(wb + h * STEP_WBLD + 4 * q) = wr.v[j];
+    }
+}
+#endif
 
-// hid = dropout(relu(W1 xr + b1)):  8 lanes per hidden unit, DPP sum inside the lane group
-DEV void step_head_fc1(const HeadFused& hf, const HeadRegs& hr, int g, const float* b1, const float* xr,
-                       float* hid, uint32_t step, uint32_t thresh, float keep_scale) {
-    const int R = hf.R, H = hf.H;
+// hid = dropout(relu(b1 + P0 + P1)),  P_br = W1[:, br*32:(br+1)*32] readout_br  (this workgroup's half
+// product: 8 lanes per hidden unit, DPP sum inside the lane group; the other half comes from the
+// partner workgroup through `xg`, the [n_branch][H] exchange words of graph g).
+// `part` as in net_step_graph: 1 = publish only, 2 = from the wait on (emulation passes).
+DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
+                       const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
+                       uint32_t thresh, float keep_scale, int part) {
+    const int H = hf.H;
 #ifdef DRGNN_EMU
-    (void)hr;
+    if (part != 2) {
+        for (int h = 0; h < H; ++h) {
+            float p = 0.0f;
+            for (int c = 0; c < DRGNN_H2; ++c) p = fmaf(wb[h * STEP_WBLD + c], xr[c], p);
+            if (nb > 1) xchg_publish(xg + (long)br * H + h, tag, p);
+            else hid[h] = p;
+        }
+    }
+    if (part == 1) return;
     for (int h = 0; h < H; ++h) {
-        float v = b1[h];
-        for (int r = 0; r < R; ++r) v = fmaf(hf.w1[h * R + r], xr[r], v);
+        float v = (nb > 1) ? xchg_wait(xg + h, tag) + xchg_wait(xg + H + h, tag) : hid[h];
+        v += b1[h];
         v = v > 0.0f ? v : 0.0f;
         if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
         hid[h] = v;
     }
 #else
-    const int per = (R + 7) >> 3;
+    (void)part;
     const int items = (H * 8 + 63) & ~63;         // whole waves: the lane-group sums need every lane
     for (int t = threadIdx.x; t < items; t += DRGNN_NTHREADS) {
         const int h = t >> 3, q = t & 7;
         float acc = 0.0f;
-        if (hr.on) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int r = q * per + j;
-                acc = fmaf(hr.wf[j], xr[r < R ? r : 0], acc);      // wf is 0 past the slice
-            }
-        } else if (h < H) {
-            const int lo = q * per, hi = imin(R, lo + per);
-            const float* wr = hf.w1 + (long)h * R;
-            for (int r = lo; r < hi; ++r) acc = fmaf(wr[r], xr[r], acc);
+        if (h < H) {
+            const drgnn_f4 w = *(const drgnn_f4*)(wb + h * STEP_WBLD + 4 * q);
+            const drgnn_f4 x = *(const drgnn_f4*)(xr + 4 * q);
+            acc = fmaf(w[0], x[0], fmaf(w[1], x[1], fmaf(w[2], x[2], w[3] * x[3])));
         }
         acc = lanes8_sum(acc);
         if (q == 0 && h < H) {
-            float v = acc + b1[h];
+            float v = acc;
+            if (nb > 1) {
+                xchg_publish(xg + (long)br * H + h, tag, acc);
+                float other = 0.0f;
+                PH(7) other = xchg_wait(xg + (long)(1 - br) * H + h, tag);
+                v = (br == 0) ? acc + other : other + acc;       // P0 + P1 in both workgroups
+            }
+            v += b1[h];
             v = v > 0.0f ? v : 0.0f;
             if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
             hid[h] = v;
@@ -329,17 +368,16 @@ DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, co
 #endif
 }
 
-// d readout (this branch's 32 columns) = dhid W1[:, br*32 : br*32+32], scattered straight into
-// dZ2 through the depth-1 argmax (mean over the C1 clusters -> factor inv)
-DEV void step_head_dreadout(const HeadFused& hf, const HeadRegs& hr, int br, const float* dhid, const int* a1,
-                            int C1, float* z2) {
-    const int H = hf.H, R = hf.R;
+// d readout (this branch's 32 columns) = dhid wb, scattered straight into dZ2 through the depth-1
+// argmax (mean over the C1 clusters -> factor inv)
+DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* dhid, const int* a1, int C1,
+                            float* z2) {
+    const int H = hf.H;
     const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
 #ifdef DRGNN_EMU
-    (void)hr;
     for (int c = 0; c < DRGNN_H2; ++c) {
         float acc = 0.0f;
-        for (int h = 0; h < H; ++h) acc = fmaf(dhid[h], hf.w1[h * R + br * DRGNN_H2 + c], acc);
+        for (int h = 0; h < H; ++h) acc = fmaf(dhid[h], wb[h * STEP_WBLD + c], acc);
         for (int k = 0; k < C1; ++k) {
             const int r = a1[k * DRGNN_H2 + c];
             if (r >= 0) z2[r * DRGNN_H2 + c] = acc * inv;
@@ -349,15 +387,7 @@ DEV void step_head_dreadout(const HeadFused& hf, const HeadRegs& hr, int br, con
     for (int t = threadIdx.x; t < DRGNN_H2 * 32; t += DRGNN_NTHREADS) {
         const int c = t >> 5, q = t & 31;
         float acc = 0.0f;
-        if (hr.on) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int h = q + 32 * j;
-                acc = fmaf(hr.wd[j], dhid[h < H ? h : 0], acc);       // wd is 0 past H
-            }
-        } else {
-            for (int h = q; h < H; h += 32) acc = fmaf(dhid[h], hf.w1[(long)h * R + br * DRGNN_H2 + c], acc);
-        }
+        for (int h = q; h < H; h += 32) acc = fmaf(dhid[h], wb[h * STEP_WBLD + c], acc);
         const float v = lanes32_sum(acc) * inv;
         for (int k = q; k < C1; k += 32) {
             const int r = a1[k * DRGNN_H2 + c];
@@ -384,8 +414,7 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
     const int R = hf.R, H = hf.H, O = hf.O;
     const int XLD = F + 4;
     StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
-    HeadRegs hr;
-    step_head_prefetch(hr, hf, br);
+    WBlockRegs wreg;
     const uint32_t done = (uint32_t)a.step2[0];
     const uint32_t tag = done + 1u;
     const drgnn_conv_params& c1 = a.net.conv1[br];
@@ -399,9 +428,9 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
         // ---- one burst of independent loads: everything this graph needs -> LDS ------------
         PHASE_MARK();
         const float* xg = a.x + (long)d.n0 * F;
-        const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C) && O * H <= 2 * DRGNN_BCAP && H <= DRGNN_BCAP;
+        const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C) && O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP;
         if (burst) {
-            BurstX<4> bx;       burst_load_x(bx, xg, d.N, F);
+            BurstX<4> bx;       burst_load_x(bx, xg, (DRGNN_SKIP == 20) ? 0 : d.N, F);
             BurstW<1> bw1, bw2, bs1, bs2;
             burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
             burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
@@ -422,6 +451,7 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
             burst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
             burst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
             burst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+            step_wblock_load(wreg, hf, br);
             burst_load(bhb1, hf.b1, H);
             burst_load(bhw2, hf.w2, O * H);
             burst_load(bhb2, hf.b2, O);
@@ -446,6 +476,7 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
             burst_store(brp1, s.rp1); burst_store(bcx1, s.cx1);
             burst_store(bcp1, s.cp1); burst_store(brx1, s.rx1);
             burst_store(bmp1, s.mp1); burst_store(bmem1, s.mem1);
+            step_wblock_store(wreg, hf, br, s.wb);
             burst_store(bhb1, s.hb1); burst_store(bhw2, s.hw2); burst_store(bhb2, s.hb2);
             if (KIND != DRGNN_GINET) {
                 burst_store_w(bs1, s.ws1, DRGNN_W1LD);
@@ -472,6 +503,9 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
             step_copy_i32(s.rx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
             step_copy_i32(s.mp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
             step_copy_i32(s.mem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+            FOR_TID(e, H * DRGNN_H2) {
+                s.wb[(e / DRGNN_H2) * STEP_WBLD + e % DRGNN_H2] = hf.w1[(long)(e / DRGNN_H2) * R + br * DRGNN_H2 + e % DRGNN_H2];
+            }
             step_copy_f32(s.hb1, hf.b1, H);
             step_copy_f32(s.hw2, hf.w2, O * H);
             step_copy_f32(s.hb2, hf.b2, O);
@@ -518,54 +552,48 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
             FOR_TID(i, 1) { s.misc[STEP_M_DENOM] = 1.0f; }
         }
         BARRIER();
+        EXIT_AFTER(1);
 
         // ---- forward ------------------------------------------------------------------
-        wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.wn1, DRGNN_W1LD, 1, s.u1, HC1, 1);
+        PH(1) wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.wn1, DRGNN_W1LD, 1, s.u1, HC1, 1);
         if (KIND != DRGNN_GINET)
             wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.ws1, DRGNN_W1LD, 1, s.u1 + DRGNN_H1, HC1, 1);
         net_row_coefs<KIND>(d.N, s.rp0, s.ew0, s.dv0, s.sc0);
         net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
         BARRIER();
-        net_aggregate<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
+        EXIT_AFTER(2);
+        PH(2) net_aggregate<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
         BARRIER();
-        net_cluster_max<DRGNN_H1>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
+        EXIT_AFTER(3);
+        PH(3) net_cluster_max<DRGNN_H1>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
         BARRIER();
-        wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.wn2, DRGNN_W2LD, 1, s.u2, HC2, 1);
+        EXIT_AFTER(4);
+        PH(4) wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.wn2, DRGNN_W2LD, 1, s.u2, HC2, 1);
         if (KIND != DRGNN_GINET)
             wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.ws2, DRGNN_W2LD, 1, s.u2 + DRGNN_H2, HC2, 1);
         FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }      // Z1 is consumed: becomes dZ1
         BARRIER();
-        net_aggregate<KIND, DRGNN_H2, true>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+        EXIT_AFTER(5);
+        PH(5) net_aggregate<KIND, DRGNN_H2, true>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
         BARRIER();
-        net_cluster_max<DRGNN_H2>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
+        EXIT_AFTER(6);
+        PH(6) net_cluster_max<DRGNN_H2>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
         BARRIER();
-        // graph readout: mean over the depth-1 clusters; publish this branch's 32 columns
+        EXIT_AFTER(7);
+        // graph readout: mean over the depth-1 clusters (this branch's 32 columns)
         FOR_TID(c, DRGNN_H2) {
             int bad; memcpy(&bad, &s.misc[STEP_M_BAD], 4);
             float acc = 0.0f;
             for (int k = 0; k < d.C1; ++k) acc += s.p2[k * DRGNN_H2 + c];
             acc = acc / (float)(d.C1 > 0 ? d.C1 : 1);
             if (bad) acc = DRGNN_NAN;
-            const long slot = (long)g * R + br * DRGNN_H2 + c;
-            s.xr[br * DRGNN_H2 + c] = acc;
-            const_cast<float*>(hf.readout)[slot] = acc;
-            if (nb > 1) xchg_publish(a.xchg + slot, tag, acc);
+            s.xr[c] = acc;
+            const_cast<float*>(hf.readout)[(long)g * R + br * DRGNN_H2 + c] = acc;
         }
         FOR_TID(item, d.C * DRGNN_H2) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2
+        BARRIER();
+        EXIT_AFTER(8);
     }
-    if (part == 1) return;
-    if (nb > 1) {
-        FOR_TID(t, DRGNN_H2 * (nb - 1)) {
-            const int ob = (br + 1 + t / DRGNN_H2) % nb, c = t % DRGNN_H2;
-            const long slot = (long)g * R + ob * DRGNN_H2 + c;
-#ifdef DRGNN_EMU
-            s.xr[ob * DRGNN_H2 + c] = hf.readout[slot];
-#else
-            s.xr[ob * DRGNN_H2 + c] = xchg_wait(a.xchg + slot, tag);
-#endif
-        }
-    }
-    BARRIER();
 
     // ---- FC head + loss + their backward ---------------------------------------------------
     const float keep_scale = (hf.p_drop > 0.0f) ? 1.0f / (1.0f - hf.p_drop) : 1.0f;
@@ -576,12 +604,18 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
     float* p_hw2 = p_dhid + H;
     float* p_hb2 = p_hw2 + (long)O * H;
     float* p_loss = p_hb2 + O;
-    step_head_fc1(hf, hr, g, b1, s.xr, s.hid, done, thresh, keep_scale);
+    // half product of fc1 with this branch's readout, exchange with the partner workgroup, hid
+    PH(8) step_head_fc1(hf, g, br, nb, s.wb, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
+                        keep_scale, part);
+    if (part == 1) return;
     BARRIER();
-    step_head_loss(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    EXIT_AFTER(9);
+    PH(9) step_head_loss(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
     BARRIER();
-    step_head_dreadout(hf, hr, br, s.dhid, s.a1, d.C1, s.z2);
+    EXIT_AFTER(10);
+    PH(10) step_head_dreadout(hf, s.wb, s.dhid, s.a1, d.C1, s.z2);
     BARRIER();
+    EXIT_AFTER(11);
 
     // ---- backward body ---------------------------------------------------------------------
     float* part_w = a.partials + ((long)g * nb + br) * a.n_partial;
@@ -591,7 +625,7 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
     float* p_w2n = p_b1 + DRGNN_H1;
     float* p_w2s = p_w2n + DRGNN_H1 * DRGNN_H2;
     float* p_b2 = p_w2s + DRGNN_H1 * DRGNN_H2;
-    net_aggregate_bwd<KIND, DRGNN_H2, true>(d.C, s.rp1, s.cp1, s.rx1, s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
+    PH(11) net_aggregate_bwd<KIND, DRGNN_H2, true>(d.C, s.rp1, s.cp1, s.rx1, s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
     if (KIND != DRGNN_GINET) {
         FOR_TID(c, DRGNN_H2) {
             float acc = 0.0f;
@@ -600,14 +634,16 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
         }
     }
     BARRIER();
-    wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2, HC2, 1, p_w2n, DRGNN_H2, 1);
+    EXIT_AFTER(12);
+    PH(12) wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2, HC2, 1, p_w2n, DRGNN_H2, 1);
     if (KIND != DRGNN_GINET)
         wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2 + DRGNN_H2, HC2, 1, p_w2s, DRGNN_H2, 1);
-    wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, s.wn2, 1, DRGNN_W2LD, s.dxp, DRGNN_H1, 1);
+    PH(13) wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, s.wn2, 1, DRGNN_W2LD, s.dxp, DRGNN_H1, 1);
     if (KIND != DRGNN_GINET)
         wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2 + DRGNN_H2, HC2, 1, s.ws2, 1, DRGNN_W2LD, s.p2, DRGNN_H1, 1);
     BARRIER();
-    FOR_TID(item, d.C * DRGNN_H1) {
+    EXIT_AFTER(13);
+    PH(14) FOR_TID(item, d.C * DRGNN_H1) {
         const int m = s.a0[item];
         const int c = item % DRGNN_H1;
         if (m >= 0) {
@@ -617,7 +653,8 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
         }
     }
     BARRIER();
-    net_aggregate_bwd<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cp0, s.rx0, s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
+    EXIT_AFTER(14);
+    PH(15) net_aggregate_bwd<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cp0, s.rx0, s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
     if (KIND != DRGNN_GINET) {
         FOR_TID(c, DRGNN_H1) {
             float acc = 0.0f;
@@ -626,13 +663,15 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
         }
     }
     BARRIER();
+    EXIT_AFTER(15);
     {
         const int mtiles = (F + 15) >> 4;
         int KS = imin(DRGNN_NWAVES / mtiles, 2048 / (F * DRGNN_H1));
         if (KS < 1) KS = 1;
-        wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, XLD, s.u1, HC1, 1, p_w1n, DRGNN_H1, 1, KS, s.gp);
+        PH(16) wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, XLD, s.u1, HC1, 1, p_w1n, DRGNN_H1, 1, KS, s.gp);
         if (KIND != DRGNN_GINET) {
             BARRIER();
+            EXIT_AFTER(16);
             wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, XLD, s.u1 + DRGNN_H1, HC1, 1, p_w1s, DRGNN_H1, 1, KS, s.gp);
         }
     }

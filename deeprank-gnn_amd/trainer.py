@@ -142,7 +142,7 @@ class FusedTrainer(object):
         if nb > 1:
             xchg = self._xchg.get(B)
             if xchg is None:
-                xchg = self._xchg[B] = torch.zeros((max(B, 1), H2 * nb), dtype=torch.int64, device=dev)
+                xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * self.H), dtype=torch.int64, device=dev)
         g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
         g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
         for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, nb)):

@@ -349,8 +349,8 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   head_partials OUT [B][drgnn_head_compact_elems]: [dhid H][dW_fc2 O*H][db_fc2 O][loss][weight]
  *             (dW_fc1 = dhid^T readout is formed by drgnn_step_update)
  *   partials  OUT [B*n_branch][drgnn_net_partial_elems]
- *   xchg      uint64 [B, 32*n_branch], zero-filled ONCE by the caller and then left alone: the two
- *             branch workgroups of a GINet graph exchange their readout halves through it
+ *   xchg      uint64 [B, n_branch, H], zero-filled ONCE by the caller and then left alone: the two
+ *             branch workgroups of a GINet graph exchange their halves of fc1's product through it
  *             (may be NULL when n_branch == 1)
  * Needs max_nodes/max_edges/max_c0 bounds; returns DRGNN_E_CAPACITY when a graph of that size does
  * not fit the 160 KiB LDS (drgnn_net_step_lds_bytes): use drgnn_net_forward +
