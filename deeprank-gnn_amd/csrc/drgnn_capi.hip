@@ -279,9 +279,8 @@ template <int KIND>
 DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
     const int nb = L.a.net.n_branch;
     const int g = blk / nb, br = blk % nb;
-    const int n0 = L.a.tv.p[DRGNN_TI_NPTR][g], e0 = L.a.tv.p[DRGNN_TI_EPTR][g];
-    if (L.a.tv.p[DRGNN_TI_NPTR][g + 1] - n0 > L.capN || L.a.tv.p[DRGNN_TI_EPTR][g + 1] - e0 > L.capE ||
-        L.a.tv.p[DRGNN_TI_NC0][g] > L.capC) {
+    const GraphDims d = net_dims(L.a.tv, g);      // ONE round trip for all per-graph sizes
+    if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
         // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
         if (part != 2) {
             const uint32_t tag = (uint32_t)L.a.step2[0] + 1u;
@@ -296,7 +295,7 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
         }
         return;
     }
-    net_step_graph<KIND>(L.a, g, br, lds, L.capN, L.capE, L.capC, part);
+    net_step_graph<KIND>(L.a, d, g, br, lds, L.capN, L.capE, L.capC, part);
 }
 
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------

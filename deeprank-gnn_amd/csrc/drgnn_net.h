@@ -396,15 +396,24 @@ DEV NetScratch net_carve(float* base, int kind, int F, int capN, int capE, int c
 
 struct GraphDims { int n0, N, e0, E, C, E1, C1, rowbase; };
 
+// workgroup-uniform value -> scalar register (the compiler cannot prove these loads uniform itself)
+#ifdef DRGNN_EMU
+#define WG_UNIFORM(x) (x)
+#else
+#define WG_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
 DEV GraphDims net_dims(const TopoView& tv, int g) {
     GraphDims d;
-    d.n0 = tv.p[DRGNN_TI_NPTR][g];
-    d.N = tv.p[DRGNN_TI_NPTR][g + 1] - d.n0;
-    d.e0 = tv.p[DRGNN_TI_EPTR][g];
-    d.E = tv.p[DRGNN_TI_EPTR][g + 1] - d.e0;
-    d.C = tv.p[DRGNN_TI_NC0][g];
-    d.E1 = tv.p[DRGNN_TI_NE1][g];
-    d.C1 = tv.p[DRGNN_TI_NC1][g];
+    const int n0 = tv.p[DRGNN_TI_NPTR][g], n1 = tv.p[DRGNN_TI_NPTR][g + 1];
+    const int e0 = tv.p[DRGNN_TI_EPTR][g], e1 = tv.p[DRGNN_TI_EPTR][g + 1];
+    const int c = tv.p[DRGNN_TI_NC0][g], m1 = tv.p[DRGNN_TI_NE1][g], c1 = tv.p[DRGNN_TI_NC1][g];
+    d.n0 = WG_UNIFORM(n0);
+    d.N = WG_UNIFORM(n1) - d.n0;
+    d.e0 = WG_UNIFORM(e0);
+    d.E = WG_UNIFORM(e1) - d.e0;
+    d.C = WG_UNIFORM(c);
+    d.E1 = WG_UNIFORM(m1);
+    d.C1 = WG_UNIFORM(c1);
     d.rowbase = d.n0 + g;
     return d;
 }

@@ -267,6 +267,43 @@ template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
 }
 #endif
 
+// ---------------------------------------------------------------------------------
+// Burst staging through buffer loads (gfx950 `buffer_load_dword ... offen`): the hardware range
+// check of the resource descriptor returns 0 for lanes past the end, so a load is ONE instruction
+// with the lane offset shared by every array (no per-array compare / exec mask / 64-bit add).
+// The LDS side writes lanes past the end to a per-lane dummy word instead of masking them.
+// ---------------------------------------------------------------------------------
+#ifdef DRGNN_EMU
+template <int J> struct BufBurst { const int32_t* src; int n; };
+template <int J> DEV void bufburst_load(BufBurst<J>& b, const void* src, int n) { b.src = (const int32_t*)src; b.n = n; }
+template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* dummy) {
+    (void)dummy;
+    for (int i = 0; i < b.n; ++i) ((int32_t*)dst)[i] = b.src[i];
+}
+#else
+DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+template <int J> struct BufBurst { int v[J * DRGNN_BSCALE]; int n; };
+template <int J> DEV void bufburst_load(BufBurst<J>& b, const void* src, int n) {
+    b.n = n;
+    const __amdgpu_buffer_rsrc_t r = buf_rsrc(src, n * 4);
+    const int voff = threadIdx.x * 4;
+#pragma unroll
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j)
+        b.v[j] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, j * DRGNN_NTHREADS * 4, 0);
+}
+template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* dummy) {
+    int* d = (int*)dst;
+#pragma unroll
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        const int i = threadIdx.x + j * DRGNN_NTHREADS;
+        int* p = (i < b.n) ? d + i : dummy + (threadIdx.x & 63);
+        *p = b.v[j];
+    }
+}
+#endif
+
 // x tile with rows padded to ld = F + 4 floats (16-byte aligned rows: one 128-bit LDS store per
 // float4; 36-float rows keep the 16 row lanes of an MFMA A-operand read on distinct banks)
 #ifdef DRGNN_EMU

@@ -102,7 +102,7 @@ struct StepScratch {
     X(dv1, capC, !gin)                                                                         \
     X(sc1, capC, !gin)                                                                         \
     X(gp, 2048, 1)                                                                             \
-    X(misc, 64, 1)                                                                             \
+    X(misc, 128, 1)                                                                            \
     X(xr, R, 1)                                                                                \
     X(hid, H, 1)                                                                               \
     X(dhid, H, 1)                                                                              \
@@ -402,13 +402,12 @@ DEV void step_copy_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { ds
 
 // `part`: 0 = whole step (device), 1 = up to the readout publication, 2 = from the head on
 template <int KIND>
-DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int capN, int capE, int capC,
-                        int part) {
+DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, float* scratch, int capN,
+                        int capE, int capC, int part) {
     constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
     constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const TopoView& tv = a.tv;
     const HeadFused& hf = a.hf;
-    const GraphDims d = net_dims(tv, g);
     const int F = a.net.n_feat;
     const int nb = a.net.n_branch;
     const int R = hf.R, H = hf.H, O = hf.O;
@@ -424,69 +423,77 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
     const float* b2 = s.hb2;
 
     if (part != 2) {
-        if (g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }
         // ---- one burst of independent loads: everything this graph needs -> LDS ------------
         PHASE_MARK();
         const float* xg = a.x + (long)d.n0 * F;
         const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C) && O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP;
+        // Burst registers live across the first barrier: the x tile and the conv1 weights are
+        // written to LDS at once, conv1's dense product starts, and everything else (index arrays, conv2
+        // and head weights) is written to LDS after it -- their memory time hides behind the MFMAs.
+        BurstX<4> bx;
+        BurstW<1> bw1, bw2, bs1, bs2;
+        BufBurst<1> brp0, bcp0, bmp0, bmem0, brp1, bcp1, bmp1, bmem1, bb1, bb2, bhb1, bhb2;
+        BufBurst<2> bcx0, brx0, bcx1, brx1, bts0, bts1, bew0, bew1, bhw2;
+        int* const dummy = (int*)(s.misc + 64);
+#if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
+        asm volatile("" :: "s"(d.N), "s"(d.E1));      // per-graph sizes have arrived
+        PHASE_MARK();
+#endif
+#ifndef DRGNN_EMU
+        {   // fetch every workspace pointer in one go: otherwise each array's staging starts with its own
+            // kernarg read + wait
+            const int32_t* const* P = tv.p;
+            asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR0]), "s"(P[DRGNN_TI_COL0]), "s"(P[DRGNN_TI_COLPTR0]),
+                         "s"(P[DRGNN_TI_ROWIDX0]), "s"(P[DRGNN_TI_MPTR0]), "s"(P[DRGNN_TI_MEM0]));
+            asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR1]), "s"(P[DRGNN_TI_COL1]), "s"(P[DRGNN_TI_COLPTR1]),
+                         "s"(P[DRGNN_TI_ROWIDX1]), "s"(P[DRGNN_TI_MPTR1]), "s"(P[DRGNN_TI_MEM1]));
+        }
+#endif
         if (burst) {
-            BurstX<4> bx;       burst_load_x(bx, xg, (DRGNN_SKIP == 20) ? 0 : d.N, F);
-            BurstW<1> bw1, bw2, bs1, bs2;
+            burst_load_x(bx, xg, (DRGNN_SKIP == 20) ? 0 : d.N, F);
             burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
             burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
-            Burst<int, 1> brp0, bcp0, bmp0, bmem0, brp1, bcp1, bmp1, bmem1;
-            Burst<int, 2> bcx0, brx0, bcx1, brx1, bts0, bts1;
-            Burst<float, 2> bew0, bew1;
-            Burst<float, 1> bb1, bb2, bhb1, bhb2;
-            Burst<float, 2> bhw2;
-            burst_load(brp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
-            burst_load(bcx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
-            burst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
-            burst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
-            burst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
-            burst_load(bmem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
-            burst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
-            burst_load(bcx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
-            burst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
-            burst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
-            burst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
-            burst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+            bufburst_load(brp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+            bufburst_load(bcx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
+            bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+            bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+            bufburst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
+            bufburst_load(bmem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
+            bufburst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+            bufburst_load(bcx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
+            bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+            bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            bufburst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
+            bufburst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
             step_wblock_load(wreg, hf, br);
-            burst_load(bhb1, hf.b1, H);
-            burst_load(bhw2, hf.w2, O * H);
-            burst_load(bhb2, hf.b2, O);
+            bufburst_load(bhb1, hf.b1, H);
+            bufburst_load(bhw2, hf.w2, O * H);
+            bufburst_load(bhb2, hf.b2, O);
             if (KIND != DRGNN_GINET) {
                 burst_load_w(bs1, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
                 burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
-                burst_load(bb1, c1.bias, DRGNN_H1);
-                burst_load(bb2, c2.bias, DRGNN_H2);
+                bufburst_load(bb1, c1.bias, DRGNN_H1);
+                bufburst_load(bb2, c2.bias, DRGNN_H2);
             }
             if (KIND == DRGNN_SGAT) {
-                burst_load(bew0, (const float*)(tv.w0 + d.e0), d.E);
-                burst_load(bew1, (const float*)(tv.w1 + d.e0), d.E1);
-                burst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
-                burst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+                bufburst_load(bew0, tv.w0 + d.e0, d.E);
+                bufburst_load(bew1, tv.w1 + d.e0, d.E1);
+                bufburst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+                bufburst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
             }
+#if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
+            PHASE_MARK();                                  // all loads issued
+            asm volatile("" :: "v"(bx.v[0][0]));
+            PHASE_MARK();                                  // first x data here
+            asm volatile("" :: "v"(bw1.v[0]));
+            PHASE_MARK();                                  // conv1 weights here
+#endif
             burst_store_x4(bx, s.xs);
             burst_store_w(bw1, s.wn1, DRGNN_W1LD);
-            burst_store_w(bw2, s.wn2, DRGNN_W2LD);
-            burst_store(brp0, s.rp0); burst_store(bcx0, s.cx0);
-            burst_store(bcp0, s.cp0); burst_store(brx0, s.rx0);
-            burst_store(bmp0, s.mp0); burst_store(bmem0, s.mem0);
-            burst_store(brp1, s.rp1); burst_store(bcx1, s.cx1);
-            burst_store(bcp1, s.cp1); burst_store(brx1, s.rx1);
-            burst_store(bmp1, s.mp1); burst_store(bmem1, s.mem1);
-            step_wblock_store(wreg, hf, br, s.wb);
-            burst_store(bhb1, s.hb1); burst_store(bhw2, s.hw2); burst_store(bhb2, s.hb2);
-            if (KIND != DRGNN_GINET) {
-                burst_store_w(bs1, s.ws1, DRGNN_W1LD);
-                burst_store_w(bs2, s.ws2, DRGNN_W2LD);
-                burst_store(bb1, s.b1); burst_store(bb2, s.b2);
-            }
-            if (KIND == DRGNN_SGAT) {
-                burst_store(bew0, s.ew0); burst_store(bew1, s.ew1);
-                burst_store(bts0, s.ts0); burst_store(bts1, s.ts1);
-            }
+            if (KIND != DRGNN_GINET) burst_store_w(bs1, s.ws1, DRGNN_W1LD);
+#if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
+            PHASE_MARK();                                  // LDS stores issued
+#endif
         } else {
             FOR_TID(e, d.N * F) { s.xs[(e / F) * XLD + e % F] = xg[e]; }
             stage_weight(s.wn1, DRGNN_W1LD, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
@@ -522,6 +529,32 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
                 step_copy_i32(s.ts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
             }
         }
+        BARRIER();
+        EXIT_AFTER(1);
+
+        // ---- forward ------------------------------------------------------------------
+        PH(1) wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.wn1, DRGNN_W1LD, 1, s.u1, HC1, 1);
+        if (KIND != DRGNN_GINET)
+            wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.ws1, DRGNN_W1LD, 1, s.u1 + DRGNN_H1, HC1, 1);
+        if (burst) {
+            burst_store_w(bw2, s.wn2, DRGNN_W2LD);
+            bufburst_store(brp0, s.rp0, dummy); bufburst_store(bcx0, s.cx0, dummy);
+            bufburst_store(bcp0, s.cp0, dummy); bufburst_store(brx0, s.rx0, dummy);
+            bufburst_store(bmp0, s.mp0, dummy); bufburst_store(bmem0, s.mem0, dummy);
+            bufburst_store(brp1, s.rp1, dummy); bufburst_store(bcx1, s.cx1, dummy);
+            bufburst_store(bcp1, s.cp1, dummy); bufburst_store(brx1, s.rx1, dummy);
+            bufburst_store(bmp1, s.mp1, dummy); bufburst_store(bmem1, s.mem1, dummy);
+            step_wblock_store(wreg, hf, br, s.wb);
+            bufburst_store(bhb1, s.hb1, dummy); bufburst_store(bhw2, s.hw2, dummy); bufburst_store(bhb2, s.hb2, dummy);
+            if (KIND != DRGNN_GINET) {
+                burst_store_w(bs2, s.ws2, DRGNN_W2LD);
+                bufburst_store(bb1, s.b1, dummy); bufburst_store(bb2, s.b2, dummy);
+            }
+            if (KIND == DRGNN_SGAT) {
+                bufburst_store(bew0, s.ew0, dummy); bufburst_store(bew1, s.ew1, dummy);
+                bufburst_store(bts0, s.ts0, dummy); bufburst_store(bts1, s.ts1, dummy);
+            }
+        }
         // per-graph scalars of the readout / loss phases (their global latency hides in the burst)
         FOR_TID(i, 1) {
             const int bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g] | tv.p[DRGNN_TI_GSTAT][a.n_graphs + g];
@@ -552,16 +585,12 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
             FOR_TID(i, 1) { s.misc[STEP_M_DENOM] = 1.0f; }
         }
         BARRIER();
-        EXIT_AFTER(1);
-
-        // ---- forward ------------------------------------------------------------------
-        PH(1) wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.wn1, DRGNN_W1LD, 1, s.u1, HC1, 1);
-        if (KIND != DRGNN_GINET)
-            wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.ws1, DRGNN_W1LD, 1, s.u1 + DRGNN_H1, HC1, 1);
-        net_row_coefs<KIND>(d.N, s.rp0, s.ew0, s.dv0, s.sc0);
-        net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
-        BARRIER();
         EXIT_AFTER(2);
+        if (KIND != DRGNN_GINET) {
+            net_row_coefs<KIND>(d.N, s.rp0, s.ew0, s.dv0, s.sc0);
+            net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
+            BARRIER();
+        }
         PH(2) net_aggregate<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
         BARRIER();
         EXIT_AFTER(3);
@@ -604,6 +633,7 @@ DEV void net_step_graph(const StepArgs& a, int g, int br, float* scratch, int ca
     float* p_hw2 = p_dhid + H;
     float* p_hb2 = p_hw2 + (long)O * H;
     float* p_loss = p_hb2 + O;
+    if (part != 2 && g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
     // half product of fc1 with this branch's readout, exchange with the partner workgroup, hid
     PH(8) step_head_fc1(hf, g, br, nb, s.wb, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
                         keep_scale, part);
