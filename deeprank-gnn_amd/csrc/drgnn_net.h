@@ -493,10 +493,11 @@ DEV void net_row_coefs(int n, const int* rp, const float* w, float* dv, float* s
         else { (p)[0] = v0; (p)[1] = v1; (p)[2] = v2; (p)[3] = v3; }                           \
     } while (0)
 #endif
-template <int KIND, int H, bool A16 = false>
+// LDU: row stride of u in floats (0: dense rows of HC = H or 2H)
+template <int KIND, int H, bool A16 = false, int LDU = 0>
 DEV void net_aggregate(int n, const int* rp, const int* col, const float* w, const float* dv,
                        const float* sc, const float* u, const float* bias, float* z) {
-    constexpr int HC = (KIND == DRGNN_GINET) ? H : 2 * H;
+    constexpr int HC = LDU ? LDU : ((KIND == DRGNN_GINET) ? H : 2 * H);
     constexpr int G = H / 4;
     FOR_TID(item, n * G) {
         const int i = item / G, c = (item % G) * 4;
@@ -532,7 +533,8 @@ DEV void net_aggregate(int n, const int* rp, const int* col, const float* w, con
 
 // cluster max with argmax (first maximum in ascending member order; NaN never wins;
 // empty cluster -> 0).  arg = -1 where no gradient can flow (value <= 0 or empty).
-template <int H>
+// LDO: row stride of `out` in floats (0: dense rows of H)
+template <int H, int LDO = 0>
 DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, float* out,
                          float* g_out, int32_t* g_arg) {
     FOR_TID(item, nc * H) {
@@ -546,7 +548,7 @@ DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, 
             if (v > best) { best = v; arg = m; }
         }
         if (arg < 0) best = 0.0f;
-        out[item] = best;
+        out[LDO ? r * LDO + c : item] = best;
         if (g_out) g_out[item] = best;
         g_arg[item] = (best > 0.0f) ? arg : -1;
     }
@@ -675,11 +677,11 @@ HD int64_t net_partial_floats(int n_feat) {
 
 // dU[j, 0:H]   = sum over CSC entries t of column j : coef * dZ[row(t), :]
 // dU[i, H:2H]  = sc[i] * dZ[i, :]
-template <int KIND, int H, bool A16 = false>
+template <int KIND, int H, bool A16 = false, int LDU = 0>
 DEV void net_aggregate_bwd(int n, const int* deg_rp, const int* cp, const int* ridx, const int* tslot,
                            const float* w, const float* dv, const float* sc, const float* dz,
                            float* du) {
-    constexpr int HC = (KIND == DRGNN_GINET) ? H : 2 * H;
+    constexpr int HC = LDU ? LDU : ((KIND == DRGNN_GINET) ? H : 2 * H);
     constexpr int G = H / 4;
     FOR_TID(item, n * G) {
         const int j = item / G, c = (item % G) * 4;

@@ -197,6 +197,9 @@ template <int J> DEV void burst_load_w(BurstW<J>& b, const float* src, long sk, 
 template <int J> DEV void burst_store_w(const BurstW<J>& b, float* dst, int ld) {
     for (int k = 0; k < b.K; ++k) for (int h = 0; h < b.H; ++h) dst[k * ld + h] = b.src[k * b.sk + h * b.sh];
 }
+template <int J> DEV void burst_store_wt(const BurstW<J>& b, float* dst, int ld) {     // dst[h*ld + k]
+    for (int k = 0; k < b.K; ++k) for (int h = 0; h < b.H; ++h) dst[h * ld + k] = b.src[k * b.sk + h * b.sh];
+}
 template <int J> struct BurstX { const float* src; int rows, F; };
 template <int J> DEV void burst_load_x(BurstX<J>& b, const float* src, int rows, int F) { b.src = src; b.rows = rows; b.F = F; }
 template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
@@ -238,6 +241,15 @@ template <int J> DEV void burst_store_w(const BurstW<J>& b, float* dst, int ld) 
         const int e = threadIdx.x + j * DRGNN_NTHREADS;
         const int k = fastdiv(fd, e), h = fastmod(fd, e, k);
         if (e < b.n) dst[k * ld + h] = b.v[j];
+    }
+}
+template <int J> DEV void burst_store_wt(const BurstW<J>& b, float* dst, int ld) {     // dst[h*ld + k]
+    const FastDiv fd = fastdiv_make(b.H);
+#pragma unroll
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        const int e = threadIdx.x + j * DRGNN_NTHREADS;
+        const int k = fastdiv(fd, e), h = fastmod(fd, e, k);
+        if (e < b.n) dst[h * ld + k] = b.v[j];
     }
 }
 // x tile [rows, F] (F % 4 == 0, 16-byte aligned) -> padded rows dst[i*(F+1) + f], float4 loads
@@ -304,21 +316,21 @@ template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* d
 }
 #endif
 
-// x tile with rows padded to ld = F + 4 floats (16-byte aligned rows: one 128-bit LDS store per
-// float4; 36-float rows keep the 16 row lanes of an MFMA A-operand read on distinct banks)
+// x tile with rows padded to `ld` floats (ld % 4 == 0: 16-byte aligned rows, one 128-bit LDS store per
+// float4; ld = 36 keeps the 16 row lanes of an MFMA A-operand read on distinct banks)
 #ifdef DRGNN_EMU
-template <int J> DEV void burst_store_x4(const BurstX<J>& b, float* dst) {
-    for (int i = 0; i < b.rows; ++i) for (int f = 0; f < b.F; ++f) dst[i * (b.F + 4) + f] = b.src[i * b.F + f];
+template <int J> DEV void burst_store_x4(const BurstX<J>& b, float* dst, int ld) {
+    for (int i = 0; i < b.rows; ++i) for (int f = 0; f < b.F; ++f) dst[i * ld + f] = b.src[i * b.F + f];
 }
 #else
-template <int J> DEV void burst_store_x4(const BurstX<J>& b, float* dst) {
+template <int J> DEV void burst_store_x4(const BurstX<J>& b, float* dst, int ld) {
     const FastDiv fd = fastdiv_make(b.F >> 2);
 #pragma unroll
     for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
         const int q = threadIdx.x + j * DRGNN_NTHREADS;
         if (q < b.n4) {
             const int row = fastdiv(fd, q);
-            *(drgnn_f4*)(dst + row * (b.F + 4) + 4 * fastmod(fd, q, row)) = b.v[j];
+            *(drgnn_f4*)(dst + row * ld + 4 * fastmod(fd, q, row)) = b.v[j];
         }
     }
 }

@@ -48,11 +48,15 @@ struct StepArgs {
 
 HD int64_t head_compact_floats(int R, int H, int O) { (void)R; return (int64_t)H + (int64_t)O * H + O + 2; }
 
+#define STEP_XPLD (DRGNN_H1 + 4)     // pooled features: 20-float rows (conflict-free 128-bit row reads)
+#define STEP_GP_WORDS 4096           // partial tiles of step_gemm_tn: 16 units x 256 floats
+HD int step_pad4(int n) { return (n + 3) & ~3; }
+HD int step_pad16(int n) { return (n + 15) & ~15; }
 #define STEP_WBLD (DRGNN_H2 + 4)     // row stride of the fc1.weight column block in LDS (16-byte aligned rows)
 
 // ---- scratch ---------------------------------------------------------------------------------
 struct StepScratch {
-    float* xs; float* wn1; float* ws1; float* b1; float* wn2; float* ws2; float* b2;
+    float* xs; float* w1t; float* ws1t; float* b1; float* w2t; float* w2n; float* ws2t; float* ws2n; float* b2;
     int* rp0; int* cx0; float* ew0; int* cp0; int* rx0; int* ts0; int* mp0; int* mem0;
     int* rp1; int* cx1; float* ew1; int* cp1; int* rx1; int* ts1; int* mp1; int* mem1;
     int* a0; int* a1;
@@ -65,12 +69,14 @@ struct StepScratch {
 };
 
 #define STEP_CARVE_LIST(X)                                                                     \
-    X(xs, (long)capN * (F + 4), 1)                                                             \
-    X(wn1, F * DRGNN_W1LD, 1)                                                                  \
-    X(ws1, F * DRGNN_W1LD, !gin)                                                               \
+    X(xs, (long)(capN + 4) * xld, 1)                                                           \
+    X(w1t, DRGNN_H1 * xld, 1)                                                                  \
+    X(ws1t, DRGNN_H1 * xld, !gin)                                                              \
     X(b1, DRGNN_H1, !gin)                                                                      \
-    X(wn2, DRGNN_H1 * DRGNN_W2LD, 1)                                                           \
-    X(ws2, DRGNN_H1 * DRGNN_W2LD, !gin)                                                        \
+    X(w2t, DRGNN_H2 * STEP_XPLD, 1)                                                            \
+    X(w2n, DRGNN_H1 * (DRGNN_H2 + 4), 1)                                                       \
+    X(ws2t, DRGNN_H2 * STEP_XPLD, !gin)                                                        \
+    X(ws2n, DRGNN_H1 * (DRGNN_H2 + 4), !gin)                                                   \
     X(b2, DRGNN_H2, !gin)                                                                      \
     X(rp0, capN + 1, 1)                                                                        \
     X(cx0, capE, 1)                                                                            \
@@ -90,18 +96,18 @@ struct StepScratch {
     X(mem1, capC, 1)                                                                           \
     X(a0, (long)capC * DRGNN_H1, 1)                                                            \
     X(a1, (long)capC * DRGNN_H2, 1)                                                            \
-    X(u1, (long)capN * hc1, 1)                                                                 \
+    X(u1, (long)(capN + 4) * hc1, 1)                                                           \
     X(z1, (long)capN * DRGNN_H1, 1)                                                            \
     X(dv0, capN, !gin)                                                                         \
     X(sc0, capN, !gin)                                                                         \
-    X(xp, (long)capC * DRGNN_H1, 1)                                                            \
+    X(xp, (long)(capC + 4) * STEP_XPLD, 1)                                                     \
     X(dxp, (long)capC * DRGNN_H1, 1)                                                           \
-    X(u2, (long)capC * hc2, 1)                                                                 \
+    X(u2, (long)(capC + 4) * (hc2 + 4), 1)                                                     \
     X(z2, (long)capC * DRGNN_H2, 1)                                                            \
     X(p2, (long)capC * DRGNN_H2, 1)                                                            \
     X(dv1, capC, !gin)                                                                         \
     X(sc1, capC, !gin)                                                                         \
-    X(gp, 2048, 1)                                                                             \
+    X(gp, STEP_GP_WORDS, 1)                                                                    \
     X(misc, 128, 1)                                                                            \
     X(xr, R, 1)                                                                                \
     X(hid, H, 1)                                                                               \
@@ -117,6 +123,7 @@ HD int64_t step_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, i
     const int64_t hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
     const int gin = (kind == DRGNN_GINET) ? 1 : 0;
+    const int64_t xld = step_pad16((int)F) + 4;
     int64_t w = 0;
 #define X(name, words, cond) w += (cond) ? (((int64_t)(words) + 3) & ~(int64_t)3) : 0;   /* 16-byte aligned arrays */
     STEP_CARVE_LIST(X)
@@ -129,6 +136,7 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
     const int hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
     const int gin = (kind == DRGNN_GINET) ? 1 : 0;
+    const int xld = step_pad16(F) + 4;
     StepScratch s;
     float* p = base;
 #define X(name, words, cond) s.name = (decltype(s.name))p; p += (cond) ? (((long)(words) + 3) & ~3L) : 0;
@@ -137,6 +145,122 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
     s.end = p;
     return s;
 }
+
+// ---- dense products of the step kernel ----------------------------------------------------------
+// Layout rules that let the MFMA loops run without lane predicates:
+//   * row-major operands have 16-byte aligned rows (stride % 4 == 0) and their K extent is zero padded
+//     to a multiple of 16 (step_gemm_nn) -- a lane fetches 4 consecutive k with ONE 128-bit LDS read
+//     and feeds them to 4 MFMA steps (the k order inside a 16-chunk is permuted the same way for A
+//     and B, which does not change the sum's terms);
+//   * node-major operands (K = node index) keep rows [K, pad4(K)) readable and ZERO (step_gemm_tn).
+// Rows past M of a last tile are computed from whatever LDS holds and their stores discarded.
+
+// C[M x 16*NT] (row stride ldc) = A[M x K] * Bt^T,  A rows of stride lda, Bt[n][k] rows of stride ldbt
+#ifdef DRGNN_EMU
+DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
+                      int* dummy) {
+    (void)dummy;
+    for (int i = 0; i < M; ++i)
+        for (int j = 0; j < 16 * NT; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) acc = fmaf(A[i * lda + k], Bt[j * ldbt + k], acc);
+            C[i * ldc + j] = acc;
+        }
+}
+#else
+DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
+                      int* dummy) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int units = ((M + 15) >> 4) * NT;
+    for (int u = wave; u < units; u += DRGNN_NWAVES) {
+        const int ti = (NT == 1) ? u : (u >> 1), tj = (NT == 1) ? 0 : (u & 1);      // NT is 1 or 2
+        const float* ap = A + (ti * 16 + lr) * lda + 4 * lq;
+        const float* bp = Bt + (tj * 16 + lr) * ldbt + 4 * lq;
+        drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            const drgnn_f4 a0 = *(const drgnn_f4*)(ap + k0), b0 = *(const drgnn_f4*)(bp + k0);
+            const bool two = k0 + 16 < K;
+            drgnn_f4 a1 = a0, b1 = b0;
+            if (two) { a1 = *(const drgnn_f4*)(ap + k0 + 16); b1 = *(const drgnn_f4*)(bp + k0 + 16); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc, 0, 0, 0);
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = ti * 16 + lq * 4 + r;
+            float* p = (ci < M) ? C + ci * ldc + tj * 16 + lr : (float*)dummy + lane;
+            *p = acc[r];
+        }
+    }
+}
+#endif
+
+// C[Mrows <= 16*MT x 16*NT] (global, row stride ldc) = sum_k A[k][i] * B[k][j],  A rows of stride lda (K of them),
+// B rows of stride ldb.  K is cut in KS slices (one (tile, slice) unit per wave); the partial tiles go to
+// `part` ([KS * MT * NT][64 lanes][4]) and are summed in slice order.  Contains one workgroup barrier;
+// callers put another one before reusing `part`.
+#ifdef DRGNN_EMU
+DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
+                      float* C, int ldc, int Mrows) {
+    (void)KS; (void)part; (void)MT;
+    for (int i = 0; i < Mrows; ++i)
+        for (int j = 0; j < 16 * NT; ++j) {
+            float acc = 0.0f;
+            for (int k = 0; k < K; ++k) acc = fmaf(A[k * lda + i], B[k * ldb + j], acc);
+            C[i * ldc + j] = acc;
+        }
+}
+#else
+DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
+                      float* C, int ldc, int Mrows) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int K4 = step_pad4(K);
+    const int kslice = (((K4 >> 2) + KS - 1) / KS) << 2;
+    const int tiles = MT * NT, units = tiles * KS;
+    for (int u = wave; u < units; u += DRGNN_NWAVES) {
+        const int ks = u / tiles, t = u - ks * tiles;
+        const int ti = t / NT, tj = t - ti * NT;
+        const int kbeg = ks * kslice, kend = imin(K4, kbeg + kslice);
+        drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* ap = A + (kbeg + lq) * lda + ti * 16 + lr;
+        const float* bp = B + (kbeg + lq) * ldb + tj * 16 + lr;
+        for (int k0 = kbeg; k0 < kend; k0 += 32) {
+            float a[8], b[8];
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {      // unconditional: rows past kend exist in LDS and are not used
+                a[s2] = ap[4 * s2 * lda];
+                b[s2] = bp[4 * s2 * ldb];
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2)
+                if (k0 + 4 * s2 < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2], b[s2], acc, 0, 0, 0);
+            ap += 32 * lda;
+            bp += 32 * ldb;
+        }
+        *(drgnn_f4*)(part + (u * 64 + lane) * 4) = drgnn_f4{acc[0], acc[1], acc[2], acc[3]};
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < tiles * 64; e += DRGNN_NTHREADS) {
+        const int t = e >> 6, l = e & 63;
+        const int ti = t / NT, tj = t - ti * NT;
+        drgnn_f4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < KS; ++ks) {
+            const drgnn_f4 v = *(const drgnn_f4*)(part + ((ks * tiles + t) * 64 + l) * 4);
+            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
+        }
+        const int row = ti * 16 + (l >> 4) * 4;
+        float* c = C + row * ldc + tj * 16 + (l & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (row + r < Mrows) c[r * ldc] = sum[r];
+    }
+}
+#endif
 
 // ---- readout exchange between the branch workgroups of a graph -----------------------------------
 #ifdef DRGNN_EMU
@@ -397,6 +521,13 @@ DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* d
 #endif
 }
 
+// strided [K,H] weight -> transposed dense rows dst[h*ld + k]
+DEV void step_stage_wt(float* dst, int ld, const float* src, long sk, long sh, int K, int H) {
+    FOR_TID(e, K * H) {
+        const int k = e / H, h = e % H;
+        dst[h * ld + k] = src[(long)k * sk + (long)h * sh];
+    }
+}
 DEV void step_copy_i32(int* dst, const int32_t* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 DEV void step_copy_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 
@@ -408,12 +539,15 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const TopoView& tv = a.tv;
     const HeadFused& hf = a.hf;
+    EXIT_AFTER(0);
     const int F = a.net.n_feat;
     const int nb = a.net.n_branch;
     const int R = hf.R, H = hf.H, O = hf.O;
-    const int XLD = F + 4;
+    const int F16 = step_pad16(F), XLD = F16 + 4;
+    constexpr int U2LD = HC2 + 4, W2NLD = DRGNN_H2 + 4;
     StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
     WBlockRegs wreg;
+    int* const dummy = (int*)(s.misc + 64);      // 64 words that absorb discarded lanes' LDS stores
     const uint32_t done = (uint32_t)a.step2[0];
     const uint32_t tag = done + 1u;
     const drgnn_conv_params& c1 = a.net.conv1[br];
@@ -434,7 +568,6 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         BurstW<1> bw1, bw2, bs1, bs2;
         BufBurst<1> brp0, bcp0, bmp0, bmem0, brp1, bcp1, bmp1, bmem1, bb1, bb2, bhb1, bhb2;
         BufBurst<2> bcx0, brx0, bcx1, brx1, bts0, bts1, bew0, bew1, bhw2;
-        int* const dummy = (int*)(s.misc + 64);
 #if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
         asm volatile("" :: "s"(d.N), "s"(d.E1));      // per-graph sizes have arrived
         PHASE_MARK();
@@ -488,16 +621,17 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             asm volatile("" :: "v"(bw1.v[0]));
             PHASE_MARK();                                  // conv1 weights here
 #endif
-            burst_store_x4(bx, s.xs);
-            burst_store_w(bw1, s.wn1, DRGNN_W1LD);
-            if (KIND != DRGNN_GINET) burst_store_w(bs1, s.ws1, DRGNN_W1LD);
+            burst_store_x4(bx, s.xs, XLD);
+            burst_store_wt(bw1, s.w1t, XLD);
+            if (KIND != DRGNN_GINET) burst_store_wt(bs1, s.ws1t, XLD);
 #if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
             PHASE_MARK();                                  // LDS stores issued
 #endif
         } else {
             FOR_TID(e, d.N * F) { s.xs[(e / F) * XLD + e % F] = xg[e]; }
-            stage_weight(s.wn1, DRGNN_W1LD, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
-            stage_weight(s.wn2, DRGNN_W2LD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+            step_stage_wt(s.w1t, XLD, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
+            step_stage_wt(s.w2t, STEP_XPLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+            stage_weight(s.w2n, W2NLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
             step_copy_i32(s.rp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
             step_copy_i32(s.cx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
             step_copy_i32(s.cp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
@@ -517,8 +651,9 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             step_copy_f32(s.hw2, hf.w2, O * H);
             step_copy_f32(s.hb2, hf.b2, O);
             if (KIND != DRGNN_GINET) {
-                stage_weight(s.ws1, DRGNN_W1LD, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
-                stage_weight(s.ws2, DRGNN_W2LD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+                step_stage_wt(s.ws1t, XLD, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
+                step_stage_wt(s.ws2t, STEP_XPLD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+                stage_weight(s.ws2n, W2NLD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
                 step_copy_f32(s.b1, c1.bias, DRGNN_H1);
                 step_copy_f32(s.b2, c2.bias, DRGNN_H2);
             }
@@ -529,15 +664,26 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
                 step_copy_i32(s.ts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
             }
         }
+        // zero padding the predicate-free products rely on: x rows [N, pad4(N)), and (F % 16 != 0) the
+        // k columns [F, F16) of the x tile and of the transposed conv1 weights
+        FOR_TID(e, (step_pad4(d.N) - d.N) * XLD) { s.xs[d.N * XLD + e] = 0.0f; }
+        if (F16 > F) {
+            const int padc = F16 - F;
+            FOR_TID(e, d.N * padc) { s.xs[(e / padc) * XLD + F + e % padc] = 0.0f; }
+            FOR_TID(e, DRGNN_H1 * padc) {
+                s.w1t[(e / padc) * XLD + F + e % padc] = 0.0f;
+                if (KIND != DRGNN_GINET) s.ws1t[(e / padc) * XLD + F + e % padc] = 0.0f;
+            }
+        }
         BARRIER();
         EXIT_AFTER(1);
 
         // ---- forward ------------------------------------------------------------------
-        PH(1) wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.wn1, DRGNN_W1LD, 1, s.u1, HC1, 1);
-        if (KIND != DRGNN_GINET)
-            wg_gemm(d.N, DRGNN_H1, F, s.xs, XLD, 1, s.ws1, DRGNN_W1LD, 1, s.u1 + DRGNN_H1, HC1, 1);
+        PH(1) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t, XLD, s.u1, HC1, dummy);
+        if (KIND != DRGNN_GINET) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.ws1t, XLD, s.u1 + DRGNN_H1, HC1, dummy);
         if (burst) {
-            burst_store_w(bw2, s.wn2, DRGNN_W2LD);
+            burst_store_wt(bw2, s.w2t, STEP_XPLD);
+            burst_store_w(bw2, s.w2n, W2NLD);
             bufburst_store(brp0, s.rp0, dummy); bufburst_store(bcx0, s.cx0, dummy);
             bufburst_store(bcp0, s.cp0, dummy); bufburst_store(brx0, s.rx0, dummy);
             bufburst_store(bmp0, s.mp0, dummy); bufburst_store(bmem0, s.mem0, dummy);
@@ -547,7 +693,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             step_wblock_store(wreg, hf, br, s.wb);
             bufburst_store(bhb1, s.hb1, dummy); bufburst_store(bhw2, s.hw2, dummy); bufburst_store(bhb2, s.hb2, dummy);
             if (KIND != DRGNN_GINET) {
-                burst_store_w(bs2, s.ws2, DRGNN_W2LD);
+                burst_store_wt(bs2, s.ws2t, STEP_XPLD);
+                burst_store_w(bs2, s.ws2n, W2NLD);
                 bufburst_store(bb1, s.b1, dummy); bufburst_store(bb2, s.b2, dummy);
             }
             if (KIND == DRGNN_SGAT) {
@@ -555,6 +702,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
                 bufburst_store(bts0, s.ts0, dummy); bufburst_store(bts1, s.ts1, dummy);
             }
         }
+        FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
         // per-graph scalars of the readout / loss phases (their global latency hides in the burst)
         FOR_TID(i, 1) {
             const int bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g] | tv.p[DRGNN_TI_GSTAT][a.n_graphs + g];
@@ -594,16 +742,19 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         PH(2) net_aggregate<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
         BARRIER();
         EXIT_AFTER(3);
-        PH(3) net_cluster_max<DRGNN_H1>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
+        PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
         BARRIER();
         EXIT_AFTER(4);
-        PH(4) wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.wn2, DRGNN_W2LD, 1, s.u2, HC2, 1);
+        PH(4) step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.w2t, STEP_XPLD, s.u2, U2LD, dummy);
         if (KIND != DRGNN_GINET)
-            wg_gemm(d.C, DRGNN_H2, DRGNN_H1, s.xp, DRGNN_H1, 1, s.ws2, DRGNN_W2LD, 1, s.u2 + DRGNN_H2, HC2, 1);
+            step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.ws2t, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, dummy);
         FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }      // Z1 is consumed: becomes dZ1
+        // node rows [n, pad4(n)) of the backward products' K operands: zero (never written otherwise)
+        FOR_TID(e, (step_pad4(d.N) - d.N) * HC1) { s.u1[d.N * HC1 + e] = 0.0f; }
+        FOR_TID(e, (step_pad4(d.C) - d.C) * U2LD) { s.u2[d.C * U2LD + e] = 0.0f; }
         BARRIER();
         EXIT_AFTER(5);
-        PH(5) net_aggregate<KIND, DRGNN_H2, true>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+        PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
         BARRIER();
         EXIT_AFTER(6);
         PH(6) net_cluster_max<DRGNN_H2>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
@@ -655,7 +806,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     float* p_w2n = p_b1 + DRGNN_H1;
     float* p_w2s = p_w2n + DRGNN_H1 * DRGNN_H2;
     float* p_b2 = p_w2s + DRGNN_H1 * DRGNN_H2;
-    PH(11) net_aggregate_bwd<KIND, DRGNN_H2, true>(d.C, s.rp1, s.cp1, s.rx1, s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
+    PH(11) net_aggregate_bwd<KIND, DRGNN_H2, true, U2LD>(d.C, s.rp1, s.cp1, s.rx1, s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
     if (KIND != DRGNN_GINET) {
         FOR_TID(c, DRGNN_H2) {
             float acc = 0.0f;
@@ -665,12 +816,15 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     }
     BARRIER();
     EXIT_AFTER(12);
-    PH(12) wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2, HC2, 1, p_w2n, DRGNN_H2, 1);
+    // dXP = dU2n W2n^T (+ dU2s W2s^T);  dW2 = XP^T dU2 (K = pooled nodes, split over the waves)
+    PH(13) step_gemm_nn(d.C, 1, DRGNN_H2, s.u2, U2LD, s.w2n, W2NLD, s.dxp, DRGNN_H1, dummy);
     if (KIND != DRGNN_GINET)
-        wg_gemm(DRGNN_H1, DRGNN_H2, d.C, s.xp, 1, DRGNN_H1, s.u2 + DRGNN_H2, HC2, 1, p_w2s, DRGNN_H2, 1);
-    PH(13) wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2, HC2, 1, s.wn2, 1, DRGNN_W2LD, s.dxp, DRGNN_H1, 1);
-    if (KIND != DRGNN_GINET)
-        wg_gemm(d.C, DRGNN_H1, DRGNN_H2, s.u2 + DRGNN_H2, HC2, 1, s.ws2, 1, DRGNN_W2LD, s.p2, DRGNN_H1, 1);
+        step_gemm_nn(d.C, 1, DRGNN_H2, s.u2 + DRGNN_H2, U2LD, s.ws2n, W2NLD, s.p2, DRGNN_H1, dummy);
+    PH(12) step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2, U2LD, DRGNN_NWAVES / 2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
+    if (KIND != DRGNN_GINET) {
+        BARRIER();
+        step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, DRGNN_NWAVES / 2, s.gp, p_w2s, DRGNN_H2, DRGNN_H1);
+    }
     BARRIER();
     EXIT_AFTER(13);
     PH(14) FOR_TID(item, d.C * DRGNN_H1) {
@@ -694,15 +848,14 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     }
     BARRIER();
     EXIT_AFTER(15);
-    {
-        const int mtiles = (F + 15) >> 4;
-        int KS = imin(DRGNN_NWAVES / mtiles, 2048 / (F * DRGNN_H1));
+    {   // dW1 = X^T dU1: K = nodes of the graph, split in slices over the waves
+        const int mtiles = F16 >> 4;
+        int KS = imin(DRGNN_NWAVES / mtiles, STEP_GP_WORDS / (mtiles * 256));
         if (KS < 1) KS = 1;
-        PH(16) wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, XLD, s.u1, HC1, 1, p_w1n, DRGNN_H1, 1, KS, s.gp);
+        PH(16) step_gemm_tn(mtiles, 1, d.N, s.xs, XLD, s.u1, HC1, KS, s.gp, p_w1n, DRGNN_H1, F);
         if (KIND != DRGNN_GINET) {
             BARRIER();
-            EXIT_AFTER(16);
-            wg_gemm(F, DRGNN_H1, d.N, s.xs, 1, XLD, s.u1 + DRGNN_H1, HC1, 1, p_w1s, DRGNN_H1, 1, KS, s.gp);
+            step_gemm_tn(mtiles, 1, d.N, s.xs, XLD, s.u1 + DRGNN_H1, HC1, KS, s.gp, p_w1s, DRGNN_H1, F);
         }
     }
 }
