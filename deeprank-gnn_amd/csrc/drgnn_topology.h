@@ -102,6 +102,7 @@ struct TopoScratch {
     int* t5;
     int* fl;         // [capF]
     int capF;
+    int capT;        // ints in each of t1..t5
 };
 
 #define TOPO_PAD4(n) (((n) + 3) & ~3LL)
@@ -148,6 +149,7 @@ DEV TopoScratch topo_carve(IntPtr base, int capN, int capE, int capT, int capF) 
     s.t5 = base + o;   o += (int)TOPO_PAD4(capT);
     s.fl = base + o;   o += (int)TOPO_PAD4(capF);
     s.capF = capF;
+    s.capT = capT;
     return s;
 }
 
@@ -471,8 +473,56 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
     }
 
-    // ---- pool_edge: bucket the CSR0 slots by the pooled row of their source node (stable:
-    // slot order = (member, edge) order), then rank every bucket by (target cluster, slot) ------
+    // ---- pool_edge --------------------------------------------------------------------------
+    // Without edge weights the pooled graph is just the SET of (cluster(row), cluster(col)) pairs of
+    // the edges minus self loops: every pooled row keeps a bitmap of its target clusters (LDS atomic
+    // OR, order independent), the sorted unique targets are its set bits in ascending order.  No
+    // sorting at all; used whenever the C x ceil(C/32) words fit the sort scratch.
+    const int BW = (C + 31) >> 5;
+    const bool bitmap = !has_w && (long)C * BW + 1 <= (long)s.capT;
+    int E1;
+    int32_t* g_rowptr1 = tv.p[DRGNN_TI_ROWPTR1] + rowbase;
+    int32_t* g_col1 = tv.p[DRGNN_TI_COL1] + e0;
+    if (bitmap) {
+        int* bm = s.t1;          // [C][BW] target bitmaps
+        int* pre = s.t2;         // [C*BW + 1] set bits before each word
+        FOR_TID(q, C * BW) { bm[q] = 0; }
+        FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-1 cluster ranks
+        FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+        BARRIER();
+        FOR_TID(k, E) {
+            const int r = s.cl[s.seg[k]], cc = s.cl[s.col[k]];
+            if (cc != r) ATOMIC_OR(&bm[r * BW + (cc >> 5)], (int)(1u << (cc & 31)));
+        }
+        BARRIER();
+        FOR_TID(q, C * BW + 1) { pre[q] = (q < C * BW) ? __builtin_popcount((unsigned)bm[q]) : 0; }
+        BARRIER();
+        E1 = wg_exscan(pre, C * BW + 1, s.part);
+        FOR_TID(q, C * BW) {
+            unsigned bits = (unsigned)bm[q];
+            const int r = q / BW, base_col = (q - r * BW) << 5;
+            int slot = pre[q];
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                s.col1[slot] = base_col + b;
+                s.seg[slot] = r;               // row of pooled CSR slot (s.seg is free again)
+                g_col1[slot] = base_col + b;
+                ++slot;
+            }
+        }
+        FOR_TID(r, C + 1) {
+            const int v = pre[r * BW];
+            s.rp1[r] = v;
+            g_rowptr1[r] = v;
+            s.cp[r] = 0;                                          // histogram / cursors of the CSC1 build
+            s.cur[r] = 0;
+        }
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
+        BARRIER();
+    } else {
+    // weighted (or very large) graphs: bucket the CSR0 slots by the pooled row of their source node
+    // (stable: slot order = (member, edge) order), then rank every bucket by (target cluster, slot)
     FOR_TID(r, C + 1) { s.pp[r] = 0; s.cur[r] = 0; }
     FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-1 cluster ranks
     FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
@@ -513,9 +563,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         s.t1[j] = head;
     }
     BARRIER();
-    const int E1 = wg_exscan(s.t1, E + 1, s.part);
-    int32_t* g_rowptr1 = tv.p[DRGNN_TI_ROWPTR1] + rowbase;
-    int32_t* g_col1 = tv.p[DRGNN_TI_COL1] + e0;
+    E1 = wg_exscan(s.t1, E + 1, s.part);
     FOR_TID(j, E) {
         const int key = s.t4[j];
         const int r = s.t3[j];
@@ -541,6 +589,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     }
     FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
     BARRIER();
+    }
 
     // ---- CSC1 ----------------------------------------------------------------------
     wg_csc_build(C, E1, s.col1, s.seg, s, tv.p[DRGNN_TI_COLPTR1] + rowbase,

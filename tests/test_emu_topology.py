@@ -42,13 +42,14 @@ def random_graph(rng, n, e, n_c0, n_c1, sym=True, self_loops=False, dup=False):
 @pytest.mark.parametrize("make", [lambda: fixture_batch(8), lambda: fixture_batch(10), syn4_batch,
                                   lambda: synth.make_batch(0, 3)])
 @pytest.mark.parametrize("derive", [False, True])
-def test_topology_matches_oracle(make, derive):
+@pytest.mark.parametrize("weights", [True, False])      # False: pooled graph through the bitmap path
+def test_topology_matches_oracle(make, derive, weights):
     batch = make()
     if derive:
         strip_layout(batch)
-    topo = Topology.from_batch(batch, api=emu())
+    topo = Topology.from_batch(batch, api=emu(), need_weights=weights)
     assert topo.status()[0] == 0
-    check_against_oracle(topo, batch)
+    check_against_oracle(topo, batch, weights=weights)
 
 
 @pytest.mark.parametrize("seed", range(6))
@@ -64,9 +65,10 @@ def test_topology_random_ragged(seed):
     batch = Batch.from_data_list(graphs)
     if seed % 2:
         strip_layout(batch)
-    topo = Topology.from_batch(batch, api=emu())
-    assert topo.status()[0] == 0
-    check_against_oracle(topo, batch)
+    for weights in (True, False):
+        topo = Topology.from_batch(batch, api=emu(), need_weights=weights)
+        assert topo.status()[0] == 0
+        check_against_oracle(topo, batch, weights=weights)
 
 
 def test_topology_global_scratch_path():

@@ -60,9 +60,10 @@ def test_topology_vs_oracle(which):
         for k in ("_node_ptr", "_edge_ptr", "_c1_ptr", "_max_nodes", "_max_edges", "_max_c0"):
             batch.__dict__.pop(k, None)
     gb = batch.clone().to(dev())
-    topo = Topology.from_batch(gb)
-    assert topo.status()[0] == 0
-    check_against_oracle(topo, batch)
+    for weights in (True, False):        # False: pooled graph through the bitmap path
+        topo = Topology.from_batch(gb, need_weights=weights)
+        assert topo.status()[0] == 0
+        check_against_oracle(topo, batch, weights=weights)
 
 
 def test_topology_random_ragged_and_global_scratch():
@@ -81,9 +82,10 @@ def test_topology_random_ragged_and_global_scratch():
         if seed == 3:
             batch.__dict__["_max_nodes"] = 100000      # LDS estimate too large -> global scratch
             batch.__dict__["_max_edges"] = 100000
-        topo = Topology.from_batch(batch.clone().to(dev()))
-        assert topo.status()[0] == 0
-        check_against_oracle(topo, batch)
+        for weights in (True, False):
+            topo = Topology.from_batch(batch.clone().to(dev()), need_weights=weights)
+            assert topo.status()[0] == 0
+            check_against_oracle(topo, batch, weights=weights)
 
 
 def test_topology_flags_bad_input():

@@ -16,13 +16,15 @@ def expand(topo):
     return a
 
 
-def check_against_oracle(topo, batch, level1=True):
+def check_against_oracle(topo, batch, level1=True, weights=True):
     a = expand(topo)
     B = topo.n_graphs
     nptr, eptr = a["NPTR"], a["EPTR"]
     ei = batch.edge_index.cpu()
     bvec = batch.batch.cpu()
     ea = None if getattr(batch, "edge_attr", None) is None else batch.edge_attr.cpu().reshape(-1)
+    if not weights or topo.ws_f32 is None:      # structure-only build: no W0 / W1 to compare
+        ea = None
     # offsets
     counts = torch.bincount(bvec, minlength=B).numpy() if bvec.numel() else np.zeros(B, int)
     np.testing.assert_array_equal(nptr[:B + 1], np.concatenate([[0], np.cumsum(counts)]))
