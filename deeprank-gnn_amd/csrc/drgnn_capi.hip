@@ -275,7 +275,7 @@ struct StepCoLaunch {
     int n_net;
 };
 
-template <int KIND>
+template <int KIND, int XF>
 DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
     const int nb = L.a.net.n_branch;
     const int g = blk / nb, br = blk % nb;
@@ -295,7 +295,7 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
         }
         return;
     }
-    net_step_graph<KIND>(L.a, d, g, br, lds, L.capN, L.capE, L.capC, part);
+    net_step_graph<KIND, XF>(L.a, d, g, br, lds, L.capN, L.capE, L.capC, part);
 }
 
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
@@ -391,11 +391,11 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net_co_topo(CoLaunch C) {
     if ((int)blockIdx.x < C.n_net) net_block<KIND, BWD, true>(C.net, blockIdx.x, smem_c);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_c);
 }
-template <int KIND>
+template <int KIND, int XF>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C) {
     extern __shared__ __attribute__((aligned(16))) float smem_s[];
     PHASE_BEGIN();
-    if ((int)blockIdx.x < C.n_net) step_block<KIND>(C.step, blockIdx.x, smem_s, 0);
+    if ((int)blockIdx.x < C.n_net) step_block<KIND, XF>(C.step, blockIdx.x, smem_s, 0);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);
 }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
@@ -973,9 +973,9 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
         for (int pass = 1; pass <= 2; ++pass)
             for (int b = 0; b < blocks; ++b) {
                 float* lds_b = slabs.data() + (size_t)b * (size_t)(L.words + 16);
-                if (kind == DRGNN_GINET) step_block<DRGNN_GINET>(L, b, lds_b, pass);
-                else if (kind == DRGNN_SGAT) step_block<DRGNN_SGAT>(L, b, lds_b, pass);
-                else step_block<DRGNN_FOUT>(L, b, lds_b, pass);
+                if (kind == DRGNN_GINET) step_block<DRGNN_GINET, 0>(L, b, lds_b, pass);
+                else if (kind == DRGNN_SGAT) step_block<DRGNN_SGAT, 0>(L, b, lds_b, pass);
+                else step_block<DRGNN_FOUT, 0>(L, b, lds_b, pass);
             }
         if (co_ok) {
             std::vector<int> tbuf((size_t)(tlds / 4) + 16);
@@ -989,17 +989,29 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
         int64_t both = lds;
         int extra = 0;
         if (co_ok) { C.topo = T; both = lds > tlds ? lds : tlds; extra = T.args.n_graphs * T.roles; }
-#define DRGNN_STEP_LAUNCH(K)                                                                                \
+#define DRGNN_STEP_LAUNCH(K, XF)                                                                            \
     do {                                                                                                    \
         if (both > 64 * 1024)                                                                               \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_step_co_topo<K>,                                     \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_step_co_topo<K, XF>,                                 \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));            \
-        hipLaunchKernelGGL((k_step_co_topo<K>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),    \
+        hipLaunchKernelGGL((k_step_co_topo<K, XF>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
                            (size_t)both, stream, C);                                                        \
     } while (0)
-        if (kind == DRGNN_GINET) DRGNN_STEP_LAUNCH(DRGNN_GINET);
-        else if (kind == DRGNN_SGAT) DRGNN_STEP_LAUNCH(DRGNN_SGAT);
-        else DRGNN_STEP_LAUNCH(DRGNN_FOUT);
+        // instantiated feature widths: F16 in {16, 32, 48, 64}; anything else runs the generic kernel
+#define DRGNN_STEP_WIDTHS(K)                                                                                \
+    do {                                                                                                    \
+        switch (step_pad16(F)) {                                                                            \
+            case 16: DRGNN_STEP_LAUNCH(K, 16); break;                                                       \
+            case 32: DRGNN_STEP_LAUNCH(K, 32); break;                                                       \
+            case 48: DRGNN_STEP_LAUNCH(K, 48); break;                                                       \
+            case 64: DRGNN_STEP_LAUNCH(K, 64); break;                                                       \
+            default: DRGNN_STEP_LAUNCH(K, 0); break;                                                        \
+        }                                                                                                   \
+    } while (0)
+        if (kind == DRGNN_GINET) DRGNN_STEP_WIDTHS(DRGNN_GINET);
+        else if (kind == DRGNN_SGAT) DRGNN_STEP_WIDTHS(DRGNN_SGAT);
+        else DRGNN_STEP_WIDTHS(DRGNN_FOUT);
+#undef DRGNN_STEP_WIDTHS
 #undef DRGNN_STEP_LAUNCH
         HIP_TRY(hipGetLastError());
 #endif

@@ -131,6 +131,11 @@ HD int64_t step_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, i
     return w + 16;
 }
 
+#ifdef DRGNN_EMU
+#define STEP_PIN(x) ((void)0)
+#else
+#define STEP_PIN(x) asm volatile("" : "+v"(x))
+#endif
 DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int capC, int R, int H, int O) {
     const int hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
     const int hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
@@ -138,11 +143,16 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
     const int gin = (kind == DRGNN_GINET) ? 1 : 0;
     const int xld = step_pad16(F) + 4;
     StepScratch s;
-    float* p = base;
-#define X(name, words, cond) s.name = (decltype(s.name))p; p += (cond) ? (((long)(words) + 3) & ~3L) : 0;
+    int o = 0;
+    // Every array offset is pinned in a vector register once: there are too many of them for the
+    // scalar file, and otherwise each phase of each wave recomputes its operands' offsets from the
+    // capacities (measured: ~15% of the kernel).
+#define X(name, words, cond)                                                          \
+    { int off = o; STEP_PIN(off); s.name = (decltype(s.name))(base + off); }          \
+    o += (cond) ? (int)(((long)(words) + 3) & ~3L) : 0;
     STEP_CARVE_LIST(X)
 #undef X
-    s.end = p;
+    s.end = base + o;
     return s;
 }
 
@@ -532,7 +542,10 @@ DEV void step_copy_i32(int* dst, const int32_t* src, int n) { FOR_TID(i, n) { ds
 DEV void step_copy_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 
 // `part`: 0 = whole step (device), 1 = up to the readout publication, 2 = from the head on
-template <int KIND>
+// XF: padded feature width F16 as a compile-time constant (16/32/48/64), 0 = taken from the descriptor.
+// The strides of the x tile and of conv1's weights and the K loop of conv1's products hang on it;
+// with it known the kernel is ~8% faster, so the common widths are instantiated.
+template <int KIND, int XF>
 DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, float* scratch, int capN,
                         int capE, int capC, int part) {
     constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
@@ -540,10 +553,19 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     const TopoView& tv = a.tv;
     const HeadFused& hf = a.hf;
     EXIT_AFTER(0);
+#ifdef DRGNN_FIXED_CAPS      // experiments only: SYN sizes as constants
+    capN = 200; capE = 1014; capC = 50;
+#endif
+    // the branch count (hence the readout width) follows from the kind of net
+    constexpr int nb = (KIND == DRGNN_GINET) ? 2 : 1;
+    constexpr int R = DRGNN_H2 * nb;
     const int F = a.net.n_feat;
-    const int nb = a.net.n_branch;
-    const int R = hf.R, H = hf.H, O = hf.O;
-    const int F16 = step_pad16(F), XLD = F16 + 4;
+#ifdef DRGNN_FIXED_HO
+    const int H = 128, O = 1;
+#else
+    const int H = hf.H, O = hf.O;
+#endif
+    const int F16 = XF ? XF : step_pad16(F), XLD = F16 + 4;
     constexpr int U2LD = HC2 + 4, W2NLD = DRGNN_H2 + 4;
     StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
     WBlockRegs wreg;
