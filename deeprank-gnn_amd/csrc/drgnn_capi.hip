@@ -277,8 +277,14 @@ struct StepCoLaunch {
 
 template <int KIND, int XF>
 DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
-    const int nb = L.a.net.n_branch;
-    const int g = blk / nb, br = blk % nb;
+    constexpr int nb = (KIND == DRGNN_GINET) ? 2 : 1;
+    // Workgroups go to the 8 XCDs round robin (block id mod 8) and each XCD has its own L2.  The two
+    // branch workgroups of a graph read the same x tile and the same topology: they are placed 8
+    // block ids apart so that they share an L2 (the second one's misses merge with the first one's).
+    int g, br;
+    if (nb == 2) { g = ((blk >> 4) << 3) + (blk & 7); br = (blk >> 3) & 1; }
+    else { g = blk; br = 0; }
+    if (g >= L.a.n_graphs) return;                // padding of the last group of 8 graphs
     const GraphDims d = net_dims(L.a.tv, g);      // ONE round trip for all per-graph sizes
     if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
         // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
@@ -952,7 +958,8 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
     hf.readout = readout; hf.step = step2; hf.pred = pred; hf.partials = head_partials; hf.stage = 0;
 
-    const int blocks = (int)n_graphs * net->n_branch;
+    // grid of the step part: graphs in groups of 8 x n_branch (see step_block)
+    const int blocks = (net->n_branch == 2) ? (int)((n_graphs + 7) / 8) * 16 : (int)n_graphs;
     TopoLaunch T;
     int64_t tlds = 0;
     bool co_ok = false;

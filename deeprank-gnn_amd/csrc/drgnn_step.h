@@ -31,7 +31,16 @@
 #ifndef DRGNN_EXIT_AFTER
 #define DRGNN_EXIT_AFTER (-1)
 #endif
-#define EXIT_AFTER(k) do { if (DRGNN_EXIT_AFTER == (k)) return; } while (0)
+// (the checksum over the whole scratch keeps every earlier LDS store alive in the truncated kernel)
+#define EXIT_AFTER(k)                                                                          \
+    do {                                                                                       \
+        if (DRGNN_EXIT_AFTER == (k)) {                                                         \
+            float acc_ = 0.0f;                                                                 \
+            if ((k) > 0) { FOR_TID(i_, (int)(s.end - scratch)) { acc_ += scratch[i_]; } }      \
+            if (acc_ == 12345.678f) a.hf.pred[0] = acc_;                                       \
+            return;                                                                            \
+        }                                                                                      \
+    } while (0)
 
 struct StepArgs {
     drgnn_net_desc net;
@@ -552,7 +561,6 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const TopoView& tv = a.tv;
     const HeadFused& hf = a.hf;
-    EXIT_AFTER(0);
 #ifdef DRGNN_FIXED_CAPS      // experiments only: SYN sizes as constants
     capN = 200; capE = 1014; capC = 50;
 #endif
@@ -568,6 +576,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     const int F16 = XF ? XF : step_pad16(F), XLD = F16 + 4;
     constexpr int U2LD = HC2 + 4, W2NLD = DRGNN_H2 + 4;
     StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
+    EXIT_AFTER(0);
     WBlockRegs wreg;
     int* const dummy = (int*)(s.misc + 64);      // 64 words that absorb discarded lanes' LDS stores
     const uint32_t done = (uint32_t)a.step2[0];
@@ -604,6 +613,32 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
                          "s"(P[DRGNN_TI_ROWIDX1]), "s"(P[DRGNN_TI_MPTR1]), "s"(P[DRGNN_TI_MEM1]));
         }
 #endif
+        // per-graph scalars of the readout / loss phases: requested here so that their latency hides in
+        // the burst (every lane asks for the same words; lane 0 files them in LDS after conv1's product)
+        int m_bad, m_y;
+        float m_wy = 1.0f, m_denom = 1.0f;
+        {
+            m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g] | tv.p[DRGNN_TI_GSTAT][a.n_graphs + g];
+            if (hf.task == DRGNN_TASK_REG) {
+                const float y = hf.y_reg[g];
+                memcpy(&m_y, &y, 4);
+            } else {
+                m_y = (int)hf.y_cls[g];
+                m_wy = hf.class_w ? hf.class_w[m_y] : 1.0f;
+                // CrossEntropyLoss(weight): mean over the sum of the targets' weights
+#ifdef DRGNN_EMU
+                m_denom = 0.0f;
+                for (int q = 0; q < hf.B; ++q) m_denom += hf.class_w ? hf.class_w[hf.y_cls[q]] : 1.0f;
+#else
+                m_denom = (float)hf.B;
+                if (hf.class_w && threadIdx.x < 64) {
+                    float part_sum = 0.0f;
+                    for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w[hf.y_cls[q]];
+                    m_denom = lanes64_sum(part_sum);
+                }
+#endif
+            }
+        }
         if (burst) {
             burst_load_x(bx, xg, (DRGNN_SKIP == 20) ? 0 : d.N, F);
             burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
@@ -704,15 +739,17 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         PH(1) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t, XLD, s.u1, HC1, dummy);
         if (KIND != DRGNN_GINET) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.ws1t, XLD, s.u1 + DRGNN_H1, HC1, dummy);
         if (burst) {
-            burst_store_wt(bw2, s.w2t, STEP_XPLD);
-            burst_store_w(bw2, s.w2n, W2NLD);
+            PH(41) { burst_store_wt(bw2, s.w2t, STEP_XPLD);
+            burst_store_w(bw2, s.w2n, W2NLD); }
+            PH(42) {
             bufburst_store(brp0, s.rp0, dummy); bufburst_store(bcx0, s.cx0, dummy);
             bufburst_store(bcp0, s.cp0, dummy); bufburst_store(brx0, s.rx0, dummy);
             bufburst_store(bmp0, s.mp0, dummy); bufburst_store(bmem0, s.mem0, dummy);
             bufburst_store(brp1, s.rp1, dummy); bufburst_store(bcx1, s.cx1, dummy);
             bufburst_store(bcp1, s.cp1, dummy); bufburst_store(brx1, s.rx1, dummy);
             bufburst_store(bmp1, s.mp1, dummy); bufburst_store(bmem1, s.mem1, dummy);
-            step_wblock_store(wreg, hf, br, s.wb);
+            }
+            PH(43) step_wblock_store(wreg, hf, br, s.wb);
             bufburst_store(bhb1, s.hb1, dummy); bufburst_store(bhw2, s.hw2, dummy); bufburst_store(bhb2, s.hb2, dummy);
             if (KIND != DRGNN_GINET) {
                 burst_store_wt(bs2, s.ws2t, STEP_XPLD);
@@ -725,34 +762,12 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             }
         }
         FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
-        // per-graph scalars of the readout / loss phases (their global latency hides in the burst)
+        // per-graph scalars of the readout / loss phases (fetched with the burst, see above)
         FOR_TID(i, 1) {
-            const int bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g] | tv.p[DRGNN_TI_GSTAT][a.n_graphs + g];
-            memcpy(&s.misc[STEP_M_BAD], &bad, 4);
-            if (hf.task == DRGNN_TASK_REG) {
-                s.misc[STEP_M_Y] = hf.y_reg[g];
-                s.misc[STEP_M_WY] = 1.0f;
-            } else {
-                const int yc = (int)hf.y_cls[g];
-                memcpy(&s.misc[STEP_M_Y], &yc, 4);
-                s.misc[STEP_M_WY] = hf.class_w ? hf.class_w[yc] : 1.0f;
-            }
-        }
-        if (hf.task == DRGNN_TASK_CLASS) {      // CrossEntropyLoss(weight): mean over sum of target weights
-#ifdef DRGNN_EMU
-            float denom = 0.0f;
-            for (int q = 0; q < hf.B; ++q) denom += hf.class_w ? hf.class_w[hf.y_cls[q]] : 1.0f;
-            s.misc[STEP_M_DENOM] = denom;
-#else
-            if (threadIdx.x < 64) {
-                float part_sum = 0.0f;
-                for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w ? hf.class_w[hf.y_cls[q]] : 1.0f;
-                part_sum = lanes64_sum(part_sum);
-                if (threadIdx.x == 0) s.misc[STEP_M_DENOM] = part_sum;
-            }
-#endif
-        } else {
-            FOR_TID(i, 1) { s.misc[STEP_M_DENOM] = 1.0f; }
+            memcpy(&s.misc[STEP_M_BAD], &m_bad, 4);
+            memcpy(&s.misc[STEP_M_Y], &m_y, 4);
+            s.misc[STEP_M_WY] = m_wy;
+            s.misc[STEP_M_DENOM] = m_denom;
         }
         BARRIER();
         EXIT_AFTER(2);
