@@ -246,6 +246,14 @@ struct AdamArgs {
 
 // torch.optim.Adam (no amsgrad, maximize=False): identical operation order to the reference
 // implementation (_single_tensor_adam): denom = sqrt(v)/sqrt(bc2) + eps; p -= (lr/bc1) * m/denom
+DEV double adam_ipow(double b, int t) {
+    double r = 1.0;
+    for (unsigned e = (unsigned)(t > 0 ? t : 0); e; e >>= 1) {
+        if (e & 1u) r *= b;
+        b *= b;
+    }
+    return r;
+}
 DEV void adam_item(const AdamArgs& a, int64_t i) {
     if (i >= a.n) return;
     const float t = (float)a.step[0];
@@ -256,9 +264,10 @@ DEV void adam_item(const AdamArgs& a, int64_t i) {
     const float v = a.beta2 * a.exp_avg_sq[i] + (1.0f - a.beta2) * g * g;
     a.exp_avg[i] = m;
     a.exp_avg_sq[i] = v;
-    // bias corrections in double, as the Python-side scalars of torch's reference path
-    const double bc1 = 1.0 - pow((double)a.beta1, (double)t);
-    const double bc2 = 1.0 - pow((double)a.beta2, (double)t);
+    // bias corrections in double, as the Python-side scalars of torch's reference path; beta^t by
+    // repeated squaring (t is an integer): a libm pow() in double costs more than the rest of the launch
+    const double bc1 = 1.0 - adam_ipow((double)a.beta1, a.step[0]);
+    const double bc2 = 1.0 - adam_ipow((double)a.beta2, a.step[0]);
     const float step_size = (float)((double)a.lr / bc1);
     const float denom = sqrtf(v) / (float)sqrt(bc2) + a.eps;
     a.param[i] = p - step_size * (m / denom);

@@ -57,4 +57,6 @@ def on_current(fn):
 t_step = timed(graph_of(on_current(lambda: tr._fused_launch_step(c, None))))
 t_co = timed(graph_of(on_current(lambda: tr._fused_launch_step(c, nxt))))
 t_upd = timed(graph_of(on_current(lambda: tr._fused_launch_update(c, True, lr=0.0))))
-print("graph %6s  step %.2f us   step+topo %.2f us   update %.2f us" % (tag, t_step, t_co, t_upd), flush=True)
+t_red = timed(graph_of(on_current(lambda: tr._fused_launch_update(c, False))))
+print("graph %6s  step %.2f us   step+topo %.2f us   update %.2f us   update w/o Adam %.2f us"
+      % (tag, t_step, t_co, t_upd, t_red), flush=True)
