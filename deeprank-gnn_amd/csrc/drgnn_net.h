@@ -534,9 +534,9 @@ DEV void net_aggregate(int n, const int* rp, const int* col, const float* w, con
 // cluster max with argmax (first maximum in ascending member order; NaN never wins;
 // empty cluster -> 0).  arg = -1 where no gradient can flow (value <= 0 or empty).
 // LDO: row stride of `out` in floats (0: dense rows of H)
-template <int H, int LDO = 0>
+template <int H, int LDO = 0, class ArgT = int32_t>
 DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, float* out,
-                         float* g_out, int32_t* g_arg) {
+                         float* g_out, ArgT* g_arg) {
     FOR_TID(item, nc * H) {
         const int r = item / H, c = item % H;
         float best = DRGNN_NEG_INF;
@@ -550,7 +550,7 @@ DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, 
         if (arg < 0) best = 0.0f;
         out[LDO ? r * LDO + c : item] = best;
         if (g_out) g_out[item] = best;
-        g_arg[item] = (best > 0.0f) ? arg : -1;
+        g_arg[item] = (ArgT)((best > 0.0f) ? arg : -1);
     }
 }
 

@@ -68,7 +68,7 @@ struct StepScratch {
     float* xs; float* w1t; float* ws1t; float* b1; float* w2t; float* w2n; float* ws2t; float* ws2n; float* b2;
     int* rp0; int* cx0; float* ew0; int* cp0; int* rx0; int* ts0; int* mp0; int* mem0;
     int* rp1; int* cx1; float* ew1; int* cp1; int* rx1; int* ts1; int* mp1; int* mem1;
-    int* a0; int* a1;
+    short* a0; short* a1;        // argmax node ids as 16-bit (a graph in LDS has < 32768 nodes)
     float* u1; float* z1; float* dv0; float* sc0;
     float* xp; float* dxp; float* u2; float* z2; float* p2; float* dv1; float* sc1;
     float* gp; float* misc;
@@ -103,8 +103,8 @@ struct StepScratch {
     X(ts1, capE, sg)                                                                           \
     X(mp1, capC + 1, 1)                                                                        \
     X(mem1, capC, 1)                                                                           \
-    X(a0, (long)capC * DRGNN_H1, 1)                                                            \
-    X(a1, (long)capC * DRGNN_H2, 1)                                                            \
+    X(a0, ((long)capC * DRGNN_H1 + 1) / 2, 1)                                                    \
+    X(a1, ((long)capC * DRGNN_H2 + 1) / 2, 1)                                                    \
     X(u1, (long)(capN + 4) * hc1, 1)                                                           \
     X(z1, (long)capN * DRGNN_H1, 1)                                                            \
     X(dv0, capN, !gin)                                                                         \
@@ -116,12 +116,11 @@ struct StepScratch {
     X(p2, (long)capC * DRGNN_H2, 1)                                                            \
     X(dv1, capC, !gin)                                                                         \
     X(sc1, capC, !gin)                                                                         \
-    X(gp, STEP_GP_WORDS, 1)                                                                    \
     X(misc, 128, 1)                                                                            \
     X(xr, R, 1)                                                                                \
     X(hid, H, 1)                                                                               \
     X(dhid, H, 1)                                                                              \
-    X(wb, (long)H * STEP_WBLD, 1)                                                              \
+    X(wb, ((long)H * STEP_WBLD > STEP_GP_WORDS ? (long)H * STEP_WBLD : STEP_GP_WORDS), 1)          \
     X(hb1, H, 1)                                                                               \
     X(hw2, (long)O * H, 1)                                                                     \
     X(hb2, O, 1)
@@ -162,6 +161,9 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
     STEP_CARVE_LIST(X)
 #undef X
     s.end = base + o;
+    // fc1's column block is dead after the head's backward; the K-split products that follow (dW2, dW1)
+    // keep their partial tiles there
+    s.gp = s.wb;
     return s;
 }
 
@@ -513,7 +515,7 @@ DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, co
 
 // d readout (this branch's 32 columns) = dhid wb, scattered straight into dZ2 through the depth-1
 // argmax (mean over the C1 clusters -> factor inv)
-DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* dhid, const int* a1, int C1,
+DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* dhid, const short* a1, int C1,
                             float* z2) {
     const int H = hf.H;
     const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
@@ -779,7 +781,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         PH(2) net_aggregate<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
         BARRIER();
         EXIT_AFTER(3);
-        PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
+        PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
         BARRIER();
         EXIT_AFTER(4);
         PH(4) step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.w2t, STEP_XPLD, s.u2, U2LD, dummy);
@@ -794,7 +796,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
         BARRIER();
         EXIT_AFTER(6);
-        PH(6) net_cluster_max<DRGNN_H2>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
+        PH(6) net_cluster_max<DRGNN_H2, 0, short>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
         BARRIER();
         EXIT_AFTER(7);
         // graph readout: mean over the depth-1 clusters (this branch's 32 columns)
