@@ -58,6 +58,8 @@ def parse():
     ap.add_argument("--force-dp-path", action="store_true",
                     help="run the data-parallel code path (gradient graph, eager all-reduce, Adam graph) even "
                          "with one process -- for testing on a single GPU")
+    ap.add_argument("--steps-per-replay", type=int, default=20,
+                    help="training steps captured per hipGraph replay (pipelined native mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -203,10 +205,14 @@ def main():
                 update_part()
 
             if two_flavours:
-                def pair():
-                    whole_step()
-                    whole_step()
-                g_pair = graph_of(pair)                         # parity 0 -> 0
+                # one replay = CHUNK steps (an even number: the workspace parity returns to 0); the
+                # remainder of any --steps / --warmup runs through single-step graphs of either parity
+                CHUNK = 2 * max(1, args.steps_per_replay // 2)
+
+                def chunk():
+                    for _ in range(CHUNK):
+                        whole_step()
+                g_chunk = graph_of(chunk)                       # parity 0 -> 0
                 g_one = [graph_of(whole_step), graph_of(whole_step)]   # parity 0 -> 1, then 1 -> 0
                 state["k"] = 0
 
@@ -215,11 +221,13 @@ def main():
                         g_one[1].replay()
                         state["k"] = 0
                         n -= 1
-                    for _ in range(n // 2):
-                        g_pair.replay()
-                    if n % 2:
-                        g_one[0].replay()
-                        state["k"] = 1
+                    for _ in range(n // CHUNK):
+                        g_chunk.replay()
+                    n %= CHUNK
+                    while n > 0:
+                        g_one[state["k"]].replay()
+                        state["k"] ^= 1
+                        n -= 1
             else:
                 g_step = graph_of(whole_step)
 
