@@ -534,7 +534,7 @@ DEV void net_aggregate(int n, const int* rp, const int* col, const float* w, con
 // cluster max with argmax (first maximum in ascending member order; NaN never wins;
 // empty cluster -> 0).  arg = -1 where no gradient can flow (value <= 0 or empty).
 // LDO: row stride of `out` in floats (0: dense rows of H)
-template <int H, int LDO = 0, class ArgT = int32_t>
+template <int H, int LDO = 0, class ArgT = int32_t, int LDZ = 0>
 DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, float* out,
                          float* g_out, ArgT* g_arg) {
     FOR_TID(item, nc * H) {
@@ -544,7 +544,7 @@ DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, 
 #pragma unroll 4
         for (int p = mp[r]; p < mp[r + 1]; ++p) {
             const int m = mem[p];
-            const float v = z[(long)m * H + c];
+            const float v = z[m * (LDZ ? LDZ : H) + c];
             if (v > best) { best = v; arg = m; }
         }
         if (arg < 0) best = 0.0f;

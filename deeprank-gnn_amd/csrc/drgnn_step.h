@@ -112,8 +112,8 @@ struct StepScratch {
     X(xp, (long)(capC + 4) * STEP_XPLD, 1)                                                     \
     X(dxp, (long)capC * DRGNN_H1, 1)                                                           \
     X(u2, (long)(capC + 4) * (hc2 + 4), 1)                                                     \
-    X(z2, (long)capC * DRGNN_H2, 1)                                                            \
-    X(p2, (long)capC * DRGNN_H2, 1)                                                            \
+    X(z2, (long)(capC + 4) * (DRGNN_H2 + 4), 1)                                                \
+    X(p2, ((long)capC * DRGNN_H2 > (long)(capC + 4) * STEP_XPLD ? (long)capC * DRGNN_H2 : (long)(capC + 4) * STEP_XPLD), 1) \
     X(dv1, capC, !gin)                                                                         \
     X(sc1, capC, !gin)                                                                         \
     X(misc, 128, 1)                                                                            \
@@ -177,7 +177,9 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
 // Rows past M of a last tile are computed from whatever LDS holds and their stores discarded.
 
 // C[M x 16*NT] (row stride ldc) = A[M x K] * Bt^T,  A rows of stride lda, Bt[n][k] rows of stride ldbt
+// RELU: C = relu(...) with NaN passing through, like torch
 #ifdef DRGNN_EMU
+template <bool RELU = false>
 DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
                       int* dummy) {
     (void)dummy;
@@ -185,10 +187,12 @@ DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float
         for (int j = 0; j < 16 * NT; ++j) {
             float acc = 0.0f;
             for (int k = 0; k < K; ++k) acc = fmaf(A[i * lda + k], Bt[j * ldbt + k], acc);
+            if (RELU) acc = (acc < 0.0f) ? 0.0f : acc;
             C[i * ldc + j] = acc;
         }
 }
 #else
+template <bool RELU = false>
 DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
                       int* dummy) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -215,7 +219,9 @@ DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float
         for (int r = 0; r < 4; ++r) {
             const int ci = ti * 16 + lq * 4 + r;
             float* p = (ci < M) ? C + ci * ldc + tj * 16 + lr : (float*)dummy + lane;
-            *p = acc[r];
+            float v = acc[r];
+            if (RELU) v = (v < 0.0f) ? 0.0f : v;
+            *p = v;
         }
     }
 }
@@ -282,6 +288,47 @@ DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const floa
     }
 }
 #endif
+
+// ---- GINet's second convolution, aggregation first ------------------------------------------------
+// relu(A (XP W2)) = relu((A XP) W2): summing the 16-wide pooled rows BEFORE the dense product halves the
+// bytes the LDS gathers move (64 instead of 128 per edge), forward and backward alike.
+// dst[i][0:16] = sum over CSR row i of src[col][0:16]; rows of LD floats, 4 lanes per row
+template <int LD>
+DEV void step_gather_rows(int n, const int* rp, const int* col, const float* src, float* dst) {
+    FOR_TID(item, n * 4) {
+        const int i = item >> 2, c = (item & 3) * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int lo = rp[i], hi = rp[i + 1];
+#pragma unroll 4
+        for (int k = lo; k < hi; ++k) {
+            float v0, v1, v2, v3;
+            NET_LD4(true, src + col[k] * LD + c, v0, v1, v2, v3);
+            a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+        }
+        NET_ST4(true, dst + i * LD + c, a0, a1, a2, a3);
+    }
+}
+// the transposed sum (CSC: column j gathers the rows of its entries), scattered straight through the
+// depth-0 argmax into dZ1 (row stride 16): the pooling backward needs no pass of its own
+template <int LD>
+DEV void step_gather_scatter(int n, const int* cp, const int* ridx, const float* src, const short* arg, float* dz) {
+    FOR_TID(item, n * 4) {
+        const int j = item >> 2, c = (item & 3) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int lo = cp[j], hi = cp[j + 1];
+#pragma unroll 4
+        for (int t = lo; t < hi; ++t) {
+            float v0, v1, v2, v3;
+            NET_LD4(true, src + ridx[t] * LD + c, v0, v1, v2, v3);
+            acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = arg[j * DRGNN_H1 + c + q];
+            if (m >= 0) dz[m * DRGNN_H1 + c + q] = acc[q];
+        }
+    }
+}
 
 // ---- readout exchange between the branch workgroups of a graph -----------------------------------
 #ifdef DRGNN_EMU
@@ -516,7 +563,7 @@ DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, co
 // d readout (this branch's 32 columns) = dhid wb, scattered straight into dZ2 through the depth-1
 // argmax (mean over the C1 clusters -> factor inv)
 DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* dhid, const short* a1, int C1,
-                            float* z2) {
+                            float* z2, int ldz) {
     const int H = hf.H;
     const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
 #ifdef DRGNN_EMU
@@ -525,7 +572,7 @@ DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* d
         for (int h = 0; h < H; ++h) acc = fmaf(dhid[h], wb[h * STEP_WBLD + c], acc);
         for (int k = 0; k < C1; ++k) {
             const int r = a1[k * DRGNN_H2 + c];
-            if (r >= 0) z2[r * DRGNN_H2 + c] = acc * inv;
+            if (r >= 0) z2[r * ldz + c] = acc * inv;
         }
     }
 #else
@@ -536,7 +583,7 @@ DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* d
         const float v = lanes32_sum(acc) * inv;
         for (int k = q; k < C1; k += 32) {
             const int r = a1[k * DRGNN_H2 + c];
-            if (r >= 0) z2[r * DRGNN_H2 + c] = v;
+            if (r >= 0) z2[r * ldz + c] = v;
         }
     }
 #endif
@@ -577,6 +624,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
 #endif
     const int F16 = XF ? XF : step_pad16(F), XLD = F16 + 4;
     constexpr int U2LD = HC2 + 4, W2NLD = DRGNN_H2 + 4;
+    constexpr bool GIN = (KIND == DRGNN_GINET);
+    constexpr int Z2LD = GIN ? DRGNN_H2 + 4 : DRGNN_H2;      // GINet: Z2 rows feed a dense product (128-bit rows)
     StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
     EXIT_AFTER(0);
     WBlockRegs wreg;
@@ -784,19 +833,27 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
         BARRIER();
         EXIT_AFTER(4);
-        PH(4) step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.w2t, STEP_XPLD, s.u2, U2LD, dummy);
-        if (KIND != DRGNN_GINET)
+        if (GIN) {      // S = A XP (16-wide gather), kept in the u2 area with rows of STEP_XPLD floats
+            PH(4) step_gather_rows<STEP_XPLD>(d.C, s.rp1, s.cx1, s.xp, s.u2);
+            FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.u2[d.C * STEP_XPLD + e] = 0.0f; }
+        } else {
+            PH(4) step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.w2t, STEP_XPLD, s.u2, U2LD, dummy);
             step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.ws2t, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, dummy);
+            FOR_TID(e, (step_pad4(d.C) - d.C) * U2LD) { s.u2[d.C * U2LD + e] = 0.0f; }
+        }
         FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }      // Z1 is consumed: becomes dZ1
         // node rows [n, pad4(n)) of the backward products' K operands: zero (never written otherwise)
         FOR_TID(e, (step_pad4(d.N) - d.N) * HC1) { s.u1[d.N * HC1 + e] = 0.0f; }
-        FOR_TID(e, (step_pad4(d.C) - d.C) * U2LD) { s.u2[d.C * U2LD + e] = 0.0f; }
         BARRIER();
         EXIT_AFTER(5);
-        PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+        if (GIN) {      // Z2 = relu(S W2)
+            PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H1, s.u2, STEP_XPLD, s.w2t, STEP_XPLD, s.z2, Z2LD, dummy);
+        } else {
+            PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+        }
         BARRIER();
         EXIT_AFTER(6);
-        PH(6) net_cluster_max<DRGNN_H2, 0, short>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
+        PH(6) net_cluster_max<DRGNN_H2, 0, short, Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
         BARRIER();
         EXIT_AFTER(7);
         // graph readout: mean over the depth-1 clusters (this branch's 32 columns)
@@ -809,7 +866,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             s.xr[c] = acc;
             const_cast<float*>(hf.readout)[(long)g * R + br * DRGNN_H2 + c] = acc;
         }
-        FOR_TID(item, d.C * DRGNN_H2) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2
+        FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
         BARRIER();
         EXIT_AFTER(8);
     }
@@ -833,7 +890,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     PH(9) step_head_loss(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
     BARRIER();
     EXIT_AFTER(10);
-    PH(10) step_head_dreadout(hf, s.wb, s.dhid, s.a1, d.C1, s.z2);
+    PH(10) step_head_dreadout(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
     BARRIER();
     EXIT_AFTER(11);
 
@@ -845,8 +902,19 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     float* p_w2n = p_b1 + DRGNN_H1;
     float* p_w2s = p_w2n + DRGNN_H1 * DRGNN_H2;
     float* p_b2 = p_w2s + DRGNN_H1 * DRGNN_H2;
+    if (GIN) {
+        // dS = dZ2 W2^T (into the p2 area, rows of STEP_XPLD floats);  dW2 = S^T dZ2 (K = pooled nodes)
+        PH(11) step_gemm_nn(d.C, 1, DRGNN_H2, s.z2, Z2LD, s.w2n, W2NLD, s.p2, STEP_XPLD, dummy);
+        PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, DRGNN_NWAVES / 2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
+        BARRIER();
+        EXIT_AFTER(12);
+        // dXP = A^T dS, scattered through the depth-0 argmax into dZ1
+        PH(13) step_gather_scatter<STEP_XPLD>(d.C, s.cp1, s.rx1, s.p2, s.a0, s.z1);
+        BARRIER();
+        EXIT_AFTER(14);
+    } else {
     PH(11) net_aggregate_bwd<KIND, DRGNN_H2, true, U2LD>(d.C, s.rp1, s.cp1, s.rx1, s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
-    if (KIND != DRGNN_GINET) {
+    {
         FOR_TID(c, DRGNN_H2) {
             float acc = 0.0f;
             for (int r = 0; r < d.C; ++r) acc += s.z2[r * DRGNN_H2 + c];
@@ -855,28 +923,22 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     }
     BARRIER();
     EXIT_AFTER(12);
-    // dXP = dU2n W2n^T (+ dU2s W2s^T);  dW2 = XP^T dU2 (K = pooled nodes, split over the waves)
+    // dXP = dU2n W2n^T + dU2s W2s^T;  dW2 = XP^T dU2 (K = pooled nodes, split over the waves)
     PH(13) step_gemm_nn(d.C, 1, DRGNN_H2, s.u2, U2LD, s.w2n, W2NLD, s.dxp, DRGNN_H1, dummy);
-    if (KIND != DRGNN_GINET)
-        step_gemm_nn(d.C, 1, DRGNN_H2, s.u2 + DRGNN_H2, U2LD, s.ws2n, W2NLD, s.p2, DRGNN_H1, dummy);
+    step_gemm_nn(d.C, 1, DRGNN_H2, s.u2 + DRGNN_H2, U2LD, s.ws2n, W2NLD, s.p2, DRGNN_H1, dummy);
     PH(12) step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2, U2LD, DRGNN_NWAVES / 2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
-    if (KIND != DRGNN_GINET) {
-        BARRIER();
-        step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, DRGNN_NWAVES / 2, s.gp, p_w2s, DRGNN_H2, DRGNN_H1);
-    }
+    BARRIER();
+    step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, DRGNN_NWAVES / 2, s.gp, p_w2s, DRGNN_H2, DRGNN_H1);
     BARRIER();
     EXIT_AFTER(13);
     PH(14) FOR_TID(item, d.C * DRGNN_H1) {
         const int m = s.a0[item];
         const int c = item % DRGNN_H1;
-        if (m >= 0) {
-            float v = s.dxp[item];
-            if (KIND != DRGNN_GINET) v += s.p2[item];
-            s.z1[m * DRGNN_H1 + c] = v;
-        }
+        if (m >= 0) s.z1[m * DRGNN_H1 + c] = s.dxp[item] + s.p2[item];
     }
     BARRIER();
     EXIT_AFTER(14);
+    }
     PH(15) net_aggregate_bwd<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cp0, s.rx0, s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
     if (KIND != DRGNN_GINET) {
         FOR_TID(c, DRGNN_H1) {
