@@ -287,10 +287,11 @@ def main():
 
 def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
     """Average duration of each launch of the native step, measured with HIP events around
-    `iters` back-to-back launches on torch's current stream (= the stream the kernels are launched
-    on), and the dominant one against the HBM roofline.  Algorithmic bytes: SURVEY.md §8(d)
+    `iters` back-to-back launches (replayed from a hipGraph on torch's current stream = the stream
+    the kernels are launched on), and the dominant one against the HBM roofline.  Algorithmic bytes: SURVEY.md §8(d)
     per-graph figures x 64 graphs."""
     import copy
+    from deeprank_gnn_amd import _lib
     from deeprank_gnn_amd.topology import Topology
     from deeprank_gnn_amd.trainer import FusedTrainer
     tr = FusedTrainer(copy.deepcopy(net), lr=1e-3, task="reg", seed=99)
@@ -312,6 +313,10 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
     def k_update():
         tr._fused_launch_update(c, True, lr=0.0)
 
+    def run(fn):
+        c["stream"] = _lib.current_stream(c["x"])      # the capture stream while capturing
+        fn()
+
     upd_bytes = (c["partials"].numel() + c["hp"].numel() + c["readout"].numel() + 7 * tr.flat_p.numel()) * 4 / B
     # SURVEY figures of forward + backward (the fused launch moves less: xp/arg0/arg1 stay in LDS)
     step_bytes = BYTES_FWD - 5808 + BYTES_BWD
@@ -323,16 +328,27 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
             ("k_topo (own launch; not on the pipelined path)", k_topo, BYTES_TOPO),
             ("k_step_co_topo<GINet> without the co-launched topology (not on the pipelined path)", k_step,
              step_bytes)):
-        for _ in range(10):
-            fn()
+        # 20 back-to-back launches per hipGraph replay: the device-side duration, not the host's launch rate
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run(fn)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gr = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gr):
+            for _ in range(20):
+                run(fn)
+        for _ in range(3):
+            gr.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
-        for _ in range(iters):
-            fn()
+        for _ in range(iters // 20):
+            gr.replay()
         e1.record()
         torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / iters
+        us = e0.elapsed_time(e1) * 1e3 / (20 * (iters // 20))
         out[name] = {"avg_us": us, "alg_bytes_per_launch": nbytes * B,
                      "achieved_GBs": nbytes * B / (us * 1e-6) / 1e9}
     on_path = list(out)[:2]

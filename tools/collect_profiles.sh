@@ -1,0 +1,17 @@
+#!/bin/bash
+# Runs on the GPU box (gpurun): rocprofv3 kernel-trace stats + FETCH_SIZE / WRITE_SIZE passes (separate
+# runs, counters never combined with API tracing) of the default bench, plus the bench line itself.
+# usage: tools/collect_profiles.sh <tag>     -> gpurun_out/<tag>/{stats,fetch,write}/..., benchline.json
+set -e
+TAG=${1:-prof}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd $R
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $OUT/write.log 2>&1
+python bench.py > $OUT/benchline.json 2> $OUT/bench.err
+find $OUT -name "*.csv" | head -20
+tail -c 400 $OUT/benchline.json
