@@ -1,0 +1,65 @@
+"""Fused training-step launch vs the forward/backward pair of launches on the same inputs."""
+import copy
+
+import numpy as np
+import torch
+
+from deeprank_gnn_amd.data import Batch
+from deeprank_gnn_amd.trainer import FusedTrainer
+
+
+def ragged_batch(seed, n_feat):
+    from test_emu_topology import random_graph
+    rng = np.random.default_rng(seed)
+    graphs = []
+    for k in range(6):
+        n = int(rng.integers(2, 50))
+        e = int(rng.integers(0, 4 * n))
+        g = random_graph(rng, n, e, int(rng.integers(1, n + 1)), int(rng.integers(1, 5)), sym=bool(k % 2),
+                         self_loops=(k == 3), dup=(k == 4))
+        g.x = torch.from_numpy(rng.standard_normal((n, n_feat)).astype(np.float32))
+        graphs.append(g)
+    graphs.insert(2, random_graph(rng, 1, 0, 1, 1))              # single node, no edge
+    graphs[2].x = torch.from_numpy(rng.standard_normal((1, n_feat)).astype(np.float32))
+    return Batch.from_data_list(graphs)
+
+
+def check_fused_matches_pair(Net, n_feat, task, device, api=None, seed=0, steps=2):
+    torch.manual_seed(seed)
+    batch = ragged_batch(seed, n_feat)
+    n_out = 1 if task == "reg" else 3
+    cw = None
+    if task == "class":
+        batch.y = torch.tensor([k % 3 for k in range(batch.num_graphs)])
+        cw = torch.tensor([0.2, 0.5, 0.3])
+    else:
+        batch.y = torch.arange(batch.num_graphs, dtype=torch.float32) * 0.3 - 1.0
+    a = Net(n_feat, n_out, 1)
+    if hasattr(a, "dropout"):
+        a.dropout = 0.0
+    b = copy.deepcopy(a)
+    batch = batch.to(device)
+    kw = {} if api is None else {"api": api}
+    cwd = None if cw is None else cw.to(device)
+    ta = FusedTrainer(a.to(device), lr=0.01, task=task, class_weights=cwd, **kw)
+    tb = FusedTrainer(b.to(device), lr=0.01, task=task, class_weights=cwd, **kw)
+    tb.fused_step = False
+    fused_used = False
+    for it in range(steps):
+        la = ta.train_step(batch)
+        lb = tb.train_step(batch)
+        from deeprank_gnn_amd.topology import Topology
+        from deeprank_gnn_amd import _lib
+        topo = Topology.from_batch(batch, build=False, need_weights=(ta.kind == _lib.SGAT), **kw)
+        fused_used = fused_used or ta._can_fuse(topo, n_feat)
+        isolated = Net.__name__ == "FoutNet"       # FoutLayer: NaN rows for isolated nodes are dropped by the max-pool
+        np.testing.assert_allclose(float(la), float(lb), rtol=2e-5, equal_nan=isolated)
+        np.testing.assert_allclose(ta.last_pred.cpu().numpy(), tb.last_pred.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        ga, gb = ta.flat_g.cpu().numpy(), tb.flat_g.cpu().numpy()
+        np.testing.assert_allclose(ga, gb, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(gb).max())),
+                                   err_msg="gradient, step %d" % it)
+        # Adam normalises every gradient element by its own running magnitude: elements with a gradient at
+        # rounding-noise level may move by a visible fraction of lr differently in the two paths
+        np.testing.assert_allclose(ta.flat_p.cpu().numpy(), tb.flat_p.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    assert int(ta.step) == steps and int(tb.step) == steps
+    return fused_used

@@ -113,3 +113,16 @@ def test_pipelined_topology_co_launch_matches_plain_training():
             assert nxt.status()[0] == 0
         topo = nxt
     assert torch.equal(ta.flat_p, tb.flat_p)
+
+
+@pytest.mark.parametrize("net_name", ["GINet", "sGAT", "FoutNet"])
+@pytest.mark.parametrize("n_feat,task", [(5, "reg"), (16, "class"), (40, "reg"), (32, "reg")])
+def test_fused_step_matches_launch_pair_on_ragged_batches(net_name, n_feat, task):
+    """Fused training-step launch (incl. the cross-workgroup exchange of the two GINet branches, the generic and
+    the width-specialised instantiations, odd feature widths, single-node graphs) vs forward + backward launches."""
+    from step_check import check_fused_matches_pair
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.sGAT import sGAT
+    from deeprank_gnn_amd.foutnet import FoutNet
+    Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[net_name]
+    assert check_fused_matches_pair(Net, n_feat, task, torch.device("cuda:0"), seed=n_feat)
