@@ -911,7 +911,7 @@ static int64_t step_lds_bytes(int kind, int F, int capN, int capE, int capC, int
 
 int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                  int32_t max_c0, int32_t R, int32_t H, int32_t O) {
-    if (max_nodes <= 0 || max_nodes > 32767 || n_feat > 256) return 0;      // else: the forward/backward pair of launches
+    if (max_nodes <= 0 || max_nodes > 32767 || max_edges > 65535 || n_feat > 256) return 0;   // else: the launch pair
     const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
     return step_lds_bytes(kind, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, R, H, O);
 }
@@ -933,7 +933,7 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
     if (net->kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
     if (hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
         return DRGNN_E_WIDTH;
-    if (max_nodes <= 0 || max_nodes > 32767 || net->n_feat > 256) return DRGNN_E_CAPACITY;
+    if (max_nodes <= 0 || max_nodes > 32767 || max_edges > 65535 || net->n_feat > 256) return DRGNN_E_CAPACITY;
     StepLaunch L;
     L.capN = max_nodes;
     L.capE = max_edges > 0 ? max_edges : 1;

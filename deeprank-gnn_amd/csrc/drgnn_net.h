@@ -494,8 +494,8 @@ DEV void net_row_coefs(int n, const int* rp, const float* w, float* dv, float* s
     } while (0)
 #endif
 // LDU: row stride of u in floats (0: dense rows of HC = H or 2H)
-template <int KIND, int H, bool A16 = false, int LDU = 0>
-DEV void net_aggregate(int n, const int* rp, const int* col, const float* w, const float* dv,
+template <int KIND, int H, bool A16 = false, int LDU = 0, class IdxT = int>
+DEV void net_aggregate(int n, const int* rp, const IdxT* col, const float* w, const float* dv,
                        const float* sc, const float* u, const float* bias, float* z) {
     constexpr int HC = LDU ? LDU : ((KIND == DRGNN_GINET) ? H : 2 * H);
     constexpr int G = H / 4;
@@ -677,8 +677,8 @@ HD int64_t net_partial_floats(int n_feat) {
 
 // dU[j, 0:H]   = sum over CSC entries t of column j : coef * dZ[row(t), :]
 // dU[i, H:2H]  = sc[i] * dZ[i, :]
-template <int KIND, int H, bool A16 = false, int LDU = 0>
-DEV void net_aggregate_bwd(int n, const int* deg_rp, const int* cp, const int* ridx, const int* tslot,
+template <int KIND, int H, bool A16 = false, int LDU = 0, class IdxT = int>
+DEV void net_aggregate_bwd(int n, const int* deg_rp, const int* cp, const IdxT* ridx, const IdxT* tslot,
                            const float* w, const float* dv, const float* sc, const float* dz,
                            float* du) {
     constexpr int HC = LDU ? LDU : ((KIND == DRGNN_GINET) ? H : 2 * H);

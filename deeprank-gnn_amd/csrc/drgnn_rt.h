@@ -292,6 +292,10 @@ template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* d
     (void)dummy;
     for (int i = 0; i < b.n; ++i) ((int32_t*)dst)[i] = b.src[i];
 }
+template <int J> DEV void bufburst_store16(const BufBurst<J>& b, unsigned short* dst, int* dummy) {
+    (void)dummy;
+    for (int i = 0; i < b.n; ++i) dst[i] = (unsigned short)b.src[i];
+}
 #else
 DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -312,6 +316,15 @@ template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* d
         const int i = threadIdx.x + j * DRGNN_NTHREADS;
         int* p = (i < b.n) ? d + i : dummy + (threadIdx.x & 63);
         *p = b.v[j];
+    }
+}
+// same, narrowing to 16 bits (index arrays of a graph that lives in LDS: values < 65536)
+template <int J> DEV void bufburst_store16(const BufBurst<J>& b, unsigned short* dst, int* dummy) {
+#pragma unroll
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        const int i = threadIdx.x + j * DRGNN_NTHREADS;
+        unsigned short* p = (i < b.n) ? dst + i : (unsigned short*)(dummy + (threadIdx.x & 63));
+        *p = (unsigned short)b.v[j];
     }
 }
 #endif

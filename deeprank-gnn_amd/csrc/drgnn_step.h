@@ -58,14 +58,22 @@ struct StepArgs {
 HD int64_t head_compact_floats(int R, int H, int O) { (void)R; return (int64_t)H + (int64_t)O * H + O + 2; }
 
 #define STEP_XPLD (DRGNN_H1 + 4)     // pooled features: 20-float rows (conflict-free 128-bit row reads)
-#define STEP_GP_WORDS 4096           // partial tiles of step_gemm_tn: 16 units x 256 floats
+// the fc1 column block [H][STEP_WBLD] and, after the head, the partial tiles of step_gemm_tn (256 floats per
+// (tile, K slice) unit) share one area: at least 8 units, all 16 when H makes it that large anyway
+#define STEP_WBLD (DRGNN_H2 + 4)     // row stride of the fc1.weight column block in LDS (16-byte aligned rows)
+HD int step_gp_words(int H) { return H * STEP_WBLD > 2048 ? H * STEP_WBLD : 2048; }
 HD int step_pad4(int n) { return (n + 3) & ~3; }
 HD int step_pad16(int n) { return (n + 15) & ~15; }
-#define STEP_WBLD (DRGNN_H2 + 4)     // row stride of the fc1.weight column block in LDS (16-byte aligned rows)
+
+template <bool NARROW> struct StepIdx { typedef int type; };
+template <> struct StepIdx<true> { typedef unsigned short type; };
 
 // ---- scratch ---------------------------------------------------------------------------------
 struct StepScratch {
     float* xs; float* w1t; float* ws1t; float* b1; float* w2t; float* w2n; float* ws2t; float* ws2n; float* b2;
+    // edge-indexed arrays (cx*, rx*, ts*): node ids / slot numbers of ONE graph.  32 bits each for GINet and
+    // FoutNet; 16 bits for sGAT, whose per-edge weights and slot maps would not fit LDS otherwise (the narrow
+    // loads cost GINet 1.6 us of 17.7, so it keeps the wide ones)
     int* rp0; int* cx0; float* ew0; int* cp0; int* rx0; int* ts0; int* mp0; int* mem0;
     int* rp1; int* cx1; float* ew1; int* cp1; int* rx1; int* ts1; int* mp1; int* mem1;
     short* a0; short* a1;        // argmax node ids as 16-bit (a graph in LDS has < 32768 nodes)
@@ -88,19 +96,19 @@ struct StepScratch {
     X(ws2n, DRGNN_H1 * (DRGNN_H2 + 4), !gin)                                                   \
     X(b2, DRGNN_H2, !gin)                                                                      \
     X(rp0, capN + 1, 1)                                                                        \
-    X(cx0, capE, 1)                                                                            \
+    X(cx0, (sg ? (capE + 1) / 2 : capE), 1)                                                    \
     X(ew0, capE, sg)                                                                           \
     X(cp0, capN + 1, 1)                                                                        \
-    X(rx0, capE, 1)                                                                            \
-    X(ts0, capE, sg)                                                                           \
+    X(rx0, (sg ? (capE + 1) / 2 : capE), 1)                                                    \
+    X(ts0, (sg ? (capE + 1) / 2 : capE), sg)                                                   \
     X(mp0, capC + 1, 1)                                                                        \
     X(mem0, capN, 1)                                                                           \
     X(rp1, capC + 1, 1)                                                                        \
-    X(cx1, capE, 1)                                                                            \
+    X(cx1, (sg ? (capE + 1) / 2 : capE), 1)                                                    \
     X(ew1, capE, sg)                                                                           \
     X(cp1, capC + 1, 1)                                                                        \
-    X(rx1, capE, 1)                                                                            \
-    X(ts1, capE, sg)                                                                           \
+    X(rx1, (sg ? (capE + 1) / 2 : capE), 1)                                                    \
+    X(ts1, (sg ? (capE + 1) / 2 : capE), sg)                                                   \
     X(mp1, capC + 1, 1)                                                                        \
     X(mem1, capC, 1)                                                                           \
     X(a0, ((long)capC * DRGNN_H1 + 1) / 2, 1)                                                    \
@@ -120,7 +128,7 @@ struct StepScratch {
     X(xr, R, 1)                                                                                \
     X(hid, H, 1)                                                                               \
     X(dhid, H, 1)                                                                              \
-    X(wb, ((long)H * STEP_WBLD > STEP_GP_WORDS ? (long)H * STEP_WBLD : STEP_GP_WORDS), 1)          \
+    X(wb, step_gp_words((int)H), 1)                                                            \
     X(hb1, H, 1)                                                                               \
     X(hw2, (long)O * H, 1)                                                                     \
     X(hb2, O, 1)
@@ -293,8 +301,8 @@ DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const floa
 // relu(A (XP W2)) = relu((A XP) W2): summing the 16-wide pooled rows BEFORE the dense product halves the
 // bytes the LDS gathers move (64 instead of 128 per edge), forward and backward alike.
 // dst[i][0:16] = sum over CSR row i of src[col][0:16]; rows of LD floats, 4 lanes per row
-template <int LD>
-DEV void step_gather_rows(int n, const int* rp, const int* col, const float* src, float* dst) {
+template <int LD, class IdxT>
+DEV void step_gather_rows(int n, const int* rp, const IdxT* col, const float* src, float* dst) {
     FOR_TID(item, n * 4) {
         const int i = item >> 2, c = (item & 3) * 4;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
@@ -310,8 +318,8 @@ DEV void step_gather_rows(int n, const int* rp, const int* col, const float* src
 }
 // the transposed sum (CSC: column j gathers the rows of its entries), scattered straight through the
 // depth-0 argmax into dZ1 (row stride 16): the pooling backward needs no pass of its own
-template <int LD>
-DEV void step_gather_scatter(int n, const int* cp, const int* ridx, const float* src, const short* arg, float* dz) {
+template <int LD, class IdxT>
+DEV void step_gather_scatter(int n, const int* cp, const IdxT* ridx, const float* src, const short* arg, float* dz) {
     FOR_TID(item, n * 4) {
         const int j = item >> 2, c = (item & 3) * 4;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
@@ -597,6 +605,14 @@ DEV void step_stage_wt(float* dst, int ld, const float* src, long sk, long sh, i
     }
 }
 DEV void step_copy_i32(int* dst, const int32_t* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
+template <bool NARROW> DEV void step_copy_idx(int* dst, const int32_t* src, int n) {
+    if (NARROW) { unsigned short* d16 = (unsigned short*)dst; FOR_TID(i, n) { d16[i] = (unsigned short)src[i]; } }
+    else { FOR_TID(i, n) { dst[i] = src[i]; } }
+}
+template <bool NARROW, int J> DEV void step_store_idx(const BufBurst<J>& b, int* dst, int* dummy) {
+    if (NARROW) bufburst_store16(b, (unsigned short*)dst, dummy);
+    else bufburst_store(b, dst, dummy);
+}
 DEV void step_copy_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 
 // `part`: 0 = whole step (device), 1 = up to the readout publication, 2 = from the head on
@@ -625,6 +641,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     const int F16 = XF ? XF : step_pad16(F), XLD = F16 + 4;
     constexpr int U2LD = HC2 + 4, W2NLD = DRGNN_H2 + 4;
     constexpr bool GIN = (KIND == DRGNN_GINET);
+    constexpr bool NARROW = (KIND == DRGNN_SGAT);
+    typedef typename StepIdx<NARROW>::type EIdx;      // element type of the edge-indexed LDS arrays
     constexpr int Z2LD = GIN ? DRGNN_H2 + 4 : DRGNN_H2;      // GINet: Z2 rows feed a dense product (128-bit rows)
     StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
     EXIT_AFTER(0);
@@ -741,15 +759,15 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             step_stage_wt(s.w2t, STEP_XPLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
             stage_weight(s.w2n, W2NLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
             step_copy_i32(s.rp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
-            step_copy_i32(s.cx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
+            step_copy_idx<NARROW>(s.cx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
             step_copy_i32(s.cp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
-            step_copy_i32(s.rx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+            step_copy_idx<NARROW>(s.rx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
             step_copy_i32(s.mp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
             step_copy_i32(s.mem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
             step_copy_i32(s.rp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
-            step_copy_i32(s.cx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
+            step_copy_idx<NARROW>(s.cx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
             step_copy_i32(s.cp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
-            step_copy_i32(s.rx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            step_copy_idx<NARROW>(s.rx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
             step_copy_i32(s.mp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
             step_copy_i32(s.mem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
             FOR_TID(e, H * DRGNN_H2) {
@@ -768,8 +786,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             if (KIND == DRGNN_SGAT) {
                 step_copy_f32(s.ew0, tv.w0 + d.e0, d.E);
                 step_copy_f32(s.ew1, tv.w1 + d.e0, d.E1);
-                step_copy_i32(s.ts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
-                step_copy_i32(s.ts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+                step_copy_idx<NARROW>(s.ts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+                step_copy_idx<NARROW>(s.ts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
             }
         }
         // zero padding the predicate-free products rely on: x rows [N, pad4(N)), and (F % 16 != 0) the
@@ -793,11 +811,11 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             PH(41) { burst_store_wt(bw2, s.w2t, STEP_XPLD);
             burst_store_w(bw2, s.w2n, W2NLD); }
             PH(42) {
-            bufburst_store(brp0, s.rp0, dummy); bufburst_store(bcx0, s.cx0, dummy);
-            bufburst_store(bcp0, s.cp0, dummy); bufburst_store(brx0, s.rx0, dummy);
+            bufburst_store(brp0, s.rp0, dummy); step_store_idx<NARROW>(bcx0, s.cx0, dummy);
+            bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
             bufburst_store(bmp0, s.mp0, dummy); bufburst_store(bmem0, s.mem0, dummy);
-            bufburst_store(brp1, s.rp1, dummy); bufburst_store(bcx1, s.cx1, dummy);
-            bufburst_store(bcp1, s.cp1, dummy); bufburst_store(brx1, s.rx1, dummy);
+            bufburst_store(brp1, s.rp1, dummy); step_store_idx<NARROW>(bcx1, s.cx1, dummy);
+            bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
             bufburst_store(bmp1, s.mp1, dummy); bufburst_store(bmem1, s.mem1, dummy);
             }
             PH(43) step_wblock_store(wreg, hf, br, s.wb);
@@ -809,7 +827,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             }
             if (KIND == DRGNN_SGAT) {
                 bufburst_store(bew0, s.ew0, dummy); bufburst_store(bew1, s.ew1, dummy);
-                bufburst_store(bts0, s.ts0, dummy); bufburst_store(bts1, s.ts1, dummy);
+                step_store_idx<NARROW>(bts0, s.ts0, dummy); step_store_idx<NARROW>(bts1, s.ts1, dummy);
             }
         }
         FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
@@ -827,14 +845,14 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
             BARRIER();
         }
-        PH(2) net_aggregate<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
+        PH(2) net_aggregate<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, (const EIdx*)s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
         BARRIER();
         EXIT_AFTER(3);
         PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
         BARRIER();
         EXIT_AFTER(4);
         if (GIN) {      // S = A XP (16-wide gather), kept in the u2 area with rows of STEP_XPLD floats
-            PH(4) step_gather_rows<STEP_XPLD>(d.C, s.rp1, s.cx1, s.xp, s.u2);
+            PH(4) step_gather_rows<STEP_XPLD, EIdx>(d.C, s.rp1, (const EIdx*)s.cx1, s.xp, s.u2);
             FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.u2[d.C * STEP_XPLD + e] = 0.0f; }
         } else {
             PH(4) step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.w2t, STEP_XPLD, s.u2, U2LD, dummy);
@@ -849,7 +867,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         if (GIN) {      // Z2 = relu(S W2)
             PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H1, s.u2, STEP_XPLD, s.w2t, STEP_XPLD, s.z2, Z2LD, dummy);
         } else {
-            PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD>(d.C, s.rp1, s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+            PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD, EIdx>(d.C, s.rp1, (const EIdx*)s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
         }
         BARRIER();
         EXIT_AFTER(6);
@@ -902,18 +920,20 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     float* p_w2n = p_b1 + DRGNN_H1;
     float* p_w2s = p_w2n + DRGNN_H1 * DRGNN_H2;
     float* p_b2 = p_w2s + DRGNN_H1 * DRGNN_H2;
+    const int gp_units = step_gp_words(H) / 256;                 // (tile, K slice) units the partial-tile area holds
+    const int KS2 = imin(DRGNN_NWAVES / 2, gp_units / 2);        // dW2: 2 tiles
     if (GIN) {
         // dS = dZ2 W2^T (into the p2 area, rows of STEP_XPLD floats);  dW2 = S^T dZ2 (K = pooled nodes)
         PH(11) step_gemm_nn(d.C, 1, DRGNN_H2, s.z2, Z2LD, s.w2n, W2NLD, s.p2, STEP_XPLD, dummy);
-        PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, DRGNN_NWAVES / 2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
+        PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
         BARRIER();
         EXIT_AFTER(12);
         // dXP = A^T dS, scattered through the depth-0 argmax into dZ1
-        PH(13) step_gather_scatter<STEP_XPLD>(d.C, s.cp1, s.rx1, s.p2, s.a0, s.z1);
+        PH(13) step_gather_scatter<STEP_XPLD, EIdx>(d.C, s.cp1, (const EIdx*)s.rx1, s.p2, s.a0, s.z1);
         BARRIER();
         EXIT_AFTER(14);
     } else {
-    PH(11) net_aggregate_bwd<KIND, DRGNN_H2, true, U2LD>(d.C, s.rp1, s.cp1, s.rx1, s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
+    PH(11) net_aggregate_bwd<KIND, DRGNN_H2, true, U2LD, EIdx>(d.C, s.rp1, s.cp1, (const EIdx*)s.rx1, (const EIdx*)s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
     {
         FOR_TID(c, DRGNN_H2) {
             float acc = 0.0f;
@@ -926,9 +946,9 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     // dXP = dU2n W2n^T + dU2s W2s^T;  dW2 = XP^T dU2 (K = pooled nodes, split over the waves)
     PH(13) step_gemm_nn(d.C, 1, DRGNN_H2, s.u2, U2LD, s.w2n, W2NLD, s.dxp, DRGNN_H1, dummy);
     step_gemm_nn(d.C, 1, DRGNN_H2, s.u2 + DRGNN_H2, U2LD, s.ws2n, W2NLD, s.p2, DRGNN_H1, dummy);
-    PH(12) step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2, U2LD, DRGNN_NWAVES / 2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
+    PH(12) step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2, U2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
     BARRIER();
-    step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, DRGNN_NWAVES / 2, s.gp, p_w2s, DRGNN_H2, DRGNN_H1);
+    step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, KS2, s.gp, p_w2s, DRGNN_H2, DRGNN_H1);
     BARRIER();
     EXIT_AFTER(13);
     PH(14) FOR_TID(item, d.C * DRGNN_H1) {
@@ -939,7 +959,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     BARRIER();
     EXIT_AFTER(14);
     }
-    PH(15) net_aggregate_bwd<KIND, DRGNN_H1, true>(d.N, s.rp0, s.cp0, s.rx0, s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
+    PH(15) net_aggregate_bwd<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, s.cp0, (const EIdx*)s.rx0, (const EIdx*)s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
     if (KIND != DRGNN_GINET) {
         FOR_TID(c, DRGNN_H1) {
             float acc = 0.0f;
@@ -951,7 +971,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     EXIT_AFTER(15);
     {   // dW1 = X^T dU1: K = nodes of the graph, split in slices over the waves
         const int mtiles = F16 >> 4;
-        int KS = imin(DRGNN_NWAVES / mtiles, STEP_GP_WORDS / (mtiles * 256));
+        int KS = imin(DRGNN_NWAVES / mtiles, gp_units / mtiles);
         if (KS < 1) KS = 1;
         PH(16) step_gemm_tn(mtiles, 1, d.N, s.xs, XLD, s.u1, HC1, KS, s.gp, p_w1n, DRGNN_H1, F);
         if (KIND != DRGNN_GINET) {
