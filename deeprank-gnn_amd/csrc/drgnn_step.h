@@ -251,12 +251,16 @@ DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const floa
         }
 }
 #else
-DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
-                      float* C, int ldc, int Mrows) {
+// MT/NT compile-time (0: run-time value in mt_rt / nt_rt), KS a power of two: no integer division left
+template <int MTC, int NTC>
+DEV void step_gemm_tn_t(int mt_rt, int nt_rt, int K, const float* A, int lda, const float* B, int ldb, int KS,
+                        float* part, float* C, int ldc, int Mrows) {
+    const int MT = MTC ? MTC : mt_rt, NT = NTC ? NTC : nt_rt;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int K4 = step_pad4(K);
-    const int kslice = (((K4 >> 2) + KS - 1) / KS) << 2;
+    const int ks_log = 31 - __builtin_clz((unsigned)KS);
+    const int kslice = (((K4 >> 2) + KS - 1) >> ks_log) << 2;
     const int tiles = MT * NT, units = tiles * KS;
     for (int u = wave; u < units; u += DRGNN_NWAVES) {
         const int ks = u / tiles, t = u - ks * tiles;
@@ -294,6 +298,14 @@ DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const floa
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (row + r < Mrows) c[r * ldc] = sum[r];
     }
+}
+DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
+                      float* C, int ldc, int Mrows) {
+    KS = 1 << (31 - __builtin_clz((unsigned)(KS > 0 ? KS : 1)));       // round down to a power of two
+    if (MT == 1 && NT == 2) step_gemm_tn_t<1, 2>(1, 2, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
+    else if (MT == 2 && NT == 1) step_gemm_tn_t<2, 1>(2, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
+    else if (MT == 1 && NT == 1) step_gemm_tn_t<1, 1>(1, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
+    else step_gemm_tn_t<0, 0>(MT, NT, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
 }
 #endif
 
