@@ -332,22 +332,48 @@ DEV void step_gather_rows(int n, const int* rp, const IdxT* col, const float* sr
 // depth-0 argmax into dZ1 (row stride 16): the pooling backward needs no pass of its own
 template <int LD, class IdxT>
 DEV void step_gather_scatter(int n, const int* cp, const IdxT* ridx, const float* src, const short* arg, float* dz) {
+#ifdef DRGNN_EMU
     FOR_TID(item, n * 4) {
         const int j = item >> 2, c = (item & 3) * 4;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
-        const int lo = cp[j], hi = cp[j + 1];
-#pragma unroll 4
-        for (int t = lo; t < hi; ++t) {
+        for (int t = cp[j]; t < cp[j + 1]; ++t) {
             float v0, v1, v2, v3;
             NET_LD4(true, src + ridx[t] * LD + c, v0, v1, v2, v3);
             acc[0] += v0; acc[1] += v1; acc[2] += v2; acc[3] += v3;
         }
-#pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int m = arg[j * DRGNN_H1 + c + q];
             if (m >= 0) dz[m * DRGNN_H1 + c + q] = acc[q];
         }
     }
+#else
+    // 16 lanes per pooled node: 4 channel groups x 4 interleaved slices of its entry list (the pooled graph
+    // has few, long rows: one lane per (node, group) left 3/4 of the workgroup idle behind ~15-deep
+    // dependent gathers); the 4 slice sums are combined in fixed order with two DPP steps
+    const int items = ((n * 16) + 63) & ~63;
+    for (int item = threadIdx.x; item < items; item += DRGNN_NTHREADS) {
+        const int j = item >> 4, sl = (item >> 2) & 3, c = (item & 3) * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (j < n) {
+            const int lo = cp[j], hi = cp[j + 1];
+            for (int t = lo + sl; t < hi; t += 4) {
+                const drgnn_f4 v = *(const drgnn_f4*)(src + ridx[t] * LD + c);
+                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            }
+        }
+        // the 4 slices of a node sit 4 lanes apart inside a 16-lane row: rotate by 8, then by 4
+        a0 += dpp_take<0x128>(a0); a1 += dpp_take<0x128>(a1); a2 += dpp_take<0x128>(a2); a3 += dpp_take<0x128>(a3);
+        a0 += dpp_take<0x124>(a0); a1 += dpp_take<0x124>(a1); a2 += dpp_take<0x124>(a2); a3 += dpp_take<0x124>(a3);
+        if (sl == 0 && j < n) {
+            const float acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = arg[j * DRGNN_H1 + c + q];
+                if (m >= 0) dz[m * DRGNN_H1 + c + q] = acc[q];
+            }
+        }
+    }
+#endif
 }
 
 // ---- readout exchange between the branch workgroups of a graph -----------------------------------
@@ -638,18 +664,11 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const TopoView& tv = a.tv;
     const HeadFused& hf = a.hf;
-#ifdef DRGNN_FIXED_CAPS      // experiments only: SYN sizes as constants
-    capN = 200; capE = 1014; capC = 50;
-#endif
     // the branch count (hence the readout width) follows from the kind of net
     constexpr int nb = (KIND == DRGNN_GINET) ? 2 : 1;
     constexpr int R = DRGNN_H2 * nb;
     const int F = a.net.n_feat;
-#ifdef DRGNN_FIXED_HO
-    const int H = 128, O = 1;
-#else
     const int H = hf.H, O = hf.O;
-#endif
     const int F16 = XF ? XF : step_pad16(F), XLD = F16 + 4;
     constexpr int U2LD = HC2 + 4, W2NLD = DRGNN_H2 + 4;
     constexpr bool GIN = (KIND == DRGNN_GINET);
