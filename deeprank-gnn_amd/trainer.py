@@ -236,6 +236,10 @@ class FusedTrainer(object):
             return
         if n_global:
             self.flat_g.mul_(float(n_local if n_local is not None else self.last_batch_size) / float(n_global))
+        elif dist.get_backend(group) == "nccl":
+            # equal shards: RCCL averages inside the collective (one launch less per step)
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG, group=group)
+            return
         else:
             self.flat_g.mul_(1.0 / world)
         dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
