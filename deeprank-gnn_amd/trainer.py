@@ -236,10 +236,14 @@ class FusedTrainer(object):
             return
         if n_global:
             self.flat_g.mul_(float(n_local if n_local is not None else self.last_batch_size) / float(n_global))
-        elif dist.get_backend(group) == "nccl":
+        elif dist.get_backend(group) == "nccl" and getattr(self, "_avg_ok", True):
             # equal shards: RCCL averages inside the collective (one launch less per step)
-            dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG, group=group)
-            return
+            try:
+                dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG, group=group)
+                return
+            except (RuntimeError, ValueError):      # a build without ncclAvg: scale + sum from now on
+                self._avg_ok = False
+                self.flat_g.mul_(1.0 / world)
         else:
             self.flat_g.mul_(1.0 / world)
         dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
