@@ -187,18 +187,33 @@ def main():
 
         state["k"] = 0
         if split:
-            # [gradient graph (one per workspace parity)] -> eager all-reduce (RCCL) -> [Adam graph]
-            g_grad = [graph_of(grad_part) for _ in range(2 if two_flavours else 1)]
+            # Data parallel: the all-reduce (RCCL) stays an eager call between graph replays.  One replay per
+            # step: the Adam launch of step t is recorded in FRONT of step t+1's gradient launches
+            # ([Adam(t); grad(t+1)]), the first step of a run replays [grad] alone and the run ends with a
+            # lone [Adam] -- n gradient passes, n all-reduces, n Adam updates per run_steps(n), n+1 replays.
+            nfl = 2 if two_flavours else 1
+
+            def adam_then_grad():
+                update_part()
+                grad_part()
+            g_first, g_next = [], []
+            for k in range(nfl):
+                state["k"] = k
+                g_first.append(graph_of(grad_part))
+                state["k"] = k
+                g_next.append(graph_of(adam_then_grad))
             g_upd = graph_of(update_part)
             state["k"] = 0
 
             def run_steps(n):
-                for _ in range(n):
-                    g_grad[state["k"] if two_flavours else 0].replay()
+                for i in range(n):
+                    k = state["k"] if two_flavours else 0
+                    (g_first if i == 0 else g_next)[k].replay()
                     all_reduce()
-                    g_upd.replay()
                     if two_flavours:
                         state["k"] ^= 1
+                if n > 0:
+                    g_upd.replay()
         else:
             def whole_step():
                 grad_part()
