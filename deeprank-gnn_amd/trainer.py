@@ -63,6 +63,7 @@ class FusedTrainer(object):
         self.step = self.step2[:1]
         self.fused_step = True       # one launch for fwd + head + bwd whenever a graph fits LDS
         self._xchg = {}              # readout exchange words of the fused step, per batch size
+        self._desc_cache, self._slab_cache = {}, {}
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.offset = {}
         off = 0
@@ -143,20 +144,28 @@ class FusedTrainer(object):
             xchg = self._xchg.get(B)
             if xchg is None:
                 xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * self.H), dtype=torch.int64, device=dev)
-        g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-        g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-        for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, nb)):
-            _fill_grads(g1[b], self.kind, l1, n_feat, H1)
-            _fill_grads(g2[b], self.kind, l2, H1, H2)
+        # descriptors only depend on the (fixed) parameter storage and the feature width: built once
+        ck = self._desc_cache.get(n_feat)
+        if ck is None:
+            g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+            g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+            for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, nb)):
+                _fill_grads(g1[b], self.kind, l1, n_feat, H1)
+                _fill_grads(g2[b], self.kind, l2, H1, H2)
+            ck = self._desc_cache[n_feat] = (g1, g2, _describe(self.kind, n_feat, self.live, nb))
+        g1, g2, desc = ck
+        # slabs are internal scratch of the step: one set per batch size (predictions stay per-step tensors)
+        bk = self._slab_cache.get((B, n_feat))
+        if bk is None:
+            bk = self._slab_cache[(B, n_feat)] = (
+                torch.empty((B, H2 * nb), dtype=torch.float32, device=dev),
+                torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
+                torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
+        readout, partials, hp = bk
         return dict(
-            x=x, y=y, topo=topo, B=B, n_nodes=n_nodes, xchg=xchg, g1=g1, g2=g2,
-            desc=_describe(self.kind, n_feat, self.live, nb), stream=_lib.current_stream(x),
-            pred=torch.empty((B, self.O), dtype=torch.float32, device=dev),
-            readout=torch.empty((B, H2 * nb), dtype=torch.float32, device=dev),
-            partials=torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)),
-                                 dtype=torch.float32, device=dev),
-            hp=torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)),
-                           dtype=torch.float32, device=dev))
+            x=x, y=y, topo=topo, B=B, n_nodes=n_nodes, xchg=xchg, g1=g1, g2=g2, desc=desc,
+            stream=_lib.current_stream(x), pred=torch.empty((B, self.O), dtype=torch.float32, device=dev),
+            readout=readout, partials=partials, hp=hp)
 
     def _fused_launch_step(self, c, next_topo=None):
         """ONE launch: body fwd + head/loss + body bwd (+ the next mini-batch's topology)."""
