@@ -451,10 +451,14 @@ DEV void step_wblock_store(const WBlockRegs& wr, const HeadFused& hf, int br, fl
 // product: 8 lanes per hidden unit, DPP sum inside the lane group; the other half comes from the
 // partner workgroup through `xg`, the [n_branch][H] exchange words of graph g).
 // `part` as in net_step_graph: 1 = publish only, 2 = from the wait on (emulation passes).
-DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
-                       const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
-                       uint32_t thresh, float keep_scale, int part) {
-    const int H = hf.H;
+// HC / OC: the head's widths as compile-time constants (0: taken from the descriptor).  The reference nets use
+// fc1 widths 128 (GINet) and 64 (sGAT, FoutNet) and one output for regression: those get their own copies of
+// the four small head routines (loops of known length), everything else the generic ones.
+template <int HC>
+DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
+                         const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
+                         uint32_t thresh, float keep_scale, int part) {
+    const int H = HC ? HC : hf.H;
 #ifdef DRGNN_EMU
     if (part != 2) {
         for (int h = 0; h < H; ++h) {
@@ -500,6 +504,13 @@ DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* 
     }
 #endif
 }
+DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
+                       const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
+                       uint32_t thresh, float keep_scale, int part) {
+    if (hf.H == 128) step_head_fc1_t<128>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
+    else if (hf.H == 64) step_head_fc1_t<64>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
+    else step_head_fc1_t<0>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
+}
 
 // per-graph scalars of the loss, fetched during staging:  misc = [bad (int)][y or class id][wy][denom]
 #define STEP_M_BAD 0
@@ -510,10 +521,11 @@ DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* 
 // outs = W2 hid + b2, loss, d loss / d outs, then dhid = relu'/dropout' (W2^T douts).  Device: every
 // wave evaluates outs redundantly (lane o keeps outs[o] / douts[o]) so that no barrier separates
 // them from their consumers.  Branch 0 writes predictions and the head slab.
-DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
-                        const float* misc, float keep_scale, float* dhid, float* p_dhid, float* p_hw2,
-                        float* p_hb2, float* p_loss) {
-    const int H = hf.H, O = hf.O;
+template <int HC, int OC>
+DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
+                          const float* misc, float keep_scale, float* dhid, float* p_dhid, float* p_hw2,
+                          float* p_hb2, float* p_loss) {
+    const int H = HC ? HC : hf.H, O = OC ? OC : hf.O;
     const float denom = misc[STEP_M_DENOM], wy = misc[STEP_M_WY];
 #ifdef DRGNN_EMU
     float outs[DRGNN_MAX_OUT], douts[DRGNN_MAX_OUT];
@@ -605,12 +617,23 @@ DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, co
     }
 #endif
 }
+DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
+                        const float* misc, float keep_scale, float* dhid, float* p_dhid, float* p_hw2,
+                        float* p_hb2, float* p_loss) {
+    if (hf.H == 128 && hf.O == 1)
+        step_head_loss_t<128, 1>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    else if (hf.H == 64 && hf.O == 1)
+        step_head_loss_t<64, 1>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    else
+        step_head_loss_t<0, 0>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
+}
 
 // d readout (this branch's 32 columns) = dhid wb, scattered straight into dZ2 through the depth-1
 // argmax (mean over the C1 clusters -> factor inv)
-DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* dhid, const short* a1, int C1,
-                            float* z2, int ldz) {
-    const int H = hf.H;
+template <int HC>
+DEV void step_head_dreadout_t(const HeadFused& hf, const float* wb, const float* dhid, const short* a1, int C1,
+                              float* z2, int ldz) {
+    const int H = HC ? HC : hf.H;
     const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
 #ifdef DRGNN_EMU
     for (int c = 0; c < DRGNN_H2; ++c) {
@@ -633,6 +656,12 @@ DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* d
         }
     }
 #endif
+}
+DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* dhid, const short* a1, int C1,
+                            float* z2, int ldz) {
+    if (hf.H == 128) step_head_dreadout_t<128>(hf, wb, dhid, a1, C1, z2, ldz);
+    else if (hf.H == 64) step_head_dreadout_t<64>(hf, wb, dhid, a1, C1, z2, ldz);
+    else step_head_dreadout_t<0>(hf, wb, dhid, a1, C1, z2, ldz);
 }
 
 // strided [K,H] weight -> transposed dense rows dst[h*ld + k]
