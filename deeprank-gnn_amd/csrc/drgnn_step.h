@@ -376,6 +376,63 @@ DEV void step_gather_scatter(int n, const int* cp, const IdxT* ridx, const float
 #endif
 }
 
+// per-graph scalars of the loss, fetched during staging:  misc = [bad (int)][y or class id][wy][denom]
+#define STEP_M_BAD 0
+#define STEP_M_Y 1
+#define STEP_M_WY 2
+#define STEP_M_DENOM 3
+
+// Depth-1 max-pool with argmax (first maximum in ascending member order, NaN never wins, empty cluster -> 0,
+// arg = -1 where no gradient can flow) fused with the graph readout = mean over the depth-1 clusters.
+template <int LDZ>
+DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z, short* arg, const float* misc,
+                           float* xr, float* g_readout) {
+    int bad; memcpy(&bad, &misc[STEP_M_BAD], 4);
+    const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
+#ifdef DRGNN_EMU
+    for (int c = 0; c < DRGNN_H2; ++c) {
+        float acc = 0.0f;
+        for (int k = 0; k < C1; ++k) {
+            float best = DRGNN_NEG_INF;
+            int am = -1;
+            for (int p = mp[k]; p < mp[k + 1]; ++p) {
+                const int m = mem[p];
+                const float v = z[m * LDZ + c];
+                if (v > best) { best = v; am = m; }
+            }
+            if (am < 0) best = 0.0f;
+            arg[k * DRGNN_H2 + c] = (short)((best > 0.0f) ? am : -1);
+            acc += best;
+        }
+        acc *= inv;
+        if (bad) acc = DRGNN_NAN;
+        xr[c] = acc;
+        g_readout[c] = acc;
+    }
+#else
+    for (int t = threadIdx.x; t < DRGNN_H2 * 16; t += DRGNN_NTHREADS) {      // 512 lanes: whole waves
+        const int c = t >> 4, kk = t & 15;
+        float acc = 0.0f;
+        for (int k = kk; k < C1; k += 16) {
+            float best = DRGNN_NEG_INF;
+            int am = -1;
+#pragma unroll 4
+            for (int p = mp[k]; p < mp[k + 1]; ++p) {
+                const int m = mem[p];
+                const float v = z[m * LDZ + c];
+                if (v > best) { best = v; am = m; }
+            }
+            if (am < 0) best = 0.0f;
+            arg[k * DRGNN_H2 + c] = (short)((best > 0.0f) ? am : -1);
+            acc += best;
+        }
+        acc = lanes16_sum(acc) * inv;
+        if (bad) acc = DRGNN_NAN;
+        if (kk == 0) { xr[c] = acc; g_readout[c] = acc; }
+    }
+#endif
+}
+
 // ---- readout exchange between the branch workgroups of a graph -----------------------------------
 #ifdef DRGNN_EMU
 DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v) {
@@ -512,11 +569,6 @@ DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* 
     else step_head_fc1_t<0>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
 }
 
-// per-graph scalars of the loss, fetched during staging:  misc = [bad (int)][y or class id][wy][denom]
-#define STEP_M_BAD 0
-#define STEP_M_Y 1
-#define STEP_M_WY 2
-#define STEP_M_DENOM 3
 
 // outs = W2 hid + b2, loss, d loss / d outs, then dhid = relu'/dropout' (W2^T douts).  Device: every
 // wave evaluates outs redundantly (lane o keeps outs[o] / douts[o]) so that no barrier separates
@@ -931,20 +983,10 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         }
         BARRIER();
         EXIT_AFTER(6);
-        PH(6) net_cluster_max<DRGNN_H2, 0, short, Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.p2, nullptr, s.a1);
-        BARRIER();
-        EXIT_AFTER(7);
-        // graph readout: mean over the depth-1 clusters (this branch's 32 columns)
-        FOR_TID(c, DRGNN_H2) {
-            int bad; memcpy(&bad, &s.misc[STEP_M_BAD], 4);
-            float acc = 0.0f;
-            for (int k = 0; k < d.C1; ++k) acc += s.p2[k * DRGNN_H2 + c];
-            acc = acc / (float)(d.C1 > 0 ? d.C1 : 1);
-            if (bad) acc = DRGNN_NAN;
-            s.xr[c] = acc;
-            const_cast<float*>(hf.readout)[(long)g * R + br * DRGNN_H2 + c] = acc;
-        }
-        FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
+        // depth-1 cluster max (+ argmax) and the graph readout (mean over those clusters) in one phase: 16 lanes
+        // per channel share the clusters k = lane, lane+16, ..; their partial sums meet in a 16-lane DPP sum
+        PH(6) step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.a1, s.misc, s.xr,
+                                      const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2);
         BARRIER();
         EXIT_AFTER(8);
     }
@@ -959,6 +1001,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     float* p_hb2 = p_hw2 + (long)O * H;
     float* p_loss = p_hb2 + O;
     if (part != 2 && g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+    FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
     // half product of fc1 with this branch's readout, exchange with the partner workgroup, hid
     PH(8) step_head_fc1(hf, g, br, nb, s.wb, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
                         keep_scale, part);
