@@ -296,8 +296,11 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
             }
         }
         if (part != 1 && br == 0) {
-            float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
-            FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            if (L.a.hf.train) {
+                float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+                FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            }
+            FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
         }
         return;
     }
@@ -894,7 +897,7 @@ int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_de
         return DRGNN_E_WIDTH;
     HeadFused hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
-    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = -1;
+    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = -1; hf.train = 1;
     hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
     hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
@@ -926,9 +929,9 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
                          const drgnn_topology_request* next, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
-    if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2 || !x || !target || !step2 || !ws_i32 || !pred ||
-        !readout || !head_partials || !partials)
+    if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2 || !x || !step2 || !ws_i32 || !pred || !readout)
         return DRGNN_E_ARG;
+    if (hd->train && (!target || !head_partials || !partials)) return DRGNN_E_ARG;      // inference needs neither
     if (net->n_branch > 1 && !xchg) return DRGNN_E_ARG;
     if (net->kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
     if (hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
@@ -952,7 +955,7 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
     a.xchg = (unsigned long long*)xchg; a.step2 = step2;
     HeadFused& hf = a.hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
-    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0;
+    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0; hf.train = hd->train ? 1 : 0;
     hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
     hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;

@@ -153,6 +153,7 @@ struct HeadFused {
     float* pred;                 // [B, O]
     float* partials;             // [B][head_partial_floats]
     int stage;                   // 1: the launch reserved LDS for W1/b1/W2/b2/readout row
+    int train;                   // fused step only: 0 = inference (predictions, no loss / backward / slabs)
 };
 HD int64_t head_stage_words(int R, int H, int O) { return (int64_t)H * (R + 1) + H + (int64_t)O * H + O + R + 16; }
 

@@ -551,6 +551,9 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
                 xchg_publish(xg + (long)br * H + h, tag, acc);
                 float other = 0.0f;
                 PH(7) other = xchg_wait(xg + (long)(1 - br) * H + h, tag);
+                // consumed: clear the word, so that a later launch with the same tag (inference: the step
+                // counter does not move) can never pick up this launch's value
+                __hip_atomic_store(xg + (long)(1 - br) * H + h, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 v = (br == 0) ? acc + other : other + acc;       // P0 + P1 in both workgroups
             }
             v += b1[h];
@@ -578,6 +581,16 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
                           const float* misc, float keep_scale, float* dhid, float* p_dhid, float* p_hw2,
                           float* p_hb2, float* p_loss) {
     const int H = HC ? HC : hf.H, O = OC ? OC : hf.O;
+    if (!hf.train) {            // inference: predictions only
+        if (br == 0) {
+            FOR_TID(o, O) {
+                float acc = b2[o];
+                for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
+                hf.pred[(long)g * O + o] = acc;
+            }
+        }
+        return;
+    }
     const float denom = misc[STEP_M_DENOM], wy = misc[STEP_M_WY];
 #ifdef DRGNN_EMU
     float outs[DRGNN_MAX_OUT], douts[DRGNN_MAX_OUT];
@@ -800,7 +813,9 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         float m_wy = 1.0f, m_denom = 1.0f;
         {
             m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g] | tv.p[DRGNN_TI_GSTAT][a.n_graphs + g];
-            if (hf.task == DRGNN_TASK_REG) {
+            if (!hf.train) {
+                m_y = 0;
+            } else if (hf.task == DRGNN_TASK_REG) {
                 const float y = hf.y_reg[g];
                 memcpy(&m_y, &y, 4);
             } else {
@@ -1000,7 +1015,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     float* p_hw2 = p_dhid + H;
     float* p_hb2 = p_hw2 + (long)O * H;
     float* p_loss = p_hb2 + O;
-    if (part != 2 && g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+    if (hf.train && part != 2 && g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
     FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
     // half product of fc1 with this branch's readout, exchange with the partner workgroup, hid
     PH(8) step_head_fc1(hf, g, br, nb, s.wb, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
@@ -1009,6 +1024,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     BARRIER();
     EXIT_AFTER(9);
     PH(9) step_head_loss(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    if (!hf.train) return;
     BARRIER();
     EXIT_AFTER(10);
     PH(10) step_head_dreadout(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);

@@ -137,8 +137,9 @@ class FusedTrainer(object):
         n_nodes, n_feat = x.shape
         dev = x.device
         B, nb = topo.n_graphs, self.n_branch
-        y = batch.y
-        y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
+        y = getattr(batch, "y", None)
+        if y is not None:
+            y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
         xchg = None
         if nb > 1:
             xchg = self._xchg.get(B)
@@ -318,10 +319,17 @@ class FusedTrainer(object):
 
     @torch.no_grad()
     def predict(self, batch, topo=None):
-        """Inference (dropout off), fully on the native path; returns pred [B, O]."""
+        """Inference (dropout off), fully on the native path; returns pred [B, O].  One launch (the fused step
+        kernel in inference mode) when the graphs fit its LDS budget, else body forward + head."""
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
+        if self._can_fuse(topo, batch.x.shape[1]):
+            c = self._fused_prepare(batch, topo)
+            api.net_train_step(c["desc"], self._head_desc(False), c["x"], None, self.step2, topo.ws_i32, topo.ws_f32,
+                               c["n_nodes"], topo.n_edges, c["B"], topo.max_nodes, topo.max_edges, topo.max_c0,
+                               c["pred"], c["readout"], None, None, c["xchg"], c["stream"])
+            return c["pred"]
         stream = _lib.current_stream(batch.x)
         x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream)
         pred = torch.empty((topo.n_graphs, self.O), dtype=torch.float32, device=x.device)

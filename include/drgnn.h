@@ -352,6 +352,8 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   xchg      uint64 [B, n_branch, H], zero-filled ONCE by the caller and then left alone: the two
  *             branch workgroups of a GINet graph exchange their halves of fc1's product through it
  *             (may be NULL when n_branch == 1)
+ * head->train == 0: inference -- forward + head only (dropout off), writes pred and readout; target,
+ * head_partials and partials may be NULL and the step counters are left alone.
  * Needs max_nodes/max_edges/max_c0 bounds; returns DRGNN_E_CAPACITY when a graph of that size does
  * not fit the 160 KiB LDS (drgnn_net_step_lds_bytes): use drgnn_net_forward +
  * drgnn_net_backward_fused_head + drgnn_train_update then. */

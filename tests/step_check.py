@@ -63,3 +63,28 @@ def check_fused_matches_pair(Net, n_feat, task, device, api=None, seed=0, steps=
         np.testing.assert_allclose(ta.flat_p.cpu().numpy(), tb.flat_p.cpu().numpy(), rtol=1e-4, atol=2e-5)
     assert int(ta.step) == steps and int(tb.step) == steps
     return fused_used
+
+
+def check_fused_predict(Net, n_feat, task, device, api=None, seed=0):
+    """Inference through the fused kernel: equals the forward/head pair, is repeatable back to back (the exchange
+    words carry the same tag in every inference launch) and leaves training untouched when interleaved with it."""
+    torch.manual_seed(seed)
+    batch = ragged_batch(seed, n_feat)
+    n_out = 1 if task == "reg" else 3
+    batch.y = (torch.tensor([k % 3 for k in range(batch.num_graphs)]) if task == "class"
+               else torch.arange(batch.num_graphs, dtype=torch.float32) * 0.3 - 1.0)
+    a = Net(n_feat, n_out, 1)
+    b = copy.deepcopy(a)
+    batch = batch.to(device)
+    kw = {} if api is None else {"api": api}
+    ta = FusedTrainer(a.to(device), lr=0.01, task=task, **kw)
+    tb = FusedTrainer(b.to(device), lr=0.01, task=task, **kw)
+    tb.fused_step = False
+    for it in range(2):
+        p1 = ta.predict(batch).cpu().numpy()
+        p2 = ta.predict(batch).cpu().numpy()
+        np.testing.assert_array_equal(p1, p2)
+        np.testing.assert_allclose(p1, tb.predict(batch).cpu().numpy(), rtol=1e-4, atol=1e-5)
+        la, lb = ta.train_step(batch), tb.train_step(batch)
+        np.testing.assert_allclose(float(la), float(lb), rtol=2e-5, equal_nan=(Net.__name__ == "FoutNet"))
+    assert int(ta.step) == 2

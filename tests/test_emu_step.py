@@ -13,3 +13,10 @@ from deeprank_gnn_amd.foutnet import FoutNet
 @pytest.mark.parametrize("n_feat,task", [(5, "reg"), (16, "class"), (40, "reg")])
 def test_fused_step_matches_launch_pair(Net, n_feat, task):
     assert check_fused_matches_pair(Net, n_feat, task, "cpu", api=emu(), seed=n_feat)
+
+
+@pytest.mark.parametrize("Net,n_feat,task", [(GINet, 32, "reg"), (GINet, 5, "class"), (sGAT, 16, "reg"),
+                                            (FoutNet, 40, "reg")])
+def test_fused_inference(Net, n_feat, task):
+    from step_check import check_fused_predict
+    check_fused_predict(Net, n_feat, task, "cpu", api=emu(), seed=7 + n_feat)

@@ -126,3 +126,14 @@ def test_fused_step_matches_launch_pair_on_ragged_batches(net_name, n_feat, task
     from deeprank_gnn_amd.foutnet import FoutNet
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[net_name]
     assert check_fused_matches_pair(Net, n_feat, task, torch.device("cuda:0"), seed=n_feat)
+
+
+@pytest.mark.parametrize("net_name,n_feat,task", [("GINet", 32, "reg"), ("GINet", 5, "class"), ("sGAT", 16, "reg"),
+                                                  ("FoutNet", 40, "reg")])
+def test_fused_inference_launch(net_name, n_feat, task):
+    from step_check import check_fused_predict
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.sGAT import sGAT
+    from deeprank_gnn_amd.foutnet import FoutNet
+    Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[net_name]
+    check_fused_predict(Net, n_feat, task, torch.device("cuda:0"), seed=7 + n_feat)
