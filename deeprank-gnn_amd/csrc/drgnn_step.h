@@ -551,9 +551,12 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
                 xchg_publish(xg + (long)br * H + h, tag, acc);
                 float other = 0.0f;
                 PH(7) other = xchg_wait(xg + (long)(1 - br) * H + h, tag);
-                // consumed: clear the word, so that a later launch with the same tag (inference: the step
-                // counter does not move) can never pick up this launch's value
-                __hip_atomic_store(xg + (long)(1 - br) * H + h, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // inference launches all carry the same tag (the step counter does not move): the reader clears
+                // the word it consumed, so that the next launch cannot pick up this one's value.  Training
+                // launches skip it -- their tag changes every step and the write-through store would sit on the
+                // critical path (measured +0.8 us)
+                if (!hf.train)
+                    __hip_atomic_store(xg + (long)(1 - br) * H + h, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 v = (br == 0) ? acc + other : other + acc;       // P0 + P1 in both workgroups
             }
             v += b1[h];
