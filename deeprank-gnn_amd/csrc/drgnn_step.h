@@ -637,6 +637,9 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
         if (br == 0) p_dhid[h] = dh;
     }
 #else
+    // only the waves that own a hidden unit below (wave 0 also writes the predictions) need the outputs: the
+    // others would just repeat the same ~150 instructions on the same SIMDs
+    if ((int)(threadIdx.x & ~63u) >= H && threadIdx.x >= 64) return;
     const int lane = threadIdx.x & 63;
     float my_out = 0.0f;
     for (int o = 0; o < O; ++o) {
