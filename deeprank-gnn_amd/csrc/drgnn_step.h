@@ -799,10 +799,6 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         BurstW<1> bw1, bw2, bs1, bs2;
         BufBurst<1> brp0, bcp0, bmp0, bmem0, brp1, bcp1, bmp1, bmem1, bb1, bb2, bhb1, bhb2;
         BufBurst<2> bcx0, brx0, bcx1, brx1, bts0, bts1, bew0, bew1, bhw2;
-#if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
-        asm volatile("" :: "s"(d.N), "s"(d.E1));      // per-graph sizes have arrived
-        PHASE_MARK();
-#endif
 #ifndef DRGNN_EMU
         {   // fetch every workspace pointer in one go: otherwise each array's staging starts with its own
             // kernarg read + wait
@@ -842,50 +838,21 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             }
         }
         if (burst) {
+            // first burst: only what conv1 needs (x tile, its weights, CSR0, depth-0 member lists)
             burst_load_x(bx, xg, (DRGNN_SKIP == 20) ? 0 : d.N, F);
             burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
-            burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
-            bufburst_load(brp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
-            bufburst_load(bcx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
-            bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
-            bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
-            bufburst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
-            bufburst_load(bmem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
-            bufburst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
-            bufburst_load(bcx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
-            bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
-            bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
-            bufburst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
-            bufburst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
-            step_wblock_load(wreg, hf, br);
-            bufburst_load(bhb1, hf.b1, H);
-            bufburst_load(bhw2, hf.w2, O * H);
-            bufburst_load(bhb2, hf.b2, O);
             if (KIND != DRGNN_GINET) {
                 burst_load_w(bs1, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
-                burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
                 bufburst_load(bb1, c1.bias, DRGNN_H1);
-                bufburst_load(bb2, c2.bias, DRGNN_H2);
             }
-            if (KIND == DRGNN_SGAT) {
-                bufburst_load(bew0, tv.w0 + d.e0, d.E);
-                bufburst_load(bew1, tv.w1 + d.e0, d.E1);
-                bufburst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
-                bufburst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
-            }
-#if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
-            PHASE_MARK();                                  // all loads issued
-            asm volatile("" :: "v"(bx.v[0][0]));
-            PHASE_MARK();                                  // first x data here
-            asm volatile("" :: "v"(bw1.v[0]));
-            PHASE_MARK();                                  // conv1 weights here
-#endif
+            bufburst_load(brp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
+            bufburst_load(bcx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
+            bufburst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
+            bufburst_load(bmem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
+            if (KIND == DRGNN_SGAT) bufburst_load(bew0, tv.w0 + d.e0, d.E);
             burst_store_x4(bx, s.xs, XLD);
             burst_store_wt(bw1, s.w1t, XLD);
             if (KIND != DRGNN_GINET) burst_store_wt(bs1, s.ws1t, XLD);
-#if defined(DRGNN_PHASE_TIMING) && !defined(DRGNN_EMU)
-            PHASE_MARK();                                  // LDS stores issued
-#endif
         } else {
             FOR_TID(e, d.N * F) { s.xs[(e / F) * XLD + e % F] = xg[e]; }
             step_stage_wt(s.w1t, XLD, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
@@ -938,30 +905,38 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         EXIT_AFTER(1);
 
         // ---- forward ------------------------------------------------------------------
+        if (burst) {
+            // second burst, in flight behind conv1's product and aggregation: everything the later phases use
+            burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+            bufburst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
+            bufburst_load(bcx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
+            bufburst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
+            bufburst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+            step_wblock_load(wreg, hf, br);
+            bufburst_load(bhb1, hf.b1, H);
+            bufburst_load(bhw2, hf.w2, O * H);
+            bufburst_load(bhb2, hf.b2, O);
+            bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+            bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+            bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+            bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            if (KIND != DRGNN_GINET) {
+                burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+                bufburst_load(bb2, c2.bias, DRGNN_H2);
+            }
+            if (KIND == DRGNN_SGAT) {
+                bufburst_load(bew1, tv.w1 + d.e0, d.E1);
+                bufburst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+                bufburst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+            }
+        }
         PH(1) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t, XLD, s.u1, HC1, dummy);
         if (KIND != DRGNN_GINET) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.ws1t, XLD, s.u1 + DRGNN_H1, HC1, dummy);
         if (burst) {
-            PH(41) { burst_store_wt(bw2, s.w2t, STEP_XPLD);
-            burst_store_w(bw2, s.w2n, W2NLD); }
-            PH(42) {
             bufburst_store(brp0, s.rp0, dummy); step_store_idx<NARROW>(bcx0, s.cx0, dummy);
-            bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
             bufburst_store(bmp0, s.mp0, dummy); bufburst_store(bmem0, s.mem0, dummy);
-            bufburst_store(brp1, s.rp1, dummy); step_store_idx<NARROW>(bcx1, s.cx1, dummy);
-            bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
-            bufburst_store(bmp1, s.mp1, dummy); bufburst_store(bmem1, s.mem1, dummy);
-            }
-            PH(43) step_wblock_store(wreg, hf, br, s.wb);
-            bufburst_store(bhb1, s.hb1, dummy); bufburst_store(bhw2, s.hw2, dummy); bufburst_store(bhb2, s.hb2, dummy);
-            if (KIND != DRGNN_GINET) {
-                burst_store_wt(bs2, s.ws2t, STEP_XPLD);
-                burst_store_w(bs2, s.ws2n, W2NLD);
-                bufburst_store(bb1, s.b1, dummy); bufburst_store(bb2, s.b2, dummy);
-            }
-            if (KIND == DRGNN_SGAT) {
-                bufburst_store(bew0, s.ew0, dummy); bufburst_store(bew1, s.ew1, dummy);
-                step_store_idx<NARROW>(bts0, s.ts0, dummy); step_store_idx<NARROW>(bts1, s.ts1, dummy);
-            }
+            if (KIND != DRGNN_GINET) bufburst_store(bb1, s.b1, dummy);
+            if (KIND == DRGNN_SGAT) bufburst_store(bew0, s.ew0, dummy);
         }
         FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
         // per-graph scalars of the readout / loss phases (fetched with the burst, see above)
@@ -975,13 +950,32 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         EXIT_AFTER(2);
         if (KIND != DRGNN_GINET) {
             net_row_coefs<KIND>(d.N, s.rp0, s.ew0, s.dv0, s.sc0);
-            net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
             BARRIER();
         }
         PH(2) net_aggregate<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, (const EIdx*)s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
+        if (burst) {      // the second burst has landed by now: file it in LDS
+            burst_store_wt(bw2, s.w2t, STEP_XPLD);
+            burst_store_w(bw2, s.w2n, W2NLD);
+            bufburst_store(brp1, s.rp1, dummy); step_store_idx<NARROW>(bcx1, s.cx1, dummy);
+            bufburst_store(bmp1, s.mp1, dummy); bufburst_store(bmem1, s.mem1, dummy);
+            step_wblock_store(wreg, hf, br, s.wb);
+            bufburst_store(bhb1, s.hb1, dummy); bufburst_store(bhw2, s.hw2, dummy); bufburst_store(bhb2, s.hb2, dummy);
+            bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
+            bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
+            if (KIND != DRGNN_GINET) {
+                burst_store_wt(bs2, s.ws2t, STEP_XPLD);
+                burst_store_w(bs2, s.ws2n, W2NLD);
+                bufburst_store(bb2, s.b2, dummy);
+            }
+            if (KIND == DRGNN_SGAT) {
+                bufburst_store(bew1, s.ew1, dummy);
+                step_store_idx<NARROW>(bts0, s.ts0, dummy); step_store_idx<NARROW>(bts1, s.ts1, dummy);
+            }
+        }
         BARRIER();
         EXIT_AFTER(3);
         PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
+        if (KIND != DRGNN_GINET) net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
         BARRIER();
         EXIT_AFTER(4);
         if (GIN) {      // S = A XP (16-wide gather), kept in the u2 area with rows of STEP_XPLD floats
