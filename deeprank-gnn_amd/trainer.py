@@ -318,9 +318,11 @@ class FusedTrainer(object):
                 buf.zero_()
 
     @torch.no_grad()
-    def predict(self, batch, topo=None):
+    def predict(self, batch, topo=None, next_topo=None):
         """Inference (dropout off), fully on the native path; returns pred [B, O].  One launch (the fused step
-        kernel in inference mode) when the graphs fit its LDS budget, else body forward + head."""
+        kernel in inference mode) when the graphs fit its LDS budget, else body forward + head.  ``next_topo``
+        (``Topology.from_batch(next_batch, build=False)``) is built by extra workgroups of the same launch, as in
+        training: a stream of batches needs one launch per batch."""
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
@@ -328,8 +330,11 @@ class FusedTrainer(object):
             c = self._fused_prepare(batch, topo)
             api.net_train_step(c["desc"], self._head_desc(False), c["x"], None, self.step2, topo.ws_i32, topo.ws_f32,
                                c["n_nodes"], topo.n_edges, c["B"], topo.max_nodes, topo.max_edges, topo.max_c0,
-                               c["pred"], c["readout"], None, None, c["xchg"], c["stream"])
+                               c["pred"], c["readout"], None, None, c["xchg"], c["stream"],
+                               next_topology=None if next_topo is None else next_topo.request())
             return c["pred"]
+        if next_topo is not None:
+            next_topo.rebuild()
         stream = _lib.current_stream(batch.x)
         x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream)
         pred = torch.empty((topo.n_graphs, self.O), dtype=torch.float32, device=x.device)

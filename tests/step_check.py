@@ -88,3 +88,13 @@ def check_fused_predict(Net, n_feat, task, device, api=None, seed=0):
         la, lb = ta.train_step(batch), tb.train_step(batch)
         np.testing.assert_allclose(float(la), float(lb), rtol=2e-5, equal_nan=(Net.__name__ == "FoutNet"))
     assert int(ta.step) == 2
+    # a stream of batches: the next batch's topology is built inside the current inference launch
+    from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd import _lib
+    need_w = ta.kind == _lib.SGAT
+    t0 = Topology.from_batch(batch, need_weights=need_w, **kw)
+    t1 = Topology.from_batch(batch, need_weights=need_w, build=False, **kw)
+    pa = ta.predict(batch, topo=t0, next_topo=t1).cpu().numpy()
+    pb = ta.predict(batch, topo=t1).cpu().numpy()          # t1 was built by the previous call
+    np.testing.assert_array_equal(pa, pb)
+    np.testing.assert_allclose(pa, tb.predict(batch).cpu().numpy(), rtol=1e-4, atol=1e-5)
