@@ -137,3 +137,29 @@ def test_fused_inference_launch(net_name, n_feat, task):
     from deeprank_gnn_amd.foutnet import FoutNet
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[net_name]
     check_fused_predict(Net, n_feat, task, torch.device("cuda:0"), seed=7 + n_feat)
+
+
+def test_fused_step_full_size_properties():
+    """BASELINE size (64 graphs x 200 nodes): (1) the fused training step is bit-reproducible, (2) a graph's
+    prediction does not depend on the rest of the batch (fused inference on the batch == on the graph alone)."""
+    import copy
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    dev = torch.device("cuda:0")
+    batch = synth.make_batch(0, 64).to(dev)
+    torch.manual_seed(3)
+    net = GINet(32, 1, 1).to(dev)
+    runs = []
+    for _ in range(2):
+        tr = FusedTrainer(copy.deepcopy(net), lr=1e-3, seed=9)
+        for _ in range(3):
+            tr.train_step(batch)
+        runs.append((tr.flat_p.clone(), tr.flat_g.clone(), tr.loss.clone(), tr.last_pred.clone()))
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
+    tr = FusedTrainer(copy.deepcopy(net), lr=1e-3)
+    full = tr.predict(batch).cpu().numpy()
+    for g in (0, 17, 63):
+        single = synth.make_batch(g, 1).to(dev)
+        np.testing.assert_array_equal(tr.predict(single).cpu().numpy()[0], full[g])
