@@ -10,7 +10,8 @@
 //     only part of that matrix it ever touches: 16 KB in LDS, also used by the head's backward) and
 //     the two workgroups of a graph exchange the H half-products through tagged 64-bit words in
 //     global memory (one relaxed agent-scope atomic per value; tag = index of this step, so a
-//     word is valid exactly when its tag matches -- no fence, no flag),
+//     word is valid exactly when its tag matches -- no fence, no flag; inference launches, whose tag does
+//     not change, have the reader clear the word it consumed),
 //   * dW_fc1 = dhid^T readout is left to the update kernel (it only needs dhid [B,H] and the
 //     readout [B,R]), so the head writes a compact slab  [dhid H][dW2 O*H][db2 O][loss][weight].
 // Phases are separated by BARRIER(); the host emulation (tests) runs the two halves of the
