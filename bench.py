@@ -83,6 +83,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+    elif args.force_dp_path and args.backend == "nccl":
+        # one-rank RCCL group: the DP schedule then issues a REAL (identity) all-reduce launch per step
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=dev)
 
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd import _lib
@@ -138,6 +146,8 @@ def main():
             def all_reduce():
                 if world > 1:
                     trainer.all_reduce_gradients()
+                elif dist.is_initialized():
+                    dist.all_reduce(trainer.flat_g)
                 elif args.force_dp_path:
                     trainer.flat_g.mul_(1.0)
 
@@ -170,6 +180,8 @@ def main():
         all_reduce()
         update_part()
 
+    pre_steps = 0          # training steps already run while validating recorded graphs; counted as warm-up
+    dp_mode = "eager all-reduce between %s" % ("graph replays" if capture else "eager launches")
     if capture:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -179,9 +191,9 @@ def main():
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
 
-        def graph_of(fn):
+        def graph_of(fn, **kw):
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, **kw):
                 fn()
             return g
 
@@ -214,6 +226,68 @@ def main():
                         state["k"] ^= 1
                 if n > 0:
                     g_upd.replay()
+
+            # With RCCL the collective is recorded INSIDE the hipGraph as well: one replay per DP_CHUNK whole
+            # steps [grad; all-reduce; Adam] instead of one replay + one eager collective call per step (the
+            # eager call costs ~18 us of host time per step, more than the collective itself for a 60 KB
+            # buffer).  RCCL's watchdog thread polls events while we record, hence the thread-local capture
+            # mode.  A failure while recording falls back to the scheme above; a first replay that does not
+            # complete within 60 s aborts the run with a message instead of hanging.  DRGNN_DP_GRAPH=0 opts out.
+            use_dp_graph = (dist.is_initialized() and dist.get_backend() == "nccl"
+                            and os.environ.get("DRGNN_DP_GRAPH", "1") != "0")
+            if use_dp_graph:
+                try:
+                    DP_CHUNK = 2 * max(1, args.steps_per_replay // 2)
+
+                    def dp_chunk():
+                        for _ in range(DP_CHUNK):
+                            grad_part()
+                            all_reduce()
+                            update_part()
+
+                    def dp_one():
+                        grad_part()
+                        all_reduce()
+                        update_part()
+                    state["k"] = 0
+                    g_dp = graph_of(dp_chunk, capture_error_mode="thread_local")
+                    g_dp1 = []
+                    for k in range(nfl):
+                        state["k"] = k
+                        g_dp1.append(graph_of(dp_one, capture_error_mode="thread_local"))
+                    state["k"] = 0
+                    done = torch.cuda.Event()
+                    for k in range(2):                       # an even count: parity back to 0 afterwards
+                        g_dp1[k % nfl].replay()
+                    done.record()
+                    t_lim = time.time() + 60.0
+                    while not done.query():
+                        if time.time() > t_lim:
+                            sys.stderr.write("rank %d: graph-recorded all-reduce did not complete; "
+                                             "rerun with DRGNN_DP_GRAPH=0\n" % rank)
+                            sys.stderr.flush()
+                            os._exit(3)
+                        time.sleep(0.001)
+                    pre_steps = 2
+                    dp_mode = "hipGraph of %d x [grad; RCCL all-reduce; Adam]" % DP_CHUNK
+
+                    def run_steps(n):            # noqa: F811
+                        if n > 0 and two_flavours and state["k"] == 1:
+                            g_dp1[1].replay()
+                            state["k"] = 0
+                            n -= 1
+                        for _ in range(n // DP_CHUNK):
+                            g_dp.replay()
+                        n %= DP_CHUNK
+                        while n > 0:
+                            k = state["k"] if two_flavours else 0
+                            g_dp1[k].replay()
+                            if two_flavours:
+                                state["k"] ^= 1
+                            n -= 1
+                except Exception as exc:       # pragma: no cover - depends on the collective library
+                    sys.stderr.write("rank %d: recording the collective failed (%s); eager all-reduce\n" % (rank, exc))
+                    state["k"] = 0
         else:
             def whole_step():
                 grad_part()
@@ -254,7 +328,7 @@ def main():
             for _ in range(n):
                 eager_step()
 
-    run_steps(args.warmup)
+    run_steps(max(args.warmup - pre_steps, 0))
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -270,6 +344,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss_out.item())
+    in_sync = None
+    if world > 1:
+        # data parallel invariant: every rank applied the same averaged gradients, so the parameters agree bit
+        # for bit (checked on a checksum and on the extreme values, max == min over ranks)
+        flat = torch.cat([q.detach().reshape(-1).double() for q in net.parameters()])
+        probe = torch.stack([flat.sum(), flat.abs().max(), flat.min()])
+        hi, lo = probe.clone(), probe.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        in_sync = bool(torch.equal(hi, lo))
 
     result = None
     if rank == 0:
@@ -289,12 +373,17 @@ def main():
                                     "(double-buffered)" if pipeline else "rebuilt every step, own launch"),
                        "final_loss": final_loss},
         }
+        if split:
+            result["config"]["dp_exchange"] = dp_mode
+            result["config"]["params_in_sync"] = in_sync
         if args.net == "GINet":
             result["roofline"] = measure_roofline(net, batch, dev, value)
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.net, batch_cpu, args.cpu_seconds)
     if world > 1:
         dist.barrier()
+        dist.destroy_process_group()
+    elif dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(result))
