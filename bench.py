@@ -60,13 +60,18 @@ def parse():
                          "with one process -- for testing on a single GPU")
     ap.add_argument("--steps-per-replay", type=int, default=20,
                     help="training steps captured per hipGraph replay (pipelined native mode)")
+    ap.add_argument("--graphs-per-gpu", type=int, default=GRAPHS_PER_GPU,
+                    help="mini-batch per GPU; %d is BASELINE.json's configuration, other values are for the "
+                         "batch-size sweep in DESIGN.md" % GRAPHS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
 
 def main():
+    global GRAPHS_PER_GPU
     args = parse()
+    GRAPHS_PER_GPU = args.graphs_per_gpu
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
