@@ -37,7 +37,8 @@ N_FEAT = 32
 # algorithmic HBM bytes per graph (derivation table): GINet
 BYTES_FWD, BYTES_BWD = 67668, 90208
 BYTES_TOPO = 4804 + 1800 + 5808 + 16 * 1000        # read edge_index (int64 [2,E]) + clusters, write CSR0 + pooled CSR
-PMC_FILE = "r01_bench_native_v6_pmc.json"
+PMC_FILE = "r01_bench_native_v7_pmc.json"
+SQ_FILE = "r01_bench_native_v7_sq.json"
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
 
 
@@ -470,7 +471,15 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
         for k, v in pmc.items():
             if "k_step_co_topo" in k and "k_step_co_topo" in dom:
                 traffic = v["hbm_bytes_per_launch"]
+    mfma = None
+    sq_path = os.path.join(ROOT, "profiles", SQ_FILE)
+    if os.path.exists(sq_path):           # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES of this same command (offline pass)
+        for k, v in json.load(open(sq_path)).items():
+            if "k_step_co_topo" in k and "k_step_co_topo" in dom:
+                # busy cycles summed over SIMDs / (1024 SIMDs x kernel cycles at the measured 2.28 GHz shader clock)
+                mfma = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (out[dom]["avg_us"] * 1e3 * 2.28 * 1024.0)
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "mfma_util": mfma,
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
             "traffic_note": "bytes/launch from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, profiles/"
                             "%s); FETCH doubled per MI355X_MICROARCH.md" % PMC_FILE,
