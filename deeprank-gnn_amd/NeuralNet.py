@@ -15,8 +15,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .data import Batch
 from .dataset import GraphDataSet
+from .resident import ResidentGraphSet
 from .topology import Topology
 from .trainer import FusedTrainer
 
@@ -110,38 +110,61 @@ class NeuralNet(object):
             self.trainer.load_optimizer_state_dict(opt_state)
         self.train_loss, self.valid_loss, self.train_acc, self.valid_acc = [], [], [], []
         self.data = {}
+        self._resident_sets = {}
+        self.native_epoch = True      # False: step mini-batch by mini-batch from Python (same results)
 
     # ------------------------------------------------------------------------------
+    def _resident(self, dataset):
+        """The graph set of ``dataset`` in HBM (uploaded on first use, every graph read once): mini-batches are
+        then assembled on the device from graph numbers (resident.py) instead of re-reading and collating on
+        the host per batch and per epoch as the reference does (DataSet.py:231-366, NeuralNet.py:153-154)."""
+        rs = self._resident_sets.get(id(dataset), (None, None))[1]
+        if rs is None:
+            rs = ResidentGraphSet(dataset, self.device, api=self._api)
+            if self.task == 'class' and rs.y is not None:
+                # format_output's target half (NeuralNet.py:616-631): class labels -> class indices
+                rs.set_targets(torch.tensor([self.classes_to_idx[int(v)] for v in rs.y.cpu().tolist()]))
+            self._resident_sets[id(dataset)] = (dataset, rs)       # keeps the dataset alive: ids stay unique
+        return rs
+
     def _batches(self, dataset, indices, shuffle):
-        order = list(indices)
+        order = [int(i) for i in indices]
         if shuffle:
             order = [order[i] for i in torch.randperm(len(order)).tolist()]
+        if not order:
+            return
+        rs = self._resident(dataset)
+        ids_dev = rs.upload_ids(order)                 # one small upload per epoch
         for lo in range(0, len(order), self.batch_size):
-            graphs = [dataset[i] for i in order[lo:lo + self.batch_size]]
-            batch = Batch.from_data_list(graphs)
-            yield self._targets(batch).to(self.device)
-
-    def _targets(self, batch):
-        """format_output's target half (NeuralNet.py:616-631): class labels -> class indices."""
-        if self.task == 'class' and batch.y is not None:
-            batch.y = torch.tensor([self.classes_to_idx[int(v)] for v in batch.y])
-        return batch
+            yield rs.batch(order[lo:lo + self.batch_size], ids_dev[lo:lo + self.batch_size])
 
     def _collect(self, pred, batch, store):
+        """Keeps the batch's outputs ON THE DEVICE; _finish turns them into the reference's lists once per
+        pass (the reference syncs per batch: .item() / .cpu(), NeuralNet.py:446-460,508-523)."""
+        store['_pred'].append(pred.detach().clone())   # the trainer reuses its output buffer
+        if batch.y is not None:
+            store['_y'].append(batch.y)
+        store['mol'] += list(batch['mol'])
+
+    def _finish(self, store):
+        preds, ys = store.pop('_pred'), store.pop('_y')
+        if not preds:
+            return store
+        pred = torch.cat(preds).cpu()
+        y = torch.cat(ys).cpu() if ys else None
         if self.task == 'class':
-            prob = torch.softmax(pred.detach().cpu(), dim=1)
+            prob = torch.softmax(pred, dim=1)
             store['raw_outputs'] += prob.tolist()
-            out = prob.argmax(dim=1).tolist()
-            store['outputs'] += [self.idx_to_classes[i] for i in out]
-            if batch.y is not None:
-                store['targets'] += [self.idx_to_classes[int(i)] for i in batch.y.tolist()]
+            store['outputs'] += [self.idx_to_classes[i] for i in prob.argmax(dim=1).tolist()]
+            if y is not None:
+                store['targets'] += [self.idx_to_classes[int(i)] for i in y.tolist()]
         else:
-            out = pred.detach().cpu().reshape(-1).tolist()
+            out = pred.reshape(-1).tolist()
             store['raw_outputs'] += out
             store['outputs'] += out
-            if batch.y is not None:
-                store['targets'] += batch.y.tolist()
-        store['mol'] += list(batch['mol'])
+            if y is not None:
+                store['targets'] += y.tolist()
+        return store
 
     def _accuracy(self, store):
         if not store['targets']:
@@ -151,10 +174,29 @@ class NeuralNet(object):
         t, o = np.asarray(store['targets']), np.asarray(store['outputs'])
         return float(np.mean((t < self.threshold) == (o < self.threshold)))
 
+    @staticmethod
+    def _new_store():
+        return {'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': [], '_pred': [], '_y': []}
+
     def _epoch(self, epoch):
-        """One pass over the training set (NeuralNet.py:477-537) on the native step."""
-        store = {'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': []}
-        running = 0.0
+        """One pass over the training set (NeuralNet.py:477-537) on the native step.  No host sync inside
+        the loop: batches come from the resident set, the running loss stays on the device."""
+        store = self._new_store()
+        if self.native_epoch and self.train_index:
+            # the whole epoch enqueued by the native loop (drgnn_train_epoch): collate, step (+ next topology) and
+            # update launches for every mini-batch, one host synchronisation at the end
+            rs = self._resident(self.dataset)
+            order = [int(i) for i in self.train_index]
+            if self.shuffle:
+                order = [order[i] for i in torch.randperm(len(order)).tolist()]
+            done = self.trainer.train_epoch(rs, order, self.batch_size)
+            if done is not None:
+                losses, pred = done
+                store['_pred'].append(pred)
+                store['_y'].append(rs.y[torch.as_tensor(order, dtype=torch.long, device=rs.y.device)])
+                store['mol'] += [rs.mols[i] for i in order]
+                return float(losses.sum()), self._finish(store)
+        running = torch.zeros((), dtype=torch.float32, device=self.device)
         need_w = self.trainer.kind == _lib.SGAT
         it = self._batches(self.dataset, self.train_index, self.shuffle)
         batch = next(it, None)
@@ -167,26 +209,34 @@ class NeuralNet(object):
             nxt_topo = None if nxt is None else Topology.from_batch(nxt, api=self.trainer.api,
                                                                     need_weights=need_w, build=False)
             loss = self.trainer.train_step(batch, topo=topo, next_topo=nxt_topo)
-            running += float(loss)                      # host sync per batch, as the reference's .item()
+            running += loss.reshape(())
             self._collect(self.trainer.last_pred, batch, store)
             batch, topo = nxt, nxt_topo
-        return running, store
+        return float(running), self._finish(store)
 
     def eval(self, dataset=None, indices=None):
         """Forward only (NeuralNet.py:414-475); returns (loss_sum, store)."""
         dataset = dataset or self.dataset
         indices = self.valid_index if indices is None else indices
-        store = {'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': []}
-        total = 0.0
-        for batch in self._batches(dataset, indices, False):
-            pred = self.trainer.predict(batch)
+        store = self._new_store()
+        total = torch.zeros((), dtype=torch.float32, device=self.device)
+        need_w = self.trainer.kind == _lib.SGAT
+        it = self._batches(dataset, indices, False)
+        batch = next(it, None)
+        topo = None if batch is None else Topology.from_batch(batch, api=self.trainer.api, need_weights=need_w)
+        while batch is not None:
+            nxt = next(it, None)
+            nxt_topo = None if nxt is None else Topology.from_batch(nxt, api=self.trainer.api,
+                                                                    need_weights=need_w, build=False)
+            pred = self.trainer.predict(batch, topo=topo, next_topo=nxt_topo)
             if batch.y is not None:
                 if self.task == 'reg':
-                    total += float(torch.nn.functional.mse_loss(pred.reshape(-1), batch.y))
+                    total += torch.nn.functional.mse_loss(pred.reshape(-1), batch.y)
                 else:
-                    total += float(torch.nn.functional.cross_entropy(pred, batch.y, weight=self.trainer.class_w))
+                    total += torch.nn.functional.cross_entropy(pred, batch.y, weight=self.trainer.class_w)
             self._collect(pred, batch, store)
-        return total, store
+            batch, topo = nxt, nxt_topo
+        return float(total), self._finish(store)
 
     def train(self, nepoch=1, validate=False, save_model='last', hdf5='train_data.npz', save_epoch='intermediate',
               save_every=5):

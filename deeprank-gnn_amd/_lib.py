@@ -59,6 +59,27 @@ class TopologyRequest(ctypes.Structure):
                 ("ws_i32", _vp), ("ws_f32", _vp), ("scratch_i32", _vp)]
 
 
+class GraphSet(ctypes.Structure):
+    """drgnn_graph_set: the dataset resident in HBM, graph-major (include/drgnn.h)."""
+    _fields_ = [("n_graphs", _c_i64), ("n_nodes", _c_i64), ("n_edges", _c_i64), ("len_cluster1", _c_i64),
+                ("n_feat", _c_i32), ("y_bytes", _c_i32),
+                ("node_ptr", _vp), ("edge_ptr", _vp), ("c1_ptr", _vp),
+                ("x", _vp), ("edge_index", _vp), ("edge_attr", _vp),
+                ("cluster0", _vp), ("cluster1", _vp), ("y", _vp)]
+
+
+class EpochPlan(ctypes.Structure):
+    """drgnn_epoch_plan (include/drgnn.h); pointer members are filled by FusedTrainer.train_epoch."""
+    _fields_ = [("set", _vp), ("host_node_ptr", _vp), ("host_edge_ptr", _vp), ("host_c1_ptr", _vp),
+                ("ids", _vp), ("host_ids", _vp), ("n_ids", _c_i64),
+                ("batch_size", _c_i32), ("need_weights", _c_i32),
+                ("net", _vp), ("head", _vp), ("g_conv1", _vp), ("g_conv2", _vp),
+                ("head_offset", _c_i64),
+                ("flat_param", _vp), ("flat_grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("n_param", _c_i64),
+                ("step2", _vp),
+                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
 class HeadDesc(ctypes.Structure):
     _fields_ = [("R", _c_i32), ("H", _c_i32), ("O", _c_i32), ("task", _c_i32), ("train", _c_i32),
                 ("p_drop", ctypes.c_float), ("seed", ctypes.c_uint32), ("reserved", _c_i32),
@@ -144,6 +165,10 @@ class Api(object):
         lib.drgnn_pooled_edges_export.argtypes = [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp]
         lib.drgnn_cluster_offset.argtypes = [_vp, _vp, _c_i64, _vp, _vp]
         lib.drgnn_mcl.argtypes = [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp]
+        lib.drgnn_train_epoch_scratch_bytes.argtypes = [ctypes.POINTER(EpochPlan)]
+        lib.drgnn_train_epoch_scratch_bytes.restype = _c_i64
+        lib.drgnn_train_epoch.argtypes = [ctypes.POINTER(EpochPlan), _vp, _c_i64, _vp, _vp, _vp]
+        lib.drgnn_collate.argtypes = [ctypes.POINTER(GraphSet), _vp] + [_c_i64] * 3 + [_vp] * 11
         lib.drgnn_head_partial_elems.argtypes = [_c_i32] * 3
         lib.drgnn_head_partial_elems.restype = _c_i64
         lib.drgnn_head_num_slabs.argtypes = [_c_i64]
@@ -302,6 +327,26 @@ class Api(object):
             info, stream):
         _check(self.lib.drgnn_mcl(_ptr(edge_index), n_edges, _ptr(node_ptr), _ptr(edge_ptr), _ptr(mat_ptr), n_graphs,
                                   _ptr(mat_scratch), _ptr(int_scratch), _ptr(labels), _ptr(info), stream), "drgnn_mcl")
+
+    def collate(self, gset, ids, n_graphs, n_nodes, n_edges, x, edge_index, edge_attr, batch, cluster0, cluster1,
+                y, node_ptr, edge_ptr, c1_ptr, stream):
+        _check(self.lib.drgnn_collate(ctypes.byref(gset), _ptr(ids), n_graphs, n_nodes, n_edges, _ptr(x),
+                                      _ptr(edge_index), _ptr(edge_attr), _ptr(batch), _ptr(cluster0),
+                                      _ptr(cluster1), _ptr(y), _ptr(node_ptr), _ptr(edge_ptr), _ptr(c1_ptr),
+                                      stream), "drgnn_collate")
+
+    def train_epoch_scratch_bytes(self, plan):
+        """Bytes of device scratch for the plan; None when a graph does not fit the fused kernels."""
+        n = int(self.lib.drgnn_train_epoch_scratch_bytes(ctypes.byref(plan)))
+        if n == -2:
+            return None
+        if n < 0:
+            _check(n, "drgnn_train_epoch_scratch_bytes")
+        return n
+
+    def train_epoch(self, plan, scratch, pred, losses, stream):
+        _check(self.lib.drgnn_train_epoch(ctypes.byref(plan), _ptr(scratch), scratch.numel() * scratch.element_size(),
+                                          _ptr(pred), _ptr(losses), stream), "drgnn_train_epoch")
 
     # -- head / loss / optimiser ------------------------------------------------
     def head_partial_elems(self, R, H, O):

@@ -8,6 +8,7 @@
 #include "drgnn_step.h"
 #include "drgnn_layers.h"
 #include "drgnn_mcl.h"
+#include "drgnn_collate.h"
 
 #include <vector>
 #ifdef DRGNN_EMU
@@ -436,6 +437,10 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_mcl(MclArgs a) {
     __shared__ double red[DRGNN_NTHREADS];
     __shared__ int flag[2];
     mcl_graph(a, blockIdx.x, flag, red);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_collate(CollateArgs a) {
+    __shared__ int sh[4];
+    collate_block(a, blockIdx.x, sh);
 }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_head(HeadArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem_h[];
@@ -1404,6 +1409,194 @@ int drgnn_mcl(const int64_t* edge_index, int64_t n_edges, const int32_t* node_pt
     hipLaunchKernelGGL(k_mcl, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
 #endif
+    return 0;
+}
+
+// ---- mini-batch assembly from the resident graph set -----------------------------------------------
+int drgnn_collate(const drgnn_graph_set* set, const int32_t* ids, int64_t n_graphs, int64_t n_nodes,
+                  int64_t n_edges, float* x, int64_t* edge_index, float* edge_attr, int64_t* batch,
+                  int64_t* cluster0, int64_t* cluster1, void* y, int32_t* node_ptr, int32_t* edge_ptr,
+                  int32_t* c1_ptr, void* stream) {
+    if (!set || !ids || n_graphs < 0 || n_nodes < 0 || n_edges < 0 || !node_ptr || !edge_ptr) return DRGNN_E_ARG;
+    if (!set->node_ptr || !set->edge_ptr || set->n_feat <= 0 || set->n_graphs < 0) return DRGNN_E_ARG;
+    if (n_nodes > 0 && (!x || !batch || !set->x)) return DRGNN_E_ARG;
+    if (n_edges > 0 && (!edge_index || !set->edge_index)) return DRGNN_E_ARG;
+    if ((edge_attr && !set->edge_attr) || (cluster0 && !set->cluster0)) return DRGNN_E_ARG;
+    if (cluster1 && (!set->cluster1 || !set->c1_ptr || !c1_ptr)) return DRGNN_E_ARG;
+    if (y && (!set->y || (set->y_bytes != 4 && set->y_bytes != 8))) return DRGNN_E_ARG;
+    if (n_nodes > 0x7fffffffLL || n_edges > 0x7fffffffLL) return DRGNN_E_CAPACITY;   // int32 offset tables
+    if (n_graphs == 0) return 0;
+    CollateArgs a;
+    a.set = *set; a.ids = ids; a.n_graphs = (int)n_graphs; a.n_edges = n_edges;
+    a.x = x; a.edge_index = edge_index; a.edge_attr = edge_attr; a.batch = batch;
+    a.cluster0 = cluster0; a.cluster1 = cluster1; a.y = y;
+    a.node_ptr = node_ptr; a.edge_ptr = edge_ptr; a.c1_ptr = set->c1_ptr ? c1_ptr : nullptr;
+#ifdef DRGNN_EMU
+    int sh[4];
+    for (int g = 0; g < n_graphs; ++g) collate_block(a, g, sh);
+    (void)stream;
+#else
+    hipLaunchKernelGGL(k_collate, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+// ---- one training epoch, driven from here ---------------------------------------------------------
+namespace {
+struct EpochBatch { int64_t first, B, N, E, C; int maxN, maxE, maxC; };
+struct EpochSlot {
+    float* x; int64_t* edge_index; float* edge_attr; int64_t* batch; int64_t* cluster0; int64_t* cluster1; void* y;
+    int32_t* ptrs; int32_t* ws_i32; float* ws_f32;
+};
+struct EpochCarve {
+    EpochSlot slot[2];
+    float* readout; float* partials; float* head_partials; uint64_t* xchg; int64_t xchg_bytes;
+    int64_t bytes;
+};
+int epoch_batch(const drgnn_epoch_plan* p, int64_t k, EpochBatch* b) {
+    const int64_t G = p->set->n_graphs;
+    b->first = k * p->batch_size;
+    b->B = p->n_ids - b->first < p->batch_size ? p->n_ids - b->first : p->batch_size;
+    b->N = b->E = b->C = 0; b->maxN = b->maxE = b->maxC = 0;
+    for (int64_t q = 0; q < b->B; ++q) {
+        const int64_t id = p->host_ids[b->first + q];
+        if (id < 0 || id >= G) return DRGNN_E_ARG;
+        const int64_t n = p->host_node_ptr[id + 1] - p->host_node_ptr[id];
+        const int64_t e = p->host_edge_ptr[id + 1] - p->host_edge_ptr[id];
+        const int64_t c = p->host_c1_ptr ? p->host_c1_ptr[id + 1] - p->host_c1_ptr[id] : 0;
+        if (n < 0 || e < 0 || c < 0) return DRGNN_E_ARG;
+        b->N += n; b->E += e; b->C += c;
+        if (n > b->maxN) b->maxN = (int)n;
+        if (e > b->maxE) b->maxE = (int)e;
+        if (c > b->maxC) b->maxC = (int)c;
+    }
+    return 0;
+}
+int epoch_check(const drgnn_epoch_plan* p) {
+    if (!p || !p->set || !p->host_node_ptr || !p->host_edge_ptr || !p->ids || !p->host_ids || p->n_ids < 0 ||
+        p->batch_size < 1 || !p->net || !p->head || !p->g_conv1 || !p->g_conv2 || !p->flat_param || !p->flat_grad ||
+        !p->exp_avg || !p->exp_avg_sq || !p->step2)
+        return DRGNN_E_ARG;
+    if (!p->set->cluster0 || !p->set->cluster1 || !p->set->c1_ptr || !p->host_c1_ptr || !p->set->y) return DRGNN_E_ARG;
+    if (p->need_weights && !p->set->edge_attr) return DRGNN_E_ARG;
+    if (p->set->n_feat != p->net->n_feat) return DRGNN_E_WIDTH;
+    if (p->set->y_bytes != (p->head->task == DRGNN_TASK_REG ? 4 : 8)) return DRGNN_E_ARG;
+    return 0;
+}
+// sizes the two mini-batch slots and the step slabs for the largest mini-batch of the plan
+int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
+    int rc = epoch_check(p);
+    if (rc) return rc;
+    const int64_t nb = (p->n_ids + p->batch_size - 1) / p->batch_size;
+    int64_t capN = 1, capE = 1, capC = 1, capB = 1, ws_i = 4, ws_f = 4;
+    const drgnn_head_desc* hd = p->head;
+    for (int64_t k = 0; k < nb; ++k) {
+        EpochBatch b;
+        if ((rc = epoch_batch(p, k, &b))) return rc;
+        if (b.maxN <= 0) return DRGNN_E_CAPACITY;
+        if (drgnn_net_step_lds_bytes(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O) > DRGNN_LDS_LIMIT ||
+            b.maxN > 32767 || b.maxE > 65535 || drgnn_topology_lds_bytes(b.maxN, b.maxE) > DRGNN_LDS_LIMIT)
+            return DRGNN_E_CAPACITY;
+        TopoLayout lay;
+        topo_layout(b.N, b.E, b.B, &lay);
+        if (lay.i32[DRGNN_TI_COUNT] > ws_i) ws_i = lay.i32[DRGNN_TI_COUNT];
+        if (lay.f32[DRGNN_TF_COUNT] > ws_f) ws_f = lay.f32[DRGNN_TF_COUNT];
+        if (b.N > capN) capN = b.N;
+        if (b.E > capE) capE = b.E;
+        if (b.C > capC) capC = b.C;
+        if (b.B > capB) capB = b.B;
+    }
+    int64_t o = 0;
+    auto take = [&](int64_t bytes) { char* q = base ? base + o : nullptr; o += (bytes + 255) & ~(int64_t)255; return (void*)q; };
+    const int F = p->net->n_feat, nbr = p->net->n_branch;
+    for (int s = 0; s < 2; ++s) {
+        EpochSlot& t = c->slot[s];
+        t.x = (float*)take(capN * F * 4);
+        t.edge_index = (int64_t*)take(2 * capE * 8);
+        t.edge_attr = p->need_weights ? (float*)take(capE * 4) : nullptr;
+        t.batch = (int64_t*)take(capN * 8);
+        t.cluster0 = (int64_t*)take(capN * 8);
+        t.cluster1 = (int64_t*)take(capC * 8);
+        t.y = take(capB * 8);
+        t.ptrs = (int32_t*)take(3 * (capB + 1) * 4);
+        t.ws_i32 = (int32_t*)take(ws_i * 4);
+        t.ws_f32 = p->need_weights ? (float*)take(ws_f * 4) : nullptr;
+    }
+    c->readout = (float*)take(capB * hd->R * 4);
+    c->partials = (float*)take(capB * nbr * drgnn_net_partial_elems(p->net->kind, F) * 4);
+    c->head_partials = (float*)take(capB * drgnn_head_compact_elems(hd->R, hd->H, hd->O) * 4);
+    c->xchg_bytes = capB * nbr * (int64_t)hd->H * 8;
+    c->xchg = (uint64_t*)take(c->xchg_bytes);
+    c->bytes = o;
+    return 0;
+}
+}  // namespace
+
+int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan) {
+    EpochCarve c;
+    const int rc = epoch_carve(plan, nullptr, &c);
+    return rc ? (int64_t)rc : c.bytes;
+}
+
+int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_bytes, float* pred, float* losses,
+                      void* stream) {
+    EpochCarve c;
+    int rc = epoch_carve(p, (char*)scratch, &c);
+    if (rc) return rc;
+    if (p->n_ids == 0) return 0;
+    if (!scratch || !pred || !losses || ((uintptr_t)scratch & 15)) return DRGNN_E_ARG;
+    if (scratch_bytes < c.bytes) return DRGNN_E_CAPACITY;
+    const int64_t nb = (p->n_ids + p->batch_size - 1) / p->batch_size;
+    const drgnn_head_desc* hd = p->head;
+    drgnn_head_desc head = *hd;
+    head.train = 1;
+    // the exchange words carry the step index as a tag: they only have to start from a value no step uses
+#ifdef DRGNN_EMU
+    memset(c.xchg, 0, (size_t)c.xchg_bytes);
+#else
+    HIP_TRY(hipMemsetAsync(c.xchg, 0, (size_t)c.xchg_bytes, (hipStream_t)stream));
+#endif
+    auto collate = [&](int64_t k, const EpochBatch& b) {
+        const EpochSlot& t = c.slot[k & 1];
+        return drgnn_collate(p->set, p->ids + b.first, b.B, b.N, b.E, t.x, t.edge_index, t.edge_attr, t.batch, t.cluster0,
+                             t.cluster1, t.y, t.ptrs, t.ptrs + (b.B + 1), t.ptrs + 2 * (b.B + 1), stream);
+    };
+    EpochBatch cur, nxt;
+    if ((rc = epoch_batch(p, 0, &cur))) return rc;
+    if ((rc = collate(0, cur))) return rc;
+    {
+        const EpochSlot& t = c.slot[0];
+        rc = drgnn_topology_build(t.edge_index, t.edge_attr, t.batch, t.cluster0, t.cluster1, t.ptrs, t.ptrs + (cur.B + 1),
+                                  t.ptrs + 2 * (cur.B + 1), cur.N, cur.E, cur.C, cur.B, cur.maxN, cur.maxE, t.ws_i32,
+                                  t.ws_f32, nullptr, stream);
+        if (rc) return rc;
+    }
+    for (int64_t k = 0; k < nb; ++k) {
+        const EpochSlot& t = c.slot[k & 1];
+        drgnn_topology_request req;
+        const bool more = k + 1 < nb;
+        if (more) {
+            if ((rc = epoch_batch(p, k + 1, &nxt))) return rc;
+            if ((rc = collate(k + 1, nxt))) return rc;
+            const EpochSlot& u = c.slot[(k + 1) & 1];
+            req.edge_index = u.edge_index; req.edge_attr = u.edge_attr; req.batch = u.batch;
+            req.cluster0 = u.cluster0; req.cluster1 = u.cluster1;
+            req.node_ptr = u.ptrs; req.edge_ptr = u.ptrs + (nxt.B + 1); req.c1_ptr = u.ptrs + 2 * (nxt.B + 1);
+            req.n_nodes = nxt.N; req.n_edges = nxt.E; req.len_cluster1 = nxt.C; req.n_graphs = nxt.B;
+            req.max_nodes = nxt.maxN; req.max_edges = nxt.maxE;
+            req.ws_i32 = u.ws_i32; req.ws_f32 = u.ws_f32; req.scratch_i32 = nullptr;
+        }
+        rc = drgnn_net_train_step(p->net, &head, t.x, t.y, p->step2, t.ws_i32, t.ws_f32, cur.N, cur.E, cur.B, cur.maxN,
+                                  cur.maxE, cur.maxC, pred + cur.first * hd->O, c.readout, c.head_partials, c.partials,
+                                  c.xchg, more ? &req : nullptr, stream);
+        if (rc) return rc;
+        rc = drgnn_step_update(p->net, c.partials, cur.B, p->g_conv1, p->g_conv2, c.head_partials, c.readout, hd->R, hd->H,
+                               hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
+                               p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, 1, stream);
+        if (rc) return rc;
+        if (more) cur = nxt;
+    }
     return 0;
 }
 

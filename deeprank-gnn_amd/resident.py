@@ -1,0 +1,145 @@
+"""The dataset resident in HBM, mini-batches assembled on the device.
+
+The reference re-opens the HDF5 file and re-reads every graph, per graph and per epoch
+(reference DataSet.py:231-366, ``h5py.File`` at :241), then collates each mini-batch on the host
+(torch_geometric DataLoader, reference NeuralNet.py:153-154) and copies it to the device (:434,491).
+An MI355X holds 288 GB: the whole graph set is uploaded ONCE, graph-major with local node ids, and a
+mini-batch is a list of graph numbers handed to ``drgnn_collate`` (csrc/drgnn_collate.h) -- one launch,
+no host tensor work.  The ``Batch`` it returns has the fields, dtypes and values of
+``Batch.from_data_list`` (data.py; pinned by tests/golden/collate.npz) for the keys the path reads:
+``x, edge_index, edge_attr, batch, cluster0, cluster1, y, mol`` plus the per-graph offset tables.
+``pos`` and the internal edges, which no shipped net reads, stay on the host copy.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+from .data import Batch
+
+__all__ = ["ResidentGraphSet"]
+
+
+def _counts_to_ptr(counts):
+    ptr = np.zeros(len(counts) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(counts, dtype=np.int64), out=ptr[1:])
+    return ptr
+
+
+class ResidentGraphSet(object):
+    """``graphs``: a sequence of ``Data`` (e.g. a ``GraphDataSet``); every graph is read once."""
+
+    def __init__(self, graphs, device, api=None, indices=None):
+        self.api = api or _lib.get()
+        self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        if self.api is _lib._API and self.device.type != "cuda":
+            raise _lib.DrgnnError("ResidentGraphSet keeps the data in HBM: it needs an MI355X device, got %s. "
+                                  "There is no CPU path." % self.device)
+        order = range(len(graphs)) if indices is None else list(indices)
+        items = [graphs[i] for i in order]
+        if not items:
+            raise ValueError("cannot build a resident set from zero graphs")
+        self.mols = [getattr(g, "mol", None) for g in items]
+        first = items[0]
+        self.has_attr = first.edge_attr is not None
+        self.has_c0 = getattr(first, "cluster0", None) is not None
+        self.has_c1 = getattr(first, "cluster1", None) is not None
+        self.has_y = first.y is not None
+        for g in items:
+            if g.edge_attr is not None and g.edge_attr.dim() == 2 and g.edge_attr.size(1) != 1:
+                raise ValueError("only one edge feature is supported (the reference's layers broadcast "
+                                 "edge_attr [E,1] over the channels, sGAT.py:76)")
+        self.n_nodes = np.asarray([g.num_nodes for g in items], dtype=np.int64)
+        self.n_edges = np.asarray([g.num_edges for g in items], dtype=np.int64)
+        self.n_c1 = np.asarray([int(g.cluster1.numel()) if self.has_c1 else 0 for g in items], dtype=np.int64)
+        self.node_ptr, self.edge_ptr, self.c1_ptr = (_counts_to_ptr(c) for c in (self.n_nodes, self.n_edges, self.n_c1))
+        dev = self.device
+
+        def cat(parts, dtype, dim=0):
+            return torch.cat([p.to(dtype) for p in parts], dim=dim).contiguous().to(dev)
+        x = [g.x if g.x.dim() == 2 else g.x.reshape(-1, 1) for g in items]
+        self.x = cat(x, torch.float32)
+        self.n_feat = int(self.x.size(1))
+        self.edge_index = cat([g.edge_index.reshape(2, -1) for g in items], torch.int64, dim=1)   # local ids
+        self.edge_attr = cat([g.edge_attr.reshape(-1) for g in items], torch.float32) if self.has_attr else None
+        self.cluster0 = cat([g.cluster0 for g in items], torch.int64) if self.has_c0 else None
+        self.cluster1 = cat([g.cluster1 for g in items], torch.int64) if self.has_c1 else None
+        self.y = None
+        if self.has_y:
+            y = torch.cat([g.y.reshape(-1)[:1] for g in items])
+            self.y = (y.to(torch.float32) if y.is_floating_point() else y.to(torch.int64)).contiguous().to(dev)
+        self._ptr_dev = [torch.from_numpy(p).to(dev) for p in (self.node_ptr, self.edge_ptr, self.c1_ptr)]
+        gs = _lib.GraphSet()
+        gs.n_graphs, gs.n_nodes, gs.n_edges = len(items), int(self.node_ptr[-1]), int(self.edge_ptr[-1])
+        gs.len_cluster1 = int(self.c1_ptr[-1])
+        gs.n_feat = self.n_feat
+        gs.y_bytes = 0 if self.y is None else self.y.element_size()
+        p = _lib._ptr
+        gs.node_ptr, gs.edge_ptr = p(self._ptr_dev[0]), p(self._ptr_dev[1])
+        gs.c1_ptr = p(self._ptr_dev[2]) if self.has_c1 else None
+        gs.x, gs.edge_index, gs.edge_attr = p(self.x), p(self.edge_index), p(self.edge_attr)
+        gs.cluster0, gs.cluster1, gs.y = p(self.cluster0), p(self.cluster1), p(self.y)
+        self._desc = gs
+
+    def __len__(self):
+        return len(self.mols)
+
+    def set_targets(self, y):
+        """Replace the targets (e.g. class labels mapped to class indices); ``y``: [G] tensor."""
+        y = y.reshape(-1)
+        if y.numel() != len(self):
+            raise ValueError("expected %d targets, got %d" % (len(self), y.numel()))
+        self.y = (y.to(torch.float32) if y.is_floating_point() else y.to(torch.int64)).contiguous().to(self.device)
+        self.has_y = True
+        self._desc.y = self.y.data_ptr()
+        self._desc.y_bytes = self.y.element_size()
+
+    def upload_ids(self, ids):
+        """Graph numbers of one or more mini-batches as a device int32 tensor (slice it per batch)."""
+        ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+        if ids.size and (ids.min() < 0 or ids.max() >= len(self)):
+            raise IndexError("graph number out of range [0, %d)" % len(self))
+        return torch.from_numpy(ids.astype(np.int32)).to(self.device)
+
+    def batch(self, ids, ids_dev=None):
+        """The mini-batch of graphs ``ids`` (host sequence of graph numbers, slot order).  ``ids_dev``: the same
+        numbers already on the device (a slice of ``upload_ids`` of a whole epoch), else they are uploaded."""
+        ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+        B = int(ids.size)
+        if B == 0:
+            raise ValueError("cannot batch an empty list of graphs")
+        if ids.min() < 0 or ids.max() >= len(self):
+            raise IndexError("graph number out of range [0, %d)" % len(self))
+        if ids_dev is None:
+            ids_dev = torch.from_numpy(ids.astype(np.int32)).to(self.device)
+        elif ids_dev.numel() != B or ids_dev.dtype != torch.int32 or ids_dev.device != self.device:
+            raise ValueError("ids_dev must be the %d graph numbers as int32 on %s" % (B, self.device))
+        nn, ne, nc = self.n_nodes[ids], self.n_edges[ids], self.n_c1[ids]
+        N, E, C = int(nn.sum()), int(ne.sum()), int(nc.sum())
+        dev = self.device
+        x = torch.empty((N, self.n_feat), dtype=torch.float32, device=dev)
+        edge_index = torch.empty((2, E), dtype=torch.int64, device=dev)
+        edge_attr = torch.empty((E, 1), dtype=torch.float32, device=dev) if self.has_attr else None
+        owner = torch.empty((N,), dtype=torch.int64, device=dev)
+        cluster0 = torch.empty((N,), dtype=torch.int64, device=dev) if self.has_c0 else None
+        cluster1 = torch.empty((C,), dtype=torch.int64, device=dev) if self.has_c1 else None
+        y = torch.empty((B,), dtype=self.y.dtype, device=dev) if self.y is not None else None
+        ptrs = torch.empty((3, B + 1), dtype=torch.int32, device=dev)
+        self.api.collate(self._desc, ids_dev.contiguous(), B, N, E, x, edge_index, edge_attr, owner, cluster0,
+                         cluster1, y, ptrs[0], ptrs[1], ptrs[2] if self.has_c1 else None,
+                         _lib.current_stream(x))
+        out = Batch(batch=owner, x=x, edge_index=edge_index, edge_attr=edge_attr, y=y)
+        if self.has_c0:
+            out.cluster0 = cluster0
+        if self.has_c1:
+            out.cluster1 = cluster1
+        out.mol = [self.mols[i] for i in ids.tolist()]
+        d = out.__dict__
+        d["_num_graphs"] = B
+        d["_node_ptr"], d["_edge_ptr"] = ptrs[0], ptrs[1]
+        d["_max_nodes"], d["_max_edges"] = int(nn.max()), int(ne.max())
+        if self.has_c1:
+            d["_c1_ptr"] = ptrs[2]
+            d["_max_c0"] = int(nc.max())
+        return out

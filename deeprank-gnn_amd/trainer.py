@@ -64,6 +64,7 @@ class FusedTrainer(object):
         self.fused_step = True       # one launch for fwd + head + bwd whenever a graph fits LDS
         self._xchg = {}              # readout exchange words of the fused step, per batch size
         self._desc_cache, self._slab_cache = {}, {}
+        self._epoch_scratch = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
         self.offset = {}
         off = 0
@@ -280,6 +281,74 @@ class FusedTrainer(object):
         self.all_reduce_gradients(n_global=n_global, group=group)
         self.apply_update()
         return loss
+
+    def train_epoch(self, gset, order, batch_size):
+        """A whole epoch over the resident set ``gset`` (resident.ResidentGraphSet) in visiting order ``order``
+        (graph numbers), driven by the native loop ``drgnn_train_epoch``: per mini-batch one collate launch, the
+        fused step launch (which also builds the next mini-batch's topology) and the update launch -- no Python
+        and no host synchronisation between mini-batches.  Returns (losses [n_batches], pred [len(order), O]) as
+        device tensors, or None when this configuration needs the per-batch path (data parallel, weight decay,
+        a graph too large for the fused kernels)."""
+        import ctypes
+        import numpy as np
+        if self.weight_decay != 0.0 or not self.fused_step:
+            return None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return None
+        if not (gset.has_c0 and gset.has_c1 and gset.y is not None):
+            return None
+        need_w = self.kind == _lib.SGAT
+        if need_w and gset.edge_attr is None:
+            return None
+        want = torch.float32 if self.task == _lib.TASK_REG else torch.int64
+        if gset.y.dtype != want:
+            return None
+        ids_host = np.ascontiguousarray(np.asarray(order, dtype=np.int32).reshape(-1))
+        n = int(ids_host.size)
+        dev = self.flat_p.device
+        nb = (n + batch_size - 1) // batch_size
+        losses = torch.zeros((nb,), dtype=torch.float32, device=dev)
+        pred = torch.empty((n, self.O), dtype=torch.float32, device=dev)
+        if n == 0:
+            return losses, pred
+        ids_dev = gset.upload_ids(ids_host)
+        n_feat = gset.n_feat
+        ck = self._desc_cache.get(n_feat)
+        if ck is None:
+            g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+            g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+            for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, self.n_branch)):
+                _fill_grads(g1[b], self.kind, l1, n_feat, H1)
+                _fill_grads(g2[b], self.kind, l2, H1, H2)
+            ck = self._desc_cache[n_feat] = (g1, g2, _describe(self.kind, n_feat, self.live, self.n_branch))
+        g1, g2, desc = ck
+        head = self._head_desc(True)
+        vp = ctypes.c_void_p
+        plan = _lib.EpochPlan()
+        plan.set = ctypes.cast(ctypes.pointer(gset._desc), vp)
+        plan.host_node_ptr, plan.host_edge_ptr = gset.node_ptr.ctypes.data, gset.edge_ptr.ctypes.data
+        plan.host_c1_ptr = gset.c1_ptr.ctypes.data
+        plan.ids, plan.host_ids, plan.n_ids = ids_dev.data_ptr(), ids_host.ctypes.data, n
+        plan.batch_size, plan.need_weights = int(batch_size), int(need_w)
+        plan.net = ctypes.cast(ctypes.pointer(desc), vp)
+        plan.head = ctypes.cast(ctypes.pointer(head), vp)
+        plan.g_conv1, plan.g_conv2 = ctypes.cast(g1, vp), ctypes.cast(g2, vp)
+        plan.head_offset = self.head_grad_offset
+        plan.flat_param, plan.flat_grad = self.flat_p.data_ptr(), self.flat_g.data_ptr()
+        plan.exp_avg, plan.exp_avg_sq, plan.n_param = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.flat_p.numel()
+        plan.step2 = self.step2.data_ptr()
+        plan.lr, plan.beta1, plan.beta2, plan.eps = self.lr, self.betas[0], self.betas[1], self.eps
+        nbytes = self.api.train_epoch_scratch_bytes(plan)
+        if nbytes is None:
+            return None
+        scratch = self._epoch_scratch
+        if scratch is None or scratch.numel() < nbytes:
+            scratch = self._epoch_scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.api.train_epoch(plan, scratch, pred, losses, _lib.current_stream(self.flat_p))
+        self.last_pred = pred[(nb - 1) * batch_size:]
+        self.last_batch_size = n - (nb - 1) * batch_size
+        self.loss.copy_(losses[nb - 1:nb])
+        return losses, pred
 
     # -- torch.optim.Adam compatible optimiser state --------------------------------------
     def optimizer_state_dict(self):

@@ -387,6 +387,58 @@ int drgnn_mcl(const int64_t* edge_index, int64_t n_edges, const int32_t* node_pt
               const int64_t* mat_ptr, int64_t n_graphs, double* mat_scratch, int32_t* int_scratch,
               int64_t* labels, int32_t* info, void* stream);
 
+/* ---- device-resident graph set and mini-batch assembly --------------------
+ * Replaces the host collate of every mini-batch: torch_geometric DataLoader -> Batch.from_data_list over
+ * HDF5DataSet.load_one_graph's Data objects (NeuralNet.py:153-154, DataSet.py:231-366).  The set is the
+ * whole dataset uploaded once, graph-major: x [sumN, F]; edge_index [2, sumE] with LOCAL node ids (the
+ * per-graph tensors of DataSet.py:266-269 back to back, row block then column block); edge_attr [sumE];
+ * cluster0 [sumN]; cluster1 [sumC0]; y [G] (4- or 8-byte elements); int64 offset tables [G+1].
+ * drgnn_collate assembles the mini-batch ids[0..B) (graph numbers, any order, repeats allowed) exactly as
+ * the PyG collate does: x / cluster0 / cluster1 / edge_attr concatenated, both rows of edge_index shifted by
+ * the slot's node offset, batch[n] = slot, y gathered; plus the int32 per-slot offset tables node_ptr /
+ * edge_ptr / c1_ptr [B+1] that drgnn_topology_build and the step kernels take.  The caller sizes the
+ * outputs from its host copy of the tables (N = sum of the selected node counts, ...).  One workgroup per
+ * slot; ids outside [0, G) select an empty graph. */
+typedef struct drgnn_graph_set {
+    int64_t n_graphs, n_nodes, n_edges, len_cluster1;
+    int32_t n_feat, y_bytes;
+    const int64_t* node_ptr; const int64_t* edge_ptr; const int64_t* c1_ptr;   /* c1_ptr null: no cluster1 */
+    const float* x; const int64_t* edge_index; const float* edge_attr;          /* edge_attr may be null */
+    const int64_t* cluster0; const int64_t* cluster1; const void* y;            /* each may be null */
+} drgnn_graph_set;
+int drgnn_collate(const drgnn_graph_set* set, const int32_t* ids, int64_t n_graphs, int64_t n_nodes,
+                  int64_t n_edges, float* x, int64_t* edge_index, float* edge_attr, int64_t* batch,
+                  int64_t* cluster0, int64_t* cluster1, void* y, int32_t* node_ptr, int32_t* edge_ptr,
+                  int32_t* c1_ptr, void* stream);
+
+/* ---- one training epoch, driven natively --------------------------------------------
+ * The body of NeuralNet._epoch's loop (NeuralNet.py:486-506) for EVERY mini-batch of an epoch, enqueued on
+ * `stream` without touching the host language in between and without any synchronisation: for mini-batch k
+ *     drgnn_collate(k+1)  ->  drgnn_net_train_step(k)  [+ topology of k+1 in the same launch]  ->  drgnn_step_update
+ * with two mini-batch slots carved out of `scratch` (k trains from one while k+1 is assembled in the other).
+ * ids / host_ids: the epoch's visiting order (graph numbers of `set`) on the device and on the host; mini-batch k
+ * = ids[k*batch_size, min((k+1)*batch_size, n_ids)).  host_*_ptr: host copies of the set's offset tables (they size
+ * every launch).  Outputs: pred [n_ids, O] in visiting order, losses [ceil(n_ids / batch_size)] (mean loss of each
+ * mini-batch, what the reference accumulates with loss.item()).  Model / optimiser arguments as for
+ * drgnn_net_train_step / drgnn_step_update.  Returns DRGNN_E_CAPACITY when some graph does not fit the fused step
+ * kernel's or the topology builder's LDS budget (the caller then steps mini-batch by mini-batch).
+ * drgnn_train_epoch_scratch_bytes: bytes of device scratch the plan needs (< 0: error code). */
+typedef struct drgnn_epoch_plan {
+    const drgnn_graph_set* set;
+    const int64_t* host_node_ptr; const int64_t* host_edge_ptr; const int64_t* host_c1_ptr;
+    const int32_t* ids; const int32_t* host_ids; int64_t n_ids;
+    int32_t batch_size, need_weights;
+    const drgnn_net_desc* net; const drgnn_head_desc* head;
+    drgnn_conv_grads* g_conv1; drgnn_conv_grads* g_conv2;
+    int64_t head_offset;
+    float* flat_param; float* flat_grad; float* exp_avg; float* exp_avg_sq; int64_t n_param;
+    int32_t* step2;
+    float lr, beta1, beta2, eps;
+} drgnn_epoch_plan;
+int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan);
+int drgnn_train_epoch(const drgnn_epoch_plan* plan, void* scratch, int64_t scratch_bytes, float* pred,
+                      float* losses, void* stream);
+
 int drgnn_abi_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,52 @@
+"""drgnn_train_epoch (native epoch loop over the resident set) against stepping the same mini-batches one by one
+through FusedTrainer.train_step on host-collated batches.  Shared by the emulated (CPU) and the MI355X test."""
+import copy
+
+import numpy as np
+import torch
+
+from deeprank_gnn_amd.data import Batch
+from deeprank_gnn_amd.resident import ResidentGraphSet
+from deeprank_gnn_amd.trainer import FusedTrainer
+
+
+def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=2, seed=0, exact=True):
+    torch.manual_seed(seed)
+    n_out = 1 if task == "reg" else 3
+    net = Net(n_feat, n_out, 1).to(device)
+    if hasattr(net, "dropout"):
+        net.dropout = 0.4                       # the dropout stream follows the step counter in both paths
+    rs = ResidentGraphSet(graphs, device, api=api)
+    if task == "class":
+        labels = torch.arange(len(graphs)) % n_out
+        rs.set_targets(labels)
+        graphs = [copy.copy(g) for g in graphs]
+        for g, lab in zip(graphs, labels.tolist()):
+            g.y = torch.tensor([lab])
+    tr_a = FusedTrainer(net, lr=1e-2, task=task, api=api, seed=7)
+    tr_b = FusedTrainer(copy.deepcopy(net), lr=1e-2, task=task, api=api, seed=7)
+    rng = np.random.default_rng(seed)
+    for _ in range(epochs):
+        order = rng.permutation(len(graphs)).tolist()
+        got = tr_a.train_epoch(rs, order, batch_size)
+        assert got is not None, "the native epoch loop refused a configuration that fits"
+        losses, pred = got
+        want_l, want_p = [], []
+        for lo in range(0, len(order), batch_size):
+            b = Batch.from_data_list([graphs[i] for i in order[lo:lo + batch_size]]).to(device)
+            want_l.append(float(tr_b.train_step(b)))
+            want_p.append(tr_b.last_pred.detach().cpu().clone())
+        want_p = torch.cat(want_p)
+        if exact:
+            assert losses.cpu().tolist() == want_l
+            assert torch.equal(pred.cpu(), want_p)
+        else:
+            np.testing.assert_allclose(losses.cpu().numpy(), want_l, rtol=1e-5)
+            np.testing.assert_allclose(pred.cpu().numpy(), want_p.numpy(), rtol=1e-4, atol=1e-5)
+    assert int(tr_a.step) == int(tr_b.step) == epochs * ((len(graphs) + batch_size - 1) // batch_size)
+    if exact:
+        assert torch.equal(tr_a.flat_p.cpu(), tr_b.flat_p.cpu())
+        assert torch.equal(tr_a.exp_avg_sq.cpu(), tr_b.exp_avg_sq.cpu())
+    else:
+        np.testing.assert_allclose(tr_a.flat_p.cpu().numpy(), tr_b.flat_p.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    return tr_a

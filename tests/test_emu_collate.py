@@ -1,0 +1,50 @@
+"""Resident graph set + device collate, kernels emulated on the CPU."""
+import numpy as np
+import pytest
+import torch
+
+from collate_check import check_collate, ragged_graphs
+from emu_api import emu
+from helpers import fixture_graphs, syn4_graphs
+from deeprank_gnn_amd.resident import ResidentGraphSet
+from deeprank_gnn_amd import _lib
+
+
+@pytest.mark.parametrize("n_feat", [1, 7, 12, 32])
+def test_collate_ragged(n_feat):
+    check_collate(ragged_graphs(3 + n_feat, n_feat), "cpu", api=emu())
+
+
+def test_collate_fixture_and_synthetic():
+    check_collate(fixture_graphs(), "cpu", api=emu())
+    check_collate(syn4_graphs(), "cpu", api=emu())
+
+
+def test_collate_without_optional_fields():
+    graphs = ragged_graphs(1, 5)
+    for g in graphs:
+        g.edge_attr = None
+        g.y = None
+        g.__dict__.pop("cluster1", None)
+    check_collate(graphs, "cpu", api=emu())
+
+
+def test_collate_class_targets_and_errors():
+    graphs = ragged_graphs(2, 4)
+    rs = ResidentGraphSet(graphs, "cpu", api=emu())
+    rs.set_targets(torch.arange(len(graphs)) % 2)
+    b = rs.batch([3, 1, 4])
+    assert b.y.dtype == torch.int64 and b.y.tolist() == [1, 1, 0]
+    with pytest.raises(IndexError):
+        rs.batch([0, len(graphs)])
+    with pytest.raises(ValueError):
+        rs.batch([])
+    with pytest.raises(ValueError):
+        rs.batch([0, 1], torch.zeros(3, dtype=torch.int32))
+
+
+def test_resident_set_refuses_cpu_without_emulation():
+    if not __import__("os").path.exists(_lib.LIB_PATH):
+        pytest.skip("product library not built")
+    with pytest.raises(_lib.DrgnnError):
+        ResidentGraphSet(ragged_graphs(0, 3), "cpu")

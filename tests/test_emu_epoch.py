@@ -1,0 +1,20 @@
+"""Native epoch loop (drgnn_train_epoch), kernels emulated on the CPU."""
+import pytest
+
+from collate_check import ragged_graphs
+from emu_api import emu
+from epoch_check import check_epoch
+from helpers import fixture_graphs, NODE_FEATURES
+from deeprank_gnn_amd.ginet import GINet
+from deeprank_gnn_amd.sGAT import sGAT
+from deeprank_gnn_amd.foutnet import FoutNet
+
+
+@pytest.mark.parametrize("Net,task,bs", [(GINet, "reg", 4), (sGAT, "reg", 3), (FoutNet, "reg", 9), (GINet, "class", 2),
+                                         (FoutNet, "class", 5)])
+def test_epoch_ragged(Net, task, bs):
+    check_epoch(Net, ragged_graphs(11, 12), 12, task, "cpu", bs, api=emu())
+
+
+def test_epoch_fixture():
+    check_epoch(GINet, fixture_graphs(), 28, "reg", "cpu", 4, api=emu())

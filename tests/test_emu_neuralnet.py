@@ -57,9 +57,11 @@ def test_needs_gpu_without_emulation():
         NeuralNet(DB, GINet, node_feature=NODE_FEATURES, target='irmsd')
 
 
-def test_epoch_with_several_batches_uses_the_lookahead(tmp_path):
+@pytest.mark.parametrize("native_epoch", [False, True])
+def test_epoch_with_several_batches_uses_the_lookahead(tmp_path, native_epoch):
     """batch_size 3 -> three mini-batches per epoch: the topology of batch k+1 is built inside
-    the backward launch of batch k.  Same losses as stepping every batch with its own build."""
+    the backward launch of batch k.  Same losses as stepping every batch with its own build, from the
+    Python loop and from the native epoch loop (drgnn_train_epoch)."""
     from deeprank_gnn_amd.topology import Topology
     built = {"n": 0}
     orig = Topology.rebuild
@@ -71,12 +73,14 @@ def test_epoch_with_several_batches_uses_the_lookahead(tmp_path):
     np.random.seed(0)
     nn = NeuralNet(DB, sGAT, node_feature=NODE_FEATURES, edge_feature=['dist'], target='irmsd',
                    batch_size=3, percent=[0.8, 0.2], shuffle=False, outdir=str(tmp_path), _api=emu(), device='cpu')
+    nn.native_epoch = native_epoch
     Topology.rebuild = counting
     try:
         nn.train(nepoch=2, validate=False, save_model=None, hdf5=None)
     finally:
         Topology.rebuild = orig
-    assert built["n"] == 2                     # one explicit build per epoch (first batch); the rest rode along
+    # Python loop: one explicit build per epoch (first batch), the rest rode along; native loop: none from Python
+    assert built["n"] == (0 if native_epoch else 2)
     assert np.isfinite(nn.train_loss).all() and nn.train_loss[1] < nn.train_loss[0]
     # reference run: every batch builds its own topology
     torch.manual_seed(0)
@@ -90,3 +94,30 @@ def test_epoch_with_several_batches_uses_the_lookahead(tmp_path):
             run += float(ref.trainer.train_step(batch))
         total.append(run)
     np.testing.assert_allclose(nn.train_loss, total, rtol=1e-6)
+
+
+def test_resident_batches_train_like_host_collated_batches(tmp_path):
+    """The epoch loop takes its mini-batches from the resident set (device collate); stepping a twin trainer
+    over Batch.from_data_list of the same graphs in the same order gives the same losses and predictions."""
+    from deeprank_gnn_amd.data import Batch
+    torch.manual_seed(0)
+    np.random.seed(0)
+    kw = dict(node_feature=NODE_FEATURES, edge_feature=['dist'], target='irmsd', batch_size=4, percent=[1.0, 0.0],
+              shuffle=False, outdir=str(tmp_path), _api=emu(), device='cpu')
+    nn = NeuralNet(DB, FoutNet, **kw)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    twin = NeuralNet(DB, FoutNet, **kw)
+    nn.train(nepoch=2, validate=False, save_model=None, hdf5=None)
+    losses, outs = [], []
+    for _ in range(2):
+        run, outs = 0.0, []
+        order = list(twin.train_index)
+        for lo in range(0, len(order), 4):
+            host = Batch.from_data_list([twin.dataset[i] for i in order[lo:lo + 4]])
+            run += float(twin.trainer.train_step(host))
+            outs += twin.trainer.last_pred.reshape(-1).tolist()
+        losses.append(run)
+    np.testing.assert_allclose(nn.train_loss, losses, rtol=1e-6)
+    np.testing.assert_allclose(nn.data['epoch_0002/train']['outputs'], outs, rtol=1e-6)
+    assert nn.data['epoch_0002/train']['mol'] == [twin.dataset.mols[i] for i in twin.train_index]
