@@ -56,7 +56,9 @@ class TopologyRequest(ctypes.Structure):
                 ("node_ptr", _vp), ("edge_ptr", _vp), ("c1_ptr", _vp),
                 ("n_nodes", _c_i64), ("n_edges", _c_i64), ("len_cluster1", _c_i64), ("n_graphs", _c_i64),
                 ("max_nodes", _c_i32), ("max_edges", _c_i32),
-                ("ws_i32", _vp), ("ws_f32", _vp), ("scratch_i32", _vp)]
+                ("ws_i32", _vp), ("ws_f32", _vp), ("scratch_i32", _vp),
+                # resident-set mode (include/drgnn.h); left NULL by the Python-level Topology
+                ("set", _vp), ("ids", _vp), ("x_out", _vp), ("y_out", _vp)]
 
 
 class GraphSet(ctypes.Structure):
@@ -168,6 +170,8 @@ class Api(object):
         lib.drgnn_train_epoch_scratch_bytes.argtypes = [ctypes.POINTER(EpochPlan)]
         lib.drgnn_train_epoch_scratch_bytes.restype = _c_i64
         lib.drgnn_train_epoch.argtypes = [ctypes.POINTER(EpochPlan), _vp, _c_i64, _vp, _vp, _vp]
+        lib.drgnn_topology_build_request.argtypes = [ctypes.POINTER(TopologyRequest), _vp]
+        lib.drgnn_batch_offsets.argtypes = [ctypes.POINTER(GraphSet), _vp, _c_i64, _c_i32, _vp, _vp]
         lib.drgnn_collate.argtypes = [ctypes.POINTER(GraphSet), _vp] + [_c_i64] * 3 + [_vp] * 11
         lib.drgnn_head_partial_elems.argtypes = [_c_i32] * 3
         lib.drgnn_head_partial_elems.restype = _c_i64
@@ -334,6 +338,13 @@ class Api(object):
                                       _ptr(edge_index), _ptr(edge_attr), _ptr(batch), _ptr(cluster0),
                                       _ptr(cluster1), _ptr(y), _ptr(node_ptr), _ptr(edge_ptr), _ptr(c1_ptr),
                                       stream), "drgnn_collate")
+
+    def topology_build_request(self, request, stream):
+        _check(self.lib.drgnn_topology_build_request(ctypes.byref(request), stream), "drgnn_topology_build_request")
+
+    def batch_offsets(self, gset, ids, n_ids, batch_size, ptrs, stream):
+        _check(self.lib.drgnn_batch_offsets(ctypes.byref(gset), _ptr(ids), n_ids, batch_size, _ptr(ptrs), stream),
+               "drgnn_batch_offsets")
 
     def train_epoch_scratch_bytes(self, plan):
         """Bytes of device scratch for the plan; None when a graph does not fit the fused kernels."""

@@ -130,7 +130,7 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
         int len = C0;
         if (g == L.args.n_graphs - 1 && (int64_t)begin + C0 != L.args.len_cluster1) len = -1;
         if ((int64_t)begin + C0 > L.args.len_cluster1) len = -1;
-        topo_graph_level1(L.tv, L.args, g, n0, C0, begin, len, s, g);
+        topo_graph_level1(L.tv, L.args, g, n0, C0, L.args.cluster1 + begin, len, s, g);
     }
 }
 
@@ -438,6 +438,10 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_mcl(MclArgs a) {
     __shared__ int flag[2];
     mcl_graph(a, blockIdx.x, flag, red);
 }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_batch_offsets(OffsetsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int smem_o[];
+    batch_offsets_block(a, blockIdx.x, smem_o + DRGNN_NTHREADS + 4, smem_o);
+}
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_collate(CollateArgs a) {
     __shared__ int sh[4];
     collate_block(a, blockIdx.x, sh);
@@ -540,7 +544,8 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
                         int64_t n_nodes, int64_t n_edges, int64_t len_cluster1, int64_t n_graphs,
                         int32_t max_nodes, int32_t max_edges, int32_t* ws_i32, float* ws_f32,
                         int32_t* scratch_i32) {
-    if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !ws_i32 || !batch) return DRGNN_E_ARG;
+    if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !ws_i32) return DRGNN_E_ARG;
+    if (!batch && !(node_ptr && edge_ptr)) return DRGNN_E_ARG;      // the offsets are derived from `batch`
     if (!cluster0 && cluster1) return DRGNN_E_ARG;
     if (n_edges > 0 && !edge_index) return DRGNN_E_ARG;
     if (edge_attr && !ws_f32) return DRGNN_E_ARG;
@@ -556,6 +561,9 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     L.args.n_edges = n_edges;
     L.args.len_cluster1 = len_cluster1;
     L.args.n_graphs = (int)n_graphs;
+    L.args.set_ids = nullptr; L.args.set_node_ptr = L.args.set_edge_ptr = L.args.set_c1_ptr = nullptr;
+    L.args.set_x = nullptr; L.args.set_y = nullptr; L.args.x_out = nullptr; L.args.y_out = nullptr;
+    L.args.n_set = 0; L.args.n_feat = 0; L.args.y_bytes = 0;
     L.gscratch = scratch_i32;
     L.level1_only = 0;
     L.roles = 1;
@@ -573,6 +581,30 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     if (L.capN > 0 && cluster0 != nullptr && L.user_nptr != nullptr && !(cluster1 != nullptr && c1_ptr == nullptr))
         L.roles = 2;
     *lds_out = lds;
+    return 0;
+}
+
+// a request in either mode -> launch description
+static int topo_prepare_req(TopoLaunch& T, int64_t* tlds, const drgnn_topology_request* r) {
+    const drgnn_graph_set* gs = r->set;
+    if (!gs)
+        return topo_prepare(T, tlds, r->edge_index, r->edge_attr, r->batch, r->cluster0, r->cluster1, r->node_ptr,
+                            r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs, r->max_nodes,
+                            r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32);
+    if (!r->ids || !r->node_ptr || !r->edge_ptr || !gs->node_ptr || !gs->edge_ptr || !gs->cluster0) return DRGNN_E_ARG;
+    if (gs->cluster1 && (!gs->c1_ptr || !r->c1_ptr)) return DRGNN_E_ARG;
+    if (r->x_out && (!gs->x || gs->n_feat <= 0)) return DRGNN_E_ARG;
+    if (r->y_out && (!gs->y || (gs->y_bytes != 4 && gs->y_bytes != 8))) return DRGNN_E_ARG;
+    const float* attr = (r->ws_f32 && gs->edge_attr) ? gs->edge_attr : nullptr;
+    const int rc = topo_prepare(T, tlds, gs->edge_index, attr, nullptr, gs->cluster0, gs->cluster1, r->node_ptr,
+                                r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs,
+                                r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32);
+    if (rc) return rc;
+    TopoArgs& a = T.args;
+    a.n_edges = gs->n_edges;                  // row stride of the SET's edge_index
+    a.set_ids = r->ids; a.set_node_ptr = gs->node_ptr; a.set_edge_ptr = gs->edge_ptr; a.set_c1_ptr = gs->c1_ptr;
+    a.set_x = gs->x; a.set_y = gs->y; a.x_out = r->x_out; a.y_out = r->y_out;
+    a.n_set = gs->n_graphs; a.n_feat = gs->n_feat; a.y_bytes = gs->y_bytes;
     return 0;
 }
 
@@ -628,6 +660,56 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
         if (L.capN > 0) hipLaunchKernelGGL(k_topo<true>, dim3((unsigned)(n_graphs * L.roles)), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
         else hipLaunchKernelGGL(k_topo<false>, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, stream, L);
     }
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_topology_build_request(const drgnn_topology_request* r, void* stream_) {
+    if (!r) return DRGNN_E_ARG;
+    if (!r->set)
+        return drgnn_topology_build(r->edge_index, r->edge_attr, r->batch, r->cluster0, r->cluster1, r->node_ptr,
+                                    r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs,
+                                    r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, stream_);
+    TopoLaunch L;
+    int64_t lds = 0;
+    const int rc = topo_prepare_req(L, &lds, r);
+    if (rc) return rc;
+    if (L.capN == 0 && !r->scratch_i32) return DRGNN_E_CAPACITY;
+    if (r->n_graphs == 0) return 0;
+#ifdef DRGNN_EMU
+    std::vector<int> lds_buf((size_t)(lds / 4) + 16);
+    for (int gph = 0; gph < r->n_graphs * L.roles; ++gph) {
+        if (L.capN > 0) topo_block<true>(L, gph, lds_buf.data());
+        else topo_block<false>(L, gph, lds_buf.data());
+    }
+    (void)stream_;
+#else
+    hipStream_t stream = (hipStream_t)stream_;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_topo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (L.capN > 0) hipLaunchKernelGGL(k_topo<true>, dim3((unsigned)(r->n_graphs * L.roles)), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
+    else hipLaunchKernelGGL(k_topo<false>, dim3((unsigned)r->n_graphs), dim3(DRGNN_NTHREADS), 0, stream, L);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_batch_offsets(const drgnn_graph_set* set, const int32_t* ids, int64_t n_ids, int32_t batch_size,
+                        int32_t* ptrs, void* stream_) {
+    if (!set || !ids || !ptrs || n_ids < 0 || batch_size < 1 || !set->node_ptr || !set->edge_ptr) return DRGNN_E_ARG;
+    if (batch_size > 4096) return DRGNN_E_CAPACITY;
+    if (n_ids == 0) return 0;
+    OffsetsArgs a;
+    a.set = *set; a.ids = ids; a.n_ids = n_ids; a.batch_size = batch_size; a.ptrs = ptrs;
+    const int64_t nb = (n_ids + batch_size - 1) / batch_size;
+    const size_t words = (size_t)DRGNN_NTHREADS + 4 + 3 * ((size_t)batch_size + 1);
+#ifdef DRGNN_EMU
+    std::vector<int> buf(words);
+    for (int64_t k = 0; k < nb; ++k) batch_offsets_block(a, (int)k, buf.data() + DRGNN_NTHREADS + 4, buf.data());
+    (void)stream_;
+#else
+    hipLaunchKernelGGL(k_batch_offsets, dim3((unsigned)nb), dim3(DRGNN_NTHREADS), words * 4, (hipStream_t)stream_, a);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;
@@ -860,19 +942,13 @@ static int net_backward_impl(const drgnn_net_desc* net, const float* x, const fl
     }
     TopoLaunch T;
     int64_t tlds = 0;
-    rc = topo_prepare(T, &tlds, next->edge_index, next->edge_attr, next->batch, next->cluster0, next->cluster1,
-                      next->node_ptr, next->edge_ptr, next->c1_ptr, next->n_nodes, next->n_edges,
-                      next->len_cluster1, next->n_graphs, next->max_nodes, next->max_edges, next->ws_i32,
-                      next->ws_f32, next->scratch_i32);
+    rc = topo_prepare_req(T, &tlds, next);
     if (rc) return rc;
     const int rc2 = net_launch<true>(L, max_nodes, max_edges, max_c0, scratch_f32, stream_, &T, tlds);
     if (rc2 < 0 || rc2 > 1) return rc2;
     if (rc2 == 1) return 0;
     // could not share the launch: build the next topology with its own launches
-    return drgnn_topology_build(next->edge_index, next->edge_attr, next->batch, next->cluster0, next->cluster1,
-                                next->node_ptr, next->edge_ptr, next->c1_ptr, next->n_nodes, next->n_edges,
-                                next->len_cluster1, next->n_graphs, next->max_nodes, next->max_edges,
-                                next->ws_i32, next->ws_f32, next->scratch_i32, stream_);
+    return drgnn_topology_build_request(next, stream_);
 }
 
 }  // extern "C"
@@ -972,10 +1048,7 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
     int64_t tlds = 0;
     bool co_ok = false;
     if (next) {
-        rc = topo_prepare(T, &tlds, next->edge_index, next->edge_attr, next->batch, next->cluster0, next->cluster1,
-                          next->node_ptr, next->edge_ptr, next->c1_ptr, next->n_nodes, next->n_edges,
-                          next->len_cluster1, next->n_graphs, next->max_nodes, next->max_edges, next->ws_i32,
-                          next->ws_f32, next->scratch_i32);
+        rc = topo_prepare_req(T, &tlds, next);
         if (rc) return rc;
         co_ok = T.capN > 0 && T.user_nptr != nullptr && !(T.args.cluster1 != nullptr && T.args.c1_ptr == nullptr) &&
                 T.args.n_graphs > 0 && blocks > 0;
@@ -1032,10 +1105,7 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
 #endif
     }
     if (next && (!co_ok || blocks == 0))
-        return drgnn_topology_build(next->edge_index, next->edge_attr, next->batch, next->cluster0, next->cluster1,
-                                    next->node_ptr, next->edge_ptr, next->c1_ptr, next->n_nodes, next->n_edges,
-                                    next->len_cluster1, next->n_graphs, next->max_nodes, next->max_edges,
-                                    next->ws_i32, next->ws_f32, next->scratch_i32, stream_);
+        return drgnn_topology_build_request(next, stream_);
     return 0;
 }
 
@@ -1445,12 +1515,10 @@ int drgnn_collate(const drgnn_graph_set* set, const int32_t* ids, int64_t n_grap
 // ---- one training epoch, driven from here ---------------------------------------------------------
 namespace {
 struct EpochBatch { int64_t first, B, N, E, C; int maxN, maxE, maxC; };
-struct EpochSlot {
-    float* x; int64_t* edge_index; float* edge_attr; int64_t* batch; int64_t* cluster0; int64_t* cluster1; void* y;
-    int32_t* ptrs; int32_t* ws_i32; float* ws_f32;
-};
+struct EpochSlot { float* x; void* y; int32_t* ws_i32; float* ws_f32; };
 struct EpochCarve {
     EpochSlot slot[2];
+    int32_t* ptrs;                 // [n_batches][3][batch_size + 1]
     float* readout; float* partials; float* head_partials; uint64_t* xchg; int64_t xchg_bytes;
     int64_t bytes;
 };
@@ -1464,7 +1532,7 @@ int epoch_batch(const drgnn_epoch_plan* p, int64_t k, EpochBatch* b) {
         if (id < 0 || id >= G) return DRGNN_E_ARG;
         const int64_t n = p->host_node_ptr[id + 1] - p->host_node_ptr[id];
         const int64_t e = p->host_edge_ptr[id + 1] - p->host_edge_ptr[id];
-        const int64_t c = p->host_c1_ptr ? p->host_c1_ptr[id + 1] - p->host_c1_ptr[id] : 0;
+        const int64_t c = p->host_c1_ptr[id + 1] - p->host_c1_ptr[id];
         if (n < 0 || e < 0 || c < 0) return DRGNN_E_ARG;
         b->N += n; b->E += e; b->C += c;
         if (n > b->maxN) b->maxN = (int)n;
@@ -1478,10 +1546,14 @@ int epoch_check(const drgnn_epoch_plan* p) {
         p->batch_size < 1 || !p->net || !p->head || !p->g_conv1 || !p->g_conv2 || !p->flat_param || !p->flat_grad ||
         !p->exp_avg || !p->exp_avg_sq || !p->step2)
         return DRGNN_E_ARG;
-    if (!p->set->cluster0 || !p->set->cluster1 || !p->set->c1_ptr || !p->host_c1_ptr || !p->set->y) return DRGNN_E_ARG;
-    if (p->need_weights && !p->set->edge_attr) return DRGNN_E_ARG;
-    if (p->set->n_feat != p->net->n_feat) return DRGNN_E_WIDTH;
-    if (p->set->y_bytes != (p->head->task == DRGNN_TASK_REG ? 4 : 8)) return DRGNN_E_ARG;
+    const drgnn_graph_set* gs = p->set;
+    if (!gs->node_ptr || !gs->edge_ptr || !gs->x || !gs->cluster0 || !gs->cluster1 || !gs->c1_ptr || !p->host_c1_ptr || !gs->y)
+        return DRGNN_E_ARG;
+    if (gs->n_edges > 0 && !gs->edge_index) return DRGNN_E_ARG;
+    if (p->need_weights && !gs->edge_attr) return DRGNN_E_ARG;
+    if (gs->n_feat != p->net->n_feat) return DRGNN_E_WIDTH;
+    if (gs->y_bytes != (p->head->task == DRGNN_TASK_REG ? 4 : 8)) return DRGNN_E_ARG;
+    if (p->batch_size > 4096) return DRGNN_E_CAPACITY;
     return 0;
 }
 // sizes the two mini-batch slots and the step slabs for the largest mini-batch of the plan
@@ -1489,22 +1561,20 @@ int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
     int rc = epoch_check(p);
     if (rc) return rc;
     const int64_t nb = (p->n_ids + p->batch_size - 1) / p->batch_size;
-    int64_t capN = 1, capE = 1, capC = 1, capB = 1, ws_i = 4, ws_f = 4;
+    int64_t capN = 1, capB = 1, ws_i = 4, ws_f = 4;
     const drgnn_head_desc* hd = p->head;
     for (int64_t k = 0; k < nb; ++k) {
         EpochBatch b;
         if ((rc = epoch_batch(p, k, &b))) return rc;
         if (b.maxN <= 0) return DRGNN_E_CAPACITY;
         if (drgnn_net_step_lds_bytes(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O) > DRGNN_LDS_LIMIT ||
-            b.maxN > 32767 || b.maxE > 65535 || drgnn_topology_lds_bytes(b.maxN, b.maxE) > DRGNN_LDS_LIMIT)
+            b.maxN > 32767 || b.maxE > 65535 || drgnn_topology_lds_bytes(b.maxN, b.maxE > 0 ? b.maxE : 1) > DRGNN_LDS_LIMIT)
             return DRGNN_E_CAPACITY;
         TopoLayout lay;
         topo_layout(b.N, b.E, b.B, &lay);
         if (lay.i32[DRGNN_TI_COUNT] > ws_i) ws_i = lay.i32[DRGNN_TI_COUNT];
         if (lay.f32[DRGNN_TF_COUNT] > ws_f) ws_f = lay.f32[DRGNN_TF_COUNT];
         if (b.N > capN) capN = b.N;
-        if (b.E > capE) capE = b.E;
-        if (b.C > capC) capC = b.C;
         if (b.B > capB) capB = b.B;
     }
     int64_t o = 0;
@@ -1513,16 +1583,11 @@ int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
     for (int s = 0; s < 2; ++s) {
         EpochSlot& t = c->slot[s];
         t.x = (float*)take(capN * F * 4);
-        t.edge_index = (int64_t*)take(2 * capE * 8);
-        t.edge_attr = p->need_weights ? (float*)take(capE * 4) : nullptr;
-        t.batch = (int64_t*)take(capN * 8);
-        t.cluster0 = (int64_t*)take(capN * 8);
-        t.cluster1 = (int64_t*)take(capC * 8);
         t.y = take(capB * 8);
-        t.ptrs = (int32_t*)take(3 * (capB + 1) * 4);
         t.ws_i32 = (int32_t*)take(ws_i * 4);
         t.ws_f32 = p->need_weights ? (float*)take(ws_f * 4) : nullptr;
     }
+    c->ptrs = (int32_t*)take((nb > 0 ? nb : 1) * 3 * ((int64_t)p->batch_size + 1) * 4);
     c->readout = (float*)take(capB * hd->R * 4);
     c->partials = (float*)take(capB * nbr * drgnn_net_partial_elems(p->net->kind, F) * 4);
     c->head_partials = (float*)take(capB * drgnn_head_compact_elems(hd->R, hd->H, hd->O) * 4);
@@ -1557,20 +1622,25 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
 #else
     HIP_TRY(hipMemsetAsync(c.xchg, 0, (size_t)c.xchg_bytes, (hipStream_t)stream));
 #endif
-    auto collate = [&](int64_t k, const EpochBatch& b) {
-        const EpochSlot& t = c.slot[k & 1];
-        return drgnn_collate(p->set, p->ids + b.first, b.B, b.N, b.E, t.x, t.edge_index, t.edge_attr, t.batch, t.cluster0,
-                             t.cluster1, t.y, t.ptrs, t.ptrs + (b.B + 1), t.ptrs + 2 * (b.B + 1), stream);
+    if ((rc = drgnn_batch_offsets(p->set, p->ids, p->n_ids, p->batch_size, c.ptrs, stream))) return rc;
+    const int64_t W = (int64_t)p->batch_size + 1;
+    // mini-batch k's topology + node features + targets, straight from the resident set into slot k & 1
+    auto request = [&](int64_t k, const EpochBatch& b) {
+        const EpochSlot& u = c.slot[k & 1];
+        drgnn_topology_request r = {};
+        int32_t* pk = c.ptrs + k * 3 * W;
+        r.node_ptr = pk; r.edge_ptr = pk + W; r.c1_ptr = pk + 2 * W;
+        r.n_nodes = b.N; r.n_edges = b.E; r.len_cluster1 = b.C; r.n_graphs = b.B;
+        r.max_nodes = b.maxN; r.max_edges = b.maxE;
+        r.ws_i32 = u.ws_i32; r.ws_f32 = u.ws_f32; r.scratch_i32 = nullptr;
+        r.set = p->set; r.ids = p->ids + b.first; r.x_out = u.x; r.y_out = u.y;
+        return r;
     };
     EpochBatch cur, nxt;
     if ((rc = epoch_batch(p, 0, &cur))) return rc;
-    if ((rc = collate(0, cur))) return rc;
     {
-        const EpochSlot& t = c.slot[0];
-        rc = drgnn_topology_build(t.edge_index, t.edge_attr, t.batch, t.cluster0, t.cluster1, t.ptrs, t.ptrs + (cur.B + 1),
-                                  t.ptrs + 2 * (cur.B + 1), cur.N, cur.E, cur.C, cur.B, cur.maxN, cur.maxE, t.ws_i32,
-                                  t.ws_f32, nullptr, stream);
-        if (rc) return rc;
+        const drgnn_topology_request r0 = request(0, cur);
+        if ((rc = drgnn_topology_build_request(&r0, stream))) return rc;
     }
     for (int64_t k = 0; k < nb; ++k) {
         const EpochSlot& t = c.slot[k & 1];
@@ -1578,14 +1648,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         const bool more = k + 1 < nb;
         if (more) {
             if ((rc = epoch_batch(p, k + 1, &nxt))) return rc;
-            if ((rc = collate(k + 1, nxt))) return rc;
-            const EpochSlot& u = c.slot[(k + 1) & 1];
-            req.edge_index = u.edge_index; req.edge_attr = u.edge_attr; req.batch = u.batch;
-            req.cluster0 = u.cluster0; req.cluster1 = u.cluster1;
-            req.node_ptr = u.ptrs; req.edge_ptr = u.ptrs + (nxt.B + 1); req.c1_ptr = u.ptrs + 2 * (nxt.B + 1);
-            req.n_nodes = nxt.N; req.n_edges = nxt.E; req.len_cluster1 = nxt.C; req.n_graphs = nxt.B;
-            req.max_nodes = nxt.maxN; req.max_edges = nxt.maxE;
-            req.ws_i32 = u.ws_i32; req.ws_f32 = u.ws_f32; req.scratch_i32 = nullptr;
+            req = request(k + 1, nxt);
         }
         rc = drgnn_net_train_step(p->net, &head, t.x, t.y, p->step2, t.ws_i32, t.ws_f32, cur.N, cur.E, cur.B, cur.maxN,
                                   cur.maxE, cur.maxC, pred + cur.first * hd->O, c.readout, c.head_partials, c.partials,

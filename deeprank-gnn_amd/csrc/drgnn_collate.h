@@ -103,3 +103,27 @@ DEV void collate_block(const CollateArgs& a, int g, int* sh) {
         FOR_TID(j, c) { a.cluster1[c0 + j] = s.cluster1[sc + j]; }
     }
 }
+
+// prefix sums of the slots' extents, one workgroup per mini-batch (cnt: 3 * (batch_size + 1) ints + scan scratch)
+struct OffsetsArgs {
+    drgnn_graph_set set; const int32_t* ids; int64_t n_ids; int batch_size; int32_t* ptrs;
+};
+DEV void batch_offsets_block(const OffsetsArgs& a, int k, int* cnt, int* part) {
+    const int W = a.batch_size + 1;
+    const int64_t first = (int64_t)k * a.batch_size;
+    const int B = (int)((a.n_ids - first) < a.batch_size ? (a.n_ids - first) : a.batch_size);
+    const int G = (int)a.set.n_graphs;
+    FOR_TID(q, 3 * W) { cnt[q] = 0; }
+    BARRIER();
+    FOR_TID(q, B) {
+        const int id = a.ids[first + q];
+        int64_t f; int c;
+        collate_extent(a.set.node_ptr, G, id, &f, &c); cnt[q] = c;
+        collate_extent(a.set.edge_ptr, G, id, &f, &c); cnt[W + q] = c;
+        collate_extent(a.set.c1_ptr, G, id, &f, &c); cnt[2 * W + q] = c;
+    }
+    BARRIER();
+    for (int t = 0; t < 3; ++t) wg_exscan(cnt + t * W, W, part);
+    int32_t* out = a.ptrs + (int64_t)k * 3 * W;
+    FOR_TID(q, 3 * W) { out[q] = cnt[q]; }
+}

@@ -307,17 +307,85 @@ struct TopoArgs {
     int64_t n_edges;
     int64_t len_cluster1;
     int n_graphs;
+    // Resident-set mode (set_ids != null): the arrays above are those of the WHOLE graph set (graph-major, local
+    // node ids, n_edges = the set's edge total) and slot g of the mini-batch is graph set_ids[g] of the set; the
+    // builder then also gathers the slot's node features and target into the mini-batch's compact buffers.
+    const int32_t* set_ids;       // [B] or null
+    const int64_t* set_node_ptr;  // [G+1]
+    const int64_t* set_edge_ptr;  // [G+1]
+    const int64_t* set_c1_ptr;    // [G+1]
+    const float* set_x;           // [sumN, F]
+    const void* set_y;            // [G] elements of y_bytes bytes, or null
+    float* x_out;                 // [N, F] of the mini-batch
+    void* y_out;                  // [B]
+    int64_t n_set;
+    int n_feat, y_bytes;
 };
 
+// where slot g's index data lives: in the mini-batch tensors (global ids, shifted by n0) or in the resident set
+struct TopoSrc {
+    const int64_t* row; const int64_t* col; const float* attr; const int64_t* cl0; const int64_t* cl1;
+    long long shift; long long x_row;
+};
+DEV TopoSrc topo_src(const TopoArgs& a, int g, int n0, int e0) {
+    TopoSrc t;
+    if (a.set_ids == nullptr) {
+        t.row = a.edge_index + e0;
+        t.col = a.edge_index + a.n_edges + e0;
+        t.attr = a.edge_attr ? a.edge_attr + e0 : nullptr;
+        t.cl0 = a.cluster0 ? a.cluster0 + n0 : nullptr;
+        t.cl1 = (a.cluster1 && a.c1_ptr) ? a.cluster1 + a.c1_ptr[g] : nullptr;
+        t.shift = n0;
+        t.x_row = n0;
+    } else {
+        long long id = a.set_ids[g];
+        if (id < 0 || id >= a.n_set) id = 0;      // the caller validated the ids; never read outside the set
+        const long long se = a.set_edge_ptr[id], sn = a.set_node_ptr[id];
+        t.row = a.edge_index + se;
+        t.col = a.edge_index + a.n_edges + se;
+        t.attr = a.edge_attr ? a.edge_attr + se : nullptr;
+        t.cl0 = a.cluster0 ? a.cluster0 + sn : nullptr;
+        t.cl1 = (a.cluster1 && a.set_c1_ptr) ? a.cluster1 + a.set_c1_ptr[id] : nullptr;
+        t.shift = 0;
+        t.x_row = sn;
+    }
+    return t;
+}
+// resident-set mode: node features and target of slot g -> the mini-batch's compact buffers
+DEV void topo_gather_rows(const TopoArgs& a, const TopoSrc& src, int g, int n0, int N) {
+    if (a.set_ids == nullptr || a.x_out == nullptr) return;
+    const int F = a.n_feat;
+    const float* xs = a.set_x + src.x_row * F;
+    float* xd = a.x_out + (long long)n0 * F;
+#ifndef DRGNN_EMU
+    if ((F & 3) == 0) {
+        const drgnn_f4* xs4 = (const drgnn_f4*)xs;
+        drgnn_f4* xd4 = (drgnn_f4*)xd;
+        FOR_TID(i, N * (F >> 2)) { xd4[i] = xs4[i]; }
+    } else
+#endif
+    {
+        FOR_TID(i, N * F) { xd[i] = xs[i]; }
+    }
+    if (a.y_out && a.set_y) {
+        long long id = a.set_ids[g];
+        if (id < 0 || id >= a.n_set) id = 0;
+        FOR_TID(i, 1) {
+            if (a.y_bytes == 8) ((int64_t*)a.y_out)[g] = ((const int64_t*)a.set_y)[id];
+            else ((int32_t*)a.y_out)[g] = ((const int32_t*)a.set_y)[id];
+        }
+    }
+}
+
 // C0 = number of depth-0 clusters of the graph; sidx = this workgroup's status word
-DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0, int C0, int c1_begin,
+DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0, int C0, const int64_t* ids1,
                            int c1_len, TopoScratch& s, int sidx, bool prepared = false) {
     const int rowbase = n0 + g;
     if (c1_len != C0) {
         FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, sidx); }
     }
     const int n = imin(C0, imax(c1_len, 0));
-    const int C1 = wg_cluster_rank(tv, sidx, a.cluster1 + c1_begin, n, s, prepared);
+    const int C1 = wg_cluster_rank(tv, sidx, ids1, n, s, prepared);
     int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
     int32_t* g_mptr1 = tv.p[DRGNN_TI_MPTR1] + rowbase;
     int32_t* g_mem1 = tv.p[DRGNN_TI_MEM1] + n0;
@@ -336,10 +404,12 @@ DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0,
 
 DEV void topo_members(const TopoView& tv, const TopoArgs& a, int g, int n0, int N, TopoScratch& s, int sidx) {
     const int rowbase = n0 + g;
+    const TopoSrc src = topo_src(a, g, n0, 0);
+    topo_gather_rows(a, src, g, n0, N);
     FOR_TID(v, s.capF) { s.fl[v] = 0; }
     FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
     BARRIER();
-    const int C = wg_cluster_rank(tv, sidx, a.cluster0 + n0, N, s, true);
+    const int C = wg_cluster_rank(tv, sidx, src.cl0, N, s, true);
     int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
     int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
     int32_t* g_mem0 = tv.p[DRGNN_TI_MEM0] + n0;
@@ -351,7 +421,7 @@ DEV void topo_members(const TopoView& tv, const TopoArgs& a, int g, int n0, int 
     BARRIER();
     if (a.cluster1 != nullptr && a.c1_ptr != nullptr) {
         const int b = a.c1_ptr[g];
-        topo_graph_level1(tv, a, g, n0, C, b, a.c1_ptr[g + 1] - b, s, sidx, true);
+        topo_graph_level1(tv, a, g, n0, C, src.cl1, a.c1_ptr[g + 1] - b, s, sidx, true);
     }
 }
 
@@ -370,8 +440,11 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         E = 0;
     }
     PHASE_MARK();
-    const int64_t* src_row = a.edge_index + e0;
-    const int64_t* src_col = a.edge_index + a.n_edges + e0;
+    const TopoSrc src = topo_src(a, g, n0, e0);
+    if (role == TOPO_ROLE_ALL) topo_gather_rows(a, src, g, n0, N);
+    const int64_t* src_row = src.row;
+    const int64_t* src_col = src.col;
+    const long long shift = src.shift;
     const int Nm1 = N - 1;
     int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
     int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
@@ -386,7 +459,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     int* cur_r = s.cur;
     int* cur_c = s.nb;
     FOR_TID(e, E) {
-        long long r = (long long)src_row[e] - n0, c = (long long)src_col[e] - n0;
+        long long r = (long long)src_row[e] - shift, c = (long long)src_col[e] - shift;
         if (r < 0 || r > Nm1 || c < 0 || c > Nm1) {
             topo_flag(tv, DRGNN_S_EDGE_RANGE, g);
             r = (r < 0 || r > Nm1) ? 0 : r;
@@ -439,7 +512,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         s.t5[e] = k;                                   // edge -> CSR0 slot
         g_col0[k] = c;
         g_eid0[k] = e;
-        if (has_w) { const float w = a.edge_attr[e0 + e]; s.w0[k] = w; g_w0[k] = w; }
+        if (has_w) { const float w = src.attr[e]; s.w0[k] = w; g_w0[k] = w; }
     }
     {
         int32_t* g_colptr0 = tv.p[DRGNN_TI_COLPTR0] + rowbase;
@@ -463,7 +536,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     }
     // ---- depth-0 clusters (touches t1, t2, cur, fl, cl, mp, mem only) ----------------------
     const bool members = (role == TOPO_ROLE_ALL);
-    const int C = wg_cluster_rank(tv, g, a.cluster0 + n0, N, s, true, members);
+    const int C = wg_cluster_rank(tv, g, src.cl0, N, s, true, members);
     if (members) {
         int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
         int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
@@ -598,6 +671,6 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     // ---- depth-1 clusters (when the caller knows where this graph's ids start) --------
     if (role == TOPO_ROLE_ALL && a.cluster1 != nullptr && a.c1_ptr != nullptr) {
         const int b = a.c1_ptr[g];
-        topo_graph_level1(tv, a, g, n0, C, b, a.c1_ptr[g + 1] - b, s, g, true);
+        topo_graph_level1(tv, a, g, n0, C, src.cl1, a.c1_ptr[g + 1] - b, s, g, true);
     }
 }

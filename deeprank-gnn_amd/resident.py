@@ -102,6 +102,50 @@ class ResidentGraphSet(object):
             raise IndexError("graph number out of range [0, %d)" % len(self))
         return torch.from_numpy(ids.astype(np.int32)).to(self.device)
 
+    def batch_offsets(self, ids_dev, batch_size):
+        """Slot offset tables of every mini-batch of the visiting order ``ids_dev`` (``upload_ids``), one launch:
+        int32 [n_batches, 3, batch_size + 1] = node / edge / cluster1 offsets (drgnn_batch_offsets)."""
+        n = int(ids_dev.numel())
+        nb = (n + batch_size - 1) // batch_size
+        ptrs = torch.zeros((nb, 3, batch_size + 1), dtype=torch.int32, device=self.device)
+        self.api.batch_offsets(self._desc, ids_dev.contiguous(), n, int(batch_size), ptrs, _lib.current_stream(ptrs))
+        return ptrs
+
+    def build_topology(self, ids, ids_dev, ptrs, need_weights=False, topo=None):
+        """Topology workspace, node features and targets of the mini-batch ``ids`` straight from the resident
+        set (no collate: the builder reads the graphs' index data in place).  ``ptrs``: this mini-batch's [3, B+1]
+        slice of ``batch_offsets``; ``topo``: an allocated workspace of the right size to build into.
+        Returns (Topology, x [N, F], y [B])."""
+        from .topology import Topology
+        ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+        B = int(ids.size)
+        nn, ne, nc = self.n_nodes[ids], self.n_edges[ids], self.n_c1[ids]
+        N, E, C = int(nn.sum()), int(ne.sum()), int(nc.sum())
+        want_w = bool(need_weights and self.has_attr)
+        if topo is None:
+            topo = Topology(self.api, N, E, B, self.device, want_w)
+        topo.max_nodes, topo.max_edges, topo.max_c0 = int(nn.max()), int(ne.max()), int(nc.max())
+        topo.has_level1 = self.has_c1
+        x = torch.empty((N, self.n_feat), dtype=torch.float32, device=self.device)
+        y = torch.empty((B,), dtype=self.y.dtype, device=self.device) if self.y is not None else None
+        r = _lib.TopologyRequest()
+        p = _lib._ptr
+        r.node_ptr, r.edge_ptr = p(ptrs[0]), p(ptrs[1])
+        r.c1_ptr = p(ptrs[2]) if self.has_c1 else None
+        r.n_nodes, r.n_edges, r.len_cluster1, r.n_graphs = N, E, C, B
+        r.max_nodes, r.max_edges = topo.max_nodes, topo.max_edges
+        r.ws_i32, r.ws_f32 = p(topo.ws_i32), p(topo.ws_f32)
+        scratch = None
+        if self.api.topology_lds_bytes(topo.max_nodes, max(topo.max_edges, 1)) > 160 * 1024:
+            scratch = torch.empty(self.api.topology_scratch_elems(N, E, B), dtype=torch.int32, device=self.device)
+        r.scratch_i32 = p(scratch)
+        import ctypes
+        r.set = ctypes.cast(ctypes.pointer(self._desc), ctypes.c_void_p)
+        r.ids, r.x_out, r.y_out = p(ids_dev), p(x), p(y)
+        self.api.topology_build_request(r, _lib.current_stream(x))
+        topo._inputs = None
+        return topo, x, y
+
     def batch(self, ids, ids_dev=None):
         """The mini-batch of graphs ``ids`` (host sequence of graph numbers, slot order).  ``ids_dev``: the same
         numbers already on the device (a slice of ``upload_ids`` of a whole epoch), else they are uploaded."""

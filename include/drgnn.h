@@ -280,6 +280,14 @@ typedef struct drgnn_head_desc {
  * jobs are independent -- the builder only reads index tensors -- so one hides behind the other and
  * a kernel boundary disappears (software pipelining across training steps).  Falls back to
  * separate launches when LDS does not fit or the per-graph offsets are not supplied. */
+/* The dataset resident in HBM, graph-major (described at drgnn_collate below). */
+typedef struct drgnn_graph_set {
+    int64_t n_graphs, n_nodes, n_edges, len_cluster1;
+    int32_t n_feat, y_bytes;
+    const int64_t* node_ptr; const int64_t* edge_ptr; const int64_t* c1_ptr;   /* c1_ptr null: no cluster1 */
+    const float* x; const int64_t* edge_index; const float* edge_attr;          /* edge_attr may be null */
+    const int64_t* cluster0; const int64_t* cluster1; const void* y;            /* each may be null */
+} drgnn_graph_set;
 typedef struct drgnn_topology_request {
     const int64_t* edge_index; const float* edge_attr; const int64_t* batch;
     const int64_t* cluster0; const int64_t* cluster1;
@@ -287,7 +295,20 @@ typedef struct drgnn_topology_request {
     int64_t n_nodes, n_edges, len_cluster1, n_graphs;
     int32_t max_nodes, max_edges;
     int32_t* ws_i32; float* ws_f32; int32_t* scratch_i32;
+    /* Resident-set mode (set != NULL; the five tensor pointers above are ignored): slot g of the mini-batch is
+     * graph ids[g] of `set`, whose index data is read in place (local ids, no collate); node_ptr / edge_ptr /
+     * c1_ptr are the mini-batch's slot offset tables (drgnn_batch_offsets) and are required.  The builder also
+     * gathers the slots' node features into x_out [n_nodes, F] and targets into y_out [n_graphs] (either may be
+     * NULL).  Pooled edge weights are built when ws_f32 and set->edge_attr are both given. */
+    const drgnn_graph_set* set; const int32_t* ids; float* x_out; void* y_out;
 } drgnn_topology_request;
+/* drgnn_topology_build from a request (either mode), own launch. */
+int drgnn_topology_build_request(const drgnn_topology_request* request, void* stream);
+/* Slot offset tables of EVERY mini-batch of an epoch in one launch: mini-batch k = ids[k*batch_size, ...) gets
+ * ptrs[k][0] = node offsets, ptrs[k][1] = edge offsets, ptrs[k][2] = cluster1 offsets, each batch_size+1 int32
+ * (ptrs: [n_batches][3][batch_size+1]; a short last mini-batch uses a prefix of each row).  batch_size <= 4096. */
+int drgnn_batch_offsets(const drgnn_graph_set* set, const int32_t* ids, int64_t n_ids, int32_t batch_size,
+                        int32_t* ptrs, void* stream);
 
 /* Backward of the body with the FC head, loss and their backward evaluated per graph INSIDE the
  * same launch (the head is row-wise), instead of taking grad_readout from drgnn_head_step:
@@ -399,13 +420,6 @@ int drgnn_mcl(const int64_t* edge_index, int64_t n_edges, const int32_t* node_pt
  * edge_ptr / c1_ptr [B+1] that drgnn_topology_build and the step kernels take.  The caller sizes the
  * outputs from its host copy of the tables (N = sum of the selected node counts, ...).  One workgroup per
  * slot; ids outside [0, G) select an empty graph. */
-typedef struct drgnn_graph_set {
-    int64_t n_graphs, n_nodes, n_edges, len_cluster1;
-    int32_t n_feat, y_bytes;
-    const int64_t* node_ptr; const int64_t* edge_ptr; const int64_t* c1_ptr;   /* c1_ptr null: no cluster1 */
-    const float* x; const int64_t* edge_index; const float* edge_attr;          /* edge_attr may be null */
-    const int64_t* cluster0; const int64_t* cluster1; const void* y;            /* each may be null */
-} drgnn_graph_set;
 int drgnn_collate(const drgnn_graph_set* set, const int32_t* ids, int64_t n_graphs, int64_t n_nodes,
                   int64_t n_edges, float* x, int64_t* edge_index, float* edge_attr, int64_t* batch,
                   int64_t* cluster0, int64_t* cluster1, void* y, int32_t* node_ptr, int32_t* edge_ptr,
@@ -415,7 +429,10 @@ int drgnn_collate(const drgnn_graph_set* set, const int32_t* ids, int64_t n_grap
  * The body of NeuralNet._epoch's loop (NeuralNet.py:486-506) for EVERY mini-batch of an epoch, enqueued on
  * `stream` without touching the host language in between and without any synchronisation: for mini-batch k
  *     drgnn_collate(k+1)  ->  drgnn_net_train_step(k)  [+ topology of k+1 in the same launch]  ->  drgnn_step_update
- * with two mini-batch slots carved out of `scratch` (k trains from one while k+1 is assembled in the other).
+ * -- in fact without the collate launch: the topology builder of mini-batch k+1 (extra workgroups of step k's
+ * launch) reads the graphs' index data in place from the resident set and gathers their node features and
+ * targets into the slot's compact buffers (drgnn_topology_request, resident-set mode); two mini-batch slots are
+ * carved out of `scratch` (k trains from one while k+1 is assembled in the other).
  * ids / host_ids: the epoch's visiting order (graph numbers of `set`) on the device and on the host; mini-batch k
  * = ids[k*batch_size, min((k+1)*batch_size, n_ids)).  host_*_ptr: host copies of the set's offset tables (they size
  * every launch).  Outputs: pred [n_ids, O] in visiting order, losses [ceil(n_ids / batch_size)] (mean loss of each

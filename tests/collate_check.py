@@ -61,3 +61,38 @@ def check_collate(graphs, device, api=None, selections=None):
         assert_same_batch(rs.batch(ids, dev_ids[lo:lo + len(ids)]), Batch.from_data_list([graphs[i] for i in ids]))
         lo += len(ids)
     return rs
+
+
+def check_set_topology(graphs, device, api=None, need_weights=True, batch_size=4):
+    """Resident-set mode of the topology builder (no collate) against the builder run on the collated mini-batch:
+    identical workspaces, node features and targets; slot offset tables against numpy prefix sums."""
+    from deeprank_gnn_amd.topology import Topology
+    rs = ResidentGraphSet(graphs, device, api=api)
+    order = np.random.default_rng(9).permutation(len(graphs)).tolist()
+    ids_dev = rs.upload_ids(order)
+    ptrs = rs.batch_offsets(ids_dev, batch_size)
+    for k, lo in enumerate(range(0, len(order), batch_size)):
+        ids = order[lo:lo + batch_size]
+        B = len(ids)
+        for t, counts in enumerate((rs.n_nodes, rs.n_edges, rs.n_c1)):
+            want = np.concatenate([[0], np.cumsum(counts[ids])])
+            assert ptrs[k, t, :B + 1].cpu().tolist() == want.tolist()
+        ref_batch = rs.batch(ids)
+        ref = Topology.from_batch(ref_batch, api=rs.api, need_weights=need_weights, build=False)
+        mine = Topology(rs.api, ref.n_nodes, ref.n_edges, B, rs.device, need_weights)
+        for t in (ref, mine):                       # unused tails of the workspace arrays compare equal
+            t.ws_i32.zero_()
+            if t.ws_f32 is not None:
+                t.ws_f32.zero_()
+        ref.rebuild()
+        topo, x, y = rs.build_topology(ids, ids_dev[lo:lo + B], ptrs[k, :, :B + 1].contiguous(),
+                                       need_weights=need_weights, topo=mine)
+        assert (topo.max_nodes, topo.max_edges, topo.max_c0) == (ref.max_nodes, ref.max_edges, ref.max_c0)
+        assert torch.equal(x.cpu(), ref_batch.x.cpu()) and torch.equal(y.cpu(), ref_batch.y.cpu())
+        assert topo.status()[0] == 0 and ref.status()[0] == 0
+        for name in ("NPTR", "EPTR", "ROWPTR0", "COL0", "COLPTR0", "ROWIDX0", "CL0", "MPTR0", "MEM0", "NC0", "NE1",
+                     "ROWPTR1", "COL1", "COLPTR1", "ROWIDX1", "CL1", "MPTR1", "MEM1", "NC1"):
+            assert torch.equal(topo.array(name).cpu(), ref.array(name).cpu()), name
+        if need_weights:
+            for name in ("W0", "W1"):
+                assert torch.equal(topo.weights(name).cpu(), ref.weights(name).cpu()), name

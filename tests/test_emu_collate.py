@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from collate_check import check_collate, ragged_graphs
+from collate_check import check_collate, check_set_topology, ragged_graphs
 from emu_api import emu
 from helpers import fixture_graphs, syn4_graphs
 from deeprank_gnn_amd.resident import ResidentGraphSet
@@ -48,3 +48,9 @@ def test_resident_set_refuses_cpu_without_emulation():
         pytest.skip("product library not built")
     with pytest.raises(_lib.DrgnnError):
         ResidentGraphSet(ragged_graphs(0, 3), "cpu")
+
+
+@pytest.mark.parametrize("need_weights", [False, True])
+def test_topology_from_the_resident_set(need_weights):
+    check_set_topology(ragged_graphs(4, 6), "cpu", api=emu(), need_weights=need_weights, batch_size=4)
+    check_set_topology(fixture_graphs(), "cpu", api=emu(), need_weights=need_weights, batch_size=3)

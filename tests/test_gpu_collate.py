@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from collate_check import check_collate, ragged_graphs
+from collate_check import check_collate, check_set_topology, ragged_graphs
 from helpers import fixture_graphs, syn4_graphs
 
 pytestmark = pytest.mark.gpu
@@ -46,3 +46,11 @@ def test_collate_full_size_batches_train_identically():
         la = float(tr_a.train_step(dev_batch))
         lb = float(tr_b.train_step(host_batch))
         assert la == lb
+
+
+@pytest.mark.parametrize("need_weights", [False, True])
+def test_topology_from_the_resident_set(need_weights):
+    import deeprank_gnn_amd.synthetic as synth
+    check_set_topology(ragged_graphs(4, 6), "cuda", need_weights=need_weights, batch_size=4)
+    check_set_topology(fixture_graphs(), "cuda", need_weights=need_weights, batch_size=3)
+    check_set_topology([synth.make_graph(i) for i in range(96)], "cuda", need_weights=need_weights, batch_size=64)
