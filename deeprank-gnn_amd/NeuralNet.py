@@ -214,11 +214,35 @@ class NeuralNet(object):
             batch, topo = nxt, nxt_topo
         return float(running), self._finish(store)
 
+    def _sum_of_batch_losses(self, pred, y):
+        """Sum over the mini-batches of each batch's mean loss (what the reference accumulates, NeuralNet.py:441-447)."""
+        bs = self.batch_size
+        total = torch.zeros((), dtype=torch.float32, device=pred.device)
+        for lo in range(0, pred.size(0), bs):
+            if self.task == 'reg':
+                total += torch.nn.functional.mse_loss(pred[lo:lo + bs].reshape(-1), y[lo:lo + bs])
+            else:
+                total += torch.nn.functional.cross_entropy(pred[lo:lo + bs], y[lo:lo + bs], weight=self.trainer.class_w)
+        return total
+
     def eval(self, dataset=None, indices=None):
         """Forward only (NeuralNet.py:414-475); returns (loss_sum, store)."""
         dataset = dataset or self.dataset
         indices = self.valid_index if indices is None else indices
         store = self._new_store()
+        order = [int(i) for i in indices]
+        if self.native_epoch and order:
+            rs = self._resident(dataset)
+            pred = self.trainer.predict_epoch(rs, order, self.batch_size)
+            if pred is not None:
+                store['_pred'].append(pred)
+                store['mol'] += [rs.mols[i] for i in order]
+                total = 0.0
+                if rs.y is not None:
+                    y = rs.y[torch.as_tensor(order, dtype=torch.long, device=rs.y.device)]
+                    store['_y'].append(y)
+                    total = float(self._sum_of_batch_losses(pred, y))
+                return total, self._finish(store)
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         need_w = self.trainer.kind == _lib.SGAT
         it = self._batches(dataset, indices, False)

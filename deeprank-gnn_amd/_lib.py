@@ -74,7 +74,7 @@ class EpochPlan(ctypes.Structure):
     """drgnn_epoch_plan (include/drgnn.h); pointer members are filled by FusedTrainer.train_epoch."""
     _fields_ = [("set", _vp), ("host_node_ptr", _vp), ("host_edge_ptr", _vp), ("host_c1_ptr", _vp),
                 ("ids", _vp), ("host_ids", _vp), ("n_ids", _c_i64),
-                ("batch_size", _c_i32), ("need_weights", _c_i32),
+                ("batch_size", _c_i32), ("need_weights", _c_i32), ("inference", _c_i32), ("reserved", _c_i32),
                 ("net", _vp), ("head", _vp), ("g_conv1", _vp), ("g_conv2", _vp),
                 ("head_offset", _c_i64),
                 ("flat_param", _vp), ("flat_grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("n_param", _c_i64),

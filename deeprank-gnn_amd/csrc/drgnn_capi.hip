@@ -1543,16 +1543,18 @@ int epoch_batch(const drgnn_epoch_plan* p, int64_t k, EpochBatch* b) {
 }
 int epoch_check(const drgnn_epoch_plan* p) {
     if (!p || !p->set || !p->host_node_ptr || !p->host_edge_ptr || !p->ids || !p->host_ids || p->n_ids < 0 ||
-        p->batch_size < 1 || !p->net || !p->head || !p->g_conv1 || !p->g_conv2 || !p->flat_param || !p->flat_grad ||
-        !p->exp_avg || !p->exp_avg_sq || !p->step2)
+        p->batch_size < 1 || !p->net || !p->head || !p->step2)
+        return DRGNN_E_ARG;
+    if (!p->inference && (!p->g_conv1 || !p->g_conv2 || !p->flat_param || !p->flat_grad || !p->exp_avg || !p->exp_avg_sq))
         return DRGNN_E_ARG;
     const drgnn_graph_set* gs = p->set;
-    if (!gs->node_ptr || !gs->edge_ptr || !gs->x || !gs->cluster0 || !gs->cluster1 || !gs->c1_ptr || !p->host_c1_ptr || !gs->y)
+    if (!gs->node_ptr || !gs->edge_ptr || !gs->x || !gs->cluster0 || !gs->cluster1 || !gs->c1_ptr || !p->host_c1_ptr)
         return DRGNN_E_ARG;
+    if (!p->inference && !gs->y) return DRGNN_E_ARG;
     if (gs->n_edges > 0 && !gs->edge_index) return DRGNN_E_ARG;
     if (p->need_weights && !gs->edge_attr) return DRGNN_E_ARG;
     if (gs->n_feat != p->net->n_feat) return DRGNN_E_WIDTH;
-    if (gs->y_bytes != (p->head->task == DRGNN_TASK_REG ? 4 : 8)) return DRGNN_E_ARG;
+    if (!p->inference && gs->y_bytes != (p->head->task == DRGNN_TASK_REG ? 4 : 8)) return DRGNN_E_ARG;
     if (p->batch_size > 4096) return DRGNN_E_CAPACITY;
     return 0;
 }
@@ -1610,12 +1612,13 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
     int rc = epoch_carve(p, (char*)scratch, &c);
     if (rc) return rc;
     if (p->n_ids == 0) return 0;
-    if (!scratch || !pred || !losses || ((uintptr_t)scratch & 15)) return DRGNN_E_ARG;
+    const bool train = !p->inference;
+    if (!scratch || !pred || (train && !losses) || ((uintptr_t)scratch & 15)) return DRGNN_E_ARG;
     if (scratch_bytes < c.bytes) return DRGNN_E_CAPACITY;
     const int64_t nb = (p->n_ids + p->batch_size - 1) / p->batch_size;
     const drgnn_head_desc* hd = p->head;
     drgnn_head_desc head = *hd;
-    head.train = 1;
+    head.train = train ? 1 : 0;
     // the exchange words carry the step index as a tag: they only have to start from a value no step uses
 #ifdef DRGNN_EMU
     memset(c.xchg, 0, (size_t)c.xchg_bytes);
@@ -1633,7 +1636,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         r.n_nodes = b.N; r.n_edges = b.E; r.len_cluster1 = b.C; r.n_graphs = b.B;
         r.max_nodes = b.maxN; r.max_edges = b.maxE;
         r.ws_i32 = u.ws_i32; r.ws_f32 = u.ws_f32; r.scratch_i32 = nullptr;
-        r.set = p->set; r.ids = p->ids + b.first; r.x_out = u.x; r.y_out = u.y;
+        r.set = p->set; r.ids = p->ids + b.first; r.x_out = u.x; r.y_out = train ? u.y : nullptr;
         return r;
     };
     EpochBatch cur, nxt;
@@ -1650,10 +1653,12 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
             if ((rc = epoch_batch(p, k + 1, &nxt))) return rc;
             req = request(k + 1, nxt);
         }
-        rc = drgnn_net_train_step(p->net, &head, t.x, t.y, p->step2, t.ws_i32, t.ws_f32, cur.N, cur.E, cur.B, cur.maxN,
-                                  cur.maxE, cur.maxC, pred + cur.first * hd->O, c.readout, c.head_partials, c.partials,
-                                  c.xchg, more ? &req : nullptr, stream);
+        rc = drgnn_net_train_step(p->net, &head, t.x, train ? t.y : nullptr, p->step2, t.ws_i32, t.ws_f32, cur.N, cur.E,
+                                  cur.B, cur.maxN, cur.maxE, cur.maxC, pred + cur.first * hd->O, c.readout,
+                                  train ? c.head_partials : nullptr, train ? c.partials : nullptr, c.xchg,
+                                  more ? &req : nullptr, stream);
         if (rc) return rc;
+        if (!train) { if (more) cur = nxt; continue; }
         rc = drgnn_step_update(p->net, c.partials, cur.B, p->g_conv1, p->g_conv2, c.head_partials, c.readout, hd->R, hd->H,
                                hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
                                p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, 1, stream);

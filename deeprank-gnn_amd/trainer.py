@@ -282,26 +282,35 @@ class FusedTrainer(object):
         self.apply_update()
         return loss
 
+    def predict_epoch(self, gset, order, batch_size):
+        """Inference over the graphs ``order`` of the resident set, native loop (one launch per mini-batch, no
+        synchronisation): pred [len(order), O] on the device, or None when a graph needs the per-batch path."""
+        done = self._run_epoch(gset, order, batch_size, inference=True)
+        return None if done is None else done[1]
+
     def train_epoch(self, gset, order, batch_size):
         """A whole epoch over the resident set ``gset`` (resident.ResidentGraphSet) in visiting order ``order``
-        (graph numbers), driven by the native loop ``drgnn_train_epoch``: per mini-batch one collate launch, the
-        fused step launch (which also builds the next mini-batch's topology) and the update launch -- no Python
-        and no host synchronisation between mini-batches.  Returns (losses [n_batches], pred [len(order), O]) as
+        (graph numbers), driven by the native loop ``drgnn_train_epoch``: per mini-batch the fused step launch
+        (whose extra workgroups build the next mini-batch's topology and gather its node rows straight from the
+        resident set) and the update launch -- no Python and no host synchronisation between mini-batches.  Returns (losses [n_batches], pred [len(order), O]) as
         device tensors, or None when this configuration needs the per-batch path (data parallel, weight decay,
         a graph too large for the fused kernels)."""
-        import ctypes
-        import numpy as np
-        if self.weight_decay != 0.0 or not self.fused_step:
+        if self.weight_decay != 0.0:
             return None
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return None
-        if not (gset.has_c0 and gset.has_c1 and gset.y is not None):
+        want = torch.float32 if self.task == _lib.TASK_REG else torch.int64
+        if gset.y is None or gset.y.dtype != want:
+            return None
+        return self._run_epoch(gset, order, batch_size, inference=False)
+
+    def _run_epoch(self, gset, order, batch_size, inference):
+        import ctypes
+        import numpy as np
+        if not self.fused_step or not (gset.has_c0 and gset.has_c1):
             return None
         need_w = self.kind == _lib.SGAT
         if need_w and gset.edge_attr is None:
-            return None
-        want = torch.float32 if self.task == _lib.TASK_REG else torch.int64
-        if gset.y.dtype != want:
             return None
         ids_host = np.ascontiguousarray(np.asarray(order, dtype=np.int32).reshape(-1))
         n = int(ids_host.size)
@@ -322,9 +331,10 @@ class FusedTrainer(object):
                 _fill_grads(g2[b], self.kind, l2, H1, H2)
             ck = self._desc_cache[n_feat] = (g1, g2, _describe(self.kind, n_feat, self.live, self.n_branch))
         g1, g2, desc = ck
-        head = self._head_desc(True)
+        head = self._head_desc(not inference)
         vp = ctypes.c_void_p
         plan = _lib.EpochPlan()
+        plan.inference = int(inference)
         plan.set = ctypes.cast(ctypes.pointer(gset._desc), vp)
         plan.host_node_ptr, plan.host_edge_ptr = gset.node_ptr.ctypes.data, gset.edge_ptr.ctypes.data
         plan.host_c1_ptr = gset.c1_ptr.ctypes.data
@@ -345,9 +355,10 @@ class FusedTrainer(object):
         if scratch is None or scratch.numel() < nbytes:
             scratch = self._epoch_scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.api.train_epoch(plan, scratch, pred, losses, _lib.current_stream(self.flat_p))
-        self.last_pred = pred[(nb - 1) * batch_size:]
-        self.last_batch_size = n - (nb - 1) * batch_size
-        self.loss.copy_(losses[nb - 1:nb])
+        if not inference:
+            self.last_pred = pred[(nb - 1) * batch_size:]
+            self.last_batch_size = n - (nb - 1) * batch_size
+            self.loss.copy_(losses[nb - 1:nb])
         return losses, pred
 
     # -- torch.optim.Adam compatible optimiser state --------------------------------------

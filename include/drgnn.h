@@ -445,6 +445,8 @@ typedef struct drgnn_epoch_plan {
     const int64_t* host_node_ptr; const int64_t* host_edge_ptr; const int64_t* host_c1_ptr;
     const int32_t* ids; const int32_t* host_ids; int64_t n_ids;
     int32_t batch_size, need_weights;
+    int32_t inference, reserved;   /* inference != 0: forward + head only (dropout off), pred is the only output;
+                                      the optimiser members, step2 excepted, and the set's targets may be NULL */
     const drgnn_net_desc* net; const drgnn_head_desc* head;
     drgnn_conv_grads* g_conv1; drgnn_conv_grads* g_conv2;
     int64_t head_offset;

@@ -43,6 +43,16 @@ def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=
         else:
             np.testing.assert_allclose(losses.cpu().numpy(), want_l, rtol=1e-5)
             np.testing.assert_allclose(pred.cpu().numpy(), want_p.numpy(), rtol=1e-4, atol=1e-5)
+    # inference pass over a permutation (dropout off): native loop vs predict() on host-collated mini-batches
+    order = rng.permutation(len(graphs)).tolist()
+    got = tr_a.predict_epoch(rs, order, batch_size)
+    assert got is not None
+    want = torch.cat([tr_b.predict(Batch.from_data_list([graphs[i] for i in order[lo:lo + batch_size]]).to(device)).cpu()
+                      for lo in range(0, len(order), batch_size)])
+    if exact:
+        assert torch.equal(got.cpu(), want)
+    else:
+        np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-5)
     assert int(tr_a.step) == int(tr_b.step) == epochs * ((len(graphs) + batch_size - 1) // batch_size)
     if exact:
         assert torch.equal(tr_a.flat_p.cpu(), tr_b.flat_p.cpu())
