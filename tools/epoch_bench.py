@@ -51,13 +51,15 @@ def main():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--epochs", type=int, default=3)
     ap.add_argument("--net", choices=["GINet", "sGAT", "FoutNet"], default="GINet")
+    ap.add_argument("--only", default=None, help="run a single mode (for profiling)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     graphs = [synth.make_graph(i) for i in range(args.graphs)]
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[args.net]
     need_w = args.net == "sGAT"
     results = {}
-    for mode in ("host-collate", "resident", "native-epoch"):
+    modes = ("host-collate", "resident", "native-epoch") if args.only is None else (args.only,)
+    for mode in modes:
         torch.manual_seed(0)
         net = Net(32, 1, 1).to(dev)
         tr = FusedTrainer(net, lr=1e-3, task="reg")
@@ -90,6 +92,8 @@ def main():
                          "us_per_batch": dt / (args.epochs * n_batches) * 1e6, "epochs": args.epochs,
                          "graphs": args.graphs, "batch": args.batch, "epoch_losses": losses}
         print(json.dumps(results[mode]))
+    if args.only is not None:
+        return
     a, b, c = results["host-collate"], results["resident"], results["native-epoch"]
     print(json.dumps({"speedup_resident_over_host_collate": b["graphs_per_s"] / a["graphs_per_s"],
                       "speedup_native_epoch_over_host_collate": c["graphs_per_s"] / a["graphs_per_s"],
