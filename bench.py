@@ -65,6 +65,8 @@ def parse():
                     help="mini-batch per GPU; %d is BASELINE.json's configuration, other values are for the "
                          "batch-size sweep in DESIGN.md" % GRAPHS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--epoch-graphs", type=int, default=4096,
+                    help="size of the resident graph set of the secondary whole-epoch measurement (0: skip it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -384,6 +386,11 @@ def main():
             result["config"]["params_in_sync"] = in_sync
         if args.net == "GINet":
             result["roofline"] = measure_roofline(net, batch, dev, value)
+        if world == 1 and native and args.epoch_graphs > 0:
+            try:
+                result["epoch_loop"] = measure_epoch_loop(Net, args.net, args.epoch_graphs, dev)
+            except Exception as exc:                      # secondary figure: never lose the bench line over it
+                result["epoch_loop"] = {"error": repr(exc)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.net, batch_cpu, args.cpu_seconds)
     if world > 1:
@@ -485,6 +492,39 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
                             "%s); FETCH doubled per MI355X_MICROARCH.md" % PMC_FILE,
             "whole_step_frac": graphs_per_s * (BYTES_FWD + BYTES_BWD) / 1e9 / HBM_PEAK_GBS,
             "kernels": out}
+
+
+def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=3):
+    """Secondary figure (not `value`): whole shuffled epochs over a graph set resident in HBM, driven by the native
+    loop drgnn_train_epoch -- every mini-batch is a different random selection of graphs, read in place by the topology
+    builder; includes the shuffle, the id upload, the outputs' copy back and one synchronisation per epoch."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    graphs = [synth.make_graph(GRAPHS_PER_GPU + i) for i in range(n_graphs)]
+    torch.manual_seed(0)
+    tr = FusedTrainer(Net(N_FEAT, 1, 1).to(dev), lr=1e-3, task="reg")
+    rs = ResidentGraphSet(graphs, dev)
+    gen = torch.Generator().manual_seed(0)
+
+    def epoch():
+        order = torch.randperm(n_graphs, generator=gen).tolist()
+        done = tr.train_epoch(rs, order, GRAPHS_PER_GPU)
+        if done is None:
+            raise RuntimeError("the native epoch loop refused this configuration")
+        losses, pred = done
+        pred.cpu()
+        return float(losses.sum())
+    epoch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    sums = [epoch() for _ in range(epochs)]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nb = (n_graphs + GRAPHS_PER_GPU - 1) // GRAPHS_PER_GPU
+    return {"graphs_per_s": n_graphs * epochs / dt, "us_per_batch": dt / (epochs * nb) * 1e6, "epochs": epochs,
+            "resident_graphs": n_graphs, "batch": GRAPHS_PER_GPU, "net": net_name, "last_epoch_loss_sum": sums[-1],
+            "what": "shuffled epochs via drgnn_train_epoch (native loop, mini-batches read in place from the resident set)"}
 
 
 def cpu_baseline(net_name, batch_cpu, seconds):
