@@ -28,7 +28,7 @@ def _counts_to_ptr(counts):
 class ResidentGraphSet(object):
     """``graphs``: a sequence of ``Data`` (e.g. a ``GraphDataSet``); every graph is read once."""
 
-    def __init__(self, graphs, device, api=None, indices=None):
+    def _open(self, device, api):
         self.api = api or _lib.get()
         self.device = torch.device(device)
         if self.device.type == "cuda" and self.device.index is None:
@@ -36,42 +36,59 @@ class ResidentGraphSet(object):
         if self.api is _lib._API and self.device.type != "cuda":
             raise _lib.DrgnnError("ResidentGraphSet keeps the data in HBM: it needs an MI355X device, got %s. "
                                   "There is no CPU path." % self.device)
+
+    def __init__(self, graphs, device, api=None, indices=None):
+        self._open(device, api)
         order = range(len(graphs)) if indices is None else list(indices)
         items = [graphs[i] for i in order]
         if not items:
             raise ValueError("cannot build a resident set from zero graphs")
-        self.mols = [getattr(g, "mol", None) for g in items]
         first = items[0]
-        self.has_attr = first.edge_attr is not None
-        self.has_c0 = getattr(first, "cluster0", None) is not None
-        self.has_c1 = getattr(first, "cluster1", None) is not None
-        self.has_y = first.y is not None
+        has_attr = first.edge_attr is not None
+        has_c0 = getattr(first, "cluster0", None) is not None
+        has_c1 = getattr(first, "cluster1", None) is not None
         for g in items:
             if g.edge_attr is not None and g.edge_attr.dim() == 2 and g.edge_attr.size(1) != 1:
                 raise ValueError("only one edge feature is supported (the reference's layers broadcast "
                                  "edge_attr [E,1] over the channels, sGAT.py:76)")
-        self.n_nodes = np.asarray([g.num_nodes for g in items], dtype=np.int64)
-        self.n_edges = np.asarray([g.num_edges for g in items], dtype=np.int64)
-        self.n_c1 = np.asarray([int(g.cluster1.numel()) if self.has_c1 else 0 for g in items], dtype=np.int64)
-        self.node_ptr, self.edge_ptr, self.c1_ptr = (_counts_to_ptr(c) for c in (self.n_nodes, self.n_edges, self.n_c1))
-        dev = self.device
 
         def cat(parts, dtype, dim=0):
-            return torch.cat([p.to(dtype) for p in parts], dim=dim).contiguous().to(dev)
-        x = [g.x if g.x.dim() == 2 else g.x.reshape(-1, 1) for g in items]
-        self.x = cat(x, torch.float32)
+            return torch.cat([p.to(dtype) for p in parts], dim=dim).contiguous()
+        y = None
+        if first.y is not None:
+            y = torch.cat([g.y.reshape(-1)[:1] for g in items])
+        self._adopt(
+            mols=[getattr(g, "mol", None) for g in items],
+            n_nodes=[g.num_nodes for g in items], n_edges=[g.num_edges for g in items],
+            n_c1=[int(g.cluster1.numel()) if has_c1 else 0 for g in items],
+            x=cat([g.x if g.x.dim() == 2 else g.x.reshape(-1, 1) for g in items], torch.float32),
+            edge_index=cat([g.edge_index.reshape(2, -1) for g in items], torch.int64, dim=1),     # local ids
+            edge_attr=cat([g.edge_attr.reshape(-1) for g in items], torch.float32) if has_attr else None,
+            cluster0=cat([g.cluster0 for g in items], torch.int64) if has_c0 else None,
+            cluster1=cat([g.cluster1 for g in items], torch.int64) if has_c1 else None, y=y)
+
+    def _adopt(self, mols, n_nodes, n_edges, n_c1, x, edge_index, edge_attr, cluster0, cluster1, y):
+        """Takes the concatenated host arrays, uploads them and fills the drgnn_graph_set descriptor."""
+        dev = self.device
+        self.mols = list(mols)
+        self.n_nodes = np.asarray(n_nodes, dtype=np.int64)
+        self.n_edges = np.asarray(n_edges, dtype=np.int64)
+        self.n_c1 = np.asarray(n_c1, dtype=np.int64)
+        self.node_ptr, self.edge_ptr, self.c1_ptr = (_counts_to_ptr(c) for c in (self.n_nodes, self.n_edges, self.n_c1))
+        self.has_attr, self.has_c0, self.has_c1 = edge_attr is not None, cluster0 is not None, cluster1 is not None
+        self.has_y = y is not None
+        self.x = x.to(torch.float32).contiguous().to(dev)
         self.n_feat = int(self.x.size(1))
-        self.edge_index = cat([g.edge_index.reshape(2, -1) for g in items], torch.int64, dim=1)   # local ids
-        self.edge_attr = cat([g.edge_attr.reshape(-1) for g in items], torch.float32) if self.has_attr else None
-        self.cluster0 = cat([g.cluster0 for g in items], torch.int64) if self.has_c0 else None
-        self.cluster1 = cat([g.cluster1 for g in items], torch.int64) if self.has_c1 else None
+        self.edge_index = edge_index.to(torch.int64).contiguous().to(dev)
+        self.edge_attr = edge_attr.to(torch.float32).contiguous().to(dev) if self.has_attr else None
+        self.cluster0 = cluster0.to(torch.int64).contiguous().to(dev) if self.has_c0 else None
+        self.cluster1 = cluster1.to(torch.int64).contiguous().to(dev) if self.has_c1 else None
         self.y = None
         if self.has_y:
-            y = torch.cat([g.y.reshape(-1)[:1] for g in items])
             self.y = (y.to(torch.float32) if y.is_floating_point() else y.to(torch.int64)).contiguous().to(dev)
         self._ptr_dev = [torch.from_numpy(p).to(dev) for p in (self.node_ptr, self.edge_ptr, self.c1_ptr)]
         gs = _lib.GraphSet()
-        gs.n_graphs, gs.n_nodes, gs.n_edges = len(items), int(self.node_ptr[-1]), int(self.edge_ptr[-1])
+        gs.n_graphs, gs.n_nodes, gs.n_edges = len(self.mols), int(self.node_ptr[-1]), int(self.edge_ptr[-1])
         gs.len_cluster1 = int(self.c1_ptr[-1])
         gs.n_feat = self.n_feat
         gs.y_bytes = 0 if self.y is None else self.y.element_size()
@@ -84,6 +101,34 @@ class ResidentGraphSet(object):
 
     def __len__(self):
         return len(self.mols)
+
+    # -- one-file image of the set: start-up without per-graph parsing ------------------------------------
+    def save(self, path):
+        """Write the set as ONE ``.npz`` of concatenated arrays (the layout that is uploaded), so that later runs
+        skip the per-graph reads of the HDF5 / npz store (reference DataSet.py:231-366 does them per epoch)."""
+        arrays = {"node_ptr": self.node_ptr, "edge_ptr": self.edge_ptr, "c1_ptr": self.c1_ptr,
+                  "x": self.x.cpu().numpy(), "edge_index": self.edge_index.cpu().numpy(),
+                  "mol": np.asarray(["" if m is None else str(m) for m in self.mols])}
+        for name in ("edge_attr", "cluster0", "cluster1", "y"):
+            t = getattr(self, name)
+            if t is not None:
+                arrays[name] = t.cpu().numpy()
+        np.savez(path, **arrays)
+
+    @classmethod
+    def load(cls, path, device, api=None):
+        """Inverse of ``save``: the arrays go to the device as they are (no per-graph objects)."""
+        with np.load(path, allow_pickle=False) as z:
+            a = {k: z[k] for k in z.files}
+        self = cls.__new__(cls)
+        self._open(device, api)
+
+        def opt(name):
+            return torch.from_numpy(a[name]) if name in a else None
+        self._adopt(mols=[str(m) for m in a["mol"]], n_nodes=np.diff(a["node_ptr"]), n_edges=np.diff(a["edge_ptr"]),
+                    n_c1=np.diff(a["c1_ptr"]), x=torch.from_numpy(a["x"]), edge_index=torch.from_numpy(a["edge_index"]),
+                    edge_attr=opt("edge_attr"), cluster0=opt("cluster0"), cluster1=opt("cluster1"), y=opt("y"))
+        return self
 
     def set_targets(self, y):
         """Replace the targets (e.g. class labels mapped to class indices); ``y``: [G] tensor."""

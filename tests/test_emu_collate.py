@@ -54,3 +54,15 @@ def test_resident_set_refuses_cpu_without_emulation():
 def test_topology_from_the_resident_set(need_weights):
     check_set_topology(ragged_graphs(4, 6), "cpu", api=emu(), need_weights=need_weights, batch_size=4)
     check_set_topology(fixture_graphs(), "cpu", api=emu(), need_weights=need_weights, batch_size=3)
+
+
+def test_resident_set_image_round_trip(tmp_path):
+    from collate_check import assert_same_batch
+    graphs = ragged_graphs(8, 5)
+    rs = ResidentGraphSet(graphs, "cpu", api=emu())
+    path = str(tmp_path / "set.npz")
+    rs.save(path)
+    back = ResidentGraphSet.load(path, "cpu", api=emu())
+    assert len(back) == len(rs) and back.mols == rs.mols
+    for ids in ([0, 3, 5], list(range(len(graphs)))[::-1]):
+        assert_same_batch(back.batch(ids), rs.batch(ids))

@@ -58,7 +58,8 @@ def main():
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[args.net]
     need_w = args.net == "sGAT"
     results = {}
-    modes = ("host-collate", "resident", "native-epoch") if args.only is None else (args.only,)
+    modes = ("host-collate", "resident", "native-epoch") if args.only is None else (
+        (args.only,) if args.only != "native-predict" else ())
     for mode in modes:
         torch.manual_seed(0)
         net = Net(32, 1, 1).to(dev)
@@ -92,6 +93,23 @@ def main():
                          "us_per_batch": dt / (args.epochs * n_batches) * 1e6, "epochs": args.epochs,
                          "graphs": args.graphs, "batch": args.batch, "epoch_losses": losses}
         print(json.dumps(results[mode]))
+    if args.only is None or args.only == "native-predict":
+        # inference over the whole set in a fixed order (validation / test pass), native loop
+        torch.manual_seed(0)
+        tr = FusedTrainer(Net(32, 1, 1).to(dev), lr=1e-3, task="reg")
+        rs = ResidentGraphSet(graphs, dev)
+        order = list(range(args.graphs))
+        tr.predict_epoch(rs, order, args.batch).cpu()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.epochs):
+            out = tr.predict_epoch(rs, order, args.batch).cpu()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n_batches = (args.graphs + args.batch - 1) // args.batch
+        print(json.dumps({"mode": "native-predict", "net": args.net, "graphs_per_s": args.graphs * args.epochs / dt,
+                          "us_per_batch": dt / (args.epochs * n_batches) * 1e6, "graphs": args.graphs,
+                          "batch": args.batch, "pred_checksum": float(out.double().sum())}))
     if args.only is not None:
         return
     a, b, c = results["host-collate"], results["resident"], results["native-epoch"]
