@@ -166,6 +166,7 @@ class Api(object):
         lib.drgnn_segmax_backward.argtypes = [_vp, _vp, _c_i64, _c_i32, _c_i64, _vp, _vp]
         lib.drgnn_pooled_edges_export.argtypes = [_vp, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp]
         lib.drgnn_cluster_offset.argtypes = [_vp, _vp, _c_i64, _vp, _vp]
+        lib.drgnn_graclus.argtypes = [_vp, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _vp, _vp, _vp, _vp]
         lib.drgnn_mcl.argtypes = [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp]
         lib.drgnn_train_epoch_scratch_bytes.argtypes = [ctypes.POINTER(EpochPlan)]
         lib.drgnn_train_epoch_scratch_bytes.restype = _c_i64
@@ -326,6 +327,10 @@ class Api(object):
     def cluster_offset(self, cluster, node_ptr, n_graphs, scratch, stream):
         _check(self.lib.drgnn_cluster_offset(_ptr(cluster), _ptr(node_ptr), n_graphs, _ptr(scratch), stream),
                "drgnn_cluster_offset")
+
+    def graclus(self, ws_i32, n_nodes, n_edges, n_graphs, max_nodes, max_edges, weight, perm, cluster, stream):
+        _check(self.lib.drgnn_graclus(_ptr(ws_i32), n_nodes, n_edges, n_graphs, max_nodes, max_edges, _ptr(weight),
+                                      _ptr(perm), _ptr(cluster), stream), "drgnn_graclus")
 
     def mcl(self, edge_index, n_edges, node_ptr, edge_ptr, mat_ptr, n_graphs, mat_scratch, int_scratch, labels,
             info, stream):

@@ -4,6 +4,7 @@ the torch_geometric / torch_scatter helpers its models import), on the device pa
     get_preloaded_cluster(cluster, batch)        community_pooling.py:25-30
     community_pooling(cluster, data)             community_pooling.py:161-251
     max_pool_x(cluster, x, batch)                [torch_geometric.nn] used at ginet.py:114
+    graclus / normalized_cut / max_pool          [torch_geometric.nn] README.md:98-126 custom-net recipe
     scatter_mean / scatter_sum / scatter_max     [torch_scatter] used at ginet.py:133 etc.
 
 These return dynamically-shaped tensors, so -- like the reference -- they synchronise with the
@@ -19,8 +20,8 @@ from . import _lib
 from .data import Batch, Data
 from .topology import Topology
 
-__all__ = ["get_preloaded_cluster", "community_pooling", "max_pool_x", "scatter_mean", "scatter_sum",
-           "scatter_max", "community_detection", "community_detection_per_batch"]
+__all__ = ["get_preloaded_cluster", "community_pooling", "max_pool", "max_pool_x", "graclus", "normalized_cut",
+           "scatter_mean", "scatter_sum", "scatter_max", "community_detection", "community_detection_per_batch"]
 
 _API = None      # tests point this at the host-emulation build
 
@@ -108,6 +109,61 @@ def _pool_edges(topo, e1_total, with_attr):
     topo.api.pooled_edges_export(topo.ws_i32, topo.ws_f32, topo.n_nodes, topo.n_edges, topo.n_graphs, e1_total,
                                  ei, ea, _lib.current_stream(topo.ws_i32))
     return ei, ea
+
+
+def graclus(edge_index, weight=None, num_nodes=None, perm=None, batch=None):
+    """``torch_geometric.nn.graclus(edge_index, weight, num_nodes)`` (README.md:98-126): greedy maximal matching,
+    every node labelled ``min(u, v)`` of its pair (or itself).  torch_cluster visits the nodes in a random
+    permutation; here the order is explicit: ``perm`` [N] (graph-major, LOCAL node ids of each graph) or identity,
+    so results are reproducible.  ``batch`` [N] splits a block-diagonal batch into its graphs (one workgroup
+    each); without it the input is one graph."""
+    api = _api()
+    edge_index = edge_index.to(torch.int64).contiguous()
+    dev = edge_index.device
+    if batch is not None:
+        n = batch.numel()
+    elif num_nodes is not None:
+        n = int(num_nodes)
+    else:
+        n = int(edge_index.max()) + 1 if edge_index.numel() else 0
+    s = types.SimpleNamespace(edge_index=edge_index, edge_attr=None, cluster0=None, cluster1=None)
+    if batch is None:
+        s.batch = torch.zeros(n, dtype=torch.int64, device=dev)
+        s.__dict__["_num_graphs"] = 1 if n else 0
+    else:
+        s.batch = batch
+    topo = Topology.from_batch(s, api=api, with_level1=False, graph_only=True, need_weights=False)
+    topo.check()
+    cluster = torch.empty((n,), dtype=torch.int64, device=dev)
+    if weight is not None:
+        weight = weight.to(torch.float32).reshape(-1).contiguous()
+        if weight.numel() != edge_index.size(1):
+            raise ValueError("graclus: one weight per edge expected")
+    if perm is not None:
+        perm = perm.to(torch.int64).contiguous()
+        if perm.numel() != n:
+            raise ValueError("graclus: perm must hold one (local) node id per node")
+    if n:
+        api.graclus(topo.ws_i32, n, topo.n_edges, topo.n_graphs, topo.max_nodes, topo.max_edges, weight, perm,
+                    cluster, _lib.current_stream(cluster))
+    return cluster
+
+
+def normalized_cut(edge_index, edge_attr, num_nodes=None):
+    """``torch_geometric.utils.normalized_cut``: edge_attr * (1/deg[row] + 1/deg[col]), deg = degree by target."""
+    row, col = edge_index[0], edge_index[1]
+    n = int(num_nodes) if num_nodes is not None else (int(edge_index.max()) + 1 if edge_index.numel() else 0)
+    inv = 1.0 / torch.bincount(col, minlength=n).to(torch.float32)
+    return edge_attr.reshape(-1).to(torch.float32) * (inv[row] + inv[col])
+
+
+def max_pool(cluster, data):
+    """``torch_geometric.nn.max_pool(cluster, data)`` (README.md:98-126): per-cluster feature maximum, pooled edges
+    (relabelled, self loops dropped, duplicates merged with summed attributes), mean positions, pooled batch vector.
+    ``cluster`` must not span graphs (graclus / get_preloaded_cluster labels do not)."""
+    plain = types.SimpleNamespace(x=data.x, edge_index=data.edge_index, edge_attr=getattr(data, "edge_attr", None),
+                                  pos=getattr(data, "pos", None), batch=getattr(data, "batch", None))
+    return community_pooling(cluster, plain)
 
 
 def community_pooling(cluster, data):

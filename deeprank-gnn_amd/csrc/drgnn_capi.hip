@@ -438,6 +438,10 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_mcl(MclArgs a) {
     __shared__ int flag[2];
     mcl_graph(a, blockIdx.x, flag, red);
 }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_graclus(GraclusArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int smem_g[];
+    graclus_block(a, blockIdx.x, smem_g);
+}
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_batch_offsets(OffsetsArgs a) {
     extern __shared__ __attribute__((aligned(16))) int smem_o[];
     batch_offsets_block(a, blockIdx.x, smem_o + DRGNN_NTHREADS + 4, smem_o);
@@ -1453,6 +1457,33 @@ int drgnn_cluster_offset(int64_t* cluster, const int32_t* node_ptr, int64_t n_gr
     hipLaunchKernelGGL(k_cluster_max, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_cluster_scan, dim3(1), dim3(64), 0, (hipStream_t)stream, a);
     hipLaunchKernelGGL(k_cluster_add, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+// ---- graclus ----------------------------------------------------------------------------------------
+int drgnn_graclus(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
+                  int32_t max_edges, const float* weight, const int64_t* perm, int64_t* cluster, void* stream) {
+    if (!ws_i32 || n_nodes < 0 || n_edges < 0 || n_graphs < 0 || max_nodes < 0 || max_edges < 0) return DRGNN_E_ARG;
+    if (n_nodes > 0 && !cluster) return DRGNN_E_ARG;
+    if (n_graphs == 0) return 0;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    GraclusArgs a;
+    a.tv = topo_view(const_cast<int32_t*>(ws_i32), nullptr, lay);
+    a.n_graphs = (int)n_graphs; a.weight = weight; a.perm = perm; a.cluster = cluster;
+    a.capN = max_nodes > 0 ? max_nodes : 1; a.capE = max_edges > 0 ? max_edges : 1;
+    const int64_t words = (int64_t)(a.capN + 1) + 2 * (int64_t)a.capE + a.capN;
+    if (words * 4 > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
+#ifdef DRGNN_EMU
+    std::vector<int> buf((size_t)words + 16);
+    for (int g = 0; g < n_graphs; ++g) graclus_block(a, g, buf.data());
+    (void)stream;
+#else
+    if (words * 4 > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void*)k_graclus, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(words * 4)));
+    hipLaunchKernelGGL(k_graclus, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), (size_t)(words * 4), (hipStream_t)stream, a);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

@@ -223,6 +223,59 @@ DEV void edge_export_block(const EdgeExportArgs& a, int g) {
     }
 }
 
+// ---- graclus: greedy maximal matching of every graph (README.md:98-126 custom net; torch_cluster) ----
+// Visits the nodes of a graph in the order `perm` (identity when null); an unmatched node u takes, among its
+// unmatched neighbours v != u, the one with the largest edge weight (the first one in edge-id order when there are
+// no weights or on ties) and both get the label min(u, v); a node without a free neighbour keeps its own label.
+// Inherently sequential per graph: the graph's CSR is staged in LDS and one lane walks it; graphs run in parallel.
+// lds: (N+1) row pointers, E columns, E weights, N labels.
+struct GraclusArgs {
+    TopoView tv; int n_graphs;
+    const float* weight;       // [E] by input edge id, or null
+    const int64_t* perm;       // [N] visiting order (LOCAL node ids per graph, graph-major), or null
+    int64_t* cluster;          // [N] out: batch-global label n0 + min(u, v)
+    int capN, capE;
+};
+DEV void graclus_block(const GraclusArgs& a, int g, int* lds) {
+    const TopoView& tv = a.tv;
+    const int n0 = tv.p[DRGNN_TI_NPTR][g], N = tv.p[DRGNN_TI_NPTR][g + 1] - n0;
+    const int e0 = tv.p[DRGNN_TI_EPTR][g], E = tv.p[DRGNN_TI_EPTR][g + 1] - e0;
+    if (N > a.capN || E > a.capE) return;                  // the host sized the carve from max_nodes / max_edges
+    int* rp = lds;
+    int* col = rp + (a.capN + 1);
+    float* w = (float*)(col + a.capE);
+    int* lab = (int*)(w + a.capE);
+    const int32_t* g_rp = tv.p[DRGNN_TI_ROWPTR0] + n0 + g;
+    const int32_t* g_col = tv.p[DRGNN_TI_COL0] + e0;
+    const int32_t* g_eid = tv.p[DRGNN_TI_EID0] + e0;
+    FOR_TID(i, N + 1) { rp[i] = g_rp[i]; }
+    FOR_TID(k, E) {
+        col[k] = g_col[k];
+        w[k] = a.weight ? a.weight[e0 + g_eid[k]] : 0.0f;
+    }
+    FOR_TID(i, N) { lab[i] = -1; }
+    BARRIER();
+    FOR_TID(t, 1) {
+        for (int k = 0; k < N; ++k) {
+            long long u = a.perm ? a.perm[n0 + k] : k;
+            if (u < 0 || u >= N || lab[u] >= 0) continue;
+            int best = -1;
+            float bw = 0.0f;
+            for (int j = rp[u]; j < rp[u + 1]; ++j) {
+                const int v = col[j];
+                if (v == (int)u || lab[v] >= 0) continue;
+                if (!a.weight) { best = v; break; }
+                if (best < 0 || w[j] > bw) { best = v; bw = w[j]; }
+            }
+            const int m = (best >= 0 && best < (int)u) ? best : (int)u;
+            lab[u] = m;
+            if (best >= 0) lab[best] = m;
+        }
+    }
+    BARRIER();
+    FOR_TID(i, N) { a.cluster[n0 + i] = (long long)n0 + (lab[i] >= 0 ? lab[i] : i); }
+}
+
 // ---- get_preloaded_cluster: per-graph running offset, in place ---------------------------------
 struct ClusterOffsetArgs {
     int64_t* cluster;          // [n] in/out

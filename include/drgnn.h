@@ -397,6 +397,16 @@ int drgnn_step_update(const drgnn_net_desc* net, const float* conv_partials, int
                       int32_t* step2, float* loss, float lr, float beta1, float beta2, float eps,
                       int32_t apply_adam, void* stream);
 
+/* ---- graclus ---------------------------------------------------------------------
+ * Greedy maximal matching of every graph of a built topology (CSR0), the clustering the README's custom net
+ * feeds to max_pool / max_pool_x (README.md:98-126; torch_geometric.nn.graclus -> torch_cluster, whose node
+ * visiting order is a random permutation: pass it as `perm`, LOCAL ids per graph, to reproduce a given run;
+ * NULL = identity).  An unmatched node takes its unmatched neighbour of largest weight (weight [E] indexed by
+ * input edge id; NULL or ties: first in edge-id order); both are labelled min(u, v).  cluster [N] int64 receives
+ * batch-global labels.  max_nodes / max_edges size the LDS carve (DRGNN_E_CAPACITY beyond 160 KiB). */
+int drgnn_graclus(const int32_t* ws_i32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
+                  int32_t max_edges, const float* weight, const int64_t* perm, int64_t* cluster, void* stream);
+
 /* ---- offline clustering --------------------------------------------------------
  * Markov clustering of every graph of a batch: community_detection(edge_index, num_nodes,
  * method='mcl') (community_pooling.py:95-158; markov_clustering.run_mcl defaults), as PreCluster
