@@ -82,8 +82,15 @@ struct TopoLaunch {
 template <bool LDS>
 DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
     TopoScratch s;
-    const int g = (L.roles == 2) ? (blk >> 1) : blk;
-    const int role = (L.roles == 2) ? ((blk & 1) ? TOPO_ROLE_MEMBERS : TOPO_ROLE_EDGES) : TOPO_ROLE_ALL;
+    // Two workgroups per graph: within full groups of 8 graphs both land on XCD (graph % 8) -- workgroups are dealt
+    // round-robin to the 8 XCDs and the step kernels put graph g there too (step_block), so what the builder writes
+    // is read back through the same L2 by the launch that trains on it.
+    int g = blk, role = TOPO_ROLE_ALL;
+    if (L.roles == 2) {
+        const int full = (L.args.n_graphs >> 3) << 4;
+        if (blk < full) { g = ((blk >> 4) << 3) + (blk & 7); role = ((blk >> 3) & 1) ? TOPO_ROLE_MEMBERS : TOPO_ROLE_EDGES; }
+        else { const int t = blk - full; g = (full >> 1) + (t >> 1); role = (t & 1) ? TOPO_ROLE_MEMBERS : TOPO_ROLE_EDGES; }
+    }
     const int sidx = (role == TOPO_ROLE_MEMBERS) ? L.args.n_graphs + g : g;
     const int32_t* NP = L.user_nptr ? L.user_nptr : L.tv.p[DRGNN_TI_NPTR];
     const int32_t* EP = L.user_eptr ? L.user_eptr : L.tv.p[DRGNN_TI_EPTR];
