@@ -9,12 +9,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python bench.py --no-cpu-baseline > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $OUT/write.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python bench.py --no-cpu-baseline --epoch-graphs 0 > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline --epoch-graphs 0 > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline --epoch-graphs 0 > $OUT/write.log 2>&1
 # SQ counters (own passes, kernel trace only): MFMA busy, wave-cycle breakdown, LDS conflicts
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/sq1 -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $OUT/sq1.log 2>&1 || true
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace -d $OUT/sq2 -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline > $OUT/sq2.log 2>&1 || true
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/sq1 -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline --epoch-graphs 0 > $OUT/sq1.log 2>&1 || true
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace -d $OUT/sq2 -o run --output-format csv -- python bench.py --steps 40 --warmup 20 --no-cpu-baseline --epoch-graphs 0 > $OUT/sq2.log 2>&1 || true
 python bench.py > $OUT/benchline.json 2> $OUT/bench.err
 find $OUT -name "*.csv" | head -20
 tail -c 400 $OUT/benchline.json
