@@ -66,3 +66,19 @@ def test_resident_set_image_round_trip(tmp_path):
     assert len(back) == len(rs) and back.mols == rs.mols
     for ids in ([0, 3, 5], list(range(len(graphs)))[::-1]):
         assert_same_batch(back.batch(ids), rs.batch(ids))
+
+
+def test_topology_from_the_resident_set_global_scratch_path():
+    """A graph too large for the builder's LDS budget: the resident-set mode also runs out of global scratch."""
+    import numpy as np
+    from test_emu_topology import random_graph
+    rng = np.random.default_rng(12)
+    graphs = ragged_graphs(6, 4, count=3)
+    big = random_graph(rng, 2500, 30000, 300, 40, sym=True)
+    big.x = torch.from_numpy(rng.standard_normal((2500, 4)).astype(np.float32))
+    big.edge_attr = torch.from_numpy(rng.uniform(0.1, 2.0, (big.edge_index.size(1), 1)).astype(np.float32))
+    big.y = torch.tensor([1.0])
+    big.mol = "big"
+    graphs.insert(1, big)
+    assert emu().topology_lds_bytes(2500, int(big.edge_index.size(1))) > 160 * 1024
+    check_set_topology(graphs, "cpu", api=emu(), need_weights=True, batch_size=4)
