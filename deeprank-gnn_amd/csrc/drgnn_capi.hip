@@ -475,19 +475,38 @@ __global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
         const int64_t item = (int64_t)blockIdx.x * 64 + lane;
         const bool live = item < (int64_t)a.n_branch * a.n_partial && reduce_live(a, (int)(item % a.n_partial));
         const int br = live ? (int)(item / a.n_partial) : 0, p = live ? (int)(item % a.n_partial) : 0;
+        // wave 0 owns the element's update: its parameter / moment loads and the bias corrections are issued
+        // BEFORE the slab loads, so that Adam starts from registers once the quarter sums are in
+        float* d = (q == 0 && live) ? reduce_dst(a, br, p) : nullptr;
+        const bool upd = d != nullptr && u.apply_adam;
+        const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
+        const AdamPre pre = adam_prefetch(u.ad, idx);
         quarter[q][lane] = live ? reduce_sum(a, br, p, q, 4) : 0.0f;
         __syncthreads();
-        if (q == 0 && live) {
-            float* d = reduce_dst(a, br, p);
-            if (d) update_store(u, d, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
+        if (d) {
+            const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
+            *d = g;                                   // keep p.grad inspectable
+            if (upd) adam_apply(u.ad, idx, g, pre);
         }
     } else {
         const int item = ((int)blockIdx.x - u.conv_blocks) * 64 + lane;
         const bool live = item < update_head_items(u);
+        const int n_grad = update_head_items(u) - 1;
+        float* d = (q == 0 && live && item < n_grad) ? u.h.grad + item : nullptr;
+        const bool upd = d != nullptr && u.apply_adam;
+        const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
+        const AdamPre pre = adam_prefetch(u.ad, idx);
         quarter[q][lane] = live ? update_head_sum(u, item, q, 4) : 0.0f;
         __syncthreads();
-        if (q == 0 && live)
-            update_head_store(u, item, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
+        if (q == 0 && live) {
+            const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
+            if (d) {
+                *d = g;
+                if (upd) adam_apply(u.ad, idx, g, pre);
+            } else if (item == n_grad && u.h.loss) {
+                u.h.loss[0] = g;
+            }
+        }
     }
     // nobody reads step2[0] in this launch (Adam reads step2[1]): safe to commit it here
     if (u.step2 && blockIdx.x == 0 && threadIdx.x == 0) u.step2[0] = u.step2[1];

@@ -254,6 +254,34 @@ DEV double adam_ipow(double b, int t) {
     }
     return r;
 }
+// adam_item split in two so that a caller can have the element's state and the step-dependent scalars in flight
+// while it is still computing the gradient (same arithmetic, same order -> same bits)
+struct AdamPre { float p, m, v, step_size, sqrt_bc2; bool ok; };
+DEV AdamPre adam_prefetch(const AdamArgs& a, int64_t i) {
+    AdamPre r;
+    r.ok = i >= 0 && i < a.n;
+    r.p = r.m = r.v = 0.0f; r.step_size = 0.0f; r.sqrt_bc2 = 1.0f;
+    if (!r.ok) return r;
+    r.p = a.param[i];
+    r.m = a.exp_avg[i];
+    r.v = a.exp_avg_sq[i];
+    const int t = a.step[0];
+    const double bc1 = 1.0 - adam_ipow((double)a.beta1, t);
+    const double bc2 = 1.0 - adam_ipow((double)a.beta2, t);
+    r.step_size = (float)((double)a.lr / bc1);
+    r.sqrt_bc2 = (float)sqrt(bc2);
+    return r;
+}
+DEV void adam_apply(const AdamArgs& a, int64_t i, float g, const AdamPre& r) {
+    if (!r.ok) return;
+    if (a.weight_decay != 0.0f) g = fmaf(a.weight_decay, r.p, g);
+    const float m = r.m + (g - r.m) * (1.0f - a.beta1);          // lerp
+    const float v = a.beta2 * r.v + (1.0f - a.beta2) * g * g;
+    a.exp_avg[i] = m;
+    a.exp_avg_sq[i] = v;
+    const float denom = sqrtf(v) / r.sqrt_bc2 + a.eps;
+    a.param[i] = r.p - r.step_size * (m / denom);
+}
 DEV void adam_item(const AdamArgs& a, int64_t i) {
     if (i >= a.n) return;
     const float t = (float)a.step[0];
