@@ -204,8 +204,17 @@ DEV float reduce_sum(const ReduceArgs& a, int br, int p, int first, int stride) 
     const float* src = a.partials + (int64_t)br * a.n_partial + p;
     const int64_t step = (int64_t)a.n_branch * a.n_partial;
     float acc = 0.0f;
-#pragma unroll 4
-    for (int g = first; g < a.n_graphs; g += stride) acc += src[(int64_t)g * step];
+    // all the loads of a lane's share in flight at once (16 for 64 graphs, 4 waves): the launch is one memory round
+    // trip deep instead of four
+    float v[16];
+    int g = first;
+    for (; g + 15 * stride < a.n_graphs; g += 16 * stride) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)(g + k * stride) * step];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+    for (; g < a.n_graphs; g += stride) acc += src[(int64_t)g * step];
     return acc;
 }
 
@@ -345,15 +354,29 @@ DEV float update_head_sum(const UpdateArgs& u, int item, int first, int stride) 
             const int h = item / u.hR, r = item - h * u.hR;
             const float* dh = u.h.partials + h;
             const float* xr = u.readout + r;
-#pragma unroll 4
-            for (int w = first; w < u.h.n_wg; w += stride) acc = fmaf(dh[(long)w * u.h.P], xr[(long)w * u.hR], acc);
+            float va[16], vb[16];
+            int w = first;
+            for (; w + 15 * stride < u.h.n_wg; w += 16 * stride) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { va[k] = dh[(long)(w + k * stride) * u.h.P]; vb[k] = xr[(long)(w + k * stride) * u.hR]; }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fmaf(va[k], vb[k], acc);
+            }
+            for (; w < u.h.n_wg; w += stride) acc = fmaf(dh[(long)w * u.h.P], xr[(long)w * u.hR], acc);
             return acc;
         }
         item -= HR;
     }
     const float* src = u.h.partials + item;
-#pragma unroll 4
-    for (int w = first; w < u.h.n_wg; w += stride) acc += src[(long)w * u.h.P];
+    float v[16];
+    int w = first;
+    for (; w + 15 * stride < u.h.n_wg; w += 16 * stride) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = src[(long)(w + k * stride) * u.h.P];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+    for (; w < u.h.n_wg; w += stride) acc += src[(long)w * u.h.P];
     return acc;
 }
 DEV void update_head_store(const UpdateArgs& u, int item, float acc) {
