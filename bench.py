@@ -74,6 +74,10 @@ def parse():
 def main():
     global GRAPHS_PER_GPU
     args = parse()
+    # RCCL writes its version banner to STDOUT (NCCL_DEBUG unset or =VERSION, as this image exports it); stdout
+    # carries the ONE json line.  Other NCCL_DEBUG levels are left as the user set them.
+    if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+        os.environ["NCCL_DEBUG"] = "NONE"
     GRAPHS_PER_GPU = args.graphs_per_gpu
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -399,7 +403,12 @@ def main():
     elif dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(result))
+        try:                                  # anything a native library left in C stdio goes out BEFORE the line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(result), flush=True)
 
 
 def measure_roofline(net, batch, dev, graphs_per_s, iters=200):

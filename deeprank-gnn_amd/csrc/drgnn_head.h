@@ -265,6 +265,8 @@ DEV AdamPre adam_prefetch(const AdamArgs& a, int64_t i) {
     r.p = a.param[i];
     r.m = a.exp_avg[i];
     r.v = a.exp_avg_sq[i];
+    // bias corrections in double, as the Python-side scalars of torch's reference path; beta^t by
+    // repeated squaring (t is an integer): a libm pow() in double costs more than the rest of the launch
     const int t = a.step[0];
     const double bc1 = 1.0 - adam_ipow((double)a.beta1, t);
     const double bc2 = 1.0 - adam_ipow((double)a.beta2, t);
@@ -273,6 +275,9 @@ DEV AdamPre adam_prefetch(const AdamArgs& a, int64_t i) {
     return r;
 }
 DEV void adam_apply(const AdamArgs& a, int64_t i, float g, const AdamPre& r) {
+#ifndef DRGNN_EMU
+#pragma clang fp contract(off)      // every product and sum rounded on its own: the same bits wherever this is inlined
+#endif
     if (!r.ok) return;
     if (a.weight_decay != 0.0f) g = fmaf(a.weight_decay, r.p, g);
     const float m = r.m + (g - r.m) * (1.0f - a.beta1);          // lerp
@@ -284,19 +289,7 @@ DEV void adam_apply(const AdamArgs& a, int64_t i, float g, const AdamPre& r) {
 }
 DEV void adam_item(const AdamArgs& a, int64_t i) {
     if (i >= a.n) return;
-    const float t = (float)a.step[0];
-    float g = a.grad[i];
-    float p = a.param[i];
-    if (a.weight_decay != 0.0f) g = fmaf(a.weight_decay, p, g);
-    const float m = a.exp_avg[i] + (g - a.exp_avg[i]) * (1.0f - a.beta1);          // lerp
-    const float v = a.beta2 * a.exp_avg_sq[i] + (1.0f - a.beta2) * g * g;
-    a.exp_avg[i] = m;
-    a.exp_avg_sq[i] = v;
-    // bias corrections in double, as the Python-side scalars of torch's reference path; beta^t by
-    // repeated squaring (t is an integer): a libm pow() in double costs more than the rest of the launch
-    const double bc1 = 1.0 - adam_ipow((double)a.beta1, a.step[0]);
-    const double bc2 = 1.0 - adam_ipow((double)a.beta2, a.step[0]);
-    const float step_size = (float)((double)a.lr / bc1);
-    const float denom = sqrtf(v) / (float)sqrt(bc2) + a.eps;
-    a.param[i] = p - step_size * (m / denom);
+    const float g = a.grad[i];
+    const AdamPre r = adam_prefetch(a, i);
+    adam_apply(a, i, g, r);          // ONE statement of the arithmetic for every caller: identical bits
 }
