@@ -125,6 +125,9 @@ class NeuralNet(object):
                 # format_output's target half (NeuralNet.py:616-631): class labels -> class indices
                 rs.set_targets(torch.tensor([self.classes_to_idx[int(v)] for v in rs.y.cpu().tolist()]))
             self._resident_sets[id(dataset)] = (dataset, rs)       # keeps the dataset alive: ids stay unique
+            keep = {id(self.dataset), id(self.eval_dataset), id(dataset)}
+            for key in [k for k in self._resident_sets if k not in keep][:-2]:
+                del self._resident_sets[key]                       # test sets of earlier test() calls
         return rs
 
     def _batches(self, dataset, indices, shuffle):
