@@ -1138,10 +1138,11 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
         hipLaunchKernelGGL((k_step_co_topo<K, XF>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
                            (size_t)both, stream, C);                                                        \
     } while (0)
-        // instantiated feature widths: F16 in {16, 32, 48, 64}; anything else runs the generic kernel
+        // instantiated feature widths: F16 in {16, 32, 48, 64} (burst prologue guaranteed for the whole batch);
+        // anything else runs the generic kernel
 #define DRGNN_STEP_WIDTHS(K)                                                                                \
     do {                                                                                                    \
-        switch (step_pad16(F)) {                                                                            \
+        switch (step_burst_guaranteed(x, F, L.capN, L.capE, L.capC, hd->H, hd->O) ? step_pad16(F) : 0) {   \
             case 16: DRGNN_STEP_LAUNCH(K, 16); break;                                                       \
             case 32: DRGNN_STEP_LAUNCH(K, 32); break;                                                       \
             case 48: DRGNN_STEP_LAUNCH(K, 48); break;                                                       \

@@ -754,6 +754,13 @@ template <bool NARROW, int J> DEV void step_store_idx(const BufBurst<J>& b, int*
 }
 DEV void step_copy_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 
+// host side of the same conditions (net_burst_ok + the head's), from the batch-wide bounds
+static inline bool step_burst_guaranteed(const float* x, int F, int capN, int capE, int capC, int H, int O) {
+    return ((((uintptr_t)x) & 15) == 0) && (F % 4 == 0) && (F * DRGNN_H1 <= DRGNN_BCAP) && ((long)capN * F <= 16L * DRGNN_BCAP) &&
+           (capN + 1 <= DRGNN_BCAP) && (capE <= 2 * DRGNN_BCAP) && (capC * DRGNN_H1 <= 4 * DRGNN_BCAP) &&
+           O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP;
+}
+
 // `part`: 0 = whole step (device), 1 = up to the readout publication, 2 = from the head on
 // XF: padded feature width F16 as a compile-time constant (16/32/48/64), 0 = taken from the descriptor.
 // The strides of the x tile and of conv1's weights and the K loop of conv1's products hang on it;
@@ -792,7 +799,12 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         // ---- one burst of independent loads: everything this graph needs -> LDS ------------
         PHASE_MARK();
         const float* xg = a.x + (long)d.n0 * F;
-        const bool burst = net_burst_ok(xg, F, d.N, d.E, d.C) && O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP;
+        // The width-specialised kernels (XF != 0) are only launched when the HOST has established that every graph of
+        // the batch takes the register-burst prologue (step_burst_guaranteed): the plain per-array loops are compiled
+        // out of them, which takes ~15% off a kernel that is twice the instruction cache.  The generic kernel decides
+        // per graph.
+        const bool burst = (XF != 0) ? true
+                                     : (net_burst_ok(xg, F, d.N, d.E, d.C) && O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP);
         // Burst registers live across the first barrier: the x tile and the conv1 weights are
         // written to LDS at once, conv1's dense product starts, and everything else (index arrays, conv2
         // and head weights) is written to LDS after it -- their memory time hides behind the MFMAs.
