@@ -1142,7 +1142,7 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
         // anything else runs the generic kernel
 #define DRGNN_STEP_WIDTHS(K)                                                                                \
     do {                                                                                                    \
-        switch (step_burst_guaranteed(x, F, L.capN, L.capE, L.capC, hd->H, hd->O) ? step_pad16(F) : 0) {   \
+        switch (step_burst_guaranteed(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) ? step_pad16(F) : 0) {   \
             case 16: DRGNN_STEP_LAUNCH(K, 16); break;                                                       \
             case 32: DRGNN_STEP_LAUNCH(K, 32); break;                                                       \
             case 48: DRGNN_STEP_LAUNCH(K, 48); break;                                                       \

@@ -568,11 +568,14 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
     }
 #endif
 }
+// WREF: the fc1 width of the reference net of this kind (128 for GINet, 64 for sGAT / FoutNet) -- the one width a
+// kernel carries a specialised copy for besides the generic routines (every copy is instruction-cache footprint)
+// ONLY: the host has checked H == WREF for this launch (width-specialised kernels): no generic copy at all
+template <int WREF, bool ONLY>
 DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
                        const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
                        uint32_t thresh, float keep_scale, int part) {
-    if (hf.H == 128) step_head_fc1_t<128>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
-    else if (hf.H == 64) step_head_fc1_t<64>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
+    if (ONLY || hf.H == WREF) step_head_fc1_t<WREF>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
     else step_head_fc1_t<0>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
 }
 
@@ -689,13 +692,12 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
     }
 #endif
 }
+template <int WREF, bool ONLY>
 DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
                         const float* misc, float keep_scale, float* dhid, float* p_dhid, float* p_hw2,
                         float* p_hb2, float* p_loss) {
-    if (hf.H == 128 && hf.O == 1)
-        step_head_loss_t<128, 1>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
-    else if (hf.H == 64 && hf.O == 1)
-        step_head_loss_t<64, 1>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    if (hf.H == WREF && hf.O == 1)
+        step_head_loss_t<WREF, 1>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
     else
         step_head_loss_t<0, 0>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
 }
@@ -729,10 +731,10 @@ DEV void step_head_dreadout_t(const HeadFused& hf, const float* wb, const float*
     }
 #endif
 }
+template <int WREF, bool ONLY>
 DEV void step_head_dreadout(const HeadFused& hf, const float* wb, const float* dhid, const short* a1, int C1,
                             float* z2, int ldz) {
-    if (hf.H == 128) step_head_dreadout_t<128>(hf, wb, dhid, a1, C1, z2, ldz);
-    else if (hf.H == 64) step_head_dreadout_t<64>(hf, wb, dhid, a1, C1, z2, ldz);
+    if (ONLY || hf.H == WREF) step_head_dreadout_t<WREF>(hf, wb, dhid, a1, C1, z2, ldz);
     else step_head_dreadout_t<0>(hf, wb, dhid, a1, C1, z2, ldz);
 }
 
@@ -755,7 +757,8 @@ template <bool NARROW, int J> DEV void step_store_idx(const BufBurst<J>& b, int*
 DEV void step_copy_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 
 // host side of the same conditions (net_burst_ok + the head's), from the batch-wide bounds
-static inline bool step_burst_guaranteed(const float* x, int F, int capN, int capE, int capC, int H, int O) {
+static inline bool step_burst_guaranteed(int kind, const float* x, int F, int capN, int capE, int capC, int H, int O) {
+    if (H != ((kind == DRGNN_GINET) ? 128 : 64)) return false;      // the specialised kernels carry the reference head width only
     return ((((uintptr_t)x) & 15) == 0) && (F % 4 == 0) && (F * DRGNN_H1 <= DRGNN_BCAP) && ((long)capN * F <= 16L * DRGNN_BCAP) &&
            (capN + 1 <= DRGNN_BCAP) && (capE <= 2 * DRGNN_BCAP) && (capC * DRGNN_H1 <= 4 * DRGNN_BCAP) &&
            O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP;
@@ -775,6 +778,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     // the branch count (hence the readout width) follows from the kind of net
     constexpr int nb = (KIND == DRGNN_GINET) ? 2 : 1;
     constexpr int R = DRGNN_H2 * nb;
+    constexpr int WREF = (KIND == DRGNN_GINET) ? 128 : 64;       // ginet.py:136 / sGAT.py:134, foutnet.py:121
     const int F = a.net.n_feat;
     const int H = hf.H, O = hf.O;
     const int F16 = XF ? XF : step_pad16(F), XLD = F16 + 4;
@@ -800,9 +804,9 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         PHASE_MARK();
         const float* xg = a.x + (long)d.n0 * F;
         // The width-specialised kernels (XF != 0) are only launched when the HOST has established that every graph of
-        // the batch takes the register-burst prologue (step_burst_guaranteed): the plain per-array loops are compiled
-        // out of them, which takes ~15% off a kernel that is twice the instruction cache.  The generic kernel decides
-        // per graph.
+        // the batch takes the register-burst prologue and that the head has the reference width (step_burst_guaranteed):
+        // the plain per-array loops and the generic head routines are compiled out of them -- the kernel image is about
+        // twice the instruction cache and every kilobyte of it shows.  The generic kernel decides per graph.
         const bool burst = (XF != 0) ? true
                                      : (net_burst_ok(xg, F, d.N, d.E, d.C) && O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP);
         // Burst registers live across the first barrier: the x tile and the conv1 weights are
@@ -1031,16 +1035,16 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     if (hf.train && part != 2 && g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
     FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
     // half product of fc1 with this branch's readout, exchange with the partner workgroup, hid
-    PH(8) step_head_fc1(hf, g, br, nb, s.wb, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
+    PH(8) step_head_fc1<WREF, (XF != 0)>(hf, g, br, nb, s.wb, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
                         keep_scale, part);
     if (part == 1) return;
     BARRIER();
     EXIT_AFTER(9);
-    PH(9) step_head_loss(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    PH(9) step_head_loss<WREF, (XF != 0)>(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
     if (!hf.train) return;
     BARRIER();
     EXIT_AFTER(10);
-    PH(10) step_head_dreadout(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
+    PH(10) step_head_dreadout<WREF, (XF != 0)>(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
     BARRIER();
     EXIT_AFTER(11);
 
