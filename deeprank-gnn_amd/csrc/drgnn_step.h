@@ -471,18 +471,20 @@ DEV float xchg_wait(unsigned long long* slot, uint32_t tag) {
 // STEP_WBLD floats).  Loaded as float4 (8 lanes cover the 128 contiguous bytes of a row).
 #define STEP_WB_J 4        // float4 per lane: H * 8 <= STEP_WB_J * 1024  (H <= 512)
 #ifdef DRGNN_EMU
-struct WBlockRegs { int dummy; };
-DEV void step_wblock_load(WBlockRegs&, const HeadFused&, int) {}
-DEV void step_wblock_store(const WBlockRegs&, const HeadFused& hf, int br, float* wb) {
+template <int WJ> struct WBlockRegs { int dummy; };
+template <int WJ> DEV void step_wblock_load(WBlockRegs<WJ>&, const HeadFused&, int) {}
+template <int WJ> DEV void step_wblock_store(const WBlockRegs<WJ>&, const HeadFused& hf, int br, float* wb) {
     for (int h = 0; h < hf.H; ++h)
         for (int c = 0; c < DRGNN_H2; ++c) wb[h * STEP_WBLD + c] = hf.w1[(long)h * hf.R + br * DRGNN_H2 + c];
 }
 #else
-struct WBlockRegs { drgnn_f4 v[STEP_WB_J * DRGNN_BSCALE]; };
-DEV void step_wblock_load(WBlockRegs& wr, const HeadFused& hf, int br) {
+// WJ: float4 per lane; 1 covers H <= 128 (the reference heads -- what the width-specialised kernels are launched
+// for), STEP_WB_J the general case.  Twelve VGPRs apart, which is what the sGAT / FoutNet kernels spill otherwise.
+template <int WJ> struct WBlockRegs { drgnn_f4 v[WJ * DRGNN_BSCALE]; };
+template <int WJ> DEV void step_wblock_load(WBlockRegs<WJ>& wr, const HeadFused& hf, int br) {
     const bool vec = ((((uintptr_t)hf.w1) & 15) == 0);       // R = 32*n_branch floats: rows stay 16-byte aligned
 #pragma unroll
-    for (int j = 0; j < STEP_WB_J * DRGNN_BSCALE; ++j) {
+    for (int j = 0; j < WJ * DRGNN_BSCALE; ++j) {
         const int t = threadIdx.x + j * DRGNN_NTHREADS;
         const int h = t >> 3, q = t & 7;
         drgnn_f4 v = {0.f, 0.f, 0.f, 0.f};
@@ -494,10 +496,10 @@ DEV void step_wblock_load(WBlockRegs& wr, const HeadFused& hf, int br) {
         wr.v[j] = v;
     }
 }
-DEV void step_wblock_store(const WBlockRegs& wr, const HeadFused& hf, int br, float* wb) {
+template <int WJ> DEV void step_wblock_store(const WBlockRegs<WJ>& wr, const HeadFused& hf, int br, float* wb) {
     (void)br;
 #pragma unroll
-    for (int j = 0; j < STEP_WB_J * DRGNN_BSCALE; ++j) {
+    for (int j = 0; j < WJ * DRGNN_BSCALE; ++j) {
         const int t = threadIdx.x + j * DRGNN_NTHREADS;
         const int h = t >> 3, q = t & 7;
         if (h < hf.H) *(drgnn_f4*)(wb + h * STEP_WBLD + 4 * q) = wr.v[j];
@@ -789,7 +791,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     constexpr int Z2LD = GIN ? DRGNN_H2 + 4 : DRGNN_H2;      // GINet: Z2 rows feed a dense product (128-bit rows)
     StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
     EXIT_AFTER(0);
-    WBlockRegs wreg;
+    WBlockRegs<(XF != 0) ? 1 : STEP_WB_J> wreg;      // XF != 0: H is the reference width (step_burst_guaranteed)
     int* const dummy = (int*)(s.misc + 64);      // 64 words that absorb discarded lanes' LDS stores
     const uint32_t done = (uint32_t)a.step2[0];
     const uint32_t tag = done + 1u;
