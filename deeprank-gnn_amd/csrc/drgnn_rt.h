@@ -260,6 +260,7 @@ template <int J> DEV void burst_load_x(BurstX<J>& b, const float* src, int rows,
     const drgnn_f4* s4 = (const drgnn_f4*)src;
 #pragma unroll
     for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        if (j > 0 && b.n4 <= j * DRGNN_NTHREADS) break;          // uniform: the tile ends before this chunk
         const int q = threadIdx.x + j * DRGNN_NTHREADS;
         b.v[j] = (q < b.n4) ? s4[q] : drgnn_f4{0.f, 0.f, 0.f, 0.f};
     }
@@ -305,14 +306,18 @@ template <int J> DEV void bufburst_load(BufBurst<J>& b, const void* src, int n) 
     b.n = n;
     const __amdgpu_buffer_rsrc_t r = buf_rsrc(src, n * 4);
     const int voff = threadIdx.x * 4;
+    // chunks that lie wholly past the end are skipped by a branch on n alone (uniform for the whole workgroup):
+    // most arrays fill one chunk, their other load / store instructions would be issued by 16 waves for nothing
 #pragma unroll
     for (int j = 0; j < J * DRGNN_BSCALE; ++j)
-        b.v[j] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, j * DRGNN_NTHREADS * 4, 0);
+        if (j == 0 || n > j * DRGNN_NTHREADS)
+            b.v[j] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, j * DRGNN_NTHREADS * 4, 0);
 }
 template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* dummy) {
     int* d = (int*)dst;
 #pragma unroll
     for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        if (j > 0 && b.n <= j * DRGNN_NTHREADS) break;
         const int i = threadIdx.x + j * DRGNN_NTHREADS;
         int* p = (i < b.n) ? d + i : dummy + (threadIdx.x & 63);
         *p = b.v[j];
@@ -322,6 +327,7 @@ template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* d
 template <int J> DEV void bufburst_store16(const BufBurst<J>& b, unsigned short* dst, int* dummy) {
 #pragma unroll
     for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        if (j > 0 && b.n <= j * DRGNN_NTHREADS) break;
         const int i = threadIdx.x + j * DRGNN_NTHREADS;
         unsigned short* p = (i < b.n) ? dst + i : (unsigned short*)(dummy + (threadIdx.x & 63));
         *p = (unsigned short)b.v[j];
@@ -340,6 +346,7 @@ template <int J> DEV void burst_store_x4(const BurstX<J>& b, float* dst, int ld)
     const FastDiv fd = fastdiv_make(b.F >> 2);
 #pragma unroll
     for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        if (j > 0 && b.n4 <= j * DRGNN_NTHREADS) break;
         const int q = threadIdx.x + j * DRGNN_NTHREADS;
         if (q < b.n4) {
             const int row = fastdiv(fd, q);
