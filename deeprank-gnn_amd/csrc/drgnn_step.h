@@ -86,7 +86,15 @@ struct StepScratch {
     float* end;
 };
 
+// The head's small arrays come FIRST: their sizes depend on the head's widths only, so in the width-specialised
+// kernels (H = reference width, a constant) their offsets fold into immediates instead of living in pinned VGPRs.
 #define STEP_CARVE_LIST(X)                                                                     \
+    X(misc, 128, 1)                                                                            \
+    X(xr, R, 1)                                                                                \
+    X(hid, H, 1)                                                                               \
+    X(dhid, H, 1)                                                                              \
+    X(hb1, H, 1)                                                                               \
+    X(wb, step_gp_words((int)H), 1)                                                            \
     X(xs, (long)(capN + 4) * xld, 1)                                                           \
     X(w1t, DRGNN_H1 * xld, 1)                                                                  \
     X(ws1t, DRGNN_H1 * xld, !gin)                                                              \
@@ -125,12 +133,6 @@ struct StepScratch {
     X(p2, ((long)capC * DRGNN_H2 > (long)(capC + 4) * STEP_XPLD ? (long)capC * DRGNN_H2 : (long)(capC + 4) * STEP_XPLD), 1) \
     X(dv1, capC, !gin)                                                                         \
     X(sc1, capC, !gin)                                                                         \
-    X(misc, 128, 1)                                                                            \
-    X(xr, R, 1)                                                                                \
-    X(hid, H, 1)                                                                               \
-    X(dhid, H, 1)                                                                              \
-    X(wb, step_gp_words((int)H), 1)                                                            \
-    X(hb1, H, 1)                                                                               \
     X(hw2, (long)O * H, 1)                                                                     \
     X(hb2, O, 1)
 
@@ -789,7 +791,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     constexpr bool NARROW = (KIND == DRGNN_SGAT);
     typedef typename StepIdx<NARROW>::type EIdx;      // element type of the edge-indexed LDS arrays
     constexpr int Z2LD = GIN ? DRGNN_H2 + 4 : DRGNN_H2;      // GINet: Z2 rows feed a dense product (128-bit rows)
-    StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, H, O);
+    StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, (XF != 0) ? WREF : H, O);
     EXIT_AFTER(0);
     WBlockRegs<(XF != 0) ? 1 : STEP_WB_J> wreg;      // XF != 0: H is the reference width (step_burst_guaranteed)
     int* const dummy = (int*)(s.misc + 64);      // 64 words that absorb discarded lanes' LDS stores
