@@ -86,8 +86,9 @@ struct StepScratch {
     float* end;
 };
 
-// The head's small arrays come FIRST: their sizes depend on the head's widths only, so in the width-specialised
-// kernels (H = reference width, a constant) their offsets fold into immediates instead of living in pinned VGPRs.
+// The head's small arrays and the weights come FIRST: their sizes depend on the head's widths and on the padded
+// feature width only, so in the width-specialised kernels (both constants) their offsets fold into immediates instead
+// of living in pinned VGPRs.
 #define STEP_CARVE_LIST(X)                                                                     \
     X(misc, 128, 1)                                                                            \
     X(xr, R, 1)                                                                                \
@@ -95,7 +96,6 @@ struct StepScratch {
     X(dhid, H, 1)                                                                              \
     X(hb1, H, 1)                                                                               \
     X(wb, step_gp_words((int)H), 1)                                                            \
-    X(xs, (long)(capN + 4) * xld, 1)                                                           \
     X(w1t, DRGNN_H1 * xld, 1)                                                                  \
     X(ws1t, DRGNN_H1 * xld, !gin)                                                              \
     X(b1, DRGNN_H1, !gin)                                                                      \
@@ -104,6 +104,7 @@ struct StepScratch {
     X(ws2t, DRGNN_H2 * STEP_XPLD, !gin)                                                        \
     X(ws2n, DRGNN_H1 * (DRGNN_H2 + 4), !gin)                                                   \
     X(b2, DRGNN_H2, !gin)                                                                      \
+    X(xs, (long)(capN + 4) * xld, 1)                                                           \
     X(rp0, capN + 1, 1)                                                                        \
     X(cx0, (sg ? (capE + 1) / 2 : capE), 1)                                                    \
     X(ew0, capE, sg)                                                                           \
@@ -791,7 +792,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     constexpr bool NARROW = (KIND == DRGNN_SGAT);
     typedef typename StepIdx<NARROW>::type EIdx;      // element type of the edge-indexed LDS arrays
     constexpr int Z2LD = GIN ? DRGNN_H2 + 4 : DRGNN_H2;      // GINet: Z2 rows feed a dense product (128-bit rows)
-    StepScratch s = step_carve(scratch, KIND, F, capN, capE, capC, R, (XF != 0) ? WREF : H, O);
+    StepScratch s = step_carve(scratch, KIND, (XF != 0) ? XF : F, capN, capE, capC, R, (XF != 0) ? WREF : H, O);
     EXIT_AFTER(0);
     WBlockRegs<(XF != 0) ? 1 : STEP_WB_J> wreg;      // XF != 0: H is the reference width (step_burst_guaranteed)
     int* const dummy = (int*)(s.misc + 64);      // 64 words that absorb discarded lanes' LDS stores
