@@ -37,8 +37,8 @@ N_FEAT = 32
 # algorithmic HBM bytes per graph (derivation table): GINet
 BYTES_FWD, BYTES_BWD = 67668, 90208
 BYTES_TOPO = 4804 + 1800 + 5808 + 16 * 1000        # read edge_index (int64 [2,E]) + clusters, write CSR0 + pooled CSR
-PMC_FILE = "r01_bench_native_v11_pmc.json"
-SQ_FILE = "r01_bench_native_v11_sq.json"
+PMC_FILE = "r01_bench_native_v12_pmc.json"
+SQ_FILE = "r01_bench_native_v12_sq.json"
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
 
 
