@@ -29,7 +29,7 @@ def dump(title):
 
 for rep in range(2):
     buf.zero_()
-    topo = Topology.from_batch(batch, api=api)
+    topo = Topology.from_batch(batch, api=api, need_weights=(kind_name == "sGAT"))   # GINet / FoutNet: no edge weights
     if rep: dump("k_topo")
     buf.zero_(); torch.cuda.synchronize()
     x = batch.x
