@@ -156,6 +156,12 @@ HD int64_t step_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, i
 #else
 #define STEP_PIN(x) asm volatile("" : "+v"(x))
 #endif
+constexpr bool step_streq(const char* a, const char* b) { return *a == *b && (*a == 0 || step_streq(a + 1, b + 1)); }
+constexpr bool step_cold_array(const char* n) {
+    return step_streq(n, "ew0") || step_streq(n, "ts0") || step_streq(n, "ew1") || step_streq(n, "ts1") ||
+           step_streq(n, "dv0") || step_streq(n, "sc0") || step_streq(n, "dv1") || step_streq(n, "sc1") ||
+           step_streq(n, "b1") || step_streq(n, "b2");
+}
 DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int capC, int R, int H, int O) {
     const int hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
     const int hc2 = (kind == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
@@ -167,9 +173,12 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
     // Every array offset is pinned in a vector register once: there are too many of them for the
     // scalar file, and otherwise each phase of each wave recomputes its operands' offsets from the
     // capacities (measured: ~15% of the kernel).
+    // Arrays only the sGAT / FoutNet variants use in one or two phases (edge weights, transposed slots, degree and
+    // scale vectors, biases) are NOT pinned: their offset is one add away from the pinned offset in front of them (the
+    // running offset restarts from every pinned value), and those kernels sit at the VGPR limit.
 #define X(name, words, cond)                                                          \
-    { int off = o; STEP_PIN(off); s.name = (decltype(s.name))(base + off); }          \
-    o += (cond) ? (int)(((long)(words) + 3) & ~3L) : 0;
+    { int off = o; if (!step_cold_array(#name)) { STEP_PIN(off); } s.name = (decltype(s.name))(base + off);          \
+      o = off + ((cond) ? (int)(((long)(words) + 3) & ~3L) : 0); }
     STEP_CARVE_LIST(X)
 #undef X
     s.end = base + o;
