@@ -34,12 +34,51 @@ import torch.nn.functional as F
 
 GRAPHS_PER_GPU = 64
 N_FEAT = 32
-# algorithmic HBM bytes per graph (derivation table): GINet
-BYTES_FWD, BYTES_BWD = 67668, 90208
-BYTES_TOPO = 4804 + 1800 + 5808 + 16 * 1000        # read edge_index (int64 [2,E]) + clusters, write CSR0 + pooled CSR
-PMC_FILE = "r01_bench_native_v12_pmc.json"
-SQ_FILE = "r01_bench_native_v12_sq.json"
+# ALGORITHMIC HBM bytes per graph, forward + backward (derivation table): the figure
+# roofline.achieved / roofline.frac are computed from.  (fwd, bwd) per net.
+ALG_BYTES = {"GINet": (67668, 90208), "sGAT": (62440, 49904), "FoutNet": (52840, 45104)}
+# what the co-launched topology builder moves on top of that (NOT part of §8(d)'s figure; reported separately as
+# roofline.with_builder): read edge_index (int64 [2,E]) + clusters, write CSR0 + pooled CSR (+ edge_attr for sGAT)
+BYTES_TOPO = {"GINet": 4804 + 1800 + 5808 + 16 * 1000, "FoutNet": 4804 + 1800 + 5808 + 16 * 1000,
+              "sGAT": 4804 + 1800 + 5808 + 16 * 1000 + 4000 + 4 * 200}
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
+MIN_TIMED_SECONDS = 0.25                            # the K-step block is repeated until the timed region is this long
+
+
+def source_hash():
+    """sha256 (16 hex digits) over the kernel sources: the key that ties a committed rocprofv3 counter summary
+    (profiles/*_pmc.json, *_sq.json: collected offline, PMC passes cannot run inside this process) to the build it
+    was taken from.  A summary of another build is NOT reported."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "deeprank-gnn_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip")))
+    files.append(os.path.join(ROOT, "include", "drgnn.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def counter_summary(kind, net_name):
+    """(values, note): the per-kernel counter averages of profiles/*_<kind>.json (kind = 'pmc' | 'sq') whose
+    recorded source hash AND net match this build, else (None, reason)."""
+    import glob
+    want = source_hash()
+    seen = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_%s.json" % kind)), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        meta = d.get("_meta") if isinstance(d, dict) else None
+        if not meta:
+            continue
+        seen.append(os.path.basename(path))
+        if meta.get("source_hash") == want and meta.get("net", "GINet") == net_name:
+            return d, os.path.basename(path)
+    return None, ("no counter summary under profiles/ was collected from this build (source hash %s, net %s; "
+                  "collect with tools/collect_profiles.sh)" % (want, net_name))
 
 
 def parse():
@@ -68,6 +107,9 @@ def parse():
     ap.add_argument("--epoch-graphs", type=int, default=4096,
                     help="size of the resident graph set of the secondary whole-epoch measurement (0: skip it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--min-seconds", type=float, default=MIN_TIMED_SECONDS,
+                    help="the K-step block is repeated until the timed region is at least this long (0: one block; "
+                         "used by the rocprofv3 counter passes, which only need a few launches)")
     return ap.parse_args()
 
 
@@ -79,6 +121,17 @@ def main():
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "NONE"
     GRAPHS_PER_GPU = args.graphs_per_gpu
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not launched by torch.distributed.run: spawn the N ranks ourselves (same command line) instead of
+        # silently measuring one GPU
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -249,7 +302,7 @@ def main():
                             and os.environ.get("DRGNN_DP_GRAPH", "1") != "0")
             if use_dp_graph:
                 try:
-                    DP_CHUNK = 2 * max(1, args.steps_per_replay // 2)
+                    DP_CHUNK = 2 * max(1, min(args.steps_per_replay, max(args.steps, 2)) // 2)
 
                     def dp_chunk():
                         for _ in range(DP_CHUNK):
@@ -308,7 +361,7 @@ def main():
             if two_flavours:
                 # one replay = CHUNK steps (an even number: the workspace parity returns to 0); the
                 # remainder of any --steps / --warmup runs through single-step graphs of either parity
-                CHUNK = 2 * max(1, args.steps_per_replay // 2)
+                CHUNK = 2 * max(1, min(args.steps_per_replay, max(args.steps, 2)) // 2)
 
                 def chunk():
                     for _ in range(CHUNK):
@@ -340,21 +393,50 @@ def main():
             for _ in range(n):
                 eager_step()
 
-    run_steps(max(args.warmup - pre_steps, 0))
+    # Warm-up: W steps as asked, rounded UP to an even count so that the two topology workspaces are back at
+    # parity 0 and every timed block starts on the recorded chunk (a block of K steps = K // CHUNK chunk replays
+    # + K % CHUNK single-step replays, whatever K and W are).
+    warm = max(args.warmup - pre_steps, 0)
+    if two_flavours_parity(state):
+        warm += 1
+    warm += warm & 1
+    run_steps(warm)
+    torch.cuda.synchronize()
+    # One untimed block to size the timed region: the K-step block is repeated until the region is at least
+    # MIN_TIMED_SECONDS long (a single 20-step block is ~0.5 ms: shorter than a host timer tick is accurate for
+    # and invisible to an SMI poll).  Every rank uses the same repeat count.
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    t_block = max(time.perf_counter() - t0, 1e-6)
+    if args.steps & 1:
+        run_steps(1)                          # parity back to 0
+    repeats = int(min(max(1, -(-args.min_seconds // t_block)), 20000))
+    if world > 1:
+        t = torch.tensor([repeats], device=dev, dtype=torch.int64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        repeats = int(t.item())
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(repeats + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    ev[0].record()
+    for r in range(repeats):
+        run_steps(args.steps)
+        ev[r + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    blocks_ms = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(repeats))
+    block_med_ms = blocks_ms[len(blocks_ms) // 2]
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, block_med_ms], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, block_med_ms = float(t[0].item()), float(t[1].item())
+    timed_steps = args.steps * repeats
     final_loss = float(loss_out.item())
     in_sync = None
     if world > 1:
@@ -369,12 +451,16 @@ def main():
 
     result = None
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = GRAPHS_PER_GPU * world * args.steps / elapsed
+        # wall clock over `repeats` back-to-back blocks of K steps (barrier + synchronize on both sides, max over
+        # ranks): K x repeats steps in `elapsed`
+        ms = elapsed / timed_steps * 1e3
+        value = GRAPHS_PER_GPU * world * timed_steps / elapsed
         result = {
-            "metric": "interface-graphs/sec (fwd+bwd) %s batch=64 per GPU" % args.net,
+            "metric": "interface-graphs/sec (fwd+bwd) %s batch=%d per GPU" % (args.net, GRAPHS_PER_GPU),
             "value": value, "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms, "repeats": repeats, "timed_steps": timed_steps,
+            "timed_seconds": elapsed, "block_ms_median": block_med_ms,
+            "ms_per_step_median_block": block_med_ms / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s train step (topology + body fwd + FC head/MSE + bwd + grad all-reduce + Adam) on SYN graphs: "
                                    "200 nodes, ~1000 directed edges, 32 node feats, 50->16 clusters "
@@ -388,8 +474,8 @@ def main():
         if split:
             result["config"]["dp_exchange"] = dp_mode
             result["config"]["params_in_sync"] = in_sync
-        if args.net == "GINet":
-            result["roofline"] = measure_roofline(net, batch, dev, value)
+        if native:
+            result["roofline"] = measure_roofline(net, args.net, batch, dev, value / world)
         if world == 1 and native and args.epoch_graphs > 0:
             try:
                 result["epoch_loop"] = measure_epoch_loop(Net, args.net, args.epoch_graphs, dev)
@@ -411,19 +497,30 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
-    """Average duration of each launch of the native step, measured with HIP events around
-    `iters` back-to-back launches (replayed from a hipGraph on torch's current stream = the stream
-    the kernels are launched on), and the dominant one against the HBM roofline.  Algorithmic bytes: SURVEY.md §8(d)
-    per-graph figures x 64 graphs."""
+def two_flavours_parity(state):
+    return state["k"] == 1
+
+
+def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400):
+    """Average duration of each launch of the native step, measured LIVE with HIP events around `iters`
+    back-to-back launches (20 per hipGraph replay, on torch's current stream = the stream the kernels are launched
+    on), and the dominant one against the HBM roofline.
+
+    roofline.achieved = ALGORITHMIC bytes per launch / that duration, algorithmic bytes = SURVEY.md §8(d)'s per-graph
+    figure for forward + backward of this net (GINet 157 876 B, sGAT 112 344 B, FoutNet 97 944 B) x the graphs one
+    launch processes.  The bytes the co-launched topology builder moves in the same launch are NOT part of §8(d)'s
+    figure: the figure that includes them is reported separately (`with_builder`)."""
     import copy
     from deeprank_gnn_amd import _lib
     from deeprank_gnn_amd.topology import Topology
     from deeprank_gnn_amd.trainer import FusedTrainer
+    need_w = net_name == "sGAT"
     tr = FusedTrainer(copy.deepcopy(net), lr=1e-3, task="reg", seed=99)
-    topo = Topology.from_batch(batch, need_weights=False)
-    nxt = Topology.from_batch(batch, need_weights=False, build=False)
+    topo = Topology.from_batch(batch, need_weights=need_w)
+    nxt = Topology.from_batch(batch, need_weights=need_w, build=False)
     assert tr._can_fuse(topo, batch.x.shape[1]), "SYN graphs must take the fused-step path"
+    variant = tr.api.step_is_specialised(tr.kind, batch.x, batch.x.shape[1], topo.max_nodes, topo.max_edges,
+                                         topo.max_c0, tr.H, tr.O)
     c = tr._fused_prepare(batch, topo)
     B = c["B"]
 
@@ -443,17 +540,16 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
         c["stream"] = _lib.current_stream(c["x"])      # the capture stream while capturing
         fn()
 
+    fwd_b, bwd_b = ALG_BYTES[net_name]
+    alg = fwd_b + bwd_b
     upd_bytes = (c["partials"].numel() + c["hp"].numel() + c["readout"].numel() + 7 * tr.flat_p.numel()) * 4 / B
-    # SURVEY figures of forward + backward (the fused launch moves less: xp/arg0/arg1 stay in LDS)
-    step_bytes = BYTES_FWD - 5808 + BYTES_BWD
+    kname = "k_step_co_topo<%s,%d>" % (net_name, variant)
     out = {}
     for name, fn, nbytes in (
-            ("k_step_co_topo<GINet> (fwd + head/loss + bwd, + topology of the next batch)", k_step_co,
-             step_bytes + BYTES_TOPO),
+            (kname + " (fwd + head/loss + bwd, + topology of the next batch)", k_step_co, alg),
             ("k_update (partials reduction + Adam)", k_update, upd_bytes),
-            ("k_topo (own launch; not on the pipelined path)", k_topo, BYTES_TOPO),
-            ("k_step_co_topo<GINet> without the co-launched topology (not on the pipelined path)", k_step,
-             step_bytes)):
+            ("k_topo (own launch; not on the pipelined path)", k_topo, BYTES_TOPO[net_name]),
+            (kname + " without the co-launched topology (not on the pipelined path)", k_step, alg)):
         # 20 back-to-back launches per hipGraph replay: the device-side duration, not the host's launch rate
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -480,26 +576,41 @@ def measure_roofline(net, batch, dev, graphs_per_s, iters=200):
     on_path = list(out)[:2]
     dom = max(on_path, key=lambda k: out[k]["avg_us"])
     ach = out[dom]["achieved_GBs"]
-    traffic = None
-    pmc_path = os.path.join(ROOT, "profiles", PMC_FILE)
-    if os.path.exists(pmc_path):          # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this same command (offline passes)
-        pmc = json.load(open(pmc_path))
-        for k, v in pmc.items():
-            if "k_step_co_topo" in k and "k_step_co_topo" in dom:
-                traffic = v["hbm_bytes_per_launch"]
-    mfma = None
-    sq_path = os.path.join(ROOT, "profiles", SQ_FILE)
-    if os.path.exists(sq_path):           # rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES of this same command (offline pass)
-        for k, v in json.load(open(sq_path)).items():
-            if "k_step_co_topo" in k and "k_step_co_topo" in dom:
-                # busy cycles summed over SIMDs / (1024 SIMDs x kernel cycles at the measured 2.28 GHz shader clock)
-                mfma = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (out[dom]["avg_us"] * 1e3 * 2.28 * 1024.0)
+    step_us = out[on_path[0]]["avg_us"]
+    with_builder = (alg + BYTES_TOPO[net_name]) * B / (step_us * 1e-6) / 1e9
+    # HBM traffic and MFMA busy cycles come from rocprofv3 --pmc passes, which cannot run inside this process: they
+    # are read from the summary under profiles/ that was collected from THIS build (matched by source hash and net),
+    # and reported as null otherwise
+    traffic, traffic_note, mfma, mfma_note = None, None, None, None
+    if "k_step_co_topo" in dom:
+        pmc, where = counter_summary("pmc", net_name)
+        if pmc is None:
+            traffic_note = where
+        else:
+            for k, v in pmc.items():
+                if "k_step_co_topo" in k:
+                    traffic = v["hbm_bytes_per_launch"]
+                    traffic_note = ("bytes/launch from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, "
+                                    "profiles/%s, same sources as this build); FETCH doubled per "
+                                    "MI355X_MICROARCH.md" % where)
+        sq, where = counter_summary("sq", net_name)
+        if sq is None:
+            mfma_note = where
+        else:
+            for k, v in sq.items():
+                if "k_step_co_topo" in k:
+                    # busy cycles summed over SIMDs / (1024 SIMDs x kernel cycles at the 2.28 GHz shader clock)
+                    mfma = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (step_us * 1e3 * 2.28 * 1024.0)
+                    mfma_note = "SQ_VALU_MFMA_BUSY_CYCLES from profiles/%s (same sources as this build)" % where
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "mfma_util": mfma,
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_note": "bytes/launch from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, profiles/"
-                            "%s); FETCH doubled per MI355X_MICROARCH.md" % PMC_FILE,
-            "whole_step_frac": graphs_per_s * (BYTES_FWD + BYTES_BWD) / 1e9 / HBM_PEAK_GBS,
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+            "mfma_util": mfma, "mfma_note": mfma_note,
+            "alg_bytes_per_graph": alg, "graphs_per_launch": B, "source_hash": source_hash(),
+            "with_builder": {"achieved": with_builder, "frac": with_builder / HBM_PEAK_GBS,
+                             "bytes_per_graph": alg + BYTES_TOPO[net_name],
+                             "note": "adds what the co-launched topology builder of the same launch moves (int64 "
+                                     "edge_index + clusters read, CSR0 + pooled CSR written); not SURVEY 8(d)'s figure"},
+            "whole_step_frac": graphs_per_s * alg / 1e9 / HBM_PEAK_GBS,
             "kernels": out}
 
 

@@ -142,6 +142,8 @@ class Api(object):
                                            [ctypes.c_float] * 4 + [_c_i32, _vp])
         lib.drgnn_net_step_lds_bytes.argtypes = [_c_i32] * 8
         lib.drgnn_net_step_lds_bytes.restype = _c_i64
+        lib.drgnn_net_step_variant.argtypes = [_c_i32, _vp] + [_c_i32] * 6
+        lib.drgnn_net_step_variant.restype = _c_i32
         lib.drgnn_head_compact_elems.argtypes = [_c_i32] * 3
         lib.drgnn_head_compact_elems.restype = _c_i64
         lib.drgnn_net_train_step.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc)] + [_vp] * 5 +
@@ -264,6 +266,10 @@ class Api(object):
     # -- fused training step ------------------------------------------------------
     def net_step_lds_bytes(self, kind, n_feat, max_nodes, max_edges, max_c0, R, H, O):
         return int(self.lib.drgnn_net_step_lds_bytes(kind, n_feat, max_nodes, max_edges, max_c0, R, H, O))
+
+    def step_is_specialised(self, kind, x, n_feat, max_nodes, max_edges, max_c0, H, O):
+        """Padded feature width of the width-specialised fused step kernel these bounds launch (0: generic)."""
+        return int(self.lib.drgnn_net_step_variant(kind, _ptr(x), n_feat, max_nodes, max_edges, max_c0, H, O))
 
     def head_compact_elems(self, R, H, O):
         return int(self.lib.drgnn_head_compact_elems(R, H, O))

@@ -1055,6 +1055,18 @@ int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes
 
 int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O) { return head_compact_floats(R, H, O); }
 
+static int step_variant(int kind, const float* x, int F, int capN, int capE, int capC, int H, int O) {
+    if (!step_burst_guaranteed(kind, x, F, capN, capE, capC, H, O)) return 0;
+    const int f16 = step_pad16(F);
+    return (f16 == 16 || f16 == 32 || f16 == 48 || f16 == 64) ? f16 : 0;
+}
+
+int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
+                               int32_t max_c0, int32_t H, int32_t O) {
+    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    return step_variant(kind, x, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, H, O);
+}
+
 int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, const float* x,
                          const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
                          int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
@@ -1142,7 +1154,7 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
         // anything else runs the generic kernel
 #define DRGNN_STEP_WIDTHS(K)                                                                                \
     do {                                                                                                    \
-        switch (step_burst_guaranteed(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) ? step_pad16(F) : 0) {   \
+        switch (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O)) {                          \
             case 16: DRGNN_STEP_LAUNCH(K, 16); break;                                                       \
             case 32: DRGNN_STEP_LAUNCH(K, 32); break;                                                       \
             case 48: DRGNN_STEP_LAUNCH(K, 48); break;                                                       \

@@ -381,6 +381,11 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
 int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                  int32_t max_c0, int32_t R, int32_t H, int32_t O);
 int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O);
+/* Which instantiation of the fused step kernel drgnn_net_train_step launches for these bounds: the padded
+ * feature width (16/32/48/64) of the width-specialised kernel, or 0 for the generic one.  Host-side only
+ * (lets tests and bench.py state which kernel instance they exercised). */
+int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
+                               int32_t max_c0, int32_t H, int32_t O);
 int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head, const float* x,
                          const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
                          int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,

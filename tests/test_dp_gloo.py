@@ -70,6 +70,52 @@ def test_two_rank_training_matches_single_process(net_name, sizes):
     np.testing.assert_allclose(p[0], tr.flat_p.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def _worker8(rank, world, init_file, out_dir):
+    from emu_api import emu
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    graphs = _graphs(8 * world)
+    batch = Batch.from_data_list(graphs[8 * rank:8 * rank + 8])
+    tr = FusedTrainer(_make_net("GINet"), lr=0.01, api=emu())
+    tr.compute_gradients(batch)
+    np.save(os.path.join(out_dir, "l%d.npy" % rank), tr.flat_g.numpy().copy())     # this rank's shard gradient
+    tr.all_reduce_gradients()                                                       # equal shards: 1 / world
+    np.save(os.path.join(out_dir, "g%d.npy" % rank), tr.flat_g.numpy().copy())
+    tr.apply_update()
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), tr.flat_p.numpy().copy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gradients_match_single_process():
+    """DP-8 gradients == single-process gradients on the same graphs (1e-5 relative).  8 ranks x 8
+    graphs over gloo; the single process runs the union of the 64 graphs as one batch."""
+    from emu_api import emu
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    emu()
+    world = 8
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_worker8, args=(world, init_file, tmp), nprocs=world, join=True)
+        g = [np.load(os.path.join(tmp, "g%d.npy" % r)) for r in range(world)]
+        loc = [np.load(os.path.join(tmp, "l%d.npy" % r)) for r in range(world)]
+        p = [np.load(os.path.join(tmp, "p%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(g[0], g[r])       # every rank holds the same reduced gradient ...
+        np.testing.assert_array_equal(p[0], p[r])       # ... and the same parameters after Adam
+    assert any(not np.array_equal(loc[0], loc[r]) for r in range(1, world))     # shards really differ
+    tr = FusedTrainer(_make_net("GINet"), lr=0.01, api=emu())
+    tr.compute_gradients(Batch.from_data_list(_graphs(8 * world)))
+    ref = tr.flat_g.numpy()
+    scale = float(np.abs(ref).max())
+    np.testing.assert_allclose(g[0], ref, rtol=1e-5, atol=1e-5 * scale)
+    tr.apply_update()
+    np.testing.assert_allclose(p[0], tr.flat_p.numpy(), rtol=1e-5, atol=1e-6)
+
+
 def test_shard_range_covers_everything():
     from deeprank_gnn_amd.parallel import shard_range
     for n in (0, 1, 7, 64, 513):

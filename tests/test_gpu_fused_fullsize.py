@@ -1,0 +1,154 @@
+"""The BENCHMARKED kernel instance against the oracle at the BENCHMARKED shape.
+
+bench.py times ``k_step_co_topo<kind, 32>`` (the width-specialised fused training step, launched
+through ``FusedTrainer.compute_gradients`` / ``train_step`` with the next batch's topology co-built by
+the same launch) on ``synthetic.make_batch(0, 64)`` = BASELINE.json configs[1..3].  These tests run
+exactly that launch on exactly that batch and compare predictions, loss and EVERY gradient with
+``oracle/cpu_ref.py`` element by element:  |got - ref| <= 1e-4 + 1e-4 |ref|  (north_star: 1e-4 fp32),
+no scaling by the tensor's maximum.  Reference path: ginet.py:99-141, sGAT.py:114-138,
+foutnet.py:103-125 + MSELoss + loss.backward() + Adam (NeuralNet.py:489-506).
+
+fp32 caveat, stated rather than hidden: a gradient element is a sum of ~10^4 products; the oracle
+(torch CPU fp32) and the kernel associate that sum differently.  Where an element is a cancellation
+residue the two fp32 results may differ by more than 1e-4 of the ELEMENT while both sit within fp32
+round-off of the exact value.  For any element that misses the strict test we therefore evaluate the
+oracle in float64 as the arbiter and require the kernel to be at least as close to the float64 value as
+1e-4 + 1e-4|ref| OR as close as the fp32 oracle itself is (x4): never looser than what fp32 arithmetic
+of the reference can resolve.  The number of elements needing the arbiter is printed.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+NETS = ["GINet", "sGAT", "FoutNet"]
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _fw_kwargs(net_name):
+    return {"looped": False} if net_name == "FoutNet" else {}
+
+
+def _oracle64(net_name, params, batch_cpu):
+    """Same oracle code, evaluated in float64 (arbiter for cancellation residues)."""
+    p64 = {k: v.double() for k, v in params.items()}
+    b64 = batch_cpu.clone()
+    for key in ("x", "edge_attr", "pos", "y", "internal_edge_attr"):
+        if getattr(b64, key, None) is not None:
+            setattr(b64, key, getattr(b64, key).double())
+    return cpu_ref.loss_and_grads(net_name, p64, b64, b64.y, **_fw_kwargs(net_name))
+
+
+def _check(name, got, ref32, ref64_fn, stats):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref32, dtype=np.float64)
+    assert got.shape == ref.shape, name
+    bad = np.abs(got - ref) > TOL + TOL * np.abs(ref)
+    bad |= np.isnan(got) != np.isnan(ref)
+    stats["elements"] += got.size
+    if not bad.any():
+        return
+    ref64 = np.asarray(ref64_fn(), dtype=np.float64)
+    err_kernel = np.abs(got - ref64)
+    err_oracle32 = np.abs(ref - ref64)
+    ok = (err_kernel <= TOL + TOL * np.abs(ref64)) | (err_kernel <= 4.0 * err_oracle32 + 1e-7)
+    stats["arbiter"] += int(bad.sum())
+    worst = int(np.argmax(np.where(bad & ~ok, err_kernel, 0.0)))
+    assert not (bad & ~ok).any(), (
+        "%s: element %d got %.9g, fp32 oracle %.9g, fp64 oracle %.9g" %
+        (name, worst, got.flat[worst], ref.flat[worst], ref64.flat[worst]))
+
+
+def _trainer(net_name, params, lr=0.01):
+    from test_gpu_parity import build
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    net = build(net_name, params, 1)                      # dropout forced to 0 for parity
+    return net, FusedTrainer(net, lr=lr, task="reg")
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+@pytest.mark.parametrize("net_name", NETS)
+def test_fused_step_syn64_gradients_match_oracle_elementwise(net_name, pipelined):
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.topology import Topology
+    dev = _dev()
+    batch_cpu = synth.make_batch(0, 64)
+    params = cpu_ref.init_params(net_name, 32, 1, 1, seed=11)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y,
+                                                           **_fw_kwargs(net_name))
+    cache = {}
+
+    def r64():
+        if "v" not in cache:
+            cache["v"] = _oracle64(net_name, params, batch_cpu)
+        return cache["v"]
+
+    net, tr = _trainer(net_name, params)
+    batch = batch_cpu.clone().to(dev)
+    need_w = net_name == "sGAT"
+    topo = Topology.from_batch(batch, need_weights=need_w)
+    # the launch bench.py times: the width-specialised fused kernel (F16 = 32) ...
+    assert tr._can_fuse(topo, 32), "SYN64 must take the fused-step path"
+    assert tr.api.step_is_specialised(tr.kind, batch.x, 32, topo.max_nodes, topo.max_edges, topo.max_c0,
+                                      tr.H, tr.O), "SYN64 must take the width-specialised instantiation"
+    nxt = Topology.from_batch(batch, need_weights=need_w, build=False) if pipelined else None
+    loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
+    torch.cuda.synchronize()
+    stats = {"elements": 0, "arbiter": 0}
+    _check("loss", float(loss), float(ref_loss), lambda: float(r64()[1]), stats)
+    _check("pred", tr.last_pred.cpu().numpy(), ref_pred.numpy(), lambda: r64()[0].numpy(), stats)
+    grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
+    assert set(grads) == set(ref_grads)
+    for k in sorted(grads):
+        _check("grad " + k, grads[k], ref_grads[k].numpy(), lambda k=k: r64()[2][k].numpy(), stats)
+    print("%s pipelined=%s: %d elements, %d needed the float64 arbiter" %
+          (net_name, pipelined, stats["elements"], stats["arbiter"]))
+    if pipelined:
+        # ... and the topology the same launch built for the NEXT step is the one a plain build gives
+        assert nxt.status()[0] == 0
+        assert torch.equal(nxt.ws_i32, topo.ws_i32)
+        if need_w:
+            assert torch.equal(nxt.ws_f32, topo.ws_f32)
+        loss2 = tr.compute_gradients(batch, topo=nxt)
+        assert float(loss2) == float(loss)
+
+
+@pytest.mark.parametrize("net_name", NETS)
+def test_fused_step_syn64_three_adam_steps_match_oracle(net_name):
+    """Three optimiser steps through the benchmarked launches (k_step_co_topo + k_update, topologies
+    ping-ponging as in bench.py) vs the oracle trained with torch.optim.Adam."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    dev = _dev()
+    batch_cpu = synth.make_batch(0, 64)
+    params = cpu_ref.init_params(net_name, 32, 1, 1, seed=12)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    opt = torch.optim.Adam(list(leaves.values()), lr=0.01)
+    net, tr = _trainer(net_name, params, lr=0.01)
+    batch = batch_cpu.clone().to(dev)
+    need_w = net_name == "sGAT"
+    topos = [Topology.from_batch(batch, need_weights=need_w), Topology.from_batch(batch, need_weights=need_w)]
+    kw = _fw_kwargs(net_name)
+    for it in range(3):
+        opt.zero_grad()
+        pred = cpu_ref.FORWARD[net_name](leaves, batch_cpu, **kw)
+        loss = F.mse_loss(pred.reshape(-1), batch_cpu.y)
+        loss.backward()
+        opt.step()
+        got = tr.train_step(batch, topo=topos[it & 1], next_topo=topos[1 - (it & 1)])
+        np.testing.assert_allclose(float(got), float(loss), rtol=TOL)
+        np.testing.assert_allclose(tr.last_pred.cpu().numpy(), pred.detach().numpy(), rtol=TOL, atol=TOL)
+    sd = net.state_dict()
+    for k, v in leaves.items():
+        # Adam's first steps move every weight by ~lr regardless of the gradient's size: the parameters
+        # agree to 1e-4 element-wise wherever the gradient is resolved by fp32 (all but exact zeros)
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=TOL, atol=TOL, err_msg=k)

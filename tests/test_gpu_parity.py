@@ -46,8 +46,11 @@ def test_library_is_the_hip_build():
     from deeprank_gnn_amd import _lib
     api = _lib.get()
     assert api.path.endswith("csrc/libdrgnn.so")
-    maps = open("/proc/self/maps").read()
-    assert "libdrgnn.so" in maps and "libdrgnn_emu" not in maps.replace("libdrgnn_emu.so", "") or True
+    assert api.lib.drgnn_abi_version() == 1
+    mapped = [ln.split()[-1] for ln in open("/proc/self/maps") if "libdrgnn" in ln]
+    assert any(m.endswith("csrc/libdrgnn.so") for m in mapped), mapped
+    # the package's API object must be bound to the gfx950 build, not to the host-emulation build of the CPU suite
+    assert "libdrgnn_emu" not in api.path
 
 
 @pytest.mark.parametrize("which", ["fix8", "fix10", "syn4", "syn3_full", "derived"])

@@ -1,43 +1,74 @@
-"""Turn rocprofv3 CSV output (gpurun_out/...) into the tracked summaries under profiles/.
+"""Turn rocprofv3 CSV output (gpurun_out/<tag>/, written by tools/collect_profiles.sh) into the tracked summaries
+under profiles/.
 
-usage: python tools/summarize_profile.py <tag> <kernel_stats.csv> [<fetch counter_collection.csv> <write counter_collection.csv>
-                                          [<SQ counter_collection.csv> ...]]
-writes profiles/<tag>_kernel_stats.csv (the rocprofv3 --stats table, top rows),
-       profiles/<tag>_summary.md, profiles/<tag>_pmc.json (per-kernel FETCH_SIZE / WRITE_SIZE averages),
-       profiles/<tag>_sq.json (per-kernel averages of the SQ / GRBM counters of the extra passes)."""
+usage: python tools/summarize_profile.py <name> <gpurun_out/tag dir> [net]
+writes profiles/<name>_kernel_stats.csv (the rocprofv3 --stats table, top rows),
+       profiles/<name>_summary.md,
+       profiles/<name>_pmc.json (per-kernel FETCH_SIZE / WRITE_SIZE averages, FETCH doubled per MI355X_MICROARCH.md),
+       profiles/<name>_sq.json  (per-kernel averages of the SQ / GRBM counters of the extra passes),
+       profiles/<name>_benchline.json, <name>_benchline_driver_args.json (the bench lines of the same build).
+The two json summaries carry `_meta` = {source_hash, net}: bench.py reports roofline.traffic / mfma_util from them
+only when the hash matches the sources it runs from."""
 import collections
 import csv
+import glob
 import json
 import os
+import shutil
 import sys
 
-tag, stats = sys.argv[1], sys.argv[2]
+name, src = sys.argv[1], sys.argv[2]
+net = sys.argv[3] if len(sys.argv) > 3 else "GINet"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
 out = os.path.join(root, "profiles")
+
+
+def find(sub, suffix):
+    hits = sorted(glob.glob(os.path.join(src, sub, "**", "*" + suffix), recursive=True))
+    return hits[0] if hits else None
+
+
+def source_hash():
+    import bench
+    return bench.source_hash()
+
+
+meta = {"source_hash": source_hash(), "net": net,
+        "command": "tools/collect_profiles.sh (rocprofv3 --kernel-trace --stats / --pmc passes of bench.py --net %s)" % net}
+stats = find("stats", "kernel_stats.csv")
 rows = list(csv.DictReader(open(stats)))
-with open(os.path.join(out, tag + "_kernel_stats.csv"), "w", newline="") as f:
+with open(os.path.join(out, name + "_kernel_stats.csv"), "w", newline="") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader()
     for r in rows[:25]:
         w.writerow(r)
+
+
+def agg(path, counter):
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in d.items()}
+
+
 pmc = {}
-if len(sys.argv) >= 5:
-    def agg(path, counter):
-        d = collections.defaultdict(list)
-        for r in csv.DictReader(open(path)):
-            if r["Counter_Name"] == counter:
-                d[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-        return {k: sum(v) / len(v) for k, v in d.items()}
-    fe, wr = agg(sys.argv[3], "FETCH_SIZE"), agg(sys.argv[4], "WRITE_SIZE")
+fetch, write = find("fetch", "counter_collection.csv"), find("write", "counter_collection.csv")
+if fetch and write:
+    fe, wr = agg(fetch, "FETCH_SIZE"), agg(write, "WRITE_SIZE")
     for k in fe:
         if "k_" in k[:12]:
             pmc[k] = {"FETCH_SIZE_KB_avg": fe[k], "WRITE_SIZE_KB_avg": wr.get(k),
                       "hbm_bytes_per_launch": (2.0 * fe[k] + (wr.get(k) or 0.0)) * 1024.0,
                       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); "
                               "WRITE_SIZE uncalibrated; Infinity-Cache hits are counted"}
-    json.dump(pmc, open(os.path.join(out, tag + "_pmc.json"), "w"), indent=1)
+    json.dump(dict(pmc, _meta=meta), open(os.path.join(out, name + "_pmc.json"), "w"), indent=1)
 sq = collections.defaultdict(dict)
-for path in sys.argv[5:]:
+for sub in ("sq1", "sq2"):
+    path = find(sub, "counter_collection.csv")
+    if not path:
+        continue
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(path)):
         if "k_" in r["Kernel_Name"][:12]:
@@ -46,9 +77,13 @@ for path in sys.argv[5:]:
         for c, x in v.items():
             sq[k][c] = sum(x) / len(x)
 if sq:
-    json.dump(sq, open(os.path.join(out, tag + "_sq.json"), "w"), indent=1)
-with open(os.path.join(out, tag + "_summary.md"), "w") as f:
-    f.write("# %s -- rocprofv3 --kernel-trace --stats\n\n" % tag)
+    json.dump(dict(sq, _meta=meta), open(os.path.join(out, name + "_sq.json"), "w"), indent=1)
+for b in ("benchline.json", "benchline_driver_args.json"):
+    if os.path.exists(os.path.join(src, b)) and os.path.getsize(os.path.join(src, b)) > 0:
+        shutil.copy(os.path.join(src, b), os.path.join(out, name + "_" + b))
+with open(os.path.join(out, name + "_summary.md"), "w") as f:
+    f.write("# %s -- rocprofv3 --kernel-trace --stats -- python bench.py --net %s --no-cpu-baseline --epoch-graphs 0\n\n" % (name, net))
+    f.write("kernel sources hash `%s`\n\n" % meta["source_hash"])
     f.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
     for r in rows[:16]:
         f.write("| `%s` | %s | %.2f | %.2f | %.2f | %s |\n" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3,
@@ -77,4 +112,4 @@ with open(os.path.join(out, tag + "_summary.md"), "w") as f:
                 100.0 * v.get("SQ_ACTIVE_INST_ANY", 0.0) / wc,
                 100.0 * v.get("SQ_LDS_BANK_CONFLICT", 0.0) / (v.get("SQ_LDS_IDX_ACTIVE") or 1.0),
                 v.get("SQ_INSTS_VALU", 0.0), v.get("SQ_INSTS_LDS", 0.0), v.get("SQ_INSTS_SALU", 0.0)))
-print("wrote profiles/%s_*" % tag)
+print("wrote profiles/%s_*" % name)
