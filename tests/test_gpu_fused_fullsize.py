@@ -114,10 +114,9 @@ def test_fused_step_syn64_gradients_match_oracle_elementwise(net_name, pipelined
           (net_name, pipelined, stats["elements"], stats["arbiter"]))
     if pipelined:
         # ... and the topology the same launch built for the NEXT step is the one a plain build gives
+        from topo_check import check_against_oracle
         assert nxt.status()[0] == 0
-        assert torch.equal(nxt.ws_i32, topo.ws_i32)
-        if need_w:
-            assert torch.equal(nxt.ws_f32, topo.ws_f32)
+        check_against_oracle(nxt, batch_cpu, weights=need_w)
         loss2 = tr.compute_gradients(batch, topo=nxt)
         assert float(loss2) == float(loss)
 
