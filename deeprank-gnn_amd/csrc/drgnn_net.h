@@ -495,26 +495,37 @@ DEV void net_row_coefs(int n, const int* rp, const float* w, float* dv, float* s
     } while (0)
 #endif
 // LDU: row stride of u in floats (0: dense rows of HC = H or 2H)
-template <int KIND, int H, bool A16 = false, int LDU = 0, class IdxT = int>
-DEV void net_aggregate(int n, const int* rp, const IdxT* col, const float* w, const float* dv,
-                       const float* sc, const float* u, const float* bias, float* z) {
+// COEF: the per-row coefficients (net_row_coefs: dv = 1/deg, sc = mean edge weight | 1) are formed HERE from the row's
+// own entry list (same summation order) and filed in dv / sc for the backward pass by the lane that owns the row's
+// first channel group -- no coefficient phase, no barrier of its own (fused step kernel)
+template <int KIND, int H, bool A16 = false, int LDU = 0, class IdxT = int, bool COEF = false>
+DEV void net_aggregate(int n, const int* rp, const IdxT* col, const float* w, float* dv,
+                       float* sc, const float* u, const float* bias, float* z) {
     constexpr int HC = LDU ? LDU : ((KIND == DRGNN_GINET) ? H : 2 * H);
     constexpr int G = H / 4;
     FOR_TID(item, n * G) {
         const int i = item / G, c = (item % G) * 4;
         const int lo = rp[i], hi = rp[i + 1];
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, asum = 0.f;
 #pragma unroll 4
         for (int k = lo; k < hi; ++k) {
             const float* uj = u + col[k] * HC + c;
             float cf = 1.0f, v0, v1, v2, v3;
-            if (KIND == DRGNN_SGAT) cf = w[k];
+            if (KIND == DRGNN_SGAT) { cf = w[k]; if (COEF) asum += cf; }
             NET_LD4(A16, uj, v0, v1, v2, v3);
             a0 = fmaf(cf, v0, a0); a1 = fmaf(cf, v1, a1);
             a2 = fmaf(cf, v2, a2); a3 = fmaf(cf, v3, a3);
         }
         if (KIND != DRGNN_GINET) {
-            const float d = dv[i], s = sc[i];
+            float d, s;
+            if (COEF) {
+                const int deg = hi - lo;
+                if (KIND == DRGNN_SGAT) { d = 1.0f / (float)(deg > 0 ? deg : 1); s = asum * d; }
+                else { d = deg > 0 ? 1.0f / (float)deg : 0.0f; s = 1.0f; }
+                if (c == 0) { dv[i] = d; sc[i] = s; }
+            } else {
+                d = dv[i]; s = sc[i];
+            }
             const float* us = u + i * HC + H + c;
             float s0, s1, s2, s3;
             NET_LD4(A16, us, s0, s1, s2, s3);

@@ -83,6 +83,7 @@ struct StepScratch {
     float* gp; float* misc;
     float* xr; float* hid; float* dhid;
     float* wb; float* hb1; float* hw2; float* hb2;
+    float* bsum;                 // [16 waves][32] wave partials of the bias-gradient column sums (sGAT / FoutNet)
     float* end;
 };
 
@@ -95,6 +96,7 @@ struct StepScratch {
     X(hid, H, 1)                                                                               \
     X(dhid, H, 1)                                                                              \
     X(hb1, H, 1)                                                                               \
+    X(bsum, DRGNN_NWAVES * DRGNN_H2, !gin)                                                     \
     X(wb, step_gp_words((int)H), 1)                                                            \
     X(w1t, DRGNN_H1 * xld, 1)                                                                  \
     X(ws1t, DRGNN_H1 * xld, !gin)                                                              \
@@ -160,7 +162,7 @@ constexpr bool step_streq(const char* a, const char* b) { return *a == *b && (*a
 constexpr bool step_cold_array(const char* n) {
     return step_streq(n, "ew0") || step_streq(n, "ts0") || step_streq(n, "ew1") || step_streq(n, "ts1") ||
            step_streq(n, "dv0") || step_streq(n, "sc0") || step_streq(n, "dv1") || step_streq(n, "sc1") ||
-           step_streq(n, "b1") || step_streq(n, "b2");
+           step_streq(n, "b1") || step_streq(n, "b2") || step_streq(n, "bsum");
 }
 DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int capC, int R, int H, int O) {
     const int hc1 = (kind == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
@@ -263,11 +265,19 @@ DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const floa
             C[i * ldc + j] = acc;
         }
 }
+// two products sharing the A operand in one pass: B holds [B0 | B1] side by side (16*NTH columns each), the results
+// go to C and C + chalf (sGAT / FoutNet: neighbour and self weight gradients)
+DEV void step_gemm_tn_pair(int MT, int NTH, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
+                           float* C, int chalf, int ldc, int Mrows) {
+    step_gemm_tn(MT, NTH, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
+    step_gemm_tn(MT, NTH, K, A, lda, B + 16 * NTH, ldb, KS, part, C + chalf, ldc, Mrows);
+}
 #else
 // MT/NT compile-time (0: run-time value in mt_rt / nt_rt), KS a power of two: no integer division left
-template <int MTC, int NTC>
+// NTH: column tiles per output block (NT = NTH: one block at C; NT = 2 * NTH: second block at C + chalf)
+template <int MTC, int NTC, int NTH = 0>
 DEV void step_gemm_tn_t(int mt_rt, int nt_rt, int K, const float* A, int lda, const float* B, int ldb, int KS,
-                        float* part, float* C, int ldc, int Mrows) {
+                        float* part, float* C, int ldc, int Mrows, int chalf = 0) {
     const int MT = MTC ? MTC : mt_rt, NT = NTC ? NTC : nt_rt;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
@@ -307,10 +317,19 @@ DEV void step_gemm_tn_t(int mt_rt, int nt_rt, int K, const float* A, int lda, co
             sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
         }
         const int row = ti * 16 + (l >> 4) * 4;
-        float* c = C + row * ldc + tj * 16 + (l & 15);
+        float* c = (NTH == 0) ? C + row * ldc + tj * 16 + (l & 15)
+                              : C + (tj / NTH) * chalf + row * ldc + (tj % NTH) * 16 + (l & 15);
 #pragma unroll
         for (int r = 0; r < 4; ++r) if (row + r < Mrows) c[r * ldc] = sum[r];
     }
+}
+DEV void step_gemm_tn_pair(int MT, int NTH, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
+                           float* C, int chalf, int ldc, int Mrows) {
+    KS = 1 << (31 - __builtin_clz((unsigned)(KS > 0 ? KS : 1)));       // round down to a power of two
+    if (NTH == 2 && MT == 1) step_gemm_tn_t<1, 4, 2>(1, 4, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, chalf);
+    else if (NTH == 1 && MT == 2) step_gemm_tn_t<2, 2, 1>(2, 2, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, chalf);
+    else if (NTH == 1) step_gemm_tn_t<0, 2, 1>(MT, 2, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, chalf);
+    else step_gemm_tn_t<0, 4, 2>(MT, 4, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, chalf);
 }
 DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
                       float* C, int ldc, int Mrows) {
@@ -385,6 +404,48 @@ DEV void step_gather_scatter(int n, const int* cp, const IdxT* ridx, const float
                 if (m >= 0) dz[m * DRGNN_H1 + c + q] = acc[q];
             }
         }
+    }
+#endif
+}
+
+// Bias gradient = column sums of dZ [n x H] (dense rows of H floats).  Two stages around a barrier the caller has
+// anyway: (1) every lane sums a float4 column group over the rows r = t / (H/4), + 1024/(H/4), .. and the lanes of a
+// wave that hold the same group are combined by lane exchanges -> one partial row per wave in `wpart` [16][H];
+// (2) after the barrier H lanes add the 16 wave rows in wave order.  Fixed order -> bit-reproducible.
+template <int H>
+DEV void step_colsum_partial(int n, const float* dz, float* wpart) {
+#ifdef DRGNN_EMU
+    for (int c = 0; c < H; ++c) {
+        float acc = 0.0f;
+        for (int r = 0; r < n; ++r) acc += dz[r * H + c];
+        wpart[c] = acc;
+    }
+#else
+    constexpr int G = H / 4;                      // lanes per row
+    const int t = threadIdx.x, cg = t % G, r0 = t / G;
+    drgnn_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < n; r += DRGNN_NTHREADS / G) {
+        const drgnn_f4 v = *(const drgnn_f4*)(dz + r * H + 4 * cg);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+    }
+#pragma unroll
+    for (int m = G; m < 64; m <<= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], m, 64);
+    }
+    if ((t & 63) < G) *(drgnn_f4*)(wpart + (t >> 6) * H + 4 * cg) = acc;
+#endif
+}
+template <int H>
+DEV void step_colsum_finish(const float* wpart, float* out) {
+#ifdef DRGNN_EMU
+    for (int c = 0; c < H; ++c) out[c] = wpart[c];
+#else
+    if ((int)threadIdx.x < H) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < DRGNN_NWAVES; ++w) acc += wpart[w * H + threadIdx.x];
+        out[threadIdx.x] = acc;
     }
 #endif
 }
@@ -799,6 +860,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     constexpr int U2LD = HC2 + 4, W2NLD = DRGNN_H2 + 4;
     constexpr bool GIN = (KIND == DRGNN_GINET);
     constexpr bool NARROW = (KIND == DRGNN_SGAT);
+    constexpr bool LATE3 = !GIN;                      // backward-only index arrays staged by a third, later burst
     typedef typename StepIdx<NARROW>::type EIdx;      // element type of the edge-indexed LDS arrays
     constexpr int Z2LD = GIN ? DRGNN_H2 + 4 : DRGNN_H2;      // GINet: Z2 rows feed a dense product (128-bit rows)
     StepScratch s = step_carve(scratch, KIND, (XF != 0) ? XF : F, capN, capE, capC, R, (XF != 0) ? WREF : H, O);
@@ -947,19 +1009,17 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             bufburst_load(bhb1, hf.b1, H);
             bufburst_load(bhw2, hf.w2, O * H);
             bufburst_load(bhb2, hf.b2, O);
-            bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
-            bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
-            bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
-            bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            if (!LATE3) {
+                bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+                bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+                bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+                bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            }
             if (KIND != DRGNN_GINET) {
                 burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
                 bufburst_load(bb2, c2.bias, DRGNN_H2);
             }
-            if (KIND == DRGNN_SGAT) {
-                bufburst_load(bew1, tv.w1 + d.e0, d.E1);
-                bufburst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
-                bufburst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
-            }
+            if (KIND == DRGNN_SGAT) bufburst_load(bew1, tv.w1 + d.e0, d.E1);
         }
         PH(1) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t, XLD, s.u1, HC1, dummy);
         if (KIND != DRGNN_GINET) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.ws1t, XLD, s.u1 + DRGNN_H1, HC1, dummy);
@@ -979,11 +1039,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         }
         BARRIER();
         EXIT_AFTER(2);
-        if (KIND != DRGNN_GINET) {
-            net_row_coefs<KIND>(d.N, s.rp0, s.ew0, s.dv0, s.sc0);
-            BARRIER();
-        }
-        PH(2) net_aggregate<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, (const EIdx*)s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
+        // (the per-row coefficients of sGAT / FoutNet are formed inside the aggregation from the row's own entries)
+        PH(2) net_aggregate<KIND, DRGNN_H1, true, 0, EIdx, true>(d.N, s.rp0, (const EIdx*)s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
         if (burst) {      // the second burst has landed by now: file it in LDS
             burst_store_wt(bw2, s.w2t, STEP_XPLD);
             burst_store_w(bw2, s.w2n, W2NLD);
@@ -991,22 +1048,32 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
             bufburst_store(bmp1, s.mp1, dummy); bufburst_store(bmem1, s.mem1, dummy);
             step_wblock_store(wreg, hf, br, s.wb);
             bufburst_store(bhb1, s.hb1, dummy); bufburst_store(bhw2, s.hw2, dummy); bufburst_store(bhb2, s.hb2, dummy);
-            bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
-            bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
+            if (!LATE3) {
+                bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
+                bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
+            }
             if (KIND != DRGNN_GINET) {
                 burst_store_wt(bs2, s.ws2t, STEP_XPLD);
                 burst_store_w(bs2, s.ws2n, W2NLD);
                 bufburst_store(bb2, s.b2, dummy);
             }
-            if (KIND == DRGNN_SGAT) {
-                bufburst_store(bew1, s.ew1, dummy);
-                step_store_idx<NARROW>(bts0, s.ts0, dummy); step_store_idx<NARROW>(bts1, s.ts1, dummy);
-            }
+            if (KIND == DRGNN_SGAT) bufburst_store(bew1, s.ew1, dummy);
         }
         BARRIER();
         EXIT_AFTER(3);
+        if (burst && LATE3) {
+            // third burst: the arrays only the BACKWARD pass reads (CSC of both levels, sGAT's transposed slot maps).
+            // Requested here, filed two phases later: their registers are not alive during the crowded second burst
+            bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
+            bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
+            bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
+            bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            if (KIND == DRGNN_SGAT) {
+                bufburst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
+                bufburst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+            }
+        }
         PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
-        if (KIND != DRGNN_GINET) net_row_coefs<KIND>(d.C, s.rp1, s.ew1, s.dv1, s.sc1);
         BARRIER();
         EXIT_AFTER(4);
         if (GIN) {      // S = A XP (16-wide gather), kept in the u2 area with rows of STEP_XPLD floats
@@ -1025,7 +1092,12 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         if (GIN) {      // Z2 = relu(S W2)
             PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H1, s.u2, STEP_XPLD, s.w2t, STEP_XPLD, s.z2, Z2LD, dummy);
         } else {
-            PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD, EIdx>(d.C, s.rp1, (const EIdx*)s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+            PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD, EIdx, true>(d.C, s.rp1, (const EIdx*)s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+        }
+        if (burst && LATE3) {
+            bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
+            bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
+            if (KIND == DRGNN_SGAT) { step_store_idx<NARROW>(bts0, s.ts0, dummy); step_store_idx<NARROW>(bts1, s.ts1, dummy); }
         }
         BARRIER();
         EXIT_AFTER(6);
@@ -1084,21 +1156,16 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         EXIT_AFTER(14);
     } else {
     PH(11) net_aggregate_bwd<KIND, DRGNN_H2, true, U2LD, EIdx>(d.C, s.rp1, s.cp1, (const EIdx*)s.rx1, (const EIdx*)s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
-    {
-        FOR_TID(c, DRGNN_H2) {
-            float acc = 0.0f;
-            for (int r = 0; r < d.C; ++r) acc += s.z2[r * DRGNN_H2 + c];
-            p_b2[c] = acc;
-        }
-    }
+    step_colsum_partial<DRGNN_H2>(d.C, s.z2, s.bsum);     // db2, stage 1
     BARRIER();
     EXIT_AFTER(12);
+    step_colsum_finish<DRGNN_H2>(s.bsum, p_b2);
     // dXP = dU2n W2n^T + dU2s W2s^T;  dW2 = XP^T dU2 (K = pooled nodes, split over the waves)
     PH(13) step_gemm_nn(d.C, 1, DRGNN_H2, s.u2, U2LD, s.w2n, W2NLD, s.dxp, DRGNN_H1, dummy);
     step_gemm_nn(d.C, 1, DRGNN_H2, s.u2 + DRGNN_H2, U2LD, s.ws2n, W2NLD, s.p2, DRGNN_H1, dummy);
-    PH(12) step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2, U2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
-    BARRIER();
-    step_gemm_tn(1, 2, d.C, s.xp, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, KS2, s.gp, p_w2s, DRGNN_H2, DRGNN_H1);
+    // both weight gradients of the layer in one pass (4 column tiles: [dU2n | dU2s])
+    PH(12) step_gemm_tn_pair(1, 2, d.C, s.xp, STEP_XPLD, s.u2, U2LD, imin(DRGNN_NWAVES / 4, gp_units / 4), s.gp, p_w2n,
+                             DRGNN_H1 * DRGNN_H2, DRGNN_H2, DRGNN_H1);
     BARRIER();
     EXIT_AFTER(13);
     PH(14) FOR_TID(item, d.C * DRGNN_H1) {
@@ -1110,21 +1177,22 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
     EXIT_AFTER(14);
     }
     PH(15) net_aggregate_bwd<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, s.cp0, (const EIdx*)s.rx0, (const EIdx*)s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
-    if (KIND != DRGNN_GINET) {
-        FOR_TID(c, DRGNN_H1) {
-            float acc = 0.0f;
-            for (int i = 0; i < d.N; ++i) acc += s.z1[i * DRGNN_H1 + c];
-            p_b1[c] = acc;
-        }
-    }
+    if (KIND != DRGNN_GINET) step_colsum_partial<DRGNN_H1>(d.N, s.z1, s.bsum);     // db1, stage 1
     BARRIER();
     EXIT_AFTER(15);
+    if (KIND != DRGNN_GINET) step_colsum_finish<DRGNN_H1>(s.bsum, p_b1);
     {   // dW1 = X^T dU1: K = nodes of the graph, split in slices over the waves
         const int mtiles = F16 >> 4;
         int KS = imin(DRGNN_NWAVES / mtiles, gp_units / mtiles);
         if (KS < 1) KS = 1;
-        PH(16) step_gemm_tn(mtiles, 1, d.N, s.xs, XLD, s.u1, HC1, KS, s.gp, p_w1n, DRGNN_H1, F);
-        if (KIND != DRGNN_GINET) {
+        if (KIND == DRGNN_GINET) {
+            PH(16) step_gemm_tn(mtiles, 1, d.N, s.xs, XLD, s.u1, HC1, KS, s.gp, p_w1n, DRGNN_H1, F);
+        } else if (2 * mtiles <= gp_units) {      // [dU1n | dU1s] in one pass
+            int KSP = imin(DRGNN_NWAVES / (2 * mtiles), gp_units / (2 * mtiles));
+            if (KSP < 1) KSP = 1;
+            PH(16) step_gemm_tn_pair(mtiles, 1, d.N, s.xs, XLD, s.u1, HC1, KSP, s.gp, p_w1n, F * DRGNN_H1, DRGNN_H1, F);
+        } else {                                   // very wide inputs: the partial-tile area holds one product at a time
+            step_gemm_tn(mtiles, 1, d.N, s.xs, XLD, s.u1, HC1, KS, s.gp, p_w1n, DRGNN_H1, F);
             BARRIER();
             step_gemm_tn(mtiles, 1, d.N, s.xs, XLD, s.u1 + DRGNN_H1, HC1, KS, s.gp, p_w1s, DRGNN_H1, F);
         }
