@@ -93,6 +93,11 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true",
                     help="native mode: build each step's topology with its own launch at the start of the step "
                          "instead of inside the previous step's backward launch (double-buffered workspaces)")
+    ap.add_argument("--topology", choices=["rebuilt", "cached"], default="rebuilt",
+                    help="rebuilt (default, the headline): every step builds the topology of a mini-batch from its int64 "
+                         "edge_index / cluster tensors, like the reference redoes its index work in every forward pass; "
+                         "cached (declared second mode): per-graph topology built once at upload of the resident graph "
+                         "set, a mini-batch is a list of graph numbers, no builder workgroups in the step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for "
                     "exercising the multi-process path on a single GPU)")
     ap.add_argument("--force-dp-path", action="store_true",
@@ -174,7 +179,8 @@ def main():
     native = args.mode.startswith("native")
     capture = args.mode in ("native", "graph")
     need_w = args.net == "sGAT"
-    pipeline = native and not args.no_pipeline
+    cached = native and args.topology == "cached"
+    pipeline = native and not args.no_pipeline and not cached
     dp_path = world > 1 or args.force_dp_path
     state = {"k": 0}       # which of the two topology workspaces the next step trains from
     if native:
@@ -184,12 +190,23 @@ def main():
         # Two persistent topology workspaces.  Pipelined: while step t trains out of one, the
         # topology of step t+1 is built into the other INSIDE step t's backward launch (the builder
         # only depends on index tensors).  Every step still builds one topology and consumes one.
-        topos = [Topology.from_batch(batch, need_weights=need_w),
-                 Topology.from_batch(batch, need_weights=need_w)]
+        cache = None
+        if cached:
+            from deeprank_gnn_amd.resident import ResidentGraphSet
+            rs = ResidentGraphSet([synth.make_graph(rank * GRAPHS_PER_GPU + i) for i in range(GRAPHS_PER_GPU)], dev)
+            cache = rs.topology_cache(need_weights=need_w)
+            ids_host = list(range(GRAPHS_PER_GPU))
+            ids_dev = rs.upload_ids(ids_host)
+            topos = []
+        else:
+            topos = [Topology.from_batch(batch, need_weights=need_w),
+                     Topology.from_batch(batch, need_weights=need_w)]
 
         def one_step(fn):
             k = state["k"]
-            if pipeline:
+            if cached:
+                trainer.train_step_cached(cache, ids_host, ids_dev, apply_adam=(fn == trainer.train_step))
+            elif pipeline:
                 fn(batch, topo=topos[k], next_topo=topos[1 - k])
                 state["k"] = 1 - k
             else:
@@ -467,7 +484,9 @@ def main():
                                    "(BASELINE.json configs[1])" % args.net,
                        "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,
                        "parallelism": "dp%d" % world, "mode": args.mode,
-                       "topology": ("rebuilt every step; the build of step t+1 shares step t's backward launch "
+                       "topology": ("cached per graph (declared): built once at upload of the resident set, the step "
+                                    "reads it in place, no builder workgroups" if cached else
+                                    "rebuilt every step; the build of step t+1 shares step t's backward launch "
                                     "(double-buffered)" if pipeline else "rebuilt every step, own launch"),
                        "final_loss": final_loss},
         }
@@ -475,7 +494,8 @@ def main():
             result["config"]["dp_exchange"] = dp_mode
             result["config"]["params_in_sync"] = in_sync
         if native:
-            result["roofline"] = measure_roofline(net, args.net, batch, dev, value / world)
+            result["roofline"] = measure_roofline(net, args.net, batch, dev, value / world,
+                                                  cache=(cache, ids_host, ids_dev) if cached else None)
         if world == 1 and native and args.epoch_graphs > 0:
             try:
                 result["epoch_loop"] = measure_epoch_loop(Net, args.net, args.epoch_graphs, dev)
@@ -501,7 +521,7 @@ def two_flavours_parity(state):
     return state["k"] == 1
 
 
-def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400):
+def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=None):
     """Average duration of each launch of the native step, measured LIVE with HIP events around `iters`
     back-to-back launches (20 per hipGraph replay, on torch's current stream = the stream the kernels are launched
     on), and the dominant one against the HBM roofline.
@@ -533,6 +553,12 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400):
     def k_step():
         tr._fused_launch_step(c, None)
 
+    cc = tr._cached_prepare(cache[0], cache[1], cache[2]) if cache else None
+
+    def k_step_cached():
+        cc["stream"] = _lib.current_stream(c["x"])
+        tr._cached_launch_step(cc, True)
+
     def k_update():
         tr._fused_launch_update(c, True, lr=0.0)
 
@@ -545,8 +571,10 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400):
     upd_bytes = (c["partials"].numel() + c["hp"].numel() + c["readout"].numel() + 7 * tr.flat_p.numel()) * 4 / B
     kname = "k_step_co_topo<%s,%d>" % (net_name, variant)
     out = {}
+    first = ((kname + " (fwd + head/loss + bwd, topology read from the per-graph cache)", k_step_cached, alg) if cache else
+             (kname + " (fwd + head/loss + bwd, + topology of the next batch)", k_step_co, alg))
     for name, fn, nbytes in (
-            (kname + " (fwd + head/loss + bwd, + topology of the next batch)", k_step_co, alg),
+            first,
             ("k_update (partials reduction + Adam)", k_update, upd_bytes),
             ("k_topo (own launch; not on the pipelined path)", k_topo, BYTES_TOPO[net_name]),
             (kname + " without the co-launched topology (not on the pipelined path)", k_step, alg)):
@@ -577,7 +605,8 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400):
     dom = max(on_path, key=lambda k: out[k]["avg_us"])
     ach = out[dom]["achieved_GBs"]
     step_us = out[on_path[0]]["avg_us"]
-    with_builder = (alg + BYTES_TOPO[net_name]) * B / (step_us * 1e-6) / 1e9
+    extra = 0 if cache else BYTES_TOPO[net_name]
+    with_builder = (alg + extra) * B / (step_us * 1e-6) / 1e9
     # HBM traffic and MFMA busy cycles come from rocprofv3 --pmc passes, which cannot run inside this process: they
     # are read from the summary under profiles/ that was collected from THIS build (matched by source hash and net),
     # and reported as null otherwise
@@ -627,24 +656,35 @@ def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=3):
     rs = ResidentGraphSet(graphs, dev)
     gen = torch.Generator().manual_seed(0)
 
-    def epoch():
-        order = torch.randperm(n_graphs, generator=gen).tolist()
-        done = tr.train_epoch(rs, order, GRAPHS_PER_GPU)
-        if done is None:
-            raise RuntimeError("the native epoch loop refused this configuration")
-        losses, pred = done
-        pred.cpu()
-        return float(losses.sum())
-    epoch()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    sums = [epoch() for _ in range(epochs)]
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    def run(cached):
+        def epoch():
+            order = torch.randperm(n_graphs, generator=gen).tolist()
+            done = tr.train_epoch(rs, order, GRAPHS_PER_GPU, cached=cached)
+            if done is None:
+                raise RuntimeError("the native epoch loop refused this configuration")
+            losses, pred = done
+            pred.cpu()
+            return float(losses.sum())
+        epoch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sums = [epoch() for _ in range(epochs)]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"graphs_per_s": n_graphs * epochs / dt, "us_per_batch": dt / (epochs * nb) * 1e6,
+                "last_epoch_loss_sum": sums[-1]}
     nb = (n_graphs + GRAPHS_PER_GPU - 1) // GRAPHS_PER_GPU
-    return {"graphs_per_s": n_graphs * epochs / dt, "us_per_batch": dt / (epochs * nb) * 1e6, "epochs": epochs,
-            "resident_graphs": n_graphs, "batch": GRAPHS_PER_GPU, "net": net_name, "last_epoch_loss_sum": sums[-1],
-            "what": "shuffled epochs via drgnn_train_epoch (native loop, mini-batches read in place from the resident set)"}
+    out = run(False)
+    out.update({"epochs": epochs, "resident_graphs": n_graphs, "batch": GRAPHS_PER_GPU, "net": net_name,
+                "what": "shuffled epochs via drgnn_train_epoch (native loop, mini-batches read in place from the resident "
+                        "set, topology rebuilt for every mini-batch)"})
+    try:
+        c = run(True)
+        c["what"] = "same loop, declared cached-topology mode (per-graph topology built once at upload)"
+        out["cached_topology"] = c
+    except Exception as exc:
+        out["cached_topology"] = {"error": repr(exc)[:200]}
+    return out
 
 
 def cpu_baseline(net_name, batch_cpu, seconds):

@@ -79,7 +79,14 @@ class EpochPlan(ctypes.Structure):
                 ("head_offset", _c_i64),
                 ("flat_param", _vp), ("flat_grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("n_param", _c_i64),
                 ("step2", _vp),
-                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                ("cache", _vp)]
+
+
+class TopologyCacheDesc(ctypes.Structure):
+    """drgnn_topology_cache: one topology workspace over a whole resident set + its node features / targets."""
+    _fields_ = [("n_graphs", _c_i64), ("n_nodes", _c_i64), ("n_edges", _c_i64),
+                ("ws_i32", _vp), ("ws_f32", _vp), ("x", _vp), ("y", _vp), ("y_bytes", _c_i32), ("reserved", _c_i32)]
 
 
 class HeadDesc(ctypes.Structure):
@@ -149,6 +156,9 @@ class Api(object):
         lib.drgnn_net_train_step.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc)] + [_vp] * 5 +
                                              [_c_i64] * 3 + [_c_i32] * 3 + [_vp] * 5 +
                                              [ctypes.POINTER(TopologyRequest), _vp])
+        lib.drgnn_net_train_step_cached.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc),
+                                                     ctypes.POINTER(TopologyCacheDesc), _vp, _c_i64] + [_c_i32] * 3 +
+                                                    [_vp] * 7)
         lib.drgnn_step_update.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] +
                                           [ctypes.POINTER(ConvGrads)] * 2 + [_vp, _vp] + [_c_i32] * 3 +
                                           [_c_i64] + [_vp] * 4 + [_c_i64] + [_vp] * 2 +
@@ -282,6 +292,13 @@ class Api(object):
             _ptr(ws_f32), n_nodes, n_edges, n_graphs, max_nodes, max_edges, max_c0, _ptr(pred), _ptr(readout),
             _ptr(head_partials), _ptr(partials), _ptr(xchg),
             None if next_topology is None else ctypes.byref(next_topology), stream), "drgnn_net_train_step")
+
+    def net_train_step_cached(self, desc, head, cache, ids, n_graphs, max_nodes, max_edges, max_c0, step2, pred,
+                              readout, head_partials, partials, xchg, stream):
+        _check(self.lib.drgnn_net_train_step_cached(
+            ctypes.byref(desc), ctypes.byref(head), ctypes.byref(cache), _ptr(ids), n_graphs, max_nodes, max_edges,
+            max_c0, _ptr(step2), _ptr(pred), _ptr(readout), _ptr(head_partials), _ptr(partials), _ptr(xchg), stream),
+            "drgnn_net_train_step_cached")
 
     def step_update(self, desc, conv_partials, n_graphs, g1, g2, head_partials, readout, R, H, O, head_offset,
                     flat_p, flat_g, exp_avg, exp_avg_sq, step2, loss, lr, beta1, beta2, eps, stream,

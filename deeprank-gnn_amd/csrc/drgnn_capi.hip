@@ -302,7 +302,8 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
     if (nb == 2) { g = ((blk >> 4) << 3) + (blk & 7); br = (blk >> 3) & 1; }
     else { g = blk; br = 0; }
     if (g >= L.a.n_graphs) return;                // padding of the last group of 8 graphs
-    const GraphDims d = net_dims(L.a.tv, g);      // ONE round trip for all per-graph sizes
+    const int gi = L.a.gather_ids ? WG_UNIFORM(L.a.gather_ids[g]) : g;      // cached mode: graph number in the set
+    const GraphDims d = net_dims(L.a.tv, gi);     // ONE round trip for all per-graph sizes
     if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
         // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
         if (part != 2) {
@@ -321,7 +322,7 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
         }
         return;
     }
-    net_step_graph<KIND, XF>(L.a, d, g, br, lds, L.capN, L.capE, L.capC, part);
+    net_step_graph<KIND, XF>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, part);
 }
 
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
@@ -1067,12 +1068,15 @@ int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int
     return step_variant(kind, x, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, H, O);
 }
 
-int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, const float* x,
-                         const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
-                         int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
-                         int32_t max_edges, int32_t max_c0, float* pred, float* readout,
-                         float* head_partials, float* partials, uint64_t* xchg,
-                         const drgnn_topology_request* next, void* stream_) {
+// n_graphs graphs of the launch; (n_nodes, n_edges, ws_graphs): the shape the workspace was laid out for (the
+// mini-batch itself, or a whole cached set whose graphs gather_ids[0..n_graphs) are stepped)
+static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd, const float* x,
+                           const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
+                           int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int64_t ws_graphs,
+                           const int32_t* gather_ids, int32_t max_nodes,
+                           int32_t max_edges, int32_t max_c0, float* pred, float* readout,
+                           float* head_partials, float* partials, uint64_t* xchg,
+                           const drgnn_topology_request* next, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
     if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2 || !x || !step2 || !ws_i32 || !pred || !readout)
@@ -1092,8 +1096,9 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
     if (lds > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
     L.words = lds / 4;
     TopoLayout lay;
-    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    topo_layout(n_nodes, n_edges, ws_graphs, &lay);
     StepArgs& a = L.a;
+    a.gather_ids = gather_ids; a.ws_graphs = (int)ws_graphs;
     a.net = *net; a.x = x;
     a.tv = topo_view(const_cast<int32_t*>(ws_i32), const_cast<float*>(ws_f32), lay);
     a.n_nodes = n_nodes; a.n_graphs = (int)n_graphs;
@@ -1173,6 +1178,29 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
     if (next && (!co_ok || blocks == 0))
         return drgnn_topology_build_request(next, stream_);
     return 0;
+}
+
+int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, const float* x,
+                         const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
+                         int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
+                         int32_t max_edges, int32_t max_c0, float* pred, float* readout,
+                         float* head_partials, float* partials, uint64_t* xchg,
+                         const drgnn_topology_request* next, void* stream_) {
+    return train_step_impl(net, hd, x, target, step2, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, n_graphs, nullptr,
+                           max_nodes, max_edges, max_c0, pred, readout, head_partials, partials, xchg, next, stream_);
+}
+
+int drgnn_net_train_step_cached(const drgnn_net_desc* net, const drgnn_head_desc* hd,
+                                const drgnn_topology_cache* cache, const int32_t* ids, int64_t n_graphs,
+                                int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t* step2, float* pred,
+                                float* readout, float* head_partials, float* partials, uint64_t* xchg, void* stream_) {
+    if (!cache || !ids || !cache->ws_i32 || !cache->x || n_graphs < 0 || n_graphs > cache->n_graphs) return DRGNN_E_ARG;
+    if (hd && hd->train) {
+        if (!cache->y || cache->y_bytes != (hd->task == DRGNN_TASK_REG ? 4 : 8)) return DRGNN_E_ARG;
+    }
+    return train_step_impl(net, hd, cache->x, cache->y, step2, cache->ws_i32, cache->ws_f32, cache->n_nodes,
+                           cache->n_edges, n_graphs, cache->n_graphs, ids, max_nodes, max_edges, max_c0, pred, readout,
+                           head_partials, partials, xchg, nullptr, stream_);
 }
 
 int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,
@@ -1641,6 +1669,15 @@ int epoch_check(const drgnn_epoch_plan* p) {
     if (!p->inference && (!p->g_conv1 || !p->g_conv2 || !p->flat_param || !p->flat_grad || !p->exp_avg || !p->exp_avg_sq))
         return DRGNN_E_ARG;
     const drgnn_graph_set* gs = p->set;
+    if (p->cache) {      // cached topology: the set is only consulted for sizes (host tables)
+        const drgnn_topology_cache* tc = p->cache;
+        if (!tc->ws_i32 || !tc->x || tc->n_graphs != gs->n_graphs || !p->host_c1_ptr) return DRGNN_E_ARG;
+        if (p->need_weights && !tc->ws_f32) return DRGNN_E_ARG;
+        if (!p->inference && (!tc->y || tc->y_bytes != (p->head->task == DRGNN_TASK_REG ? 4 : 8))) return DRGNN_E_ARG;
+        if (gs->n_feat != p->net->n_feat) return DRGNN_E_WIDTH;
+        if (p->batch_size > 4096) return DRGNN_E_CAPACITY;
+        return 0;
+    }
     if (!gs->node_ptr || !gs->edge_ptr || !gs->x || !gs->cluster0 || !gs->cluster1 || !gs->c1_ptr || !p->host_c1_ptr)
         return DRGNN_E_ARG;
     if (!p->inference && !gs->y) return DRGNN_E_ARG;
@@ -1663,7 +1700,8 @@ int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
         if ((rc = epoch_batch(p, k, &b))) return rc;
         if (b.maxN <= 0) return DRGNN_E_CAPACITY;
         if (drgnn_net_step_lds_bytes(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O) > DRGNN_LDS_LIMIT ||
-            b.maxN > 32767 || b.maxE > 65535 || drgnn_topology_lds_bytes(b.maxN, b.maxE > 0 ? b.maxE : 1) > DRGNN_LDS_LIMIT)
+            b.maxN > 32767 || b.maxE > 65535 ||
+            (!p->cache && drgnn_topology_lds_bytes(b.maxN, b.maxE > 0 ? b.maxE : 1) > DRGNN_LDS_LIMIT))
             return DRGNN_E_CAPACITY;
         TopoLayout lay;
         topo_layout(b.N, b.E, b.B, &lay);
@@ -1677,12 +1715,13 @@ int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
     const int F = p->net->n_feat, nbr = p->net->n_branch;
     for (int s = 0; s < 2; ++s) {
         EpochSlot& t = c->slot[s];
+        if (p->cache) { t.x = nullptr; t.y = nullptr; t.ws_i32 = nullptr; t.ws_f32 = nullptr; continue; }   // nothing to build
         t.x = (float*)take(capN * F * 4);
         t.y = take(capB * 8);
         t.ws_i32 = (int32_t*)take(ws_i * 4);
         t.ws_f32 = p->need_weights ? (float*)take(ws_f * 4) : nullptr;
     }
-    c->ptrs = (int32_t*)take((nb > 0 ? nb : 1) * 3 * ((int64_t)p->batch_size + 1) * 4);
+    c->ptrs = p->cache ? nullptr : (int32_t*)take((nb > 0 ? nb : 1) * 3 * ((int64_t)p->batch_size + 1) * 4);
     c->readout = (float*)take(capB * hd->R * 4);
     c->partials = (float*)take(capB * nbr * drgnn_net_partial_elems(p->net->kind, F) * 4);
     c->head_partials = (float*)take(capB * drgnn_head_compact_elems(hd->R, hd->H, hd->O) * 4);
@@ -1718,6 +1757,25 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
 #else
     HIP_TRY(hipMemsetAsync(c.xchg, 0, (size_t)c.xchg_bytes, (hipStream_t)stream));
 #endif
+    if (p->cache) {
+        // cached topology: a mini-batch is its list of graph numbers -- step launch (+ update launch), nothing else
+        for (int64_t k = 0; k < nb; ++k) {
+            EpochBatch b;
+            if ((rc = epoch_batch(p, k, &b))) return rc;
+            drgnn_topology_cache tc = *p->cache;
+            if (!train) tc.y = nullptr;
+            rc = drgnn_net_train_step_cached(p->net, &head, &tc, p->ids + b.first, b.B, b.maxN, b.maxE, b.maxC, p->step2,
+                                             pred + b.first * hd->O, c.readout, train ? c.head_partials : nullptr,
+                                             train ? c.partials : nullptr, c.xchg, stream);
+            if (rc) return rc;
+            if (!train) continue;
+            rc = drgnn_step_update(p->net, c.partials, b.B, p->g_conv1, p->g_conv2, c.head_partials, c.readout, hd->R, hd->H,
+                                   hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
+                                   p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, 1, stream);
+            if (rc) return rc;
+        }
+        return 0;
+    }
     if ((rc = drgnn_batch_offsets(p->set, p->ids, p->n_ids, p->batch_size, c.ptrs, stream))) return rc;
     const int64_t W = (int64_t)p->batch_size + 1;
     // mini-batch k's topology + node features + targets, straight from the resident set into slot k & 1

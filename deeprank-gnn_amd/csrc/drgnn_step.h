@@ -54,6 +54,10 @@ struct StepArgs {
     HeadFused hf;                // hf.readout: [B][R] OUTPUT; hf.partials: [B][head_compact_floats]
     unsigned long long* xchg;    // [B][n_branch][H] tagged fc1 half-products (zero-initialised once by the owner)
     int32_t* step2;              // [0] steps completed so far (read)   [1] index of this step (written)
+    // cached-topology mode: slot g of the launch is graph gather_ids[g] of the workspace `tv` describes (a whole
+    // resident set, ws_graphs graphs); null: slot g = graph g of a per-mini-batch workspace
+    const int32_t* gather_ids;
+    int ws_graphs;
 };
 
 HD int64_t head_compact_floats(int R, int H, int O) { (void)R; return (int64_t)H + (int64_t)O * H + O + 2; }
@@ -844,7 +848,7 @@ static inline bool step_burst_guaranteed(int kind, const float* x, int F, int ca
 // The strides of the x tile and of conv1's weights and the K loop of conv1's products hang on it;
 // with it known the kernel is ~8% faster, so the common widths are instantiated.
 template <int KIND, int XF>
-DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, float* scratch, int capN,
+DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, int br, float* scratch, int capN,
                         int capE, int capC, int part) {
     constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
     constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
@@ -907,24 +911,25 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int br, fl
         int m_bad, m_y;
         float m_wy = 1.0f, m_denom = 1.0f;
         {
-            m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][g] | tv.p[DRGNN_TI_GSTAT][a.n_graphs + g];
+            // gi: this graph's number in the workspace (= g unless the launch gathers from a cached set)
+            m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][a.ws_graphs + gi];
             if (!hf.train) {
                 m_y = 0;
             } else if (hf.task == DRGNN_TASK_REG) {
-                const float y = hf.y_reg[g];
+                const float y = hf.y_reg[gi];
                 memcpy(&m_y, &y, 4);
             } else {
-                m_y = (int)hf.y_cls[g];
+                m_y = (int)hf.y_cls[gi];
                 m_wy = hf.class_w ? hf.class_w[m_y] : 1.0f;
                 // CrossEntropyLoss(weight): mean over the sum of the targets' weights
 #ifdef DRGNN_EMU
                 m_denom = 0.0f;
-                for (int q = 0; q < hf.B; ++q) m_denom += hf.class_w ? hf.class_w[hf.y_cls[q]] : 1.0f;
+                for (int q = 0; q < hf.B; ++q) m_denom += hf.class_w ? hf.class_w[hf.y_cls[a.gather_ids ? a.gather_ids[q] : q]] : 1.0f;
 #else
                 m_denom = (float)hf.B;
                 if (hf.class_w && threadIdx.x < 64) {
                     float part_sum = 0.0f;
-                    for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w[hf.y_cls[q]];
+                    for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w[hf.y_cls[a.gather_ids ? a.gather_ids[q] : q]];
                     m_denom = lanes64_sum(part_sum);
                 }
 #endif

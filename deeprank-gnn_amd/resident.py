@@ -130,6 +130,20 @@ class ResidentGraphSet(object):
                     edge_attr=opt("edge_attr"), cluster0=opt("cluster0"), cluster1=opt("cluster1"), y=opt("y"))
         return self
 
+    # -- cached topology (declared mode) ---------------------------------------------------------------------
+    def topology_cache(self, need_weights=False):
+        """The topology of EVERY graph of the set, built once (``TopologyCache``).  Per-graph topology is independent of
+        the mini-batch (ids inside a graph's segment are local), so the fused step can read graph ``ids[g]``'s segments in
+        place: no builder workgroups, no per-step index work (``FusedTrainer.train_step_cached`` / ``train_epoch(...,
+        cached=True)``).  Built by the same builder as a mini-batch's workspace (resident-set mode, ids = 0..G-1)."""
+        key = bool(need_weights and self.has_attr)
+        cache = getattr(self, "_topo_cache", {}).get(key)
+        if cache is None:
+            if not hasattr(self, "_topo_cache"):
+                self._topo_cache = {}
+            cache = self._topo_cache[key] = TopologyCache(self, key)
+        return cache
+
     def set_targets(self, y):
         """Replace the targets (e.g. class labels mapped to class indices); ``y``: [G] tensor."""
         y = y.reshape(-1)
@@ -139,6 +153,8 @@ class ResidentGraphSet(object):
         self.has_y = True
         self._desc.y = self.y.data_ptr()
         self._desc.y_bytes = self.y.element_size()
+        for cache in getattr(self, "_topo_cache", {}).values():
+            cache.refresh_targets()
 
     def upload_ids(self, ids):
         """Graph numbers of one or more mini-batches as a device int32 tensor (slice it per batch)."""
@@ -232,3 +248,60 @@ class ResidentGraphSet(object):
             d["_c1_ptr"] = ptrs[2]
             d["_max_c0"] = int(nc.max())
         return out
+
+
+class TopologyCache(object):
+    """One topology workspace over a whole ``ResidentGraphSet`` (drgnn_topology_cache, include/drgnn.h)."""
+
+    def __init__(self, gset, with_weights, topo=None):
+        from .topology import Topology
+        self.set = gset
+        api, dev = gset.api, gset.device
+        G = len(gset)
+        N, E = int(gset.node_ptr[-1]), int(gset.edge_ptr[-1])
+        if N + G >= 2 ** 31 - 1 or E >= 2 ** 31 - 1:
+            raise _lib.DrgnnError("the set is too large for one int32-indexed workspace: split it")
+        if not (gset.has_c0 and gset.has_c1):
+            raise ValueError("a topology cache needs cluster0 and cluster1 on every graph")
+        self.with_weights = bool(with_weights)
+        self.max_nodes, self.max_edges = int(gset.n_nodes.max()), int(gset.n_edges.max())
+        self.max_c0 = int(gset.n_c1.max())
+        if topo is None:
+            topo = Topology(api, N, E, G, dev, self.with_weights)
+            topo.max_nodes, topo.max_edges, topo.max_c0 = self.max_nodes, self.max_edges, self.max_c0
+            topo.has_level1 = True
+            self._ptrs32 = torch.from_numpy(np.stack([gset.node_ptr, gset.edge_ptr, gset.c1_ptr]).astype(np.int32)).to(dev)
+            ids = torch.arange(G, dtype=torch.int32, device=dev)
+            r = _lib.TopologyRequest()
+            p = _lib._ptr
+            r.node_ptr, r.edge_ptr, r.c1_ptr = p(self._ptrs32[0]), p(self._ptrs32[1]), p(self._ptrs32[2])
+            r.n_nodes, r.n_edges, r.len_cluster1, r.n_graphs = N, E, int(gset.c1_ptr[-1]), G
+            r.max_nodes, r.max_edges = self.max_nodes, self.max_edges
+            r.ws_i32, r.ws_f32 = p(topo.ws_i32), p(topo.ws_f32)
+            scratch = None
+            if api.topology_lds_bytes(self.max_nodes, max(self.max_edges, 1)) > 160 * 1024:
+                scratch = torch.empty(api.topology_scratch_elems(N, E, G), dtype=torch.int32, device=dev)
+            r.scratch_i32 = p(scratch)
+            import ctypes
+            r.set = ctypes.cast(ctypes.pointer(gset._desc), ctypes.c_void_p)
+            r.ids, r.x_out, r.y_out = p(ids), None, None
+            api.topology_build_request(r, _lib.current_stream(gset.x))
+            topo._inputs = None
+            self._keep = (ids, scratch)
+        self.topo = topo
+        d = _lib.TopologyCacheDesc()
+        d.n_graphs, d.n_nodes, d.n_edges = G, N, E
+        d.ws_i32, d.ws_f32, d.x = _lib._ptr(topo.ws_i32), _lib._ptr(topo.ws_f32), _lib._ptr(gset.x)
+        self._desc = d
+        self.refresh_targets()
+
+    def refresh_targets(self):
+        y = self.set.y
+        self._desc.y = None if y is None else y.data_ptr()
+        self._desc.y_bytes = 0 if y is None else y.element_size()
+
+    def bounds(self, ids):
+        """(max_nodes, max_edges, max_c0) over the graphs ``ids`` (host numbers)."""
+        ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+        s = self.set
+        return int(s.n_nodes[ids].max()), int(s.n_edges[ids].max()), int(s.n_c1[ids].max())

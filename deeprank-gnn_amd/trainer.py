@@ -192,6 +192,74 @@ class FusedTrainer(object):
         self.last_batch_size = c["B"]
         return self.loss
 
+    # -- cached topology (declared mode): a mini-batch is a list of graph numbers of a resident set ---------------
+    def _cached_prepare(self, cache, ids, ids_dev=None):
+        """Buffers of one step over the graphs ``ids`` (host numbers; ``ids_dev``: the same as int32 on the device) of
+        ``cache`` (resident.TopologyCache)."""
+        import numpy as np
+        api = self.api
+        ids = np.asarray(ids, dtype=np.int64).reshape(-1)
+        B = int(ids.size)
+        gset = cache.set
+        if ids_dev is None:
+            ids_dev = gset.upload_ids(ids)
+        n_feat, dev, nb = gset.n_feat, gset.device, self.n_branch
+        if self.kind == _lib.SGAT and not cache.with_weights:
+            raise ValueError("sGAT needs a topology cache built with edge weights (topology_cache(need_weights=True))")
+        max_nodes, max_edges, max_c0 = cache.bounds(ids)
+        need = api.net_step_lds_bytes(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O)
+        if not (0 < need <= 160 * 1024):
+            raise _lib.DrgnnError("a graph of this mini-batch does not fit the fused step kernel's LDS budget")
+        xchg = None
+        if nb > 1:
+            xchg = self._xchg.get(B)
+            if xchg is None:
+                xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * self.H), dtype=torch.int64, device=dev)
+        ck = self._desc_cache.get(n_feat)
+        if ck is None:
+            g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+            g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+            for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, nb)):
+                _fill_grads(g1[b], self.kind, l1, n_feat, H1)
+                _fill_grads(g2[b], self.kind, l2, H1, H2)
+            ck = self._desc_cache[n_feat] = (g1, g2, _describe(self.kind, n_feat, self.live, nb))
+        g1, g2, desc = ck
+        bk = self._slab_cache.get((B, n_feat))
+        if bk is None:
+            bk = self._slab_cache[(B, n_feat)] = (
+                torch.empty((B, H2 * nb), dtype=torch.float32, device=dev),
+                torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
+                torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
+        readout, partials, hp = bk
+        return dict(cache=cache, ids_dev=ids_dev, B=B, bounds=(max_nodes, max_edges, max_c0), xchg=xchg, g1=g1, g2=g2,
+                    desc=desc, stream=_lib.current_stream(gset.x), readout=readout, partials=partials, hp=hp,
+                    pred=torch.empty((B, self.O), dtype=torch.float32, device=dev))
+
+    def _cached_launch_step(self, c, train=True):
+        mn, me, mc = c["bounds"]
+        self.api.net_train_step_cached(c["desc"], self._head_desc(train), c["cache"]._desc, c["ids_dev"], c["B"], mn, me, mc,
+                                       self.step2, c["pred"], c["readout"], c["hp"] if train else None,
+                                       c["partials"] if train else None, c["xchg"], c["stream"])
+
+    def train_step_cached(self, cache, ids, ids_dev=None, apply_adam=True):
+        """One optimisation step on the graphs ``ids`` of a cached set: the fused step launch reading the cached
+        topology in place + the update launch.  Same arithmetic as ``train_step`` on the collated mini-batch."""
+        c = self._cached_prepare(cache, ids, ids_dev)
+        want = torch.float32 if self.task == _lib.TASK_REG else torch.int64
+        if cache.set.y is None or cache.set.y.dtype != want:
+            raise ValueError("the set's targets must be %s for this task" % want)
+        self._cached_launch_step(c, True)
+        self._fused_launch_update(c, apply_adam)
+        self.last_pred = c["pred"]
+        self.last_batch_size = c["B"]
+        return self.loss
+
+    @torch.no_grad()
+    def predict_cached(self, cache, ids, ids_dev=None):
+        c = self._cached_prepare(cache, ids, ids_dev)
+        self._cached_launch_step(c, False)
+        return c["pred"]
+
     def _backward(self, batch, topo, apply_adam, next_topo=None):
         """Fused step when every graph fits LDS (see _fused); else fwd (++step) -> bwd with the per-graph
         head + loss inside (and, when given, the NEXT mini-batch's topology build sharing that launch)
@@ -282,13 +350,13 @@ class FusedTrainer(object):
         self.apply_update()
         return loss
 
-    def predict_epoch(self, gset, order, batch_size):
+    def predict_epoch(self, gset, order, batch_size, cached=False):
         """Inference over the graphs ``order`` of the resident set, native loop (one launch per mini-batch, no
         synchronisation): pred [len(order), O] on the device, or None when a graph needs the per-batch path."""
-        done = self._run_epoch(gset, order, batch_size, inference=True)
+        done = self._run_epoch(gset, order, batch_size, inference=True, cached=cached)
         return None if done is None else done[1]
 
-    def train_epoch(self, gset, order, batch_size):
+    def train_epoch(self, gset, order, batch_size, cached=False):
         """A whole epoch over the resident set ``gset`` (resident.ResidentGraphSet) in visiting order ``order``
         (graph numbers), driven by the native loop ``drgnn_train_epoch``: per mini-batch the fused step launch
         (whose extra workgroups build the next mini-batch's topology and gather its node rows straight from the
@@ -302,9 +370,12 @@ class FusedTrainer(object):
         want = torch.float32 if self.task == _lib.TASK_REG else torch.int64
         if gset.y is None or gset.y.dtype != want:
             return None
-        return self._run_epoch(gset, order, batch_size, inference=False)
+        return self._run_epoch(gset, order, batch_size, inference=False, cached=cached)
 
-    def _run_epoch(self, gset, order, batch_size, inference):
+    def _run_epoch(self, gset, order, batch_size, inference, cached=False):
+        """``cached``: step the mini-batches out of the set's topology cache (built once, ``gset.topology_cache``):
+        no builder / offset / gather work in the loop (declared mode; the default rebuilds every mini-batch's topology
+        like the reference does in every forward pass)."""
         import ctypes
         import numpy as np
         if not self.fused_step or not (gset.has_c0 and gset.has_c1):
@@ -348,6 +419,9 @@ class FusedTrainer(object):
         plan.exp_avg, plan.exp_avg_sq, plan.n_param = self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(), self.flat_p.numel()
         plan.step2 = self.step2.data_ptr()
         plan.lr, plan.beta1, plan.beta2, plan.eps = self.lr, self.betas[0], self.betas[1], self.eps
+        if cached:
+            cache = gset.topology_cache(need_weights=need_w)
+            plan.cache = ctypes.cast(ctypes.pointer(cache._desc), vp)
         nbytes = self.api.train_epoch_scratch_bytes(plan)
         if nbytes is None:
             return None

@@ -455,6 +455,27 @@ int drgnn_collate(const drgnn_graph_set* set, const int32_t* ids, int64_t n_grap
  * drgnn_net_train_step / drgnn_step_update.  Returns DRGNN_E_CAPACITY when some graph does not fit the fused step
  * kernel's or the topology builder's LDS budget (the caller then steps mini-batch by mini-batch).
  * drgnn_train_epoch_scratch_bytes: bytes of device scratch the plan needs (< 0: error code). */
+/* ---- cached topology (declared mode) -----------------------------------------------------------------
+ * Per-graph topology does not depend on the mini-batch (all ids inside a graph's segment are local), so a
+ * resident graph set can build it ONCE: one topology workspace over the whole set (drgnn_topology_build_request
+ * in resident-set mode with ids = 0..G-1 and the set's own offset tables), kept next to the set's node features
+ * and targets.  A mini-batch is then just a list of graph numbers: the fused step reads graph ids[g]'s segments
+ * of the cached workspace in place -- no builder workgroups, no per-step index work at all.
+ * (The reference redoes this work in every forward pass: community_pooling.py:25-30,197-201; "rebuilt every
+ * step" stays the default mode of this library and of bench.py's headline.) */
+typedef struct drgnn_topology_cache {
+    int64_t n_graphs, n_nodes, n_edges;          /* of the WHOLE set = the shape the workspace was laid out for */
+    const int32_t* ws_i32; const float* ws_f32;  /* ws_f32 may be NULL (nets without edge weights) */
+    const float* x;                              /* [n_nodes, F] node features, graph-major (the set's x) */
+    const void* y; int32_t y_bytes, reserved;    /* [n_graphs] targets: 4 = float32, 8 = int64; may be NULL (inference) */
+} drgnn_topology_cache;
+/* drgnn_net_train_step over the graphs ids[0..n_graphs) of a cached set: same outputs, same arithmetic (slot g
+ * of every output = graph ids[g]); max_* bound the graphs of THIS mini-batch. */
+int drgnn_net_train_step_cached(const drgnn_net_desc* net, const drgnn_head_desc* head,
+                                const drgnn_topology_cache* cache, const int32_t* ids, int64_t n_graphs,
+                                int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t* step2, float* pred,
+                                float* readout, float* head_partials, float* partials, uint64_t* xchg, void* stream);
+
 typedef struct drgnn_epoch_plan {
     const drgnn_graph_set* set;
     const int64_t* host_node_ptr; const int64_t* host_edge_ptr; const int64_t* host_c1_ptr;
@@ -468,6 +489,9 @@ typedef struct drgnn_epoch_plan {
     float* flat_param; float* flat_grad; float* exp_avg; float* exp_avg_sq; int64_t n_param;
     int32_t* step2;
     float lr, beta1, beta2, eps;
+    /* cached-topology mode (non-NULL): mini-batches are stepped straight out of the cache, the loop issues no
+     * offset-table, builder or gather work; `set` is then only consulted for the graphs' sizes on the host */
+    const drgnn_topology_cache* cache;
 } drgnn_epoch_plan;
 int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan);
 int drgnn_train_epoch(const drgnn_epoch_plan* plan, void* scratch, int64_t scratch_bytes, float* pred,

@@ -10,7 +10,9 @@ from deeprank_gnn_amd.resident import ResidentGraphSet
 from deeprank_gnn_amd.trainer import FusedTrainer
 
 
-def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=2, seed=0, exact=True):
+def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=2, seed=0, exact=True, cached=False):
+    """``cached``: the native loop steps the mini-batches out of the set's topology cache (built once, no builder in the
+    loop) -- must give the SAME bits as rebuilding every mini-batch's topology."""
     torch.manual_seed(seed)
     n_out = 1 if task == "reg" else 3
     net = Net(n_feat, n_out, 1).to(device)
@@ -28,7 +30,7 @@ def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=
     rng = np.random.default_rng(seed)
     for _ in range(epochs):
         order = rng.permutation(len(graphs)).tolist()
-        got = tr_a.train_epoch(rs, order, batch_size)
+        got = tr_a.train_epoch(rs, order, batch_size, cached=cached)
         assert got is not None, "the native epoch loop refused a configuration that fits"
         losses, pred = got
         want_l, want_p = [], []
@@ -45,7 +47,7 @@ def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=
             np.testing.assert_allclose(pred.cpu().numpy(), want_p.numpy(), rtol=1e-4, atol=1e-5)
     # inference pass over a permutation (dropout off): native loop vs predict() on host-collated mini-batches
     order = rng.permutation(len(graphs)).tolist()
-    got = tr_a.predict_epoch(rs, order, batch_size)
+    got = tr_a.predict_epoch(rs, order, batch_size, cached=cached)
     assert got is not None
     want = torch.cat([tr_b.predict(Batch.from_data_list([graphs[i] for i in order[lo:lo + batch_size]]).to(device)).cpu()
                       for lo in range(0, len(order), batch_size)])
@@ -59,4 +61,19 @@ def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=
         assert torch.equal(tr_a.exp_avg_sq.cpu(), tr_b.exp_avg_sq.cpu())
     else:
         np.testing.assert_allclose(tr_a.flat_p.cpu().numpy(), tr_b.flat_p.cpu().numpy(), rtol=1e-4, atol=1e-6)
+    if cached:
+        # single steps out of the cache == single steps on the collated mini-batch
+        ids = order[:batch_size]
+        b = Batch.from_data_list([graphs[i] for i in ids]).to(device)
+        la = float(tr_a.train_step_cached(rs.topology_cache(need_weights=True), ids))
+        lb = float(tr_b.train_step(b))
+        pa = tr_a.predict_cached(rs.topology_cache(need_weights=True), ids).cpu()
+        pb = tr_b.predict(b).cpu()
+        if exact:
+            assert la == lb
+            assert torch.equal(tr_a.flat_p.cpu(), tr_b.flat_p.cpu())
+            assert torch.equal(pa, pb)
+        else:
+            np.testing.assert_allclose(la, lb, rtol=1e-5)
+            np.testing.assert_allclose(pa.numpy(), pb.numpy(), rtol=1e-4, atol=1e-5)
     return tr_a

@@ -18,3 +18,9 @@ def test_epoch_ragged(Net, task, bs):
 
 def test_epoch_fixture():
     check_epoch(GINet, fixture_graphs(), 28, "reg", "cpu", 4, api=emu())
+
+
+@pytest.mark.parametrize("Net,task,bs", [(GINet, "reg", 4), (sGAT, "reg", 3), (FoutNet, "class", 5)])
+def test_epoch_cached_topology(Net, task, bs):
+    """Declared cached-topology mode (topology of every graph built once at upload, mini-batch = list of graph numbers)."""
+    check_epoch(Net, ragged_graphs(11, 12), 12, task, "cpu", bs, api=emu(), cached=True)

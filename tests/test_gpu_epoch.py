@@ -27,6 +27,18 @@ def test_epoch_full_size(Net):
     check_epoch(Net, [synth.make_graph(i) for i in range(200)], 32, "reg", "cuda", 64)
 
 
+@pytest.mark.parametrize("Net,task,bs", [(GINet, "reg", 4), (sGAT, "reg", 3), (FoutNet, "class", 5)])
+def test_epoch_cached_topology_ragged(Net, task, bs):
+    check_epoch(Net, ragged_graphs(11, 12), 12, task, "cuda", bs, cached=True)
+
+
+@pytest.mark.parametrize("Net", [GINet, sGAT, FoutNet])
+def test_epoch_cached_topology_full_size(Net):
+    """Cached-topology mode at BASELINE size: same bits as rebuilding the topology of every mini-batch."""
+    import deeprank_gnn_amd.synthetic as synth
+    check_epoch(Net, [synth.make_graph(i) for i in range(200)], 32, "reg", "cuda", 64, cached=True)
+
+
 @pytest.mark.parametrize("net_name", ["GINet", "sGAT", "FoutNet"])
 def test_native_epochs_match_oracle_training(net_name):
     """Two shuffled epochs of the native loop over a resident set of 40 SYN graphs (mini-batches of 16, ragged last one)
