@@ -400,10 +400,19 @@ def main():
                         state["k"] ^= 1
                         n -= 1
             else:
+                # one workspace (own-launch builder, or cached topology): CHUNK steps per replay + single steps
+                CHUNK = max(1, min(args.steps_per_replay, args.steps))
+
+                def chunk():
+                    for _ in range(CHUNK):
+                        whole_step()
+                g_chunk = graph_of(chunk)
                 g_step = graph_of(whole_step)
 
                 def run_steps(n):
-                    for _ in range(n):
+                    for _ in range(n // CHUNK):
+                        g_chunk.replay()
+                    for _ in range(n % CHUNK):
                         g_step.replay()
     else:
         def run_steps(n):

@@ -1,0 +1,560 @@
+// drgnn_kernels.h -- launch descriptions, per-workgroup drivers and the __global__ kernels of the library.
+//
+// Included by drgnn_capi.hip (which defines DRGNN_KERNELS_MAIN: it owns the plain kernels and the host side) and by
+// drgnn_step_tu.hip, compiled once per kind of net: the instantiations of the fused step kernel are by far the largest
+// part of the build, so three more translation units compile them in parallel (make -j).
+#pragma once
+#include "drgnn_head.h"
+#include "drgnn_step.h"
+#include "drgnn_layers.h"
+#include "drgnn_mcl.h"
+#include "drgnn_collate.h"
+
+// =====================================================================================
+// kernels
+// =====================================================================================
+struct PtrArgs {
+    const int64_t* batch;
+    const int64_t* edge_row;
+    int64_t n_nodes, n_edges;
+    int n_graphs;
+    int32_t* nptr;
+    int32_t* eptr;
+    int32_t* err;
+};
+
+// per-graph offsets from the (sorted) batch vector and the graph-grouped edge list
+DEV void ptr_item(const PtrArgs& a, int64_t i) {
+    const int B = a.n_graphs;
+    if (i < a.n_nodes) {
+        long long b = a.batch[i];
+        long long prev = (i > 0) ? (long long)a.batch[i - 1] : -1;
+        if (b < prev || b < 0 || b >= B) { ATOMIC_OR(&a.err[0], DRGNN_S_UNSORTED); a.err[1] = 0; b = prev < 0 ? 0 : prev; }
+        for (long long gph = prev + 1; gph <= b && gph <= B; ++gph) a.nptr[gph] = (int32_t)i;
+        if (i == a.n_nodes - 1)
+            for (long long gph = b + 1; gph <= B; ++gph) a.nptr[gph] = (int32_t)a.n_nodes;
+    }
+    if (i < a.n_edges) {
+        auto graph_of = [&](int64_t e) -> long long {
+            const long long r = a.edge_row[e];
+            if (r < 0 || r >= a.n_nodes) return -2;
+            return (long long)a.batch[r];
+        };
+        long long b = graph_of(i);
+        long long prev = (i > 0) ? graph_of(i - 1) : -1;
+        if (b == -2 || prev == -2) { ATOMIC_OR(&a.err[0], DRGNN_S_EDGE_RANGE); a.err[1] = 0; if (b == -2) b = prev < 0 ? 0 : prev; if (prev == -2) prev = b; }
+        if (b < prev || b >= B) { ATOMIC_OR(&a.err[0], DRGNN_S_UNSORTED); a.err[1] = 0; b = prev; }
+        for (long long gph = prev + 1; gph <= b && gph <= B; ++gph) a.eptr[gph] = (int32_t)i;
+        if (i == a.n_edges - 1)
+            for (long long gph = b + 1; gph <= B; ++gph) a.eptr[gph] = (int32_t)a.n_edges;
+    }
+    if (i == 0) {
+        if (a.n_nodes == 0) for (int gph = 0; gph <= B; ++gph) a.nptr[gph] = 0;
+        if (a.n_edges == 0) for (int gph = 0; gph <= B; ++gph) a.eptr[gph] = 0;
+    }
+}
+
+struct TopoLaunch {
+    TopoView tv;
+    TopoArgs args;
+    const int32_t* user_nptr;   // caller-supplied per-graph offsets (null: k_ptrs filled the workspace)
+    const int32_t* user_eptr;
+    int32_t* gscratch;     // global scratch (when not in LDS)
+    int capN, capE;        // LDS capacities (0 = use global scratch)
+    int level1_only;       // second pass: only depth-1 clusters, c1 offsets from NC0
+    int roles;             // 1: one workgroup per graph; 2: edge structures / member lists split
+};
+
+// LDS is a compile-time property so that every scratch access is a ds_* instruction (a
+// run-time choice between LDS and global would make them all flat_* accesses)
+template <bool LDS>
+DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
+    TopoScratch s;
+    // Two workgroups per graph: within full groups of 8 graphs both land on XCD (graph % 8) -- workgroups are dealt
+    // round-robin to the 8 XCDs and the step kernels put graph g there too (step_block), so what the builder writes
+    // is read back through the same L2 by the launch that trains on it.
+    int g = blk, role = TOPO_ROLE_ALL;
+    if (L.roles == 2) {
+        const int full = (L.args.n_graphs >> 3) << 4;
+        if (blk < full) { g = ((blk >> 4) << 3) + (blk & 7); role = ((blk >> 3) & 1) ? TOPO_ROLE_MEMBERS : TOPO_ROLE_EDGES; }
+        else { const int t = blk - full; g = (full >> 1) + (t >> 1); role = (t & 1) ? TOPO_ROLE_MEMBERS : TOPO_ROLE_EDGES; }
+    }
+    const int sidx = (role == TOPO_ROLE_MEMBERS) ? L.args.n_graphs + g : g;
+    const int32_t* NP = L.user_nptr ? L.user_nptr : L.tv.p[DRGNN_TI_NPTR];
+    const int32_t* EP = L.user_eptr ? L.user_eptr : L.tv.p[DRGNN_TI_EPTR];
+    const int n0 = NP[g], n1 = NP[g + 1], N = n1 - n0;
+    const int e0 = EP[g], e1 = EP[g + 1], E = e1 - e0;
+    if (!L.level1_only) {
+        FOR_TID(i, 1) {
+            L.tv.p[DRGNN_TI_GSTAT][sidx] = 0;
+            if (role == TOPO_ROLE_ALL) L.tv.p[DRGNN_TI_GSTAT][L.args.n_graphs + g] = 0;
+            if (L.user_nptr && role != TOPO_ROLE_MEMBERS) {       // publish the offsets for the kernels that follow
+                L.tv.p[DRGNN_TI_NPTR][g] = n0; L.tv.p[DRGNN_TI_NPTR][g + 1] = n1;
+                L.tv.p[DRGNN_TI_EPTR][g] = e0; L.tv.p[DRGNN_TI_EPTR][g + 1] = e1;
+                if (g == 0) L.tv.p[DRGNN_TI_ERR][0] = 0;
+            }
+        }
+        BARRIER();
+    }
+    if (LDS) {
+        const int capT = imax(L.capN, L.capE) + 1;
+        s = topo_carve(lds, L.capN, L.capE, capT, L.capN + L.capE + 2);
+        if (N > L.capN || E > L.capE) {   // caller's bound was wrong: refuse loudly
+            FOR_TID(i, 1) { topo_flag(L.tv, DRGNN_S_EDGE_RANGE, sidx); }
+            return;
+        }
+    } else {
+        // linear placement (see topo_gscratch_base): disjoint regions without a scan
+        s = topo_carve(L.gscratch + topo_gscratch_base(n0, e0, g), N, E, N + E + 1, N + E + 2);
+    }
+    if (!L.level1_only) {
+        topo_graph(L.tv, L.args, g, n0, n1, e0, e1, s, role);
+    } else {
+        // offset of this graph's ids inside cluster1 = number of depth-0 clusters before it
+        FOR_TID(i, 1) { s.part[0] = 0; }
+        BARRIER();
+        FOR_TID(t, DRGNN_NTHREADS) {
+            int acc = 0;
+            for (int q = t; q < g; q += DRGNN_NTHREADS) acc += L.tv.p[DRGNN_TI_NC0][q];
+            if (acc) ATOMIC_ADD(&s.part[0], acc);
+        }
+        BARRIER();
+        const int begin = s.part[0];
+        const int C0 = L.tv.p[DRGNN_TI_NC0][g];
+        BARRIER();
+        int len = C0;
+        if (g == L.args.n_graphs - 1 && (int64_t)begin + C0 != L.args.len_cluster1) len = -1;
+        if ((int64_t)begin + C0 > L.args.len_cluster1) len = -1;
+        topo_graph_level1(L.tv, L.args, g, n0, C0, L.args.cluster1 + begin, len, s, g);
+    }
+}
+
+struct ScanArgs { TopoView tv; int n_graphs; };
+DEV void finalize_block(const ScanArgs& a, int* part) {
+    const int B = a.n_graphs;
+    const int src[3] = {DRGNN_TI_NC0, DRGNN_TI_NE1, DRGNN_TI_NC1};
+    const int dst[3] = {DRGNN_TI_CPTR0, DRGNN_TI_E1PTR, DRGNN_TI_CPTR1};
+    for (int w = 0; w < 3; ++w) {
+        int32_t* out = a.tv.p[dst[w]];
+        const int32_t* in = a.tv.p[src[w]];
+        FOR_TID(i, B + 1) { out[i] = (i < B) ? in[i] : 0; }
+        BARRIER();
+        wg_exscan(out, B + 1, part);
+    }
+}
+
+struct ReduceArgs {
+    const float* partials;
+    int n_graphs, n_branch, n_feat, n_partial;
+    int kind;
+    drgnn_conv_params lay1[DRGNN_MAX_BRANCH], lay2[DRGNN_MAX_BRANCH];   // striding (pointers unused)
+    drgnn_conv_grads g1[DRGNN_MAX_BRANCH], g2[DRGNN_MAX_BRANCH];
+    float* grad_x; int64_t n_nodes;    // [n_branch][Ntot][F] -> summed into branch 0
+};
+
+// where one reduced partial element lives inside the model's own (strided) gradient tensor
+DEV float* reduce_dst(const ReduceArgs& a, int br, int p) {
+    const int F = a.n_feat;
+    const int o_w1s = F * DRGNN_H1, o_b1 = 2 * F * DRGNN_H1, o_w2n = o_b1 + DRGNN_H1;
+    const int o_w2s = o_w2n + DRGNN_H1 * DRGNN_H2, o_b2 = o_w2s + DRGNN_H1 * DRGNN_H2;
+    if (p < o_w1s)
+        return a.g1[br].w_nbr ? a.g1[br].w_nbr + (int64_t)(p / DRGNN_H1) * a.lay1[br].nbr_sk + (int64_t)(p % DRGNN_H1) * a.lay1[br].nbr_sh : nullptr;
+    if (p < o_b1) {
+        const int q = p - o_w1s;
+        return a.g1[br].w_self ? a.g1[br].w_self + (int64_t)(q / DRGNN_H1) * a.lay1[br].self_sk + (int64_t)(q % DRGNN_H1) * a.lay1[br].self_sh : nullptr;
+    }
+    if (p < o_w2n) return a.g1[br].bias ? a.g1[br].bias + (p - o_b1) : nullptr;
+    if (p < o_w2s) {
+        const int q = p - o_w2n;
+        return a.g2[br].w_nbr ? a.g2[br].w_nbr + (int64_t)(q / DRGNN_H2) * a.lay2[br].nbr_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].nbr_sh : nullptr;
+    }
+    if (p < o_b2) {
+        const int q = p - o_w2s;
+        return a.g2[br].w_self ? a.g2[br].w_self + (int64_t)(q / DRGNN_H2) * a.lay2[br].self_sk + (int64_t)(q % DRGNN_H2) * a.lay2[br].self_sh : nullptr;
+    }
+    return a.g2[br].bias ? a.g2[br].bias + (p - o_b2) : nullptr;
+}
+DEV void reduce_write(const ReduceArgs& a, int br, int p, float acc) {
+    float* d = reduce_dst(a, br, p);
+    if (d) *d = acc;
+}
+
+// is this partial slot ever written by the backward kernel?  (GINet has no self / bias terms)
+DEV bool reduce_live(const ReduceArgs& a, int p) {
+    if (a.kind != DRGNN_GINET) return true;
+    const int F = a.n_feat;
+    const int o_w1s = F * DRGNN_H1, o_w2n = 2 * F * DRGNN_H1 + DRGNN_H1, o_w2s = o_w2n + DRGNN_H1 * DRGNN_H2;
+    return p < o_w1s || (p >= o_w2n && p < o_w2s);
+}
+
+// sum of one partial element over the graphs g = first, first+stride, ... (ascending)
+DEV float reduce_sum(const ReduceArgs& a, int br, int p, int first, int stride) {
+    const float* src = a.partials + (int64_t)br * a.n_partial + p;
+    const int64_t step = (int64_t)a.n_branch * a.n_partial;
+    float acc = 0.0f;
+    // all the loads of a lane's share in flight at once (16 for 64 graphs, 4 waves): the launch is one memory round
+    // trip deep instead of four
+    float v[16];
+    int g = first;
+    for (; g + 15 * stride < a.n_graphs; g += 16 * stride) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = src[(int64_t)(g + k * stride) * step];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+    for (; g < a.n_graphs; g += stride) acc += src[(int64_t)g * step];
+    return acc;
+}
+
+DEV void reduce_grad_x(const ReduceArgs& a, int64_t item) {
+    if (a.grad_x != nullptr && a.n_branch > 1 && item < a.n_nodes * a.n_feat) {
+        float acc = a.grad_x[item];
+        for (int br = 1; br < a.n_branch; ++br) acc += a.grad_x[(int64_t)br * a.n_nodes * a.n_feat + item];
+        a.grad_x[item] = acc;
+    }
+}
+
+struct NetLaunch {
+    NetArgs a;
+    float* gscratch;
+    int capN, capE, capC;   // LDS capacities (capN == 0 -> global scratch)
+    int64_t n_edges;
+};
+
+// A body launch that ALSO builds the topology of the next mini-batch: workgroups
+// [0, n_net) run the body, [n_net, n_net + n_graphs_next) the topology builder.  The two jobs
+// are independent (the builder reads index tensors only), so this hides one of them behind
+// the other and saves a kernel boundary -- software pipelining across training steps.
+struct CoLaunch {
+    NetLaunch net;
+    TopoLaunch topo;
+    int n_net;
+};
+
+// global-scratch placement: net_scratch_words is affine in (capN, capE, capC)
+HD int64_t net_gscratch_base(int kind, int F, int64_t n0, int64_t e0, int64_t g, int bwd) {
+    const int64_t c0 = net_scratch_words(kind, F, 0, 0, 0, bwd);
+    return net_scratch_words(kind, F, n0, e0, n0, bwd) - c0 + c0 * g;
+}
+
+template <int KIND, bool BWD, bool LDS>
+DEV void net_block(const NetLaunch& L, int blk, float* lds) {
+    const int nb = L.a.net.n_branch;
+    const int g = blk / nb, br = blk % nb;
+    float* scratch;
+    int capN, capE, capC;
+    if (LDS) {
+        scratch = lds; capN = L.capN; capE = L.capE; capC = L.capC;
+        const int n0 = L.a.tv.p[DRGNN_TI_NPTR][g], e0 = L.a.tv.p[DRGNN_TI_EPTR][g];
+        if (L.a.tv.p[DRGNN_TI_NPTR][g + 1] - n0 > capN || L.a.tv.p[DRGNN_TI_EPTR][g + 1] - e0 > capE ||
+            L.a.tv.p[DRGNN_TI_NC0][g] > capC) {
+            // the caller's bounds were wrong: poison the output instead of overrunning LDS
+            if (!BWD) {
+                FOR_TID(c, DRGNN_H2) { L.a.readout[(long)g * DRGNN_H2 * nb + br * DRGNN_H2 + c] = DRGNN_NAN; }
+            }
+            return;
+        }
+    } else {
+        const int n0 = L.a.tv.p[DRGNN_TI_NPTR][g], e0 = L.a.tv.p[DRGNN_TI_EPTR][g];
+        capN = L.a.tv.p[DRGNN_TI_NPTR][g + 1] - n0;
+        capE = L.a.tv.p[DRGNN_TI_EPTR][g + 1] - e0;
+        capC = capN;
+        const int F = L.a.net.n_feat;
+        const int64_t per_branch = net_gscratch_base(KIND, F, L.a.n_nodes, L.n_edges, L.a.n_graphs, BWD);
+        scratch = L.gscratch + (int64_t)br * per_branch + net_gscratch_base(KIND, F, n0, e0, g, BWD);
+    }
+    if (BWD) net_backward_graph<KIND>(L.a, g, br, scratch, capN, capE, capC);
+    else net_forward_graph<KIND>(L.a, g, br, scratch, capN, capE, capC);
+}
+
+// ---- fused training step (drgnn_step.h): one launch for body fwd + head/loss + body bwd, sharing the
+// grid with the topology builder of the next mini-batch exactly like CoLaunch above ---------------
+struct StepLaunch {
+    StepArgs a;
+    int capN, capE, capC;
+    int64_t words;          // scratch words per workgroup (emulation: one persistent slab each)
+};
+struct StepCoLaunch {
+    StepLaunch step;
+    TopoLaunch topo;
+    int n_net;
+};
+
+// GATHER: cached-topology mode (slot g of the launch = graph gather_ids[g] of a whole-set workspace).  A template
+// parameter, not a run-time branch: the per-mini-batch kernels keep exactly the code (and register allocation) they had
+template <int KIND, int XF, bool GATHER = false>
+DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
+    constexpr int nb = (KIND == DRGNN_GINET) ? 2 : 1;
+    // Workgroups go to the 8 XCDs round robin (block id mod 8) and each XCD has its own L2.  The two
+    // branch workgroups of a graph read the same x tile and the same topology: they are placed 8
+    // block ids apart so that they share an L2 (the second one's misses merge with the first one's).
+    int g, br;
+    if (nb == 2) { g = ((blk >> 4) << 3) + (blk & 7); br = (blk >> 3) & 1; }
+    else { g = blk; br = 0; }
+    if (g >= L.a.n_graphs) return;                // padding of the last group of 8 graphs
+    const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;      // cached mode: graph number in the set
+    const GraphDims d = net_dims(L.a.tv, gi);     // ONE round trip for all per-graph sizes
+    if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
+        // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
+        if (part != 2) {
+            const uint32_t tag = (uint32_t)L.a.step2[0] + 1u;
+            FOR_TID(c, DRGNN_H2) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + br * DRGNN_H2 + c] = DRGNN_NAN; }
+            if (nb > 1) {
+                FOR_TID(h, L.a.hf.H) { xchg_publish(L.a.xchg + ((long)g * nb + br) * L.a.hf.H + h, tag, DRGNN_NAN); }
+            }
+        }
+        if (part != 1 && br == 0) {
+            if (L.a.hf.train) {
+                float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+                FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            }
+            FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
+        }
+        return;
+    }
+    net_step_graph<KIND, XF, GATHER>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, part);
+}
+
+// ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
+struct UpdateArgs {
+    ReduceArgs r;
+    HeadReduceArgs h;       // h.grad = flat gradient block of the FC head; h.step unused here
+    AdamArgs ad;            // flat buffers; ad.grad = base of the flat gradient
+    int conv_blocks;        // blocks [0, conv_blocks) reduce conv partials, the rest the head's
+    int apply_adam;         // 0: only produce the flat gradient (data parallel: all-reduce comes next)
+    // fused-step mode: head slabs are compact ([dhid H][dW2][db2][loss][weight], u.h.P floats each) and
+    // dW_fc1[h][r] = sum_g dhid[g][h] * readout[g][r] is formed here
+    const float* readout;   // [n_wg][R] or null (legacy slabs that already hold dW_fc1)
+    int hR, hH;
+    int32_t* step2;         // non-null: commit step2[0] = step2[1] (the step index Adam just used)
+};
+
+DEV void update_store(const UpdateArgs& u, float* dst, float g) {
+    *dst = g;                                   // keep p.grad inspectable
+    if (u.apply_adam) adam_item(u.ad, (int64_t)(dst - u.ad.grad));
+}
+
+// number of head items one update launch produces: the gradient block + the loss
+DEV int update_head_items(const UpdateArgs& u) { return (u.readout ? u.hH * u.hR : 0) + u.h.P - 1; }
+// sum of one head-partial element over the slabs w = first, first+stride, ...
+DEV float update_head_sum(const UpdateArgs& u, int item, int first, int stride) {
+    float acc = 0.0f;
+    if (u.readout) {
+        const int HR = u.hH * u.hR;
+        if (item < HR) {
+            const int h = item / u.hR, r = item - h * u.hR;
+            const float* dh = u.h.partials + h;
+            const float* xr = u.readout + r;
+            float va[16], vb[16];
+            int w = first;
+            for (; w + 15 * stride < u.h.n_wg; w += 16 * stride) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) { va[k] = dh[(long)(w + k * stride) * u.h.P]; vb[k] = xr[(long)(w + k * stride) * u.hR]; }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fmaf(va[k], vb[k], acc);
+            }
+            for (; w < u.h.n_wg; w += stride) acc = fmaf(dh[(long)w * u.h.P], xr[(long)w * u.hR], acc);
+            return acc;
+        }
+        item -= HR;
+    }
+    const float* src = u.h.partials + item;
+    float v[16];
+    int w = first;
+    for (; w + 15 * stride < u.h.n_wg; w += 16 * stride) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = src[(long)(w + k * stride) * u.h.P];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += v[k];
+    }
+    for (; w < u.h.n_wg; w += stride) acc += src[(long)w * u.h.P];
+    return acc;
+}
+DEV void update_head_store(const UpdateArgs& u, int item, float acc) {
+    const int n_grad = update_head_items(u) - 1;
+    if (item < n_grad) update_store(u, u.h.grad + item, acc);
+    else if (item == n_grad && u.h.loss) u.h.loss[0] = acc;
+}
+
+#ifndef DRGNN_EMU
+#ifdef DRGNN_KERNELS_MAIN
+__global__ void __launch_bounds__(256) k_ptrs(PtrArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ptr_item(a, i);
+}
+#endif  // DRGNN_KERNELS_MAIN
+template <bool LDS>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_topo(TopoLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) int smem_i[];
+    PHASE_BEGIN();
+    topo_block<LDS>(L, blockIdx.x, smem_i);
+}
+#ifdef DRGNN_KERNELS_MAIN
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_finalize(ScanArgs a) {
+    __shared__ int part[DRGNN_NTHREADS + 4];
+    finalize_block(a, part);
+}
+// 64 gradient elements per workgroup; the 4 waves sum interleaved quarters of the graphs, the
+// quarter sums are combined in fixed order -> deterministic, and 4x16 loads in flight per lane
+__global__ void __launch_bounds__(256) k_reduce(ReduceArgs a, int64_t n_items) {
+    __shared__ float quarter[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int64_t item = (int64_t)blockIdx.x * 64 + lane;
+    const bool live = item < (int64_t)a.n_branch * a.n_partial && reduce_live(a, (int)(item % a.n_partial));
+    const int br = live ? (int)(item / a.n_partial) : 0, p = live ? (int)(item % a.n_partial) : 0;
+    quarter[q][lane] = live ? reduce_sum(a, br, p, q, 4) : 0.0f;
+    __syncthreads();
+    if (q == 0) {
+        if (live) reduce_write(a, br, p, (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]));
+    } else {
+        // the other waves fold the per-branch d loss / d x slabs (only when it was requested)
+        for (int64_t e = (int64_t)blockIdx.x * 192 + (threadIdx.x - 64); e < a.n_nodes * a.n_feat && a.grad_x; e += (int64_t)gridDim.x * 192)
+            reduce_grad_x(a, e);
+    }
+}
+#endif  // DRGNN_KERNELS_MAIN
+template <int KIND, bool BWD, bool LDS>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_net(NetLaunch L) {
+    extern __shared__ __attribute__((aligned(16))) float smem_f[];
+    PHASE_BEGIN();
+    net_block<KIND, BWD, LDS>(L, blockIdx.x, smem_f);
+}
+template <int KIND, bool BWD>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_net_co_topo(CoLaunch C) {
+    extern __shared__ __attribute__((aligned(16))) float smem_c[];
+    PHASE_BEGIN();
+    if ((int)blockIdx.x < C.n_net) net_block<KIND, BWD, true>(C.net, blockIdx.x, smem_c);
+    else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_c);
+}
+template <int KIND, int XF, bool GATHER>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C) {
+    extern __shared__ __attribute__((aligned(16))) float smem_s[];
+    PHASE_BEGIN();
+    if ((int)blockIdx.x < C.n_net) step_block<KIND, XF, GATHER>(C.step, blockIdx.x, smem_s, 0);
+    else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);
+}
+#ifdef DRGNN_KERNELS_MAIN
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_conv_aggregate(ConvLayerArgs a) {
+    conv_aggregate_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) k_conv_bwd_du(ConvLayerArgs a) {
+    conv_bwd_du_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_bwd_dw(ConvLayerArgs a) { conv_bwd_dw_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_conv_reduce(ConvReduceArgs a) {
+    conv_reduce_item(a, blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(256) k_conv_bwd_dx(ConvLayerArgs a) {
+    conv_bwd_dx_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_segpool_fwd(SegPoolArgs a) { segpool_fwd_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(256) k_segmax_bwd(SegPoolArgs a, int64_t n_items, int64_t n_nodes) {
+    segmax_bwd_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, n_items, n_nodes);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_edge_export(EdgeExportArgs a) { edge_export_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_cluster_max(ClusterOffsetArgs a) {
+    __shared__ long long mm[2];
+    cluster_max_block(a, blockIdx.x, mm);
+}
+__global__ void k_cluster_scan(ClusterOffsetArgs a) { cluster_scan_single(a); }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_cluster_add(ClusterOffsetArgs a) { cluster_add_block(a, blockIdx.x); }
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_mcl(MclArgs a) {
+    __shared__ double red[DRGNN_NTHREADS];
+    __shared__ int flag[2];
+    mcl_graph(a, blockIdx.x, flag, red);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_graclus(GraclusArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int smem_g[];
+    graclus_block(a, blockIdx.x, smem_g);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_batch_offsets(OffsetsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) int smem_o[];
+    batch_offsets_block(a, blockIdx.x, smem_o + DRGNN_NTHREADS + 4, smem_o);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_collate(CollateArgs a) {
+    __shared__ int sh[4];
+    collate_block(a, blockIdx.x, sh);
+}
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_head(HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem_h[];
+    head_block(a, blockIdx.x, smem_h);
+}
+__global__ void __launch_bounds__(256) k_head_reduce(HeadReduceArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.P - 1) head_reduce_item(a, i);
+}
+// 64 gradient elements per workgroup; the 4 waves sum interleaved quarters of the partial
+// slabs, the quarter sums are combined in fixed order, then Adam is applied to that element
+__global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
+    __shared__ float quarter[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if ((int)blockIdx.x < u.conv_blocks) {
+        const ReduceArgs& a = u.r;
+        const int64_t item = (int64_t)blockIdx.x * 64 + lane;
+        const bool live = item < (int64_t)a.n_branch * a.n_partial && reduce_live(a, (int)(item % a.n_partial));
+        const int br = live ? (int)(item / a.n_partial) : 0, p = live ? (int)(item % a.n_partial) : 0;
+        // wave 0 owns the element's update: its parameter / moment loads and the bias corrections are issued
+        // BEFORE the slab loads, so that Adam starts from registers once the quarter sums are in
+        float* d = (q == 0 && live) ? reduce_dst(a, br, p) : nullptr;
+        const bool upd = d != nullptr && u.apply_adam;
+        const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
+        const AdamPre pre = adam_prefetch(u.ad, idx);
+        quarter[q][lane] = live ? reduce_sum(a, br, p, q, 4) : 0.0f;
+        __syncthreads();
+        if (d) {
+            const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
+            *d = g;                                   // keep p.grad inspectable
+            if (upd) adam_apply(u.ad, idx, g, pre);
+        }
+    } else {
+        const int item = ((int)blockIdx.x - u.conv_blocks) * 64 + lane;
+        const bool live = item < update_head_items(u);
+        const int n_grad = update_head_items(u) - 1;
+        float* d = (q == 0 && live && item < n_grad) ? u.h.grad + item : nullptr;
+        const bool upd = d != nullptr && u.apply_adam;
+        const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
+        const AdamPre pre = adam_prefetch(u.ad, idx);
+        quarter[q][lane] = live ? update_head_sum(u, item, q, 4) : 0.0f;
+        __syncthreads();
+        if (q == 0 && live) {
+            const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
+            if (d) {
+                *d = g;
+                if (upd) adam_apply(u.ad, idx, g, pre);
+            } else if (item == n_grad && u.h.loss) {
+                u.h.loss[0] = g;
+            }
+        }
+    }
+    // nobody reads step2[0] in this launch (Adam reads step2[1]): safe to commit it here
+    if (u.step2 && blockIdx.x == 0 && threadIdx.x == 0) u.step2[0] = u.step2[1];
+}
+__global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
+    adam_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// topology prologue when the caller supplies the per-graph offsets: copy them into the
+// workspace and clear the status words (one launch instead of two copies and a fill)
+__global__ void __launch_bounds__(256) k_topo_begin(const int32_t* node_ptr, const int32_t* edge_ptr,
+                                                    int32_t* nptr, int32_t* eptr, int32_t* err, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        if (node_ptr) { nptr[i] = node_ptr[i]; eptr[i] = edge_ptr[i]; }
+    }
+    if (i < 4) err[i] = 0;
+}
+#endif  // DRGNN_KERNELS_MAIN
+// The instantiations of the fused step kernel live in drgnn_step_tu.hip (one translation unit per kind of net) when
+// the library is built from several translation units (Makefile: DRGNN_SPLIT_TU); a single-unit build (profiling
+// variants) instantiates them implicitly at their launch sites.
+#define DRGNN_STEP_FOR_WIDTHS(X, K) X(K, 0) X(K, 16) X(K, 32) X(K, 48) X(K, 64)
+#if defined(DRGNN_SPLIT_TU) && defined(DRGNN_KERNELS_MAIN)
+#define DRGNN_STEP_EXTERN(K, XF)                                                   \
+    extern template __global__ void k_step_co_topo<K, XF, false>(StepCoLaunch);    \
+    extern template __global__ void k_step_co_topo<K, XF, true>(StepCoLaunch);
+DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_GINET)
+DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_SGAT)
+DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_FOUT)
+#undef DRGNN_STEP_EXTERN
+#endif
+#endif  // !DRGNN_EMU

@@ -847,7 +847,7 @@ static inline bool step_burst_guaranteed(int kind, const float* x, int F, int ca
 // XF: padded feature width F16 as a compile-time constant (16/32/48/64), 0 = taken from the descriptor.
 // The strides of the x tile and of conv1's weights and the K loop of conv1's products hang on it;
 // with it known the kernel is ~8% faster, so the common widths are instantiated.
-template <int KIND, int XF>
+template <int KIND, int XF, bool GATHER = false>
 DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, int br, float* scratch, int capN,
                         int capE, int capC, int part) {
     constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
@@ -912,7 +912,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, in
         float m_wy = 1.0f, m_denom = 1.0f;
         {
             // gi: this graph's number in the workspace (= g unless the launch gathers from a cached set)
-            m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][a.ws_graphs + gi];
+            m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
             if (!hf.train) {
                 m_y = 0;
             } else if (hf.task == DRGNN_TASK_REG) {
@@ -924,12 +924,12 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, in
                 // CrossEntropyLoss(weight): mean over the sum of the targets' weights
 #ifdef DRGNN_EMU
                 m_denom = 0.0f;
-                for (int q = 0; q < hf.B; ++q) m_denom += hf.class_w ? hf.class_w[hf.y_cls[a.gather_ids ? a.gather_ids[q] : q]] : 1.0f;
+                for (int q = 0; q < hf.B; ++q) m_denom += hf.class_w ? hf.class_w[hf.y_cls[GATHER ? a.gather_ids[q] : q]] : 1.0f;
 #else
                 m_denom = (float)hf.B;
                 if (hf.class_w && threadIdx.x < 64) {
                     float part_sum = 0.0f;
-                    for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w[hf.y_cls[a.gather_ids ? a.gather_ids[q] : q]];
+                    for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w[hf.y_cls[GATHER ? a.gather_ids[q] : q]];
                     m_denom = lanes64_sum(part_sum);
                 }
 #endif

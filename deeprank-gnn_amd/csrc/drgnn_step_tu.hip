@@ -1,0 +1,10 @@
+// drgnn_step_tu.hip -- explicit instantiations of the fused step kernel for ONE kind of net (-DDRGNN_TU_KIND=0|1|2):
+// five feature widths x {per-mini-batch workspace, cached whole-set workspace}.  See drgnn_kernels.h.
+#include "drgnn_kernels.h"
+#ifndef DRGNN_TU_KIND
+#error "compile with -DDRGNN_TU_KIND=<kind>"
+#endif
+#define DRGNN_STEP_INST(K, XF)                                              \
+    template __global__ void k_step_co_topo<K, XF, false>(StepCoLaunch);    \
+    template __global__ void k_step_co_topo<K, XF, true>(StepCoLaunch);
+DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
