@@ -4,9 +4,11 @@ without torch_geometric / h5py: same constructor vocabulary, ``train`` / ``eval`
 (NeuralNet.py:775-790), with the per-batch body executed by ``FusedTrainer`` (native step).
 
 ``PreCluster`` (MCL) runs on the device when the graphs do not carry
-``clustering/<method>/depth_{0,1}`` yet.  What is NOT reproduced: Louvain clustering,
-``Metrics`` / plots, and the HDF5 epoch export (written as ``.npz`` with the same group names
-because h5py is absent on the target image).
+``clustering/<method>/depth_{0,1}`` yet.  ``database`` / ``database_eval`` / ``database_test`` take one path or a
+list of paths (.drgs native container, .npz, or .hdf5 where h5py exists).  The per-epoch export keeps the reference's
+group / dataset names (``epoch_%04d/{train,eval,test}/{mol,outputs,targets,raw_outputs}`` + the attributes task /
+target / batch_size, NeuralNet.py:827-872) in the native container; ``tools/native_to_hdf5.py`` turns it into the HDF5
+file the reference writes.  What is NOT reproduced: Louvain clustering, ``Metrics`` beyond the accuracy, plots.
 """
 import os
 import time
@@ -67,11 +69,10 @@ class NeuralNet(object):
                              ('transform_sigmoid', 'transform_sigmoid')):
                 setattr(self, dst, state[src])
             opt_state, model_state = state['optimizer'], state['model']
-        if self.transform_sigmoid:
-            raise NotImplementedError("transform_sigmoid is not on the native path")
-
+        self.pretrained = pretrained_model is not None
         self.dataset = GraphDataSet(database, node_feature=self.node_feature, edge_feature=self.edge_feature,
-                                    target=self.target, clustering_method=self.cluster_nodes or 'mcl', index=self.index)
+                                    target=self.target, clustering_method=self.cluster_nodes or 'mcl',
+                                    index=None if self.pretrained else self.index)     # load_pretrained_model: no index
         first = self.dataset[0]
         if getattr(first, "cluster0", None) is None:
             # the reference runs PreCluster at every construction (NeuralNet.py:139-143); here only
@@ -105,13 +106,18 @@ class NeuralNet(object):
             weights = w / w.sum()
         elif self.task == 'class' and isinstance(self.class_weights, (list, tuple)):
             weights = torch.tensor(self.class_weights, dtype=torch.float32)
-        self.trainer = FusedTrainer(self.model, lr=self.lr, task=self.task, class_weights=weights, api=_api)
+        self.trainer = FusedTrainer(self.model, lr=self.lr, task=self.task, class_weights=weights, api=_api,
+                                    transform_sigmoid=bool(self.transform_sigmoid))
         if opt_state is not None:
             self.trainer.load_optimizer_state_dict(opt_state)
         self.train_loss, self.valid_loss, self.train_acc, self.valid_acc = [], [], [], []
         self.data = {}
         self._resident_sets = {}
         self.native_epoch = True      # False: step mini-batch by mini-batch from Python (same results)
+        # declared mode: per-graph topology built once when a set is uploaded and read in place by every step (no
+        # builder work per mini-batch); False rebuilds every mini-batch's topology as the reference does per forward
+        self.cached_topology = False
+        self.exported = []            # (epoch, file) of the epoch data written so far
 
     # ------------------------------------------------------------------------------
     def _resident(self, dataset):
@@ -169,13 +175,23 @@ class NeuralNet(object):
                 store['targets'] += y.tolist()
         return store
 
-    def _accuracy(self, store):
+    def _accuracy(self, store, threshold=None):
+        """Metrics(...).accuracy of the reference (Metrics.py:10-31,113-120,170): predictions and targets are made
+        binary at ``threshold`` -- in class-INDEX space for classification (NeuralNet.get_metrics, NeuralNet.py:548-549)
+        -- '>' for fnat / bin_class, '<' for the others, and the accuracy is the fraction on which the two agree."""
         if not store['targets']:
             return None
+        threshold = self.threshold if threshold is None else threshold
         if self.task == 'class':
-            return float(np.mean(np.asarray(store['outputs']) == np.asarray(store['targets'])))
-        t, o = np.asarray(store['targets']), np.asarray(store['outputs'])
-        return float(np.mean((t < self.threshold) == (o < self.threshold)))
+            # (test()'s default threshold 4 is a capri class; other class sets fall back to the trainer's threshold)
+            thr = self.classes_to_idx[threshold if threshold in self.classes_to_idx else self.threshold]
+            o = np.asarray([self.classes_to_idx[v] for v in store['outputs']])
+            t = np.asarray([self.classes_to_idx[v] for v in store['targets']])
+        else:
+            thr, o, t = threshold, np.asarray(store['outputs']), np.asarray(store['targets'])
+        if self.target in ('fnat', 'bin_class'):
+            return float(np.mean((o > thr) == (t > thr)))
+        return float(np.mean((o < thr) == (t < thr)))
 
     @staticmethod
     def _new_store():
@@ -192,7 +208,7 @@ class NeuralNet(object):
             order = [int(i) for i in self.train_index]
             if self.shuffle:
                 order = [order[i] for i in torch.randperm(len(order)).tolist()]
-            done = self.trainer.train_epoch(rs, order, self.batch_size)
+            done = self.trainer.train_epoch(rs, order, self.batch_size, cached=self.cached_topology)
             if done is not None:
                 losses, pred = done
                 store['_pred'].append(pred)
@@ -230,13 +246,13 @@ class NeuralNet(object):
 
     def eval(self, dataset=None, indices=None):
         """Forward only (NeuralNet.py:414-475); returns (loss_sum, store)."""
-        dataset = dataset or self.dataset
+        dataset = self.dataset if dataset is None else dataset
         indices = self.valid_index if indices is None else indices
         store = self._new_store()
         order = [int(i) for i in indices]
         if self.native_epoch and order:
             rs = self._resident(dataset)
-            pred = self.trainer.predict_epoch(rs, order, self.batch_size)
+            pred = self.trainer.predict_epoch(rs, order, self.batch_size, cached=self.cached_topology)
             if pred is not None:
                 store['_pred'].append(pred)
                 store['mol'] += [rs.mols[i] for i in order]
@@ -265,52 +281,94 @@ class NeuralNet(object):
             batch, topo = nxt, nxt_topo
         return float(total), self._finish(store)
 
-    def train(self, nepoch=1, validate=False, save_model='last', hdf5='train_data.npz', save_epoch='intermediate',
+    def train(self, nepoch=1, validate=False, save_model='last', hdf5='train_data.drgs', save_epoch='intermediate',
               save_every=5):
-        best = None
+        """NeuralNet.train (NeuralNet.py:265-355): same arguments; epoch data is exported for the last epoch and, with
+        ``save_epoch='all'`` / ``'intermediate'``, for every / every ``save_every``-th epoch; the other epochs' outputs are
+        dropped as soon as the epoch is over.  'best' checkpoints carry the reference's file name."""
+        self.nepoch = nepoch
+        fname = self.update_name(hdf5, self.outdir) if hdf5 else None
+        self.data, pending = {}, {}
         for epoch in range(1, nepoch + 1):
             t0 = time.time()
+            self.data = {}
             loss, store = self._epoch(epoch)
             self.train_loss.append(loss)
             self.train_acc.append(self._accuracy(store))
-            self.data['epoch_%04d/train' % epoch] = store
+            self.data['train'] = store
             line = "Epoch [%04d] : train loss %e" % (epoch, loss)
+            best_of = self.train_loss
             if validate and (self.valid_index or self.eval_dataset is not None):
-                ds = self.eval_dataset or self.dataset
+                ds = self.dataset if self.eval_dataset is None else self.eval_dataset
                 idx = range(len(ds)) if self.eval_dataset is not None else self.valid_index
                 vloss, vstore = self.eval(ds, list(idx))
                 self.valid_loss.append(vloss)
                 self.valid_acc.append(self._accuracy(vstore))
-                self.data['epoch_%04d/eval' % epoch] = vstore
+                self.data['eval'] = vstore
                 line += " | valid loss %e" % vloss
-                if save_model == 'best' and (best is None or vloss < best):
-                    best = vloss
-                    self.save_model(os.path.join(self.outdir, 'best_model.pth.tar'))
+                best_of = self.valid_loss
+            if save_model == 'best' and min(best_of) == best_of[-1]:
+                self.save_model(os.path.join(self.outdir, 't{}_y{}_b{}_e{}_lr{}_{}.pth.tar'.format(
+                    self.task, self.target, str(self.batch_size), str(nepoch), str(self.lr), str(epoch))))
             print(line + " | time %.3f s" % (time.time() - t0))
+            if (save_epoch == 'all') or (epoch == nepoch) or (save_epoch == 'intermediate' and epoch % save_every == 0):
+                pending['epoch_%04d' % epoch] = self.data
         if save_model == 'last':
-            self.save_model(os.path.join(self.outdir, 'last_model.pth.tar'))
-        if hdf5:
-            self.export(os.path.join(self.outdir, hdf5))
+            self.save_model(os.path.join(self.outdir, 't{}_y{}_b{}_e{}_lr{}.pth.tar'.format(
+                self.task, self.target, str(self.batch_size), str(nepoch), str(self.lr))))
+        if fname:
+            self.export(fname, pending)
+        return self
 
-    def test(self, database_test=None, threshold=4, hdf5='test_data.npz'):
+    def test(self, database_test=None, threshold=4, hdf5='test_data.drgs'):
+        # (without database_test the loaded dataset is tested, pretrained or not)
         ds = self.dataset if database_test is None else GraphDataSet(
             database_test, node_feature=self.node_feature, edge_feature=self.edge_feature, target=self.target,
             clustering_method=self.cluster_nodes or 'mcl')
+        if database_test is not None and getattr(ds[0], "cluster0", None) is None:
+            from .clustering import PreCluster
+            PreCluster(ds, method=self.cluster_nodes or 'mcl', api=self._api, device=self.device)
         loss, store = self.eval(ds, list(range(len(ds))))
-        self.data['epoch_0000/test'] = store
-        self.test_loss, self.test_acc = loss, self._accuracy(store)
+        self.data = {'test': store}
+        self.test_loss = loss
+        self.test_acc = self._accuracy(store, threshold) if store['targets'] else None
         if hdf5:
-            self.export(os.path.join(self.outdir, hdf5))
+            self.export(self.update_name(hdf5, self.outdir), {'epoch_0000': self.data})
         return store
 
-    def export(self, fname):
-        """Per-epoch outputs/targets/mol, same group names as the reference's HDF5 export
-        (NeuralNet.py:827-872; tests/data/train_ref/train_data.hdf5), written as .npz."""
+    @staticmethod
+    def update_name(hdf5, outdir):
+        """NeuralNet.update_name (NeuralNet.py:633-656): never overwrite an existing export, number the new one."""
+        fname = os.path.join(outdir, hdf5)
+        stem, ext = os.path.splitext(hdf5)
+        count = 0
+        while os.path.exists(fname):
+            count += 1
+            fname = os.path.join(outdir, '{}_{:03d}{}'.format(stem, count, ext))
+        return fname
+
+    def export(self, fname, epochs=None):
+        """_export_epoch_hdf5 (NeuralNet.py:827-872): groups ``epoch_%04d/<pass>/{mol,outputs,targets,raw_outputs}`` and
+        the group attributes task / target / batch_size -- as a native container whose tree mirror
+        ``tools/native_to_hdf5.py`` turns into that HDF5 file (``.npz``: flat keys, no attributes)."""
+        epochs = {'epoch_0000': self.data} if epochs is None else epochs
         flat = {}
-        for grp, store in self.data.items():
-            for k, v in store.items():
-                flat["%s/%s" % (grp, k)] = np.asarray(v)
-        np.savez_compressed(fname, **flat)
+        for grp, passes in epochs.items():
+            for pass_type, store in passes.items():
+                for k, v in store.items():
+                    if k.startswith('_'):
+                        continue
+                    flat["%s/%s/%s" % (grp, pass_type, k)] = np.asarray(v, dtype='S') if k == 'mol' else np.asarray(v)
+        if str(fname).endswith('.npz'):
+            np.savez_compressed(fname, **flat)
+        else:
+            from .container import write_container
+            attrs = {grp: {'task': self.task, 'target': self.target, 'batch_size': int(self.batch_size)} for grp in epochs}
+            write_container(fname, {"tree/" + k: v for k, v in flat.items()},
+                            meta={"kind": "tree", "mols": list(epochs), "attrs": attrs,
+                                  "schema": "deeprank_gnn NeuralNet._export_epoch_hdf5 (reference NeuralNet.py:827-872)"})
+        self.exported.append(fname)
+        return fname
 
     def save_model(self, filename='model.pth.tar'):
         state = {'model': {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},

@@ -88,17 +88,17 @@ def precluster(batch, api=None):
 def PreCluster(dataset, method='mcl', batch_size=64, device=None, api=None):
     """Pre-clusters the nodes of every graph of a ``GraphDataSet`` and attaches the labels to its
     store as ``clustering/<method>/depth_0`` and ``depth_1`` (reference DataSet.py:45-88, which
-    writes them into the HDF5).  Call ``dataset.store.save_npz(path)`` to persist."""
+    writes them into the HDF5).  Call ``store.save_native(path)`` / ``save_npz(path)`` on ``dataset.stores`` to persist."""
     from .data import Batch
     if method.lower() != 'mcl':
         raise ValueError("only 'mcl' is available on the device (louvain is randomised)")
     api = api or _lib.get()
     if device is None:
         device = 'cuda' if api is _lib._API or torch.cuda.is_available() else 'cpu'
-    mols = list(dataset.mols)
-    for lo in range(0, len(mols), batch_size):
-        chunk = mols[lo:lo + batch_size]
-        graphs = [dataset.load_one_graph(m) for m in chunk]
+    where = [dataset.store_of(i) for i in range(len(dataset))]       # (store, mol) per entry: several files allowed
+    for lo in range(0, len(where), batch_size):
+        chunk = where[lo:lo + batch_size]
+        graphs = [dataset.load_one_graph(m, st) for st, m in chunk]
         for g in graphs:
             g.cluster0 = None
             g.cluster1 = None
@@ -106,12 +106,12 @@ def PreCluster(dataset, method='mcl', batch_size=64, device=None, api=None):
         d0, d1 = precluster(batch, api=api)
         d0, d1 = d0.cpu().numpy(), d1.cpu().numpy()
         n_off = c_off = 0
-        for m, g in zip(chunk, graphs):
+        for (st, m), g in zip(chunk, graphs):
             n = g.num_nodes
             lab0 = d0[n_off:n_off + n]
             c = int(len(set(lab0.tolist())))
-            dataset.store.set(m, "clustering/%s/depth_0" % method.lower(), lab0.copy())
-            dataset.store.set(m, "clustering/%s/depth_1" % method.lower(), d1[c_off:c_off + c].copy())
+            st.set(m, "clustering/%s/depth_0" % method.lower(), lab0.copy())
+            st.set(m, "clustering/%s/depth_1" % method.lower(), d1[c_off:c_off + c].copy())
             n_off += n
             c_off += c
     return dataset

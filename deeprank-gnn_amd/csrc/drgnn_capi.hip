@@ -503,7 +503,7 @@ int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_de
         return DRGNN_E_WIDTH;
     HeadFused hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
-    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = -1; hf.train = 1;
+    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = -1; hf.train = 1; hf.sigmoid = hd->transform_sigmoid;
     hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
     hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
@@ -577,7 +577,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     a.xchg = (unsigned long long*)xchg; a.step2 = step2;
     HeadFused& hf = a.hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
-    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0; hf.train = hd->train ? 1 : 0;
+    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0; hf.train = hd->train ? 1 : 0; hf.sigmoid = hd->transform_sigmoid;
     hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
     hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
@@ -745,7 +745,7 @@ int drgnn_head_step(const drgnn_head_desc* hd, const float* readout, const void*
     a.step = step; a.pred = pred; a.grad_readout = hd->train ? grad_readout : nullptr;
     a.partials = partials;
     a.B = (int)n_graphs; a.R = hd->R; a.H = hd->H; a.O = hd->O;
-    a.task = hd->task; a.train = hd->train; a.p_drop = hd->p_drop; a.seed = hd->seed;
+    a.task = hd->task; a.train = hd->train; a.p_drop = hd->p_drop; a.seed = hd->seed; a.sigmoid = hd->transform_sigmoid;
     a.T = head_tile(n_graphs);
     const int blocks = (int)((n_graphs + a.T - 1) / a.T);
     const int64_t lds = 4 * head_lds_words(hd->R, hd->H, hd->O, a.T);

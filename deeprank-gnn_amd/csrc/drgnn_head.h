@@ -38,6 +38,7 @@ struct HeadArgs {
     int B, R, H, O, T;        // T = graphs per workgroup
     int task;
     int train;                // apply dropout, compute gradients
+    int sigmoid;              // regression: pred = sigmoid(output) before the loss
     float p_drop;
     uint32_t seed;
 };
@@ -117,6 +118,7 @@ DEV void head_block(const HeadArgs& a, int blk, float* lds) {
         const int g = fastdiv(dO, go), o = fastmod(dO, go, g);
         float acc = b2s[o];
         for (int q = 0; q < 8; ++q) acc += tmp[go * 8 + q];
+        if (a.sigmoid && a.task == DRGNN_TASK_REG) acc = drgnn_sigmoid(acc);
         outs[g * DRGNN_MAX_OUT + o] = acc;
         if (g < G) a.pred[(long)(g0 + g) * O + o] = acc;
     }
@@ -131,9 +133,10 @@ DEV void head_block(const HeadArgs& a, int blk, float* lds) {
                 // MSELoss()(pred.reshape(-1), y): mean over B*O elements (O == 1 in the reference)
                 const float inv = 1.0f / (float)(a.B * O);
                 for (int o = 0; o < O; ++o) {
-                    const float d = outs[g * DRGNN_MAX_OUT + o] - a.y_reg[g0 + g];
+                    const float ov = outs[g * DRGNN_MAX_OUT + o];
+                    const float d = ov - a.y_reg[g0 + g];
                     loss += d * d * inv;
-                    douts[g * DRGNN_MAX_OUT + o] = 2.0f * d * inv;
+                    douts[g * DRGNN_MAX_OUT + o] = 2.0f * d * inv * (a.sigmoid ? ov * (1.0f - ov) : 1.0f);
                 }
                 wsum = 1.0f;
             } else {

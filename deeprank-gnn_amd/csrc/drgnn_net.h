@@ -154,7 +154,9 @@ struct HeadFused {
     float* partials;             // [B][head_partial_floats]
     int stage;                   // 1: the launch reserved LDS for W1/b1/W2/b2/readout row
     int train;                   // fused step only: 0 = inference (predictions, no loss / backward / slabs)
+    int sigmoid;                 // regression: pred = sigmoid(output) before the loss (NeuralNet.py:625)
 };
+DEV float drgnn_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 HD int64_t head_stage_words(int R, int H, int O) { return (int64_t)H * (R + 1) + H + (int64_t)O * H + O + R + 16; }
 
 // scratch `gp`: >= 1024 + H + R + 2*DRGNN_MAX_OUT floats; dr_out: this branch's 32 columns
@@ -208,9 +210,11 @@ DEV void head_graph(const HeadFused& hf, int g, int br, float* gp, float* dr_out
     }
     BARRIER();
     FOR_TID(i, 1) {
+        const bool sig = hf.sigmoid && hf.task == DRGNN_TASK_REG;
         for (int o = 0; o < O; ++o) {
             float acc = b2[o];
             for (int q = 0; q < 16; ++q) acc += tmp[o * 16 + q];
+            if (sig) acc = drgnn_sigmoid(acc);
             outs[o] = acc;
             if (br == 0) hf.pred[(long)g * O + o] = acc;
         }
@@ -220,7 +224,7 @@ DEV void head_graph(const HeadFused& hf, int g, int br, float* gp, float* dr_out
             for (int o = 0; o < O; ++o) {
                 const float d = outs[o] - hf.y_reg[g];
                 loss += d * d * inv;
-                douts[o] = 2.0f * d * inv;
+                douts[o] = 2.0f * d * inv * (sig ? outs[o] * (1.0f - outs[o]) : 1.0f);
             }
         } else {
             float denom = 0.0f;

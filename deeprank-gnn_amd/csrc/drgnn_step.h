@@ -672,11 +672,13 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
             FOR_TID(o, O) {
                 float acc = b2[o];
                 for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
+                if (hf.sigmoid && hf.task == DRGNN_TASK_REG) acc = drgnn_sigmoid(acc);
                 hf.pred[(long)g * O + o] = acc;
             }
         }
         return;
     }
+    const bool sig = hf.sigmoid && hf.task == DRGNN_TASK_REG;
     const float denom = misc[STEP_M_DENOM], wy = misc[STEP_M_WY];
 #ifdef DRGNN_EMU
     float outs[DRGNN_MAX_OUT], douts[DRGNN_MAX_OUT];
@@ -684,6 +686,7 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
         float acc = 0.0f;
         for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
         outs[o] = acc + b2[o];
+        if (sig) outs[o] = drgnn_sigmoid(outs[o]);
     }
     float loss = 0.0f, wsum = 1.0f;
     if (hf.task == DRGNN_TASK_REG) {
@@ -691,7 +694,7 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
         for (int o = 0; o < O; ++o) {
             const float d = outs[o] - misc[STEP_M_Y];
             loss += d * d * inv;
-            douts[o] = 2.0f * d * inv;
+            douts[o] = 2.0f * d * inv * (sig ? outs[o] * (1.0f - outs[o]) : 1.0f);
         }
     } else {
         int yc; memcpy(&yc, &misc[STEP_M_Y], 4);
@@ -731,12 +734,13 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
         acc = lanes64_sum(acc) + b2[o];
         if (lane == o) my_out = acc;
     }
+    if (sig) my_out = drgnn_sigmoid(my_out);
     float my_dout = 0.0f, loss, wsum = 1.0f;
     if (hf.task == DRGNN_TASK_REG) {
         const float inv = 1.0f / (float)(hf.B * O);
         const float d = my_out - misc[STEP_M_Y];
         loss = lanes64_sum(lane < O ? d * d * inv : 0.0f);
-        my_dout = lane < O ? 2.0f * d * inv : 0.0f;
+        my_dout = lane < O ? 2.0f * d * inv * (sig ? my_out * (1.0f - my_out) : 1.0f) : 0.0f;
     } else {
         const int yc = __builtin_amdgcn_readfirstlane(__float_as_int(misc[STEP_M_Y]));
         const float mx = lanes64_max(lane < O ? my_out : DRGNN_NEG_INF);

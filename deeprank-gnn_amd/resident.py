@@ -144,6 +144,71 @@ class ResidentGraphSet(object):
             cache = self._topo_cache[key] = TopologyCache(self, key)
         return cache
 
+    # -- native container: the uploaded image, optionally with the cached topology ------------------------------
+    def save_native(self, path, with_topology=True, need_weights=None):
+        """Write the set as ONE native container (container.py): sections ``set/*`` = the concatenated arrays exactly as
+        they are uploaded, and (``with_topology``) ``topo/*`` = the cached per-graph topology (int32 CSR / CSC of both
+        levels, consecutive clusters, member lists, pooled CSR; f32 edge weights when the set has edge attributes), so a
+        later run uploads everything with a few copies: no per-graph parsing, no topology build at all."""
+        from .container import write_container
+        sec = {"set/node_ptr": self.node_ptr, "set/edge_ptr": self.edge_ptr, "set/c1_ptr": self.c1_ptr,
+               "set/x": self.x.cpu().numpy(), "set/edge_index": self.edge_index.cpu().numpy()}
+        for name in ("edge_attr", "cluster0", "cluster1", "y"):
+            t = getattr(self, name)
+            if t is not None:
+                sec["set/" + name] = t.cpu().numpy()
+        meta = {"kind": "resident_set", "mols": ["" if m is None else str(m) for m in self.mols],
+                "n_graphs": len(self), "n_feat": self.n_feat, "abi": 1}
+        if with_topology and self.has_c0 and self.has_c1:
+            want_w = self.has_attr if need_weights is None else bool(need_weights and self.has_attr)
+            cache = self.topology_cache(need_weights=want_w)
+            st = cache.topo.status()
+            if st[0]:
+                raise _lib.DrgnnError("the set's topology is flagged malformed (status %d, graph %d): not saved" % (st[0], st[1]))
+            sec["topo/ws_i32"] = cache.topo.ws_i32.cpu().numpy()
+            if cache.topo.ws_f32 is not None:
+                sec["topo/ws_f32"] = cache.topo.ws_f32.cpu().numpy()
+            meta["topology"] = {"n_nodes": cache.topo.n_nodes, "n_edges": cache.topo.n_edges, "n_graphs": cache.topo.n_graphs,
+                                "with_weights": cache.topo.ws_f32 is not None,
+                                "off_i32": [int(v) for v in cache.topo.off_i32], "off_f32": [int(v) for v in cache.topo.off_f32],
+                                "arrays_i32": sorted(_lib.TI, key=_lib.TI.get), "arrays_f32": sorted(_lib.TF, key=_lib.TF.get)}
+        write_container(path, sec, meta=meta)
+
+    @classmethod
+    def load_native(cls, path, device, api=None):
+        """Inverse of ``save_native``.  A stored topology is adopted as the set's cache when its layout is the one this
+        library lays out for the same shape (else it is ignored and rebuilt on demand)."""
+        from .container import read_container
+        from .topology import Topology
+        meta, a = read_container(path)
+        if meta.get("kind") != "resident_set":
+            raise ValueError("%s holds %r, not a resident set" % (path, meta.get("kind")))
+        self = cls.__new__(cls)
+        self._open(device, api)
+
+        def opt(name):
+            return torch.from_numpy(a["set/" + name]) if "set/" + name in a else None
+        self._adopt(mols=[(m or None) for m in meta["mols"]], n_nodes=np.diff(a["set/node_ptr"]),
+                    n_edges=np.diff(a["set/edge_ptr"]), n_c1=np.diff(a["set/c1_ptr"]), x=torch.from_numpy(a["set/x"]),
+                    edge_index=torch.from_numpy(a["set/edge_index"]), edge_attr=opt("edge_attr"),
+                    cluster0=opt("cluster0"), cluster1=opt("cluster1"), y=opt("y"))
+        t = meta.get("topology")
+        if t is not None and "topo/ws_i32" in a:
+            topo = Topology(self.api, t["n_nodes"], t["n_edges"], t["n_graphs"], self.device, t["with_weights"])
+            same = ([int(v) for v in topo.off_i32] == t["off_i32"] and [int(v) for v in topo.off_f32] == t["off_f32"]
+                    and t["n_graphs"] == len(self) and topo.ws_i32.numel() == a["topo/ws_i32"].size)
+            if same:
+                topo.ws_i32.copy_(torch.from_numpy(a["topo/ws_i32"]))
+                if topo.ws_f32 is not None:
+                    topo.ws_f32.copy_(torch.from_numpy(a["topo/ws_f32"]))
+                topo.max_nodes, topo.max_edges = int(self.n_nodes.max()), int(self.n_edges.max())
+                topo.max_c0, topo.has_level1, topo._inputs = int(self.n_c1.max()), True, None
+                self._topo_cache = {bool(t["with_weights"]): TopologyCache(self, bool(t["with_weights"]), topo=topo)}
+                if t["with_weights"]:
+                    # a weighted workspace serves the nets that ignore the weights as well
+                    self._topo_cache[False] = self._topo_cache[True]
+        return self
+
     def set_targets(self, y):
         """Replace the targets (e.g. class labels mapped to class indices); ``y``: [G] tensor."""
         y = y.reshape(-1)

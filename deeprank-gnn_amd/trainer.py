@@ -41,12 +41,18 @@ def _net_layout(net):
 
 class FusedTrainer(object):
     def __init__(self, net, lr=0.01, task="reg", class_weights=None, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, seed=0, api=None):
+                 weight_decay=0.0, seed=None, api=None, transform_sigmoid=False):
         self.net = net
+        self.transform_sigmoid = bool(transform_sigmoid)      # regression: sigmoid on the output before the loss
         self.api = api or _lib.get()
         self.kind, self.n_branch, self.convs = _net_layout(net)
         self.task = _lib.TASK_REG if task == "reg" else _lib.TASK_CLASS
         self.lr, self.betas, self.eps, self.weight_decay = float(lr), betas, float(eps), float(weight_decay)
+        if seed is None:
+            # dropout stream: follows torch.manual_seed (like the reference's F.dropout) and differs per rank, so that
+            # data-parallel ranks do not draw the same masks for their different graphs
+            rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+            seed = (torch.initial_seed() ^ (rank * 0x9E3779B1)) & 0xFFFFFFFF
         self.seed = int(seed) & 0xFFFFFFFF
         params = list(net.parameters())
         dev = params[0].device
@@ -96,6 +102,7 @@ class FusedTrainer(object):
         hd.R, hd.H, hd.O, hd.task, hd.train = self.R, self.H, self.O, self.task, int(train)
         hd.p_drop = float(getattr(self.net, "dropout", 0.0)) if train else 0.0
         hd.seed = self.seed
+        hd.transform_sigmoid = int(self.transform_sigmoid and self.task == _lib.TASK_REG)
         n = self.net
         hd.w1, hd.b1 = n.fc1.weight.data_ptr(), n.fc1.bias.data_ptr()
         hd.w2, hd.b2 = n.fc2.weight.data_ptr(), n.fc2.bias.data_ptr()

@@ -270,7 +270,8 @@ typedef struct drgnn_head_desc {
     int32_t train;            /* 1: dropout + loss + gradients; 0: predictions only           */
     float   p_drop;           /* dropout probability (GINet 0.4, others 0)                    */
     uint32_t seed;            /* dropout stream seed (mixed with the device step counter)     */
-    int32_t reserved;
+    int32_t transform_sigmoid; /* regression only: pred = sigmoid(fc2 output) before the loss (reference
+                                  NeuralNet.format_output, NeuralNet.py:616-631); predictions are reported transformed */
     const float* w1; const float* b1; const float* w2; const float* b2;
     const float* class_w;     /* [O] class weights or NULL                                    */
 } drgnn_head_desc;

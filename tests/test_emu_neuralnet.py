@@ -45,8 +45,21 @@ def test_train_save_reload(Net, task, target, tmp_path):
     b = nn.test(hdf5=None)
     np.testing.assert_allclose(a['raw_outputs'], b['raw_outputs'], rtol=1e-6)
     assert a['mol'] == b['mol'] and len(a['mol']) == 10
-    exp = np.load(os.path.join(str(tmp_path), 'train_data.npz'))
-    assert 'epoch_0003/train/outputs' in exp.files and 'epoch_0003/eval/targets' in exp.files
+    # the epoch export: the reference's group / dataset names and group attributes (tests/data/train_ref/train_data.hdf5,
+    # layout recorded in tests/golden/train_ref_layout.json), in the native container
+    import json
+    from deeprank_gnn_amd.container import read_container
+    meta, exp = read_container(os.path.join(str(tmp_path), 'train_data.drgs'))
+    layout = json.load(open(os.path.join(GOLDEN, 'train_ref_layout.json')))
+    (ref_epoch,) = [g for g in layout['groups'] if '/' not in g]          # 'epoch_0005' in the reference's file
+    for name, d in layout['datasets'].items():
+        mine = 'tree/' + name.replace(ref_epoch, 'epoch_0003')
+        assert mine in exp, mine
+        assert exp[mine].ndim == d['ndim'] and (exp[mine].dtype.kind == 'S') == (d['kind'] == 'S'), mine
+    assert sorted(meta['attrs']['epoch_0003']) == layout['groups'][ref_epoch] == ['batch_size', 'target', 'task']
+    assert sorted(exp['tree/epoch_0003/train/mol'].astype(str)) == sorted(nn.dataset.mols[i] for i in nn.train_index)
+    assert 'tree/epoch_0003/train/raw_outputs' in exp            # the current reference code also writes these
+    assert nn.update_name('train_data.drgs', str(tmp_path)).endswith('train_data_001.drgs')
 
 
 def test_needs_gpu_without_emulation():
@@ -119,5 +132,5 @@ def test_resident_batches_train_like_host_collated_batches(tmp_path):
             outs += twin.trainer.last_pred.reshape(-1).tolist()
         losses.append(run)
     np.testing.assert_allclose(nn.train_loss, losses, rtol=1e-6)
-    np.testing.assert_allclose(nn.data['epoch_0002/train']['outputs'], outs, rtol=1e-6)
-    assert nn.data['epoch_0002/train']['mol'] == [twin.dataset.mols[i] for i in twin.train_index]
+    np.testing.assert_allclose(nn.data['train']['outputs'], outs, rtol=1e-6)
+    assert nn.data['train']['mol'] == [twin.dataset.mols[i] for i in twin.train_index]
