@@ -57,6 +57,37 @@ def test_three_steps_match_torch_adam(Net, task):
     assert set(net.state_dict()) == set(ref.state_dict())
 
 
+@pytest.mark.parametrize("Net,fused", [(GINet, True), (sGAT, True), (FoutNet, False)])
+def test_transform_sigmoid_matches_torch(Net, fused):
+    """transform_sigmoid (reference NeuralNet.format_output, NeuralNet.py:616-631): pred = sigmoid(out.reshape(-1)) goes
+    into the MSE loss (targets in [0, 1], e.g. fnat) and is what the trainer reports -- fused step kernel and the
+    forward / backward-with-head launch pair."""
+    torch.manual_seed(5)
+    batch = syn4_batch()
+    batch.y = torch.tensor([0.1, 0.8, 0.45, 0.0])
+    ref = Net(12, 1, 1)
+    if hasattr(ref, "dropout"):
+        ref.dropout = 0.0
+    net = copy.deepcopy(ref)
+    opt = torch.optim.Adam(ref.parameters(), lr=0.01)
+    tr = FusedTrainer(net, lr=0.01, task="reg", api=emu(), transform_sigmoid=True)
+    tr.fused_step = fused
+    for it in range(3):
+        opt.zero_grad()
+        out = torch.sigmoid(ref(batch, topo=Topology.from_batch(batch, api=emu())).reshape(-1))
+        loss = F.mse_loss(out, batch.y)
+        loss.backward()
+        opt.step()
+        got = tr.train_step(batch)
+        np.testing.assert_allclose(float(got), float(loss), rtol=2e-5)
+        np.testing.assert_allclose(tr.last_pred.reshape(-1).numpy(), out.detach().numpy(), rtol=1e-4, atol=1e-6)
+        for (name, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+            np.testing.assert_allclose(p.detach().numpy(), q.detach().numpy(), rtol=1e-5, atol=2e-6, err_msg=name)
+    ref.eval()
+    want = torch.sigmoid(ref(batch, topo=Topology.from_batch(batch, api=emu()))).detach().numpy()
+    np.testing.assert_allclose(tr.predict(batch).numpy(), want, rtol=1e-4, atol=1e-6)
+
+
 def test_dropout_statistics_and_reproducibility():
     """p = 0.4 (GINet default): kept fraction ~0.6, kept activations scaled by 1/0.6,
     the same (seed, step) reproduces the same mask, a new step draws a new one."""

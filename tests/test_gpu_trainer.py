@@ -163,3 +163,56 @@ def test_fused_step_full_size_properties():
     for g in (0, 17, 63):
         single = synth.make_batch(g, 1).to(dev)
         np.testing.assert_array_equal(tr.predict(single).cpu().numpy()[0], full[g])
+
+
+@pytest.mark.parametrize("net_name", ["GINet", "sGAT"])
+def test_transform_sigmoid_on_the_device(net_name):
+    """transform_sigmoid (reference NeuralNet.py:616-631) in the fused step's head: 3 steps vs the oracle trained on
+    sigmoid(pred) with torch Adam."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    from test_gpu_parity import build
+    dev = torch.device("cuda:0")
+    batch_cpu = synth.make_batch(0, 12, n_nodes=90, n_pairs=200)
+    batch_cpu.y = torch.rand(12, generator=torch.Generator().manual_seed(3))
+    params = cpu_ref.init_params(net_name, 32, 1, 1, seed=4)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    opt = torch.optim.Adam(list(leaves.values()), lr=0.01)
+    net = build(net_name, params, 1)
+    tr = FusedTrainer(net, lr=0.01, task="reg", transform_sigmoid=True)
+    batch = batch_cpu.clone().to(dev)
+    for it in range(3):
+        opt.zero_grad()
+        pred = torch.sigmoid(cpu_ref.FORWARD[net_name](leaves, batch_cpu).reshape(-1))
+        loss = F.mse_loss(pred, batch_cpu.y)
+        loss.backward()
+        opt.step()
+        got = tr.train_step(batch)
+        np.testing.assert_allclose(float(got), float(loss), rtol=1e-4)
+        np.testing.assert_allclose(tr.last_pred.reshape(-1).cpu().numpy(), pred.detach().numpy(), rtol=1e-4, atol=1e-5)
+    sd = net.state_dict()
+    for k, v in leaves.items():
+        np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_resident_set_native_image_on_the_device(tmp_path):
+    """save_native (set + cached topology) -> load_native on the MI355X: training out of the stored topology gives the
+    bits of rebuilding every mini-batch's topology."""
+    import copy
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    graphs = [synth.make_graph(i, n_nodes=150, n_pairs=330) for i in range(40)]
+    rs = ResidentGraphSet(graphs, "cuda")
+    path = str(tmp_path / "set.drgs")
+    rs.save_native(path)
+    back = ResidentGraphSet.load_native(path, "cuda")
+    assert True in back._topo_cache
+    torch.manual_seed(1)
+    net = GINet(32, 1, 1).to("cuda")
+    ta, tb = FusedTrainer(net, lr=0.01, seed=3), FusedTrainer(copy.deepcopy(net), lr=0.01, seed=3)
+    order = np.random.default_rng(0).permutation(40).tolist()
+    la, pa = ta.train_epoch(rs, order, 16)
+    lb, pb = tb.train_epoch(back, order, 16, cached=True)
+    assert torch.equal(la, lb) and torch.equal(pa, pb) and torch.equal(ta.flat_p, tb.flat_p)
