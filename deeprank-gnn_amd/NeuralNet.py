@@ -201,7 +201,13 @@ class NeuralNet(object):
         """One pass over the training set (NeuralNet.py:477-537) on the native step.  No host sync inside
         the loop: batches come from the resident set, the running loss stays on the device."""
         store = self._new_store()
-        if self.native_epoch and self.train_index:
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if self.native_epoch and self.train_index and world > 1:
+            done = self._epoch_data_parallel(store, world, dist.get_rank())
+            if done is not None:
+                return done
+        if self.native_epoch and self.train_index and world == 1:
             # the whole epoch enqueued by the native loop (drgnn_train_epoch): collate, step (+ next topology) and
             # update launches for every mini-batch, one host synchronisation at the end
             rs = self._resident(self.dataset)
@@ -232,6 +238,44 @@ class NeuralNet(object):
             self._collect(self.trainer.last_pred, batch, store)
             batch, topo = nxt, nxt_topo
         return float(running), self._finish(store)
+
+    def _epoch_data_parallel(self, store, world, rank):
+        """One epoch with ``batch_size`` as the GLOBAL mini-batch, sharded over the ranks (contiguous shards, sizes differ
+        by <= 1): the native loop runs this rank's shards, per mini-batch gradient launches -> one all-reduce of the flat
+        gradient (weighted n_local / n_global) -> Adam.  Every rank applies the same updates, so this equals the
+        single-process epoch on the same order.  The store / loss returned describe THIS rank's shard."""
+        import torch.distributed as dist
+        from .parallel import shard_range
+        order = torch.tensor([int(i) for i in self.train_index], dtype=torch.int64)
+        if self.shuffle:
+            order = order[torch.randperm(order.numel())]
+        if dist.get_backend() == "nccl":
+            od = order.to(self.device)
+            dist.broadcast(od, src=0)
+            order = od.cpu()
+        else:
+            dist.broadcast(order, src=0)                       # every rank walks rank 0's order
+        order = order.tolist()
+        chunks = [order[lo:lo + self.batch_size] for lo in range(0, len(order), self.batch_size)]
+        parts = [c[slice(*shard_range(len(c), rank, world))] for c in chunks]
+        sizes = [len(c) for c in chunks]
+        if any(len(c) < world for c in chunks):
+            return None                                        # a mini-batch smaller than the world: per-batch path
+        rs = self._resident(self.dataset)
+        local_bs = len(parts[0])
+        mine = [g for p in parts for g in p]
+        done = self.trainer.train_epoch(rs, mine, local_bs, cached=self.cached_topology, dp_global_sizes=sizes)
+        if done is None:
+            return None
+        losses, pred = done
+        store['_pred'].append(pred)
+        store['_y'].append(rs.y[torch.as_tensor(mine, dtype=torch.long, device=rs.y.device)])
+        store['mol'] += [rs.mols[i] for i in mine]
+        # a rank's batch loss is the mean over its shard: weight it back to the global mean of the mini-batch
+        w = torch.tensor([len(p) / float(n) for p, n in zip(parts, sizes)], dtype=torch.float32, device=losses.device)
+        total = (losses * w).sum()
+        dist.all_reduce(total)
+        return float(total), self._finish(store)
 
     def _sum_of_batch_losses(self, pred, y):
         """Sum over the mini-batches of each batch's mean loss (what the reference accumulates, NeuralNet.py:441-447)."""

@@ -1218,6 +1218,20 @@ int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan) {
     return rc ? (int64_t)rc : c.bytes;
 }
 
+// reduction of the step's slabs + optimiser update of mini-batch k: one launch, or (data parallel) gradient launch ->
+// the caller's exchange -> Adam launch
+static int epoch_update(const drgnn_epoch_plan* p, const EpochCarve& c, int64_t B, int64_t k, float* losses, void* stream) {
+    const drgnn_head_desc* hd = p->head;
+    const int fused = p->exchange ? 0 : 1;
+    int rc = drgnn_step_update(p->net, c.partials, B, p->g_conv1, p->g_conv2, c.head_partials, c.readout, hd->R, hd->H,
+                               hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
+                               p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, fused, stream);
+    if (rc || fused) return rc;
+    if ((rc = p->exchange(p->exchange_user, k, B, stream))) return rc;
+    return drgnn_adam_step(p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->step2, p->n_param, p->lr, p->beta1,
+                           p->beta2, p->eps, 0.0f, stream);
+}
+
 int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_bytes, float* pred, float* losses,
                       void* stream) {
     EpochCarve c;
@@ -1249,10 +1263,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
                                              train ? c.partials : nullptr, c.xchg, stream);
             if (rc) return rc;
             if (!train) continue;
-            rc = drgnn_step_update(p->net, c.partials, b.B, p->g_conv1, p->g_conv2, c.head_partials, c.readout, hd->R, hd->H,
-                                   hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
-                                   p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, 1, stream);
-            if (rc) return rc;
+            if ((rc = epoch_update(p, c, b.B, k, losses, stream))) return rc;
         }
         return 0;
     }
@@ -1290,10 +1301,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
                                   more ? &req : nullptr, stream);
         if (rc) return rc;
         if (!train) { if (more) cur = nxt; continue; }
-        rc = drgnn_step_update(p->net, c.partials, cur.B, p->g_conv1, p->g_conv2, c.head_partials, c.readout, hd->R, hd->H,
-                               hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
-                               p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, 1, stream);
-        if (rc) return rc;
+        if ((rc = epoch_update(p, c, cur.B, k, losses, stream))) return rc;
         if (more) cur = nxt;
     }
     return 0;

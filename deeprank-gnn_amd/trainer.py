@@ -363,7 +363,7 @@ class FusedTrainer(object):
         done = self._run_epoch(gset, order, batch_size, inference=True, cached=cached)
         return None if done is None else done[1]
 
-    def train_epoch(self, gset, order, batch_size, cached=False):
+    def train_epoch(self, gset, order, batch_size, cached=False, dp_global_sizes=None, group=None):
         """A whole epoch over the resident set ``gset`` (resident.ResidentGraphSet) in visiting order ``order``
         (graph numbers), driven by the native loop ``drgnn_train_epoch``: per mini-batch the fused step launch
         (whose extra workgroups build the next mini-batch's topology and gather its node rows straight from the
@@ -372,11 +372,16 @@ class FusedTrainer(object):
         a graph too large for the fused kernels)."""
         if self.weight_decay != 0.0:
             return None
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            return None
         want = torch.float32 if self.task == _lib.TASK_REG else torch.int64
         if gset.y is None or gset.y.dtype != want:
             return None
+        self._dp = None
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            # data parallel: ``order`` is THIS rank's shard of the epoch; per mini-batch the loop enqueues the gradient
+            # launches, calls back here for the ONE all-reduce of the flat gradient (enqueued on the same stream, no
+            # synchronisation), then enqueues Adam.  ``dp_global_sizes[k]``: graphs of mini-batch k over ALL ranks
+            # (None: equal shards); every rank must run the same number of mini-batches.
+            self._dp = (dp_global_sizes, group)
         return self._run_epoch(gset, order, batch_size, inference=False, cached=cached)
 
     def _run_epoch(self, gset, order, batch_size, inference, cached=False):
@@ -429,13 +434,34 @@ class FusedTrainer(object):
         if cached:
             cache = gset.topology_cache(need_weights=need_w)
             plan.cache = ctypes.cast(ctypes.pointer(cache._desc), vp)
+        callback = None
+        if not inference and getattr(self, "_dp", None) is not None:
+            sizes, group = self._dp
+
+            def exchange(user, k, n_local, stream):
+                try:
+                    self.all_reduce_gradients(n_local=int(n_local), n_global=(None if sizes is None else int(sizes[k])),
+                                              group=group)
+                    return 0
+                except Exception as exc:          # never let an exception cross the C frame
+                    self._dp_error = exc
+                    return -1
+            callback = _lib.EXCHANGE_FN(exchange)
+            plan.exchange = ctypes.cast(callback, vp)
         nbytes = self.api.train_epoch_scratch_bytes(plan)
         if nbytes is None:
             return None
         scratch = self._epoch_scratch
         if scratch is None or scratch.numel() < nbytes:
             scratch = self._epoch_scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        self.api.train_epoch(plan, scratch, pred, losses, _lib.current_stream(self.flat_p))
+        self._dp_error = None
+        try:
+            self.api.train_epoch(plan, scratch, pred, losses, _lib.current_stream(self.flat_p))
+        except _lib.DrgnnError:
+            if self._dp_error is not None:
+                raise self._dp_error
+            raise
+        del callback
         if not inference:
             self.last_pred = pred[(nb - 1) * batch_size:]
             self.last_batch_size = n - (nb - 1) * batch_size

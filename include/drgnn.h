@@ -477,6 +477,12 @@ int drgnn_net_train_step_cached(const drgnn_net_desc* net, const drgnn_head_desc
                                 int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t* step2, float* pred,
                                 float* readout, float* head_partials, float* partials, uint64_t* xchg, void* stream);
 
+/* Data-parallel hook of the native epoch loop: called on the host once per mini-batch, after the launches that leave
+ * this rank's gradient of mini-batch `batch_index` in flat_grad have been ENQUEUED on `stream`; it must enqueue the
+ * exchange (one all-reduce of flat_grad, weighted n_local / n_global) on the same stream and return 0.  The loop then
+ * enqueues Adam (drgnn_adam_step).  No host synchronisation is implied. */
+typedef int (*drgnn_exchange_fn)(void* user, int64_t batch_index, int64_t n_local, void* stream);
+
 typedef struct drgnn_epoch_plan {
     const drgnn_graph_set* set;
     const int64_t* host_node_ptr; const int64_t* host_edge_ptr; const int64_t* host_c1_ptr;
@@ -493,6 +499,9 @@ typedef struct drgnn_epoch_plan {
     /* cached-topology mode (non-NULL): mini-batches are stepped straight out of the cache, the loop issues no
      * offset-table, builder or gather work; `set` is then only consulted for the graphs' sizes on the host */
     const drgnn_topology_cache* cache;
+    /* data parallel (non-NULL): per mini-batch  gradient launches -> exchange(...) -> Adam launch  instead of the fused
+     * reduce+Adam launch; every rank must run the same number of mini-batches */
+    drgnn_exchange_fn exchange; void* exchange_user;
 } drgnn_epoch_plan;
 int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan);
 int drgnn_train_epoch(const drgnn_epoch_plan* plan, void* scratch, int64_t scratch_bytes, float* pred,

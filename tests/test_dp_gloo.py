@@ -116,6 +116,103 @@ def test_eight_rank_gradients_match_single_process():
     np.testing.assert_allclose(p[0], tr.flat_p.numpy(), rtol=1e-5, atol=1e-6)
 
 
+def _worker_epoch(rank, world, init_file, out_dir, cached):
+    """Native epoch loop under data parallelism: per mini-batch gradient launches -> exchange callback (ONE all-reduce
+    of the flat gradient) -> Adam, ragged shards weighted n_local / n_global."""
+    from emu_api import emu
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    graphs = _graphs(14)
+    rs = ResidentGraphSet(graphs, "cpu", api=emu())
+    tr = FusedTrainer(_make_net("sGAT"), lr=0.01, api=emu(), seed=5)
+    # global mini-batches of 6, 6, 2 graphs; rank 0 takes the first ceil(half) of each, rank 1 the rest
+    order = list(range(14))
+    mine, sizes = [], []
+    for lo in range(0, 14, 6):
+        chunk = order[lo:lo + 6]
+        half = (len(chunk) + 1) // 2
+        part = chunk[:half] if rank == 0 else chunk[half:]
+        mine.append(part)
+        sizes.append(len(chunk))
+    local_bs = 3
+    assert all(0 < len(p) <= local_bs for p in mine)
+    for _ in range(2):
+        # ragged local batches: one train_epoch call per mini-batch keeps the batch boundaries aligned across ranks
+        for k, part in enumerate(mine):
+            done = tr.train_epoch(rs, part, local_bs, cached=cached, dp_global_sizes=[sizes[k]])
+            assert done is not None
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), tr.flat_p.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cached", [False, True])
+def test_native_epoch_loop_under_data_parallel(cached):
+    from emu_api import emu
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    emu()
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_worker_epoch, args=(2, init_file, tmp, cached), nprocs=2, join=True)
+        p = [np.load(os.path.join(tmp, "p%d.npy" % r)) for r in range(2)]
+    np.testing.assert_array_equal(p[0], p[1])
+    graphs = _graphs(14)
+    tr = FusedTrainer(_make_net("sGAT"), lr=0.01, api=emu(), seed=5)
+    for _ in range(2):
+        for lo in range(0, 14, 6):
+            tr.train_step(Batch.from_data_list(graphs[lo:lo + 6]))
+    np.testing.assert_allclose(p[0], tr.flat_p.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def _worker_nn(rank, world, init_file, out_dir):
+    from emu_api import emu
+    from helpers import GOLDEN, NODE_FEATURES
+    from deeprank_gnn_amd.NeuralNet import NeuralNet
+    from deeprank_gnn_amd.ginet import GINet
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    nn = NeuralNet(os.path.join(GOLDEN, "1ATN_residue.drgs"), GINet, node_feature=NODE_FEATURES, edge_feature=['dist'],
+                   target='irmsd', batch_size=4, percent=[1.0, 0.0], shuffle=True, outdir=out_dir, _api=emu(), device='cpu')
+    nn.model.dropout = 0.0
+    nn.train(nepoch=2, validate=False, save_model=None, hdf5=None)
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), nn.trainer.flat_p.numpy())
+    np.save(os.path.join(out_dir, "l%d.npy" % rank), np.asarray(nn.train_loss))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_neuralnet_trains_data_parallel_like_a_single_process(tmp_path):
+    """deeprank_gnn_amd.NeuralNet under torch.distributed (2 ranks, gloo): batch_size is the GLOBAL mini-batch, every
+    rank runs its shards through the native epoch loop; parameters and epoch losses equal the single-process run on the
+    same (rank 0's) shuffled order."""
+    from emu_api import emu
+    from helpers import GOLDEN, NODE_FEATURES
+    from deeprank_gnn_amd.NeuralNet import NeuralNet
+    from deeprank_gnn_amd.ginet import GINet
+    emu()
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_worker_nn, args=(2, init_file, tmp), nprocs=2, join=True)
+        p = [np.load(os.path.join(tmp, "p%d.npy" % r)) for r in range(2)]
+        losses = [np.load(os.path.join(tmp, "l%d.npy" % r)) for r in range(2)]
+    np.testing.assert_array_equal(p[0], p[1])
+    np.testing.assert_array_equal(losses[0], losses[1])
+    torch.manual_seed(0)
+    np.random.seed(0)
+    nn = NeuralNet(os.path.join(GOLDEN, "1ATN_residue.drgs"), GINet, node_feature=NODE_FEATURES, edge_feature=['dist'],
+                   target='irmsd', batch_size=4, percent=[1.0, 0.0], shuffle=True, outdir=str(tmp_path), _api=emu(),
+                   device='cpu')
+    nn.model.dropout = 0.0
+    nn.train(nepoch=2, validate=False, save_model=None, hdf5=None)
+    np.testing.assert_allclose(p[0], nn.trainer.flat_p.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(losses[0], nn.train_loss, rtol=1e-4)
+
+
 def test_shard_range_covers_everything():
     from deeprank_gnn_amd.parallel import shard_range
     for n in (0, 1, 7, 64, 513):
