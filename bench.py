@@ -187,6 +187,10 @@ def main():
         from deeprank_gnn_amd.trainer import FusedTrainer
         trainer = FusedTrainer(net, lr=1e-3, task="reg", seed=1234 + rank)
         loss_out = trainer.loss
+        oneshot = None
+        if world > 1 and os.environ.get("DRGNN_DP_ONESHOT", "0") == "1":
+            # opt-in: the one-shot peer-to-peer all-reduce (csrc/drgnn_p2p.h) instead of RCCL's ring
+            oneshot = trainer.use_oneshot_allreduce()
         # Two persistent topology workspaces.  Pipelined: while step t trains out of one, the
         # topology of step t+1 is built into the other INSIDE step t's backward launch (the builder
         # only depends on index tensors).  Every step still builds one topology and consumes one.
@@ -500,8 +504,14 @@ def main():
                        "final_loss": final_loss},
         }
         if split:
+            if native and oneshot is not None:
+                dp_mode = dp_mode.replace("RCCL all-reduce", "one-shot p2p all-reduce (drgnn_allreduce_oneshot)")
+                dp_mode += " [DRGNN_DP_ONESHOT=1]"
+                oneshot.check()
             result["config"]["dp_exchange"] = dp_mode
             result["config"]["params_in_sync"] = in_sync
+            result["config"]["dp_backend"] = dist.get_backend() if dist.is_initialized() else None
+            result["config"]["dp_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
         if native:
             result["roofline"] = measure_roofline(net, args.net, batch, dev, value / world,
                                                   cache=(cache, ids_host, ids_dev) if cached else None)

@@ -183,6 +183,14 @@ class Api(object):
         lib.drgnn_cluster_offset.argtypes = [_vp, _vp, _c_i64, _vp, _vp]
         lib.drgnn_graclus.argtypes = [_vp, _c_i64, _c_i64, _c_i64, _c_i32, _c_i32, _vp, _vp, _vp, _vp]
         lib.drgnn_mcl.argtypes = [_vp, _c_i64, _vp, _vp, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp]
+        lib.drgnn_p2p_bytes.argtypes = [_c_i64]
+        lib.drgnn_p2p_bytes.restype = _c_i64
+        lib.drgnn_p2p_alloc.argtypes = [_c_i64, ctypes.POINTER(_vp), _vp]
+        lib.drgnn_p2p_open.argtypes = [_vp, ctypes.POINTER(_vp)]
+        lib.drgnn_p2p_close.argtypes = [_vp]
+        lib.drgnn_p2p_free.argtypes = [_vp]
+        lib.drgnn_allreduce_oneshot.argtypes = [_vp, _c_i64, ctypes.POINTER(_vp), _c_i32, _c_i32, ctypes.c_float, _vp, _vp,
+                                                _c_i32, _vp]
         lib.drgnn_train_epoch_scratch_bytes.argtypes = [ctypes.POINTER(EpochPlan)]
         lib.drgnn_train_epoch_scratch_bytes.restype = _c_i64
         lib.drgnn_train_epoch.argtypes = [ctypes.POINTER(EpochPlan), _vp, _c_i64, _vp, _vp, _vp]
@@ -376,6 +384,34 @@ class Api(object):
     def batch_offsets(self, gset, ids, n_ids, batch_size, ptrs, stream):
         _check(self.lib.drgnn_batch_offsets(ctypes.byref(gset), _ptr(ids), n_ids, batch_size, _ptr(ptrs), stream),
                "drgnn_batch_offsets")
+
+    # -- one-shot all-reduce over peer-mapped exchange buffers -------------------------
+    def p2p_bytes(self, n_floats):
+        return int(self.lib.drgnn_p2p_bytes(n_floats))
+
+    def p2p_alloc(self, nbytes):
+        """(device pointer, 64-byte IPC handle) of a zero-filled fine-grained exchange buffer."""
+        ptr = _vp()
+        handle = ctypes.create_string_buffer(64)
+        _check(self.lib.drgnn_p2p_alloc(nbytes, ctypes.byref(ptr), handle), "drgnn_p2p_alloc")
+        return ptr.value, handle.raw
+
+    def p2p_open(self, handle):
+        ptr = _vp()
+        buf = ctypes.create_string_buffer(bytes(handle), 64)
+        _check(self.lib.drgnn_p2p_open(buf, ctypes.byref(ptr)), "drgnn_p2p_open")
+        return ptr.value
+
+    def p2p_close(self, ptr):
+        _check(self.lib.drgnn_p2p_close(ptr), "drgnn_p2p_close")
+
+    def p2p_free(self, ptr):
+        _check(self.lib.drgnn_p2p_free(ptr), "drgnn_p2p_free")
+
+    def allreduce_oneshot(self, grad, n, peers, world, rank, weight, seq, status, stream, part=0):
+        arr = (_vp * world)(*peers)
+        _check(self.lib.drgnn_allreduce_oneshot(_ptr(grad), n, arr, world, rank, float(weight), _ptr(seq), _ptr(status),
+                                                part, stream), "drgnn_allreduce_oneshot")
 
     def train_epoch_scratch_bytes(self, plan):
         """Bytes of device scratch for the plan; None when a graph does not fit the fused kernels."""

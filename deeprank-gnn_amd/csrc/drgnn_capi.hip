@@ -8,6 +8,8 @@
 #include "drgnn_kernels.h"
 
 #include <vector>
+#include <string.h>
+#include <stdlib.h>
 #ifdef DRGNN_EMU
 #define DRGNN_LDS_LIMIT (160 * 1024)
 #else
@@ -793,6 +795,85 @@ int drgnn_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
     (void)stream_;
 #else
     hipLaunchKernelGGL(k_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream_, a);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+}  // extern "C"
+
+extern "C" {
+
+int64_t drgnn_p2p_bytes(int64_t n_floats) { return n_floats < 0 ? (int64_t)DRGNN_E_ARG : p2p_bytes(n_floats); }
+
+int drgnn_p2p_alloc(int64_t bytes, void** dev_ptr, void* handle) {
+    if (bytes <= 0 || !dev_ptr) return DRGNN_E_ARG;
+#ifdef DRGNN_EMU
+    *dev_ptr = calloc(1, (size_t)bytes);
+    if (handle) { memset(handle, 0, 64); memcpy(handle, dev_ptr, sizeof(void*)); }     // same-process "handle"
+    return *dev_ptr ? 0 : DRGNN_E_CAPACITY;
+#else
+    // fine-grained: coherent across devices WITHIN a kernel (coarse-grained memory is only coherent at launch boundaries)
+    HIP_TRY(hipExtMallocWithFlags(dev_ptr, (size_t)bytes, hipDeviceMallocFinegrained));
+    HIP_TRY(hipMemset(*dev_ptr, 0, (size_t)bytes));
+    HIP_TRY(hipDeviceSynchronize());
+    if (handle) {
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "IPC handle size");
+        HIP_TRY(hipIpcGetMemHandle((hipIpcMemHandle_t*)handle, *dev_ptr));
+    }
+    return 0;
+#endif
+}
+
+int drgnn_p2p_open(const void* handle, void** dev_ptr) {
+    if (!handle || !dev_ptr) return DRGNN_E_ARG;
+#ifdef DRGNN_EMU
+    memcpy(dev_ptr, handle, sizeof(void*));
+    return 0;
+#else
+    const hipIpcMemHandle_t h = *(const hipIpcMemHandle_t*)handle;
+    HIP_TRY(hipIpcOpenMemHandle(dev_ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+#endif
+}
+
+int drgnn_p2p_close(void* dev_ptr) {
+#ifdef DRGNN_EMU
+    (void)dev_ptr;
+    return 0;
+#else
+    if (!dev_ptr) return DRGNN_E_ARG;
+    HIP_TRY(hipIpcCloseMemHandle(dev_ptr));
+    return 0;
+#endif
+}
+
+int drgnn_p2p_free(void* dev_ptr) {
+#ifdef DRGNN_EMU
+    free(dev_ptr);
+    return 0;
+#else
+    if (!dev_ptr) return DRGNN_E_ARG;
+    HIP_TRY(hipFree(dev_ptr));
+    return 0;
+#endif
+}
+
+int drgnn_allreduce_oneshot(float* grad, int64_t n, void* const* peer_bufs, int32_t world, int32_t rank, float weight,
+                            uint32_t* seq, int32_t* status, int32_t part, void* stream_) {
+    if (!grad || n < 0 || !peer_bufs || world < 1 || world > DRGNN_P2P_MAX || rank < 0 || rank >= world || !seq || !status ||
+        part < 0 || part > 2)
+        return DRGNN_E_ARG;
+    if (n == 0) return 0;
+    P2PArgs a;
+    a.grad = grad; a.n = n; a.world = world; a.rank = rank; a.weight = weight; a.seq = seq; a.status = status; a.part = part;
+    for (int r = 0; r < DRGNN_P2P_MAX; ++r) a.peer[r] = (r < world) ? (float*)peer_bufs[r] : nullptr;
+    for (int r = 0; r < world; ++r) if (!a.peer[r]) return DRGNN_E_ARG;
+#ifdef DRGNN_EMU
+    for (int j = 0; j < DRGNN_P2P_WGS; ++j) p2p_block(a, j);
+    (void)stream_;
+#else
+    hipLaunchKernelGGL(k_allreduce_oneshot, dim3(DRGNN_P2P_WGS), dim3(DRGNN_P2P_THREADS), 0, (hipStream_t)stream_, a);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

@@ -9,6 +9,7 @@
 #include "drgnn_layers.h"
 #include "drgnn_mcl.h"
 #include "drgnn_collate.h"
+#include "drgnn_p2p.h"
 
 // =====================================================================================
 // kernels
@@ -530,6 +531,7 @@ __global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
     // nobody reads step2[0] in this launch (Adam reads step2[1]): safe to commit it here
     if (u.step2 && blockIdx.x == 0 && threadIdx.x == 0) u.step2[0] = u.step2[1];
 }
+__global__ void __launch_bounds__(DRGNN_P2P_THREADS) k_allreduce_oneshot(P2PArgs a) { p2p_block(a, blockIdx.x); }
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {
     adam_item(a, (int64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }

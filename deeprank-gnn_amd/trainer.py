@@ -320,6 +320,12 @@ class FusedTrainer(object):
         world = dist.get_world_size(group)
         if world == 1:
             return
+        oneshot = getattr(self, "_oneshot", None)
+        if oneshot is not None:
+            # opt-in: one launch, one xGMI round trip (parallel.OneShotAllReduce) instead of the RCCL ring
+            w = (float(n_local if n_local is not None else self.last_batch_size) / float(n_global)) if n_global else None
+            oneshot(self.flat_g, weight=w)
+            return
         if n_global:
             self.flat_g.mul_(float(n_local if n_local is not None else self.last_batch_size) / float(n_global))
         elif dist.get_backend(group) == "nccl" and getattr(self, "_avg_ok", True):
@@ -333,6 +339,12 @@ class FusedTrainer(object):
         else:
             self.flat_g.mul_(1.0 / world)
         dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
+
+    def use_oneshot_allreduce(self, group=None):
+        """Route ``all_reduce_gradients`` through the one-shot peer-to-peer exchange (parallel.OneShotAllReduce)."""
+        from .parallel import OneShotAllReduce
+        self._oneshot = OneShotAllReduce(self.flat_g.numel(), self.flat_g.device, api=self.api, group=group)
+        return self._oneshot
 
     def apply_update(self):
         """Adam on the flat buffers (one launch)."""

@@ -507,6 +507,24 @@ int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan);
 int drgnn_train_epoch(const drgnn_epoch_plan* plan, void* scratch, int64_t scratch_bytes, float* pred,
                       float* losses, void* stream);
 
+/* ---- one-shot all-reduce over peer-mapped exchange buffers (csrc/drgnn_p2p.h) ------------------------------
+ * Data-parallel exchange of the flat gradient without a ring: each rank owns a fine-grained exchange buffer
+ * (drgnn_p2p_alloc), hands its 64-byte IPC handle to the peers (e.g. torch.distributed.all_gather), maps theirs
+ * (drgnn_p2p_open) and then every step  drgnn_allreduce_oneshot  = publish own weighted vector, read all W vectors
+ * over xGMI, add them in rank order.  One launch, no host work, hipGraph-capturable; sums are bit-identical on all
+ * ranks.  `seq` = DRGNN_P2P_SEQ_WORDS zero-initialised uint32 device words, `status` one int32 device word (non-zero
+ * after a wait that expired: a peer did not arrive).  world <= DRGNN_P2P_MAX_RANKS. */
+#define DRGNN_P2P_MAX_RANKS 16
+#define DRGNN_P2P_SEQ_WORDS 16
+int64_t drgnn_p2p_bytes(int64_t n_floats);
+int drgnn_p2p_alloc(int64_t bytes, void** dev_ptr, void* ipc_handle_64);     /* zero-filled, fine-grained */
+int drgnn_p2p_open(const void* ipc_handle_64, void** dev_ptr);
+int drgnn_p2p_close(void* dev_ptr);
+int drgnn_p2p_free(void* dev_ptr);
+/* part: 0 = the whole exchange (product); 1 = publish only, 2 = consume only (single-process protocol tests) */
+int drgnn_allreduce_oneshot(float* grad, int64_t n, void* const* peer_bufs, int32_t world, int32_t rank,
+                            float weight, uint32_t* seq, int32_t* status, int32_t part, void* stream);
+
 int drgnn_abi_version(void);
 
 #ifdef __cplusplus
