@@ -98,7 +98,8 @@ DEV void conv_bwd_du_item(const ConvLayerArgs& a, int64_t item) {
     if (a.kind != DRGNN_GINET) {
         float dv, sc;
         conv_row_coef(a, j, dv, sc);
-        if (a.kind == DRGNN_FOUT && a.rowptr[j + 1] == a.rowptr[j]) sc = 0.0f;
+        // (FoutLayer, node without out-edges: the forward row is NaN through the empty mean, but x_j Wc still receives
+        // the upstream gradient -- autograd of `alpha + gamma`, foutnet.py:75 -- so the self path is NOT masked)
         a.u[(long)j * HC + H + h] = sc * a.grad_out[(long)j * H + h];
     }
 }

@@ -23,27 +23,33 @@ __all__ = ["FoutNet", "FoutLayer"]
 class FoutLayer(nn.Module):
     def __init__(self, in_channels, out_channels, bias=True):
         super().__init__()
-        if not bias:
-            raise NotImplementedError("only bias=True (what FoutNet builds) is on the device path")
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.Wc = Parameter(torch.Tensor(in_channels, out_channels))
         self.Wn = Parameter(torch.Tensor(in_channels, out_channels))
-        self.bias = Parameter(torch.Tensor(out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)               # foutnet.py:43-46
         self.reset_parameters()
 
     def reset_parameters(self):
         bound = 1.0 / math.sqrt(self.in_channels)
         self.Wc.data.uniform_(-bound, bound)
         self.Wn.data.uniform_(-bound, bound)
-        self.bias.data.uniform_(-bound, bound)
+        if self.bias is not None:
+            self.bias.data.uniform_(-bound, bound)
 
     def live_parameters(self):
+        if self.bias is None:
+            raise NotImplementedError("the fused FoutNet uses bias=True (what the reference net builds); "
+                                      "bias=False runs through forward()")
         return (self.Wc, self.Wn, self.bias)
 
     def forward(self, x, edge_index):
         from .layers import conv_layer_forward
-        return conv_layer_forward(_lib.FOUT, x, edge_index, None, self.live_parameters())
+        bias = self.bias if self.bias is not None else torch.zeros(self.out_channels, dtype=x.dtype, device=x.device)
+        return conv_layer_forward(_lib.FOUT, x, edge_index, None, (self.Wc, self.Wn, bias))
 
     def __repr__(self):
         return '{}({}, {})'.format(self.__class__.__name__, self.in_channels, self.out_channels)

@@ -47,6 +47,9 @@ class GINetConvLayer(nn.Module):
         _uniform(size, self.fc_edge_attr.weight)
 
     def live_parameters(self):
+        if self.fc.bias is not None:
+            raise NotImplementedError("the fused GINet uses bias=False (what the reference net builds); "
+                                      "bias=True runs through forward()")
         return (self.fc.weight,)
 
     def dead_parameters(self):
@@ -54,10 +57,19 @@ class GINetConvLayer(nn.Module):
 
     def forward(self, x, edge_index, edge_attr=None):
         from .layers import conv_layer_forward
-        if self.fc.bias is not None:
-            raise NotImplementedError("GINetConvLayer(bias=True) is never built by the reference nets")
-        z = conv_layer_forward(_lib.GINET, x, edge_index, edge_attr, self.live_parameters())
-        return zero_grad_passthrough(z, self.dead_parameters())
+        dead = self.dead_parameters()
+        if self.fc.bias is None:
+            z = conv_layer_forward(_lib.GINET, x, edge_index, edge_attr, self.live_parameters())
+        else:
+            # GINetConvLayer(bias=True) (ginet.py:26-37): fc's bias is added PER EDGE before the sum over a row's edges
+            # (z_i = sum_e (W x_col + b)); with a constant-one input column it is one more column of the weight, so
+            # the same device kernel computes it, and autograd splits the gradient back into fc.weight / fc.bias.
+            # The biases of the two dead Linear layers get zero gradients like their weights.
+            ones = torch.ones((x.size(0), 1), dtype=x.dtype, device=x.device)
+            z = conv_layer_forward(_lib.GINET, torch.cat([x, ones], dim=1), edge_index, edge_attr,
+                                   (torch.cat([self.fc.weight, self.fc.bias.view(-1, 1)], dim=1),))
+            dead = dead + (self.fc_edge_attr.bias, self.fc_attention.bias)
+        return zero_grad_passthrough(z, dead)
 
     def __repr__(self):
         return '{}({}, {})'.format(self.__class__.__name__, self.in_channels, self.out_channels)

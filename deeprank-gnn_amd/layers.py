@@ -45,6 +45,7 @@ class _ConvLayer(torch.autograd.Function):
                                _lib.current_stream(x))
         ctx.kind, ctx.api, ctx.topo, ctx.H = kind, api, topo, H
         ctx.save_for_backward(x, *params)
+        _ConvLayer.last_topology = topo
         return out
 
     @staticmethod
@@ -71,5 +72,8 @@ class _ConvLayer(torch.autograd.Function):
         return (None, None, gx, None, None) + grads
 
 
-def conv_layer_forward(kind, x, edge_index, edge_attr, params, api=None):
-    return _ConvLayer.apply(kind, api or _lib.get(), x, edge_index, edge_attr, *params)
+def conv_layer_forward(kind, x, edge_index, edge_attr, params, api=None, return_topology=False):
+    out = _ConvLayer.apply(kind, api or _lib.get(), x, edge_index, edge_attr, *params)
+    if return_topology:
+        return out, _ConvLayer.last_topology      # the single-graph workspace the call built (CSR / CSC of the input)
+    return out

@@ -23,27 +23,48 @@ __all__ = ["sGAT", "sGraphAttentionLayer"]
 class sGraphAttentionLayer(nn.Module):
     def __init__(self, in_channels, out_channels, bias=True, undirected=True):
         super().__init__()
-        if not bias or not undirected:
-            raise NotImplementedError("only the configuration the reference nets build "
-                                      "(bias=True, undirected=True) is on the device path")
         self.in_channels = in_channels
         self.out_channels = out_channels
         self.undirected = undirected
         self.weight = Parameter(torch.Tensor(2 * in_channels, out_channels))
-        self.bias = Parameter(torch.Tensor(out_channels))
+        if bias:
+            self.bias = Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter('bias', None)               # sGAT.py:50-53
         self.reset_parameters()
 
     def reset_parameters(self):
         bound = 1.0 / math.sqrt(2 * self.in_channels)
         self.weight.data.uniform_(-bound, bound)
-        self.bias.data.uniform_(-bound, bound)
+        if self.bias is not None:
+            self.bias.data.uniform_(-bound, bound)
 
     def live_parameters(self):
+        if self.bias is None or not self.undirected:
+            raise NotImplementedError("the fused nets use the configuration the reference nets build "
+                                      "(bias=True, undirected=True); other options run through forward()")
         return (self.weight, self.bias)
 
     def forward(self, x, edge_index, edge_attr):
+        """Device kernels (drgnn_conv_layer_forward / _backward) for every constructor option:
+        * bias=False: the kernel adds a constant zero row;
+        * undirected=False (sGAT.py:86-87): ``scatter_mean(alpha, col, out=out)`` adds the column sums into the row means
+          and divides the WHOLE buffer by the clamped column counts, i.e.
+              out_i = rowmean_i / max(indeg_i, 1) + colmean_i
+          and colmean is this same layer on the reversed edges with the two halves of W swapped."""
         from .layers import conv_layer_forward
-        return conv_layer_forward(_lib.SGAT, x, edge_index, edge_attr, self.live_parameters())
+        zero = torch.zeros(self.out_channels, dtype=x.dtype, device=x.device)
+        if self.undirected:
+            return conv_layer_forward(_lib.SGAT, x, edge_index, edge_attr, (self.weight, zero if self.bias is None else self.bias))
+        F_in = self.in_channels
+        rowmean = conv_layer_forward(_lib.SGAT, x, edge_index, edge_attr, (self.weight, zero))
+        swapped = torch.cat([self.weight[F_in:], self.weight[:F_in]], dim=0)
+        rev = torch.stack([edge_index[1], edge_index[0]])
+        colmean, topo_rev = conv_layer_forward(_lib.SGAT, x, rev, edge_attr, (swapped, zero), return_topology=True)
+        rp = topo_rev.array("ROWPTR0")[:x.size(0) + 1]           # CSR of the reversed graph: row i = edges with col == i
+        indeg = (rp[1:] - rp[:-1]).clamp(min=1).to(x.dtype).view(-1, 1)
+        out = rowmean / indeg + colmean
+        return out if self.bias is None else out + self.bias
 
     def __repr__(self):
         return '{}({}, {})'.format(self.__class__.__name__, self.in_channels, self.out_channels)

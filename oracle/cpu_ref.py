@@ -158,28 +158,35 @@ def community_pooling(cluster, data):
     return out
 
 
-def ginet_conv(x, edge_index, edge_attr, w_fc, w_edge, w_att):
+def ginet_conv(x, edge_index, edge_attr, w_fc, w_edge, w_att, b_fc=None, b_edge=None, b_att=None):
     """reference ginet.py:50-73 (GINetConvLayer.forward), op for op, including the
-    attention branch whose softmax over a size-1 axis is identically 1."""
+    attention branch whose softmax over a size-1 axis is identically 1.
+    ``b_*``: the three Linear biases of GINetConvLayer(bias=True) (ginet.py:26-37; the nets build bias=False)."""
     row, col = edge_index[0], edge_index[1]
     if edge_attr.dim() == 1:
         edge_attr = edge_attr.unsqueeze(-1)
-    msg_col = F.linear(x[col], w_fc)
-    msg_row = F.linear(x[row], w_fc)
-    edge_term = F.linear(edge_attr, w_edge)
-    score = F.linear(torch.cat([msg_row, msg_col, edge_term], dim=1), w_att)
+    msg_col = F.linear(x[col], w_fc, b_fc)
+    msg_row = F.linear(x[row], w_fc, b_fc)
+    edge_term = F.linear(edge_attr, w_edge, b_edge)
+    score = F.linear(torch.cat([msg_row, msg_col, edge_term], dim=1), w_att, b_att)
     score = F.softmax(F.leaky_relu(score), dim=1)
     return scatter_sum(score * msg_col, row, x.size(0))
 
 
-def sgat_conv(x, edge_index, edge_attr, weight, bias):
-    """reference sGAT.py:62-93 (sGraphAttentionLayer.forward, undirected=True)."""
+def sgat_conv(x, edge_index, edge_attr, weight, bias, undirected=True):
+    """reference sGAT.py:62-93 (sGraphAttentionLayer.forward).  ``undirected=False`` adds the second
+    ``scatter_mean(alpha, col, dim=0, out=out)`` (:86-87): torch_scatter adds the column sums INTO the row means and then
+    divides the WHOLE buffer by the column counts (clamped to 1) -- SURVEY Appendix A."""
     row, col = edge_index[0], edge_index[1]
     if edge_attr.dim() == 1:
         edge_attr = edge_attr.unsqueeze(-1)
     pair = torch.cat([x[row], x[col]], dim=-1)
     msg = edge_attr * torch.mm(pair, weight)
     out = scatter_mean(msg, row, x.size(0))
+    if not undirected:
+        n = x.size(0)
+        count = scatter_sum(torch.ones(col.numel(), dtype=msg.dtype), col, n).clamp(min=1)
+        out = (out + scatter_sum(msg, col, n)) / count.view(-1, 1)
     return out if bias is None else out + bias
 
 

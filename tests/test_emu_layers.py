@@ -163,3 +163,11 @@ def test_scatter_ops_semantics():
     b, argb = cpu_ref.scatter_max(ref, idx)
     np.testing.assert_array_equal(a.detach().numpy(), b.detach().numpy())
     np.testing.assert_array_equal(arg.numpy(), argb.numpy())
+
+
+def test_layer_constructor_options_vs_reference_golden():
+    """undirected=False / bias=False / GINetConvLayer(bias=True): forward, input gradient and every parameter gradient
+    against vectors recorded from the reference's own layer classes; the oracle restates the same options."""
+    from layer_option_check import check_layer_options, check_oracle_options
+    check_oracle_options()
+    check_layer_options("cpu")

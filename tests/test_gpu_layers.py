@@ -110,3 +110,10 @@ def test_precluster_on_device_reproduces_the_fixture_labels():
     d0, d1 = precluster(batch.to(DEV))
     np.testing.assert_array_equal(d0.cpu().numpy(), expect0)
     np.testing.assert_array_equal(d1.cpu().numpy(), expect1)
+
+
+def test_layer_constructor_options_vs_reference_golden():
+    """Layer options the shipped nets never use (undirected=False, bias=False, GINetConvLayer(bias=True)) on the
+    MI355X against the reference-recorded vectors (reference sGAT.py:86-87, :50-53, foutnet.py:43-46, ginet.py:26-37)."""
+    from layer_option_check import check_layer_options
+    check_layer_options(torch.device("cuda:0"))
