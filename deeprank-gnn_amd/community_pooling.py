@@ -271,14 +271,26 @@ class _SegSumMean(torch.autograd.Function):
 
 
 def _scatter_reduce(src, index, dim, out, dim_size, mean):
-    if dim not in (0, -2) or out is not None:
-        raise NotImplementedError("only scatter over dim 0 without a preallocated out")
+    """torch_scatter.scatter_sum / scatter_mean along dim 0.  With ``out=``: the segment sums are
+    ADDED into ``out`` (``out.scatter_add_``) and, for the mean, the WHOLE buffer -- old content included -- is divided
+    by the clamped counts, in place; ``out`` itself is returned (what the reference's sGAT layer relies on, sGAT.py:82-87)."""
+    if dim not in (0, -2):
+        raise NotImplementedError("only scatter over dim 0")
+    if out is not None:
+        dim_size = out.size(0)
     flat = src if src.dim() == 2 else src.reshape(src.size(0), -1)
     topo = _scatter_topology(index, flat.size(0))
     c0, _, _ = topo.totals()
-    pooled = _SegSumMean.apply(flat, topo, c0, mean)
+    pooled = _SegSumMean.apply(flat, topo, c0, mean and out is None)
     dense, _ = _dense_rows(pooled, index, dim_size)
-    return dense if src.dim() == 2 else dense.reshape((dense.size(0),) + tuple(src.shape[1:]))
+    dense = dense if src.dim() == 2 else dense.reshape((dense.size(0),) + tuple(src.shape[1:]))
+    if out is None:
+        return dense
+    out.add_(dense)
+    if mean:
+        count = torch.bincount(index.reshape(-1).to(torch.int64), minlength=dim_size).clamp(min=1).to(out.dtype)
+        out.div_(count.view(-1, *([1] * (out.dim() - 1))))
+    return out
 
 
 def scatter_mean(src, index, dim=0, out=None, dim_size=None):

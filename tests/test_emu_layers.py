@@ -171,3 +171,27 @@ def test_layer_constructor_options_vs_reference_golden():
     from layer_option_check import check_layer_options, check_oracle_options
     check_oracle_options()
     check_layer_options("cpu")
+
+
+def test_scatter_out_argument_like_torch_scatter():
+    """scatter_sum / scatter_mean with out= (the reference's sGAT layer calls scatter_mean(alpha, row, dim=0, out=out),
+    sGAT.py:82-87): sums are added into `out`; the mean divides the WHOLE buffer by the clamped counts."""
+    rng = np.random.default_rng(3)
+    src = torch.from_numpy(rng.normal(size=(17, 5)).astype(np.float32))
+    index = torch.from_numpy(rng.integers(0, 6, size=17))
+    base = torch.from_numpy(rng.normal(size=(8, 5)).astype(np.float32))
+    want_sum = base.clone().index_add_(0, index, src)
+    out = base.clone()
+    got = cp.scatter_sum(src, index, dim=0, out=out)
+    assert got is out
+    np.testing.assert_allclose(out.numpy(), want_sum.numpy(), rtol=1e-5, atol=1e-6)
+    count = torch.bincount(index, minlength=8).clamp(min=1).float().view(-1, 1)
+    out = base.clone()
+    got = cp.scatter_mean(src, index, dim=0, out=out)
+    assert got is out
+    np.testing.assert_allclose(out.numpy(), (want_sum / count).numpy(), rtol=1e-5, atol=1e-6)
+    # the reference layer's exact call pattern, through autograd
+    s2 = src.clone().requires_grad_(True)
+    res = cp.scatter_mean(s2, index, dim=0, out=torch.zeros(8, 5))
+    res.sum().backward()
+    np.testing.assert_allclose(s2.grad.numpy(), (1.0 / count)[index].expand(-1, 5).numpy(), rtol=1e-6)
