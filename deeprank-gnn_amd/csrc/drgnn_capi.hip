@@ -64,6 +64,9 @@ int64_t drgnn_topology_lds_bytes(int32_t max_nodes, int32_t max_edges) {
 
 }  // extern "C"
 
+#ifndef DRGNN_TOPO_SPLIT_MAX_GRAPHS
+#define DRGNN_TOPO_SPLIT_MAX_GRAPHS 160
+#endif
 // fills a TopoLaunch from the public arguments; *lds_out = LDS bytes (0: global scratch path)
 static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_index, const float* edge_attr,
                         const int64_t* batch, const int64_t* cluster0, const int64_t* cluster1,
@@ -105,7 +108,11 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     }
     // two independent workgroups per graph (edge structures / member lists) when nothing forces the
     // single-chain order: LDS path, clusters present, depth-1 ids located by the caller
-    if (L.capN > 0 && cluster0 != nullptr && L.user_nptr != nullptr && !(cluster1 != nullptr && c1_ptr == nullptr))
+    // ... and when the extra workgroups find idle CUs: two workgroups per graph shorten the builder's critical path
+    // (what counts while a mini-batch leaves CUs idle) but repeat the cluster ranking; beyond ~one workgroup per CU the
+    // total work decides and one workgroup per graph does less of it
+    if (L.capN > 0 && cluster0 != nullptr && L.user_nptr != nullptr && !(cluster1 != nullptr && c1_ptr == nullptr) &&
+        n_graphs <= DRGNN_TOPO_SPLIT_MAX_GRAPHS)
         L.roles = 2;
     *lds_out = lds;
     return 0;
