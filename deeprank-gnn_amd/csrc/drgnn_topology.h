@@ -395,69 +395,23 @@ DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0,
     BARRIER();
 }
 
-// role 0: everything in one workgroup.  With two workgroups per graph the work splits into two
-// INDEPENDENT chains: role 1 = edge structures (CSR0/CSC0, pooled graph, CSC1; it recomputes the
-// cluster ranks it needs, 5 cheap phases), role 2 = the cluster member lists of both depths.
+// role 0: everything in one workgroup.  With two workgroups per graph the work splits into two INDEPENDENT chains of
+// about equal length, each starting from its own staged copy of the edge list:
+//   role 1 "pool"      : depth-0 cluster ranks + member lists -> pooled graph (pool_edge) -> CSC1
+//   role 2 "structure" : node-feature gather, CSR0 / CSC0 (+ edge weights), depth-0 cluster count, depth-1 clusters + members
+// (round 1 had CSR0 / CSC0 in front of the pooling chain, ~41 k stamped cycles against ~29 k for the member lists; the
+// pooled graph only needs (cluster(row), cluster(col)) of the RAW edges, so CSR0 / CSC0 moved to the other chain and the
+// depth-0 member lists came over in exchange: ~37 k / ~38 k.)
 #define TOPO_ROLE_ALL 0
-#define TOPO_ROLE_EDGES 1
-#define TOPO_ROLE_MEMBERS 2
+#define TOPO_ROLE_EDGES 1        // "pool"
+#define TOPO_ROLE_MEMBERS 2      // "structure"
 
-DEV void topo_members(const TopoView& tv, const TopoArgs& a, int g, int n0, int N, TopoScratch& s, int sidx) {
-    const int rowbase = n0 + g;
-    const TopoSrc src = topo_src(a, g, n0, 0);
-    topo_gather_rows(a, src, g, n0, N);
-    FOR_TID(v, s.capF) { s.fl[v] = 0; }
-    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
-    BARRIER();
-    const int C = wg_cluster_rank(tv, sidx, src.cl0, N, s, true);
-    int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
-    int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
-    int32_t* g_mem0 = tv.p[DRGNN_TI_MEM0] + n0;
-    FOR_TID(i, N) { g_cl0[i] = s.cl[i]; g_mem0[i] = s.mem[i]; }
-    FOR_TID(c, C + 1) { g_mptr0[c] = s.mp[c]; }
-    FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
-    FOR_TID(v, s.capF) { s.fl[v] = 0; }
-    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
-    BARRIER();
-    if (a.cluster1 != nullptr && a.c1_ptr != nullptr) {
-        const int b = a.c1_ptr[g];
-        topo_graph_level1(tv, a, g, n0, C, src.cl1, a.c1_ptr[g + 1] - b, s, sidx, true);
-    }
-}
-
-DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1, int e0, int e1,
-                    TopoScratch& s, int role = TOPO_ROLE_ALL) {
-    const int N = n1 - n0;
-    int E = e1 - e0;
-    const int rowbase = n0 + g;
-    const int sidx = (role == TOPO_ROLE_MEMBERS) ? a.n_graphs + g : g;
-    if (role == TOPO_ROLE_MEMBERS) {
-        if (a.cluster0 != nullptr) topo_members(tv, a, g, n0, N, s, sidx);
-        return;
-    }
-    if (N <= 0 && E > 0) {
-        FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_EDGE_RANGE, g); }
-        E = 0;
-    }
-    PHASE_MARK();
-    const TopoSrc src = topo_src(a, g, n0, e0);
-    if (role == TOPO_ROLE_ALL) topo_gather_rows(a, src, g, n0, N);
+// ---- the edge list of the graph, once: int64 global ids -> int32 local (s.er, s.ec), weights by edge id (s.w0) ----
+DEV void topo_stage_edges(const TopoView& tv, const TopoSrc& src, int g, int N, int E, bool has_w, TopoScratch& s) {
     const int64_t* src_row = src.row;
     const int64_t* src_col = src.col;
     const long long shift = src.shift;
     const int Nm1 = N - 1;
-    int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
-    int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
-    int32_t* g_eid0 = tv.p[DRGNN_TI_EID0] + e0;
-    float* g_w0 = tv.w0 ? tv.w0 + e0 : nullptr;
-    float* g_w1 = tv.w1 ? tv.w1 + e0 : nullptr;
-    const bool has_w = (a.edge_attr != nullptr) && (g_w0 != nullptr);
-
-    // ---- stage the edge list once (int64 global ids -> int32 local), clear the histograms ----
-    int* rp = s.rp;             // [N+1]   rows
-    int* cp = s.rp + (N + 1);   // [N+1]   cols, contiguous with rp so ONE scan serves both
-    int* cur_r = s.cur;
-    int* cur_c = s.nb;
     FOR_TID(e, E) {
         long long r = (long long)src_row[e] - shift, c = (long long)src_col[e] - shift;
         if (r < 0 || r > Nm1 || c < 0 || c > Nm1) {
@@ -467,14 +421,22 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         }
         s.er[e] = (int)r;
         s.ec[e] = (int)c;
+        if (has_w) s.w0[e] = src.attr[e];
     }
-    FOR_TID(i, 2 * N + 2) { rp[i] = 0; }
-    FOR_TID(i, N + 1) { cur_r[i] = 0; }
-    FOR_TID(i, N) { cur_c[i] = 0; }
-    FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-0 cluster ranks
-    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
-    BARRIER();
-    // ---- CSR0 and CSC0 together: histogram, one scan, slot claim, rank sort by edge id ------
+}
+
+// ---- CSR0 and CSC0 together: histogram, one scan, slot claim, rank sort by edge id.  Needs the staged edges; the
+// caller has cleared rp[0 .. 2N+2), cur[0 .. N], nb[0 .. N) in an earlier phase.  Ends with a barrier. ----
+DEV void topo_csr0(const TopoView& tv, int g, int n0, int e0, int N, int E, bool has_w, TopoScratch& s) {
+    const int rowbase = n0 + g;
+    int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
+    int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
+    int32_t* g_eid0 = tv.p[DRGNN_TI_EID0] + e0;
+    float* g_w0 = tv.w0 ? tv.w0 + e0 : nullptr;
+    int* rp = s.rp;             // [N+1]   rows
+    int* cp = s.rp + (N + 1);   // [N+1]   cols, contiguous with rp so ONE scan serves both
+    int* cur_r = s.cur;
+    int* cur_c = s.nb;
     FOR_TID(e, E) {
         ATOMIC_ADD(&rp[s.er[e]], 1);
         ATOMIC_ADD(&cp[s.ec[e]], 1);
@@ -506,13 +468,10 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     BARRIER();
     FOR_TID(k, E) {
         const int e = s.t3[k];
-        const int c = s.ec[e];
-        s.col[k] = c;
-        s.seg[k] = s.er[e];
         s.t5[e] = k;                                   // edge -> CSR0 slot
-        g_col0[k] = c;
+        g_col0[k] = s.ec[e];
         g_eid0[k] = e;
-        if (has_w) { const float w = src.attr[e]; s.w0[k] = w; g_w0[k] = w; }
+        if (has_w) g_w0[k] = s.w0[e];
     }
     {
         int32_t* g_colptr0 = tv.p[DRGNN_TI_COLPTR0] + rowbase;
@@ -528,29 +487,18 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
             g_tslot0[j] = s.t5[e];
         }
     }
+    BARRIER();
+}
 
-    if (a.cluster0 == nullptr) {          // graph-only build (stand-alone conv layers): no pooling
-        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = 0; tv.p[DRGNN_TI_NE1][g] = 0; tv.p[DRGNN_TI_NC1][g] = 0; }
-        BARRIER();
-        return;
-    }
-    // ---- depth-0 clusters (touches t1, t2, cur, fl, cl, mp, mem only) ----------------------
-    const bool members = (role == TOPO_ROLE_ALL);
-    const int C = wg_cluster_rank(tv, g, src.cl0, N, s, true, members);
-    if (members) {
-        int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
-        int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
-        int32_t* g_mem0 = tv.p[DRGNN_TI_MEM0] + n0;
-        FOR_TID(i, N) { g_cl0[i] = s.cl[i]; g_mem0[i] = s.mem[i]; }
-        FOR_TID(c, C + 1) { g_mptr0[c] = s.mp[c]; }
-        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
-    }
-
-    // ---- pool_edge --------------------------------------------------------------------------
-    // Without edge weights the pooled graph is just the SET of (cluster(row), cluster(col)) pairs of
-    // the edges minus self loops: every pooled row keeps a bitmap of its target clusters (LDS atomic
-    // OR, order independent), the sorted unique targets are its set bits in ascending order.  No
-    // sorting at all; used whenever the C x ceil(C/32) words fit the sort scratch.
+// ---- pool_edge + CSC1 from the RAW staged edges and the depth-0 cluster ranks s.cl[0..N) (C clusters) -------------
+// Without edge weights the pooled graph is just the SET of (cluster(row), cluster(col)) pairs of the edges minus self
+// loops: every pooled row keeps a bitmap of its target clusters (LDS atomic OR, order independent), the sorted unique
+// targets are its set bits in ascending order.  No sorting at all; used whenever the C x ceil(C/32) words fit the sort
+// scratch.  With weights: the edges are bucketed by pooled row, every bucket ranked by (target cluster, edge id), runs of
+// equal target are the coalesced pooled edges and their weights are summed in that (fixed) order.
+DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool has_w, TopoScratch& s) {
+    const int rowbase = n0 + g;
+    float* g_w1 = tv.w1 ? tv.w1 + e0 : nullptr;
     const int BW = (C + 31) >> 5;
     const bool bitmap = !has_w && (long)C * BW + 1 <= (long)s.capT;
     int E1;
@@ -560,11 +508,9 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         int* bm = s.t1;          // [C][BW] target bitmaps
         int* pre = s.t2;         // [C*BW + 1] set bits before each word
         FOR_TID(q, C * BW) { bm[q] = 0; }
-        FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-1 cluster ranks
-        FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
         BARRIER();
-        FOR_TID(k, E) {
-            const int r = s.cl[s.seg[k]], cc = s.cl[s.col[k]];
+        FOR_TID(e, E) {
+            const int r = s.cl[s.er[e]], cc = s.cl[s.ec[e]];
             if (cc != r) ATOMIC_OR(&bm[r * BW + (cc >> 5)], (int)(1u << (cc & 31)));
         }
         BARRIER();
@@ -579,7 +525,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
                 const int b = __builtin_ctz(bits);
                 bits &= bits - 1;
                 s.col1[slot] = base_col + b;
-                s.seg[slot] = r;               // row of pooled CSR slot (s.seg is free again)
+                s.seg[slot] = r;               // row of pooled CSR slot
                 g_col1[slot] = base_col + b;
                 ++slot;
             }
@@ -594,83 +540,143 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
         BARRIER();
     } else {
-    // weighted (or very large) graphs: bucket the CSR0 slots by the pooled row of their source node
-    // (stable: slot order = (member, edge) order), then rank every bucket by (target cluster, slot)
-    FOR_TID(r, C + 1) { s.pp[r] = 0; s.cur[r] = 0; }
-    FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-1 cluster ranks
-    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
-    BARRIER();
-    FOR_TID(k, E) { ATOMIC_ADD(&s.pp[s.cl[s.seg[k]]], 1); }
-    BARRIER();
-    wg_exscan(s.pp, C + 1, s.part);
-    FOR_TID(k, E) {                                   // one work item per CSR0 slot
-        const int r = s.cl[s.seg[k]];
-        const int cc = s.cl[s.col[k]];
-        const int j = s.pp[r] + ATOMIC_ADD(&s.cur[r], 1);
-        s.t1[j] = (cc == r) ? INT_MAX : cc;           // self loop of the pooled graph: dropped
-        s.t2[j] = k;
-        s.t3[j] = r;
-    }
-    BARRIER();
-    // rank sort of every pooled row's candidates by (target cluster, CSR0 slot)
-    FOR_TID(j, E) {
-        const int r = s.t3[j];
-        const int key = s.t1[j], slot = s.t2[j];
-        const int lo = s.pp[r], hi = s.pp[r + 1];
-        int rank = 0;
-        for (int q = lo; q < hi; ++q) {
-            const int kq = s.t1[q];
-            rank += (kq < key || (kq == key && s.t2[q] < slot)) ? 1 : 0;
+        FOR_TID(r, C + 1) { s.pp[r] = 0; s.cur[r] = 0; }
+        BARRIER();
+        FOR_TID(e, E) { ATOMIC_ADD(&s.pp[s.cl[s.er[e]]], 1); }
+        BARRIER();
+        wg_exscan(s.pp, C + 1, s.part);
+        FOR_TID(e, E) {                                   // one work item per edge
+            const int r = s.cl[s.er[e]];
+            const int cc = s.cl[s.ec[e]];
+            const int j = s.pp[r] + ATOMIC_ADD(&s.cur[r], 1);
+            s.t1[j] = (cc == r) ? INT_MAX : cc;           // self loop of the pooled graph: dropped
+            s.t2[j] = e;
+            s.t3[j] = r;
         }
-        s.t4[lo + rank] = key;
-        s.t5[lo + rank] = slot;
-    }
-    BARRIER();
-    // heads of runs of equal target = the coalesced pooled edges, already (row, col) sorted
-    FOR_TID(j, E + 1) {
-        int head = 0;
-        if (j < E) {
+        BARRIER();
+        // rank sort of every pooled row's candidates by (target cluster, edge id)
+        FOR_TID(j, E) {
+            const int r = s.t3[j];
+            const int key = s.t1[j], id = s.t2[j];
+            const int lo = s.pp[r], hi = s.pp[r + 1];
+            int rank = 0;
+            for (int q = lo; q < hi; ++q) {
+                const int kq = s.t1[q];
+                rank += (kq < key || (kq == key && s.t2[q] < id)) ? 1 : 0;
+            }
+            s.t4[lo + rank] = key;
+            s.t5[lo + rank] = id;
+        }
+        BARRIER();
+        // heads of runs of equal target = the coalesced pooled edges, already (row, col) sorted
+        // (t3[j] = pooled row of sorted position j: positions of a bucket stay inside the bucket)
+        FOR_TID(j, E + 1) {
+            int head = 0;
+            if (j < E) {
+                const int key = s.t4[j];
+                head = (key != INT_MAX && (j == s.pp[s.t3[j]] || s.t4[j - 1] != key)) ? 1 : 0;
+            }
+            s.t1[j] = head;
+        }
+        BARRIER();
+        E1 = wg_exscan(s.t1, E + 1, s.part);
+        FOR_TID(j, E) {
             const int key = s.t4[j];
-            head = (key != INT_MAX && (j == s.pp[s.t3[j]] || s.t4[j - 1] != key)) ? 1 : 0;
-        }
-        s.t1[j] = head;
-    }
-    BARRIER();
-    E1 = wg_exscan(s.t1, E + 1, s.part);
-    FOR_TID(j, E) {
-        const int key = s.t4[j];
-        const int r = s.t3[j];
-        if (key != INT_MAX && (j == s.pp[r] || s.t4[j - 1] != key)) {
-            const int slot = s.t1[j];
-            s.col1[slot] = key;
-            s.seg[slot] = r;               // row of pooled CSR slot (s.seg is free again)
-            g_col1[slot] = key;
-            if (has_w) {
-                const int hi = s.pp[r + 1];
-                float w = 0.0f;
-                for (int q = j; q < hi && s.t4[q] == key; ++q) w += s.w0[s.t5[q]];
-                g_w1[slot] = w;
+            const int r = s.t3[j];
+            if (key != INT_MAX && (j == s.pp[r] || s.t4[j - 1] != key)) {
+                const int slot = s.t1[j];
+                s.col1[slot] = key;
+                s.seg[slot] = r;               // row of pooled CSR slot
+                g_col1[slot] = key;
+                if (has_w) {
+                    const int hi = s.pp[r + 1];
+                    float w = 0.0f;
+                    for (int q = j; q < hi && s.t4[q] == key; ++q) w += s.w0[s.t5[q]];
+                    g_w1[slot] = w;
+                }
             }
         }
+        FOR_TID(r, C + 1) {
+            const int v = s.t1[s.pp[r]];
+            s.rp1[r] = v;
+            g_rowptr1[r] = v;
+            s.cp[r] = 0;                                          // histogram / cursors of the CSC1 build
+            s.cur[r] = 0;
+        }
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
+        BARRIER();
     }
-    FOR_TID(r, C + 1) {
-        const int v = s.t1[s.pp[r]];
-        s.rp1[r] = v;
-        g_rowptr1[r] = v;
-        s.cp[r] = 0;                                          // histogram / cursors of the CSC1 build
-        s.cur[r] = 0;
-    }
-    FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
-    BARRIER();
-    }
-
-    // ---- CSC1 ----------------------------------------------------------------------
     wg_csc_build(C, E1, s.col1, s.seg, s, tv.p[DRGNN_TI_COLPTR1] + rowbase,
                  tv.p[DRGNN_TI_ROWIDX1] + e0, tv.p[DRGNN_TI_TSLOT1] + e0, true);
+}
 
-    // ---- depth-1 clusters (when the caller knows where this graph's ids start) --------
-    if (role == TOPO_ROLE_ALL && a.cluster1 != nullptr && a.c1_ptr != nullptr) {
-        const int b = a.c1_ptr[g];
-        topo_graph_level1(tv, a, g, n0, C, src.cl1, a.c1_ptr[g + 1] - b, s, g, true);
+// depth-0 cluster ranks; with_members: + member lists, both written out.  Returns C.
+DEV int topo_clusters0(const TopoView& tv, int g, int n0, int N, const TopoSrc& src, TopoScratch& s, int sidx,
+                       bool with_members) {
+    const int rowbase = n0 + g;
+    const int C = wg_cluster_rank(tv, sidx, src.cl0, N, s, true, with_members);
+    if (with_members) {
+        int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
+        int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
+        int32_t* g_mem0 = tv.p[DRGNN_TI_MEM0] + n0;
+        FOR_TID(i, N) { g_cl0[i] = s.cl[i]; g_mem0[i] = s.mem[i]; }
+        FOR_TID(c, C + 1) { g_mptr0[c] = s.mp[c]; }
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
     }
+    return C;
+}
+// depth-1 clusters + member lists of a graph with C depth-0 clusters (when the caller located this graph's ids)
+DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, int C, const TopoSrc& src, TopoScratch& s,
+                        int sidx) {
+    if (a.cluster1 == nullptr || a.c1_ptr == nullptr) return;
+    FOR_TID(v, s.capF) { s.fl[v] = 0; }
+    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+    BARRIER();
+    const int b = a.c1_ptr[g];
+    topo_graph_level1(tv, a, g, n0, C, src.cl1, a.c1_ptr[g + 1] - b, s, sidx, true);
+}
+
+DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1, int e0, int e1,
+                    TopoScratch& s, int role = TOPO_ROLE_ALL) {
+    const int N = n1 - n0;
+    int E = e1 - e0;
+    const int sidx = (role == TOPO_ROLE_MEMBERS) ? a.n_graphs + g : g;
+    if (N <= 0 && E > 0) {
+        FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_EDGE_RANGE, sidx); }
+        E = 0;
+    }
+    PHASE_MARK();
+    const TopoSrc src = topo_src(a, g, n0, e0);
+    const bool has_w = (a.edge_attr != nullptr) && (tv.w0 != nullptr);
+    const bool structure = (role != TOPO_ROLE_EDGES);      // CSR0 / CSC0, member lists, node-feature gather
+    const bool pool = (role != TOPO_ROLE_MEMBERS);         // pooled graph
+    if (structure) topo_gather_rows(a, src, g, n0, N);
+
+    // ---- phase 0: stage the edge list, clear what the next phases accumulate into ----
+    topo_stage_edges(tv, src, sidx, N, E, has_w, s);
+    if (structure) {
+        FOR_TID(i, 2 * N + 2) { s.rp[i] = 0; }
+        FOR_TID(i, N + 1) { s.cur[i] = 0; }
+        FOR_TID(i, N) { s.nb[i] = 0; }
+    }
+    FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-0 cluster ranks
+    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+    BARRIER();
+
+    if (structure) topo_csr0(tv, g, n0, e0, N, E, has_w, s);
+    if (a.cluster0 == nullptr) {          // graph-only build (stand-alone conv layers): no pooling
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = 0; tv.p[DRGNN_TI_NE1][g] = 0; tv.p[DRGNN_TI_NC1][g] = 0; }
+        BARRIER();
+        return;
+    }
+    if (role == TOPO_ROLE_MEMBERS) {       // structure: only the cluster COUNT of depth 0 is needed for depth 1
+        const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, false);
+        topo_clusters1(tv, a, g, n0, C, src, s, sidx);
+        return;
+    }
+    // pool (or everything): ranks + member lists of depth 0, then the pooled graph
+    const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, true);
+    BARRIER();
+    topo_pool(tv, g, n0, e0, E, C, has_w, s);
+    if (role == TOPO_ROLE_ALL) topo_clusters1(tv, a, g, n0, C, src, s, g);
 }

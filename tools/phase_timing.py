@@ -9,7 +9,7 @@ from deeprank_gnn_amd.ginet import GINet
 from deeprank_gnn_amd.sGAT import sGAT
 
 kind_name = sys.argv[1] if len(sys.argv) > 1 else "GINet"
-api = _lib.Api(os.path.join(os.path.dirname(_lib.LIB_PATH), "libdrgnn_prof.so"))
+api = _lib.Api(os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("DRGNN_PROF_LIB", "libdrgnn_prof.so")))
 api.lib.drgnn_debug_set_phase_buffer.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
 buf = torch.zeros(4100, dtype=torch.int64, device=dev)
