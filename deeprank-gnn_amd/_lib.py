@@ -86,6 +86,12 @@ class EpochPlan(ctypes.Structure):
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p)
 
 
+class StepHints(ctypes.Structure):
+    """drgnn_step_hints: host-side offset tables of a launch's graphs (pointers to HOST memory)."""
+    _fields_ = [("host_node_ptr", _vp), ("host_edge_ptr", _vp), ("set_node_ptr", _vp), ("set_edge_ptr", _vp),
+                ("host_ids", _vp)]
+
+
 class TopologyCacheDesc(ctypes.Structure):
     """drgnn_topology_cache: one topology workspace over a whole resident set + its node features / targets."""
     _fields_ = [("n_graphs", _c_i64), ("n_nodes", _c_i64), ("n_edges", _c_i64),
@@ -158,10 +164,10 @@ class Api(object):
         lib.drgnn_head_compact_elems.restype = _c_i64
         lib.drgnn_net_train_step.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc)] + [_vp] * 5 +
                                              [_c_i64] * 3 + [_c_i32] * 3 + [_vp] * 5 +
-                                             [ctypes.POINTER(TopologyRequest), _vp])
+                                             [ctypes.POINTER(TopologyRequest), ctypes.POINTER(StepHints), _vp])
         lib.drgnn_net_train_step_cached.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc),
                                                      ctypes.POINTER(TopologyCacheDesc), _vp, _c_i64] + [_c_i32] * 3 +
-                                                    [_vp] * 7)
+                                                    [_vp] * 6 + [ctypes.POINTER(StepHints), _vp])
         lib.drgnn_step_update.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] +
                                           [ctypes.POINTER(ConvGrads)] * 2 + [_vp, _vp] + [_c_i32] * 3 +
                                           [_c_i64] + [_vp] * 4 + [_c_i64] + [_vp] * 2 +
@@ -297,19 +303,22 @@ class Api(object):
 
     def net_train_step(self, desc, head, x, target, step2, ws_i32, ws_f32, n_nodes, n_edges, n_graphs,
                        max_nodes, max_edges, max_c0, pred, readout, head_partials, partials, xchg, stream,
-                       next_topology=None):
+                       next_topology=None, hints=None):
         _check(self.lib.drgnn_net_train_step(
             ctypes.byref(desc), ctypes.byref(head), _ptr(x), _ptr(target), _ptr(step2), _ptr(ws_i32),
             _ptr(ws_f32), n_nodes, n_edges, n_graphs, max_nodes, max_edges, max_c0, _ptr(pred), _ptr(readout),
             _ptr(head_partials), _ptr(partials), _ptr(xchg),
-            None if next_topology is None else ctypes.byref(next_topology), stream), "drgnn_net_train_step")
+            None if next_topology is None else ctypes.byref(next_topology),
+            None if hints is None else ctypes.byref(hints), stream), "drgnn_net_train_step")
 
     def net_train_step_cached(self, desc, head, cache, ids, n_graphs, max_nodes, max_edges, max_c0, step2, pred,
-                              readout, head_partials, partials, xchg, stream):
+                              readout, head_partials, partials, xchg, stream, hints=None):
         _check(self.lib.drgnn_net_train_step_cached(
             ctypes.byref(desc), ctypes.byref(head), ctypes.byref(cache), _ptr(ids), n_graphs, max_nodes, max_edges,
-            max_c0, _ptr(step2), _ptr(pred), _ptr(readout), _ptr(head_partials), _ptr(partials), _ptr(xchg), stream),
+            max_c0, _ptr(step2), _ptr(pred), _ptr(readout), _ptr(head_partials), _ptr(partials), _ptr(xchg),
+            None if hints is None else ctypes.byref(hints), stream),
             "drgnn_net_train_step_cached")
+
 
     def step_update(self, desc, conv_partials, n_graphs, g1, g2, head_partials, readout, R, H, O, head_offset,
                     flat_p, flat_g, exp_avg, exp_avg_sq, step2, loss, lr, beta1, beta2, eps, stream,
@@ -477,3 +486,20 @@ def current_stream(ref):
     if ref.is_cuda:
         return torch.cuda.current_stream(ref.device).cuda_stream
     return None
+
+
+def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None):
+    """(StepHints, keep-alive tuple) from numpy arrays: int32 per-mini-batch tables, or int64 set tables + int32 ids."""
+    import numpy as np
+    h = StepHints()
+    keep = []
+
+    def pin(a, dtype):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(np.asarray(a, dtype=dtype))
+        keep.append(a)
+        return a.ctypes.data
+    h.host_node_ptr, h.host_edge_ptr = pin(node_ptr, np.int32), pin(edge_ptr, np.int32)
+    h.set_node_ptr, h.set_edge_ptr, h.host_ids = pin(set_node_ptr, np.int64), pin(set_edge_ptr, np.int64), pin(ids, np.int32)
+    return h, tuple(keep)

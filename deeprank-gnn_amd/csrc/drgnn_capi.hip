@@ -556,7 +556,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
                            const int32_t* gather_ids, int32_t max_nodes,
                            int32_t max_edges, int32_t max_c0, float* pred, float* readout,
                            float* head_partials, float* partials, uint64_t* xchg,
-                           const drgnn_topology_request* next, void* stream_) {
+                           const drgnn_topology_request* next, const drgnn_step_hints* hints, void* stream_) {
     int rc = net_check(net);
     if (rc) return rc;
     if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2 || !x || !step2 || !ws_i32 || !pred || !readout)
@@ -579,6 +579,32 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     topo_layout(n_nodes, n_edges, ws_graphs, &lay);
     StepArgs& a = L.a;
     a.gather_ids = gather_ids; a.ws_graphs = (int)ws_graphs;
+    L.dims.count = 0;
+    if (hints && n_graphs > 0 && n_graphs <= DRGNN_STEP_DIMS_MAX) {
+        StepDims& D = L.dims;
+        bool ok = true;
+        if (!gather_ids && hints->host_node_ptr && hints->host_edge_ptr) {
+            for (int g = 0; g < (int)n_graphs; ++g) {
+                D.n0[g] = hints->host_node_ptr[g]; D.n[g] = hints->host_node_ptr[g + 1] - hints->host_node_ptr[g];
+                D.e0[g] = hints->host_edge_ptr[g]; D.e[g] = hints->host_edge_ptr[g + 1] - hints->host_edge_ptr[g];
+                D.gi[g] = g;
+                ok = ok && D.n[g] >= 0 && D.e[g] >= 0 && D.n[g] <= L.capN && D.e[g] <= L.capE;
+            }
+            if (ok && (hints->host_node_ptr[n_graphs] != n_nodes || hints->host_edge_ptr[n_graphs] != n_edges)) ok = false;
+        } else if (gather_ids && hints->host_ids && hints->set_node_ptr && hints->set_edge_ptr) {
+            for (int g = 0; g < (int)n_graphs; ++g) {
+                const int64_t id = hints->host_ids[g];
+                if (id < 0 || id >= ws_graphs) { ok = false; break; }
+                D.n0[g] = (int32_t)hints->set_node_ptr[id]; D.n[g] = (int32_t)(hints->set_node_ptr[id + 1] - hints->set_node_ptr[id]);
+                D.e0[g] = (int32_t)hints->set_edge_ptr[id]; D.e[g] = (int32_t)(hints->set_edge_ptr[id + 1] - hints->set_edge_ptr[id]);
+                D.gi[g] = (int32_t)id;
+                ok = ok && D.n[g] <= L.capN && D.e[g] <= L.capE;
+            }
+        } else {
+            ok = false;
+        }
+        if (ok) D.count = (int)n_graphs;       // (a table that contradicts the capacities is ignored: the device path decides)
+    }
     a.net = *net; a.x = x;
     a.tv = topo_view(const_cast<int32_t*>(ws_i32), const_cast<float*>(ws_f32), lay);
     a.n_nodes = n_nodes; a.n_graphs = (int)n_graphs;
@@ -674,22 +700,23 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* hd, c
                          int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
                          int32_t max_edges, int32_t max_c0, float* pred, float* readout,
                          float* head_partials, float* partials, uint64_t* xchg,
-                         const drgnn_topology_request* next, void* stream_) {
+                         const drgnn_topology_request* next, const drgnn_step_hints* hints, void* stream_) {
     return train_step_impl(net, hd, x, target, step2, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, n_graphs, nullptr,
-                           max_nodes, max_edges, max_c0, pred, readout, head_partials, partials, xchg, next, stream_);
+                           max_nodes, max_edges, max_c0, pred, readout, head_partials, partials, xchg, next, hints, stream_);
 }
 
 int drgnn_net_train_step_cached(const drgnn_net_desc* net, const drgnn_head_desc* hd,
                                 const drgnn_topology_cache* cache, const int32_t* ids, int64_t n_graphs,
                                 int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t* step2, float* pred,
-                                float* readout, float* head_partials, float* partials, uint64_t* xchg, void* stream_) {
+                                float* readout, float* head_partials, float* partials, uint64_t* xchg,
+                                const drgnn_step_hints* hints, void* stream_) {
     if (!cache || !ids || !cache->ws_i32 || !cache->x || n_graphs < 0 || n_graphs > cache->n_graphs) return DRGNN_E_ARG;
     if (hd && hd->train) {
         if (!cache->y || cache->y_bytes != (hd->task == DRGNN_TASK_REG ? 4 : 8)) return DRGNN_E_ARG;
     }
     return train_step_impl(net, hd, cache->x, cache->y, step2, cache->ws_i32, cache->ws_f32, cache->n_nodes,
                            cache->n_edges, n_graphs, cache->n_graphs, ids, max_nodes, max_edges, max_c0, pred, readout,
-                           head_partials, partials, xchg, nullptr, stream_);
+                           head_partials, partials, xchg, nullptr, hints, stream_);
 }
 
 int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int64_t n_nodes,
@@ -1346,9 +1373,11 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
             if ((rc = epoch_batch(p, k, &b))) return rc;
             drgnn_topology_cache tc = *p->cache;
             if (!train) tc.y = nullptr;
+            drgnn_step_hints hints = {};
+            hints.set_node_ptr = p->host_node_ptr; hints.set_edge_ptr = p->host_edge_ptr; hints.host_ids = p->host_ids + b.first;
             rc = drgnn_net_train_step_cached(p->net, &head, &tc, p->ids + b.first, b.B, b.maxN, b.maxE, b.maxC, p->step2,
                                              pred + b.first * hd->O, c.readout, train ? c.head_partials : nullptr,
-                                             train ? c.partials : nullptr, c.xchg, stream);
+                                             train ? c.partials : nullptr, c.xchg, &hints, stream);
             if (rc) return rc;
             if (!train) continue;
             if ((rc = epoch_update(p, c, b.B, k, losses, stream))) return rc;
@@ -1383,10 +1412,23 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
             if ((rc = epoch_batch(p, k + 1, &nxt))) return rc;
             req = request(k + 1, nxt);
         }
+        // the slot offsets of this mini-batch are known here (host size tables): hand them to the launch
+        drgnn_step_hints hints = {};
+        std::vector<int32_t> hn, he;
+        if (cur.B <= DRGNN_STEP_DIMS_MAX) {
+            hn.resize((size_t)cur.B + 1); he.resize((size_t)cur.B + 1);
+            hn[0] = 0; he[0] = 0;
+            for (int64_t q = 0; q < cur.B; ++q) {
+                const int64_t id = p->host_ids[cur.first + q];
+                hn[q + 1] = hn[q] + (int32_t)(p->host_node_ptr[id + 1] - p->host_node_ptr[id]);
+                he[q + 1] = he[q] + (int32_t)(p->host_edge_ptr[id + 1] - p->host_edge_ptr[id]);
+            }
+            hints.host_node_ptr = hn.data(); hints.host_edge_ptr = he.data();
+        }
         rc = drgnn_net_train_step(p->net, &head, t.x, train ? t.y : nullptr, p->step2, t.ws_i32, t.ws_f32, cur.N, cur.E,
                                   cur.B, cur.maxN, cur.maxE, cur.maxC, pred + cur.first * hd->O, c.readout,
                                   train ? c.head_partials : nullptr, train ? c.partials : nullptr, c.xchg,
-                                  more ? &req : nullptr, stream);
+                                  more ? &req : nullptr, &hints, stream);
         if (rc) return rc;
         if (!train) { if (more) cur = nxt; continue; }
         if ((rc = epoch_update(p, c, cur.B, k, losses, stream))) return rc;

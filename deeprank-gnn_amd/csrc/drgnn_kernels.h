@@ -270,10 +270,20 @@ DEV void net_block(const NetLaunch& L, int blk, float* lds) {
 
 // ---- fused training step (drgnn_step.h): one launch for body fwd + head/loss + body bwd, sharing the
 // grid with the topology builder of the next mini-batch exactly like CoLaunch above ---------------
+// Offsets and sizes of the launch's graphs when the HOST knows them (mini-batches assembled from host-side size tables:
+// Batch.from_data_list, the resident set's epoch loops): carried in the kernel arguments, so a workgroup does not have
+// to fetch them from the workspace before it can address anything (one dependent memory round trip less).
+#define DRGNN_STEP_DIMS_MAX 64
+struct StepDims {
+    int count;                              // 0: not supplied (sizes come from the workspace tables)
+    int32_t n0[DRGNN_STEP_DIMS_MAX], n[DRGNN_STEP_DIMS_MAX], e0[DRGNN_STEP_DIMS_MAX], e[DRGNN_STEP_DIMS_MAX];
+    int32_t gi[DRGNN_STEP_DIMS_MAX];        // cached-topology mode: the graph's number in the set
+};
 struct StepLaunch {
     StepArgs a;
     int capN, capE, capC;
     int64_t words;          // scratch words per workgroup (emulation: one persistent slab each)
+    StepDims dims;
 };
 struct StepCoLaunch {
     StepLaunch step;
@@ -293,6 +303,22 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
     if (nb == 2) { g = ((blk >> 4) << 3) + (blk & 7); br = (blk >> 3) & 1; }
     else { g = blk; br = 0; }
     if (g >= L.a.n_graphs) return;                // padding of the last group of 8 graphs
+    if (L.dims.count > 0) {
+        // host-supplied offsets / sizes: everything the prologue needs to address its loads is in the kernel arguments;
+        // the device-computed counts are requested here and resolved inside (late)
+        const int gi = GATHER ? L.dims.gi[g] : g;
+        GraphDims d;
+        d.n0 = L.dims.n0[g]; d.N = L.dims.n[g]; d.e0 = L.dims.e0[g]; d.E = L.dims.e[g];
+        d.rowbase = d.n0 + gi;
+        d.C = 0; d.E1 = 0; d.C1 = 0;
+        const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
+        // (N <= capN, E <= capE hold by construction: the host derived the capacities from the same table; a cluster
+        // count beyond capC can only come from malformed input, which the builder has flagged: such graphs poison
+        // their outputs through the status words like any other bad graph, and the loads below stay inside LDS because
+        // their bounds are clamped to the capacities)
+        net_step_graph<KIND, XF, GATHER>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, part, true, cnt_c, cnt_e1, cnt_c1);
+        return;
+    }
     const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;      // cached mode: graph number in the set
     const GraphDims d = net_dims(L.a.tv, gi);     // ONE round trip for all per-graph sizes
     if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {

@@ -943,9 +943,21 @@ static inline bool step_burst_guaranteed(int kind, const float* x, int F, int ca
 // XF: padded feature width F16 as a compile-time constant (16/32/48/64), 0 = taken from the descriptor.
 // The strides of the x tile and of conv1's weights and the K loop of conv1's products hang on it;
 // with it known the kernel is ~8% faster, so the common widths are instantiated.
+// `late`: the graph's offsets and sizes (d_in.n0 / N / e0 / E) came with the launch arguments (host-known) and its
+// device-computed counts (clusters of both depths, pooled edges) are still IN FLIGHT in cnt_c / cnt_e1 / cnt_c1: the
+// prologue then issues its loads with host-known bounds and resolves the counts afterwards -- one dependent memory round
+// trip less at the start of every workgroup (sizes -> arrays becomes a single wave of loads).
 template <int KIND, int XF, bool GATHER = false>
-DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, int br, float* scratch, int capN,
-                        int capE, int capC, int part) {
+DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi, int br, float* scratch, int capN,
+                        int capE, int capC, int part, bool late = false, int cnt_c = 0, int cnt_e1 = 0, int cnt_c1 = 0) {
+    GraphDims d = d_in;
+    // bounds of the prologue's loads of the pooled level: the true counts, or (late) what the host knows they cannot
+    // exceed while staying inside this graph's workspace segment and the LDS arrays
+    const int bC = late ? imin(d.N, capC) : d.C, bE1 = late ? d.E : d.E1, bC1 = late ? imin(d.N, capC) : d.C1;
+#ifdef DRGNN_EMU
+    // the emulation runs a workgroup in two passes (part 1 / part 2): the counts are plain values there, resolve at once
+    if (late) { d.C = imin(cnt_c, capC); d.E1 = imin(cnt_e1, d.E); d.C1 = imin(cnt_c1, capC); }
+#endif
     constexpr int HC1 = (KIND == DRGNN_GINET) ? DRGNN_H1 : 2 * DRGNN_H1;
     constexpr int HC2 = (KIND == DRGNN_GINET) ? DRGNN_H2 : 2 * DRGNN_H2;
     const TopoView& tv = a.tv;
@@ -984,7 +996,10 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, in
         // the plain per-array loops and the generic head routines are compiled out of them -- the kernel image is about
         // twice the instruction cache and every kilobyte of it shows.  The generic kernel decides per graph.
         const bool burst = (XF != 0) ? true
-                                     : (net_burst_ok(xg, F, d.N, d.E, d.C) && O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP);
+                                     : (net_burst_ok(xg, F, d.N, d.E, late ? capC : d.C) && O * H <= 2 * DRGNN_BCAP && H * 8 <= STEP_WB_J * DRGNN_BCAP);
+        if (late && !burst) {      // the plain staging loops need the true counts at once
+            d.C = WG_UNIFORM(cnt_c); d.E1 = WG_UNIFORM(cnt_e1); d.C1 = WG_UNIFORM(cnt_c1);
+        }
         // Burst registers live across the first barrier: the x tile and the conv1 weights are
         // written to LDS at once, conv1's dense product starts, and everything else (index arrays, conv2
         // and head weights) is written to LDS after it -- their memory time hides behind the MFMAs.
@@ -1041,7 +1056,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, in
             }
             bufburst_load(brp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
             bufburst_load(bcx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
-            bufburst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, d.C + 1);
+            bufburst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, bC + 1);
             bufburst_load(bmem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
             if (KIND == DRGNN_SGAT) bufburst_load(bew0, tv.w0 + d.e0, d.E);
             burst_store_x4(bx, s.xs, XLD);
@@ -1097,15 +1112,22 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, in
         }
         BARRIER();
         EXIT_AFTER(1);
+        if (late) {      // the counts have landed with the first burst
+            d.C = WG_UNIFORM(cnt_c); d.E1 = WG_UNIFORM(cnt_e1); d.C1 = WG_UNIFORM(cnt_c1);
+            if (d.C > capC || d.E1 > d.E || d.C1 > capC) {      // malformed input (flagged by the builder): stay inside LDS, poison
+                d.C = imin(d.C, capC); d.E1 = imin(d.E1, d.E); d.C1 = imin(d.C1, capC);
+                m_bad |= 1;
+            }
+        }
 
         // ---- forward ------------------------------------------------------------------
         if (burst) {
             // second burst, in flight behind conv1's product and aggregation: everything the later phases use
             burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
-            bufburst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, d.C + 1);
-            bufburst_load(bcx1, tv.p[DRGNN_TI_COL1] + d.e0, d.E1);
-            bufburst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, d.C1 + 1);
-            bufburst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, d.C);
+            bufburst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1);
+            bufburst_load(bcx1, tv.p[DRGNN_TI_COL1] + d.e0, bE1);
+            bufburst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1);
+            bufburst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, bC);
             step_wblock_load(wreg, hf, br);
             bufburst_load(bhb1, hf.b1, H);
             bufburst_load(bhw2, hf.w2, O * H);
@@ -1113,14 +1135,14 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, in
             if (!LATE3) {
                 bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
                 bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
-                bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
-                bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+                bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1);
+                bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, bE1);
             }
             if (KIND != DRGNN_GINET) {
                 burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
                 bufburst_load(bb2, c2.bias, DRGNN_H2);
             }
-            if (KIND == DRGNN_SGAT) bufburst_load(bew1, tv.w1 + d.e0, d.E1);
+            if (KIND == DRGNN_SGAT) bufburst_load(bew1, tv.w1 + d.e0, bE1);
         }
         PH(1) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t, XLD, s.u1, HC1, dummy);
         if (KIND != DRGNN_GINET) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.ws1t, XLD, s.u1 + DRGNN_H1, HC1, dummy);
@@ -1167,11 +1189,11 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d, int g, int gi, in
             // Requested here, filed two phases later: their registers are not alive during the crowded second burst
             bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
             bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
-            bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, d.C + 1);
-            bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, d.E1);
+            bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1);
+            bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, bE1);
             if (KIND == DRGNN_SGAT) {
                 bufburst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
-                bufburst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, d.E1);
+                bufburst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, bE1);
             }
         }
         PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);

@@ -179,6 +179,9 @@ class Batch(Data):
         d = self.__dict__
         d["_node_ptr"] = ptr(nodes)
         d["_edge_ptr"] = ptr(edges)
+        # host copies (numpy; survive .to(device)): the native step passes them with the launch arguments
+        d["_host_node_ptr"] = d["_node_ptr"].numpy().copy()
+        d["_host_edge_ptr"] = d["_edge_ptr"].numpy().copy()
         d["_max_nodes"] = max(nodes) if nodes else 0
         d["_max_edges"] = max(edges) if edges else 0
         c1 = [g["cluster1"] for g in graphs]

@@ -309,6 +309,8 @@ class ResidentGraphSet(object):
         d["_num_graphs"] = B
         d["_node_ptr"], d["_edge_ptr"] = ptrs[0], ptrs[1]
         d["_max_nodes"], d["_max_edges"] = int(nn.max()), int(ne.max())
+        d["_host_node_ptr"] = _counts_to_ptr(nn).astype(np.int32)
+        d["_host_edge_ptr"] = _counts_to_ptr(ne).astype(np.int32)
         if self.has_c1:
             d["_c1_ptr"] = ptrs[2]
             d["_max_c0"] = int(nc.max())

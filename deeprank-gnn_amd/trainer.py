@@ -171,7 +171,15 @@ class FusedTrainer(object):
                 torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
                 torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
         readout, partials, hp = bk
+        # host copies of the mini-batch's offsets (Batch.from_data_list / the resident set record them): they travel in
+        # the launch arguments, so a workgroup need not fetch them from the workspace first
+        hints = None
+        bd = getattr(batch, "__dict__", {})
+        hn, he = bd.get("_host_node_ptr"), bd.get("_host_edge_ptr")
+        if hn is not None and he is not None and len(hn) == B + 1 and B <= 64:
+            hints = _lib.step_hints(node_ptr=hn, edge_ptr=he)
         return dict(
+            hints=hints,
             x=x, y=y, topo=topo, B=B, n_nodes=n_nodes, xchg=xchg, g1=g1, g2=g2, desc=desc,
             stream=_lib.current_stream(x), pred=torch.empty((B, self.O), dtype=torch.float32, device=dev),
             readout=readout, partials=partials, hp=hp)
@@ -182,7 +190,8 @@ class FusedTrainer(object):
         self.api.net_train_step(c["desc"], self._head_desc(True), c["x"], c["y"], self.step2, t.ws_i32, t.ws_f32,
                                 c["n_nodes"], t.n_edges, c["B"], t.max_nodes, t.max_edges, t.max_c0, c["pred"],
                                 c["readout"], c["hp"], c["partials"], c["xchg"], c["stream"],
-                                next_topology=None if next_topo is None else next_topo.request())
+                                next_topology=None if next_topo is None else next_topo.request(),
+                                hints=None if c.get("hints") is None else c["hints"][0])
 
     def _fused_launch_update(self, c, apply_adam=True, lr=None):
         """Second launch: fixed-order reduction of the slabs (+ dW_fc1 = dhid^T readout) and Adam."""
@@ -238,7 +247,9 @@ class FusedTrainer(object):
                 torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
                 torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
         readout, partials, hp = bk
-        return dict(cache=cache, ids_dev=ids_dev, B=B, bounds=(max_nodes, max_edges, max_c0), xchg=xchg, g1=g1, g2=g2,
+        hints = _lib.step_hints(set_node_ptr=gset.node_ptr, set_edge_ptr=gset.edge_ptr, ids=ids) if B <= 64 else None
+        return dict(hints=hints,
+                    cache=cache, ids_dev=ids_dev, B=B, bounds=(max_nodes, max_edges, max_c0), xchg=xchg, g1=g1, g2=g2,
                     desc=desc, stream=_lib.current_stream(gset.x), readout=readout, partials=partials, hp=hp,
                     pred=torch.empty((B, self.O), dtype=torch.float32, device=dev))
 
@@ -246,7 +257,8 @@ class FusedTrainer(object):
         mn, me, mc = c["bounds"]
         self.api.net_train_step_cached(c["desc"], self._head_desc(train), c["cache"]._desc, c["ids_dev"], c["B"], mn, me, mc,
                                        self.step2, c["pred"], c["readout"], c["hp"] if train else None,
-                                       c["partials"] if train else None, c["xchg"], c["stream"])
+                                       c["partials"] if train else None, c["xchg"], c["stream"],
+                                       hints=None if c.get("hints") is None else c["hints"][0])
 
     def train_step_cached(self, cache, ids, ids_dev=None, apply_adam=True):
         """One optimisation step on the graphs ``ids`` of a cached set: the fused step launch reading the cached
@@ -530,7 +542,8 @@ class FusedTrainer(object):
             api.net_train_step(c["desc"], self._head_desc(False), c["x"], None, self.step2, topo.ws_i32, topo.ws_f32,
                                c["n_nodes"], topo.n_edges, c["B"], topo.max_nodes, topo.max_edges, topo.max_c0,
                                c["pred"], c["readout"], None, None, c["xchg"], c["stream"],
-                               next_topology=None if next_topo is None else next_topo.request())
+                               next_topology=None if next_topo is None else next_topo.request(),
+                               hints=None if c.get("hints") is None else c["hints"][0])
             return c["pred"]
         if next_topo is not None:
             next_topo.rebuild()

@@ -379,6 +379,15 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  * Needs max_nodes/max_edges/max_c0 bounds; returns DRGNN_E_CAPACITY when a graph of that size does
  * not fit the 160 KiB LDS (drgnn_net_step_lds_bytes): use drgnn_net_forward +
  * drgnn_net_backward_fused_head + drgnn_train_update then. */
+/* Optional host-side knowledge about the graphs of a launch (all pointers HOST memory, read during the call):
+ * host_node_ptr / host_edge_ptr [n_graphs + 1] = the mini-batch's node / edge offsets (the tables the topology was built
+ * with); cached mode: host_ids [n_graphs] = the graph numbers and host_node_ptr / host_edge_ptr [set graphs + 1] = the
+ * SET's int64 offset tables.  For up to 64 graphs the offsets then travel in the kernel arguments and a workgroup does
+ * not fetch them from the workspace before it can address its loads (one dependent memory round trip less). */
+typedef struct drgnn_step_hints {
+    const int32_t* host_node_ptr; const int32_t* host_edge_ptr;       /* per mini-batch (drgnn_net_train_step) */
+    const int64_t* set_node_ptr; const int64_t* set_edge_ptr; const int32_t* host_ids;   /* cached mode */
+} drgnn_step_hints;
 int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                  int32_t max_c0, int32_t R, int32_t H, int32_t O);
 int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O);
@@ -392,7 +401,8 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head,
                          int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
                          int32_t max_edges, int32_t max_c0, float* pred, float* readout,
                          float* head_partials, float* partials, uint64_t* xchg,
-                         const drgnn_topology_request* next_topology /* optional */, void* stream);
+                         const drgnn_topology_request* next_topology /* optional */,
+                         const drgnn_step_hints* hints /* optional */, void* stream);
 /* drgnn_train_update for the slabs of drgnn_net_train_step: also forms dW_fc1 from head_partials'
  * dhid rows and readout, applies Adam with step index step2[1] and commits step2[0] = step2[1]
  * (also when apply_adam = 0: data parallel, all-reduce + drgnn_adam_step(step2) follow). */
@@ -475,7 +485,8 @@ typedef struct drgnn_topology_cache {
 int drgnn_net_train_step_cached(const drgnn_net_desc* net, const drgnn_head_desc* head,
                                 const drgnn_topology_cache* cache, const int32_t* ids, int64_t n_graphs,
                                 int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t* step2, float* pred,
-                                float* readout, float* head_partials, float* partials, uint64_t* xchg, void* stream);
+                                float* readout, float* head_partials, float* partials, uint64_t* xchg,
+                                const drgnn_step_hints* hints /* optional */, void* stream);
 
 /* Data-parallel hook of the native epoch loop: called on the host once per mini-batch, after the launches that leave
  * this rank's gradient of mini-batch `batch_index` in flat_grad have been ENQUEUED on `stream`; it must enqueue the
