@@ -75,7 +75,10 @@ template <> struct StepIdx<true> { typedef unsigned short type; };
 
 // ---- scratch ---------------------------------------------------------------------------------
 struct StepScratch {
-    float* xs; float* w1t; float* ws1t; float* b1; float* w2t; float* w2n; float* ws2t; float* ws2n; float* b2;
+    float* xs; float* w1t; float* ws1t; float* b1; float* w2t; float* w2n; float* b2;
+    // sGAT / FoutNet conv2 as ONE product over the concatenated operand [S | T] (S = aggregated neighbours, T = scaled
+    // self rows): wc2t[n][k] = [Wnbr ; Wself][k][n] (forward), wc2n[k][n] = the same matrix row-major (backward)
+    float* wc2t; float* wc2n;
     // edge-indexed arrays (cx*, rx*, ts*): node ids / slot numbers of ONE graph.  32 bits each for GINet and
     // FoutNet; 16 bits for sGAT, whose per-edge weights and slot maps would not fit LDS otherwise (the narrow
     // loads cost GINet 1.6 us of 17.7, so it keeps the wide ones)
@@ -83,7 +86,7 @@ struct StepScratch {
     int* rp1; int* cx1; float* ew1; int* cp1; int* rx1; int* ts1; int* mp1; int* mem1;
     short* a0; short* a1;        // argmax node ids as 16-bit (a graph in LDS has < 32768 nodes)
     float* u1; float* z1; float* dv0; float* sc0;
-    float* xp; float* dxp; float* u2; float* z2; float* p2; float* dv1; float* sc1;
+    float* xp; float* u2; float* z2; float* p2; float* dv1; float* sc1;
     float* gp; float* misc;
     float* xr; float* hid; float* dhid;
     float* wb; float* hb1; float* hw2; float* hb2;
@@ -105,10 +108,10 @@ struct StepScratch {
     X(w1t, DRGNN_H1 * xld, 1)                                                                  \
     X(ws1t, DRGNN_H1 * xld, !gin)                                                              \
     X(b1, DRGNN_H1, !gin)                                                                      \
-    X(w2t, DRGNN_H2 * STEP_XPLD, 1)                                                            \
-    X(w2n, DRGNN_H1 * (DRGNN_H2 + 4), 1)                                                       \
-    X(ws2t, DRGNN_H2 * STEP_XPLD, !gin)                                                        \
-    X(ws2n, DRGNN_H1 * (DRGNN_H2 + 4), !gin)                                                   \
+    X(w2t, DRGNN_H2 * STEP_XPLD, gin)                                                          \
+    X(w2n, DRGNN_H1 * (DRGNN_H2 + 4), gin)                                                     \
+    X(wc2t, DRGNN_H2 * (DRGNN_H2 + 4), !gin)                                                   \
+    X(wc2n, DRGNN_H2 * (DRGNN_H2 + 4), !gin)                                                   \
     X(b2, DRGNN_H2, !gin)                                                                      \
     X(xs, (long)(capN + 4) * xld, 1)                                                           \
     X(rp0, capN + 1, 1)                                                                        \
@@ -134,10 +137,10 @@ struct StepScratch {
     X(dv0, capN, !gin)                                                                         \
     X(sc0, capN, !gin)                                                                         \
     X(xp, (long)(capC + 4) * STEP_XPLD, 1)                                                     \
-    X(dxp, (long)capC * DRGNN_H1, 1)                                                           \
-    X(u2, (long)(capC + 4) * (hc2 + 4), 1)                                                     \
+    X(u2, (long)(capC + 4) * (DRGNN_H2 + 4), 1)                                                \
     X(z2, (long)(capC + 4) * (DRGNN_H2 + 4), 1)                                                \
-    X(p2, ((long)capC * DRGNN_H2 > (long)(capC + 4) * STEP_XPLD ? (long)capC * DRGNN_H2 : (long)(capC + 4) * STEP_XPLD), 1) \
+    X(p2, (gin ? ((long)capC * DRGNN_H2 > (long)(capC + 4) * STEP_XPLD ? (long)capC * DRGNN_H2 : (long)(capC + 4) * STEP_XPLD) \
+               : (long)(capC + 4) * (DRGNN_H2 + 4)), 1)                                        \
     X(dv1, capC, !gin)                                                                         \
     X(sc1, capC, !gin)                                                                         \
     X(hw2, (long)O * H, 1)                                                                     \
@@ -208,12 +211,13 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
 #ifdef DRGNN_EMU
 template <bool RELU = false>
 DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
-                      int* dummy) {
+                      int* dummy, const float* bias = nullptr) {
     (void)dummy;
     for (int i = 0; i < M; ++i)
         for (int j = 0; j < 16 * NT; ++j) {
             float acc = 0.0f;
             for (int k = 0; k < K; ++k) acc = fmaf(A[i * lda + k], Bt[j * ldbt + k], acc);
+            if (bias) acc += bias[j];
             if (RELU) acc = (acc < 0.0f) ? 0.0f : acc;
             C[i * ldc + j] = acc;
         }
@@ -221,7 +225,7 @@ DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float
 #else
 template <bool RELU = false>
 DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
-                      int* dummy) {
+                      int* dummy, const float* bias = nullptr) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int units = ((M + 15) >> 4) * NT;
@@ -247,6 +251,7 @@ DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float
             const int ci = ti * 16 + lq * 4 + r;
             float* p = (ci < M) ? C + ci * ldc + tj * 16 + lr : (float*)dummy + lane;
             float v = acc[r];
+            if (bias) v += bias[tj * 16 + lr];
             if (RELU) v = (v < 0.0f) ? 0.0f : v;
             *p = v;
         }
@@ -383,78 +388,125 @@ DEV void step_gather_rows(int n, const int* rp, const IdxT* col, const float* sr
     }
 #endif
 }
-// sGAT / FoutNet on the POOLED graph (few, long rows; H = 32): 16 lanes per row = 8 channel groups x 2 interleaved
-// slices of the entry list, the two slice sums (and, for the coefficients, the two partial weight sums) combined by one
-// DPP step in fixed order.  Same arithmetic as net_aggregate<.., COEF = true> / net_aggregate_bwd otherwise.
-#ifndef DRGNN_EMU
-template <int KIND, int LDU, class IdxT>
-DEV void step_aggregate_pooled(int n, const int* rp, const IdxT* col, const float* w, float* dv, float* sc,
-                               const float* u, const float* bias, float* z) {
-    constexpr int H = DRGNN_H2;
+// ---- sGAT / FoutNet second convolution, aggregation first (same idea as GINet's) -------------------------------
+//   z_i = s_i (xp_i Wself) + d_i sum_k c_k (xp_col(k) Wnbr) + b  =  [S_i | T_i] [Wnbr ; Wself] + b,
+//   S_i = d_i sum_k c_k xp_col(k)   (16-wide gather instead of a 32-wide one),   T_i = s_i xp_i
+// so the layer is ONE gather of pooled rows and ONE dense product over K = 32, forward and backward.
+// FoutNet's NaN row of a node without out-edges (mean of an empty slice) is NOT materialised in [S | T] (a NaN operand
+// would poison the weight-gradient product, NaN x 0): S_i = 0 there and the depth-1 max-pool skips such rows, which is
+// what a NaN does to a '>' comparison.
+// Forward gather: ts[i] = [S_i | T_i] (rows of LDT floats), coefficients d_i / s_i filed in dv / sc for the backward.
+// 16 lanes per pooled node: 4 channel groups x 4 interleaved slices of the entry list, combined by two DPP steps.
+template <int KIND, int LDX, int LDT, class IdxT>
+DEV void step_pooled_gather(int n, const int* rp, const IdxT* col, const float* w, float* dv, float* sc,
+                            const float* xp, float* ts) {
+#ifdef DRGNN_EMU
+    FOR_TID(item, n * 4) {
+        const int i = item >> 2, c = (item & 3) * 4;
+        const int lo = rp[i], hi = rp[i + 1], deg = hi - lo;
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, asum = 0.0f;
+        for (int k = lo; k < hi; ++k) {
+            const float cf = (KIND == DRGNN_SGAT) ? w[k] : 1.0f;
+            asum += cf;
+            for (int q = 0; q < 4; ++q) a[q] = fmaf(cf, xp[col[k] * LDX + c + q], a[q]);
+        }
+        float d, sv;
+        if (KIND == DRGNN_SGAT) { d = 1.0f / (float)(deg > 0 ? deg : 1); sv = asum * d; }
+        else { d = deg > 0 ? 1.0f / (float)deg : 0.0f; sv = 1.0f; }
+        if (c == 0) { dv[i] = d; sc[i] = sv; }
+        for (int q = 0; q < 4; ++q) {
+            float v = a[q] * d;
+            ts[i * LDT + c + q] = v;
+            ts[i * LDT + DRGNN_H1 + c + q] = sv * xp[i * LDX + c + q];
+        }
+    }
+#else
     const int items = ((n * 16) + 63) & ~63;
     for (int item = threadIdx.x; item < items; item += DRGNN_NTHREADS) {
-        const int i = item >> 4, sl = (item >> 3) & 1, c = (item & 7) * 4;
+        const int i = item >> 4, sl = (item >> 2) & 3, c = (item & 3) * 4;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, asum = 0.f;
         int lo = 0, hi = 0;
         if (i < n) {
             lo = rp[i]; hi = rp[i + 1];
-            for (int k = lo + sl; k < hi; k += 2) {
-                const drgnn_f4 v = *(const drgnn_f4*)(u + col[k] * LDU + c);
+            for (int k = lo + sl; k < hi; k += 4) {
+                const drgnn_f4 v = *(const drgnn_f4*)(xp + col[k] * LDX + c);
                 float cf = 1.0f;
                 if (KIND == DRGNN_SGAT) { cf = w[k]; asum += cf; }
                 a0 = fmaf(cf, v[0], a0); a1 = fmaf(cf, v[1], a1); a2 = fmaf(cf, v[2], a2); a3 = fmaf(cf, v[3], a3);
             }
         }
         a0 += dpp_take<0x128>(a0); a1 += dpp_take<0x128>(a1); a2 += dpp_take<0x128>(a2); a3 += dpp_take<0x128>(a3);
-        asum += dpp_take<0x128>(asum);
+        a0 += dpp_take<0x124>(a0); a1 += dpp_take<0x124>(a1); a2 += dpp_take<0x124>(a2); a3 += dpp_take<0x124>(a3);
+        if (KIND == DRGNN_SGAT) { asum += dpp_take<0x128>(asum); asum += dpp_take<0x124>(asum); }
         if (sl == 0 && i < n) {
             const int deg = hi - lo;
-            float d, s;
-            if (KIND == DRGNN_SGAT) { d = 1.0f / (float)(deg > 0 ? deg : 1); s = asum * d; }
-            else { d = deg > 0 ? 1.0f / (float)deg : 0.0f; s = 1.0f; }
-            if (c == 0) { dv[i] = d; sc[i] = s; }
-            const drgnn_f4 us = *(const drgnn_f4*)(u + i * LDU + H + c);
-            a0 = fmaf(s, us[0], a0 * d) + bias[c + 0];
-            a1 = fmaf(s, us[1], a1 * d) + bias[c + 1];
-            a2 = fmaf(s, us[2], a2 * d) + bias[c + 2];
-            a3 = fmaf(s, us[3], a3 * d) + bias[c + 3];
-            if (KIND == DRGNN_FOUT && hi == lo) { a0 = a1 = a2 = a3 = DRGNN_NAN; }
-            a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
-            a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
-            *(drgnn_f4*)(z + i * H + c) = drgnn_f4{a0, a1, a2, a3};
+            float d, sv;
+            if (KIND == DRGNN_SGAT) { d = 1.0f / (float)(deg > 0 ? deg : 1); sv = asum * d; }
+            else { d = deg > 0 ? 1.0f / (float)deg : 0.0f; sv = 1.0f; }
+            if (c == 0) { dv[i] = d; sc[i] = sv; }
+            drgnn_f4 S = {a0 * d, a1 * d, a2 * d, a3 * d};
+            const drgnn_f4 x = *(const drgnn_f4*)(xp + i * LDX + c);
+            *(drgnn_f4*)(ts + i * LDT + c) = S;
+            *(drgnn_f4*)(ts + i * LDT + DRGNN_H1 + c) = drgnn_f4{sv * x[0], sv * x[1], sv * x[2], sv * x[3]};
         }
     }
+#endif
 }
-template <int KIND, int LDU, class IdxT>
-DEV void step_aggregate_pooled_bwd(int n, const int* deg_rp, const int* cp, const IdxT* ridx, const IdxT* tslot,
-                                   const float* w, const float* dv, const float* sc, const float* dz, float* du) {
-    constexpr int H = DRGNN_H2;
+// Backward of the same: d xp_j = s_j dT_j + sum over CSC entries t of column j : c_t d_row(t) dS_row(t), with
+// dts[i] = [dS_i | dT_i] (rows of LDT floats), scattered straight through the depth-0 argmax into dZ1 (row stride 16).
+// deg_rp: CSR row pointers (a FoutNet node without out-edges produced NaN and never won a max: its self path is masked).
+template <int KIND, int LDT, class IdxT>
+DEV void step_pooled_gather_bwd(int n, const int* deg_rp, const int* cp, const IdxT* ridx, const IdxT* tslot,
+                                const float* w, const float* dv, const float* sc, const float* dts, const short* arg,
+                                float* dz) {
+#ifdef DRGNN_EMU
+    FOR_TID(item, n * 4) {
+        const int j = item >> 2, c = (item & 3) * 4;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int t = cp[j]; t < cp[j + 1]; ++t) {
+            const int i = ridx[t];
+            float cf = dv[i];
+            if (KIND == DRGNN_SGAT) cf *= w[tslot[t]];
+            for (int q = 0; q < 4; ++q) acc[q] = fmaf(cf, dts[i * LDT + c + q], acc[q]);
+        }
+        float sv = sc[j];
+        if (KIND == DRGNN_FOUT && deg_rp[j + 1] == deg_rp[j]) sv = 0.0f;
+        for (int q = 0; q < 4; ++q) {
+            const int m = arg[j * DRGNN_H1 + c + q];
+            if (m >= 0) dz[m * DRGNN_H1 + c + q] = fmaf(sv, dts[j * LDT + DRGNN_H1 + c + q], acc[q]);
+        }
+    }
+#else
     const int items = ((n * 16) + 63) & ~63;
     for (int item = threadIdx.x; item < items; item += DRGNN_NTHREADS) {
-        const int j = item >> 4, sl = (item >> 3) & 1, c = (item & 7) * 4;
+        const int j = item >> 4, sl = (item >> 2) & 3, c = (item & 3) * 4;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         if (j < n) {
             const int lo = cp[j], hi = cp[j + 1];
-            for (int t = lo + sl; t < hi; t += 2) {
+            for (int t = lo + sl; t < hi; t += 4) {
                 const int i = ridx[t];
                 float cf = dv[i];
                 if (KIND == DRGNN_SGAT) cf *= w[tslot[t]];
-                const drgnn_f4 v = *(const drgnn_f4*)(dz + i * H + c);
+                const drgnn_f4 v = *(const drgnn_f4*)(dts + i * LDT + c);
                 a0 = fmaf(cf, v[0], a0); a1 = fmaf(cf, v[1], a1); a2 = fmaf(cf, v[2], a2); a3 = fmaf(cf, v[3], a3);
             }
         }
         a0 += dpp_take<0x128>(a0); a1 += dpp_take<0x128>(a1); a2 += dpp_take<0x128>(a2); a3 += dpp_take<0x128>(a3);
+        a0 += dpp_take<0x124>(a0); a1 += dpp_take<0x124>(a1); a2 += dpp_take<0x124>(a2); a3 += dpp_take<0x124>(a3);
         if (sl == 0 && j < n) {
-            float* uj = du + j * LDU + c;
-            *(drgnn_f4*)uj = drgnn_f4{a0, a1, a2, a3};
-            float s = sc[j];
-            if (KIND == DRGNN_FOUT && deg_rp[j + 1] == deg_rp[j]) s = 0.0f;   // NaN row never wins a max
-            const drgnn_f4 d = *(const drgnn_f4*)(dz + j * H + c);
-            *(drgnn_f4*)(uj + H) = drgnn_f4{d[0] * s, d[1] * s, d[2] * s, d[3] * s};
+            float sv = sc[j];
+            if (KIND == DRGNN_FOUT && deg_rp[j + 1] == deg_rp[j]) sv = 0.0f;
+            const drgnn_f4 dt = *(const drgnn_f4*)(dts + j * LDT + DRGNN_H1 + c);
+            const float acc[4] = {fmaf(sv, dt[0], a0), fmaf(sv, dt[1], a1), fmaf(sv, dt[2], a2), fmaf(sv, dt[3], a3)};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = arg[j * DRGNN_H1 + c + q];
+                if (m >= 0) dz[m * DRGNN_H1 + c + q] = acc[q];
+            }
         }
     }
-}
 #endif
+}
 
 // the transposed sum (CSC: column j gathers the rows of its entries), scattered straight through the
 // depth-0 argmax into dZ1 (row stride 16): the pooling backward needs no pass of its own
@@ -508,12 +560,12 @@ DEV void step_gather_scatter(int n, const int* cp, const IdxT* ridx, const float
 // anyway: (1) every lane sums a float4 column group over the rows r = t / (H/4), + 1024/(H/4), .. and the lanes of a
 // wave that hold the same group are combined by lane exchanges -> one partial row per wave in `wpart` [16][H];
 // (2) after the barrier H lanes add the 16 wave rows in wave order.  Fixed order -> bit-reproducible.
-template <int H>
+template <int H, int LD = H>
 DEV void step_colsum_partial(int n, const float* dz, float* wpart) {
 #ifdef DRGNN_EMU
     for (int c = 0; c < H; ++c) {
         float acc = 0.0f;
-        for (int r = 0; r < n; ++r) acc += dz[r * H + c];
+        for (int r = 0; r < n; ++r) acc += dz[r * LD + c];
         wpart[c] = acc;
     }
 #else
@@ -521,7 +573,7 @@ DEV void step_colsum_partial(int n, const float* dz, float* wpart) {
     const int t = threadIdx.x, cg = t % G, r0 = t / G;
     drgnn_f4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int r = r0; r < n; r += DRGNN_NTHREADS / G) {
-        const drgnn_f4 v = *(const drgnn_f4*)(dz + r * H + 4 * cg);
+        const drgnn_f4 v = *(const drgnn_f4*)(dz + r * LD + 4 * cg);
         acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
     }
 #pragma unroll
@@ -554,9 +606,10 @@ DEV void step_colsum_finish(const float* wpart, float* out) {
 
 // Depth-1 max-pool with argmax (first maximum in ascending member order, NaN never wins, empty cluster -> 0,
 // arg = -1 where no gradient can flow) fused with the graph readout = mean over the depth-1 clusters.
-template <int LDZ>
+// SKIP0: rows of nodes without out-edges (rp[m+1] == rp[m]) count as NaN, i.e. never win (FoutNet)
+template <int LDZ, bool SKIP0 = false>
 DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z, short* arg, const float* misc,
-                           float* xr, float* g_readout) {
+                           float* xr, float* g_readout, const int* rp = nullptr) {
     int bad; memcpy(&bad, &misc[STEP_M_BAD], 4);
     const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
 #ifdef DRGNN_EMU
@@ -567,6 +620,7 @@ DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z
             int am = -1;
             for (int p = mp[k]; p < mp[k + 1]; ++p) {
                 const int m = mem[p];
+                if (SKIP0 && rp[m + 1] == rp[m]) continue;
                 const float v = z[m * LDZ + c];
                 if (v > best) { best = v; am = m; }
             }
@@ -589,6 +643,7 @@ DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z
 #pragma unroll 4
             for (int p = mp[k]; p < mp[k + 1]; ++p) {
                 const int m = mem[p];
+                if (SKIP0 && rp[m + 1] == rp[m]) continue;
                 const float v = z[m * LDZ + c];
                 if (v > best) { best = v; am = m; }
             }
@@ -969,12 +1024,13 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
     const int F = a.net.n_feat;
     const int H = hf.H, O = hf.O;
     const int F16 = XF ? XF : step_pad16(F), XLD = F16 + 4;
-    constexpr int U2LD = HC2 + 4, W2NLD = DRGNN_H2 + 4;
+    constexpr int W2NLD = DRGNN_H2 + 4;
+    constexpr int TSLD = DRGNN_H2 + 4;                 // rows of the [S | T] operand of sGAT / FoutNet's second convolution
     constexpr bool GIN = (KIND == DRGNN_GINET);
     constexpr bool NARROW = (KIND == DRGNN_SGAT);
     constexpr bool LATE3 = !GIN;                      // backward-only index arrays staged by a third, later burst
     typedef typename StepIdx<NARROW>::type EIdx;      // element type of the edge-indexed LDS arrays
-    constexpr int Z2LD = GIN ? DRGNN_H2 + 4 : DRGNN_H2;      // GINet: Z2 rows feed a dense product (128-bit rows)
+    constexpr int Z2LD = DRGNN_H2 + 4;      // Z2 / dZ2 rows feed dense products (16-byte aligned, conflict-free 128-bit reads)
     StepScratch s = step_carve(scratch, KIND, (XF != 0) ? XF : F, capN, capE, capC, R, (XF != 0) ? WREF : H, O);
     EXIT_AFTER(0);
     WBlockRegs<(XF != 0) ? 1 : STEP_WB_J> wreg;      // XF != 0: H is the reference width (step_burst_guaranteed)
@@ -1065,8 +1121,13 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         } else {
             FOR_TID(e, d.N * F) { s.xs[(e / F) * XLD + e % F] = xg[e]; }
             step_stage_wt(s.w1t, XLD, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
-            step_stage_wt(s.w2t, STEP_XPLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
-            stage_weight(s.w2n, W2NLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+            if (GIN) {
+                step_stage_wt(s.w2t, STEP_XPLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+                stage_weight(s.w2n, W2NLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+            } else {
+                step_stage_wt(s.wc2t, TSLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+                stage_weight(s.wc2n, TSLD, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+            }
             step_copy_i32(s.rp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
             step_copy_idx<NARROW>(s.cx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
             step_copy_i32(s.cp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
@@ -1087,8 +1148,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
             step_copy_f32(s.hb2, hf.b2, O);
             if (KIND != DRGNN_GINET) {
                 step_stage_wt(s.ws1t, XLD, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
-                step_stage_wt(s.ws2t, STEP_XPLD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
-                stage_weight(s.ws2n, W2NLD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+                step_stage_wt(s.wc2t + DRGNN_H1, TSLD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+                stage_weight(s.wc2n + DRGNN_H1 * TSLD, TSLD, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
                 step_copy_f32(s.b1, c1.bias, DRGNN_H1);
                 step_copy_f32(s.b2, c2.bias, DRGNN_H2);
             }
@@ -1165,8 +1226,13 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         // (the per-row coefficients of sGAT / FoutNet are formed inside the aggregation from the row's own entries)
         PH(2) net_aggregate<KIND, DRGNN_H1, true, 0, EIdx, true>(d.N, s.rp0, (const EIdx*)s.cx0, s.ew0, s.dv0, s.sc0, s.u1, s.b1, s.z1);
         if (burst) {      // the second burst has landed by now: file it in LDS
-            burst_store_wt(bw2, s.w2t, STEP_XPLD);
-            burst_store_w(bw2, s.w2n, W2NLD);
+            if (GIN) {
+                burst_store_wt(bw2, s.w2t, STEP_XPLD);
+                burst_store_w(bw2, s.w2n, W2NLD);
+            } else {
+                burst_store_wt(bw2, s.wc2t, TSLD);                         // wc2t[n][k] = Wnbr[k][n]
+                burst_store_w(bw2, s.wc2n, TSLD);                          // wc2n[k][n] = Wnbr[k][n]
+            }
             bufburst_store(brp1, s.rp1, dummy); step_store_idx<NARROW>(bcx1, s.cx1, dummy);
             bufburst_store(bmp1, s.mp1, dummy); bufburst_store(bmem1, s.mem1, dummy);
             step_wblock_store(wreg, hf, br, s.wb);
@@ -1176,8 +1242,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
                 bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
             }
             if (KIND != DRGNN_GINET) {
-                burst_store_wt(bs2, s.ws2t, STEP_XPLD);
-                burst_store_w(bs2, s.ws2n, W2NLD);
+                burst_store_wt(bs2, s.wc2t + DRGNN_H1, TSLD);              // wc2t[n][16 + k] = Wself[k][n]
+                burst_store_w(bs2, s.wc2n + DRGNN_H1 * TSLD, TSLD);       // wc2n[16 + k][n] = Wself[k][n]
                 bufburst_store(bb2, s.b2, dummy);
             }
             if (KIND == DRGNN_SGAT) bufburst_store(bew1, s.ew1, dummy);
@@ -1202,10 +1268,9 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         if (GIN) {      // S = A XP (16-wide gather), kept in the u2 area with rows of STEP_XPLD floats
             PH(4) step_gather_rows<STEP_XPLD, EIdx>(d.C, s.rp1, (const EIdx*)s.cx1, s.xp, s.u2);
             FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.u2[d.C * STEP_XPLD + e] = 0.0f; }
-        } else {
-            PH(4) step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.w2t, STEP_XPLD, s.u2, U2LD, dummy);
-            step_gemm_nn(d.C, 2, DRGNN_H1, s.xp, STEP_XPLD, s.ws2t, STEP_XPLD, s.u2 + DRGNN_H2, U2LD, dummy);
-            FOR_TID(e, (step_pad4(d.C) - d.C) * U2LD) { s.u2[d.C * U2LD + e] = 0.0f; }
+        } else {        // [S | T]: aggregated neighbours and scaled self rows of the pooled features (u2 area, rows of TSLD)
+            PH(4) step_pooled_gather<KIND, STEP_XPLD, TSLD, EIdx>(d.C, s.rp1, (const EIdx*)s.cx1, s.ew1, s.dv1, s.sc1, s.xp, s.u2);
+            FOR_TID(e, (step_pad4(d.C) - d.C) * TSLD) { s.u2[d.C * TSLD + e] = 0.0f; }
         }
         FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; }      // Z1 is consumed: becomes dZ1
         // node rows [n, pad4(n)) of the backward products' K operands: zero (never written otherwise)
@@ -1214,15 +1279,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         EXIT_AFTER(5);
         if (GIN) {      // Z2 = relu(S W2)
             PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H1, s.u2, STEP_XPLD, s.w2t, STEP_XPLD, s.z2, Z2LD, dummy);
-        } else {
-#ifndef DRGNN_EMU
-            // (measured on the same box: the 16-lane sliced form is worth 1.3 us per step for sGAT, whose entries carry
-            // a weight lookup each, and costs FoutNet 0.2 us)
-            if (KIND == DRGNN_SGAT) {
-                PH(5) step_aggregate_pooled<KIND, U2LD, EIdx>(d.C, s.rp1, (const EIdx*)s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
-            } else
-#endif
-            PH(5) net_aggregate<KIND, DRGNN_H2, true, U2LD, EIdx, true>(d.C, s.rp1, (const EIdx*)s.cx1, s.ew1, s.dv1, s.sc1, s.u2, s.b2, s.z2);
+        } else {        // Z2 = relu([S | T] [Wnbr ; Wself] + b): one product over K = 32
+            PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H2, s.u2, TSLD, s.wc2t, TSLD, s.z2, Z2LD, dummy, s.b2);
         }
         if (burst && LATE3) {
             bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
@@ -1233,8 +1291,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         EXIT_AFTER(6);
         // depth-1 cluster max (+ argmax) and the graph readout (mean over those clusters) in one phase: 16 lanes
         // per channel share the clusters k = lane, lane+16, ..; their partial sums meet in a 16-lane DPP sum
-        PH(6) step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.a1, s.misc, s.xr,
-                                      const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2);
+        PH(6) step_pool_readout<Z2LD, KIND == DRGNN_FOUT>(d.C1, s.mp1, s.mem1, s.z2, s.a1, s.misc, s.xr,
+                                      const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2, s.rp1);
         BARRIER();
         EXIT_AFTER(8);
     }
@@ -1285,29 +1343,18 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         BARRIER();
         EXIT_AFTER(14);
     } else {
-#ifndef DRGNN_EMU
-    if (KIND == DRGNN_SGAT) {
-        PH(11) step_aggregate_pooled_bwd<KIND, U2LD, EIdx>(d.C, s.rp1, s.cp1, (const EIdx*)s.rx1, (const EIdx*)s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
-    } else
-#endif
-    PH(11) net_aggregate_bwd<KIND, DRGNN_H2, true, U2LD, EIdx>(d.C, s.rp1, s.cp1, (const EIdx*)s.rx1, (const EIdx*)s.ts1, s.ew1, s.dv1, s.sc1, s.z2, s.u2);
-    step_colsum_partial<DRGNN_H2>(d.C, s.z2, s.bsum);     // db2, stage 1
+    // d[S | T] = dZ2 [Wnbr ; Wself]^T (into the p2 area, rows of TSLD);  d[Wnbr ; Wself] = [S | T]^T dZ2 (K = pooled nodes):
+    // the slab holds dW2nbr and dW2self back to back, i.e. exactly the 32 x 32 result
+    PH(11) step_gemm_nn(d.C, 2, DRGNN_H2, s.z2, Z2LD, s.wc2n, TSLD, s.p2, TSLD, dummy);
+    PH(12) step_gemm_tn(2, 2, d.C, s.u2, TSLD, s.z2, Z2LD, imin(DRGNN_NWAVES / 4, gp_units / 4), s.gp, p_w2n, DRGNN_H2,
+                        2 * DRGNN_H1);
+    step_colsum_partial<DRGNN_H2, Z2LD>(d.C, s.z2, s.bsum);     // db2, stage 1 (the barrier inside the product serves it)
     BARRIER();
     EXIT_AFTER(12);
     step_colsum_finish<DRGNN_H2>(s.bsum, p_b2);
-    // dXP = dU2n W2n^T + dU2s W2s^T;  dW2 = XP^T dU2 (K = pooled nodes, split over the waves)
-    PH(13) step_gemm_nn(d.C, 1, DRGNN_H2, s.u2, U2LD, s.w2n, W2NLD, s.dxp, DRGNN_H1, dummy);
-    step_gemm_nn(d.C, 1, DRGNN_H2, s.u2 + DRGNN_H2, U2LD, s.ws2n, W2NLD, s.p2, DRGNN_H1, dummy);
-    // both weight gradients of the layer in one pass (4 column tiles: [dU2n | dU2s])
-    PH(12) step_gemm_tn_pair(1, 2, d.C, s.xp, STEP_XPLD, s.u2, U2LD, imin(DRGNN_NWAVES / 4, gp_units / 4), s.gp, p_w2n,
-                             DRGNN_H1 * DRGNN_H2, DRGNN_H2, DRGNN_H1);
-    BARRIER();
-    EXIT_AFTER(13);
-    PH(14) FOR_TID(item, d.C * DRGNN_H1) {
-        const int m = s.a0[item];
-        const int c = item % DRGNN_H1;
-        if (m >= 0) s.z1[m * DRGNN_H1 + c] = s.dxp[item] + s.p2[item];
-    }
+    // dXP = s dT + (d c A)^T dS, scattered through the depth-0 argmax into dZ1
+    PH(13) step_pooled_gather_bwd<KIND, TSLD, EIdx>(d.C, s.rp1, s.cp1, (const EIdx*)s.rx1, (const EIdx*)s.ts1, s.ew1, s.dv1,
+                                                    s.sc1, s.p2, s.a0, s.z1);
     BARRIER();
     EXIT_AFTER(14);
     }
