@@ -79,6 +79,7 @@ struct StepScratch {
     // sGAT / FoutNet conv2 as ONE product over the concatenated operand [S | T] (S = aggregated neighbours, T = scaled
     // self rows): wc2t[n][k] = [Wnbr ; Wself][k][n] (forward), wc2n[k][n] = the same matrix row-major (backward)
     float* wc2t; float* wc2n;
+    float* ct0;                  // [capE] coefficient of every CSC0 entry: c_e d_row(e) (sGAT / FoutNet backward of conv1)
     // edge-indexed arrays (cx*, rx*, ts*): node ids / slot numbers of ONE graph.  32 bits each for GINet and
     // FoutNet; 16 bits for sGAT, whose per-edge weights and slot maps would not fit LDS otherwise (the narrow
     // loads cost GINet 1.6 us of 17.7, so it keeps the wide ones)
@@ -120,6 +121,7 @@ struct StepScratch {
     X(cp0, capN + 1, 1)                                                                        \
     X(rx0, (sg ? (capE + 1) / 2 : capE), 1)                                                    \
     X(ts0, (sg ? (capE + 1) / 2 : capE), sg)                                                   \
+    X(ct0, capE, !gin)                                                                         \
     X(mp0, capC + 1, 1)                                                                        \
     X(mem0, capN, 1)                                                                           \
     X(rp1, capC + 1, 1)                                                                        \
@@ -211,13 +213,14 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
 #ifdef DRGNN_EMU
 template <bool RELU = false>
 DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
-                      int* dummy, const float* bias = nullptr) {
+                      int* dummy, const float* bias = nullptr, const float* nan_rows = nullptr) {
     (void)dummy;
     for (int i = 0; i < M; ++i)
         for (int j = 0; j < 16 * NT; ++j) {
             float acc = 0.0f;
             for (int k = 0; k < K; ++k) acc = fmaf(A[i * lda + k], Bt[j * ldbt + k], acc);
             if (bias) acc += bias[j];
+            if (nan_rows && nan_rows[i] == 0.0f) acc = DRGNN_NAN;
             if (RELU) acc = (acc < 0.0f) ? 0.0f : acc;
             C[i * ldc + j] = acc;
         }
@@ -225,7 +228,8 @@ DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float
 #else
 template <bool RELU = false>
 DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
-                      int* dummy, const float* bias = nullptr) {
+                      int* dummy, const float* bias = nullptr, const float* nan_rows = nullptr) {
+    // nan_rows: rows i with nan_rows[i] == 0 are written as NaN (FoutLayer's mean over an empty neighbourhood)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int units = ((M + 15) >> 4) * NT;
@@ -252,6 +256,7 @@ DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float
             float* p = (ci < M) ? C + ci * ldc + tj * 16 + lr : (float*)dummy + lane;
             float v = acc[r];
             if (bias) v += bias[tj * 16 + lr];
+            if (nan_rows && ci < M && nan_rows[ci] == 0.0f) v = DRGNN_NAN;
             if (RELU) v = (v < 0.0f) ? 0.0f : v;
             *p = v;
         }
@@ -388,13 +393,41 @@ DEV void step_gather_rows(int n, const int* rp, const IdxT* col, const float* sr
     }
 #endif
 }
+// backward of conv1's aggregation for sGAT / FoutNet with the per-entry coefficients precomputed (ct[t]):
+// dU[j, 0:16] = sum_t ct[t] dZ[row(t), :],  dU[j, 16:32] = s_j dZ[j, :]   (rows of 32 floats; dZ rows of 16)
+template <int KIND, class IdxT>
+DEV void step_aggregate_bwd_ct(int n, const int* deg_rp, const int* cp, const IdxT* ridx, const float* ct, const float* sc,
+                               const float* dz, float* du) {
+    constexpr int H = DRGNN_H1, HC = 2 * DRGNN_H1;
+    FOR_TID(item, n * 4) {
+        const int j = item >> 2, c = (item & 3) * 4;
+        const int lo = cp[j], hi = cp[j + 1];
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+        for (int t = lo; t < hi; ++t) {
+            const float cf = ct[t];
+            float v0, v1, v2, v3;
+            NET_LD4(true, dz + ridx[t] * H + c, v0, v1, v2, v3);
+            a0 = fmaf(cf, v0, a0); a1 = fmaf(cf, v1, a1); a2 = fmaf(cf, v2, a2); a3 = fmaf(cf, v3, a3);
+        }
+        float* uj = du + j * HC + c;
+        NET_ST4(true, uj, a0, a1, a2, a3);
+        float sv = sc[j];
+        if (KIND == DRGNN_FOUT && deg_rp[j + 1] == deg_rp[j]) sv = 0.0f;   // NaN row never wins a max
+        float d0, d1, d2, d3;
+        NET_LD4(true, dz + j * H + c, d0, d1, d2, d3);
+        d0 *= sv; d1 *= sv; d2 *= sv; d3 *= sv;
+        NET_ST4(true, uj + H, d0, d1, d2, d3);
+    }
+}
+
 // ---- sGAT / FoutNet second convolution, aggregation first (same idea as GINet's) -------------------------------
 //   z_i = s_i (xp_i Wself) + d_i sum_k c_k (xp_col(k) Wnbr) + b  =  [S_i | T_i] [Wnbr ; Wself] + b,
 //   S_i = d_i sum_k c_k xp_col(k)   (16-wide gather instead of a 32-wide one),   T_i = s_i xp_i
 // so the layer is ONE gather of pooled rows and ONE dense product over K = 32, forward and backward.
 // FoutNet's NaN row of a node without out-edges (mean of an empty slice) is NOT materialised in [S | T] (a NaN operand
-// would poison the weight-gradient product, NaN x 0): S_i = 0 there and the depth-1 max-pool skips such rows, which is
-// what a NaN does to a '>' comparison.
+// would poison the weight-gradient product, NaN x 0): S_i = 0 there and the product's epilogue writes the NaN row of Z2
+// (rows whose d_i is 0).
 // Forward gather: ts[i] = [S_i | T_i] (rows of LDT floats), coefficients d_i / s_i filed in dv / sc for the backward.
 // 16 lanes per pooled node: 4 channel groups x 4 interleaved slices of the entry list, combined by two DPP steps.
 template <int KIND, int LDX, int LDT, class IdxT>
@@ -1263,6 +1296,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
             }
         }
         PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
+
         BARRIER();
         EXIT_AFTER(4);
         if (GIN) {      // S = A XP (16-wide gather), kept in the u2 area with rows of STEP_XPLD floats
@@ -1280,7 +1314,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         if (GIN) {      // Z2 = relu(S W2)
             PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H1, s.u2, STEP_XPLD, s.w2t, STEP_XPLD, s.z2, Z2LD, dummy);
         } else {        // Z2 = relu([S | T] [Wnbr ; Wself] + b): one product over K = 32
-            PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H2, s.u2, TSLD, s.wc2t, TSLD, s.z2, Z2LD, dummy, s.b2);
+            PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H2, s.u2, TSLD, s.wc2t, TSLD, s.z2, Z2LD, dummy, s.b2,
+                                     (KIND == DRGNN_FOUT) ? s.dv1 : nullptr);      // dv == 0 <=> no out-edges
         }
         if (burst && LATE3) {
             bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
@@ -1291,8 +1326,18 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         EXIT_AFTER(6);
         // depth-1 cluster max (+ argmax) and the graph readout (mean over those clusters) in one phase: 16 lanes
         // per channel share the clusters k = lane, lane+16, ..; their partial sums meet in a 16-lane DPP sum
-        PH(6) step_pool_readout<Z2LD, KIND == DRGNN_FOUT>(d.C1, s.mp1, s.mem1, s.z2, s.a1, s.misc, s.xr,
-                                      const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2, s.rp1);
+        PH(6) step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.a1, s.misc, s.xr,
+                                      const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2);
+        if (!GIN && hf.train) {
+            // coefficient of every entry of the TRANSPOSED level-0 aggregation, once (one item per entry, no dependent
+            // chain; the CSC arrays have just been filed): the backward gather then reads (row, coefficient) pairs like GINet's reads rows
+            FOR_TID(t, d.E) {
+                const int i = ((const EIdx*)s.rx0)[t];
+                float cf = s.dv0[i];
+                if (KIND == DRGNN_SGAT) cf *= s.ew0[((const EIdx*)s.ts0)[t]];
+                s.ct0[t] = cf;
+            }
+        }
         BARRIER();
         EXIT_AFTER(8);
     }
@@ -1358,7 +1403,11 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
     BARRIER();
     EXIT_AFTER(14);
     }
-    PH(15) net_aggregate_bwd<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, s.cp0, (const EIdx*)s.rx0, (const EIdx*)s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
+    if (GIN) {
+        PH(15) net_aggregate_bwd<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, s.cp0, (const EIdx*)s.rx0, (const EIdx*)s.ts0, s.ew0, s.dv0, s.sc0, s.z1, s.u1);
+    } else {
+        PH(15) step_aggregate_bwd_ct<KIND, EIdx>(d.N, s.rp0, s.cp0, (const EIdx*)s.rx0, s.ct0, s.sc0, s.z1, s.u1);
+    }
     if (KIND != DRGNN_GINET) step_colsum_partial<DRGNN_H1>(d.N, s.z1, s.bsum);     // db1, stage 1
     BARRIER();
     EXIT_AFTER(15);
