@@ -264,6 +264,46 @@ DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float
 }
 #endif
 
+// Two products sharing the A operand: C[:, 0:16] = A Bt0^T, C[:, 16:32] = A Bt1^T (sGAT / FoutNet conv1: neighbour and self
+// weights).  One unit = one 16-row tile with BOTH column tiles: the A fragments are fetched once.
+#ifdef DRGNN_EMU
+DEV void step_gemm_nn_dual(int M, int K, const float* A, int lda, const float* Bt0, const float* Bt1, int ldbt, float* C,
+                           int ldc, int* dummy) {
+    step_gemm_nn(M, 1, K, A, lda, Bt0, ldbt, C, ldc, dummy);
+    step_gemm_nn(M, 1, K, A, lda, Bt1, ldbt, C + 16, ldc, dummy);
+}
+#else
+DEV void step_gemm_nn_dual(int M, int K, const float* A, int lda, const float* Bt0, const float* Bt1, int ldbt, float* C,
+                           int ldc, int* dummy) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int units = (M + 15) >> 4;
+    for (int ti = wave; ti < units; ti += DRGNN_NWAVES) {
+        const float* ap = A + (ti * 16 + lr) * lda + 4 * lq;
+        const float* bp0 = Bt0 + lr * ldbt + 4 * lq;
+        const float* bp1 = Bt1 + lr * ldbt + 4 * lq;
+        drgnn_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            const drgnn_f4 a = *(const drgnn_f4*)(ap + k0);
+            const drgnn_f4 b0 = *(const drgnn_f4*)(bp0 + k0), b1 = *(const drgnn_f4*)(bp1 + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b0[j], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b1[j], acc1, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = ti * 16 + lq * 4 + r;
+            float* p = (ci < M) ? C + ci * ldc + lr : (float*)dummy + lane;
+            float* q = (ci < M) ? C + ci * ldc + 16 + lr : (float*)dummy + lane;
+            *p = acc0[r];
+            *q = acc1[r];
+        }
+    }
+}
+#endif
+
 // C[Mrows <= 16*MT x 16*NT] (global, row stride ldc) = sum_k A[k][i] * B[k][j],  A rows of stride lda (K of them),
 // B rows of stride ldb.  K is cut in KS slices (one (tile, slice) unit per wave); the partial tiles go to
 // `part` ([KS * MT * NT][64 lanes][4]) and are summed in slice order.  Contains one workgroup barrier;
@@ -1238,8 +1278,11 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
             }
             if (KIND == DRGNN_SGAT) bufburst_load(bew1, tv.w1 + d.e0, bE1);
         }
-        PH(1) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t, XLD, s.u1, HC1, dummy);
-        if (KIND != DRGNN_GINET) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.ws1t, XLD, s.u1 + DRGNN_H1, HC1, dummy);
+        if (KIND == DRGNN_GINET) {
+            PH(1) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t, XLD, s.u1, HC1, dummy);
+        } else {
+            PH(1) step_gemm_nn_dual(d.N, F16, s.xs, XLD, s.w1t, s.ws1t, XLD, s.u1, HC1, dummy);
+        }
         if (burst) {
             bufburst_store(brp0, s.rp0, dummy); step_store_idx<NARROW>(bcx0, s.cx0, dummy);
             bufburst_store(bmp0, s.mp0, dummy); bufburst_store(bmem0, s.mem0, dummy);
