@@ -151,3 +151,31 @@ def test_fused_step_syn64_three_adam_steps_match_oracle(net_name):
         # Adam's first steps move every weight by ~lr regardless of the gradient's size: the parameters
         # agree to 1e-4 element-wise wherever the gradient is resolved by fp32 (all but exact zeros)
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=TOL, atol=TOL, err_msg=k)
+
+
+@pytest.mark.parametrize("net_name,n_graphs", [("GINet", 80), ("sGAT", 80), ("FoutNet", 200), ("GINet", 200)])
+def test_fused_step_batches_beyond_the_argument_table(net_name, n_graphs):
+    """More than 64 graphs: the per-graph offsets no longer travel in the kernel arguments (workspace tables instead), and
+    beyond 160 graphs the topology builder runs one workgroup per graph -- same numbers as the oracle either way."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    dev = _dev()
+    batch_cpu = synth.make_batch(0, n_graphs, n_nodes=48, n_pairs=90, n_c1=4, n_internal=20)
+    params = cpu_ref.init_params(net_name, 32, 1, 1, seed=3)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **_fw_kwargs(net_name))
+    net, tr = _trainer(net_name, params)
+    batch = batch_cpu.clone().to(dev)
+    need_w = net_name == "sGAT"
+    topo = Topology.from_batch(batch, need_weights=need_w)
+    nxt = Topology.from_batch(batch, need_weights=need_w, build=False)
+    assert tr._can_fuse(topo, 32)
+    loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=TOL)
+    np.testing.assert_allclose(tr.last_pred.cpu().numpy(), ref_pred.numpy(), rtol=TOL, atol=TOL)
+    for k, p in net.named_parameters():
+        ref = ref_grads[k].numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=TOL, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    from topo_check import check_against_oracle
+    check_against_oracle(nxt, batch_cpu, weights=need_w)
+    assert float(tr.compute_gradients(batch, topo=nxt)) == float(loss)
