@@ -188,9 +188,11 @@ def main():
         trainer = FusedTrainer(net, lr=1e-3, task="reg", seed=1234 + rank)
         loss_out = trainer.loss
         oneshot = None
-        if world > 1 and os.environ.get("DRGNN_DP_ONESHOT", "0") == "1":
-            # opt-in: the one-shot peer-to-peer all-reduce (csrc/drgnn_p2p.h) instead of RCCL's ring
-            oneshot = trainer.use_oneshot_allreduce()
+        if world > 1 and os.environ.get("DRGNN_DP_ONESHOT", "auto") != "0":
+            # the one-shot peer-to-peer all-reduce (csrc/drgnn_p2p.h: one launch, one xGMI round trip) instead of RCCL's
+            # ring for the 43 KB gradient -- adopted only if a verified trial exchange succeeds on EVERY rank (bounded
+            # waits: no hang), else the run stays on RCCL.  DRGNN_DP_ONESHOT=0 skips the trial.
+            oneshot = trainer.use_oneshot_allreduce(verify=True)
         # Two persistent topology workspaces.  Pipelined: while step t trains out of one, the
         # topology of step t+1 is built into the other INSIDE step t's backward launch (the builder
         # only depends on index tensors).  Every step still builds one topology and consumes one.
@@ -506,7 +508,7 @@ def main():
         if split:
             if native and oneshot is not None:
                 dp_mode = dp_mode.replace("RCCL all-reduce", "one-shot p2p all-reduce (drgnn_allreduce_oneshot)")
-                dp_mode += " [DRGNN_DP_ONESHOT=1]"
+                dp_mode += " [verified trial exchange on every rank; DRGNN_DP_ONESHOT=0 for RCCL]"
                 oneshot.check()
             result["config"]["dp_exchange"] = dp_mode
             result["config"]["params_in_sync"] = in_sync

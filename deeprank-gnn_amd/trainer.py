@@ -352,10 +352,39 @@ class FusedTrainer(object):
             self.flat_g.mul_(1.0 / world)
         dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=group)
 
-    def use_oneshot_allreduce(self, group=None):
-        """Route ``all_reduce_gradients`` through the one-shot peer-to-peer exchange (parallel.OneShotAllReduce)."""
+    def use_oneshot_allreduce(self, group=None, verify=True):
+        """Route ``all_reduce_gradients`` through the one-shot peer-to-peer exchange (parallel.OneShotAllReduce).
+        ``verify``: run a few exchanges of known vectors first and agree over the process group that every rank got the
+        right sums without an expired wait; on any failure (no peer access, hipIpc refused, a wait expired, a wrong
+        sum) the trainer stays on the collective library's all-reduce.  Returns the exchanger or None."""
         from .parallel import OneShotAllReduce
-        self._oneshot = OneShotAllReduce(self.flat_g.numel(), self.flat_g.device, api=self.api, group=group)
+        self._oneshot = None
+        ok, ar = 1, None
+        try:
+            ar = OneShotAllReduce(self.flat_g.numel(), self.flat_g.device, api=self.api, group=group)
+            if verify:
+                world, rank = ar.world, ar.rank
+                for it in range(3):
+                    v = torch.full((ar.n,), float(rank + 1 + it), dtype=torch.float32, device=self.flat_g.device)
+                    v[::7] += 0.25 * rank
+                    ar(v, weight=1.0)
+                    if v.is_cuda:
+                        torch.cuda.synchronize(v.device)
+                    want = sum(float(r + 1 + it) for r in range(world))
+                    want7 = want + 0.25 * sum(range(world))
+                    chk = v.cpu()
+                    good = bool(torch.all(chk[1::7] == want)) and bool(torch.all(chk[::7] == want7))
+                    if not good or int(ar.status.item()) != 0:
+                        ok = 0
+                        break
+        except Exception:                      # pragma: no cover - depends on the node
+            ok = 0
+        if verify and dist.is_available() and dist.is_initialized():
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.flat_g.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+            ok = int(flag.item())
+        if ok:
+            self._oneshot = ar
         return self._oneshot
 
     def apply_update(self):
