@@ -453,10 +453,23 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net_co_topo(CoLaunch C) {
     if ((int)blockIdx.x < C.n_net) net_block<KIND, BWD, true>(C.net, blockIdx.x, smem_c);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_c);
 }
+// The step workgroups read ~0.7 KB of kernel arguments (descriptors, pointers, strides) in the order the prologue's code
+// happens to need them: every first touch of a 64-byte line is a scalar-cache miss the next instructions wait for, one
+// after the other.  One batch of scalar loads (one word of every line, results discarded) makes it a single miss time.
+#define DRGNN_KA_LINE(off) "s_load_dword %0, %1, " #off "\n"
+DEV void step_kernarg_touch() {
+    static_assert(offsetof(StepLaunch, dims) + sizeof(int) >= 0x2c0, "the touched lines lie inside the step arguments");
+    int t;
+    asm volatile(DRGNN_KA_LINE(0x0) DRGNN_KA_LINE(0x40) DRGNN_KA_LINE(0x80) DRGNN_KA_LINE(0xc0) DRGNN_KA_LINE(0x100)
+                 DRGNN_KA_LINE(0x140) DRGNN_KA_LINE(0x180) DRGNN_KA_LINE(0x1c0) DRGNN_KA_LINE(0x200) DRGNN_KA_LINE(0x240)
+                 DRGNN_KA_LINE(0x280) "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t) : "s"(__builtin_amdgcn_kernarg_segment_ptr()) : "memory");
+}
 template <int KIND, int XF, bool GATHER>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C) {
     extern __shared__ __attribute__((aligned(16))) float smem_s[];
     PHASE_BEGIN();
+    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
     if ((int)blockIdx.x < C.n_net) step_block<KIND, XF, GATHER>(C.step, blockIdx.x, smem_s, 0);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);
 }

@@ -1148,17 +1148,23 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
 #endif
         // per-graph scalars of the readout / loss phases: requested here so that their latency hides in
         // the burst (every lane asks for the same words; lane 0 files them in LDS after conv1's product)
-        int m_bad, m_y;
+        // Nothing here may make the compiler WAIT for a load before the burst below is issued (a wait = one more dependent
+        // memory round trip in front of the x tile): the regression target travels as raw bits, untouched until lane 0
+        // files it; the classification branch (class weight looked up through the label) completes its own loads inside
+        // the branch, so no pending load of ITS registers reaches the join.
+        int m_bad, m_y = 0;
         float m_wy = 1.0f, m_denom = 1.0f;
         {
             // gi: this graph's number in the workspace (= g unless the launch gathers from a cached set)
             m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
-            if (!hf.train) {
-                m_y = 0;
-            } else if (hf.task == DRGNN_TASK_REG) {
+            if (hf.train && hf.task == DRGNN_TASK_REG) {
+#ifdef DRGNN_EMU
                 const float y = hf.y_reg[gi];
                 memcpy(&m_y, &y, 4);
-            } else {
+#else
+                m_y = __builtin_nontemporal_load((const int*)hf.y_reg + gi);
+#endif
+            } else if (hf.train) {
                 m_y = (int)hf.y_cls[gi];
                 m_wy = hf.class_w ? hf.class_w[m_y] : 1.0f;
                 // CrossEntropyLoss(weight): mean over the sum of the targets' weights
@@ -1172,6 +1178,10 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
                     for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w[hf.y_cls[GATHER ? a.gather_ids[q] : q]];
                     m_denom = lanes64_sum(part_sum);
                 }
+                // complete this branch's loads here (see above)
+                m_y = __builtin_amdgcn_readfirstlane(m_y);
+                m_wy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m_wy)));
+                m_bad = __builtin_amdgcn_readfirstlane(m_bad);
 #endif
             }
         }
@@ -1292,8 +1302,13 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
         // per-graph scalars of the readout / loss phases (fetched with the burst, see above)
         FOR_TID(i, 1) {
+#ifdef DRGNN_EMU
             memcpy(&s.misc[STEP_M_BAD], &m_bad, 4);
             memcpy(&s.misc[STEP_M_Y], &m_y, 4);
+#else
+            ((int*)s.misc)[STEP_M_BAD] = m_bad;       // whole words: a byte-wise copy makes the compiler take the value
+            ((int*)s.misc)[STEP_M_Y] = m_y;           // apart where it is LOADED (= a wait in the prologue)
+#endif
             s.misc[STEP_M_WY] = m_wy;
             s.misc[STEP_M_DENOM] = m_denom;
         }
