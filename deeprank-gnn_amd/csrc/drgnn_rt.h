@@ -124,24 +124,38 @@ DEV int wg_exscan(int* a, int n, int* part) {
     return run;
 }
 #else
+// inclusive scan over the 64 lanes of a wave on the DPP path (no LDS round trips): Hillis-Steele inside the rows of 16
+// lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 / lane 31 broadcast into the following rows
+template <int CTRL, int ROWMASK> DEV int dpp_add_i(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, true);
+}
+DEV int wave_incl_scan(int v) {
+    v = dpp_add_i<0x111, 0xF>(v);
+    v = dpp_add_i<0x112, 0xF>(v);
+    v = dpp_add_i<0x114, 0xF>(v);
+    v = dpp_add_i<0x118, 0xF>(v);
+    v = dpp_add_i<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+    v = dpp_add_i<0x143, 0xC>(v);      // row_bcast:31 into rows 2 and 3
+    return v;
+}
 DEV int wg_exscan(int* a, int n, int* part) {
     const int t = threadIdx.x;
     if (n <= DRGNN_NTHREADS) {
-        // one element per lane: wave-level inclusive scan (DPP shuffles), the 16 wave totals go
-        // through LDS and every lane adds the totals of the waves before its own -> 2 barriers
+        // one element per lane: wave-level inclusive scan, the totals of the waves that HOLD elements go through LDS and
+        // every lane adds the totals of the waves before its own -> 2 barriers.  Waves past the end only pass the barriers
+        // and add up the totals (an instruction of any wave occupies its SIMD for 4 cycles: typical scans here are a few
+        // hundred elements, 3 - 4 of the 16 waves).
         const int lane = t & (DRGNN_WAVE - 1), wave = t >> 6;
-        const int v = (t < n) ? a[t] : 0;
-        int inc = v;
-#pragma unroll
-        for (int d = 1; d < DRGNN_WAVE; d <<= 1) {
-            const int o = __shfl_up(inc, d, DRGNN_WAVE);
-            if (lane >= d) inc += o;
+        const int nw = (n + DRGNN_WAVE - 1) / DRGNN_WAVE;
+        int v = 0, inc = 0;
+        if (wave < nw) {
+            v = (t < n) ? a[t] : 0;
+            inc = wave_incl_scan(v);
+            if (lane == DRGNN_WAVE - 1) part[wave] = inc;
         }
-        if (lane == DRGNN_WAVE - 1) part[wave] = inc;
         __syncthreads();
         int base = 0, total = 0;
-#pragma unroll
-        for (int w = 0; w < DRGNN_NWAVES; ++w) {
+        for (int w = 0; w < nw; ++w) {
             const int tw = part[w];
             base += (w < wave) ? tw : 0;
             total += tw;

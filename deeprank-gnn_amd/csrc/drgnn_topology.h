@@ -106,9 +106,11 @@ struct TopoScratch {
 };
 
 #define TOPO_PAD4(n) (((n) + 3) & ~3LL)
+// mm[0], mm[1]: min / max of the ids being ranked; mm[2 + 2w], mm[3 + 2w]: wave w's partial min / max (wg_rank_prepare)
+#define TOPO_MM_INTS (4 + 4 * (DRGNN_NTHREADS / DRGNN_WAVE))
 // number of ints: linear in (capN, capE, capT, capF) -- keep in sync with topo_carve
 static inline int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT, int64_t capF) {
-    return 4 + TOPO_PAD4(DRGNN_NTHREADS + 1) + 6 * TOPO_PAD4(capN + 1) + 3 * TOPO_PAD4(capN) +
+    return TOPO_MM_INTS + TOPO_PAD4(DRGNN_NTHREADS + 1) + 6 * TOPO_PAD4(capN + 1) + 3 * TOPO_PAD4(capN) +
            6 * TOPO_PAD4(capE) + 5 * TOPO_PAD4(capT) + TOPO_PAD4(capF);
 }
 
@@ -116,7 +118,7 @@ static inline int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT
 // capT = N+E+1 and capF = N+E+2 the carve needs at most 15*N + 12*E + TOPO_GSCRATCH_CONST ints
 // (the constant absorbs the fixed arrays and every PAD4 rounding), so regions placed at
 // 15*n0 + 12*e0 + CONST*g (rounded up to even for the 64-bit min/max slot) never overlap.
-#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 176)
+#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 176 + 4 * (DRGNN_NTHREADS / DRGNN_WAVE))
 HD int64_t topo_gscratch_base(int64_t n0, int64_t e0, int64_t g) {
     return ((15 * n0 + 12 * e0 + (int64_t)TOPO_GSCRATCH_CONST * g) + 1) & ~(int64_t)1;
 }
@@ -125,7 +127,7 @@ template <class IntPtr>
 DEV TopoScratch topo_carve(IntPtr base, int capN, int capE, int capT, int capF) {
     TopoScratch s;
     int o = 0;
-    s.mm = (long long*)(base + o); o += 4;
+    s.mm = (long long*)(base + o); o += TOPO_MM_INTS;
     s.part = base + o; o += (int)TOPO_PAD4(DRGNN_NTHREADS + 1);
     s.rp = base + o;   o += (int)TOPO_PAD4(capN + 1);
     s.cp = base + o;   o += (int)TOPO_PAD4(capN + 1);
@@ -226,12 +228,63 @@ DEV void wg_minmax64(const int64_t* ids, int n, long long* mm, bool preinit = fa
     BARRIER();
 }
 
-// `prepared`: the caller has, in an earlier phase, set mm = {MAX, MIN} and cleared fl[0..capF)
+// Preparation of wg_cluster_rank inside an EARLIER phase of the caller (so that the ids' memory latency overlaps that
+// phase's own loads and no phase of its own is spent on the min / max): every wave leaves the min / max of the ids its
+// lanes read in mm[2 + 2w], mm[3 + 2w] and the ids' low words go to s.pp (id - min fits 32 bits whenever the flag path is
+// taken, so the low words are all that path needs).  The caller also clears fl[0..capF) and ends the phase with a barrier.
+DEV void wg_rank_prepare(const int64_t* ids, int n, TopoScratch& s) {
+#ifdef DRGNN_EMU
+    long long lo = LLONG_MAX, hi = LLONG_MIN;
+    for (int i = 0; i < n; ++i) {
+        const long long v = (long long)ids[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+        s.pp[i] = (int)(unsigned int)((unsigned long long)v & 0xffffffffull);
+    }
+    for (int w = 0; w < DRGNN_NTHREADS / DRGNN_WAVE; ++w) { s.mm[2 + 2 * w] = LLONG_MAX; s.mm[3 + 2 * w] = LLONG_MIN; }
+    s.mm[2] = lo; s.mm[3] = hi;
+#else
+    long long lo = LLONG_MAX, hi = LLONG_MIN;
+    for (int i = threadIdx.x; i < n; i += DRGNN_NTHREADS) {
+        const long long v = (long long)ids[i];
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+        s.pp[i] = (int)(unsigned int)((unsigned long long)v & 0xffffffffull);
+    }
+    // only the waves that read ids take part (the rank routine reads the first ceil(min(n, threads) / 64) slots): 64-bit
+    // butterflies cost ~25 instructions a step, and every instruction of a wave occupies its SIMD for 4 cycles
+    if ((int)(threadIdx.x & ~(DRGNN_WAVE - 1)) < n) {
+#pragma unroll
+        for (int d = DRGNN_WAVE / 2; d >= 1; d >>= 1) {
+            const long long ol = __shfl_xor(lo, d, DRGNN_WAVE), oh = __shfl_xor(hi, d, DRGNN_WAVE);
+            lo = ol < lo ? ol : lo;
+            hi = oh > hi ? oh : hi;
+        }
+        if ((threadIdx.x & (DRGNN_WAVE - 1)) == 0) {
+            s.mm[2 + 2 * (threadIdx.x / DRGNN_WAVE)] = lo;
+            s.mm[3 + 2 * (threadIdx.x / DRGNN_WAVE)] = hi;
+        }
+    }
+#endif
+}
+
+// `prepared`: the caller has run wg_rank_prepare(ids, n, s) and cleared fl[0..capF) in an earlier phase
 DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n, TopoScratch& s,
                         bool prepared = false, bool with_members = true) {
-    wg_minmax64(ids, n, s.mm, prepared);
-    const long long mn = s.mm[0];
-    const long long span = (n > 0) ? (s.mm[1] - mn + 1) : 0;
+    long long mn, mx;
+    if (prepared) {
+        mn = LLONG_MAX; mx = LLONG_MIN;
+        const int nw = imin(DRGNN_NTHREADS / DRGNN_WAVE, (n + DRGNN_WAVE - 1) / DRGNN_WAVE);     // slots that were written
+        for (int w = 0; w < nw; ++w) {
+            const long long l = s.mm[2 + 2 * w], h = s.mm[3 + 2 * w];
+            mn = l < mn ? l : mn;
+            mx = h > mx ? h : mx;
+        }
+    } else {
+        wg_minmax64(ids, n, s.mm, false);
+        mn = s.mm[0]; mx = s.mm[1];
+    }
+    const long long span = (n > 0) ? (mx - mn + 1) : 0;
     int C;
     if (span >= 0 && span <= (long long)(s.capF - 1)) {
         // usual case (ids are small labels): presence flags over [min, max] + scan, O(n + span)
@@ -240,10 +293,14 @@ DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n
             FOR_TID(v, range + 1) { s.fl[v] = 0; }
             BARRIER();
         }
-        FOR_TID(i, n) { s.fl[(int)((long long)ids[i] - mn)] = 1; }
+        // (prepared: id - min from the staged low words, exact because 0 <= id - min < capF)
+        const unsigned int mn_lo = (unsigned int)((unsigned long long)mn & 0xffffffffull);
+        if (prepared) { FOR_TID(i, n) { s.fl[(int)((unsigned int)s.pp[i] - mn_lo)] = 1; } }
+        else { FOR_TID(i, n) { s.fl[(int)((long long)ids[i] - mn)] = 1; } }
         BARRIER();
         C = wg_exscan(s.fl, range + 1, s.part);
-        FOR_TID(i, n) { s.cl[i] = s.fl[(int)((long long)ids[i] - mn)]; }
+        if (prepared) { FOR_TID(i, n) { s.cl[i] = s.fl[(int)((unsigned int)s.pp[i] - mn_lo)]; } }
+        else { FOR_TID(i, n) { s.cl[i] = s.fl[(int)((long long)ids[i] - mn)]; } }
         FOR_TID(b, n + 1) { s.mp[b] = 0; s.cur[b] = 0; }       // for the member bucket sort below
         BARRIER();
     } else {
@@ -630,10 +687,11 @@ DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, in
                         int sidx) {
     if (a.cluster1 == nullptr || a.c1_ptr == nullptr) return;
     FOR_TID(v, s.capF) { s.fl[v] = 0; }
-    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
-    BARRIER();
     const int b = a.c1_ptr[g];
-    topo_graph_level1(tv, a, g, n0, C, src.cl1, a.c1_ptr[g + 1] - b, s, sidx, true);
+    const int c1_len = a.c1_ptr[g + 1] - b;
+    wg_rank_prepare(src.cl1, imin(C, imax(c1_len, 0)), s);
+    BARRIER();
+    topo_graph_level1(tv, a, g, n0, C, src.cl1, c1_len, s, sidx, true);
 }
 
 DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1, int e0, int e1,
@@ -660,7 +718,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         FOR_TID(i, N) { s.nb[i] = 0; }
     }
     FOR_TID(v, s.capF) { s.fl[v] = 0; }                       // for the depth-0 cluster ranks
-    FOR_TID(i, 1) { s.mm[0] = LLONG_MAX; s.mm[1] = LLONG_MIN; }
+    if (a.cluster0 != nullptr) wg_rank_prepare(src.cl0, N, s);
     BARRIER();
 
     if (structure) topo_csr0(tv, g, n0, e0, N, E, has_w, s);
