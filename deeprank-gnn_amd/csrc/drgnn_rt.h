@@ -47,7 +47,8 @@ typedef void* drgnn_stream_t;
 #ifndef DRGNN_NTHREADS
 #define DRGNN_NTHREADS 1024
 #endif
-#define FOR_TID(i, n) for (int i = (int)threadIdx.x; i < (int)(n); i += DRGNN_NTHREADS)
+// (nounroll: these loops run once per workgroup with 1 - 3 trips; unrolled copies are instruction-cache misses for nothing)
+#define FOR_TID(i, n) _Pragma("nounroll") for (int i = (int)threadIdx.x; i < (int)(n); i += DRGNN_NTHREADS)
 #ifdef DRGNN_PHASE_TIMING
 // profiling build only (libdrgnn_prof.so, tools/phase_timing.py): thread 0 of workgroup 0
 // stamps (source line, shader clock) after every barrier into a global buffer.
