@@ -679,7 +679,7 @@ def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=3):
 
     def run(cached):
         def epoch():
-            order = torch.randperm(n_graphs, generator=gen).tolist()
+            order = torch.randperm(n_graphs, generator=gen)
             done = tr.train_epoch(rs, order, GRAPHS_PER_GPU, cached=cached)
             if done is None:
                 raise RuntimeError("the native epoch loop refused this configuration")

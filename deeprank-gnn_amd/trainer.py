@@ -448,6 +448,8 @@ class FusedTrainer(object):
         need_w = self.kind == _lib.SGAT
         if need_w and gset.edge_attr is None:
             return None
+        if torch.is_tensor(order):      # (a Python list of 10^4 numbers costs ~1 ms to convert: as long as 40 mini-batches)
+            order = order.detach().to(device="cpu", dtype=torch.int32).numpy()
         ids_host = np.ascontiguousarray(np.asarray(order, dtype=np.int32).reshape(-1))
         n = int(ids_host.size)
         dev = self.flat_p.device
