@@ -220,7 +220,9 @@ class NeuralNet(object):
                 store['_pred'].append(pred)
                 store['_y'].append(rs.y[torch.as_tensor(order, dtype=torch.long, device=rs.y.device)])
                 store['mol'] += [rs.mols[i] for i in order]
-                return float(losses.sum()), self._finish(store)
+                total = float(losses.sum())          # (synchronises)
+                self.trainer.check_faults()
+                return total, self._finish(store)
         running = torch.zeros((), dtype=torch.float32, device=self.device)
         need_w = self.trainer.kind == _lib.SGAT
         it = self._batches(self.dataset, self.train_index, self.shuffle)
@@ -237,7 +239,9 @@ class NeuralNet(object):
             running += loss.reshape(())
             self._collect(self.trainer.last_pred, batch, store)
             batch, topo = nxt, nxt_topo
-        return float(running), self._finish(store)
+        total = float(running)
+        self.trainer.check_faults()
+        return total, self._finish(store)
 
     def _epoch_data_parallel(self, store, world, rank):
         """One epoch with ``batch_size`` as the GLOBAL mini-batch, sharded over the ranks (contiguous shards, sizes differ
@@ -275,7 +279,9 @@ class NeuralNet(object):
         w = torch.tensor([len(p) / float(n) for p, n in zip(parts, sizes)], dtype=torch.float32, device=losses.device)
         total = (losses * w).sum()
         dist.all_reduce(total)
-        return float(total), self._finish(store)
+        total = float(total)                  # (synchronises)
+        self.trainer.check_faults()
+        return total, self._finish(store)
 
     def _sum_of_batch_losses(self, pred, y):
         """Sum over the mini-batches of each batch's mean loss (what the reference accumulates, NeuralNet.py:441-447)."""

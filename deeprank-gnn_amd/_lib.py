@@ -26,6 +26,7 @@ TI_COUNT = len(TI)
 TF = {"W0": 0, "W1": 1}
 TF_COUNT = 2
 
+FAULT_EXCHANGE = 1      # DRGNN_FAULT_EXCHANGE (step2[2])
 STATUS_BITS = {1: "edge endpoint outside its graph's node range",
                2: "batch vector / edge list not grouped by graph",
                4: "cluster ids of one graph span too large a range",

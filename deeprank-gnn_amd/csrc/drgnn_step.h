@@ -53,7 +53,7 @@ struct StepArgs {
     int n_partial;
     HeadFused hf;                // hf.readout: [B][R] OUTPUT; hf.partials: [B][head_compact_floats]
     unsigned long long* xchg;    // [B][n_branch][H] tagged fc1 half-products (zero-initialised once by the owner)
-    int32_t* step2;              // [0] steps completed so far (read)   [1] index of this step (written)
+    int32_t* step2;              // [0] steps completed so far (read)   [1] index of this step (written)   [2] sticky fault bits
     // cached-topology mode: slot g of the launch is graph gather_ids[g] of the workspace `tv` describes (a whole
     // resident set, ws_graphs graphs); null: slot g = graph g of a per-mini-batch workspace
     const int32_t* gather_ids;
@@ -737,8 +737,8 @@ DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v) {
     uint32_t bits; memcpy(&bits, &v, 4);
     *slot = ((unsigned long long)tag << 32) | bits;
 }
-DEV float xchg_wait(unsigned long long* slot, uint32_t tag) {      // emulation: the partner's pass 1 is complete
-    (void)tag;
+DEV float xchg_wait(unsigned long long* slot, uint32_t tag, int32_t* fault) {      // emulation: the partner's pass 1 is complete
+    (void)tag; (void)fault;
     const uint32_t bits = (uint32_t)*slot;
     float v; memcpy(&v, &bits, 4);
     return v;
@@ -748,16 +748,18 @@ DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v) {
     const unsigned long long w = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
     __hip_atomic_store(slot, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// Spins until the partner has published its value of THIS step.  Both branch workgroups of a graph
-// are adjacent in the grid and the launch fits the device in one wave, so the partner is resident;
-// the wait is nevertheless bounded (~0.3 s of the 100 MHz wall clock): on expiry the value is NaN,
-// which surfaces as a NaN loss instead of a hung queue.
-DEV float xchg_wait(unsigned long long* slot, uint32_t tag) {
+// Spins until the partner has published its value of THIS step.  The branch workgroups of a graph are 8 block ids apart
+// (same XCD); up to 64 graphs the launch fits the device in one wave and the partner is resident.  Larger batches rely
+// on the dispatcher handing out blocks in id order (it does; HIP does not promise it): the partner then becomes resident
+// as soon as any earlier workgroup retires, long before this wait's bound (~0.3 s of the 100 MHz wall clock).  On expiry
+// the value is NaN (a NaN loss instead of a hung queue) AND bit DRGNN_FAULT_EXCHANGE is raised in the sticky fault word
+// step2[2], which the trainers check once per epoch.
+DEV float xchg_wait(unsigned long long* slot, uint32_t tag, int32_t* fault) {
     const unsigned long long t0 = wall_clock64();
     for (;;) {
         const unsigned long long w = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((uint32_t)(w >> 32) == tag) return __uint_as_float((uint32_t)w);
-        if (wall_clock64() - t0 > 30000000ull) return DRGNN_NAN;
+        if (wall_clock64() - t0 > 30000000ull) { atomicOr(fault, DRGNN_FAULT_EXCHANGE); return DRGNN_NAN; }
         __builtin_amdgcn_s_sleep(1);
     }
 }
@@ -814,7 +816,7 @@ template <int WJ> DEV void step_wblock_store(const WBlockRegs<WJ>& wr, const Hea
 template <int HC>
 DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
                          const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
-                         uint32_t thresh, float keep_scale, int part) {
+                         uint32_t thresh, float keep_scale, int part, int32_t* fault) {
     const int H = HC ? HC : hf.H;
 #ifdef DRGNN_EMU
     if (part != 2) {
@@ -827,7 +829,7 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
     }
     if (part == 1) return;
     for (int h = 0; h < H; ++h) {
-        float v = (nb > 1) ? xchg_wait(xg + h, tag) + xchg_wait(xg + H + h, tag) : hid[h];
+        float v = (nb > 1) ? xchg_wait(xg + h, tag, fault) + xchg_wait(xg + H + h, tag, fault) : hid[h];
         v += b1[h];
         v = v > 0.0f ? v : 0.0f;
         if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
@@ -850,7 +852,7 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
             if (nb > 1) {
                 xchg_publish(xg + (long)br * H + h, tag, acc);
                 float other = 0.0f;
-                PH(7) other = xchg_wait(xg + (long)(1 - br) * H + h, tag);
+                PH(7) other = xchg_wait(xg + (long)(1 - br) * H + h, tag, fault);
                 // inference launches all carry the same tag (the step counter does not move): the reader clears
                 // the word it consumed, so that the next launch cannot pick up this one's value.  Training
                 // launches skip it -- their tag changes every step and the write-through store would sit on the
@@ -873,9 +875,9 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
 template <int WREF, bool ONLY>
 DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
                        const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
-                       uint32_t thresh, float keep_scale, int part) {
-    if (ONLY || hf.H == WREF) step_head_fc1_t<WREF>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
-    else step_head_fc1_t<0>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part);
+                       uint32_t thresh, float keep_scale, int part, int32_t* fault) {
+    if (ONLY || hf.H == WREF) step_head_fc1_t<WREF>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part, fault);
+    else step_head_fc1_t<0>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part, fault);
 }
 
 
@@ -1413,7 +1415,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
     FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
     // half product of fc1 with this branch's readout, exchange with the partner workgroup, hid
     PH(8) step_head_fc1<WREF, (XF != 0)>(hf, g, br, nb, s.wb, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
-                        keep_scale, part);
+                        keep_scale, part, a.step2 + 2);
     if (part == 1) return;
     BARRIER();
     EXIT_AFTER(9);

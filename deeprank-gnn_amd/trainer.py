@@ -65,7 +65,8 @@ class FusedTrainer(object):
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
         # [0] optimiser steps completed, [1] index of the step in flight (fused step launch writes it,
         # the update launch reads it for Adam and commits [0]); `step` is the public 1-element view
-        self.step2 = torch.zeros(2, dtype=torch.int32, device=dev)
+        # ([2]: sticky fault bits the fused step raises, see check_faults; [3] reserved)
+        self.step2 = torch.zeros(4, dtype=torch.int32, device=dev)
         self.step = self.step2[:1]
         self.fused_step = True       # one launch for fwd + head + bwd whenever a graph fits LDS
         self._xchg = {}              # readout exchange words of the fused step, per batch size
@@ -409,6 +410,21 @@ class FusedTrainer(object):
         self.all_reduce_gradients(n_global=n_global, group=group)
         self.apply_update()
         return loss
+
+    def faults(self):
+        """Sticky fault bits raised by the fused-step kernels since the last reset (synchronises): bit
+        ``_lib.FAULT_EXCHANGE`` = a GINet branch workgroup waited in vain for its partner's half of fc1 (its outputs and
+        that step's loss are NaN)."""
+        return int(self.step2[2])
+
+    def check_faults(self):
+        """Raise if a kernel has reported a fault (called by NeuralNet once per epoch, where it synchronises anyway)."""
+        bits = self.faults()
+        if bits:
+            self.step2[2] = 0
+            raise _lib.DrgnnError("fused training step reported fault bits 0x%x%s" % (
+                bits, ": the branch workgroups of a graph did not meet (exchange wait expired); the losses of this epoch "
+                      "are NaN -- reduce the batch size or set trainer.fused_step = False" if bits & _lib.FAULT_EXCHANGE else ""))
 
     def predict_epoch(self, gset, order, batch_size, cached=False):
         """Inference over the graphs ``order`` of the resident set, native loop (one launch per mini-batch, no

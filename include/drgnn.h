@@ -40,6 +40,8 @@ extern "C" {
 #define DRGNN_S_UNSORTED      2  /* batch vector / edge list not grouped by graph        */
 #define DRGNN_S_CLUSTER_RANGE 4  /* a graph's cluster ids span more than N_g+E_g+1 values*/
 #define DRGNN_S_CLUSTER1_LEN  8  /* len(cluster1) != number of depth-0 clusters          */
+/* fault bits of step2[2] (fused training step) */
+#define DRGNN_FAULT_EXCHANGE  1  /* a GINet branch workgroup waited in vain for its partner's half of fc1 (value = NaN) */
 
 /* layer kinds (what "conv" means) */
 #define DRGNN_GINET 0  /* z_i = sum_{e:row=i} W x_col            ginet.py:50-73 (alpha == 1)   */
@@ -365,8 +367,9 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  * half), optionally sharing the grid with the topology build of the NEXT mini-batch.  Replaces,
  * together with drgnn_step_update, the whole loop body of NeuralNet._epoch (NeuralNet.py:489-506:
  * zero_grad, model(batch), loss, backward, optimizer.step) for GINet / sGAT / FoutNet.
- *   step2     device int32[2]: [0] = optimiser steps completed (selects the dropout stream, read
- *             only); [1] = index of this step, written here.  drgnn_step_update commits [0] = [1].
+ *   step2     device int32[4], zero-initialised by the owner: [0] = optimiser steps completed (selects the dropout
+ *             stream, read only); [1] = index of this step, written here (drgnn_step_update commits [0] = [1]);
+ *             [2] = sticky fault bits (DRGNN_FAULT_*), only ever OR-ed into by the kernels; [3] reserved.
  *   readout   OUT [B, 32*n_branch]; pred OUT [B, O]
  *   head_partials OUT [B][drgnn_head_compact_elems]: [dhid H][dW_fc2 O*H][db_fc2 O][loss][weight]
  *             (dW_fc1 = dhid^T readout is formed by drgnn_step_update)

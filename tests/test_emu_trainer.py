@@ -177,3 +177,19 @@ def test_pipelined_topology_build_is_equivalent():
         assert la == lb
         topo = nxt
     assert torch.equal(ta.flat_p, tb.flat_p)
+
+
+def test_fault_word_is_reported_once_and_cleared():
+    """step2[2] collects sticky fault bits of the fused step (a GINet branch workgroup whose partner never published);
+    the trainer raises on them once per check and clears the word.  A clean run leaves it zero."""
+    torch.manual_seed(0)
+    batch = syn4_batch()
+    tr = FusedTrainer(GINet(12, 1, 1), lr=1e-3, task="reg", api=emu())
+    tr.train_step(batch)
+    assert tr.faults() == 0
+    tr.check_faults()
+    tr.step2[2] = _lib.FAULT_EXCHANGE
+    with pytest.raises(_lib.DrgnnError, match="did not meet"):
+        tr.check_faults()
+    assert tr.faults() == 0
+    assert int(tr.step) == 1          # the step counters next to it are untouched

@@ -1,8 +1,8 @@
-for b in 64 128 256 512 1024 2048; do
-  python bench.py --graphs-per-gpu $b --steps 200 --warmup 20 --no-cpu-baseline > gpurun_out/sweep_$b.log 2>&1
-done
-for b in 64 256 1024; do
-  python bench.py --graphs-per-gpu $b --steps 100 --warmup 10 --no-cpu-baseline --net sGAT > gpurun_out/sweep_sgat_$b.log 2>&1
-  python bench.py --graphs-per-gpu $b --steps 100 --warmup 10 --no-cpu-baseline --net FoutNet > gpurun_out/sweep_fout_$b.log 2>&1
-done
-echo done
+#!/bin/bash
+# graphs/s of the three nets at batch 64 / 256 / 1024, topology rebuilt every step and cached (DESIGN.md's table)
+mkdir -p gpurun_out/sweep
+for net in GINet sGAT FoutNet; do for mode in rebuilt cached; do for b in 64 256 1024; do
+  python bench.py --net $net --topology $mode --graphs-per-gpu $b --no-cpu-baseline --epoch-graphs 0 2>/dev/null | python -c "
+import json,sys;d=json.loads(sys.stdin.read())
+print('$net $mode B=$b  %.2f us/step  %.3f M graphs/s' % (d['ms_per_step']*1000, d['value']/1e6))" | tee -a gpurun_out/sweep/sweep.txt
+done; done; done
