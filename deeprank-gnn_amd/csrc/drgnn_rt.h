@@ -353,6 +353,66 @@ template <int J> DEV void bufburst_store16(const BufBurst<J>& b, unsigned short*
 }
 #endif
 
+// ---------------------------------------------------------------------------------
+// Wave-specialised staging of the SMALL arrays (offset tables, index lists, bias vectors): one staging job = one array
+// (or half of one) of at most 1024 32-bit words, handled by ONE wave with up to four 128-bit buffer loads (64 lanes x 4
+// words x 4) that stay in its registers until the LDS store one phase later.  Why: every instruction that all 16 waves of
+// a workgroup execute occupies every SIMD for 4 x 4 cycles whether its lanes hold data or not; a dozen arrays of a few
+// hundred words each, staged by all waves, cost ~150 instructions per wave and burst -- as one job per wave they cost ~25.
+// `src` / `n` / `dst` are wave-uniform.  dst is 16-byte aligned and padded to a multiple of 4 words (step_carve); the
+// source needs 4-byte alignment only (the hardware range check is per word: tools/probes/buffer_x4_range_probe.hip).
+// ---------------------------------------------------------------------------------
+struct StageJob { const void* src; int n; void* dst; int narrow; };      // narrow: store the words as 16-bit values
+// the two halves of an array too long for one job (n <= 2048): [0, h) and [h, n), h a multiple of 4
+DEV StageJob stage_half(StageJob j, int which) {
+    int h = ((j.n + 7) >> 3) << 2;
+    if (h > j.n) h = j.n;
+    if (which == 0) { j.n = h; return j; }
+    j.src = (const int32_t*)j.src + h;
+    j.dst = j.narrow ? (void*)((unsigned short*)j.dst + h) : (void*)((int32_t*)j.dst + h);
+    j.n -= h;
+    return j;
+}
+#ifdef DRGNN_EMU
+struct WaveStage { int dummy; };
+DEV void stage_copy(const StageJob& j) {
+    for (int i = 0; i < j.n; ++i) {
+        const int32_t v = ((const int32_t*)j.src)[i];
+        if (j.narrow) ((unsigned short*)j.dst)[i] = (unsigned short)v;
+        else ((int32_t*)j.dst)[i] = v;
+    }
+}
+#else
+typedef int drgnn_i4 __attribute__((ext_vector_type(4)));
+struct WaveStage { drgnn_i4 v[4]; int n; void* dst; int narrow; };
+DEV void wstage_load(WaveStage& w, const StageJob& j) {
+    w.n = j.src ? j.n : 0; w.dst = j.dst; w.narrow = j.narrow;
+    const __amdgpu_buffer_rsrc_t r = buf_rsrc(j.src, w.n * 4);
+    const int voff = (threadIdx.x & 63) * 16;
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+        if (it * 256 < w.n) w.v[it] = __builtin_amdgcn_raw_buffer_load_b128(r, voff, it * 1024, 0);
+}
+DEV void wstage_store(const WaveStage& w) {
+    const int lane4 = (threadIdx.x & 63) * 4;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        if (it * 256 >= w.n) break;
+        const int e = it * 256 + lane4;
+        if (e < w.n) {
+            if (w.narrow) {
+                const unsigned int lo = ((unsigned int)w.v[it][0] & 0xffffu) | ((unsigned int)w.v[it][1] << 16);
+                const unsigned int hi = ((unsigned int)w.v[it][2] & 0xffffu) | ((unsigned int)w.v[it][3] << 16);
+                typedef unsigned int drgnn_u2 __attribute__((ext_vector_type(2)));
+                *(drgnn_u2*)((unsigned short*)w.dst + e) = drgnn_u2{lo, hi};
+            } else {
+                *(drgnn_i4*)((int32_t*)w.dst + e) = w.v[it];
+            }
+        }
+    }
+}
+#endif
+
 // x tile with rows padded to `ld` floats (ld % 4 == 0: 16-byte aligned rows, one 128-bit LDS store per
 // float4; ld = 36 keeps the 16 row lanes of an MFMA A-operand read on distinct banks)
 #ifdef DRGNN_EMU

@@ -1136,8 +1136,78 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         // and head weights) is written to LDS after it -- their memory time hides behind the MFMAs.
         BurstX<4> bx;
         BurstW<1> bw1, bw2, bs1, bs2;
-        BufBurst<1> brp0, bcp0, bmp0, bmem0, brp1, bcp1, bmp1, bmem1, bb1, bb2, bhb1, bhb2;
-        BufBurst<2> bcx0, brx0, bcx1, brx1, bts0, bts1, bew0, bew1, bhw2;
+        // The small arrays (offset tables, index lists, head / bias vectors) are staged ONE ARRAY PER WAVE (rt.h,
+        // StageJob): stage_job(burst, wave) names wave `wave`'s array of a burst -- at most 16 jobs per burst.
+        //   burst 1 (requested with the x tile, filed before conv1's product): what conv1's aggregation and pooling read
+        //   burst 2 (requested before conv1's product, filed after the aggregation): the pooled level, the head, and for
+        //           GINet the CSC arrays of the backward pass
+        //   burst 3 (sGAT / FoutNet: requested with the cluster max, filed after conv2's product): backward-only arrays
+        WaveStage wst;
+#ifndef DRGNN_EMU
+        const int my_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+#endif
+        auto stage_job = [&](int burst, int w) -> StageJob {
+            const int32_t* const* P = tv.p;
+            const int nar = NARROW ? 1 : 0;
+            StageJob j = {nullptr, 0, nullptr, 0};
+            switch (burst * 16 + w) {
+            case 16 + 0: j = StageJob{P[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1, s.rp0, 0}; break;
+            case 16 + 1: j = stage_half(StageJob{P[DRGNN_TI_COL0] + d.e0, d.E, s.cx0, nar}, 0); break;
+            case 16 + 2: j = stage_half(StageJob{P[DRGNN_TI_COL0] + d.e0, d.E, s.cx0, nar}, 1); break;
+            case 16 + 3: j = StageJob{P[DRGNN_TI_MPTR0] + d.rowbase, bC + 1, s.mp0, 0}; break;
+            case 16 + 4: j = StageJob{P[DRGNN_TI_MEM0] + d.n0, d.N, s.mem0, 0}; break;
+            case 16 + 5: if (!GIN) j = StageJob{c1.bias, DRGNN_H1, s.b1, 0}; break;
+            case 16 + 6: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w0 + d.e0, d.E, s.ew0, 0}, 0); break;
+            case 16 + 7: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w0 + d.e0, d.E, s.ew0, 0}, 1); break;
+
+            case 32 + 0: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
+            case 32 + 1: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, nar}, 0); break;
+            case 32 + 2: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, nar}, 1); break;
+            case 32 + 3: j = StageJob{P[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1, s.mp1, 0}; break;
+            case 32 + 4: j = StageJob{P[DRGNN_TI_MEM1] + d.n0, bC, s.mem1, 0}; break;
+            case 32 + 5: j = StageJob{hf.b1, H, s.hb1, 0}; break;
+            case 32 + 6: j = stage_half(StageJob{hf.w2, O * H, s.hw2, 0}, 0); break;
+            case 32 + 7: j = stage_half(StageJob{hf.w2, O * H, s.hw2, 0}, 1); break;
+            case 32 + 8: j = StageJob{hf.b2, O, s.hb2, 0}; break;
+            // (waves 9 .. 14 of burst 2: GINet's backward-only CSC arrays; the other nets' bias / pooled edge weights --
+            // their backward-only arrays are burst 3)
+            case 32 + 9:
+                if (GIN) j = StageJob{P[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1, s.cp0, 0};
+                else j = StageJob{c2.bias, DRGNN_H2, s.b2, 0};
+                break;
+            case 32 + 10:
+                if (GIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX0] + d.e0, d.E, s.rx0, nar}, 0);
+                else if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 0);
+                break;
+            case 32 + 11:
+                if (GIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX0] + d.e0, d.E, s.rx0, nar}, 1);
+                else if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 1);
+                break;
+            case 32 + 12: if (GIN) j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+            case 32 + 13: if (GIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 0); break;
+            case 32 + 14: if (GIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 1); break;
+
+            case 48 + 0: if (!GIN) j = StageJob{P[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1, s.cp0, 0}; break;
+            case 48 + 1: if (!GIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX0] + d.e0, d.E, s.rx0, nar}, 0); break;
+            case 48 + 2: if (!GIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX0] + d.e0, d.E, s.rx0, nar}, 1); break;
+            case 48 + 3: if (!GIN) j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+            case 48 + 4: if (!GIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 0); break;
+            case 48 + 5: if (!GIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 1); break;
+            case 48 + 6: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT0] + d.e0, d.E, s.ts0, nar}, 0); break;
+            case 48 + 7: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT0] + d.e0, d.E, s.ts0, nar}, 1); break;
+            case 48 + 8: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 0); break;
+            case 48 + 9: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 1); break;
+            default: break;
+            }
+            return j;
+        };
+#ifdef DRGNN_EMU
+        auto stage_request = [&](int burst) { (void)burst; };
+        auto stage_file = [&](int burst) { for (int w = 0; w < 16; ++w) stage_copy(stage_job(burst, w)); };
+#else
+        auto stage_request = [&](int burst) { wstage_load(wst, stage_job(burst, my_wave)); };
+        auto stage_file = [&](int burst) { (void)burst; wstage_store(wst); };
+#endif
 #ifndef DRGNN_EMU
         {   // fetch every workspace pointer in one go: otherwise each array's staging starts with its own
             // kernarg read + wait
@@ -1191,15 +1261,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
             // first burst: only what conv1 needs (x tile, its weights, CSR0, depth-0 member lists)
             burst_load_x(bx, xg, (DRGNN_SKIP == 20) ? 0 : d.N, F);
             burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
-            if (KIND != DRGNN_GINET) {
-                burst_load_w(bs1, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
-                bufburst_load(bb1, c1.bias, DRGNN_H1);
-            }
-            bufburst_load(brp0, tv.p[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1);
-            bufburst_load(bcx0, tv.p[DRGNN_TI_COL0] + d.e0, d.E);
-            bufburst_load(bmp0, tv.p[DRGNN_TI_MPTR0] + d.rowbase, bC + 1);
-            bufburst_load(bmem0, tv.p[DRGNN_TI_MEM0] + d.n0, d.N);
-            if (KIND == DRGNN_SGAT) bufburst_load(bew0, tv.w0 + d.e0, d.E);
+            if (KIND != DRGNN_GINET) burst_load_w(bs1, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
+            stage_request(1);
             burst_store_x4(bx, s.xs, XLD);
             burst_store_wt(bw1, s.w1t, XLD);
             if (KIND != DRGNN_GINET) burst_store_wt(bs1, s.ws1t, XLD);
@@ -1268,38 +1331,18 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
 
         // ---- forward ------------------------------------------------------------------
         if (burst) {
-            // second burst, in flight behind conv1's product and aggregation: everything the later phases use
+            // burst 1 has landed with the x tile: file it (its registers serve burst 2), then request burst 2, in
+            // flight behind conv1's product and aggregation: everything the later phases use
+            stage_file(1);
             burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
-            bufburst_load(brp1, tv.p[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1);
-            bufburst_load(bcx1, tv.p[DRGNN_TI_COL1] + d.e0, bE1);
-            bufburst_load(bmp1, tv.p[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1);
-            bufburst_load(bmem1, tv.p[DRGNN_TI_MEM1] + d.n0, bC);
             step_wblock_load(wreg, hf, br);
-            bufburst_load(bhb1, hf.b1, H);
-            bufburst_load(bhw2, hf.w2, O * H);
-            bufburst_load(bhb2, hf.b2, O);
-            if (!LATE3) {
-                bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
-                bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
-                bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1);
-                bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, bE1);
-            }
-            if (KIND != DRGNN_GINET) {
-                burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
-                bufburst_load(bb2, c2.bias, DRGNN_H2);
-            }
-            if (KIND == DRGNN_SGAT) bufburst_load(bew1, tv.w1 + d.e0, bE1);
+            if (KIND != DRGNN_GINET) burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
+            stage_request(2);
         }
         if (KIND == DRGNN_GINET) {
             PH(1) step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t, XLD, s.u1, HC1, dummy);
         } else {
             PH(1) step_gemm_nn_dual(d.N, F16, s.xs, XLD, s.w1t, s.ws1t, XLD, s.u1, HC1, dummy);
-        }
-        if (burst) {
-            bufburst_store(brp0, s.rp0, dummy); step_store_idx<NARROW>(bcx0, s.cx0, dummy);
-            bufburst_store(bmp0, s.mp0, dummy); bufburst_store(bmem0, s.mem0, dummy);
-            if (KIND != DRGNN_GINET) bufburst_store(bb1, s.b1, dummy);
-            if (KIND == DRGNN_SGAT) bufburst_store(bew0, s.ew0, dummy);
         }
         FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
         // per-graph scalars of the readout / loss phases (fetched with the burst, see above)
@@ -1326,34 +1369,19 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
                 burst_store_wt(bw2, s.wc2t, TSLD);                         // wc2t[n][k] = Wnbr[k][n]
                 burst_store_w(bw2, s.wc2n, TSLD);                          // wc2n[k][n] = Wnbr[k][n]
             }
-            bufburst_store(brp1, s.rp1, dummy); step_store_idx<NARROW>(bcx1, s.cx1, dummy);
-            bufburst_store(bmp1, s.mp1, dummy); bufburst_store(bmem1, s.mem1, dummy);
             step_wblock_store(wreg, hf, br, s.wb);
-            bufburst_store(bhb1, s.hb1, dummy); bufburst_store(bhw2, s.hw2, dummy); bufburst_store(bhb2, s.hb2, dummy);
-            if (!LATE3) {
-                bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
-                bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
-            }
             if (KIND != DRGNN_GINET) {
                 burst_store_wt(bs2, s.wc2t + DRGNN_H1, TSLD);              // wc2t[n][16 + k] = Wself[k][n]
                 burst_store_w(bs2, s.wc2n + DRGNN_H1 * TSLD, TSLD);       // wc2n[16 + k][n] = Wself[k][n]
-                bufburst_store(bb2, s.b2, dummy);
             }
-            if (KIND == DRGNN_SGAT) bufburst_store(bew1, s.ew1, dummy);
+            stage_file(2);
         }
         BARRIER();
         EXIT_AFTER(3);
         if (burst && LATE3) {
             // third burst: the arrays only the BACKWARD pass reads (CSC of both levels, sGAT's transposed slot maps).
             // Requested here, filed two phases later: their registers are not alive during the crowded second burst
-            bufburst_load(bcp0, tv.p[DRGNN_TI_COLPTR0] + d.rowbase, d.N + 1);
-            bufburst_load(brx0, tv.p[DRGNN_TI_ROWIDX0] + d.e0, d.E);
-            bufburst_load(bcp1, tv.p[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1);
-            bufburst_load(brx1, tv.p[DRGNN_TI_ROWIDX1] + d.e0, bE1);
-            if (KIND == DRGNN_SGAT) {
-                bufburst_load(bts0, tv.p[DRGNN_TI_TSLOT0] + d.e0, d.E);
-                bufburst_load(bts1, tv.p[DRGNN_TI_TSLOT1] + d.e0, bE1);
-            }
+            stage_request(3);
         }
         PH(3) net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a0);
 
@@ -1377,11 +1405,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
             PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H2, s.u2, TSLD, s.wc2t, TSLD, s.z2, Z2LD, dummy, s.b2,
                                      (KIND == DRGNN_FOUT) ? s.dv1 : nullptr);      // dv == 0 <=> no out-edges
         }
-        if (burst && LATE3) {
-            bufburst_store(bcp0, s.cp0, dummy); step_store_idx<NARROW>(brx0, s.rx0, dummy);
-            bufburst_store(bcp1, s.cp1, dummy); step_store_idx<NARROW>(brx1, s.rx1, dummy);
-            if (KIND == DRGNN_SGAT) { step_store_idx<NARROW>(bts0, s.ts0, dummy); step_store_idx<NARROW>(bts1, s.ts1, dummy); }
-        }
+        if (burst && LATE3) stage_file(3);
         BARRIER();
         EXIT_AFTER(6);
         // depth-1 cluster max (+ argmax) and the graph readout (mean over those clusters) in one phase: 16 lanes
