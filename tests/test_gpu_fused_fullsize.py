@@ -179,3 +179,32 @@ def test_fused_step_batches_beyond_the_argument_table(net_name, n_graphs):
     from topo_check import check_against_oracle
     check_against_oracle(nxt, batch_cpu, weights=need_w)
     assert float(tr.compute_gradients(batch, topo=nxt)) == float(loss)
+
+
+@pytest.mark.parametrize("net_name,n_nodes,n_pairs", [("GINet", 272, 320), ("FoutNet", 264, 300)])
+def test_fused_step_offset_tables_longer_than_one_staging_pass(net_name, n_nodes, n_pairs):
+    """More than 255 nodes: the per-wave staging jobs of the offset tables (N + 1 words) take a second 128-bit pass, the
+    member lists too -- still the width-specialised fused kernel (8 features -> the 16-wide instantiation), same numbers as
+    the oracle."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    dev = _dev()
+    batch_cpu = synth.make_batch(0, 12, n_nodes=n_nodes, n_pairs=n_pairs, n_feat=8, n_c1=6, n_internal=300)
+    params = cpu_ref.init_params(net_name, 8, 1, 1, seed=4)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **_fw_kwargs(net_name))
+    from test_gpu_parity import build
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    net = build(net_name, params, 1)                      # (feature width taken from the parameters)
+    tr = FusedTrainer(net, lr=0.01, task="reg")
+    batch = batch_cpu.clone().to(dev)
+    topo = Topology.from_batch(batch, need_weights=False)
+    assert topo.max_nodes > 255
+    assert tr._can_fuse(topo, 8), "this shape must take the fused-step path"
+    assert tr.api.step_is_specialised(tr.kind, batch.x, 8, topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O)
+    loss = tr.compute_gradients(batch, topo=topo)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=TOL)
+    np.testing.assert_allclose(tr.last_pred.cpu().numpy(), ref_pred.numpy(), rtol=TOL, atol=TOL)
+    for k, p in net.named_parameters():
+        ref = ref_grads[k].numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=TOL, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
