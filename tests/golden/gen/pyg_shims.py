@@ -385,11 +385,30 @@ def _h5_File(fname, mode='r'):
     return _H5Group(_sort(tree))
 
 
-def install():
+INSTALLED = []
+
+
+def install(force=False):
+    """Register the stand-ins for the third-party packages that are NOT importable here (all of them in the build
+    image).  Where the real torch_scatter / torch_sparse / torch_geometric / h5py exist they are left alone, so the
+    generators record goldens from the real packages there; INSTALLED lists what was replaced."""
+    import importlib.util
+    real = set()
+    if not force:
+        for top in ("torch_scatter", "torch_sparse", "torch_geometric", "h5py", "community"):
+            try:
+                if top not in sys.modules and importlib.util.find_spec(top) is not None:
+                    real.add(top)
+            except (ImportError, ValueError):
+                pass
+
     def mod(name, **attrs):
+        if name.split(".")[0] in real:
+            return types.ModuleType(name)          # throw-away: the real package stays in charge
         m = types.ModuleType(name)
         m.__dict__.update(attrs)
         sys.modules[name] = m
+        INSTALLED.append(name)
         return m
 
     mod('torch_scatter', scatter_sum=scatter_sum, scatter_add=scatter_add,
