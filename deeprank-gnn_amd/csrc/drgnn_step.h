@@ -1224,8 +1224,11 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         // memory round trip in front of the x tile): the regression target travels as raw bits, untouched until lane 0
         // files it; the classification branch (class weight looked up through the label) completes its own loads inside
         // the branch, so no pending load of ITS registers reaches the join.
-        int m_bad, m_y = 0;
+        int m_bad = 0, m_y = 0;
         float m_wy = 1.0f, m_denom = 1.0f;
+#ifndef DRGNN_EMU
+        if (my_wave == 0)      // lane 0 files them: the other 15 waves have no use for the five loads
+#endif
         {
             // gi: this graph's number in the workspace (= g unless the launch gathers from a cached set)
             m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
