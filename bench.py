@@ -188,10 +188,11 @@ def main():
         trainer = FusedTrainer(net, lr=1e-3, task="reg", seed=1234 + rank)
         loss_out = trainer.loss
         oneshot = None
-        if world > 1 and os.environ.get("DRGNN_DP_ONESHOT", "auto") != "0":
-            # the one-shot peer-to-peer all-reduce (csrc/drgnn_p2p.h: one launch, one xGMI round trip) instead of RCCL's
-            # ring for the 43 KB gradient -- adopted only if a verified trial exchange succeeds on EVERY rank (bounded
-            # waits: no hang), else the run stays on RCCL.  DRGNN_DP_ONESHOT=0 skips the trial.
+        if world > 1 and os.environ.get("DRGNN_DP_ONESHOT", "0") != "0":
+            # OPT-IN (DRGNN_DP_ONESHOT=1): the one-shot peer-to-peer all-reduce (csrc/drgnn_p2p.h: one launch, one xGMI
+            # round trip) instead of RCCL's ring for the 43 KB gradient -- adopted only if a verified trial exchange
+            # succeeds on EVERY rank (bounded waits: no hang), else the run stays on RCCL.  Off by default: it has not
+            # run on a multi-GPU node yet (none in the pool), RCCL recorded in the hipGraph is the measured path.
             oneshot = trainer.use_oneshot_allreduce(verify=True)
         # Two persistent topology workspaces.  Pipelined: while step t trains out of one, the
         # topology of step t+1 is built into the other INSIDE step t's backward launch (the builder
@@ -508,7 +509,7 @@ def main():
         if split:
             if native and oneshot is not None:
                 dp_mode = dp_mode.replace("RCCL all-reduce", "one-shot p2p all-reduce (drgnn_allreduce_oneshot)")
-                dp_mode += " [verified trial exchange on every rank; DRGNN_DP_ONESHOT=0 for RCCL]"
+                dp_mode += " [opt-in DRGNN_DP_ONESHOT=1; verified trial exchange on every rank]"
                 oneshot.check()
             result["config"]["dp_exchange"] = dp_mode
             result["config"]["params_in_sync"] = in_sync
