@@ -889,7 +889,7 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
                           const float* misc, float keep_scale, float* dhid, float* p_dhid, float* p_hw2,
                           float* p_hb2, float* p_loss) {
     const int H = HC ? HC : hf.H, O = OC ? OC : hf.O;
-    if (!hf.train) {            // inference: predictions only
+    if (__builtin_expect(!hf.train, 0)) {            // inference: predictions only
         if (br == 0) {
             FOR_TID(o, O) {
                 float acc = b2[o];
@@ -958,7 +958,7 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
     }
     if (sig) my_out = drgnn_sigmoid(my_out);
     float my_dout = 0.0f, loss, wsum = 1.0f;
-    if (hf.task == DRGNN_TASK_REG) {
+    if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {      // (layout hint: the exp / log code of the other branch goes out of line)
         const float inv = 1.0f / (float)(hf.B * O);
         const float d = my_out - misc[STEP_M_Y];
         loss = lanes64_sum(lane < O ? d * d * inv : 0.0f);
@@ -1001,7 +1001,7 @@ template <int WREF, bool ONLY>
 DEV void step_head_loss(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
                         const float* misc, float keep_scale, float* dhid, float* p_dhid, float* p_hw2,
                         float* p_hb2, float* p_loss) {
-    if (hf.H == WREF && hf.O == 1)
+    if (__builtin_expect(hf.H == WREF && hf.O == 1, 1))
         step_head_loss_t<WREF, 1>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
     else
         step_head_loss_t<0, 0>(hf, g, br, hid, w2, b2, misc, keep_scale, dhid, p_dhid, p_hw2, p_hb2, p_loss);
@@ -1232,7 +1232,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         {
             // gi: this graph's number in the workspace (= g unless the launch gathers from a cached set)
             m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
-            if (hf.train && hf.task == DRGNN_TASK_REG) {
+            if (__builtin_expect(hf.train && hf.task == DRGNN_TASK_REG, 1)) {
 #ifdef DRGNN_EMU
                 const float y = hf.y_reg[gi];
                 memcpy(&m_y, &y, 4);
