@@ -298,58 +298,11 @@ template <int J> DEV void burst_store_x(const BurstX<J>& b, float* dst) {
 }
 #endif
 
-// ---------------------------------------------------------------------------------
-// Burst staging through buffer loads (gfx950 `buffer_load_dword ... offen`): the hardware range
-// check of the resource descriptor returns 0 for lanes past the end, so a load is ONE instruction
-// with the lane offset shared by every array (no per-array compare / exec mask / 64-bit add).
-// The LDS side writes lanes past the end to a per-lane dummy word instead of masking them.
-// ---------------------------------------------------------------------------------
-#ifdef DRGNN_EMU
-template <int J> struct BufBurst { const int32_t* src; int n; };
-template <int J> DEV void bufburst_load(BufBurst<J>& b, const void* src, int n) { b.src = (const int32_t*)src; b.n = n; }
-template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* dummy) {
-    (void)dummy;
-    for (int i = 0; i < b.n; ++i) ((int32_t*)dst)[i] = b.src[i];
-}
-template <int J> DEV void bufburst_store16(const BufBurst<J>& b, unsigned short* dst, int* dummy) {
-    (void)dummy;
-    for (int i = 0; i < b.n; ++i) dst[i] = (unsigned short)b.src[i];
-}
-#else
+#ifndef DRGNN_EMU
+// buffer resource of a global array (gfx950 `buffer_load ... offen`): the hardware range check of the descriptor returns 0
+// for words past the end, so loads need no per-lane compare / exec mask
 DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
-}
-template <int J> struct BufBurst { int v[J * DRGNN_BSCALE]; int n; };
-template <int J> DEV void bufburst_load(BufBurst<J>& b, const void* src, int n) {
-    b.n = n;
-    const __amdgpu_buffer_rsrc_t r = buf_rsrc(src, n * 4);
-    const int voff = threadIdx.x * 4;
-    // chunks that lie wholly past the end are skipped by a branch on n alone (uniform for the whole workgroup):
-    // most arrays fill one chunk, their other load / store instructions would be issued by 16 waves for nothing
-#pragma unroll
-    for (int j = 0; j < J * DRGNN_BSCALE; ++j)
-        if (j == 0 || n > j * DRGNN_NTHREADS)
-            b.v[j] = __builtin_amdgcn_raw_buffer_load_b32(r, voff, j * DRGNN_NTHREADS * 4, 0);
-}
-template <int J> DEV void bufburst_store(const BufBurst<J>& b, void* dst, int* dummy) {
-    int* d = (int*)dst;
-#pragma unroll
-    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
-        if (j > 0 && b.n <= j * DRGNN_NTHREADS) break;
-        const int i = threadIdx.x + j * DRGNN_NTHREADS;
-        int* p = (i < b.n) ? d + i : dummy + (threadIdx.x & 63);
-        *p = b.v[j];
-    }
-}
-// same, narrowing to 16 bits (index arrays of a graph that lives in LDS: values < 65536)
-template <int J> DEV void bufburst_store16(const BufBurst<J>& b, unsigned short* dst, int* dummy) {
-#pragma unroll
-    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
-        if (j > 0 && b.n <= j * DRGNN_NTHREADS) break;
-        const int i = threadIdx.x + j * DRGNN_NTHREADS;
-        unsigned short* p = (i < b.n) ? dst + i : (unsigned short*)(dummy + (threadIdx.x & 63));
-        *p = (unsigned short)b.v[j];
-    }
 }
 #endif
 

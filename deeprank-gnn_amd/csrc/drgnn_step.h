@@ -1055,10 +1055,6 @@ template <bool NARROW> DEV void step_copy_idx(int* dst, const int32_t* src, int 
     if (NARROW) { unsigned short* d16 = (unsigned short*)dst; FOR_TID(i, n) { d16[i] = (unsigned short)src[i]; } }
     else { FOR_TID(i, n) { dst[i] = src[i]; } }
 }
-template <bool NARROW, int J> DEV void step_store_idx(const BufBurst<J>& b, int* dst, int* dummy) {
-    if (NARROW) bufburst_store16(b, (unsigned short*)dst, dummy);
-    else bufburst_store(b, dst, dummy);
-}
 DEV void step_copy_f32(float* dst, const float* src, int n) { FOR_TID(i, n) { dst[i] = src[i]; } }
 
 // host side of the same conditions (net_burst_ok + the head's), from the batch-wide bounds
