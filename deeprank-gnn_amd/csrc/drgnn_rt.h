@@ -47,7 +47,7 @@ typedef void* drgnn_stream_t;
 #ifndef DRGNN_NTHREADS
 #define DRGNN_NTHREADS 1024
 #endif
-// (nounroll: these loops run once per workgroup with 1 - 3 trips; unrolled copies are instruction-cache misses for nothing)
+// (nounroll: these loops run once per workgroup with 1 - 3 trips; unrolled copies and their remainder loops are instructions for nothing)
 #define FOR_TID(i, n) _Pragma("nounroll") for (int i = (int)threadIdx.x; i < (int)(n); i += DRGNN_NTHREADS)
 #ifdef DRGNN_PHASE_TIMING
 // profiling build only (libdrgnn_prof.so, tools/phase_timing.py): thread 0 of workgroup 0
@@ -310,7 +310,7 @@ DEV __amdgpu_buffer_rsrc_t buf_rsrc(const void* p, int bytes) {
 // Wave-specialised staging of the SMALL arrays (offset tables, index lists, bias vectors): one staging job = one array
 // (or half of one) of at most 1024 32-bit words, handled by ONE wave with up to four 128-bit buffer loads (64 lanes x 4
 // words x 4) that stay in its registers until the LDS store one phase later.  Why: every instruction that all 16 waves of
-// a workgroup execute occupies every SIMD for 4 x 4 cycles whether its lanes hold data or not; a dozen arrays of a few
+// a workgroup execute occupies every SIMD (4 waves each, no issue slack) whether its lanes hold data or not; a dozen arrays of a few
 // hundred words each, staged by all waves, cost ~150 instructions per wave and burst -- as one job per wave they cost ~25.
 // `src` / `n` / `dst` are wave-uniform.  dst is 16-byte aligned and padded to a multiple of 4 words (step_carve); the
 // source needs 4-byte alignment only (the hardware range check is per word: tools/probes/buffer_x4_range_probe.hip).
