@@ -630,8 +630,8 @@ DEV void step_gather_scatter(int n, const int* cp, const IdxT* ridx, const float
 }
 
 // Bias gradient = column sums of dZ [n x H] (dense rows of H floats).  Two stages around a barrier the caller has
-// anyway: (1) every lane sums a float4 column group over the rows r = t / (H/4), + 1024/(H/4), .. and the lanes of a
-// wave that hold the same group are combined by lane exchanges -> one partial row per wave in `wpart` [16][H];
+// anyway: (1) every lane sums a float4 column group over its share of the rows and the lanes of a wave that hold the same
+// group are combined by lane exchanges -> one partial row per wave in `wpart` [16][H];
 // (2) after the barrier H lanes add the 16 wave rows in wave order.  Fixed order -> bit-reproducible.
 template <int H, int LD = H>
 DEV void step_colsum_partial(int n, const float* dz, float* wpart) {
@@ -642,19 +642,20 @@ DEV void step_colsum_partial(int n, const float* dz, float* wpart) {
         wpart[c] = acc;
     }
 #else
-    constexpr int G = H / 4;                      // lanes per row
-    const int t = threadIdx.x, cg = t % G, r0 = t / G;
+    // the 64 / G lanes of a wave that share a column group are CONSECUTIVE (8 for H = 32, 16 for H = 16): their partial
+    // sums meet on the DPP path (3 - 4 adds per component) instead of 3 - 4 ds_bpermute round trips per component
+    constexpr int G = H / 4;                      // column groups (float4 each)
+    constexpr int LPG = 64 / G;                   // lanes per column group inside a wave
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cg = lane / LPG, j = lane % LPG;
     drgnn_f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int r = r0; r < n; r += DRGNN_NTHREADS / G) {
+    for (int r = wave * LPG + j; r < n; r += DRGNN_NWAVES * LPG) {
         const drgnn_f4 v = *(const drgnn_f4*)(dz + r * LD + 4 * cg);
         acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
     }
 #pragma unroll
-    for (int m = G; m < 64; m <<= 1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], m, 64);
-    }
-    if ((t & 63) < G) *(drgnn_f4*)(wpart + (t >> 6) * H + 4 * cg) = acc;
+    for (int q = 0; q < 4; ++q) acc[q] = (LPG == 8) ? lanes8_sum(acc[q]) : lanes16_sum(acc[q]);
+    if (j == 0) *(drgnn_f4*)(wpart + wave * H + 4 * cg) = acc;
 #endif
 }
 template <int H>
