@@ -412,6 +412,32 @@ DEV float lanes64_sum(float v) {
     v = lanes16_sum(v);
     return (lane_get(v, 0) + lane_get(v, 16)) + (lane_get(v, 32) + lane_get(v, 48));
 }
+// min / max of a 64-bit value over the wave, every lane gets both: four DPP steps inside the rows of 16 lanes (two 32-bit
+// moves + a 64-bit compare + two selects each), then the four row results meet through v_readlane -- against six
+// ds_bpermute round trips per 32-bit half with __shfl_xor
+template <int CTRL> DEV long long dpp_take_i64(long long v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned long long)v, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)((unsigned long long)v >> 32), CTRL, 0xF, 0xF, false);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+DEV long long lane_get_i64(long long v, int lane) {
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned long long)v, lane);
+    const int hi = __builtin_amdgcn_readlane((int)((unsigned long long)v >> 32), lane);
+    return (long long)(((unsigned long long)(unsigned int)hi << 32) | (unsigned int)lo);
+}
+DEV void wave_minmax_i64(long long& lo, long long& hi) {
+#define DRGNN_MM_STEP(CTRL) { const long long ol = dpp_take_i64<CTRL>(lo), oh = dpp_take_i64<CTRL>(hi); \
+                              lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi; }
+    DRGNN_MM_STEP(0xB1) DRGNN_MM_STEP(0x4E) DRGNN_MM_STEP(0x141) DRGNN_MM_STEP(0x140)
+#undef DRGNN_MM_STEP
+    long long l = lane_get_i64(lo, 0), h = lane_get_i64(hi, 0);
+#pragma unroll
+    for (int r = 16; r < 64; r += 16) {
+        const long long ol = lane_get_i64(lo, r), oh = lane_get_i64(hi, r);
+        l = ol < l ? ol : l; h = oh > h ? oh : h;
+    }
+    lo = l; hi = h;
+}
 DEV float lanes64_max(float v) {
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) { const float o = __shfl_xor(v, m, 64); v = o > v ? o : v; }

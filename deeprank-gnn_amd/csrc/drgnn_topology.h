@@ -217,12 +217,7 @@ DEV void wg_minmax64(const int64_t* ids, int n, long long* mm, bool preinit = fa
         lo = v < lo ? v : lo;
         hi = v > hi ? v : hi;
     }
-#pragma unroll
-    for (int d = DRGNN_WAVE / 2; d >= 1; d >>= 1) {
-        const long long ol = __shfl_xor(lo, d, DRGNN_WAVE), oh = __shfl_xor(hi, d, DRGNN_WAVE);
-        lo = ol < lo ? ol : lo;
-        hi = oh > hi ? oh : hi;
-    }
+    wave_minmax_i64(lo, hi);
     if ((threadIdx.x & (DRGNN_WAVE - 1)) == 0 && lo <= hi) { ATOMIC_MIN64(&mm[0], lo); ATOMIC_MAX64(&mm[1], hi); }
 #endif
     BARRIER();
@@ -251,15 +246,9 @@ DEV void wg_rank_prepare(const int64_t* ids, int n, TopoScratch& s) {
         hi = v > hi ? v : hi;
         s.pp[i] = (int)(unsigned int)((unsigned long long)v & 0xffffffffull);
     }
-    // only the waves that read ids take part (the rank routine reads the first ceil(min(n, threads) / 64) slots): 64-bit
-    // butterflies cost ~25 instructions a step, and every instruction of a wave occupies its SIMD for 4 cycles
+    // only the waves that read ids take part (the rank routine reads the first ceil(min(n, threads) / 64) slots)
     if ((int)(threadIdx.x & ~(DRGNN_WAVE - 1)) < n) {
-#pragma unroll
-        for (int d = DRGNN_WAVE / 2; d >= 1; d >>= 1) {
-            const long long ol = __shfl_xor(lo, d, DRGNN_WAVE), oh = __shfl_xor(hi, d, DRGNN_WAVE);
-            lo = ol < lo ? ol : lo;
-            hi = oh > hi ? oh : hi;
-        }
+        wave_minmax_i64(lo, hi);
         if ((threadIdx.x & (DRGNN_WAVE - 1)) == 0) {
             s.mm[2 + 2 * (threadIdx.x / DRGNN_WAVE)] = lo;
             s.mm[3 + 2 * (threadIdx.x / DRGNN_WAVE)] = hi;
