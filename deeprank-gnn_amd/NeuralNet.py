@@ -25,6 +25,13 @@ from .trainer import FusedTrainer
 __all__ = ["NeuralNet"]
 
 
+def _dist_world_rank():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
 def _divide(n, percent, shuffle):
     """reference DivideDataSet (DataSet.py:14-42): shuffled index split."""
     index = np.arange(n)
@@ -85,6 +92,13 @@ class NeuralNet(object):
             i_train, i_valid = _divide(len(self.dataset), self.percent, True)
         else:
             i_train, i_valid = np.arange(len(self.dataset)), np.arange(0)
+        self.world, self.rank = _dist_world_rank()
+        if self.world > 1:
+            # data parallel: ONE train / validation split for the whole job (rank 0's; np.random differs per rank)
+            import torch.distributed as dist
+            box = [(i_train.tolist(), i_valid.tolist())]
+            dist.broadcast_object_list(box, src=0)
+            i_train, i_valid = np.asarray(box[0][0], dtype=np.int64), np.asarray(box[0][1], dtype=np.int64)
         self.train_index, self.valid_index = list(i_train), list(i_valid)
         self.eval_dataset = None
         if database_eval is not None:
@@ -110,6 +124,9 @@ class NeuralNet(object):
                                     transform_sigmoid=bool(self.transform_sigmoid))
         if opt_state is not None:
             self.trainer.load_optimizer_state_dict(opt_state)
+        # data parallel: the replicas start as ONE model -- rank 0's parameters, Adam moments and step counter -- whatever
+        # each rank's RNG produced at construction
+        self.trainer.broadcast_state(src=0)
         self.train_loss, self.valid_loss, self.train_acc, self.valid_acc = [], [], [], []
         self.data = {}
         self._resident_sets = {}
@@ -203,10 +220,9 @@ class NeuralNet(object):
         store = self._new_store()
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if self.native_epoch and self.train_index and world > 1:
-            done = self._epoch_data_parallel(store, world, dist.get_rank())
-            if done is not None:
-                return done
+        if self.train_index and world > 1:
+            # data parallel: batch_size is the GLOBAL mini-batch on every path (native loop or per mini-batch)
+            return self._epoch_data_parallel(store, world, dist.get_rank())
         if self.native_epoch and self.train_index and world == 1:
             # the whole epoch enqueued by the native loop (drgnn_train_epoch): collate, step (+ next topology) and
             # update launches for every mini-batch, one host synchronisation at the end
@@ -245,15 +261,26 @@ class NeuralNet(object):
 
     def _epoch_data_parallel(self, store, world, rank):
         """One epoch with ``batch_size`` as the GLOBAL mini-batch, sharded over the ranks (contiguous shards, sizes differ
-        by <= 1): the native loop runs this rank's shards, per mini-batch gradient launches -> one all-reduce of the flat
-        gradient (weighted n_local / n_global) -> Adam.  Every rank applies the same updates, so this equals the
-        single-process epoch on the same order.  The store / loss returned describe THIS rank's shard."""
+        by <= 1) in rank 0's visiting order: per mini-batch gradient launches -> one all-reduce of the flat gradient
+        (weighted n_local / n_global) -> Adam.  Every rank applies the same updates, so this equals the single-process
+        epoch on the same order (unweighted mean losses; with ``class_weights`` the per-shard normalisation by the shard's
+        weight sum makes it an approximation -- refused below).  The store / loss returned describe THIS rank's shard.
+
+        Which loop runs is decided COLLECTIVELY: the native loop (drgnn_train_epoch) only if every
+        mini-batch has at least one graph per rank AND every rank's shard fits it (all_reduce MIN of the ranks' probes);
+        otherwise all ranks step the same global mini-batches one by one.  Either way every rank issues exactly one
+        all-reduce per global mini-batch."""
         import torch.distributed as dist
         from .parallel import shard_range
+        if self.task == 'class' and self.trainer.class_w is not None:
+            raise _lib.DrgnnError("data-parallel training with class_weights is not supported: the weighted cross-entropy "
+                                  "normalises by the weight sum of the mini-batch, which per-shard means recombined by "
+                                  "graph count do not reproduce")
         order = torch.tensor([int(i) for i in self.train_index], dtype=torch.int64)
         if self.shuffle:
             order = order[torch.randperm(order.numel())]
-        if dist.get_backend() == "nccl":
+        on_dev = dist.get_backend() == "nccl"
+        if on_dev:
             od = order.to(self.device)
             dist.broadcast(od, src=0)
             order = od.cpu()
@@ -263,21 +290,40 @@ class NeuralNet(object):
         chunks = [order[lo:lo + self.batch_size] for lo in range(0, len(order), self.batch_size)]
         parts = [c[slice(*shard_range(len(c), rank, world))] for c in chunks]
         sizes = [len(c) for c in chunks]
-        if any(len(c) < world for c in chunks):
-            return None                                        # a mini-batch smaller than the world: per-batch path
         rs = self._resident(self.dataset)
-        local_bs = len(parts[0])
-        mine = [g for p in parts for g in p]
-        done = self.trainer.train_epoch(rs, mine, local_bs, cached=self.cached_topology, dp_global_sizes=sizes)
-        if done is None:
-            return None
-        losses, pred = done
-        store['_pred'].append(pred)
-        store['_y'].append(rs.y[torch.as_tensor(mine, dtype=torch.long, device=rs.y.device)])
-        store['mol'] += [rs.mols[i] for i in mine]
         # a rank's batch loss is the mean over its shard: weight it back to the global mean of the mini-batch
-        w = torch.tensor([len(p) / float(n) for p, n in zip(parts, sizes)], dtype=torch.float32, device=losses.device)
-        total = (losses * w).sum()
+        w = torch.tensor([len(p) / float(n) for p, n in zip(parts, sizes)], dtype=torch.float32, device=self.device)
+        native = bool(self.native_epoch) and all(len(c) >= world for c in chunks)     # (same answer on every rank)
+        if native:
+            local_bs = len(parts[0])
+            mine = [g for p in parts for g in p]
+            ok = self.trainer.train_epoch(rs, mine, local_bs, cached=self.cached_topology, dp_global_sizes=sizes, probe=True)
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native = bool(int(flag.item()))
+        if native:
+            done = self.trainer.train_epoch(rs, mine, local_bs, cached=self.cached_topology, dp_global_sizes=sizes)
+            if done is None:       # cannot happen after a successful probe; never continue with mismatched collectives
+                raise _lib.DrgnnError("the native epoch loop refused a configuration its probe had accepted")
+            losses, pred = done
+            store['_pred'].append(pred)
+            store['_y'].append(rs.y[torch.as_tensor(mine, dtype=torch.long, device=rs.y.device)])
+            store['mol'] += [rs.mols[i] for i in mine]
+            total = (losses * w).sum()
+        else:
+            # per mini-batch: the same global mini-batches, each rank steps its shard.  A rank without a graph of a
+            # mini-batch smaller than the world steps a stand-in (the mini-batch's first graph) with weight 0, so that
+            # the gradient all-reduce stays matched and the sum is the single-process gradient.
+            need_w = self.trainer.kind == _lib.SGAT
+            total = torch.zeros((), dtype=torch.float32, device=self.device)
+            for k, (chunk, part) in enumerate(zip(chunks, parts)):
+                ids = part if part else chunk[:1]
+                batch = rs.batch(ids, rs.upload_ids(ids))
+                topo = Topology.from_batch(batch, api=self.trainer.api, need_weights=need_w)
+                loss = self.trainer.train_step(batch, topo=topo, n_global=len(chunk), n_local=len(part))
+                total += loss.reshape(()) * w[k]
+                if part:
+                    self._collect(self.trainer.last_pred, batch, store)
         dist.all_reduce(total)
         total = float(total)                  # (synchronises)
         self.trainer.check_faults()
@@ -337,7 +383,7 @@ class NeuralNet(object):
         ``save_epoch='all'`` / ``'intermediate'``, for every / every ``save_every``-th epoch; the other epochs' outputs are
         dropped as soon as the epoch is over.  'best' checkpoints carry the reference's file name."""
         self.nepoch = nepoch
-        fname = self.update_name(hdf5, self.outdir) if hdf5 else None
+        fname = self.update_name(self._rank_name(hdf5), self.outdir) if hdf5 else None
         self.data, pending = {}, {}
         for epoch in range(1, nepoch + 1):
             t0 = time.time()
@@ -383,8 +429,15 @@ class NeuralNet(object):
         self.test_loss = loss
         self.test_acc = self._accuracy(store, threshold) if store['targets'] else None
         if hdf5:
-            self.export(self.update_name(hdf5, self.outdir), {'epoch_0000': self.data})
+            self.export(self.update_name(self._rank_name(hdf5), self.outdir), {'epoch_0000': self.data})
         return store
+
+    def _rank_name(self, hdf5):
+        """data parallel: every rank exports ITS shard's outputs; ranks > 0 under their own file name"""
+        if getattr(self, "world", 1) > 1 and self.rank > 0:
+            stem, ext = os.path.splitext(str(hdf5))
+            return "%s.rank%d%s" % (stem, self.rank, ext)
+        return hdf5
 
     @staticmethod
     def update_name(hdf5, outdir):
@@ -421,6 +474,8 @@ class NeuralNet(object):
         return fname
 
     def save_model(self, filename='model.pth.tar'):
+        if getattr(self, "world", 1) > 1 and self.rank > 0:
+            return                        # data parallel: the replicas are identical, rank 0 writes the checkpoint
         state = {'model': {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},
                  'optimizer': self.trainer.optimizer_state_dict(),
                  'node': self.node_feature, 'edge': self.edge_feature, 'target': self.target, 'task': self.task,

@@ -580,6 +580,11 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     StepArgs& a = L.a;
     a.gather_ids = gather_ids; a.ws_graphs = (int)ws_graphs;
     L.dims.count = 0;
+    // host-known graph numbers of a cached-topology launch are range-checked whatever the batch size: the kernel reads the
+    // set's tables at gather_ids[g] as is
+    if (gather_ids && hints && hints->host_ids)
+        for (int64_t g = 0; g < n_graphs; ++g)
+            if (hints->host_ids[g] < 0 || hints->host_ids[g] >= ws_graphs) return DRGNN_E_ARG;
     if (hints && n_graphs > 0 && n_graphs <= DRGNN_STEP_DIMS_MAX) {
         StepDims& D = L.dims;
         bool ok = true;

@@ -70,29 +70,50 @@ class OneShotAllReduce(object):
         self.n = int(n_floats)
         self.device = torch.device(device)
         nbytes = self.api.p2p_bytes(self.n)
-        if own is None:
-            own = self.api.p2p_alloc(nbytes)
-        self.own_ptr, self.own_handle = own
+        self.own_ptr, self.own_handle, self._opened, self.peers = None, None, [], []
+        gathered = handles is None and dist.is_available() and dist.is_initialized()
+        # Every rank makes the SAME sequence of collectives whatever fails locally: a rank whose allocation
+        # was refused still takes part in the all_gather_object, with a failure marker instead of a handle; the error is
+        # raised only after the gather, on every rank (so none is left waiting inside a collective).
+        alloc_error = None
+        try:
+            if own is None:
+                own = self.api.p2p_alloc(nbytes)
+            self.own_ptr, self.own_handle = own
+        except Exception as exc:
+            if not gathered:
+                raise
+            alloc_error = exc
         if handles is None:
-            if not (dist.is_available() and dist.is_initialized()):
+            if not gathered:
                 rank, world, handles = 0, 1, [self.own_handle]
             else:
                 rank, world = dist.get_rank(group), dist.get_world_size(group)
                 handles = [None] * world
-                dist.all_gather_object(handles, self.own_handle, group=group)
+                dist.all_gather_object(handles, ("failed", repr(alloc_error)) if alloc_error is not None else self.own_handle,
+                                       group=group)
+                bad = [r for r, h in enumerate(handles) if isinstance(h, tuple) and h and h[0] == "failed"]
+                if bad:
+                    self.close()
+                    raise _lib.DrgnnError("one-shot all-reduce: exchange buffer allocation failed on rank(s) %s: %s" %
+                                          (bad, handles[bad[0]][1]))
         self.rank, self.world = int(rank), int(world)
         if self.world > 16:
+            self.close()
             raise ValueError("at most 16 ranks")
-        self.peers, self._opened = [], []
-        for r, h in enumerate(handles):
-            if r == self.rank:
-                self.peers.append(self.own_ptr)
-            elif isinstance(h, int):               # already a device pointer valid here (ranks of one process: tests)
-                self.peers.append(h)
-            else:
-                ptr = self.api.p2p_open(h)
-                self.peers.append(ptr)
-                self._opened.append(ptr)
+        try:
+            for r, h in enumerate(handles):
+                if r == self.rank:
+                    self.peers.append(self.own_ptr)
+                elif isinstance(h, int):               # already a device pointer valid here (ranks of one process: tests)
+                    self.peers.append(h)
+                else:
+                    ptr = self.api.p2p_open(h)
+                    self.peers.append(ptr)
+                    self._opened.append(ptr)
+        except Exception:
+            self.close()                               # no leaked mappings / exchange buffer on a refused hipIpc open
+            raise
         self.seq = torch.zeros(16, dtype=torch.int32, device=self.device)
         self.status = torch.zeros(1, dtype=torch.int32, device=self.device)
 

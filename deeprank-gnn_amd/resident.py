@@ -371,4 +371,8 @@ class TopologyCache(object):
         """(max_nodes, max_edges, max_c0) over the graphs ``ids`` (host numbers)."""
         ids = np.asarray(ids, dtype=np.int64).reshape(-1)
         s = self.set
+        # numpy indexing wraps negative numbers silently while the kernel reads set_node_ptr[id] as is: refuse here,
+        # whatever the batch size (ADVICE r02)
+        if ids.size == 0 or ids.min() < 0 or ids.max() >= len(s):
+            raise IndexError("graph number out of range [0, %d)" % len(s))
         return int(s.n_nodes[ids].max()), int(s.n_edges[ids].max()), int(s.n_c1[ids].max())

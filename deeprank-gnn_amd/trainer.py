@@ -248,7 +248,8 @@ class FusedTrainer(object):
                 torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
                 torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
         readout, partials, hp = bk
-        hints = _lib.step_hints(set_node_ptr=gset.node_ptr, set_edge_ptr=gset.edge_ptr, ids=ids) if B <= 64 else None
+        # (beyond 64 graphs the offsets no longer travel in the kernel arguments, but the library still range-checks the ids)
+        hints = _lib.step_hints(set_node_ptr=gset.node_ptr, set_edge_ptr=gset.edge_ptr, ids=ids)
         return dict(hints=hints,
                     cache=cache, ids_dev=ids_dev, B=B, bounds=(max_nodes, max_edges, max_c0), xchg=xchg, g1=g1, g2=g2,
                     desc=desc, stream=_lib.current_stream(gset.x), readout=readout, partials=partials, hp=hp,
@@ -386,6 +387,8 @@ class FusedTrainer(object):
             ok = int(flag.item())
         if ok:
             self._oneshot = ar
+        elif ar is not None:
+            ar.close()               # the trial failed somewhere: release the exchange buffer and the peers' mappings
         return self._oneshot
 
     def apply_update(self):
@@ -394,7 +397,7 @@ class FusedTrainer(object):
                            self.betas[0], self.betas[1], self.eps, self.weight_decay,
                            _lib.current_stream(self.flat_p))
 
-    def train_step(self, batch, topo=None, n_global=None, group=None, next_topo=None):
+    def train_step(self, batch, topo=None, n_global=None, group=None, next_topo=None, n_local=None):
         """One optimisation step on ``batch``; returns the (device) loss of this rank's shard.
         ``next_topo``: an allocated-but-unbuilt ``Topology`` of the NEXT mini-batch
         (``Topology.from_batch(next_batch, build=False)``): it is built inside this step's backward
@@ -407,9 +410,23 @@ class FusedTrainer(object):
         if not distributed and self.weight_decay == 0.0:
             return self._backward(batch, topo, True, next_topo)
         loss = self.compute_gradients(batch, topo, next_topo)
-        self.all_reduce_gradients(n_global=n_global, group=group)
+        # n_local: this rank's weight in the global mini-batch when it differs from the batch it stepped (0 for a rank
+        # that has no graph of a mini-batch smaller than the world and steps a stand-in to keep the collectives matched)
+        self.all_reduce_gradients(n_local=n_local, n_global=n_global, group=group)
         self.apply_update()
         return loss
+
+    def broadcast_state(self, src=0, group=None):
+        """Data parallel start: every replica takes rank ``src``'s parameters, Adam moments and step counter, so that the
+        replicas are one model whatever the ranks' RNG seeds were."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        on_dev = dist.get_backend(group) == "nccl"
+        for t in (self.flat_p, self.exp_avg, self.exp_avg_sq, self.step2):
+            buf = t if on_dev else t.detach().cpu()
+            dist.broadcast(buf, src=src, group=group)
+            if not on_dev:
+                t.copy_(buf)
 
     def faults(self):
         """Sticky fault bits raised by the fused-step kernels since the last reset (synchronises): bit
@@ -432,7 +449,7 @@ class FusedTrainer(object):
         done = self._run_epoch(gset, order, batch_size, inference=True, cached=cached)
         return None if done is None else done[1]
 
-    def train_epoch(self, gset, order, batch_size, cached=False, dp_global_sizes=None, group=None):
+    def train_epoch(self, gset, order, batch_size, cached=False, dp_global_sizes=None, group=None, probe=False):
         """A whole epoch over the resident set ``gset`` (resident.ResidentGraphSet) in visiting order ``order``
         (graph numbers), driven by the native loop ``drgnn_train_epoch``: per mini-batch the fused step launch
         (whose extra workgroups build the next mini-batch's topology and gather its node rows straight from the
@@ -451,9 +468,11 @@ class FusedTrainer(object):
             # synchronisation), then enqueues Adam.  ``dp_global_sizes[k]``: graphs of mini-batch k over ALL ranks
             # (None: equal shards); every rank must run the same number of mini-batches.
             self._dp = (dp_global_sizes, group)
-        return self._run_epoch(gset, order, batch_size, inference=False, cached=cached)
+        # probe: only answer whether the native loop takes this configuration (True / None), nothing is launched -- data
+        # parallel callers agree on the answer over ALL ranks before any of them enters the loop's collectives
+        return self._run_epoch(gset, order, batch_size, inference=False, cached=cached, probe=probe)
 
-    def _run_epoch(self, gset, order, batch_size, inference, cached=False):
+    def _run_epoch(self, gset, order, batch_size, inference, cached=False, probe=False):
         """``cached``: step the mini-batches out of the set's topology cache (built once, ``gset.topology_cache``):
         no builder / offset / gather work in the loop (declared mode; the default rebuilds every mini-batch's topology
         like the reference does in every forward pass)."""
@@ -522,6 +541,8 @@ class FusedTrainer(object):
         nbytes = self.api.train_epoch_scratch_bytes(plan)
         if nbytes is None:
             return None
+        if probe:
+            return True
         scratch = self._epoch_scratch
         if scratch is None or scratch.numel() < nbytes:
             scratch = self._epoch_scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)

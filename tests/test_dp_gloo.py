@@ -213,6 +213,100 @@ def test_neuralnet_trains_data_parallel_like_a_single_process(tmp_path):
     np.testing.assert_allclose(losses[0], nn.train_loss, rtol=1e-4)
 
 
+def _worker_nn_modes(rank, world, init_file, out_dir, mode):
+    """mode 'seeds': every rank seeds its RNGs differently (the replicas and the split must still be rank 0's);
+    'small': a last global mini-batch smaller than the world; 'refuse': rank 1's native-loop probe says no."""
+    from emu_api import emu
+    from helpers import GOLDEN, NODE_FEATURES
+    from deeprank_gnn_amd.NeuralNet import NeuralNet
+    from deeprank_gnn_amd.ginet import GINet
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    seed = rank * 17 if mode == "seeds" else 0
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    percent = [0.8, 0.2] if mode == "seeds" else [1.0, 0.0]
+    nn = NeuralNet(os.path.join(GOLDEN, "1ATN_residue.drgs"), GINet, node_feature=NODE_FEATURES, edge_feature=['dist'],
+                   target='irmsd', batch_size=4, percent=percent, shuffle=True, outdir=out_dir, _api=emu(), device='cpu')
+    nn.model.dropout = 0.0
+    calls = {"probe": 0, "run": 0}
+    if mode == "refuse":
+        orig = nn.trainer.train_epoch
+
+        def train_epoch(*a, **kw):
+            if kw.get("probe"):
+                calls["probe"] += 1
+                return None if rank == 1 else orig(*a, **kw)
+            calls["run"] += 1
+            return orig(*a, **kw)
+        nn.trainer.train_epoch = train_epoch
+    torch.manual_seed(0)               # (the epochs' shuffles: rank 0's order is broadcast anyway)
+    nn.train(nepoch=2, validate=(mode == "seeds"), save_model='last' if mode == "seeds" else None,
+             hdf5='train_data.drgs' if mode == "seeds" else None)
+    if mode == "refuse":
+        assert calls["probe"] == 2 and calls["run"] == 0, calls      # every rank left the native loop alone, together
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), nn.trainer.flat_p.numpy())
+    np.save(os.path.join(out_dir, "l%d.npy" % rank), np.asarray(nn.train_loss))
+    np.save(os.path.join(out_dir, "v%d.npy" % rank), np.asarray(nn.valid_index, dtype=np.int64))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _single_process_reference(tmp_path):
+    from emu_api import emu
+    from helpers import GOLDEN, NODE_FEATURES
+    from deeprank_gnn_amd.NeuralNet import NeuralNet
+    from deeprank_gnn_amd.ginet import GINet
+    torch.manual_seed(0)
+    np.random.seed(0)
+    nn = NeuralNet(os.path.join(GOLDEN, "1ATN_residue.drgs"), GINet, node_feature=NODE_FEATURES, edge_feature=['dist'],
+                   target='irmsd', batch_size=4, percent=[1.0, 0.0], shuffle=True, outdir=str(tmp_path), _api=emu(),
+                   device='cpu')
+    nn.model.dropout = 0.0
+    torch.manual_seed(0)
+    nn.train(nepoch=2, validate=False, save_model=None, hdf5=None)
+    return nn
+
+
+@pytest.mark.parametrize("mode,world", [("small", 3), ("refuse", 2)])
+def test_neuralnet_data_parallel_fallback_is_collective_and_exact(tmp_path, mode, world):
+    """(small) 10 graphs, global mini-batches of 4 -> the last one has 2 graphs for 3 ranks: the ranks step
+    the SAME global mini-batches one by one, the rank without a graph contributes weight 0; (refuse) one rank's native
+    loop refuses its shard: ALL ranks take the per-mini-batch path (agreed with an all-reduce), none is left inside the
+    loop's collectives.  Both equal the single-process run on rank 0's order."""
+    from emu_api import emu
+    emu()
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_worker_nn_modes, args=(world, init_file, tmp, mode), nprocs=world, join=True)
+        p = [np.load(os.path.join(tmp, "p%d.npy" % r)) for r in range(world)]
+        losses = [np.load(os.path.join(tmp, "l%d.npy" % r)) for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(p[0], p[r])
+        np.testing.assert_array_equal(losses[0], losses[r])
+    nn = _single_process_reference(tmp_path)
+    np.testing.assert_allclose(p[0], nn.trainer.flat_p.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(losses[0], nn.train_loss, rtol=1e-4)
+
+
+def test_neuralnet_data_parallel_replicas_start_as_one_model():
+    """ranks seeded differently still train ONE model (rank 0's parameters / optimiser state / train-validation
+    split are broadcast at construction); checkpoints are written by rank 0 only, exports of ranks > 0 carry a suffix."""
+    from emu_api import emu
+    emu()
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_worker_nn_modes, args=(2, init_file, tmp, "seeds"), nprocs=2, join=True)
+        p = [np.load(os.path.join(tmp, "p%d.npy" % r)) for r in range(2)]
+        v = [np.load(os.path.join(tmp, "v%d.npy" % r)) for r in range(2)]
+        files = sorted(os.listdir(tmp))
+    np.testing.assert_array_equal(p[0], p[1])
+    np.testing.assert_array_equal(v[0], v[1])
+    assert len(v[0]) == 2
+    assert len([f for f in files if f.endswith(".pth.tar")]) == 1, files
+    assert "train_data.drgs" in files and "train_data.rank1.drgs" in files, files
+
+
 def test_shard_range_covers_everything():
     from deeprank_gnn_amd.parallel import shard_range
     for n in (0, 1, 7, 64, 513):

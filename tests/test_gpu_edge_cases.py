@@ -23,10 +23,10 @@ def run_vs_oracle(net_name, batch_cpu, n_feat, seed=0, tol=1e-4):
     out = net(batch, topo=topo)
     loss = F.mse_loss(out.reshape(-1), batch.y)
     loss.backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_pred.numpy(), rtol=tol, atol=tol)
-    for k, p in net.named_parameters():
-        ref = ref_grads[k].numpy()
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=tol, atol=tol * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    from elementwise import Lazy64, check_step
+    check_step(net_name, Lazy64(net_name, params, batch_cpu, **kw), loss.item(), out.detach().cpu().numpy(),
+               {k: p.grad.cpu().numpy() for k, p in net.named_parameters()}, ref_loss, ref_pred.numpy(),
+               {k: v.numpy() for k, v in ref_grads.items()})
 
 
 @pytest.mark.parametrize("net_name", ["GINet", "sGAT", "FoutNet"])

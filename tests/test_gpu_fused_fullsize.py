@@ -14,7 +14,8 @@ residue the two fp32 results may differ by more than 1e-4 of the ELEMENT while b
 round-off of the exact value.  For any element that misses the strict test we therefore evaluate the
 oracle in float64 as the arbiter and require the kernel to be at least as close to the float64 value as
 1e-4 + 1e-4|ref| OR as close as the fp32 oracle itself is (x4): never looser than what fp32 arithmetic
-of the reference can resolve.  The number of elements needing the arbiter is printed.
+of the reference can resolve (tests/elementwise.py).  The number of elements needing the arbiter is ASSERTED to stay
+below 0.1 %.
 """
 import numpy as np
 import pytest
@@ -22,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from oracle import cpu_ref
+from elementwise import Lazy64, check_step, new_stats, assert_arbiter_rate
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -37,34 +39,8 @@ def _fw_kwargs(net_name):
     return {"looped": False} if net_name == "FoutNet" else {}
 
 
-def _oracle64(net_name, params, batch_cpu):
-    """Same oracle code, evaluated in float64 (arbiter for cancellation residues)."""
-    p64 = {k: v.double() for k, v in params.items()}
-    b64 = batch_cpu.clone()
-    for key in ("x", "edge_attr", "pos", "y", "internal_edge_attr"):
-        if getattr(b64, key, None) is not None:
-            setattr(b64, key, getattr(b64, key).double())
-    return cpu_ref.loss_and_grads(net_name, p64, b64, b64.y, **_fw_kwargs(net_name))
-
-
-def _check(name, got, ref32, ref64_fn, stats):
-    got = np.asarray(got, dtype=np.float64)
-    ref = np.asarray(ref32, dtype=np.float64)
-    assert got.shape == ref.shape, name
-    bad = np.abs(got - ref) > TOL + TOL * np.abs(ref)
-    bad |= np.isnan(got) != np.isnan(ref)
-    stats["elements"] += got.size
-    if not bad.any():
-        return
-    ref64 = np.asarray(ref64_fn(), dtype=np.float64)
-    err_kernel = np.abs(got - ref64)
-    err_oracle32 = np.abs(ref - ref64)
-    ok = (err_kernel <= TOL + TOL * np.abs(ref64)) | (err_kernel <= 4.0 * err_oracle32 + 1e-7)
-    stats["arbiter"] += int(bad.sum())
-    worst = int(np.argmax(np.where(bad & ~ok, err_kernel, 0.0)))
-    assert not (bad & ~ok).any(), (
-        "%s: element %d got %.9g, fp32 oracle %.9g, fp64 oracle %.9g" %
-        (name, worst, got.flat[worst], ref.flat[worst], ref64.flat[worst]))
+def _grads_of(net):
+    return {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
 
 
 def _trainer(net_name, params, lr=0.01):
@@ -85,13 +61,7 @@ def test_fused_step_syn64_gradients_match_oracle_elementwise(net_name, pipelined
     params = cpu_ref.init_params(net_name, 32, 1, 1, seed=11)
     ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y,
                                                            **_fw_kwargs(net_name))
-    cache = {}
-
-    def r64():
-        if "v" not in cache:
-            cache["v"] = _oracle64(net_name, params, batch_cpu)
-        return cache["v"]
-
+    lazy = Lazy64(net_name, params, batch_cpu, **_fw_kwargs(net_name))
     net, tr = _trainer(net_name, params)
     batch = batch_cpu.clone().to(dev)
     need_w = net_name == "sGAT"
@@ -103,15 +73,11 @@ def test_fused_step_syn64_gradients_match_oracle_elementwise(net_name, pipelined
     nxt = Topology.from_batch(batch, need_weights=need_w, build=False) if pipelined else None
     loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
     torch.cuda.synchronize()
-    stats = {"elements": 0, "arbiter": 0}
-    _check("loss", float(loss), float(ref_loss), lambda: float(r64()[1]), stats)
-    _check("pred", tr.last_pred.cpu().numpy(), ref_pred.numpy(), lambda: r64()[0].numpy(), stats)
-    grads = {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
-    assert set(grads) == set(ref_grads)
-    for k in sorted(grads):
-        _check("grad " + k, grads[k], ref_grads[k].numpy(), lambda k=k: r64()[2][k].numpy(), stats)
-    print("%s pipelined=%s: %d elements, %d needed the float64 arbiter" %
-          (net_name, pipelined, stats["elements"], stats["arbiter"]))
+    stats = new_stats()
+    check_step("%s SYN64" % net_name, lazy, loss, tr.last_pred.cpu().numpy(), _grads_of(net), ref_loss, ref_pred.numpy(),
+               {k: v.numpy() for k, v in ref_grads.items()}, stats)
+    # the escape clause is bounded: at most 0.1 % of the elements may need the float64 arbiter (round 2: none did)
+    assert_arbiter_rate(stats, "%s pipelined=%s" % (net_name, pipelined))
     if pipelined:
         # ... and the topology the same launch built for the NEXT step is the one a plain build gives
         from topo_check import check_against_oracle
@@ -171,11 +137,8 @@ def test_fused_step_batches_beyond_the_argument_table(net_name, n_graphs):
     assert tr._can_fuse(topo, 32)
     loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
     torch.cuda.synchronize()
-    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=TOL)
-    np.testing.assert_allclose(tr.last_pred.cpu().numpy(), ref_pred.numpy(), rtol=TOL, atol=TOL)
-    for k, p in net.named_parameters():
-        ref = ref_grads[k].numpy()
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=TOL, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    check_step(net_name, Lazy64(net_name, params, batch_cpu, **_fw_kwargs(net_name)), loss, tr.last_pred.cpu().numpy(),
+               _grads_of(net), ref_loss, ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()})
     from topo_check import check_against_oracle
     check_against_oracle(nxt, batch_cpu, weights=need_w)
     assert float(tr.compute_gradients(batch, topo=nxt)) == float(loss)
@@ -203,11 +166,8 @@ def test_fused_step_offset_tables_longer_than_one_staging_pass(net_name, n_nodes
     assert tr.api.step_is_specialised(tr.kind, batch.x, 8, topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O)
     loss = tr.compute_gradients(batch, topo=topo)
     torch.cuda.synchronize()
-    np.testing.assert_allclose(float(loss), float(ref_loss), rtol=TOL)
-    np.testing.assert_allclose(tr.last_pred.cpu().numpy(), ref_pred.numpy(), rtol=TOL, atol=TOL)
-    for k, p in net.named_parameters():
-        ref = ref_grads[k].numpy()
-        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=TOL, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
+    check_step(net_name, Lazy64(net_name, params, batch_cpu, **_fw_kwargs(net_name)), loss, tr.last_pred.cpu().numpy(),
+               _grads_of(net), ref_loss, ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()})
 
 
 @pytest.mark.parametrize("net_name", NETS)
@@ -224,6 +184,7 @@ def test_fused_step_random_shapes_match_oracle(net_name):
     dev = _dev()
     rng = np.random.default_rng(20260928)
     ran = 0
+    sweep_stats = new_stats()
     for case in range(10):
         n_feat = int(rng.choice([4, 7, 16, 20, 32, 48, 64]))
         n_graphs = int(rng.integers(1, 9))
@@ -249,10 +210,7 @@ def test_fused_step_random_shapes_match_oracle(net_name):
         loss = tr.compute_gradients(batch, topo=topo)
         torch.cuda.synchronize()
         where = "case %d: F=%d, %d graphs, nodes %s" % (case, n_feat, n_graphs, [int(g.x.shape[0]) for g in graphs])
-        np.testing.assert_allclose(float(loss), float(ref_loss), rtol=TOL, err_msg=where)
-        np.testing.assert_allclose(tr.last_pred.cpu().numpy(), ref_pred.numpy(), rtol=TOL, atol=TOL, err_msg=where)
-        for k2, p in net.named_parameters():
-            ref = ref_grads[k2].numpy()
-            np.testing.assert_allclose(p.grad.cpu().numpy(), ref, rtol=TOL, atol=TOL * max(1.0, float(np.abs(ref).max())),
-                                       err_msg=where + " " + k2)
+        check_step(where, Lazy64(net_name, params, batch_cpu, **_fw_kwargs(net_name)), loss, tr.last_pred.cpu().numpy(),
+                   _grads_of(net), ref_loss, ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()}, sweep_stats)
     assert ran >= 6
+    assert_arbiter_rate(sweep_stats, "%s sweep" % net_name)

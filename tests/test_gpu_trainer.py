@@ -67,23 +67,33 @@ def test_native_step_is_graph_capturable_and_deterministic():
     assert torch.equal(results[0], results[1])
 
 
-def test_neuralnet_counterpart_on_gpu(tmp_path):
-    """reference tests/test_nn.py flow (train, save, reload) on the device."""
+@pytest.mark.parametrize("net_name,task,target", [("GINet", None, "irmsd"), ("GINet", "class", "binclass"),
+                                                  ("FoutNet", None, "irmsd"), ("sGAT", None, "irmsd")])
+def test_neuralnet_counterpart_on_gpu(tmp_path, net_name, task, target):
+    """The reference's four tests/test_nn.py flows (test_ginet, test_ginet_class, test_fout, test_sgat: train 5 epochs
+    with validation, save, reload as pretrained model; tests/test_nn.py:9-32) on the device."""
     import os
     from helpers import GOLDEN, NODE_FEATURES
     from deeprank_gnn_amd.NeuralNet import NeuralNet
     from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.foutnet import FoutNet
+    from deeprank_gnn_amd.sGAT import sGAT
+    Net = {"GINet": GINet, "FoutNet": FoutNet, "sGAT": sGAT}[net_name]
     db = os.path.join(GOLDEN, "fixture_1ATN.npz")
     torch.manual_seed(0)
     np.random.seed(0)
-    nn = NeuralNet(db, GINet, node_feature=NODE_FEATURES, edge_feature=['dist'], target='irmsd',
+    nn = NeuralNet(db, Net, node_feature=NODE_FEATURES, edge_feature=['dist'], target=target, task=task,
                    batch_size=64, percent=[0.8, 0.2], outdir=str(tmp_path))
     nn.train(nepoch=5, validate=True)
-    assert nn.train_loss[-1] < nn.train_loss[0]
+    assert len(nn.train_loss) == 5 and len(nn.valid_loss) == 5 and all(np.isfinite(nn.train_loss))
+    if task is None:
+        assert nn.train_loss[-1] < nn.train_loss[0]
     ck = os.path.join(str(tmp_path), 'test.pth.tar')
     nn.save_model(ck)
-    cpy = NeuralNet(db, GINet, pretrained_model=ck, outdir=str(tmp_path))
-    np.testing.assert_allclose(cpy.test(hdf5=None)['raw_outputs'], nn.test(hdf5=None)['raw_outputs'], rtol=1e-6)
+    cpy = NeuralNet(db, Net, pretrained_model=ck, outdir=str(tmp_path))
+    a, b = cpy.test(hdf5=None), nn.test(hdf5=None)
+    np.testing.assert_allclose(a['raw_outputs'], b['raw_outputs'], rtol=1e-6)
+    assert a['mol'] == b['mol'] and len(a['mol']) == 10
 
 
 def test_pipelined_topology_co_launch_matches_plain_training():
