@@ -110,6 +110,9 @@ def parse():
     ap.add_argument("--graphs-per-gpu", type=int, default=GRAPHS_PER_GPU,
                     help="mini-batch per GPU; %d is BASELINE.json's configuration, other values are for the "
                          "batch-size sweep in DESIGN.md" % GRAPHS_PER_GPU)
+    ap.add_argument("--step-layout", choices=["auto", "one", "two"], default="auto",
+                    help="GINet: workgroups per graph of the fused step -- auto (default): two while every workgroup of the "
+                         "launch is resident, else one (both branches in sequence); one / two: forced, for A/B runs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--epoch-graphs", type=int, default=4096,
                     help="size of the resident graph set of the secondary whole-epoch measurement (0: skip it)")
@@ -173,6 +176,8 @@ def main():
     from deeprank_gnn_amd.foutnet import FoutNet
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[args.net]
 
+    if args.step_layout != "auto":
+        _lib.get().set_step_layout({"one": 1, "two": 2}[args.step_layout])
     batch_cpu = synth.make_batch(rank * GRAPHS_PER_GPU, GRAPHS_PER_GPU)
     batch = batch_cpu.clone().to(dev)
     torch.manual_seed(0)
@@ -501,7 +506,7 @@ def main():
                                    "200 nodes, ~1000 directed edges, 32 node feats, 50->16 clusters "
                                    "(BASELINE.json configs[1])" % args.net,
                        "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,
-                       "parallelism": "dp%d" % world, "mode": args.mode,
+                       "parallelism": "dp%d" % world, "mode": args.mode, "step_layout": args.step_layout,
                        "topology": ("cached per graph (declared): built once at upload of the resident set, the step "
                                     "reads it in place, no builder workgroups" if cached else
                                     "rebuilt every step; the build of step t+1 shares step t's backward launch "

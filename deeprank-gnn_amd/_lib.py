@@ -161,6 +161,10 @@ class Api(object):
         lib.drgnn_net_step_lds_bytes.restype = _c_i64
         lib.drgnn_net_step_variant.argtypes = [_c_i32, _vp] + [_c_i32] * 6
         lib.drgnn_net_step_variant.restype = _c_i32
+        lib.drgnn_net_step_plan.argtypes = [_c_i32] * 8 + [_c_i64, _c_i64, ctypes.POINTER(_c_i64)]
+        lib.drgnn_net_step_plan.restype = _c_i32
+        lib.drgnn_set_step_layout.argtypes = [_c_i32]
+        lib.drgnn_set_step_layout.restype = _c_i32
         lib.drgnn_head_compact_elems.argtypes = [_c_i32] * 3
         lib.drgnn_head_compact_elems.restype = _c_i64
         lib.drgnn_net_train_step.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc)] + [_vp] * 5 +
@@ -292,6 +296,17 @@ class Api(object):
             "drgnn_train_update")
 
     # -- fused training step ------------------------------------------------------
+    def net_step_plan(self, kind, n_feat, max_nodes, max_edges, max_c0, R, H, O, n_graphs, co_built_graphs=0):
+        """(workgroups per graph, LDS bytes per workgroup) of the fused step launch for ``n_graphs`` graphs with these
+        bounds, the same launch building the topology of ``co_built_graphs`` graphs; (0, 0): outside the fused kernels."""
+        need = _c_i64(0)
+        wgs = int(self.lib.drgnn_net_step_plan(kind, n_feat, max_nodes, max_edges, max_c0, R, H, O, int(n_graphs),
+                                               int(co_built_graphs), ctypes.byref(need)))
+        return wgs, int(need.value)
+
+    def set_step_layout(self, mode):
+        _check(self.lib.drgnn_set_step_layout(int(mode)), "drgnn_set_step_layout")
+
     def net_step_lds_bytes(self, kind, n_feat, max_nodes, max_edges, max_c0, R, H, O):
         return int(self.lib.drgnn_net_step_lds_bytes(kind, n_feat, max_nodes, max_edges, max_c0, R, H, O))
 

@@ -536,6 +536,61 @@ int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes
 
 int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O) { return head_compact_floats(R, H, O); }
 
+// ---- launch layout of the GINet step: two workgroups per graph (branches in parallel, readouts exchanged) only while
+// EVERY workgroup of the launch is resident -- these kernels use more than half a CU's LDS, i.e. one workgroup per CU --
+// otherwise one workgroup per graph runs both branches (drgnn_step1.h), which never waits for another workgroup.
+// 0: by residency; 1: always one workgroup per graph (tests, A/B runs); 2: always two (MEASUREMENT ONLY: beyond the
+// resident size this is the pre-round-3 schedule, whose exchange leans on in-order dispatch; bounded spin + fault bit)
+static int g_step_layout_mode = 0;
+static int device_cu_count() {
+#ifdef DRGNN_EMU
+    return 256;
+#else
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
+        else cus = 1;      // unknown device: never assume co-residency
+    }
+    return cus;
+#endif
+}
+static bool step_two_workgroups_ok(int64_t n_graphs, int64_t other_workgroups) {
+    if (g_step_layout_mode == 1) return false;
+    if (g_step_layout_mode == 2) return true;
+    return 2 * n_graphs + other_workgroups <= device_cu_count();
+}
+static int64_t step1_lds_bytes(int F, int capN, int capE, int capC, int H, int O) {
+    return 4 * step1_scratch_words(F, capN, capE, capC, H, O);
+}
+int32_t drgnn_set_step_layout(int32_t mode) {
+    if (mode < 0 || mode > 2) return DRGNN_E_ARG;
+    g_step_layout_mode = mode;
+    return 0;
+}
+int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t R,
+                            int32_t H, int32_t O, int64_t n_graphs, int64_t co_built_graphs, int64_t* lds_bytes) {
+    if (lds_bytes) *lds_bytes = 0;
+    if (max_nodes <= 0 || max_nodes > 32767 || max_edges > 65535 || n_feat > 256 || n_graphs < 0) return 0;   // the launch pair
+    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    const int capE = max_edges > 0 ? max_edges : 1;
+    if (kind != DRGNN_GINET) {
+        if (lds_bytes) *lds_bytes = step_lds_bytes(kind, n_feat, max_nodes, capE, capC, R, H, O);
+        return 1;
+    }
+    // builder workgroups of the topology co-built by the same launch: two per graph up to DRGNN_TOPO_SPLIT_MAX_GRAPHS graphs
+    // (topo_prepare; an upper bound -- a launch that finds fewer only ever moves towards the two-workgroup layout, whose
+    // workgroups need less LDS than the figure returned here)
+    const int64_t extra = co_built_graphs > 0 ? co_built_graphs * (co_built_graphs <= DRGNN_TOPO_SPLIT_MAX_GRAPHS ? 2 : 1) : 0;
+    if (step_two_workgroups_ok(n_graphs, extra)) {
+        if (lds_bytes) *lds_bytes = step_lds_bytes(kind, n_feat, max_nodes, capE, capC, R, H, O);
+        return 2;
+    }
+    if (lds_bytes) *lds_bytes = step1_lds_bytes(n_feat, max_nodes, capE, capC, H, O);
+    return 1;
+}
+
 static int step_variant(int kind, const float* x, int F, int capN, int capE, int capC, int H, int O) {
     if (!step_burst_guaranteed(kind, x, F, capN, capE, capC, H, O)) return 0;
     const int f16 = step_pad16(F);
@@ -563,6 +618,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         return DRGNN_E_ARG;
     if (hd->train && (!target || !head_partials || !partials)) return DRGNN_E_ARG;      // inference needs neither
     if (net->n_branch > 1 && !xchg) return DRGNN_E_ARG;
+    if (net->n_branch > 1 && hd->H < DRGNN_H2) return DRGNN_E_WIDTH;      // the exchange words of a graph: n_branch x DRGNN_H2 of its n_branch x H
     if (net->kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
     if (hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
         return DRGNN_E_WIDTH;
@@ -572,8 +628,14 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     L.capE = max_edges > 0 ? max_edges : 1;
     L.capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
     const int kind = net->kind, F = net->n_feat;
-    const int64_t lds = step_lds_bytes(kind, F, L.capN, L.capE, L.capC, hd->R, hd->H, hd->O);
-    if (lds > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
+    int64_t lds = step_lds_bytes(kind, F, L.capN, L.capE, L.capC, hd->R, hd->H, hd->O);
+    // GINet: one workgroup per graph unless all of 2 B (+ the builder's) workgroups are resident at once; decided below,
+    // once the co-launched builder's size is known
+    const bool two_alone = (net->n_branch == 2) && step_two_workgroups_ok(n_graphs, 0);
+    const int64_t lds1 = (net->n_branch == 2) ? step1_lds_bytes(F, L.capN, L.capE, L.capC, hd->H, hd->O) : 0;
+    if (net->n_branch == 2 && !two_alone) {
+        if (lds1 > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
+    } else if (lds > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
     L.words = lds / 4;
     TopoLayout lay;
     topo_layout(n_nodes, n_edges, ws_graphs, &lay);
@@ -624,7 +686,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     hf.readout = readout; hf.step = step2; hf.pred = pred; hf.partials = head_partials; hf.stage = 0;
 
     // grid of the step part: graphs in groups of 8 x n_branch (see step_block)
-    const int blocks = (net->n_branch == 2) ? (int)((n_graphs + 7) / 8) * 16 : (int)n_graphs;
+    int blocks = (net->n_branch == 2) ? (int)((n_graphs + 7) / 8) * 16 : (int)n_graphs;
     TopoLaunch T;
     int64_t tlds = 0;
     bool co_ok = false;
@@ -634,11 +696,27 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         co_ok = T.capN > 0 && T.user_nptr != nullptr && !(T.args.cluster1 != nullptr && T.args.c1_ptr == nullptr) &&
                 T.args.n_graphs > 0 && blocks > 0;
     }
+    bool one_wg = false;       // GINet: both branches of a graph in one workgroup (drgnn_step1.h)
+    if (net->n_branch == 2) {
+        const int64_t extra_wgs = co_ok ? (int64_t)T.args.n_graphs * T.roles : 0;
+        if (!step_two_workgroups_ok(n_graphs, extra_wgs)) {
+            if (lds1 <= DRGNN_LDS_LIMIT) one_wg = true;
+            else if (two_alone) co_ok = false;      // the builder gets a launch of its own; 2 B workgroups are resident
+            else return DRGNN_E_CAPACITY;
+        }
+        if (one_wg) { lds = lds1; L.words = lds / 4; blocks = (int)n_graphs; }
+    }
     if (blocks > 0) {
 #ifdef DRGNN_EMU
         // workgroups run one after the other here: two passes (up to the readout exchange, then the
         // rest), each workgroup keeping its "LDS" in a slab of its own between the passes
         std::vector<float> slabs((size_t)blocks * (size_t)(L.words + 16));
+        if (one_wg) {
+            for (int b = 0; b < blocks; ++b) {
+                if (gather_ids) step_block_both<0, true>(L, b, slabs.data());
+                else step_block_both<0, false>(L, b, slabs.data());
+            }
+        } else
         for (int pass = 1; pass <= 2; ++pass)
             for (int b = 0; b < blocks; ++b) {
                 float* lds_b = slabs.data() + (size_t)b * (size_t)(L.words + 16);
@@ -686,12 +764,33 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             default: DRGNN_STEP_LAUNCH(K, 0); break;                                                        \
         }                                                                                                   \
     } while (0)
+#define DRGNN_STEP1_LAUNCH_G(XF, G)                                                                         \
+    do {                                                                                                    \
+        if (both > 64 * 1024)                                                                               \
+            HIP_TRY(hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G>,                                \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));            \
+        hipLaunchKernelGGL((k_step1_co_topo<XF, G>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
+                           (size_t)both, stream, C);                                                        \
+    } while (0)
+#define DRGNN_STEP1_LAUNCH(XF)                                                                              \
+    do { if (gather_ids) DRGNN_STEP1_LAUNCH_G(XF, true); else DRGNN_STEP1_LAUNCH_G(XF, false); } while (0)
+        if (one_wg) {
+            switch (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O)) {
+                case 16: DRGNN_STEP1_LAUNCH(16); break;
+                case 32: DRGNN_STEP1_LAUNCH(32); break;
+                case 48: DRGNN_STEP1_LAUNCH(48); break;
+                case 64: DRGNN_STEP1_LAUNCH(64); break;
+                default: DRGNN_STEP1_LAUNCH(0); break;
+            }
+        } else
         if (kind == DRGNN_GINET) DRGNN_STEP_WIDTHS(DRGNN_GINET);
         else if (kind == DRGNN_SGAT) DRGNN_STEP_WIDTHS(DRGNN_SGAT);
         else DRGNN_STEP_WIDTHS(DRGNN_FOUT);
 #undef DRGNN_STEP_WIDTHS
 #undef DRGNN_STEP_LAUNCH
 #undef DRGNN_STEP_LAUNCH_G
+#undef DRGNN_STEP1_LAUNCH
+#undef DRGNN_STEP1_LAUNCH_G
         HIP_TRY(hipGetLastError());
 #endif
     }
@@ -1299,8 +1398,10 @@ int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
         EpochBatch b;
         if ((rc = epoch_batch(p, k, &b))) return rc;
         if (b.maxN <= 0) return DRGNN_E_CAPACITY;
-        if (drgnn_net_step_lds_bytes(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O) > DRGNN_LDS_LIMIT ||
-            b.maxN > 32767 || b.maxE > 65535 ||
+        int64_t step_lds = 0;
+        if (drgnn_net_step_plan(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O, b.B,
+                                p->cache ? 0 : p->batch_size, &step_lds) <= 0 ||
+            step_lds > DRGNN_LDS_LIMIT || b.maxN > 32767 || b.maxE > 65535 ||
             (!p->cache && drgnn_topology_lds_bytes(b.maxN, b.maxE > 0 ? b.maxE : 1) > DRGNN_LDS_LIMIT))
             return DRGNN_E_CAPACITY;
         TopoLayout lay;

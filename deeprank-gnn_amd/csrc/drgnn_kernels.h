@@ -6,6 +6,7 @@
 #pragma once
 #include "drgnn_head.h"
 #include "drgnn_step.h"
+#include "drgnn_step1.h"
 #include "drgnn_layers.h"
 #include "drgnn_mcl.h"
 #include "drgnn_collate.h"
@@ -342,6 +343,36 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
     net_step_graph<KIND, XF, GATHER>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, part);
 }
 
+// GINet, one workgroup per graph, both branches one after the other (drgnn_step1.h): the launch layout whenever the
+// two-workgroup exchange could meet a non-resident partner (2 B + builder workgroups > CUs).  No cross-workgroup wait.
+template <int XF, bool GATHER = false>
+DEV void step_block_both(const StepLaunch& L, int g, float* lds) {
+    if (g >= L.a.n_graphs) return;
+    if (L.dims.count > 0) {
+        const int gi = GATHER ? L.dims.gi[g] : g;
+        GraphDims d;
+        d.n0 = L.dims.n0[g]; d.N = L.dims.n[g]; d.e0 = L.dims.e0[g]; d.E = L.dims.e[g];
+        d.rowbase = d.n0 + gi;
+        d.C = 0; d.E1 = 0; d.C1 = 0;
+        const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
+        net_step_graph_both<XF, GATHER>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
+        return;
+    }
+    const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;      // cached mode: graph number in the set
+    const GraphDims d = net_dims(L.a.tv, gi);
+    if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
+        // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
+        FOR_TID(c, L.a.hf.R) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + c] = DRGNN_NAN; }
+        if (L.a.hf.train) {
+            float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+            FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+        }
+        FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
+        return;
+    }
+    net_step_graph_both<XF, GATHER>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC);
+}
+
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
 struct UpdateArgs {
     ReduceArgs r;
@@ -473,6 +504,15 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C)
     if ((int)blockIdx.x < C.n_net) step_block<KIND, XF, GATHER>(C.step, blockIdx.x, smem_s, 0);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);
 }
+// GINet, one workgroup per graph (both branches), + the builder's workgroups of the next mini-batch
+template <int XF, bool GATHER>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C) {
+    extern __shared__ __attribute__((aligned(16))) float smem_s1[];
+    PHASE_BEGIN();
+    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
+    if ((int)blockIdx.x < C.n_net) step_block_both<XF, GATHER>(C.step, blockIdx.x, smem_s1);
+    else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s1);
+}
 #ifdef DRGNN_KERNELS_MAIN
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
 __global__ void __launch_bounds__(256) k_conv_aggregate(ConvLayerArgs a) {
@@ -597,5 +637,10 @@ DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_GINET)
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_SGAT)
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_FOUT)
 #undef DRGNN_STEP_EXTERN
+#define DRGNN_STEP1_EXTERN(K, XF)                                                  \
+    extern template __global__ void k_step1_co_topo<XF, false>(StepCoLaunch);      \
+    extern template __global__ void k_step1_co_topo<XF, true>(StepCoLaunch);
+DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP1_EXTERN, 0)
+#undef DRGNN_STEP1_EXTERN
 #endif
 #endif  // !DRGNN_EMU

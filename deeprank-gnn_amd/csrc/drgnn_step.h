@@ -672,6 +672,12 @@ DEV void step_colsum_finish(const float* wpart, float* out) {
 #endif
 }
 
+// which nets take the merged loss + d readout phase (step_head_back_t) instead of the two phases
+#ifndef DRGNN_HEAD_MERGED_MASK
+#define DRGNN_HEAD_MERGED_MASK 1          // bit k: kind k (GINet only)
+#endif
+#define STEP_HEAD_MERGED(kind) (((DRGNN_HEAD_MERGED_MASK) >> (kind)) & 1)
+
 // per-graph scalars of the loss, fetched during staging:  misc = [bad (int)][y or class id][wy][denom]
 #define STEP_M_BAD 0
 #define STEP_M_Y 1
@@ -681,9 +687,13 @@ DEV void step_colsum_finish(const float* wpart, float* out) {
 // Depth-1 max-pool with argmax (first maximum in ascending member order, NaN never wins, empty cluster -> 0,
 // arg = -1 where no gradient can flow) fused with the graph readout = mean over the depth-1 clusters.
 // SKIP0: rows of nodes without out-edges (rp[m+1] == rp[m]) count as NaN, i.e. never win (FoutNet)
+// pub: (GINet) this branch's DRGNN_H2 exchange words -- every readout value is published to the partner branch's workgroup
+// the moment it exists (tag = index of this step), so that it travels while both workgroups pass the phase's barrier
+DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v);
 template <int LDZ, bool SKIP0 = false>
 DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z, short* arg, const float* misc,
-                           float* xr, float* g_readout, const int* rp = nullptr) {
+                           float* xr, float* g_readout, const int* rp = nullptr, unsigned long long* pub = nullptr,
+                           uint32_t tag = 0u) {
     int bad; memcpy(&bad, &misc[STEP_M_BAD], 4);
     const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
 #ifdef DRGNN_EMU
@@ -706,6 +716,7 @@ DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z
         if (bad) acc = DRGNN_NAN;
         xr[c] = acc;
         g_readout[c] = acc;
+        if (pub) xchg_publish(pub + c, tag, acc);
     }
 #else
     for (int t = threadIdx.x; t < DRGNN_H2 * 16; t += DRGNN_NTHREADS) {      // 512 lanes: whole waves
@@ -727,7 +738,10 @@ DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z
         }
         acc = lanes16_sum(acc) * inv;
         if (bad) acc = DRGNN_NAN;
-        if (kk == 0) { xr[c] = acc; g_readout[c] = acc; }
+        if (kk == 0) {
+            if (pub) xchg_publish(pub + c, tag, acc);      // first: the store that has the farthest to go
+            xr[c] = acc; g_readout[c] = acc;
+        }
     }
 #endif
 }
@@ -763,6 +777,15 @@ DEV float xchg_wait(unsigned long long* slot, uint32_t tag, int32_t* fault) {
         if (wall_clock64() - t0 > 30000000ull) { atomicOr(fault, DRGNN_FAULT_EXCHANGE); return DRGNN_NAN; }
         __builtin_amdgcn_s_sleep(1);
     }
+}
+// the same in two halves: the first poll is REQUESTED early (its L2 round trip overlaps the caller's own work) ...
+DEV unsigned long long xchg_peek(const unsigned long long* slot) {
+    return __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ... and completed here: spins only if that first answer was not this step's word yet
+DEV float xchg_finish(unsigned long long* slot, unsigned long long w, uint32_t tag, int32_t* fault) {
+    if ((uint32_t)(w >> 32) == tag) return __uint_as_float((uint32_t)w);
+    return xchg_wait(slot, tag, fault);
 }
 #endif
 
@@ -807,39 +830,46 @@ template <int WJ> DEV void step_wblock_store(const WBlockRegs<WJ>& wr, const Hea
 }
 #endif
 
-// hid = dropout(relu(b1 + P0 + P1)),  P_br = W1[:, br*32:(br+1)*32] readout_br  (this workgroup's half
-// product: 8 lanes per hidden unit, DPP sum inside the lane group; the other half comes from the
-// partner workgroup through `xg`, the [n_branch][H] exchange words of graph g).
-// `part` as in net_step_graph: 1 = publish only, 2 = from the wait on (emulation passes).
-// HC / OC: the head's widths as compile-time constants (0: taken from the descriptor).  The reference nets use
-// fc1 widths 128 (GINet) and 64 (sGAT, FoutNet) and one output for regression: those get their own copies of
-// the four small head routines (loops of known length), everything else the generic ones.
-template <int HC>
-DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
-                         const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
-                         uint32_t thresh, float keep_scale, int part, int32_t* fault) {
+// hid = dropout(relu(b1 + P0 + P1)),  P_br = W1[:, br*32:(br+1)*32] readout_br.  8 lanes per hidden unit, DPP sum inside the
+// lane group.  GINet: BOTH branch workgroups of a graph evaluate the whole of fc1 -- the own half from the column block in
+// LDS (`wb`, which the head's backward needs anyway) and the own readout, the partner's half from the partner's column
+// block held in REGISTERS since the second burst (`wo`) and the partner's readout, which the partner published value by
+// value at the end of its pooling phase (step_pool_readout) -- one hand-off of 32 values that is already in flight while
+// this workgroup passes the barrier and forms its own half, instead of 128 half products exchanged afterwards.
+// `xg`: the [n_branch][DRGNN_H2] exchange words of graph g.  Lanes 0..31 of EVERY wave poll the partner's 32 words (a wave
+// cannot learn them from another wave without a barrier) and hand them to the lane groups with four lane reads.
+// `part` as in net_step_graph: 2 = from the wait on (emulation passes).
+// HC: the head's width as a compile-time constant (0: taken from the descriptor).
+template <int HC, int WJ>
+DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float* wb, const WBlockRegs<WJ>& wo,
+                         const float* b1, const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
+                         uint32_t thresh, float keep_scale, int32_t* fault) {
     const int H = HC ? HC : hf.H;
 #ifdef DRGNN_EMU
-    if (part != 2) {
-        for (int h = 0; h < H; ++h) {
-            float p = 0.0f;
-            for (int c = 0; c < DRGNN_H2; ++c) p = fmaf(wb[h * STEP_WBLD + c], xr[c], p);
-            if (nb > 1) xchg_publish(xg + (long)br * H + h, tag, p);
-            else hid[h] = p;
-        }
-    }
-    if (part == 1) return;
+    (void)wo;
+    float xo[DRGNN_H2];
+    for (int c = 0; c < DRGNN_H2; ++c) xo[c] = (nb > 1) ? xchg_wait(xg + (long)(1 - br) * DRGNN_H2 + c, tag, fault) : 0.0f;
     for (int h = 0; h < H; ++h) {
-        float v = (nb > 1) ? xchg_wait(xg + h, tag, fault) + xchg_wait(xg + H + h, tag, fault) : hid[h];
+        float p = 0.0f, po = 0.0f;
+        for (int c = 0; c < DRGNN_H2; ++c) p = fmaf(wb[h * STEP_WBLD + c], xr[c], p);
+        if (nb > 1)
+            for (int c = 0; c < DRGNN_H2; ++c) po = fmaf(hf.w1[(long)h * hf.R + (1 - br) * DRGNN_H2 + c], xo[c], po);
+        float v = (nb > 1) ? ((br == 0) ? p + po : po + p) : p;       // P0 + P1 in both workgroups
         v += b1[h];
         v = v > 0.0f ? v : 0.0f;
         if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
         hid[h] = v;
     }
 #else
-    (void)part;
+    const int lane = threadIdx.x & 63;
+    unsigned long long* const slot = xg + (long)(1 - br) * DRGNN_H2 + (lane & (DRGNN_H2 - 1));
+    unsigned long long w0 = 0ull;
+    if (nb > 1 && lane < DRGNN_H2) w0 = xchg_peek(slot);        // in flight behind the own half below
     const int items = (H * 8 + 63) & ~63;         // whole waves: the lane-group sums need every lane
-    for (int t = threadIdx.x; t < items; t += DRGNN_NTHREADS) {
+    drgnn_f4 xo = {0.f, 0.f, 0.f, 0.f};
+    bool have_other = false;
+    int j = 0;
+    for (int t = threadIdx.x; t < items; t += DRGNN_NTHREADS, ++j) {
         const int h = t >> 3, q = t & 7;
         float acc = 0.0f;
         if (h < H) {
@@ -848,20 +878,25 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
             acc = fmaf(w[0], x[0], fmaf(w[1], x[1], fmaf(w[2], x[2], w[3] * x[3])));
         }
         acc = lanes8_sum(acc);
-        if (q == 0 && h < H) {
-            float v = acc;
-            if (nb > 1) {
-                xchg_publish(xg + (long)br * H + h, tag, acc);
-                float other = 0.0f;
-                PH(7) other = xchg_wait(xg + (long)(1 - br) * H + h, tag, fault);
-                // inference launches all carry the same tag (the step counter does not move): the reader clears
-                // the word it consumed, so that the next launch cannot pick up this one's value.  Training
-                // launches skip it -- their tag changes every step and the write-through store would sit on the
-                // critical path (measured +0.8 us)
-                if (!hf.train)
-                    __hip_atomic_store(xg + (long)(1 - br) * H + h, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v = (br == 0) ? acc + other : other + acc;       // P0 + P1 in both workgroups
+        float v = acc;
+        if (nb > 1) {
+            if (!have_other) {       // (wave-uniform) the partner's readout: lanes 0..31 poll, every lane takes its float4
+                float pv = 0.0f;
+                PH(7) { if (lane < DRGNN_H2) pv = xchg_finish(slot, w0, tag, fault); }
+                const int src = (lane & 7) * 4;
+                xo[0] = __shfl(pv, src, 64); xo[1] = __shfl(pv, src + 1, 64);
+                xo[2] = __shfl(pv, src + 2, 64); xo[3] = __shfl(pv, src + 3, 64);
+                have_other = true;
             }
+            float other = 0.0f;
+            if (h < H) {
+                const drgnn_f4 w = wo.v[j < WJ * DRGNN_BSCALE ? j : 0];
+                other = fmaf(w[0], xo[0], fmaf(w[1], xo[1], fmaf(w[2], xo[2], w[3] * xo[3])));
+            }
+            other = lanes8_sum(other);
+            v = (br == 0) ? acc + other : other + acc;       // P0 + P1 in both workgroups
+        }
+        if (q == 0 && h < H) {
             v += b1[h];
             v = v > 0.0f ? v : 0.0f;
             if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
@@ -873,15 +908,168 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
 // WREF: the fc1 width of the reference net of this kind (128 for GINet, 64 for sGAT / FoutNet) -- the one width a
 // kernel carries a specialised copy for besides the generic routines (every copy is instruction-cache footprint)
 // ONLY: the host has checked H == WREF for this launch (width-specialised kernels): no generic copy at all
-template <int WREF, bool ONLY>
-DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* wb, const float* b1,
+template <int WREF, bool ONLY, int WJ>
+DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* wb, const WBlockRegs<WJ>& wo, const float* b1,
                        const float* xr, float* hid, unsigned long long* xg, uint32_t tag, uint32_t step,
-                       uint32_t thresh, float keep_scale, int part, int32_t* fault) {
-    if (ONLY || hf.H == WREF) step_head_fc1_t<WREF>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part, fault);
-    else step_head_fc1_t<0>(hf, g, br, nb, wb, b1, xr, hid, xg, tag, step, thresh, keep_scale, part, fault);
+                       uint32_t thresh, float keep_scale, int32_t* fault) {
+    if (ONLY || hf.H == WREF) step_head_fc1_t<WREF, WJ>(hf, g, br, nb, wb, wo, b1, xr, hid, xg, tag, step, thresh, keep_scale, fault);
+    else step_head_fc1_t<0, WJ>(hf, g, br, nb, wb, wo, b1, xr, hid, xg, tag, step, thresh, keep_scale, fault);
 }
 
 
+// outs = W2 hid + b2, loss, d loss / d outs, dhid = relu'/dropout' (W2^T douts) AND d readout (this branch's 32 columns)
+// = dhid wb scattered straight into dZ2 through the depth-1 argmax (mean over the C1 clusters -> factor inv) -- ONE phase:
+// every wave evaluates outs / douts redundantly (lane o keeps outs[o] / douts[o]; a 128-long dot product and a wave sum)
+// and every dreadout item forms the dhid values it needs from hid, w2 and the wave's douts on the fly, so that no barrier
+// separates the loss from its consumers (the two used to be phases of their own: 0.7 + 0.85 us of a 15 us kernel).
+// Branch 0 writes predictions and the head slab (dhid travels to the update kernel, which forms dW_fc1 from it).
+template <int HC, int OC>
+DEV void step_head_back_t(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
+                          const float* misc, float keep_scale, const float* wb, const short* a1, int C1, float* z2, int ldz,
+                          float* p_dhid, float* p_hw2, float* p_hb2, float* p_loss) {
+    const int H = HC ? HC : hf.H, O = OC ? OC : hf.O;
+    if (__builtin_expect(!hf.train, 0)) {            // inference: predictions only
+        if (br == 0) {
+            FOR_TID(o, O) {
+                float acc = b2[o];
+                for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
+                if (hf.sigmoid && hf.task == DRGNN_TASK_REG) acc = drgnn_sigmoid(acc);
+                hf.pred[(long)g * O + o] = acc;
+            }
+        }
+        return;
+    }
+    const bool sig = hf.sigmoid && hf.task == DRGNN_TASK_REG;
+    const float denom = misc[STEP_M_DENOM], wy = misc[STEP_M_WY];
+    const float inv_c1 = 1.0f / (float)(C1 > 0 ? C1 : 1);
+#ifdef DRGNN_EMU
+    float outs[DRGNN_MAX_OUT], douts[DRGNN_MAX_OUT];
+    for (int o = 0; o < O; ++o) {
+        float acc = 0.0f;
+        for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
+        outs[o] = acc + b2[o];
+        if (sig) outs[o] = drgnn_sigmoid(outs[o]);
+    }
+    float loss = 0.0f, wsum = 1.0f;
+    if (hf.task == DRGNN_TASK_REG) {
+        const float inv = 1.0f / (float)(hf.B * O);
+        for (int o = 0; o < O; ++o) {
+            const float d = outs[o] - misc[STEP_M_Y];
+            loss += d * d * inv;
+            douts[o] = 2.0f * d * inv * (sig ? outs[o] * (1.0f - outs[o]) : 1.0f);
+        }
+    } else {
+        int yc; memcpy(&yc, &misc[STEP_M_Y], 4);
+        float mx = outs[0];
+        for (int o = 1; o < O; ++o) mx = outs[o] > mx ? outs[o] : mx;
+        float se = 0.0f;
+        for (int o = 0; o < O; ++o) se += expf(outs[o] - mx);
+        const float lse = logf(se) + mx;
+        loss = wy * (lse - outs[yc]) / denom;
+        for (int o = 0; o < O; ++o) douts[o] = wy * (expf(outs[o] - lse) - (o == yc ? 1.0f : 0.0f)) / denom;
+        wsum = wy;
+    }
+    if (br == 0) {
+        for (int o = 0; o < O; ++o) { hf.pred[(long)g * O + o] = outs[o]; p_hb2[o] = douts[o]; }
+        p_loss[0] = loss; p_loss[1] = wsum;
+    }
+    auto dhid_of = [&](int h) -> float {
+        float acc = 0.0f;
+        for (int o = 0; o < O; ++o) acc = fmaf(douts[o], w2[o * H + h], acc);
+        return (hid[h] != 0.0f) ? acc * keep_scale : 0.0f;
+    };
+    for (int h = 0; h < H; ++h) {
+        if (br == 0) {
+            for (int o = 0; o < O; ++o) p_hw2[(long)o * H + h] = douts[o] * hid[h];
+            p_dhid[h] = dhid_of(h);
+        }
+    }
+    for (int c = 0; c < DRGNN_H2; ++c) {
+        float acc = 0.0f;
+        for (int h = 0; h < H; ++h) acc = fmaf(dhid_of(h), wb[h * STEP_WBLD + c], acc);
+        for (int k = 0; k < C1; ++k) {
+            const int r = a1[k * DRGNN_H2 + c];
+            if (r >= 0) z2[r * ldz + c] = acc * inv_c1;
+        }
+    }
+#else
+    const int lane = threadIdx.x & 63;
+    float my_out = 0.0f;
+    for (int o = 0; o < O; ++o) {
+        float acc = 0.0f;
+        for (int h = lane; h < H; h += 64) acc = fmaf(hid[h], w2[o * H + h], acc);
+        acc = lanes64_sum(acc) + b2[o];
+        if (lane == o) my_out = acc;
+    }
+    if (sig) my_out = drgnn_sigmoid(my_out);
+    float my_dout = 0.0f, loss, wsum = 1.0f;
+    if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {      // (layout hint: the exp / log code of the other branch goes out of line)
+        const float inv = 1.0f / (float)(hf.B * O);
+        const float d = my_out - misc[STEP_M_Y];
+        loss = lanes64_sum(lane < O ? d * d * inv : 0.0f);
+        my_dout = lane < O ? 2.0f * d * inv * (sig ? my_out * (1.0f - my_out) : 1.0f) : 0.0f;
+    } else {
+        const int yc = __builtin_amdgcn_readfirstlane(__float_as_int(misc[STEP_M_Y]));
+        const float mx = lanes64_max(lane < O ? my_out : DRGNN_NEG_INF);
+        const float se = lanes64_sum(lane < O ? expf(my_out - mx) : 0.0f);
+        const float lse = logf(se) + mx;
+        loss = wy * (lse - lane_get(my_out, yc)) / denom;
+        my_dout = lane < O ? wy * (expf(my_out - lse) - (lane == yc ? 1.0f : 0.0f)) / denom : 0.0f;
+        wsum = wy;
+    }
+    if (br == 0 && (int)threadIdx.x < O) {
+        hf.pred[(long)g * O + threadIdx.x] = my_out;
+        p_hb2[threadIdx.x] = my_dout;
+    }
+    if (br == 0 && threadIdx.x == 0) { p_loss[0] = loss; p_loss[1] = wsum; }
+    // d loss / d hid[h] from the wave's own douts (same arithmetic wherever it is evaluated: bit-identical copies)
+    auto dhid_of = [&](int h, float hv) -> float {
+        float acc = 0.0f;
+        for (int o = 0; o < O; ++o) acc = fmaf(lane_get(my_dout, o), w2[o * H + h], acc);
+        return (hv != 0.0f) ? acc * keep_scale : 0.0f;          // relu' and dropout mask
+    };
+    if (br == 0) {      // the head slab: waves [0, H / 64)
+        for (int h0 = 0; h0 < H; h0 += DRGNN_NTHREADS) {      // uniform trip count: lane_get is wave-wide
+            const int h = h0 + (int)threadIdx.x;
+            if ((h & ~63) >= H) break;                         // (wave-uniform)
+            const bool ok = h < H;
+            const float hv = ok ? hid[h] : 0.0f;
+            const float dh = dhid_of(ok ? h : 0, hv);
+            if (ok) {
+                for (int o = 0; o < O; ++o) p_hw2[(long)o * H + h] = lane_get(my_dout, o) * hv;
+                p_dhid[h] = dh;
+            }
+        }
+    }
+    // d readout, scattered through the depth-1 argmax into dZ2: 32 lanes per channel
+    for (int t = threadIdx.x; t < DRGNN_H2 * 32; t += DRGNN_NTHREADS) {
+        const int c = t >> 5, q = t & 31;
+        float acc = 0.0f;
+        for (int h = q; h < ((H + 31) & ~31); h += 32) {       // uniform trip count inside the wave
+            const bool ok = h < H;
+            const float dh = dhid_of(ok ? h : 0, ok ? hid[h] : 0.0f);
+            if (ok) acc = fmaf(dh, wb[h * STEP_WBLD + c], acc);
+        }
+        const float v = lanes32_sum(acc) * inv_c1;
+        for (int k = q; k < C1; k += 32) {
+            const int r = a1[k * DRGNN_H2 + c];
+            if (r >= 0) z2[r * ldz + c] = v;
+        }
+    }
+#endif
+}
+template <int WREF, bool ONLY>
+DEV void step_head_back(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
+                        const float* misc, float keep_scale, const float* wb, const short* a1, int C1, float* z2, int ldz,
+                        float* p_dhid, float* p_hw2, float* p_hb2, float* p_loss) {
+    if (__builtin_expect(hf.H == WREF && hf.O == 1, 1))
+        step_head_back_t<WREF, 1>(hf, g, br, hid, w2, b2, misc, keep_scale, wb, a1, C1, z2, ldz, p_dhid, p_hw2, p_hb2, p_loss);
+    else
+        step_head_back_t<0, 0>(hf, g, br, hid, w2, b2, misc, keep_scale, wb, a1, C1, z2, ldz, p_dhid, p_hw2, p_hb2, p_loss);
+}
+
+// ---- the same as two phases (loss | barrier | d readout): what the single-branch nets take (measured: for them the
+// merged phase costs every wave more instructions than the barrier it saves) -----------------------------------------
 // outs = W2 hid + b2, loss, d loss / d outs, then dhid = relu'/dropout' (W2^T douts).  Device: every
 // wave evaluates outs redundantly (lane o keeps outs[o] / douts[o]) so that no barrier separates
 // them from their consumers.  Branch 0 writes predictions and the head slab.
@@ -1106,6 +1294,9 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
     StepScratch s = step_carve(scratch, KIND, (XF != 0) ? XF : F, capN, capE, capC, R, (XF != 0) ? WREF : H, O);
     EXIT_AFTER(0);
     WBlockRegs<(XF != 0) ? 1 : STEP_WB_J> wreg;      // XF != 0: H is the reference width (step_burst_guaranteed)
+    // GINet: the PARTNER branch's column block of fc1, kept in registers from the second burst to the head (both branch
+    // workgroups of a graph evaluate the whole of fc1, see step_head_fc1_t)
+    WBlockRegs<(XF != 0) ? 1 : STEP_WB_J> wother;
     int* const dummy = (int*)(s.misc + 64);      // 64 words that absorb discarded lanes' LDS stores
     const uint32_t done = (uint32_t)a.step2[0];
     const uint32_t tag = done + 1u;
@@ -1291,6 +1482,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
             FOR_TID(e, H * DRGNN_H2) {
                 s.wb[(e / DRGNN_H2) * STEP_WBLD + e % DRGNN_H2] = hf.w1[(long)(e / DRGNN_H2) * R + br * DRGNN_H2 + e % DRGNN_H2];
             }
+            if (nb > 1) step_wblock_load(wother, hf, 1 - br);
             step_copy_f32(s.hb1, hf.b1, H);
             step_copy_f32(s.hw2, hf.w2, O * H);
             step_copy_f32(s.hb2, hf.b2, O);
@@ -1336,6 +1528,7 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
             stage_file(1);
             burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
             step_wblock_load(wreg, hf, br);
+            if (nb > 1) step_wblock_load(wother, hf, 1 - br);
             if (KIND != DRGNN_GINET) burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
             stage_request(2);
         }
@@ -1411,7 +1604,8 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
         // depth-1 cluster max (+ argmax) and the graph readout (mean over those clusters) in one phase: 16 lanes
         // per channel share the clusters k = lane, lane+16, ..; their partial sums meet in a 16-lane DPP sum
         PH(6) step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.a1, s.misc, s.xr,
-                                      const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2);
+                                      const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2, nullptr,
+                                      (nb > 1) ? a.xchg + (long)g * nb * H + br * DRGNN_H2 : nullptr, tag);
         if (!GIN && hf.train) {
             // coefficient of every entry of the TRANSPOSED level-0 aggregation, once (one item per entry, no dependent
             // chain; the CSC arrays have just been filed): the backward gather then reads (row, coefficient) pairs like GINet's reads rows
@@ -1436,18 +1630,37 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
     float* p_hb2 = p_hw2 + (long)O * H;
     float* p_loss = p_hb2 + O;
     if (hf.train && part != 2 && g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+    if (part == 1) return;      // (emulation: the readout is published, the partner's pass 1 completes before pass 2 starts)
     FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
-    // half product of fc1 with this branch's readout, exchange with the partner workgroup, hid
-    PH(8) step_head_fc1<WREF, (XF != 0)>(hf, g, br, nb, s.wb, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
-                        keep_scale, part, a.step2 + 2);
-    if (part == 1) return;
+    // fc1 on [own readout | the partner's readout, published at the end of its pooling phase], hid
+    PH(8) step_head_fc1<WREF, (XF != 0)>(hf, g, br, nb, s.wb, wother, b1, s.xr, s.hid, a.xchg + (long)g * nb * H, tag, done, thresh,
+                        keep_scale, a.step2 + 2);
     BARRIER();
     EXIT_AFTER(9);
-    PH(9) step_head_loss<WREF, (XF != 0)>(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
-    if (!hf.train) return;
-    BARRIER();
-    EXIT_AFTER(10);
-    PH(10) step_head_dreadout<WREF, (XF != 0)>(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
+    if (nb > 1 && !hf.train) {
+        // inference launches all carry the same tag (the step counter does not move): the reader clears the words it
+        // consumed (all 16 waves have, past the barrier), so that the next launch cannot pick up this one's values.
+        // Training launches skip it -- their tag changes every step
+        FOR_TID(c, DRGNN_H2) {
+#ifdef DRGNN_EMU
+            a.xchg[(long)g * nb * H + (1 - br) * DRGNN_H2 + c] = 0ull;
+#else
+            __hip_atomic_store(a.xchg + (long)g * nb * H + (1 - br) * DRGNN_H2 + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        }
+    }
+    if (STEP_HEAD_MERGED(KIND)) {
+        // loss, its gradient, dhid and d readout scattered into dZ2: one phase (every wave forms the loss redundantly)
+        PH(9) step_head_back<WREF, (XF != 0)>(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.wb, s.a1, d.C1, s.z2, Z2LD,
+                                             p_dhid, p_hw2, p_hb2, p_loss);
+        if (!hf.train) return;
+    } else {
+        PH(9) step_head_loss<WREF, (XF != 0)>(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+        if (!hf.train) return;
+        BARRIER();
+        EXIT_AFTER(10);
+        PH(10) step_head_dreadout<WREF, (XF != 0)>(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
+    }
     BARRIER();
     EXIT_AFTER(11);
 

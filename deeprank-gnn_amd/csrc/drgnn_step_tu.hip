@@ -1,4 +1,4 @@
-// drgnn_step_tu.hip -- explicit instantiations of the fused step kernel for ONE kind of net (-DDRGNN_TU_KIND=0|1|2):
+// drgnn_step_tu.hip -- explicit instantiations of the fused step kernel for ONE kind of net (-DDRGNN_TU_KIND=0|1|2; 3 = the one-workgroup GINet step):
 // five feature widths x {per-mini-batch workspace, cached whole-set workspace}.  See drgnn_kernels.h.
 #include "drgnn_kernels.h"
 #ifndef DRGNN_TU_KIND
@@ -7,4 +7,12 @@
 #define DRGNN_STEP_INST(K, XF)                                              \
     template __global__ void k_step_co_topo<K, XF, false>(StepCoLaunch);    \
     template __global__ void k_step_co_topo<K, XF, true>(StepCoLaunch);
+#if DRGNN_TU_KIND == 3
+// the one-workgroup-per-graph GINet step (drgnn_step1.h)
+#define DRGNN_STEP1_INST(K, XF)                                             \
+    template __global__ void k_step1_co_topo<XF, false>(StepCoLaunch);      \
+    template __global__ void k_step1_co_topo<XF, true>(StepCoLaunch);
+DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP1_INST, 0)
+#else
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
+#endif

@@ -132,12 +132,13 @@ class FusedTrainer(object):
                         topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream, step_inc=step_inc)
         return x, desc, xp, arg0, arg1, readout, scratch
 
-    def _can_fuse(self, topo, n_feat):
+    def _can_fuse(self, topo, n_feat, next_topo=None):
         if not self.fused_step or topo.max_nodes <= 0:
             return False
-        need = self.api.net_step_lds_bytes(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0,
-                                           self.R, self.H, self.O)
-        return 0 < need <= 160 * 1024
+        wgs, need = self.api.net_step_plan(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0,
+                                           self.R, self.H, self.O, topo.n_graphs,
+                                           0 if next_topo is None else next_topo.n_graphs)
+        return wgs > 0 and 0 < need <= 160 * 1024
 
     def _fused_prepare(self, batch, topo):
         """Buffers and descriptors of one fused step (allocation only, no launch)."""
@@ -153,7 +154,7 @@ class FusedTrainer(object):
         if nb > 1:
             xchg = self._xchg.get(B)
             if xchg is None:
-                xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * self.H), dtype=torch.int64, device=dev)
+                xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * max(self.H, 32)), dtype=torch.int64, device=dev)
         # descriptors only depend on the (fixed) parameter storage and the feature width: built once
         ck = self._desc_cache.get(n_feat)
         if ck is None:
@@ -224,14 +225,14 @@ class FusedTrainer(object):
         if self.kind == _lib.SGAT and not cache.with_weights:
             raise ValueError("sGAT needs a topology cache built with edge weights (topology_cache(need_weights=True))")
         max_nodes, max_edges, max_c0 = cache.bounds(ids)
-        need = api.net_step_lds_bytes(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O)
-        if not (0 < need <= 160 * 1024):
+        wgs, need = api.net_step_plan(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O, B)
+        if not (wgs > 0 and 0 < need <= 160 * 1024):
             raise _lib.DrgnnError("a graph of this mini-batch does not fit the fused step kernel's LDS budget")
         xchg = None
         if nb > 1:
             xchg = self._xchg.get(B)
             if xchg is None:
-                xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * self.H), dtype=torch.int64, device=dev)
+                xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * max(self.H, 32)), dtype=torch.int64, device=dev)
         ck = self._desc_cache.get(n_feat)
         if ck is None:
             g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
@@ -289,7 +290,7 @@ class FusedTrainer(object):
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
-        if self._can_fuse(topo, batch.x.shape[1]):
+        if self._can_fuse(topo, batch.x.shape[1], next_topo):
             return self._fused(batch, topo, apply_adam, next_topo)
         stream = _lib.current_stream(batch.x)
         x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream, step_inc=self.step)
@@ -605,7 +606,7 @@ class FusedTrainer(object):
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
-        if self._can_fuse(topo, batch.x.shape[1]):
+        if self._can_fuse(topo, batch.x.shape[1], next_topo):
             c = self._fused_prepare(batch, topo)
             api.net_train_step(c["desc"], self._head_desc(False), c["x"], None, self.step2, topo.ws_i32, topo.ws_f32,
                                c["n_nodes"], topo.n_edges, c["B"], topo.max_nodes, topo.max_edges, topo.max_c0,

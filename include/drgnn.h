@@ -374,8 +374,8 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   head_partials OUT [B][drgnn_head_compact_elems]: [dhid H][dW_fc2 O*H][db_fc2 O][loss][weight]
  *             (dW_fc1 = dhid^T readout is formed by drgnn_step_update)
  *   partials  OUT [B*n_branch][drgnn_net_partial_elems]
- *   xchg      uint64 [B, n_branch, H], zero-filled ONCE by the caller and then left alone: the two
- *             branch workgroups of a GINet graph exchange their halves of fc1's product through it
+ *   xchg      uint64 [B, n_branch, H] (H >= 32), zero-filled ONCE by the caller and then left alone: the two
+ *             branch workgroups of a GINet graph hand each other their 32 readout values through it
  *             (may be NULL when n_branch == 1)
  * head->train == 0: inference -- forward + head only (dropout off), writes pred and readout; target,
  * head_partials and partials may be NULL and the step counters are left alone.
@@ -399,6 +399,19 @@ int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O);
  * (lets tests and bench.py state which kernel instance they exercised). */
 int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                int32_t max_c0, int32_t H, int32_t O);
+/* Launch layout of the fused step for a mini-batch of n_graphs graphs with these bounds, co_built_graphs = graphs of the
+ * topology the same launch builds for the next mini-batch (0: none) (ginet.py:99-141: the two branches convolve over the
+ * same edge_index).  Returns the workgroups per graph -- 2: GINet's branches run in two
+ * workgroups that exchange their readouts, taken ONLY while all 2 * n_graphs (+ co-launched builder) workgroups are
+ * resident at once (one workgroup per CU), because HIP promises nothing about dispatch order; 1: one workgroup per graph
+ * (sGAT / FoutNet always; GINet beyond that size: both branches one after the other, staged once, no cross-workgroup
+ * wait) -- or 0 when the bounds are outside the fused kernels (use the launch pair).  *lds_bytes: LDS one workgroup of
+ * that layout needs (drgnn_net_train_step returns DRGNN_E_CAPACITY beyond 160 KiB). */
+int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t R,
+                            int32_t H, int32_t O, int64_t n_graphs, int64_t co_built_graphs, int64_t* lds_bytes);
+/* Process-wide override of that choice: 0 = by residency (default), 1 = always one workgroup per graph (tests, A/B runs),
+ * 2 = always two (measurement only: beyond the resident size the exchange then leans on in-order dispatch). */
+int32_t drgnn_set_step_layout(int32_t mode);
 int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head, const float* x,
                          const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
                          int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,

@@ -98,3 +98,65 @@ def check_fused_predict(Net, n_feat, task, device, api=None, seed=0):
     pb = ta.predict(batch, topo=t1).cpu().numpy()          # t1 was built by the previous call
     np.testing.assert_array_equal(pa, pb)
     np.testing.assert_allclose(pa, tb.predict(batch).cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+class one_workgroup_layout(object):
+    """``with one_workgroup_layout(api):`` every GINet fused-step launch inside runs both branches of a graph in ONE
+    workgroup (drgnn_set_step_layout(1)), the layout the library takes by itself beyond the resident batch size."""
+
+    def __init__(self, api=None):
+        from deeprank_gnn_amd import _lib
+        self.api = api or _lib.get()
+
+    def __enter__(self):
+        self.api.set_step_layout(1)
+        return self
+
+    def __exit__(self, *exc):
+        self.api.set_step_layout(0)
+        return False
+
+
+def check_one_workgroup_layout(n_feat, task, device, api=None, seed=0):
+    """GINet: the one-workgroup-per-graph step (both branches in sequence) against the two-workgroup step on the same
+    ragged batch -- loss, predictions, every gradient, two Adam steps, inference."""
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.topology import Topology
+    api = api or _lib.get()
+    kw = {"api": api}
+    torch.manual_seed(seed)
+    batch = ragged_batch(seed, n_feat)
+    n_out = 1 if task == "reg" else 3
+    cw = None
+    if task == "class":
+        batch.y = torch.tensor([k % 3 for k in range(batch.num_graphs)])
+        cw = torch.tensor([0.2, 0.5, 0.3]).to(device)
+    else:
+        batch.y = torch.arange(batch.num_graphs, dtype=torch.float32) * 0.3 - 1.0
+    a = GINet(n_feat, n_out, 1)
+    a.dropout = 0.0
+    b = copy.deepcopy(a)
+    batch = batch.to(device)
+    ta = FusedTrainer(a.to(device), lr=0.01, task=task, class_weights=cw, **kw)
+    tb = FusedTrainer(b.to(device), lr=0.01, task=task, class_weights=cw, **kw)
+    topo = Topology.from_batch(batch, need_weights=False, **kw)
+    assert ta._can_fuse(topo, n_feat)
+    wgs, _ = api.net_step_plan(ta.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, ta.R, ta.H, ta.O, topo.n_graphs)
+    assert wgs == 2                                  # a handful of graphs: resident, two workgroups per graph
+    with one_workgroup_layout(api):
+        assert api.net_step_plan(ta.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, ta.R, ta.H, ta.O,
+                                 topo.n_graphs)[0] == 1
+    for it in range(2):
+        with one_workgroup_layout(api):
+            pa = ta.predict(batch).cpu().numpy()
+            la = ta.train_step(batch)
+        pb = tb.predict(batch).cpu().numpy()
+        lb = tb.train_step(batch)
+        np.testing.assert_allclose(pa, pb, rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(float(la), float(lb), rtol=2e-6)
+        np.testing.assert_allclose(ta.last_pred.cpu().numpy(), tb.last_pred.cpu().numpy(), rtol=1e-5, atol=1e-6)
+        ga, gb = ta.flat_g.cpu().numpy(), tb.flat_g.cpu().numpy()
+        np.testing.assert_allclose(ga, gb, rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(gb).max())), err_msg="gradient, step %d" % it)
+        np.testing.assert_allclose(ta.flat_p.cpu().numpy(), tb.flat_p.cpu().numpy(), rtol=1e-4, atol=2e-5)
+    assert int(ta.step) == 2 and int(tb.step) == 2

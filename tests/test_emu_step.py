@@ -20,3 +20,9 @@ def test_fused_step_matches_launch_pair(Net, n_feat, task):
 def test_fused_inference(Net, n_feat, task):
     from step_check import check_fused_predict
     check_fused_predict(Net, n_feat, task, "cpu", api=emu(), seed=7 + n_feat)
+
+
+@pytest.mark.parametrize("n_feat,task", [(32, "reg"), (5, "class"), (40, "reg")])
+def test_ginet_one_workgroup_layout_matches_two_workgroup_layout(n_feat, task):
+    from step_check import check_one_workgroup_layout
+    check_one_workgroup_layout(n_feat, task, "cpu", api=emu(), seed=3 + n_feat)

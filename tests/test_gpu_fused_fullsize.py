@@ -135,13 +135,54 @@ def test_fused_step_batches_beyond_the_argument_table(net_name, n_graphs):
     topo = Topology.from_batch(batch, need_weights=need_w)
     nxt = Topology.from_batch(batch, need_weights=need_w, build=False)
     assert tr._can_fuse(topo, 32)
+    # beyond the resident size (2 B + builder workgroups > CUs) a GINet graph is ONE workgroup running both branches: no
+    # workgroup ever waits for another one, whatever the dispatch order
+    wgs, _ = tr.api.net_step_plan(tr.kind, 32, topo.max_nodes, topo.max_edges, topo.max_c0, tr.R, tr.H, tr.O, n_graphs, n_graphs)
+    assert wgs == 1, wgs
     loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
     torch.cuda.synchronize()
+    assert tr.faults() == 0
     check_step(net_name, Lazy64(net_name, params, batch_cpu, **_fw_kwargs(net_name)), loss, tr.last_pred.cpu().numpy(),
                _grads_of(net), ref_loss, ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()})
     from topo_check import check_against_oracle
     check_against_oracle(nxt, batch_cpu, weights=need_w)
     assert float(tr.compute_gradients(batch, topo=nxt)) == float(loss)
+
+
+def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_step():
+    """BASELINE-shaped graphs (200 nodes, ~1000 edges, 32 features), 130 of them: past the resident size, so the launch
+    is one workgroup per graph (both branches in sequence, drgnn_step1.h).  Element-wise against the oracle; the first 64
+    graphs' predictions equal what the two-workgroup layout gives on them alone (same arithmetic per branch)."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    dev = _dev()
+    n_graphs = 130
+    batch_cpu = synth.make_batch(0, n_graphs)
+    params = cpu_ref.init_params("GINet", 32, 1, 1, seed=21)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads("GINet", params, batch_cpu, batch_cpu.y)
+    net, tr = _trainer("GINet", params)
+    batch = batch_cpu.clone().to(dev)
+    topo = Topology.from_batch(batch, need_weights=False)
+    assert tr._can_fuse(topo, 32)
+    assert tr.api.net_step_plan(tr.kind, 32, topo.max_nodes, topo.max_edges, topo.max_c0, tr.R, tr.H, tr.O, n_graphs)[0] == 1
+    assert tr.api.step_is_specialised(tr.kind, batch.x, 32, topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O)
+    loss = tr.compute_gradients(batch, topo=topo)
+    torch.cuda.synchronize()
+    assert tr.faults() == 0
+    check_step("GINet one workgroup per graph", Lazy64("GINet", params, batch_cpu), loss, tr.last_pred.cpu().numpy(),
+               _grads_of(net), ref_loss, ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()})
+    pred_one = tr.last_pred[:64].cpu().numpy().copy()
+    small = synth.make_batch(0, 64).to(dev)
+    t64 = Topology.from_batch(small, need_weights=False)
+    assert tr.api.net_step_plan(tr.kind, 32, t64.max_nodes, t64.max_edges, t64.max_c0, tr.R, tr.H, tr.O, 64)[0] == 2
+    pred_two = tr.predict(small, topo=t64).cpu().numpy()
+    np.testing.assert_array_equal(pred_one, pred_two)      # forward arithmetic is the same code in both layouts
+
+
+@pytest.mark.parametrize("n_feat,task", [(32, "reg"), (5, "class"), (40, "reg")])
+def test_ginet_one_workgroup_layout_matches_two_workgroup_layout(n_feat, task):
+    from step_check import check_one_workgroup_layout
+    check_one_workgroup_layout(n_feat, task, "cuda:0", seed=3 + n_feat)
 
 
 @pytest.mark.parametrize("net_name,n_nodes,n_pairs", [("GINet", 272, 320), ("FoutNet", 264, 300)])
