@@ -672,10 +672,13 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
             "kernels": out}
 
 
-def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=3):
+def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=4):
     """Secondary figure (not `value`): whole shuffled epochs over a graph set resident in HBM, driven by the native
     loop drgnn_train_epoch -- every mini-batch is a different random selection of graphs, read in place by the topology
-    builder; includes the shuffle, the id upload, the outputs' copy back and one synchronisation per epoch."""
+    builder.  The host never waits for an epoch before enqueuing the next one (shuffle, id upload and the launches of
+    epoch e+1 are issued while epoch e runs; losses and predictions stay on the device and are read after the last
+    epoch), which is how NeuralNet.train drives it.  Reported for 64 mini-batches per epoch (one pass over the set) and
+    for 1024 (16 shuffled passes enqueued as one epoch)."""
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd.resident import ResidentGraphSet
     from deeprank_gnn_amd.trainer import FusedTrainer
@@ -685,34 +688,40 @@ def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=3):
     rs = ResidentGraphSet(graphs, dev)
     gen = torch.Generator().manual_seed(0)
 
-    def run(cached):
-        def epoch():
-            order = torch.randperm(n_graphs, generator=gen)
-            done = tr.train_epoch(rs, order, GRAPHS_PER_GPU, cached=cached)
+    def run(cached, passes):
+        def order():
+            return torch.cat([torch.randperm(n_graphs, generator=gen) for _ in range(passes)])
+
+        def enqueue():
+            done = tr.train_epoch(rs, order(), GRAPHS_PER_GPU, cached=cached)
             if done is None:
                 raise RuntimeError("the native epoch loop refused this configuration")
-            losses, pred = done
-            pred.cpu()
-            return float(losses.sum())
-        epoch()
+            return done
+        enqueue()[0].sum().item()                      # warm-up epoch (allocations, topology cache)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sums = [epoch() for _ in range(epochs)]
+        pending = [enqueue() for _ in range(epochs)]   # no host synchronisation between epochs
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        return {"graphs_per_s": n_graphs * epochs / dt, "us_per_batch": dt / (epochs * nb) * 1e6,
-                "last_epoch_loss_sum": sums[-1]}
-    nb = (n_graphs + GRAPHS_PER_GPU - 1) // GRAPHS_PER_GPU
-    out = run(False)
+        sums = [float(losses.sum()) for losses, _ in pending]
+        nb = passes * ((n_graphs + GRAPHS_PER_GPU - 1) // GRAPHS_PER_GPU)
+        return {"graphs_per_s": n_graphs * passes * epochs / dt, "us_per_batch": dt / (epochs * nb) * 1e6,
+                "batches_per_epoch": nb, "last_epoch_loss_sum": sums[-1]}
+    out = run(False, 1)
     out.update({"epochs": epochs, "resident_graphs": n_graphs, "batch": GRAPHS_PER_GPU, "net": net_name,
                 "what": "shuffled epochs via drgnn_train_epoch (native loop, mini-batches read in place from the resident "
-                        "set, topology rebuilt for every mini-batch)"})
-    try:
-        c = run(True)
-        c["what"] = "same loop, declared cached-topology mode (per-graph topology built once at upload)"
-        out["cached_topology"] = c
-    except Exception as exc:
-        out["cached_topology"] = {"error": repr(exc)[:200]}
+                        "set, topology rebuilt for every mini-batch; epoch e+1 enqueued while epoch e runs, outputs left on "
+                        "the device)"})
+    for key, cached, passes, what in (
+            ("cached_topology", True, 1, "same loop, declared cached-topology mode (per-graph topology built once at upload)"),
+            ("long_epochs", False, 16, "1024 mini-batches per epoch (16 shuffled passes over the set enqueued as one epoch), rebuilt"),
+            ("long_epochs_cached", True, 16, "1024 mini-batches per epoch, cached topology")):
+        try:
+            c = run(cached, passes)
+            c["what"] = what
+            out[key] = c
+        except Exception as exc:
+            out[key] = {"error": repr(exc)[:200]}
     return out
 
 

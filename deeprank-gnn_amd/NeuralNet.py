@@ -41,6 +41,33 @@ def _divide(n, percent, shuffle):
     return index[:n1], index[n1:]
 
 
+class _Staged(object):
+    """Device tensors whose host copies are STARTED now (pinned buffers, non-blocking, one event behind them) and read
+    later: the epoch loop enqueues the next epoch before it looks at the previous one's numbers, so the device never
+    idles while the host turns outputs into the reference's Python lists (NeuralNet.py:446-460,508-523 syncs per batch)."""
+
+    def __init__(self, **tensors):
+        self.host, self.event = {}, None
+        for k, t in tensors.items():
+            if t is None or not torch.is_tensor(t):
+                self.host[k] = t
+            elif t.is_cuda:
+                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h.copy_(t.detach(), non_blocking=True)
+                self.host[k] = h
+                self.event = self.event or torch.cuda.Event()
+            else:
+                self.host[k] = t.detach()
+        if self.event is not None:
+            self.event.record()
+
+    def get(self):
+        if self.event is not None:
+            self.event.synchronize()
+            self.event = None
+        return self.host
+
+
 class NeuralNet(object):
     def __init__(self, database, Net, node_feature=['type', 'polarity', 'bsa'], edge_feature=['dist'],
                  target='irmsd', lr=0.01, batch_size=32, percent=[1.0, 0.0], database_eval=None, index=None,
@@ -172,12 +199,24 @@ class NeuralNet(object):
             store['_y'].append(batch.y)
         store['mol'] += list(batch['mol'])
 
-    def _finish(self, store):
+    def _stage(self, store, loss=None):
+        """Device side of a finished pass: one prediction / target tensor each, their host copies and the pass's loss
+        (a device scalar) and the trainer's fault word on the way to pinned memory.  No synchronisation."""
         preds, ys = store.pop('_pred'), store.pop('_y')
-        if not preds:
-            return store
-        pred = torch.cat(preds).cpu()
-        y = torch.cat(ys).cpu() if ys else None
+        store['_staged'] = _Staged(pred=torch.cat(preds) if preds else None, y=torch.cat(ys) if ys else None,
+                                   loss=loss, faults=self.trainer.step2[2:3])
+        return store
+
+    def _finish(self, store):
+        """Host side: waits for the staged copies of THIS pass only and fills the reference's lists; returns the loss."""
+        if '_staged' not in store:
+            self._stage(store)
+        host = store.pop('_staged').get()
+        pred, y, loss = host['pred'], host['y'], host['loss']
+        self.trainer.raise_on_faults(int(host['faults'][0]))
+        loss = None if loss is None else float(loss)
+        if pred is None:
+            return loss
         if self.task == 'class':
             prob = torch.softmax(pred, dim=1)
             store['raw_outputs'] += prob.tolist()
@@ -190,7 +229,7 @@ class NeuralNet(object):
             store['outputs'] += out
             if y is not None:
                 store['targets'] += y.tolist()
-        return store
+        return loss
 
     def _accuracy(self, store, threshold=None):
         """Metrics(...).accuracy of the reference (Metrics.py:10-31,113-120,170): predictions and targets are made
@@ -215,8 +254,10 @@ class NeuralNet(object):
         return {'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': [], '_pred': [], '_y': []}
 
     def _epoch(self, epoch):
-        """One pass over the training set (NeuralNet.py:477-537) on the native step.  No host sync inside
-        the loop: batches come from the resident set, the running loss stays on the device."""
+        """One pass over the training set (NeuralNet.py:477-537) on the native step, ENQUEUED: no host synchronisation
+        here -- batches come from the resident set, losses / outputs stay on the device, their host copies are started
+        behind the epoch (``_stage``); ``_finish(store)`` reads them (train() does that after it has enqueued the next
+        epoch).  Returns the store."""
         store = self._new_store()
         import torch.distributed as dist
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -225,20 +266,19 @@ class NeuralNet(object):
             return self._epoch_data_parallel(store, world, dist.get_rank())
         if self.native_epoch and self.train_index and world == 1:
             # the whole epoch enqueued by the native loop (drgnn_train_epoch): collate, step (+ next topology) and
-            # update launches for every mini-batch, one host synchronisation at the end
+            # update launches for every mini-batch
             rs = self._resident(self.dataset)
-            order = [int(i) for i in self.train_index]
+            order = torch.as_tensor([int(i) for i in self.train_index], dtype=torch.int64)
             if self.shuffle:
-                order = [order[i] for i in torch.randperm(len(order)).tolist()]
+                order = order[torch.randperm(order.numel())]
             done = self.trainer.train_epoch(rs, order, self.batch_size, cached=self.cached_topology)
             if done is not None:
                 losses, pred = done
                 store['_pred'].append(pred)
-                store['_y'].append(rs.y[torch.as_tensor(order, dtype=torch.long, device=rs.y.device)])
+                store['_y'].append(rs.y[order.to(rs.y.device)])
+                order = order.tolist()
                 store['mol'] += [rs.mols[i] for i in order]
-                total = float(losses.sum())          # (synchronises)
-                self.trainer.check_faults()
-                return total, self._finish(store)
+                return self._stage(store, losses.sum())
         running = torch.zeros((), dtype=torch.float32, device=self.device)
         need_w = self.trainer.kind == _lib.SGAT
         it = self._batches(self.dataset, self.train_index, self.shuffle)
@@ -255,9 +295,7 @@ class NeuralNet(object):
             running += loss.reshape(())
             self._collect(self.trainer.last_pred, batch, store)
             batch, topo = nxt, nxt_topo
-        total = float(running)
-        self.trainer.check_faults()
-        return total, self._finish(store)
+        return self._stage(store, running)
 
     def _epoch_data_parallel(self, store, world, rank):
         """One epoch with ``batch_size`` as the GLOBAL mini-batch, sharded over the ranks (contiguous shards, sizes differ
@@ -325,9 +363,7 @@ class NeuralNet(object):
                 if part:
                     self._collect(self.trainer.last_pred, batch, store)
         dist.all_reduce(total)
-        total = float(total)                  # (synchronises)
-        self.trainer.check_faults()
-        return total, self._finish(store)
+        return self._stage(store, total)
 
     def _sum_of_batch_losses(self, pred, y):
         """Sum over the mini-batches of each batch's mean loss (what the reference accumulates, NeuralNet.py:441-447)."""
@@ -342,6 +378,12 @@ class NeuralNet(object):
 
     def eval(self, dataset=None, indices=None):
         """Forward only (NeuralNet.py:414-475); returns (loss_sum, store)."""
+        store = self._eval_enqueue(dataset, indices)
+        loss = self._finish(store)
+        return (0.0 if loss is None else loss), store
+
+    def _eval_enqueue(self, dataset=None, indices=None):
+        """The forward pass of ``eval`` enqueued, outputs staged (no synchronisation); ``_finish(store)`` completes it."""
         dataset = self.dataset if dataset is None else dataset
         indices = self.valid_index if indices is None else indices
         store = self._new_store()
@@ -352,12 +394,12 @@ class NeuralNet(object):
             if pred is not None:
                 store['_pred'].append(pred)
                 store['mol'] += [rs.mols[i] for i in order]
-                total = 0.0
+                total = None
                 if rs.y is not None:
                     y = rs.y[torch.as_tensor(order, dtype=torch.long, device=rs.y.device)]
                     store['_y'].append(y)
-                    total = float(self._sum_of_batch_losses(pred, y))
-                return total, self._finish(store)
+                    total = self._sum_of_batch_losses(pred, y)
+                return self._stage(store, total)
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         need_w = self.trainer.kind == _lib.SGAT
         it = self._batches(dataset, indices, False)
@@ -375,7 +417,7 @@ class NeuralNet(object):
                     total += torch.nn.functional.cross_entropy(pred, batch.y, weight=self.trainer.class_w)
             self._collect(pred, batch, store)
             batch, topo = nxt, nxt_topo
-        return float(total), self._finish(store)
+        return self._stage(store, total)
 
     def train(self, nepoch=1, validate=False, save_model='last', hdf5='train_data.drgs', save_epoch='intermediate',
               save_every=5):
@@ -385,30 +427,52 @@ class NeuralNet(object):
         self.nepoch = nepoch
         fname = self.update_name(self._rank_name(hdf5), self.outdir) if hdf5 else None
         self.data, pending = {}, {}
-        for epoch in range(1, nepoch + 1):
-            t0 = time.time()
-            self.data = {}
-            loss, store = self._epoch(epoch)
+        validating = validate and (bool(self.valid_index) or self.eval_dataset is not None)
+
+        def close(epoch, t0, store, vstore):
+            """host side of an epoch whose work was enqueued earlier: numbers, lists, the progress line"""
+            loss = self._finish(store)
             self.train_loss.append(loss)
             self.train_acc.append(self._accuracy(store))
-            self.data['train'] = store
+            self.data = {'train': store}
             line = "Epoch [%04d] : train loss %e" % (epoch, loss)
             best_of = self.train_loss
-            if validate and (self.valid_index or self.eval_dataset is not None):
-                ds = self.dataset if self.eval_dataset is None else self.eval_dataset
-                idx = range(len(ds)) if self.eval_dataset is not None else self.valid_index
-                vloss, vstore = self.eval(ds, list(idx))
+            if vstore is not None:
+                vloss = self._finish(vstore)
+                vloss = 0.0 if vloss is None else vloss
                 self.valid_loss.append(vloss)
                 self.valid_acc.append(self._accuracy(vstore))
                 self.data['eval'] = vstore
                 line += " | valid loss %e" % vloss
                 best_of = self.valid_loss
-            if save_model == 'best' and min(best_of) == best_of[-1]:
-                self.save_model(os.path.join(self.outdir, 't{}_y{}_b{}_e{}_lr{}_{}.pth.tar'.format(
-                    self.task, self.target, str(self.batch_size), str(nepoch), str(self.lr), str(epoch))))
             print(line + " | time %.3f s" % (time.time() - t0))
             if (save_epoch == 'all') or (epoch == nepoch) or (save_epoch == 'intermediate' and epoch % save_every == 0):
                 pending['epoch_%04d' % epoch] = self.data
+            return min(best_of) == best_of[-1]
+
+        previous = None
+        for epoch in range(1, nepoch + 1):
+            # Enqueue this epoch (training pass + validation pass) BEFORE reading the previous epoch's numbers: the device
+            # runs epoch e while the host turns epoch e-1's outputs into lists.  ('best' checkpoints need this epoch's
+            # loss while its parameters are still the current ones: that mode closes every epoch at once.)
+            t0 = time.time()
+            store = self._epoch(epoch)
+            vstore = None
+            if validating:
+                ds = self.dataset if self.eval_dataset is None else self.eval_dataset
+                idx = range(len(ds)) if self.eval_dataset is not None else self.valid_index
+                vstore = self._eval_enqueue(ds, list(idx))
+            if previous is not None:
+                close(*previous)
+                previous = None
+            if save_model == 'best':
+                if close(epoch, t0, store, vstore):
+                    self.save_model(os.path.join(self.outdir, 't{}_y{}_b{}_e{}_lr{}_{}.pth.tar'.format(
+                        self.task, self.target, str(self.batch_size), str(nepoch), str(self.lr), str(epoch))))
+            else:
+                previous = (epoch, t0, store, vstore)
+        if previous is not None:
+            close(*previous)
         if save_model == 'last':
             self.save_model(os.path.join(self.outdir, 't{}_y{}_b{}_e{}_lr{}.pth.tar'.format(
                 self.task, self.target, str(self.batch_size), str(nepoch), str(self.lr))))

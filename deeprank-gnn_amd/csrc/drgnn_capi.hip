@@ -556,6 +556,9 @@ static int device_cu_count() {
     return cus;
 #endif
 }
+#ifndef DRGNN_EMU
+static int step_current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? dev : 0; }
+#endif
 static bool step_two_workgroups_ok(int64_t n_graphs, int64_t other_workgroups) {
     if (g_step_layout_mode == 1) return false;
     if (g_step_layout_mode == 2) return true;
@@ -744,9 +747,18 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         if (co_ok) { C.topo = T; both = lds > tlds ? lds : tlds; extra = T.args.n_graphs * T.roles; }
 #define DRGNN_STEP_LAUNCH_G(K, XF, G)                                                                       \
     do {                                                                                                    \
-        if (both > 64 * 1024)                                                                               \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G>,                              \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));            \
+        /* once per kernel instance and device: the whole 160 KiB (the call costs host time on every launch otherwise) */\
+        static int lds_set_on = -1;                                                                                   \
+        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
+            if (hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G>,                                            \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
+                lds_set_on = step_current_device();                                                                   \
+            } else {      /* (profiling builds carry a static LDS word: ask for what this launch needs) */            \
+                (void)hipGetLastError();                                                                              \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G>,                                    \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
+            }                                                                                                         \
+        }                                                                                                             \
         hipLaunchKernelGGL((k_step_co_topo<K, XF, G>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
                            (size_t)both, stream, C);                                                        \
     } while (0)
@@ -766,9 +778,18 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     } while (0)
 #define DRGNN_STEP1_LAUNCH_G(XF, G)                                                                         \
     do {                                                                                                    \
-        if (both > 64 * 1024)                                                                               \
-            HIP_TRY(hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G>,                                \
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));            \
+        /* once per kernel instance and device: the whole 160 KiB (the call costs host time on every launch otherwise) */\
+        static int lds_set_on = -1;                                                                                   \
+        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
+            if (hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G>,                                              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
+                lds_set_on = step_current_device();                                                                   \
+            } else {      /* (profiling builds carry a static LDS word: ask for what this launch needs) */            \
+                (void)hipGetLastError();                                                                              \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G>,                                      \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
+            }                                                                                                         \
+        }                                                                                                             \
         hipLaunchKernelGGL((k_step1_co_topo<XF, G>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
                            (size_t)both, stream, C);                                                        \
     } while (0)

@@ -672,12 +672,6 @@ DEV void step_colsum_finish(const float* wpart, float* out) {
 #endif
 }
 
-// which nets take the merged loss + d readout phase (step_head_back_t) instead of the two phases
-#ifndef DRGNN_HEAD_MERGED_MASK
-#define DRGNN_HEAD_MERGED_MASK 1          // bit k: kind k (GINet only)
-#endif
-#define STEP_HEAD_MERGED(kind) (((DRGNN_HEAD_MERGED_MASK) >> (kind)) & 1)
-
 // per-graph scalars of the loss, fetched during staging:  misc = [bad (int)][y or class id][wy][denom]
 #define STEP_M_BAD 0
 #define STEP_M_Y 1
@@ -917,159 +911,6 @@ DEV void step_head_fc1(const HeadFused& hf, int g, int br, int nb, const float* 
 }
 
 
-// outs = W2 hid + b2, loss, d loss / d outs, dhid = relu'/dropout' (W2^T douts) AND d readout (this branch's 32 columns)
-// = dhid wb scattered straight into dZ2 through the depth-1 argmax (mean over the C1 clusters -> factor inv) -- ONE phase:
-// every wave evaluates outs / douts redundantly (lane o keeps outs[o] / douts[o]; a 128-long dot product and a wave sum)
-// and every dreadout item forms the dhid values it needs from hid, w2 and the wave's douts on the fly, so that no barrier
-// separates the loss from its consumers (the two used to be phases of their own: 0.7 + 0.85 us of a 15 us kernel).
-// Branch 0 writes predictions and the head slab (dhid travels to the update kernel, which forms dW_fc1 from it).
-template <int HC, int OC>
-DEV void step_head_back_t(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
-                          const float* misc, float keep_scale, const float* wb, const short* a1, int C1, float* z2, int ldz,
-                          float* p_dhid, float* p_hw2, float* p_hb2, float* p_loss) {
-    const int H = HC ? HC : hf.H, O = OC ? OC : hf.O;
-    if (__builtin_expect(!hf.train, 0)) {            // inference: predictions only
-        if (br == 0) {
-            FOR_TID(o, O) {
-                float acc = b2[o];
-                for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
-                if (hf.sigmoid && hf.task == DRGNN_TASK_REG) acc = drgnn_sigmoid(acc);
-                hf.pred[(long)g * O + o] = acc;
-            }
-        }
-        return;
-    }
-    const bool sig = hf.sigmoid && hf.task == DRGNN_TASK_REG;
-    const float denom = misc[STEP_M_DENOM], wy = misc[STEP_M_WY];
-    const float inv_c1 = 1.0f / (float)(C1 > 0 ? C1 : 1);
-#ifdef DRGNN_EMU
-    float outs[DRGNN_MAX_OUT], douts[DRGNN_MAX_OUT];
-    for (int o = 0; o < O; ++o) {
-        float acc = 0.0f;
-        for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
-        outs[o] = acc + b2[o];
-        if (sig) outs[o] = drgnn_sigmoid(outs[o]);
-    }
-    float loss = 0.0f, wsum = 1.0f;
-    if (hf.task == DRGNN_TASK_REG) {
-        const float inv = 1.0f / (float)(hf.B * O);
-        for (int o = 0; o < O; ++o) {
-            const float d = outs[o] - misc[STEP_M_Y];
-            loss += d * d * inv;
-            douts[o] = 2.0f * d * inv * (sig ? outs[o] * (1.0f - outs[o]) : 1.0f);
-        }
-    } else {
-        int yc; memcpy(&yc, &misc[STEP_M_Y], 4);
-        float mx = outs[0];
-        for (int o = 1; o < O; ++o) mx = outs[o] > mx ? outs[o] : mx;
-        float se = 0.0f;
-        for (int o = 0; o < O; ++o) se += expf(outs[o] - mx);
-        const float lse = logf(se) + mx;
-        loss = wy * (lse - outs[yc]) / denom;
-        for (int o = 0; o < O; ++o) douts[o] = wy * (expf(outs[o] - lse) - (o == yc ? 1.0f : 0.0f)) / denom;
-        wsum = wy;
-    }
-    if (br == 0) {
-        for (int o = 0; o < O; ++o) { hf.pred[(long)g * O + o] = outs[o]; p_hb2[o] = douts[o]; }
-        p_loss[0] = loss; p_loss[1] = wsum;
-    }
-    auto dhid_of = [&](int h) -> float {
-        float acc = 0.0f;
-        for (int o = 0; o < O; ++o) acc = fmaf(douts[o], w2[o * H + h], acc);
-        return (hid[h] != 0.0f) ? acc * keep_scale : 0.0f;
-    };
-    for (int h = 0; h < H; ++h) {
-        if (br == 0) {
-            for (int o = 0; o < O; ++o) p_hw2[(long)o * H + h] = douts[o] * hid[h];
-            p_dhid[h] = dhid_of(h);
-        }
-    }
-    for (int c = 0; c < DRGNN_H2; ++c) {
-        float acc = 0.0f;
-        for (int h = 0; h < H; ++h) acc = fmaf(dhid_of(h), wb[h * STEP_WBLD + c], acc);
-        for (int k = 0; k < C1; ++k) {
-            const int r = a1[k * DRGNN_H2 + c];
-            if (r >= 0) z2[r * ldz + c] = acc * inv_c1;
-        }
-    }
-#else
-    const int lane = threadIdx.x & 63;
-    float my_out = 0.0f;
-    for (int o = 0; o < O; ++o) {
-        float acc = 0.0f;
-        for (int h = lane; h < H; h += 64) acc = fmaf(hid[h], w2[o * H + h], acc);
-        acc = lanes64_sum(acc) + b2[o];
-        if (lane == o) my_out = acc;
-    }
-    if (sig) my_out = drgnn_sigmoid(my_out);
-    float my_dout = 0.0f, loss, wsum = 1.0f;
-    if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {      // (layout hint: the exp / log code of the other branch goes out of line)
-        const float inv = 1.0f / (float)(hf.B * O);
-        const float d = my_out - misc[STEP_M_Y];
-        loss = lanes64_sum(lane < O ? d * d * inv : 0.0f);
-        my_dout = lane < O ? 2.0f * d * inv * (sig ? my_out * (1.0f - my_out) : 1.0f) : 0.0f;
-    } else {
-        const int yc = __builtin_amdgcn_readfirstlane(__float_as_int(misc[STEP_M_Y]));
-        const float mx = lanes64_max(lane < O ? my_out : DRGNN_NEG_INF);
-        const float se = lanes64_sum(lane < O ? expf(my_out - mx) : 0.0f);
-        const float lse = logf(se) + mx;
-        loss = wy * (lse - lane_get(my_out, yc)) / denom;
-        my_dout = lane < O ? wy * (expf(my_out - lse) - (lane == yc ? 1.0f : 0.0f)) / denom : 0.0f;
-        wsum = wy;
-    }
-    if (br == 0 && (int)threadIdx.x < O) {
-        hf.pred[(long)g * O + threadIdx.x] = my_out;
-        p_hb2[threadIdx.x] = my_dout;
-    }
-    if (br == 0 && threadIdx.x == 0) { p_loss[0] = loss; p_loss[1] = wsum; }
-    // d loss / d hid[h] from the wave's own douts (same arithmetic wherever it is evaluated: bit-identical copies)
-    auto dhid_of = [&](int h, float hv) -> float {
-        float acc = 0.0f;
-        for (int o = 0; o < O; ++o) acc = fmaf(lane_get(my_dout, o), w2[o * H + h], acc);
-        return (hv != 0.0f) ? acc * keep_scale : 0.0f;          // relu' and dropout mask
-    };
-    if (br == 0) {      // the head slab: waves [0, H / 64)
-        for (int h0 = 0; h0 < H; h0 += DRGNN_NTHREADS) {      // uniform trip count: lane_get is wave-wide
-            const int h = h0 + (int)threadIdx.x;
-            if ((h & ~63) >= H) break;                         // (wave-uniform)
-            const bool ok = h < H;
-            const float hv = ok ? hid[h] : 0.0f;
-            const float dh = dhid_of(ok ? h : 0, hv);
-            if (ok) {
-                for (int o = 0; o < O; ++o) p_hw2[(long)o * H + h] = lane_get(my_dout, o) * hv;
-                p_dhid[h] = dh;
-            }
-        }
-    }
-    // d readout, scattered through the depth-1 argmax into dZ2: 32 lanes per channel
-    for (int t = threadIdx.x; t < DRGNN_H2 * 32; t += DRGNN_NTHREADS) {
-        const int c = t >> 5, q = t & 31;
-        float acc = 0.0f;
-        for (int h = q; h < ((H + 31) & ~31); h += 32) {       // uniform trip count inside the wave
-            const bool ok = h < H;
-            const float dh = dhid_of(ok ? h : 0, ok ? hid[h] : 0.0f);
-            if (ok) acc = fmaf(dh, wb[h * STEP_WBLD + c], acc);
-        }
-        const float v = lanes32_sum(acc) * inv_c1;
-        for (int k = q; k < C1; k += 32) {
-            const int r = a1[k * DRGNN_H2 + c];
-            if (r >= 0) z2[r * ldz + c] = v;
-        }
-    }
-#endif
-}
-template <int WREF, bool ONLY>
-DEV void step_head_back(const HeadFused& hf, int g, int br, const float* hid, const float* w2, const float* b2,
-                        const float* misc, float keep_scale, const float* wb, const short* a1, int C1, float* z2, int ldz,
-                        float* p_dhid, float* p_hw2, float* p_hb2, float* p_loss) {
-    if (__builtin_expect(hf.H == WREF && hf.O == 1, 1))
-        step_head_back_t<WREF, 1>(hf, g, br, hid, w2, b2, misc, keep_scale, wb, a1, C1, z2, ldz, p_dhid, p_hw2, p_hb2, p_loss);
-    else
-        step_head_back_t<0, 0>(hf, g, br, hid, w2, b2, misc, keep_scale, wb, a1, C1, z2, ldz, p_dhid, p_hw2, p_hb2, p_loss);
-}
-
-// ---- the same as two phases (loss | barrier | d readout): what the single-branch nets take (measured: for them the
-// merged phase costs every wave more instructions than the barrier it saves) -----------------------------------------
 // outs = W2 hid + b2, loss, d loss / d outs, then dhid = relu'/dropout' (W2^T douts).  Device: every
 // wave evaluates outs redundantly (lane o keeps outs[o] / douts[o]) so that no barrier separates
 // them from their consumers.  Branch 0 writes predictions and the head slab.
@@ -1649,18 +1490,13 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
 #endif
         }
     }
-    if (STEP_HEAD_MERGED(KIND)) {
-        // loss, its gradient, dhid and d readout scattered into dZ2: one phase (every wave forms the loss redundantly)
-        PH(9) step_head_back<WREF, (XF != 0)>(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.wb, s.a1, d.C1, s.z2, Z2LD,
-                                             p_dhid, p_hw2, p_hb2, p_loss);
-        if (!hf.train) return;
-    } else {
-        PH(9) step_head_loss<WREF, (XF != 0)>(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
-        if (!hf.train) return;
-        BARRIER();
-        EXIT_AFTER(10);
-        PH(10) step_head_dreadout<WREF, (XF != 0)>(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
-    }
+    // (loss and d readout as ONE phase -- every wave forming the loss redundantly, dhid recomputed inside the d-readout items --
+    // was measured: 2.0 us for the merged phase against 0.7 + 0.85 us for the two; not kept)
+    PH(9) step_head_loss<WREF, (XF != 0)>(hf, g, br, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    if (!hf.train) return;
+    BARRIER();
+    EXIT_AFTER(10);
+    PH(10) step_head_dreadout<WREF, (XF != 0)>(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
     BARRIER();
     EXIT_AFTER(11);
 

@@ -436,8 +436,11 @@ class FusedTrainer(object):
         return int(self.step2[2])
 
     def check_faults(self):
-        """Raise if a kernel has reported a fault (called by NeuralNet once per epoch, where it synchronises anyway)."""
-        bits = self.faults()
+        """Raise if a kernel has reported a fault (synchronises)."""
+        self.raise_on_faults(self.faults())
+
+    def raise_on_faults(self, bits):
+        """``bits``: the fault word as read by the caller (NeuralNet copies it to the host behind every epoch)."""
         if bits:
             self.step2[2] = 0
             raise _lib.DrgnnError("fused training step reported fault bits 0x%x%s" % (

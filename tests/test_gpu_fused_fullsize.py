@@ -175,7 +175,8 @@ def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_s
     small = synth.make_batch(0, 64).to(dev)
     t64 = Topology.from_batch(small, need_weights=False)
     assert tr.api.net_step_plan(tr.kind, 32, t64.max_nodes, t64.max_edges, t64.max_c0, tr.R, tr.H, tr.O, 64)[0] == 2
-    pred_two = tr.predict(small, topo=t64).cpu().numpy()
+    tr.compute_gradients(small, topo=t64)                  # (no update in between: same parameters)
+    pred_two = tr.last_pred.cpu().numpy()
     np.testing.assert_array_equal(pred_one, pred_two)      # forward arithmetic is the same code in both layouts
 
 
