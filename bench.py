@@ -113,6 +113,12 @@ def parse():
     ap.add_argument("--step-layout", choices=["auto", "one", "two"], default="auto",
                     help="GINet: workgroups per graph of the fused step -- auto (default): two while every workgroup of the "
                          "launch is resident, else one (both branches in sequence); one / two: forced, for A/B runs")
+    ap.add_argument("--dp-selftest", action="store_true",
+                    help="data-parallel self-test BEFORE timing (dropout off for the whole run): 3 steps eagerly and 3 through "
+                         "the recorded schedule on every rank, each checked for (a) the all-reduced gradient == rank 0's "
+                         "recompute on the union of the shards (1e-5 relative, SURVEY 8(e)) and (b) parameters in sync "
+                         "over the ranks; the result (ranks, backend, exchange, fallback taken) goes into config.dp_selftest "
+                         "and to stderr.  Works with --gpus N (RCCL) and with --gpus N --backend gloo on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--epoch-graphs", type=int, default=4096,
                     help="size of the resident graph set of the secondary whole-epoch measurement (0: skip it)")
@@ -182,6 +188,8 @@ def main():
     batch = batch_cpu.clone().to(dev)
     torch.manual_seed(0)
     net = Net(N_FEAT, 1, 1).to(dev)            # dropout stays 0.4 for GINet (training mode)
+    if args.dp_selftest and hasattr(net, "dropout"):
+        net.dropout = 0.0                      # the union recompute cannot reproduce per-rank dropout streams
     net.train()
     native = args.mode.startswith("native")
     capture = args.mode in ("native", "graph")
@@ -433,6 +441,22 @@ def main():
             for _ in range(n):
                 eager_step()
 
+    selftest = None
+    if args.dp_selftest:
+        if not native:
+            raise SystemExit("--dp-selftest needs --mode native")
+        selftest = dp_selftest(trainer, net, Net, dev, rank, world, eager_step, run_steps, state, two_flavours,
+                               {"dp_exchange": dp_mode, "split_schedule": bool(split),
+                                "backend": (dist.get_backend() if dist.is_initialized() else None),
+                                "oneshot": oneshot is not None})
+        if rank == 0:
+            sys.stderr.write("dp_selftest: %s\n" % json.dumps(selftest))
+            sys.stderr.flush()
+        if not selftest["ok"]:
+            if dist.is_initialized():
+                dist.barrier()
+                dist.destroy_process_group()
+            raise SystemExit(4)
     # Warm-up: W steps as asked, rounded UP to an even count so that the two topology workspaces are back at
     # parity 0 and every timed block starts on the recorded chunk (a block of K steps = K // CHUNK chunk replays
     # + K % CHUNK single-step replays, whatever K and W are).
@@ -522,6 +546,8 @@ def main():
             result["config"]["params_in_sync"] = in_sync
             result["config"]["dp_backend"] = dist.get_backend() if dist.is_initialized() else None
             result["config"]["dp_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
+        if selftest is not None:
+            result["config"]["dp_selftest"] = selftest
         if native:
             result["roofline"] = measure_roofline(net, args.net, batch, dev, value / world,
                                                   cache=(cache, ids_host, ids_dev) if cached else None)
@@ -544,6 +570,65 @@ def main():
         except Exception:
             pass
         print(json.dumps(result), flush=True)
+
+
+def dp_selftest(trainer, net, Net, dev, rank, world, eager_step, run_steps, state, two_flavours, info):
+    """3 eager steps + 3 steps through the recorded schedule; after every step the all-reduced gradient in
+    ``trainer.flat_g`` is compared with rank 0's recompute on the UNION of the shards (same parameters: the snapshot taken
+    before the step) and the parameters are compared over the ranks.  Collective-safe: every rank makes the same calls."""
+    import copy
+    import torch.distributed as dist
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    multi = dist.is_initialized() and dist.get_world_size() > 1
+    ref = None
+    if rank == 0:
+        ref = FusedTrainer(copy.deepcopy(net), lr=1e-3, task="reg", seed=1)
+        union = synth.make_batch(0, GRAPHS_PER_GPU * world).to(dev)
+    out = {"ranks": world, "rccl_ranks": (world if info["backend"] == "nccl" else 0), "backend": info["backend"],
+           "dp_exchange": info["dp_exchange"] if info["split_schedule"] else "single process: reduce + Adam in one launch",
+           "oneshot_allreduce": info["oneshot"], "graphs_per_rank": GRAPHS_PER_GPU, "steps": []}
+
+    def check(kind, before):
+        g = trainer.flat_g.detach().clone()
+        want = torch.zeros_like(g)
+        if rank == 0:
+            ref.flat_p.copy_(before)
+            ref.compute_gradients(union)
+            want.copy_(ref.flat_g)
+        if multi:
+            dist.broadcast(want, src=0)
+        scale = float(want.abs().max())
+        err = float((g - want).abs().max()) / max(scale, 1e-30)
+        flat = trainer.flat_p.detach().double()
+        probe = torch.stack([flat.sum(), flat.abs().max(), flat.min(), torch.tensor(err, dtype=torch.float64, device=dev)])
+        hi, lo = probe.clone(), probe.clone()
+        if multi:
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        in_sync = bool(torch.equal(hi[:3], lo[:3]))
+        worst = float(hi[3])
+        out["steps"].append({"schedule": kind, "grad_max_rel_err": worst, "params_in_sync": in_sync})
+        return in_sync and worst <= 1e-5
+
+    ok = True
+    for _ in range(3):
+        before = trainer.flat_p.detach().clone()
+        eager_step()
+        torch.cuda.synchronize()
+        ok = check("eager", before) and ok
+    if state["k"] == 1 and two_flavours:           # 3 eager steps flipped the workspace parity: one more brings it back
+        before = trainer.flat_p.detach().clone()
+        eager_step()
+        torch.cuda.synchronize()
+        ok = check("eager", before) and ok
+    for _ in range(4 if two_flavours else 3):      # (an even count keeps the recorded chunks' parity)
+        before = trainer.flat_p.detach().clone()
+        run_steps(1)
+        torch.cuda.synchronize()
+        ok = check("recorded", before) and ok
+    out["ok"] = bool(ok)
+    return out
 
 
 def two_flavours_parity(state):
