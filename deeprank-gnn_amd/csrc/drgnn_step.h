@@ -310,8 +310,9 @@ DEV void step_gemm_nn_dual(int M, int K, const float* A, int lda, const float* B
 // callers put another one before reusing `part`.
 #ifdef DRGNN_EMU
 DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
-                      float* C, int ldc, int Mrows) {
+                      float* C, int ldc, int Mrows, int stage = 0) {
     (void)KS; (void)part; (void)MT;
+    if (stage == 2) return;      // (emulation: stage 1 forms the whole product)
     for (int i = 0; i < Mrows; ++i)
         for (int j = 0; j < 16 * NT; ++j) {
             float acc = 0.0f;
@@ -329,9 +330,11 @@ DEV void step_gemm_tn_pair(int MT, int NTH, int K, const float* A, int lda, cons
 #else
 // MT/NT compile-time (0: run-time value in mt_rt / nt_rt), KS a power of two: no integer division left
 // NTH: column tiles per output block (NT = NTH: one block at C; NT = 2 * NTH: second block at C + chalf)
+// stage: 0 = the whole product (contains a workgroup barrier); 1 = only the partial tiles, 2 = only their sum and the
+// stores -- the caller's own phase barrier lies between the two, so the product adds no barrier to the chain
 template <int MTC, int NTC, int NTH = 0>
 DEV void step_gemm_tn_t(int mt_rt, int nt_rt, int K, const float* A, int lda, const float* B, int ldb, int KS,
-                        float* part, float* C, int ldc, int Mrows, int chalf = 0) {
+                        float* part, float* C, int ldc, int Mrows, int chalf = 0, int stage = 0) {
     const int MT = MTC ? MTC : mt_rt, NT = NTC ? NTC : nt_rt;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
@@ -339,6 +342,7 @@ DEV void step_gemm_tn_t(int mt_rt, int nt_rt, int K, const float* A, int lda, co
     const int ks_log = 31 - __builtin_clz((unsigned)KS);
     const int kslice = (((K4 >> 2) + KS - 1) >> ks_log) << 2;
     const int tiles = MT * NT, units = tiles * KS;
+    if (stage != 2)
     for (int u = wave; u < units; u += DRGNN_NWAVES) {
         const int ks = u / tiles, t = u - ks * tiles;
         const int ti = t / NT, tj = t - ti * NT;
@@ -361,7 +365,8 @@ DEV void step_gemm_tn_t(int mt_rt, int nt_rt, int K, const float* A, int lda, co
         }
         *(drgnn_f4*)(part + (u * 64 + lane) * 4) = drgnn_f4{acc[0], acc[1], acc[2], acc[3]};
     }
-    __syncthreads();
+    if (stage == 1) return;
+    if (stage == 0) __syncthreads();
     for (int e = threadIdx.x; e < tiles * 64; e += DRGNN_NTHREADS) {
         const int t = e >> 6, l = e & 63;
         const int ti = t / NT, tj = t - ti * NT;
@@ -386,12 +391,12 @@ DEV void step_gemm_tn_pair(int MT, int NTH, int K, const float* A, int lda, cons
     else step_gemm_tn_t<0, 4, 2>(MT, 4, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, chalf);
 }
 DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
-                      float* C, int ldc, int Mrows) {
+                      float* C, int ldc, int Mrows, int stage = 0) {
     KS = 1 << (31 - __builtin_clz((unsigned)(KS > 0 ? KS : 1)));       // round down to a power of two
-    if (MT == 1 && NT == 2) step_gemm_tn_t<1, 2>(1, 2, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
-    else if (MT == 2 && NT == 1) step_gemm_tn_t<2, 1>(2, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
-    else if (MT == 1 && NT == 1) step_gemm_tn_t<1, 1>(1, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
-    else step_gemm_tn_t<0, 0>(MT, NT, K, A, lda, B, ldb, KS, part, C, ldc, Mrows);
+    if (MT == 1 && NT == 2) step_gemm_tn_t<1, 2>(1, 2, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage);
+    else if (MT == 2 && NT == 1) step_gemm_tn_t<2, 1>(2, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage);
+    else if (MT == 1 && NT == 1) step_gemm_tn_t<1, 1>(1, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage);
+    else step_gemm_tn_t<0, 0>(MT, NT, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage);
 }
 #endif
 
@@ -1513,9 +1518,11 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
     if (GIN) {
         // dS = dZ2 W2^T (into the p2 area, rows of STEP_XPLD floats);  dW2 = S^T dZ2 (K = pooled nodes)
         PH(11) step_gemm_nn(d.C, 1, DRGNN_H2, s.z2, Z2LD, s.w2n, W2NLD, s.p2, STEP_XPLD, dummy);
-        PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1);
+        // (the partial tiles here, their sum behind the phase's own barrier: the product adds no barrier to the chain)
+        PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1, 1);
         BARRIER();
         EXIT_AFTER(12);
+        PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1, 2);
         // dXP = A^T dS, scattered through the depth-0 argmax into dZ1
         PH(13) step_gather_scatter<STEP_XPLD, EIdx>(d.C, s.cp1, (const EIdx*)s.rx1, s.p2, s.a0, s.z1);
         BARRIER();
@@ -1525,10 +1532,12 @@ DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi,
     // the slab holds dW2nbr and dW2self back to back, i.e. exactly the 32 x 32 result
     PH(11) step_gemm_nn(d.C, 2, DRGNN_H2, s.z2, Z2LD, s.wc2n, TSLD, s.p2, TSLD, dummy);
     PH(12) step_gemm_tn(2, 2, d.C, s.u2, TSLD, s.z2, Z2LD, imin(DRGNN_NWAVES / 4, gp_units / 4), s.gp, p_w2n, DRGNN_H2,
-                        2 * DRGNN_H1);
-    step_colsum_partial<DRGNN_H2, Z2LD>(d.C, s.z2, s.bsum);     // db2, stage 1 (the barrier inside the product serves it)
+                        2 * DRGNN_H1, 1);
+    step_colsum_partial<DRGNN_H2, Z2LD>(d.C, s.z2, s.bsum);     // db2, stage 1
     BARRIER();
     EXIT_AFTER(12);
+    PH(12) step_gemm_tn(2, 2, d.C, s.u2, TSLD, s.z2, Z2LD, imin(DRGNN_NWAVES / 4, gp_units / 4), s.gp, p_w2n, DRGNN_H2,
+                        2 * DRGNN_H1, 2);
     step_colsum_finish<DRGNN_H2>(s.bsum, p_b2);
     // dXP = s dT + (d c A)^T dS, scattered through the depth-0 argmax into dZ1
     PH(13) step_pooled_gather_bwd<KIND, TSLD, EIdx>(d.C, s.rp1, s.cp1, (const EIdx*)s.rx1, (const EIdx*)s.ts1, s.ew1, s.dv1,

@@ -422,7 +422,7 @@ DEV void net_step_graph_both(const StepArgs& a, const GraphDims& d_in, int g, in
         // dS = dZ2 W2^T (into the xp area, rows of STEP_XPLD floats);  dW2 = S^T dZ2 (K = pooled nodes; partial tiles in u1)
         step_gemm_nn(d.C, 1, DRGNN_H2, s.z2, Z2LD, (br ? s.w2n1 : s.w2n0), W2NLD, s.xp, STEP_XPLD, dummy);
         step_gemm_tn(1, 2, d.C, (br ? s.sg1 : s.sg0), STEP_XPLD, s.z2, Z2LD, imin(DRGNN_NWAVES / 2, u1_units / 2), s.u1, p_w2n, DRGNN_H2, DRGNN_H1);
-        BARRIER();
+        BARRIER();      // (u1's K padding rows are zeroed below, behind the sum of the partial tiles the product kept there)
         // dXP = A^T dS, scattered through the depth-0 argmax into dZ1; u1's K padding rows (partial tiles were there) zero again
         step_gather_scatter<STEP_XPLD, EIdx>(d.C, s.cp1, (const EIdx*)s.rx1, s.xp, (br ? s.a01 : s.a00), s.z1);
         FOR_TID(e, (step_pad4(d.N) - d.N) * HC1) { s.u1[d.N * HC1 + e] = 0.0f; }
