@@ -11,7 +11,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python bench.py --net $NET --no-cpu-baseline --epoch-graphs 0 > $OUT/stats.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python bench.py --net $NET --min-seconds 1 --no-cpu-baseline --epoch-graphs 0 > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/write.log 2>&1
 # SQ counters (own passes, kernel trace only): MFMA busy, wave-cycle breakdown, LDS conflicts
