@@ -24,3 +24,12 @@ def test_epoch_fixture():
 def test_epoch_cached_topology(Net, task, bs):
     """Declared cached-topology mode (topology of every graph built once at upload, mini-batch = list of graph numbers)."""
     check_epoch(Net, ragged_graphs(11, 12), 12, task, "cpu", bs, api=emu(), cached=True)
+
+
+@pytest.mark.parametrize("cached", [False, True])
+def test_long_epochs_are_enqueued_in_pieces_with_identical_results(cached, monkeypatch):
+    """An epoch longer than FusedTrainer.EPOCH_CHUNK mini-batches goes to the native loop in pieces (the host stays at most
+    two pieces ahead of the device): same losses / predictions / parameters as one call, bit for bit."""
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    monkeypatch.setattr(FusedTrainer, "EPOCH_CHUNK", 2)       # 11 graphs, batch 2 -> 6 mini-batches -> 3 pieces
+    check_epoch(GINet, ragged_graphs(11, 12), 12, "reg", "cpu", 2, api=emu(), cached=cached)
