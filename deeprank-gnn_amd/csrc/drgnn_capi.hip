@@ -1526,6 +1526,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         return r;
     };
     EpochBatch cur, nxt;
+    std::vector<int32_t> hn, he;       // (slot offset tables of the current mini-batch, reused)
     if ((rc = epoch_batch(p, 0, &cur))) return rc;
     {
         const drgnn_topology_request r0 = request(0, cur);
@@ -1541,7 +1542,6 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         }
         // the slot offsets of this mini-batch are known here (host size tables): hand them to the launch
         drgnn_step_hints hints = {};
-        std::vector<int32_t> hn, he;
         if (cur.B <= DRGNN_STEP_DIMS_MAX) {
             hn.resize((size_t)cur.B + 1); he.resize((size_t)cur.B + 1);
             hn[0] = 0; he[0] = 0;

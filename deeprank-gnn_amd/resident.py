@@ -226,7 +226,12 @@ class ResidentGraphSet(object):
         ids = np.asarray(ids, dtype=np.int64).reshape(-1)
         if ids.size and (ids.min() < 0 or ids.max() >= len(self)):
             raise IndexError("graph number out of range [0, %d)" % len(self))
-        return torch.from_numpy(ids.astype(np.int32)).to(self.device)
+        host = torch.from_numpy(ids.astype(np.int32))
+        if self.device.type == "cuda":
+            # pinned + non-blocking: a pageable copy would make the host wait for everything already enqueued on the stream
+            # (the previous epoch), i.e. serialise the epochs the trainer pipelines
+            return host.pin_memory().to(self.device, non_blocking=True)
+        return host.to(self.device)
 
     def batch_offsets(self, ids_dev, batch_size):
         """Slot offset tables of every mini-batch of the visiting order ``ids_dev`` (``upload_ids``), one launch:
