@@ -32,6 +32,14 @@ def _dist_world_rank():
     return 1, 0
 
 
+def _index_on(device, idx):
+    """int64 index tensor on ``device`` without making the host wait for the stream (pinned + non-blocking on the GPU)."""
+    t = torch.as_tensor(idx, dtype=torch.long)
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 def _divide(n, percent, shuffle):
     """reference DivideDataSet (DataSet.py:14-42): shuffled index split."""
     index = np.arange(n)
@@ -275,7 +283,7 @@ class NeuralNet(object):
             if done is not None:
                 losses, pred = done
                 store['_pred'].append(pred)
-                store['_y'].append(rs.y[order.to(rs.y.device)])
+                store['_y'].append(rs.y[_index_on(rs.y.device, order)])
                 order = order.tolist()
                 store['mol'] += [rs.mols[i] for i in order]
                 return self._stage(store, losses.sum())
@@ -345,7 +353,7 @@ class NeuralNet(object):
                 raise _lib.DrgnnError("the native epoch loop refused a configuration its probe had accepted")
             losses, pred = done
             store['_pred'].append(pred)
-            store['_y'].append(rs.y[torch.as_tensor(mine, dtype=torch.long, device=rs.y.device)])
+            store['_y'].append(rs.y[_index_on(rs.y.device, mine)])
             store['mol'] += [rs.mols[i] for i in mine]
             total = (losses * w).sum()
         else:
@@ -396,7 +404,7 @@ class NeuralNet(object):
                 store['mol'] += [rs.mols[i] for i in order]
                 total = None
                 if rs.y is not None:
-                    y = rs.y[torch.as_tensor(order, dtype=torch.long, device=rs.y.device)]
+                    y = rs.y[_index_on(rs.y.device, order)]
                     store['_y'].append(y)
                     total = self._sum_of_batch_losses(pred, y)
                 return self._stage(store, total)
