@@ -582,10 +582,9 @@ int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int
         if (lds_bytes) *lds_bytes = step_lds_bytes(kind, n_feat, max_nodes, capE, capC, R, H, O);
         return 1;
     }
-    // builder workgroups of the topology co-built by the same launch: two per graph up to DRGNN_TOPO_SPLIT_MAX_GRAPHS graphs
-    // (topo_prepare; an upper bound -- a launch that finds fewer only ever moves towards the two-workgroup layout, whose
-    // workgroups need less LDS than the figure returned here)
-    const int64_t extra = co_built_graphs > 0 ? co_built_graphs * (co_built_graphs <= DRGNN_TOPO_SPLIT_MAX_GRAPHS ? 2 : 1) : 0;
+    // builder workgroups of the topology co-built by the same launch
+    // (the builder takes ONE workgroup per graph when two would push the launch past the device: train_step_impl)
+    const int64_t extra = co_built_graphs > 0 ? co_built_graphs : 0;
     if (step_two_workgroups_ok(n_graphs, extra)) {
         if (lds_bytes) *lds_bytes = step_lds_bytes(kind, n_feat, max_nodes, capE, capC, R, H, O);
         return 2;
@@ -700,15 +699,29 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
                 T.args.n_graphs > 0 && blocks > 0;
     }
     bool one_wg = false;       // GINet: both branches of a graph in one workgroup (drgnn_step1.h)
+    // The co-launched builder runs two workgroups per graph (shorter chains) or one (fewer workgroups, each ~1.6x longer):
+    // what counts is whether the WHOLE launch is resident at once.  Measured (tools/r03_split_sweep.sh): sGAT at batch 128,
+    // 128 step + 256 builder workgroups on 256 CUs = two rounds, 37.2 us per step; 128 + 128 = one round, 29.0 us.
+    const int cus = device_cu_count();
+    const int64_t bn = co_ok ? (int64_t)T.args.n_graphs : 0;
+    const bool split_ok = co_ok && T.roles == 2;
     if (net->n_branch == 2) {
-        const int64_t extra_wgs = co_ok ? (int64_t)T.args.n_graphs * T.roles : 0;
-        if (!step_two_workgroups_ok(n_graphs, extra_wgs)) {
-            if (lds1 <= DRGNN_LDS_LIMIT) one_wg = true;
-            else if (two_alone) co_ok = false;      // the builder gets a launch of its own; 2 B workgroups are resident
-            else return DRGNN_E_CAPACITY;
+        // two workgroups per graph only while every workgroup of the launch is resident -- with the builder at two
+        // workgroups per graph if that fits, else at one
+        if (step_two_workgroups_ok(n_graphs, bn * (split_ok ? 2 : 1))) {
+        } else if (split_ok && step_two_workgroups_ok(n_graphs, bn)) {
+            T.roles = 1;
+        } else if (lds1 <= DRGNN_LDS_LIMIT) {
+            one_wg = true;
+        } else if (two_alone) {
+            co_ok = false;      // the builder gets a launch of its own; 2 B workgroups are resident
+        } else {
+            return DRGNN_E_CAPACITY;
         }
         if (one_wg) { lds = lds1; L.words = lds / 4; blocks = (int)n_graphs; }
     }
+    if (co_ok && T.roles == 2 && (net->n_branch != 2 || one_wg) && blocks + 2 * bn > cus && blocks + bn <= cus)
+        T.roles = 1;            // one round of workgroups instead of two
     if (blocks > 0) {
 #ifdef DRGNN_EMU
         // workgroups run one after the other here: two passes (up to the readout exchange, then the
