@@ -110,7 +110,7 @@ def parse():
     ap.add_argument("--graphs-per-gpu", type=int, default=GRAPHS_PER_GPU,
                     help="mini-batch per GPU; %d is BASELINE.json's configuration, other values are for the "
                          "batch-size sweep in DESIGN.md" % GRAPHS_PER_GPU)
-    ap.add_argument("--step-layout", choices=["auto", "one", "two"], default="auto",
+    ap.add_argument("--step-layout", choices=["auto", "one", "seq", "two"], default="auto",
                     help="GINet: workgroups per graph of the fused step -- auto (default): two while every workgroup of the "
                          "launch is resident, else one (both branches in sequence); one / two: forced, for A/B runs")
     ap.add_argument("--dp-selftest", action="store_true",
@@ -183,7 +183,9 @@ def main():
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[args.net]
 
     if args.step_layout != "auto":
-        _lib.get().set_step_layout({"one": 1, "two": 2}[args.step_layout])
+        if args.step_layout == "seq":                  # one workgroup per graph, branch after branch (not the paired form)
+            _lib.get().set_step_layout(3)
+        _lib.get().set_step_layout({"one": 1, "seq": 1, "two": 2}[args.step_layout])
     batch_cpu = synth.make_batch(rank * GRAPHS_PER_GPU, GRAPHS_PER_GPU)
     batch = batch_cpu.clone().to(dev)
     torch.manual_seed(0)

@@ -564,10 +564,19 @@ static bool step_two_workgroups_ok(int64_t n_graphs, int64_t other_workgroups) {
     if (g_step_layout_mode == 2) return true;
     return 2 * n_graphs + other_workgroups <= device_cu_count();
 }
-static int64_t step1_lds_bytes(int F, int capN, int capE, int capC, int H, int O) {
-    return 4 * step1_scratch_words(F, capN, capE, capC, H, O);
+static int g_step1_paired_mode = 1;         // 1: both branches per phase whenever its LDS plan fits (default); 0: never (A/B runs)
+static int64_t step1_lds_bytes_form(int F, int capN, int capE, int capC, int H, int O, int paired) {
+    return 4 * step1_scratch_words(F, capN, capE, capC, H, O, paired);
+}
+// the one-workgroup layout's LDS need: its paired form if that fits, else the branch-after-branch form
+static int64_t step1_lds_bytes(int F, int capN, int capE, int capC, int H, int O, bool* paired_out = nullptr) {
+    const int64_t p = step1_lds_bytes_form(F, capN, capE, capC, H, O, 1);
+    const bool paired = g_step1_paired_mode != 0 && p <= DRGNN_LDS_LIMIT;
+    if (paired_out) *paired_out = paired;
+    return paired ? p : step1_lds_bytes_form(F, capN, capE, capC, H, O, 0);
 }
 int32_t drgnn_set_step_layout(int32_t mode) {
+    if (mode == 3 || mode == 4) { g_step1_paired_mode = (mode == 4); return 0; }   // (A/B: 3 = branch after branch, 4 = paired)
     if (mode < 0 || mode > 2) return DRGNN_E_ARG;
     g_step_layout_mode = mode;
     return 0;
@@ -634,7 +643,8 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     // GINet: one workgroup per graph unless all of 2 B (+ the builder's) workgroups are resident at once; decided below,
     // once the co-launched builder's size is known
     const bool two_alone = (net->n_branch == 2) && step_two_workgroups_ok(n_graphs, 0);
-    const int64_t lds1 = (net->n_branch == 2) ? step1_lds_bytes(F, L.capN, L.capE, L.capC, hd->H, hd->O) : 0;
+    bool one_paired = false;
+    const int64_t lds1 = (net->n_branch == 2) ? step1_lds_bytes(F, L.capN, L.capE, L.capC, hd->H, hd->O, &one_paired) : 0;
     if (net->n_branch == 2 && !two_alone) {
         if (lds1 > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
     } else if (lds > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
@@ -729,8 +739,13 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         std::vector<float> slabs((size_t)blocks * (size_t)(L.words + 16));
         if (one_wg) {
             for (int b = 0; b < blocks; ++b) {
-                if (gather_ids) step_block_both<0, true>(L, b, slabs.data());
-                else step_block_both<0, false>(L, b, slabs.data());
+                if (one_paired) {
+                    if (gather_ids) step_block_both<0, true, true>(L, b, slabs.data());
+                    else step_block_both<0, false, true>(L, b, slabs.data());
+                } else {
+                    if (gather_ids) step_block_both<0, true, false>(L, b, slabs.data());
+                    else step_block_both<0, false, false>(L, b, slabs.data());
+                }
             }
         } else
         for (int pass = 1; pass <= 2; ++pass)
@@ -789,26 +804,33 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             default: DRGNN_STEP_LAUNCH(K, 0); break;                                                        \
         }                                                                                                   \
     } while (0)
-#define DRGNN_STEP1_LAUNCH_G(XF, G)                                                                         \
+#define DRGNN_STEP1_LAUNCH_G(XF, G) DRGNN_STEP1_LAUNCH_GP(XF, G, false)
+#define DRGNN_STEP1_LAUNCH_GP(XF, G, P)                                                                         \
     do {                                                                                                    \
         /* once per kernel instance and device: the whole 160 KiB (the call costs host time on every launch otherwise) */\
         static int lds_set_on = -1;                                                                                   \
         if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
-            if (hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G>,                                              \
+            if (hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G, P>,                                              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
                 lds_set_on = step_current_device();                                                                   \
             } else {      /* (profiling builds carry a static LDS word: ask for what this launch needs) */            \
                 (void)hipGetLastError();                                                                              \
-                HIP_TRY(hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G>,                                      \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G, P>,                                      \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_step1_co_topo<XF, G>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
+        hipLaunchKernelGGL((k_step1_co_topo<XF, G, P>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
                            (size_t)both, stream, C);                                                        \
     } while (0)
 #define DRGNN_STEP1_LAUNCH(XF)                                                                              \
     do { if (gather_ids) DRGNN_STEP1_LAUNCH_G(XF, true); else DRGNN_STEP1_LAUNCH_G(XF, false); } while (0)
-        if (one_wg) {
+        if (one_wg && one_paired) {
+            if (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32) {
+                if (gather_ids) DRGNN_STEP1_LAUNCH_GP(32, true, true); else DRGNN_STEP1_LAUNCH_GP(32, false, true);
+            } else {
+                if (gather_ids) DRGNN_STEP1_LAUNCH_GP(0, true, true); else DRGNN_STEP1_LAUNCH_GP(0, false, true);
+            }
+        } else if (one_wg) {
             switch (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O)) {
                 case 16: DRGNN_STEP1_LAUNCH(16); break;
                 case 32: DRGNN_STEP1_LAUNCH(32); break;
@@ -825,6 +847,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
 #undef DRGNN_STEP_LAUNCH_G
 #undef DRGNN_STEP1_LAUNCH
 #undef DRGNN_STEP1_LAUNCH_G
+#undef DRGNN_STEP1_LAUNCH_GP
         HIP_TRY(hipGetLastError());
 #endif
     }

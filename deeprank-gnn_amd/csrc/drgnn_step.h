@@ -213,8 +213,8 @@ DEV StepScratch step_carve(float* base, int kind, int F, int capN, int capE, int
 #ifdef DRGNN_EMU
 template <bool RELU = false>
 DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
-                      int* dummy, const float* bias = nullptr, const float* nan_rows = nullptr) {
-    (void)dummy;
+                      int* dummy, const float* bias = nullptr, const float* nan_rows = nullptr, int wave_shift = 0) {
+    (void)dummy; (void)wave_shift;
     for (int i = 0; i < M; ++i)
         for (int j = 0; j < 16 * NT; ++j) {
             float acc = 0.0f;
@@ -226,11 +226,14 @@ DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float
         }
 }
 #else
+// wave_shift: tile unit u goes to wave (u + wave_shift) mod 16 -- callers that issue two products in one phase start the
+// second one where the first one's units end, so that all 16 waves get tiles
 template <bool RELU = false>
 DEV void step_gemm_nn(int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
-                      int* dummy, const float* bias = nullptr, const float* nan_rows = nullptr) {
+                      int* dummy, const float* bias = nullptr, const float* nan_rows = nullptr, int wave_shift = 0) {
     // nan_rows: rows i with nan_rows[i] == 0 are written as NaN (FoutLayer's mean over an empty neighbourhood)
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wave = (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - wave_shift) & (DRGNN_NWAVES - 1);
+    const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int units = ((M + 15) >> 4) * NT;
     for (int u = wave; u < units; u += DRGNN_NWAVES) {
@@ -310,8 +313,8 @@ DEV void step_gemm_nn_dual(int M, int K, const float* A, int lda, const float* B
 // callers put another one before reusing `part`.
 #ifdef DRGNN_EMU
 DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
-                      float* C, int ldc, int Mrows, int stage = 0) {
-    (void)KS; (void)part; (void)MT;
+                      float* C, int ldc, int Mrows, int stage = 0, int wave_shift = 0) {
+    (void)KS; (void)part; (void)MT; (void)wave_shift;
     if (stage == 2) return;      // (emulation: stage 1 forms the whole product)
     for (int i = 0; i < Mrows; ++i)
         for (int j = 0; j < 16 * NT; ++j) {
@@ -319,6 +322,11 @@ DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const floa
             for (int k = 0; k < K; ++k) acc = fmaf(A[k * lda + i], B[k * ldb + j], acc);
             C[i * ldc + j] = acc;
         }
+}
+DEV void step_gemm_tn_bufa(int MT, int K, const float* A, int lda, int a_bytes, const float* B, int ldb, int KS, float* part,
+                           float* C, int ldc, int Mrows, int stage = 0, int wave_shift = 0) {
+    (void)a_bytes; (void)wave_shift;
+    step_gemm_tn(MT, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, stage);
 }
 // two products sharing the A operand in one pass: B holds [B0 | B1] side by side (16*NTH columns each), the results
 // go to C and C + chalf (sGAT / FoutNet: neighbour and self weight gradients)
@@ -332,11 +340,15 @@ DEV void step_gemm_tn_pair(int MT, int NTH, int K, const float* A, int lda, cons
 // NTH: column tiles per output block (NT = NTH: one block at C; NT = 2 * NTH: second block at C + chalf)
 // stage: 0 = the whole product (contains a workgroup barrier); 1 = only the partial tiles, 2 = only their sum and the
 // stores -- the caller's own phase barrier lies between the two, so the product adds no barrier to the chain
-template <int MTC, int NTC, int NTH = 0>
+// BUFA: the A operand is read straight from GLOBAL memory through a buffer descriptor over its a_bytes (rows past the end
+// read as zero, like the zero rows an LDS operand keeps): for callers whose LDS copy of A is gone by then
+template <int MTC, int NTC, int NTH = 0, bool BUFA = false>
 DEV void step_gemm_tn_t(int mt_rt, int nt_rt, int K, const float* A, int lda, const float* B, int ldb, int KS,
-                        float* part, float* C, int ldc, int Mrows, int chalf = 0, int stage = 0) {
+                        float* part, float* C, int ldc, int Mrows, int chalf = 0, int stage = 0, int a_bytes = 0,
+                        int wave_shift = 0) {
     const int MT = MTC ? MTC : mt_rt, NT = NTC ? NTC : nt_rt;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int wave = (__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - wave_shift) & (DRGNN_NWAVES - 1);
+    const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int K4 = step_pad4(K);
     const int ks_log = 31 - __builtin_clz((unsigned)KS);
@@ -350,13 +362,17 @@ DEV void step_gemm_tn_t(int mt_rt, int nt_rt, int K, const float* A, int lda, co
         drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* ap = A + (kbeg + lq) * lda + ti * 16 + lr;
         const float* bp = B + (kbeg + lq) * ldb + tj * 16 + lr;
+        const __amdgpu_buffer_rsrc_t arsrc = buf_rsrc(A, BUFA ? a_bytes : 0);
+        int aoff = ((kbeg + lq) * lda + ti * 16 + lr) * 4;
         for (int k0 = kbeg; k0 < kend; k0 += 32) {
             float a[8], b[8];
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) {      // unconditional: rows past kend exist in LDS and are not used
-                a[s2] = ap[4 * s2 * lda];
+                if (BUFA) a[s2] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(arsrc, aoff + 16 * s2 * lda, 0, 0));
+                else a[s2] = ap[4 * s2 * lda];
                 b[s2] = bp[4 * s2 * ldb];
             }
+            aoff += 128 * lda;
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2)
                 if (k0 + 4 * s2 < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2], b[s2], acc, 0, 0, 0);
@@ -390,10 +406,17 @@ DEV void step_gemm_tn_pair(int MT, int NTH, int K, const float* A, int lda, cons
     else if (NTH == 1) step_gemm_tn_t<0, 2, 1>(MT, 2, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, chalf);
     else step_gemm_tn_t<0, 4, 2>(MT, 4, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, chalf);
 }
+// A read from global memory (a_bytes bytes, rows of lda floats), NT = 1
+DEV void step_gemm_tn_bufa(int MT, int K, const float* A, int lda, int a_bytes, const float* B, int ldb, int KS, float* part,
+                           float* C, int ldc, int Mrows, int stage = 0, int wave_shift = 0) {
+    KS = 1 << (31 - __builtin_clz((unsigned)(KS > 0 ? KS : 1)));
+    if (MT == 2) step_gemm_tn_t<2, 1, 0, true>(2, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage, a_bytes, wave_shift);
+    else step_gemm_tn_t<0, 1, 0, true>(MT, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage, a_bytes, wave_shift);
+}
 DEV void step_gemm_tn(int MT, int NT, int K, const float* A, int lda, const float* B, int ldb, int KS, float* part,
-                      float* C, int ldc, int Mrows, int stage = 0) {
+                      float* C, int ldc, int Mrows, int stage = 0, int wave_shift = 0) {
     KS = 1 << (31 - __builtin_clz((unsigned)(KS > 0 ? KS : 1)));       // round down to a power of two
-    if (MT == 1 && NT == 2) step_gemm_tn_t<1, 2>(1, 2, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage);
+    if (MT == 1 && NT == 2) step_gemm_tn_t<1, 2>(1, 2, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage, 0, wave_shift);
     else if (MT == 2 && NT == 1) step_gemm_tn_t<2, 1>(2, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage);
     else if (MT == 1 && NT == 1) step_gemm_tn_t<1, 1>(1, 1, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage);
     else step_gemm_tn_t<0, 0>(MT, NT, K, A, lda, B, ldb, KS, part, C, ldc, Mrows, 0, stage);

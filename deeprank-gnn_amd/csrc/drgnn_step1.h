@@ -28,6 +28,7 @@ struct Step1Scratch {
     int* rp1; int* cx1; int* cp1; int* rx1; int* mp1; int* mem1;
     short* a00; short* a01; short* a10; short* a11;      // a<depth><branch>
     float* u1; float* z1; float* z2; float* xp; float* sg0; float* sg1;
+    float* u1b; float* z1b; float* z2b; float* xpb;      // PAIRED: branch 1's copies (branch 0 uses u1 / z1 / z2 / xp)
     float* hw2; float* hb2;
     float* end;
 };
@@ -39,6 +40,14 @@ HD int64_t step1_z1_words(int64_t capN, int64_t f16) {
     return w > m ? w : m;
 }
 
+// PAIRED (both branches share every phase): u1 / z2 / xp exist per branch; the two z1 arrays live in the x tile's area, which
+// is dead between conv1's products and the end (dW1 reads x from global memory there)
+HD int64_t step1_xs_words(int64_t capN, int64_t xld, int paired) {
+    // paired: room for the two Z1 arrays and, later, for one 256-word partial tile per 16 input columns and branch at least
+    const int64_t w = (capN + 4) * xld, z = 2 * ((capN * DRGNN_H1 + 3) & ~(int64_t)3), m = 2 * 256 * ((xld - 4) / 16);
+    if (!paired) return w;
+    return w > z ? (w > m ? w : m) : (z > m ? z : m);
+}
 #define STEP1_CARVE_LIST(X)                                                                    \
     X(misc, 128)                                                                               \
     X(xr, 2 * DRGNN_H2)                                                                        \
@@ -53,7 +62,7 @@ HD int64_t step1_z1_words(int64_t capN, int64_t f16) {
     X(w2t1, DRGNN_H2 * STEP_XPLD)                                                            \
     X(w2n0, DRGNN_H1 * (DRGNN_H2 + 4))                                                       \
     X(w2n1, DRGNN_H1 * (DRGNN_H2 + 4))                                                       \
-    X(xs, (long)(capN + 4) * xld)                                                              \
+    X(xs, step1_xs_words(capN, xld, paired))                                                   \
     X(rp0, capN + 1)                                                                           \
     X(cx0, capE)                                                                               \
     X(cp0, capN + 1)                                                                           \
@@ -71,15 +80,19 @@ HD int64_t step1_z1_words(int64_t capN, int64_t f16) {
     X(a10, ((long)capC * DRGNN_H2 + 1) / 2)                                                  \
     X(a11, ((long)capC * DRGNN_H2 + 1) / 2)                                                  \
     X(u1, step1_u1_words(capN))                                                                \
-    X(z1, step1_z1_words(capN, f16))                                                           \
+    X(z1, paired ? 0 : step1_z1_words(capN, f16))                                              \
     X(z2, (long)(capC + 4) * (DRGNN_H2 + 4))                                                   \
     X(xp, (long)(capC + 4) * STEP_XPLD)                                                        \
+    X(u1b, paired ? step1_u1_words(capN) : 0)                                                  \
+    X(z1b, 0)                                                                                  \
+    X(z2b, paired ? (long)(capC + 4) * (DRGNN_H2 + 4) : 0)                                     \
+    X(xpb, paired ? (long)(capC + 4) * STEP_XPLD : 0)                                          \
     X(sg0, (long)(capC + 4) * STEP_XPLD)                                                     \
     X(sg1, (long)(capC + 4) * STEP_XPLD)                                                     \
     X(hw2, (long)O * H)                                                                        \
     X(hb2, O)
 
-HD int64_t step1_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O) {
+HD int64_t step1_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O, int paired = 0) {
     const int64_t f16 = step_pad16((int)F), xld = f16 + 4;
     int64_t w = 0;
 #define X(name, words) w += (((int64_t)(words) + 3) & ~(int64_t)3);   /* 16-byte aligned arrays */
@@ -88,7 +101,7 @@ HD int64_t step1_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t ca
     return w + 16;
 }
 
-DEV Step1Scratch step1_carve(float* base, int F, int capN, int capE, int capC, int H, int O) {
+DEV Step1Scratch step1_carve(float* base, int F, int capN, int capE, int capC, int H, int O, int paired = 0) {
     const int f16 = step_pad16(F), xld = f16 + 4;
     Step1Scratch s;
     int o = 0;
@@ -96,6 +109,10 @@ DEV Step1Scratch step1_carve(float* base, int F, int capN, int capE, int capC, i
     STEP1_CARVE_LIST(X)
 #undef X
     s.end = base + o;
+    if (paired) {      // the two dZ1 / Z1 arrays inside the x tile's area ((capN + 4) * xld >= 2 * capN * 16 words)
+        s.z1 = s.xs;
+        s.z1b = s.xs + (((long)capN * DRGNN_H1 + 3) & ~3L);
+    }
     return s;
 }
 
@@ -163,7 +180,10 @@ DEV void step1_fc1_finish(const HeadFused& hf, int g, const float* wb, const flo
 }
 
 // XF / GATHER / late: as net_step_graph (drgnn_step.h)
-template <int XF, bool GATHER = false>
+// PAIRED: every phase works on BOTH branches (routine of branch 0, routine of branch 1, then the barrier): half the barriers
+// and twice the independent work between them -- the form taken whenever its LDS plan fits (153 KB at SYN size); the
+// branch-after-branch form (141 KB) is the fallback for larger graphs
+template <int XF, bool GATHER = false, bool PAIRED = false>
 DEV void net_step_graph_both(const StepArgs& a, const GraphDims& d_in, int g, int gi, float* scratch, int capN, int capE,
                              int capC, bool late = false, int cnt_c = 0, int cnt_e1 = 0, int cnt_c1 = 0) {
     GraphDims d = d_in;
@@ -182,7 +202,7 @@ DEV void net_step_graph_both(const StepArgs& a, const GraphDims& d_in, int g, in
     const int F = a.net.n_feat;
     const int H = hf.H, O = hf.O;
     const int F16 = XF ? XF : step_pad16(F), XLD = F16 + 4;
-    Step1Scratch s = step1_carve(scratch, (XF != 0) ? XF : F, capN, capE, capC, (XF != 0) ? WREF : H, O);
+    Step1Scratch s = step1_carve(scratch, (XF != 0) ? XF : F, capN, capE, capC, (XF != 0) ? WREF : H, O, PAIRED ? 1 : 0);
     WBlockRegs<(XF != 0) ? 1 : STEP_WB_J> wreg0, wreg1;     // fc1's two column blocks: in LDS one at a time
     int* const dummy = (int*)(s.misc + 64);
     const uint32_t done = (uint32_t)a.step2[0];
@@ -324,6 +344,125 @@ DEV void net_step_graph_both(const StepArgs& a, const GraphDims& d_in, int g, in
         }
     }
 
+    const float keep_scale = (hf.p_drop > 0.0f) ? 1.0f / (1.0f - hf.p_drop) : 1.0f;
+    const double pt = (double)hf.p_drop * 4294967296.0;
+    const uint32_t thresh = (hf.p_drop > 0.0f) ? (uint32_t)(pt > 4294967295.0 ? 4294967295.0 : pt) : 0u;
+    float* hp = hf.partials + (long)g * head_compact_floats(R, H, O);
+    float* p_dhid = hp;
+    float* p_hw2 = p_dhid + H;
+    float* p_hb2 = p_hw2 + (long)O * H;
+    float* p_loss = p_hb2 + O;
+
+    if (PAIRED) {
+        // ================= both branches in every phase =================================================
+        if (burst) {
+            stage_file(1);
+            burst_load_w(bw20, a.net.conv2[0].w_nbr, a.net.conv2[0].nbr_sk, a.net.conv2[0].nbr_sh, DRGNN_H1, DRGNN_H2);
+            burst_load_w(bw21, a.net.conv2[1].w_nbr, a.net.conv2[1].nbr_sk, a.net.conv2[1].nbr_sh, DRGNN_H1, DRGNN_H2);
+            step_wblock_load(wreg0, hf, 0);
+            step_wblock_load(wreg1, hf, 1);
+            stage_request(2);
+        }
+        step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t0, XLD, s.u1, HC1, dummy);
+        step_gemm_nn(d.N, 1, F16, s.xs, XLD, s.w1t1, XLD, s.u1b, HC1, dummy, nullptr, nullptr, (d.N + 15) >> 4);
+        FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; s.xpb[d.C * STEP_XPLD + e] = 0.0f; }
+        FOR_TID(i, 1) {
+#ifdef DRGNN_EMU
+            memcpy(&s.misc[STEP_M_BAD], &m_bad, 4);
+            memcpy(&s.misc[STEP_M_Y], &m_y, 4);
+#else
+            ((int*)s.misc)[STEP_M_BAD] = m_bad;
+            ((int*)s.misc)[STEP_M_Y] = m_y;
+#endif
+            s.misc[STEP_M_WY] = m_wy;
+            s.misc[STEP_M_DENOM] = m_denom;
+        }
+        BARRIER();
+        // (the x tile is dead from here on: Z1 of both branches takes its place)
+        net_aggregate<KIND, DRGNN_H1, true, 0, EIdx, true>(d.N, s.rp0, (const EIdx*)s.cx0, nullptr, nullptr, nullptr, s.u1, nullptr, s.z1);
+        net_aggregate<KIND, DRGNN_H1, true, 0, EIdx, true>(d.N, s.rp0, (const EIdx*)s.cx0, nullptr, nullptr, nullptr, s.u1b, nullptr, s.z1b);
+        if (burst) {
+            burst_store_wt(bw20, s.w2t0, STEP_XPLD);
+            burst_store_w(bw20, s.w2n0, W2NLD);
+            burst_store_wt(bw21, s.w2t1, STEP_XPLD);
+            burst_store_w(bw21, s.w2n1, W2NLD);
+            stage_file(2);
+        }
+        step_wblock_store(wreg0, hf, 0, s.wb);      // fc1's block of branch 0 (block 1 follows once block 0 has served)
+        BARRIER();
+        net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1, s.xp, nullptr, s.a00);
+        net_cluster_max<DRGNN_H1, STEP_XPLD, short>(d.C, s.mp0, s.mem0, s.z1b, s.xpb, nullptr, s.a01);
+        BARRIER();
+        step_gather_rows<STEP_XPLD, EIdx>(d.C, s.rp1, (const EIdx*)s.cx1, s.xp, s.sg0);
+        step_gather_rows<STEP_XPLD, EIdx>(d.C, s.rp1, (const EIdx*)s.cx1, s.xpb, s.sg1);
+        FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.sg0[d.C * STEP_XPLD + e] = 0.0f; s.sg1[d.C * STEP_XPLD + e] = 0.0f; }
+        FOR_TID(item, d.N * DRGNN_H1) { s.z1[item] = 0.0f; s.z1b[item] = 0.0f; }      // Z1 is consumed: becomes dZ1
+        BARRIER();
+        step_gemm_nn<true>(d.C, 2, DRGNN_H1, s.sg0, STEP_XPLD, s.w2t0, STEP_XPLD, s.z2, Z2LD, dummy);
+        step_gemm_nn<true>(d.C, 2, DRGNN_H1, s.sg1, STEP_XPLD, s.w2t1, STEP_XPLD, s.z2b, Z2LD, dummy, nullptr, nullptr, 2 * ((d.C + 15) >> 4));
+        BARRIER();
+        step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.a10, s.misc, s.xr, const_cast<float*>(hf.readout) + (long)g * R);
+        step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, s.z2b, s.a11, s.misc, s.xr + DRGNN_H2,
+                                const_cast<float*>(hf.readout) + (long)g * R + DRGNN_H2);
+        BARRIER();
+        // ---- head: fc1's half with block 0, block 1 into LDS, the other half + hid, loss, d readout of both branches
+        if (hf.train && g == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+        FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; s.z2b[item] = 0.0f; }      // Z2 -> dZ2 (+ zero K padding)
+        if (XF != 0 || hf.H == WREF) step1_fc1_half<WREF>(H, s.wb, s.xr, s.hp0);
+        else step1_fc1_half<0>(H, s.wb, s.xr, s.hp0);
+        BARRIER();
+        step_wblock_store(wreg1, hf, 1, s.wb);
+        BARRIER();
+        if (XF != 0 || hf.H == WREF) step1_fc1_finish<WREF>(hf, g, s.wb, b1, s.xr + DRGNN_H2, s.hp0, s.hid, done, thresh, keep_scale);
+        else step1_fc1_finish<0>(hf, g, s.wb, b1, s.xr + DRGNN_H2, s.hp0, s.hid, done, thresh, keep_scale);
+        BARRIER();
+        step_head_loss<WREF, (XF != 0)>(hf, g, 0, s.hid, w2, b2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+        if (!hf.train) return;
+        BARRIER();
+        step_head_dreadout<WREF, (XF != 0)>(hf, s.wb, s.dhid, s.a11, d.C1, s.z2b, Z2LD);      // block 1 is in LDS
+        BARRIER();
+        step_wblock_store(wreg0, hf, 0, s.wb);
+        BARRIER();
+        step_head_dreadout<WREF, (XF != 0)>(hf, s.wb, s.dhid, s.a10, d.C1, s.z2, Z2LD);
+        BARRIER();
+        // ---- backward body, both branches per phase ---------------------------------------------------
+        float* part0 = a.partials + ((long)g * 2 + 0) * a.n_partial;
+        float* part1 = a.partials + ((long)g * 2 + 1) * a.n_partial;
+        const long o_w2n = 2L * F * DRGNN_H1 + DRGNN_H1;
+        const int u1_units = (int)(step1_u1_words(capN) / 256);
+        const int KS2 = imin(DRGNN_NWAVES / 4, u1_units / 2);        // two products of 2 tiles each share the 16 waves
+        // dS = dZ2 W2^T (into the xp areas);  dW2 = S^T dZ2: partial tiles (in u1 / u1b) here, their sum behind the barrier
+        step_gemm_nn(d.C, 1, DRGNN_H2, s.z2, Z2LD, s.w2n0, W2NLD, s.xp, STEP_XPLD, dummy);
+        step_gemm_nn(d.C, 1, DRGNN_H2, s.z2b, Z2LD, s.w2n1, W2NLD, s.xpb, STEP_XPLD, dummy, nullptr, nullptr, (d.C + 15) >> 4);
+        step_gemm_tn(1, 2, d.C, s.sg0, STEP_XPLD, s.z2, Z2LD, KS2, s.u1, part0 + o_w2n, DRGNN_H2, DRGNN_H1, 1);
+        step_gemm_tn(1, 2, d.C, s.sg1, STEP_XPLD, s.z2b, Z2LD, KS2, s.u1b, part1 + o_w2n, DRGNN_H2, DRGNN_H1, 1, DRGNN_NWAVES / 2);
+        BARRIER();
+        step_gemm_tn(1, 2, d.C, s.sg0, STEP_XPLD, s.z2, Z2LD, KS2, s.u1, part0 + o_w2n, DRGNN_H2, DRGNN_H1, 2);
+        step_gemm_tn(1, 2, d.C, s.sg1, STEP_XPLD, s.z2b, Z2LD, KS2, s.u1b, part1 + o_w2n, DRGNN_H2, DRGNN_H1, 2);
+        step_gather_scatter<STEP_XPLD, EIdx>(d.C, s.cp1, (const EIdx*)s.rx1, s.xp, s.a00, s.z1);
+        step_gather_scatter<STEP_XPLD, EIdx>(d.C, s.cp1, (const EIdx*)s.rx1, s.xpb, s.a01, s.z1b);
+        BARRIER();
+        // (the partial tiles are summed: u1 / u1b take dU1; their K padding rows are zeroed in the same pass)
+        net_aggregate_bwd<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, s.cp0, (const EIdx*)s.rx0, nullptr, nullptr, nullptr, nullptr, s.z1, s.u1);
+        net_aggregate_bwd<KIND, DRGNN_H1, true, 0, EIdx>(d.N, s.rp0, s.cp0, (const EIdx*)s.rx0, nullptr, nullptr, nullptr, nullptr, s.z1b, s.u1b);
+        FOR_TID(e, (step_pad4(d.N) - d.N) * HC1) { s.u1[d.N * HC1 + e] = 0.0f; s.u1b[d.N * HC1 + e] = 0.0f; }
+        BARRIER();
+        {   // dW1 = X^T dU1, X read from global memory (its LDS tile made room for Z1); partial tiles in the dead Z1 area
+            const int mtiles = F16 >> 4;
+            const int z_units = (int)(step1_xs_words(capN, XLD, 1) / 256 / 2);      // per branch
+            int KS = imin(imax(DRGNN_NWAVES / (2 * mtiles), 1), z_units / mtiles);
+            if (KS < 1) KS = 1;
+            float* pt0 = s.xs;
+            float* pt1 = s.xs + (long)z_units * 256;
+            step_gemm_tn_bufa(mtiles, d.N, xg, F, d.N * F * 4, s.u1, HC1, KS, pt0, part0, DRGNN_H1, F, 1);
+            step_gemm_tn_bufa(mtiles, d.N, xg, F, d.N * F * 4, s.u1b, HC1, KS, pt1, part1, DRGNN_H1, F, 1, DRGNN_NWAVES / 2);
+            BARRIER();
+            step_gemm_tn_bufa(mtiles, d.N, xg, F, d.N * F * 4, s.u1, HC1, KS, pt0, part0, DRGNN_H1, F, 2);
+            step_gemm_tn_bufa(mtiles, d.N, xg, F, d.N * F * 4, s.u1b, HC1, KS, pt1, part1, DRGNN_H1, F, 2);
+        }
+        return;
+    }
+
     // ---- forward, branch 0 then branch 1 -----------------------------------------------------------
     for (int br = 0; br < 2; ++br) {
         if (br == 0 && burst) {
@@ -380,14 +519,6 @@ DEV void net_step_graph_both(const StepArgs& a, const GraphDims& d_in, int g, in
     }
 
     // ---- FC head + loss: no exchange, both readouts are here ---------------------------------------
-    const float keep_scale = (hf.p_drop > 0.0f) ? 1.0f / (1.0f - hf.p_drop) : 1.0f;
-    const double pt = (double)hf.p_drop * 4294967296.0;
-    const uint32_t thresh = (hf.p_drop > 0.0f) ? (uint32_t)(pt > 4294967295.0 ? 4294967295.0 : pt) : 0u;
-    float* hp = hf.partials + (long)g * head_compact_floats(R, H, O);
-    float* p_dhid = hp;
-    float* p_hw2 = p_dhid + H;
-    float* p_hb2 = p_hw2 + (long)O * H;
-    float* p_loss = p_hb2 + O;
     if (hf.train && g == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
     FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
     if (XF != 0 || hf.H == WREF) step1_fc1_finish<WREF>(hf, g, s.wb, b1, s.xr + DRGNN_H2, s.hp0, s.hid, done, thresh, keep_scale);

@@ -9,10 +9,16 @@
     template __global__ void k_step_co_topo<K, XF, true>(StepCoLaunch);
 #if DRGNN_TU_KIND == 3
 // the one-workgroup-per-graph GINet step (drgnn_step1.h)
-#define DRGNN_STEP1_INST(K, XF)                                             \
-    template __global__ void k_step1_co_topo<XF, false>(StepCoLaunch);      \
-    template __global__ void k_step1_co_topo<XF, true>(StepCoLaunch);
+#define DRGNN_STEP1_INST(K, XF)                                                    \
+    template __global__ void k_step1_co_topo<XF, false, false>(StepCoLaunch);      \
+    template __global__ void k_step1_co_topo<XF, true, false>(StepCoLaunch);
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP1_INST, 0)
+#elif DRGNN_TU_KIND == 4
+// ... its form with both branches in every phase (generic and 32-wide)
+template __global__ void k_step1_co_topo<0, false, true>(StepCoLaunch);
+template __global__ void k_step1_co_topo<0, true, true>(StepCoLaunch);
+template __global__ void k_step1_co_topo<32, false, true>(StepCoLaunch);
+template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
 #else
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
 #endif

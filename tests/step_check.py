@@ -104,20 +104,25 @@ class one_workgroup_layout(object):
     """``with one_workgroup_layout(api):`` every GINet fused-step launch inside runs both branches of a graph in ONE
     workgroup (drgnn_set_step_layout(1)), the layout the library takes by itself beyond the resident batch size."""
 
-    def __init__(self, api=None):
+    def __init__(self, api=None, paired=True):
+        """paired: both branches share every phase (the default form); False: branch after branch (the form graphs too
+        large for the paired LDS plan take)"""
         from deeprank_gnn_amd import _lib
         self.api = api or _lib.get()
+        self.paired = paired
 
     def __enter__(self):
+        self.api.set_step_layout(4 if self.paired else 3)
         self.api.set_step_layout(1)
         return self
 
     def __exit__(self, *exc):
         self.api.set_step_layout(0)
+        self.api.set_step_layout(4)
         return False
 
 
-def check_one_workgroup_layout(n_feat, task, device, api=None, seed=0):
+def check_one_workgroup_layout(n_feat, task, device, api=None, seed=0, paired=True):
     """GINet: the one-workgroup-per-graph step (both branches in sequence) against the two-workgroup step on the same
     ragged batch -- loss, predictions, every gradient, two Adam steps, inference."""
     from deeprank_gnn_amd import _lib
@@ -144,11 +149,11 @@ def check_one_workgroup_layout(n_feat, task, device, api=None, seed=0):
     assert ta._can_fuse(topo, n_feat)
     wgs, _ = api.net_step_plan(ta.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, ta.R, ta.H, ta.O, topo.n_graphs)
     assert wgs == 2                                  # a handful of graphs: resident, two workgroups per graph
-    with one_workgroup_layout(api):
+    with one_workgroup_layout(api, paired):
         assert api.net_step_plan(ta.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, ta.R, ta.H, ta.O,
                                  topo.n_graphs)[0] == 1
     for it in range(2):
-        with one_workgroup_layout(api):
+        with one_workgroup_layout(api, paired):
             pa = ta.predict(batch).cpu().numpy()
             la = ta.train_step(batch)
         pb = tb.predict(batch).cpu().numpy()

@@ -22,7 +22,8 @@ def test_fused_inference(Net, n_feat, task):
     check_fused_predict(Net, n_feat, task, "cpu", api=emu(), seed=7 + n_feat)
 
 
-@pytest.mark.parametrize("n_feat,task", [(32, "reg"), (5, "class"), (40, "reg")])
-def test_ginet_one_workgroup_layout_matches_two_workgroup_layout(n_feat, task):
+@pytest.mark.parametrize("paired", [True, False])
+@pytest.mark.parametrize("n_feat,task", [(32, "reg"), (5, "class"), (40, "reg"), (16, "reg")])
+def test_ginet_one_workgroup_layout_matches_two_workgroup_layout(n_feat, task, paired):
     from step_check import check_one_workgroup_layout
-    check_one_workgroup_layout(n_feat, task, "cpu", api=emu(), seed=3 + n_feat)
+    check_one_workgroup_layout(n_feat, task, "cpu", api=emu(), seed=3 + n_feat, paired=paired)

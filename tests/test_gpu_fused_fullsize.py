@@ -185,10 +185,11 @@ def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_s
     np.testing.assert_array_equal(pred_one, pred_two)      # forward arithmetic is the same code in both layouts
 
 
-@pytest.mark.parametrize("n_feat,task", [(32, "reg"), (5, "class"), (40, "reg")])
-def test_ginet_one_workgroup_layout_matches_two_workgroup_layout(n_feat, task):
+@pytest.mark.parametrize("paired", [True, False])
+@pytest.mark.parametrize("n_feat,task", [(32, "reg"), (5, "class"), (40, "reg"), (16, "reg")])
+def test_ginet_one_workgroup_layout_matches_two_workgroup_layout(n_feat, task, paired):
     from step_check import check_one_workgroup_layout
-    check_one_workgroup_layout(n_feat, task, "cuda:0", seed=3 + n_feat)
+    check_one_workgroup_layout(n_feat, task, "cuda:0", seed=3 + n_feat, paired=paired)
 
 
 @pytest.mark.parametrize("net_name,n_nodes,n_pairs", [("GINet", 272, 320), ("FoutNet", 264, 300)])
