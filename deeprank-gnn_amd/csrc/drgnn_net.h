@@ -511,6 +511,35 @@ DEV void net_aggregate(int n, const int* rp, const IdxT* col, const float* w, fl
         const int i = item / G, c = (item % G) * 4;
         const int lo = rp[i], hi = rp[i + 1];
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, asum = 0.f;
+        // sGAT (a coefficient per entry anyway): entries in batches of four independent (index -> row) chains, the last
+        // batch padded with repeats of the row's last entry under a zero coefficient (x + 0 * v = x: same sum, same order)
+        // instead of the 1 - 3 serial round trips of a remainder loop: -0.25 us per step.  GINet / FoutNet sum plain rows
+        // with packed adds; for them the padding's extra instructions cost more than the remainder loop (+0.25 us).
+        if (KIND == DRGNN_SGAT)
+        for (int k = lo; k < hi; k += 4) {
+            int kk[4];
+            float cf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kk[j] = (k + j < hi) ? k + j : hi - 1;
+                cf[j] = (k + j < hi) ? 1.0f : 0.0f;
+            }
+            if (KIND == DRGNN_SGAT) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { cf[j] *= w[kk[j]]; if (COEF) asum += cf[j]; }
+            }
+            const float* uj[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) uj[j] = u + col[kk[j]] * HC + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v0, v1, v2, v3;
+                NET_LD4(A16, uj[j], v0, v1, v2, v3);
+                a0 = fmaf(cf[j], v0, a0); a1 = fmaf(cf[j], v1, a1);
+                a2 = fmaf(cf[j], v2, a2); a3 = fmaf(cf[j], v3, a3);
+            }
+        }
+        else
 #pragma unroll 4
         for (int k = lo; k < hi; ++k) {
             const float* uj = u + col[k] * HC + c;
@@ -702,6 +731,29 @@ DEV void net_aggregate_bwd(int n, const int* deg_rp, const int* cp, const IdxT* 
     FOR_TID(item, n * G) {
         const int j = item / G, c = (item % G) * 4;
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        const int tlo = cp[j], thi = cp[j + 1];
+        if (KIND == DRGNN_SGAT)
+        for (int t = tlo; t < thi; t += 4) {      // batches of four independent chains, padded under a zero coefficient
+            int ii[4];
+            float cf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tt = (t + q < thi) ? t + q : thi - 1;
+                ii[q] = ridx[tt];
+                cf[q] = (t + q < thi) ? 1.0f : 0.0f;
+                if (KIND == DRGNN_SGAT) cf[q] *= w[tslot[tt]] * dv[ii[q]];
+                if (KIND == DRGNN_FOUT) cf[q] *= dv[ii[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float* di = dz + ii[q] * H + c;
+                float v0, v1, v2, v3;
+                NET_LD4(A16, di, v0, v1, v2, v3);
+                a0 = fmaf(cf[q], v0, a0); a1 = fmaf(cf[q], v1, a1);
+                a2 = fmaf(cf[q], v2, a2); a3 = fmaf(cf[q], v3, a3);
+            }
+        }
+        else
 #pragma unroll 4
         for (int t = cp[j]; t < cp[j + 1]; ++t) {
             const int i = ridx[t];

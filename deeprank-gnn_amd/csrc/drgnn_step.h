@@ -471,6 +471,24 @@ DEV void step_aggregate_bwd_ct(int n, const int* deg_rp, const int* cp, const Id
         const int j = item >> 2, c = (item & 3) * 4;
         const int lo = cp[j], hi = cp[j + 1];
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (KIND == DRGNN_SGAT)
+        for (int t = lo; t < hi; t += 4) {      // batches of four independent chains, padded under a zero coefficient
+            int ii[4];
+            float cf[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tt = (t + q < hi) ? t + q : hi - 1;
+                ii[q] = ridx[tt];
+                cf[q] = (t + q < hi) ? ct[tt] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v0, v1, v2, v3;
+                NET_LD4(true, dz + ii[q] * H + c, v0, v1, v2, v3);
+                a0 = fmaf(cf[q], v0, a0); a1 = fmaf(cf[q], v1, a1); a2 = fmaf(cf[q], v2, a2); a3 = fmaf(cf[q], v3, a3);
+            }
+        }
+        else
 #pragma unroll 4
         for (int t = lo; t < hi; ++t) {
             const float cf = ct[t];
