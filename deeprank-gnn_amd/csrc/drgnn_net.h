@@ -586,11 +586,19 @@ DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, 
         const int r = item / H, c = item % H;
         float best = DRGNN_NEG_INF;
         int arg = -1;
-#pragma unroll 4
-        for (int p = mp[r]; p < mp[r + 1]; ++p) {
-            const int m = mem[p];
-            const float v = z[m * (LDZ ? LDZ : H) + c];
-            if (v > best) { best = v; arg = m; }
+        // batches of four independent (member -> value) chains, a short last batch repeating the last member (which cannot
+        // win again under strict >): no serial remainder loop
+        const int plo = mp[r], phi = mp[r + 1];
+        for (int p = plo; p < phi; p += 4) {
+            int mm[4];
+            float vv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm[j] = mem[(p + j < phi) ? p + j : phi - 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vv[j] = z[mm[j] * (LDZ ? LDZ : H) + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (vv[j] > best) { best = vv[j]; arg = mm[j]; }
         }
         if (arg < 0) best = 0.0f;
         out[LDO ? r * LDO + c : item] = best;

@@ -765,12 +765,23 @@ DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z
         for (int k = kk; k < C1; k += 16) {
             float best = DRGNN_NEG_INF;
             int am = -1;
-#pragma unroll 4
-            for (int p = mp[k]; p < mp[k + 1]; ++p) {
-                const int m = mem[p];
-                if (SKIP0 && rp[m + 1] == rp[m]) continue;
-                const float v = z[m * LDZ + c];
-                if (v > best) { best = v; am = m; }
+            // members in batches of four independent (member -> value) chains; a short last batch repeats the cluster's last
+            // member, which cannot win again (strict >): same maximum, same first-maximum argmax -- without the 1 - 3 serial
+            // LDS round trips of a remainder loop (SYN's depth-1 clusters have 3 members: all remainder)
+            const int plo = mp[k], phi = mp[k + 1];
+            for (int p = plo; p < phi; p += 4) {
+                int mm[4];
+                float vv[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mm[j] = mem[(p + j < phi) ? p + j : phi - 1];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vv[j] = z[mm[j] * LDZ + c];
+                    if (SKIP0 && rp[mm[j] + 1] == rp[mm[j]]) vv[j] = DRGNN_NAN;      // (NaN never wins)
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (vv[j] > best) { best = vv[j]; am = mm[j]; }
             }
             if (am < 0) best = 0.0f;
             arg[k * DRGNN_H2 + c] = (short)((best > 0.0f) ? am : -1);
