@@ -6,16 +6,19 @@ import deeprank_gnn_amd.synthetic as synth
 from deeprank_gnn_amd.topology import Topology
 from deeprank_gnn_amd.trainer import FusedTrainer
 from deeprank_gnn_amd.ginet import GINet
+from deeprank_gnn_amd.sGAT import sGAT
+from deeprank_gnn_amd.foutnet import FoutNet
 from deeprank_gnn_amd import _lib
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "-"
+name = sys.argv[2] if len(sys.argv) > 2 else "GINet"
 dev = torch.device("cuda:0")
 batch = synth.make_batch(0, 64).to(dev)
 torch.manual_seed(0)
-net = GINet(32, 1, 1).to(dev)
+net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[name](32, 1, 1).to(dev)
 tr = FusedTrainer(net, lr=1e-3, seed=1)
-topo = Topology.from_batch(batch, need_weights=False)
-nxt = Topology.from_batch(batch, need_weights=False, build=False)
+topo = Topology.from_batch(batch, need_weights=(name == "sGAT"))
+nxt = Topology.from_batch(batch, need_weights=(name == "sGAT"), build=False)
 c = tr._fused_prepare(batch, topo)
 N = 20
 
@@ -58,5 +61,5 @@ t_step = timed(graph_of(on_current(lambda: tr._fused_launch_step(c, None))))
 t_co = timed(graph_of(on_current(lambda: tr._fused_launch_step(c, nxt))))
 t_upd = timed(graph_of(on_current(lambda: tr._fused_launch_update(c, True, lr=0.0))))
 t_red = timed(graph_of(on_current(lambda: tr._fused_launch_update(c, False))))
-print("graph %6s  step %.2f us   step+topo %.2f us   update %.2f us   update w/o Adam %.2f us"
-      % (tag, t_step, t_co, t_upd, t_red), flush=True)
+print("graph %6s %s  step %.2f us   step+topo %.2f us   update %.2f us   update w/o Adam %.2f us"
+      % (tag, name, t_step, t_co, t_upd, t_red), flush=True)
