@@ -1036,6 +1036,43 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
     // others would just repeat the same ~150 instructions on the same SIMDs
     if ((int)(threadIdx.x & ~63u) >= H && threadIdx.x >= 64) return;
     const int lane = threadIdx.x & 63;
+    if (HC != 0 && HC <= 128 && OC == 1 && hf.task == DRGNN_TASK_REG) {
+        // The reference heads (one output, MSE): this phase is ONE dependent chain in one or two waves while fourteen wait,
+        // so every LDS operand is requested up front (one round trip instead of six), the wave sum runs once (the loss of a
+        // single output needs none) and no value travels through a lane read: out and d loss / d out are wave-uniform.
+        // Same operations in the same order as the general path below: bit-identical results.
+        constexpr int NH = (HC > 0) ? (HC + 63) / 64 : 1;      // (HC == 0 never takes this path)
+        float hv[NH], wv[NH];
+#pragma unroll
+        for (int j = 0; j < NH; ++j) { hv[j] = hid[lane + 64 * j]; wv[j] = w2[lane + 64 * j]; }
+        const float bias = b2[0], yv = misc[STEP_M_Y];
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NH; ++j) acc = fmaf(hv[j], wv[j], acc);
+        float out = lanes64_sum(acc) + bias;
+        if (sig) out = drgnn_sigmoid(out);
+        const float inv = 1.0f / (float)(hf.B * O);
+        const float d = out - yv;
+        const float dout = 2.0f * d * inv * (sig ? out * (1.0f - out) : 1.0f);
+        const int wv_id = (int)(threadIdx.x >> 6);
+        float hme = hv[0], wme = wv[0];
+#pragma unroll
+        for (int j = 1; j < NH; ++j) { if (wv_id == j) { hme = hv[j]; wme = wv[j]; } }
+        const int h = (int)threadIdx.x;                       // < HC: the waves past H have returned
+        const float dh = (hme != 0.0f) ? fmaf(dout, wme, 0.0f) * keep_scale : 0.0f;     // relu' and dropout mask
+        dhid[h] = dh;
+        if (br == 0) {
+            p_hw2[h] = dout * hme;
+            p_dhid[h] = dh;
+            if (threadIdx.x == 0) {
+                hf.pred[(long)g] = out;
+                p_hb2[0] = dout;
+                p_loss[0] = (d * d * inv);
+                p_loss[1] = 1.0f;
+            }
+        }
+        return;
+    }
     float my_out = 0.0f;
     for (int o = 0; o < O; ++o) {
         float acc = 0.0f;
