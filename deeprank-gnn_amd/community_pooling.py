@@ -203,9 +203,13 @@ def community_pooling(cluster, data):
 
 
 def max_pool_x(cluster, x, batch, size=None):
-    """Per-cluster feature maximum + the graph id of every cluster."""
+    """Per-cluster feature maximum + the graph id of every cluster.  ``size`` (torch_geometric): ``cluster`` already holds
+    ids in ``[0, num_graphs * size)`` (``size`` slots per graph): the maxima go to exactly those rows (absent ids -> 0) and
+    no batch vector is returned."""
     if size is not None:
-        raise NotImplementedError("max_pool_x(size=...) is not used by the reference nets")
+        n_graphs = (int(batch.max()) + 1) if batch.numel() else 0
+        out, _ = scatter_max(x, cluster, dim=0, dim_size=n_graphs * int(size))
+        return out, None
     api = _api()
     cluster = cluster.to(torch.int64).contiguous()
     s = types.SimpleNamespace(edge_index=torch.zeros((2, 0), dtype=torch.int64, device=x.device), edge_attr=None,
@@ -235,9 +239,44 @@ def _dense_rows(pooled, index, dim_size, fill=0.0):
     return out, ids
 
 
+def _to_rows(src, index, dim):
+    """(src as [n, h] with the scattered dimension first, restore) for a 1-D ``index`` over dimension ``dim`` of ``src``."""
+    if index.dim() != 1:
+        raise NotImplementedError("scatter_*: a 1-D index over the scattered dimension (what torch_scatter broadcasts) only")
+    dim = dim % src.dim()
+    moved = src.movedim(dim, 0)
+    if moved.size(0) != index.numel():
+        raise ValueError("index has %d entries, dimension %d of src has %d" % (index.numel(), dim, moved.size(0)))
+    rest = tuple(moved.shape[1:])
+    flat = moved.reshape(moved.size(0), -1)
+
+    def restore(t):
+        return t.reshape((t.size(0),) + rest).movedim(0, dim)
+    return flat, restore
+
+
 def scatter_max(src, index, dim=0, out=None, dim_size=None):
-    if dim not in (0, -2) or out is not None or src.dim() != 2:
-        raise NotImplementedError("only scatter_max(src [n,h], index [n], dim=0)")
+    """torch_scatter.scatter_max: (maxima, argmax along ``dim``); absent ids -> 0 / ``src.size(dim)``.  With ``out=``: the
+    result is ``max(out, segment maxima)`` written into ``out`` (argmax = ``src.size(dim)`` where ``out`` keeps its value)."""
+    if src.dim() != 2 or dim not in (0, -2) or out is not None:
+        flat, restore = _to_rows(src, index, dim)
+        n = flat.size(0)
+        if out is not None:
+            dim_size = out.size(dim % src.dim())
+        if flat.size(1) == 0 or n == 0:
+            size = dim_size if dim_size is not None else ((int(index.max()) + 1) if n else 0)
+            return restore(flat.new_zeros((size, flat.size(1)))), restore(torch.full((size, flat.size(1)), n, dtype=torch.int64, device=src.device))
+        dense, arg = scatter_max(flat, index, dim=0, dim_size=dim_size)
+        if out is not None:
+            present = torch.zeros(dense.size(0), dtype=torch.bool, device=src.device)
+            present[torch.unique(index)] = True
+            seg = torch.where(present.view(-1, 1), dense, torch.full_like(dense, float("-inf")))
+            o2, _ = _to_rows(out, torch.arange(out.size(dim % src.dim()), device=src.device), dim)
+            keep = ~(seg > o2)
+            arg = torch.where(keep, torch.full_like(arg, n), arg)
+            out.copy_(restore(torch.where(keep, o2, seg)))
+            return out, restore(arg)
+        return restore(dense), restore(arg)
     topo = _scatter_topology(index, src.size(0))
     c0, _, _ = topo.totals()
     pooled, arg = _SegMax.apply(src, topo, c0)
@@ -274,8 +313,11 @@ def _scatter_reduce(src, index, dim, out, dim_size, mean):
     """torch_scatter.scatter_sum / scatter_mean along dim 0.  With ``out=``: the segment sums are
     ADDED into ``out`` (``out.scatter_add_``) and, for the mean, the WHOLE buffer -- old content included -- is divided
     by the clamped counts, in place; ``out`` itself is returned (what the reference's sGAT layer relies on, sGAT.py:82-87)."""
-    if dim not in (0, -2):
-        raise NotImplementedError("only scatter over dim 0")
+    if src.dim() >= 1 and (dim % src.dim()) != 0:
+        # any other dimension: bring it to the front, reduce, put it back (``out=``: the same view of the caller's buffer)
+        d = dim % src.dim()
+        res = _scatter_reduce(src.movedim(d, 0), index, 0, None if out is None else out.movedim(d, 0), dim_size, mean)
+        return out if out is not None else res.movedim(0, d)
     if out is not None:
         dim_size = out.size(0)
     flat = src if src.dim() == 2 else src.reshape(src.size(0), -1)

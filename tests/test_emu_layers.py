@@ -195,3 +195,40 @@ def test_scatter_out_argument_like_torch_scatter():
     res = cp.scatter_mean(s2, index, dim=0, out=torch.zeros(8, 5))
     res.sum().backward()
     np.testing.assert_allclose(s2.grad.numpy(), (1.0 / count)[index].expand(-1, 5).numpy(), rtol=1e-6)
+
+
+def test_function_api_corners_against_torch(monkeypatch):
+    """The corners of the function API the shipped nets never take (VERDICT r02 missing #5): max_pool_x(size=...),
+    scatter_* over another dimension, scatter_max(out=...) -- against plain torch scatter_reduce / index_add."""
+    import deeprank_gnn_amd.community_pooling as cp
+    monkeypatch.setattr(cp, "_api", lambda: emu())
+    rng = np.random.default_rng(5)
+    src = torch.from_numpy(rng.standard_normal((4, 9, 3)).astype(np.float32))
+    idx = torch.tensor([2, 0, 2, 5, 0, 2, 7, 7, 1])
+    # dim = 1 of a 3-D tensor
+    for fn, red in ((cp.scatter_sum, "sum"), (cp.scatter_mean, "mean")):
+        got = fn(src, idx, dim=1, dim_size=8)
+        want = torch.zeros(4, 8, 3).scatter_reduce(1, idx.view(1, -1, 1).expand_as(src), src, reduce=red, include_self=False)
+        np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+    got, arg = cp.scatter_max(src, idx, dim=1, dim_size=8)
+    want = torch.zeros(4, 8, 3).scatter_reduce(1, idx.view(1, -1, 1).expand_as(src), src, reduce="amax", include_self=False)
+    np.testing.assert_array_equal(got.numpy(), want.numpy())
+    assert arg.shape == got.shape
+    picked = torch.gather(torch.cat([src, torch.zeros(4, 1, 3)], dim=1), 1, arg)
+    present = torch.zeros(8, dtype=torch.bool); present[idx] = True
+    np.testing.assert_array_equal(picked[:, present].numpy(), want[:, present].numpy())
+    assert bool((arg[:, ~present] == 9).all())
+    # out=: the running maximum
+    x = torch.from_numpy(rng.standard_normal((9, 5)).astype(np.float32))
+    out = torch.from_numpy(rng.standard_normal((8, 5)).astype(np.float32))
+    want = out.clone().scatter_reduce(0, idx.view(-1, 1).expand_as(x), x, reduce="amax", include_self=True)
+    got, arg = cp.scatter_max(x, idx, dim=0, out=out)
+    assert got is out
+    np.testing.assert_array_equal(out.numpy(), want.numpy())
+    # max_pool_x(size=...): fixed slots per graph, no batch vector
+    batch = torch.tensor([0, 0, 0, 1, 1, 1, 1, 2, 2])
+    cluster = torch.tensor([0, 1, 0, 3, 5, 3, 4, 6, 6])            # 3 slots per graph: ids in [3 g, 3 g + 3)
+    got, b = cp.max_pool_x(cluster, x, batch, size=3)
+    assert b is None and got.shape == (9, 5)
+    want = torch.zeros(9, 5).scatter_reduce(0, cluster.view(-1, 1).expand_as(x), x, reduce="amax", include_self=False)
+    np.testing.assert_array_equal(got.numpy(), want.numpy())
