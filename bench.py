@@ -44,7 +44,7 @@ BYTES_TOPO = {"GINet": 4804 + 1800 + 5808 + 16 * 1000, "FoutNet": 4804 + 1800 + 
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
 # the K-step block is repeated until the timed region is this long: several SMI polling periods, so that an outside
 # observer (the driver's gpu_busy sampler) sees the GPU busy DURING the measurement
-MIN_TIMED_SECONDS = 6.0
+MIN_TIMED_SECONDS = 6.5          # (sized from one untimed block, which runs a little slower than the timed ones: >= 6 s result)
 
 
 def source_hash():
@@ -482,21 +482,28 @@ def main():
         t = torch.tensor([repeats], device=dev, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         repeats = int(t.item())
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(repeats + 1)]
+    # HIP events only every `stride` blocks (>= 200 steps apart): an event between every two 20-step replays costs the device a
+    # marker per replay (measured: 20.2 vs 19.8 us per step under --steps 20), and the median block time does not need them
+    stride = max(1, 200 // max(args.steps, 1))
+    n_ev = (repeats + stride - 1) // stride
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_ev + 1)]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ev[0].record()
+    spans = []
     for r in range(repeats):
         run_steps(args.steps)
-        ev[r + 1].record()
+        if (r + 1) % stride == 0 or r + 1 == repeats:
+            ev[len(spans) + 1].record()
+            spans.append((r + 1) - sum(spans))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    blocks_ms = sorted(ev[r].elapsed_time(ev[r + 1]) for r in range(repeats))
+    blocks_ms = sorted(ev[i].elapsed_time(ev[i + 1]) / spans[i] for i in range(len(spans)))
     block_med_ms = blocks_ms[len(blocks_ms) // 2]
     if world > 1:
         t = torch.tensor([elapsed, block_med_ms], device=dev, dtype=torch.float64)
