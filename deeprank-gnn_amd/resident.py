@@ -227,11 +227,28 @@ class ResidentGraphSet(object):
         if ids.size and (ids.min() < 0 or ids.max() >= len(self)):
             raise IndexError("graph number out of range [0, %d)" % len(self))
         host = torch.from_numpy(ids.astype(np.int32))
-        if self.device.type == "cuda":
-            # pinned + non-blocking: a pageable copy would make the host wait for everything already enqueued on the stream
-            # (the previous epoch), i.e. serialise the epochs the trainer pipelines
-            return host.pin_memory().to(self.device, non_blocking=True)
-        return host.to(self.device)
+        if self.device.type != "cuda":
+            return host.to(self.device)
+        # Pinned + non-blocking: a pageable copy would make the host wait for everything already enqueued on the stream (the
+        # previous epoch), i.e. serialise the epochs the trainer pipelines.  The staging buffers are a small ring owned by the
+        # set (an event per slot says when its last copy has left): allocating pinned memory per epoch costs tens of
+        # milliseconds each time and stalls the launches behind it.
+        ring = self.__dict__.setdefault("_id_staging", {"slots": [], "next": 0})
+        n = int(host.numel())
+        if not ring["slots"] or ring["slots"][0][0].numel() < n:
+            cap = max(n, 1024)
+            ring["slots"] = [[torch.empty(cap, dtype=torch.int32).pin_memory(), None] for _ in range(4)]
+            ring["next"] = 0
+        slot = ring["slots"][ring["next"]]
+        ring["next"] = (ring["next"] + 1) % len(ring["slots"])
+        if slot[1] is not None:
+            slot[1].synchronize()                  # (four uploads ago: long done)
+        slot[0][:n].copy_(host)
+        out = torch.empty(n, dtype=torch.int32, device=self.device)
+        out.copy_(slot[0][:n], non_blocking=True)
+        slot[1] = torch.cuda.Event()
+        slot[1].record()
+        return out
 
     def batch_offsets(self, ids_dev, batch_size):
         """Slot offset tables of every mini-batch of the visiting order ``ids_dev`` (``upload_ids``), one launch:
