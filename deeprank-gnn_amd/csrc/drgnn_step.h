@@ -162,6 +162,9 @@ HD int64_t step_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, i
     return w + 16;
 }
 
+#ifndef DRGNN_EMU
+typedef unsigned int drgnn_u2 __attribute__((ext_vector_type(2)));
+#endif
 #ifdef DRGNN_EMU
 #define STEP_PIN(x) ((void)0)
 #else
@@ -617,11 +620,11 @@ DEV void step_pooled_gather_bwd(int n, const int* deg_rp, const int* cp, const I
             if (KIND == DRGNN_FOUT && deg_rp[j + 1] == deg_rp[j]) sv = 0.0f;
             const drgnn_f4 dt = *(const drgnn_f4*)(dts + j * LDT + DRGNN_H1 + c);
             const float acc[4] = {fmaf(sv, dt[0], a0), fmaf(sv, dt[1], a1), fmaf(sv, dt[2], a2), fmaf(sv, dt[3], a3)};
+            const drgnn_u2 packed = *(const drgnn_u2*)(arg + j * DRGNN_H1 + c);      // (one 64-bit read: see step_gather_scatter)
+            const int m4[4] = {(short)(packed[0] & 0xffffu), (short)(packed[0] >> 16), (short)(packed[1] & 0xffffu), (short)(packed[1] >> 16)};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = arg[j * DRGNN_H1 + c + q];
-                if (m >= 0) dz[m * DRGNN_H1 + c + q] = acc[q];
-            }
+            for (int q = 0; q < 4; ++q)
+                if (m4[q] >= 0) dz[m4[q] * DRGNN_H1 + c + q] = acc[q];
         }
     }
 #endif
@@ -665,11 +668,13 @@ DEV void step_gather_scatter(int n, const int* cp, const IdxT* ridx, const float
         a0 += dpp_take<0x124>(a0); a1 += dpp_take<0x124>(a1); a2 += dpp_take<0x124>(a2); a3 += dpp_take<0x124>(a3);
         if (sl == 0 && j < n) {
             const float acc[4] = {a0, a1, a2, a3};
+            // the four argmax entries of this lane in ONE 64-bit read (8-byte aligned: c is a multiple of 4): four 16-bit reads
+            // made four dependent LDS round trips in front of four stores
+            const drgnn_u2 packed = *(const drgnn_u2*)(arg + j * DRGNN_H1 + c);
+            const int m4[4] = {(short)(packed[0] & 0xffffu), (short)(packed[0] >> 16), (short)(packed[1] & 0xffffu), (short)(packed[1] >> 16)};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int m = arg[j * DRGNN_H1 + c + q];
-                if (m >= 0) dz[m * DRGNN_H1 + c + q] = acc[q];
-            }
+            for (int q = 0; q < 4; ++q)
+                if (m4[q] >= 0) dz[m4[q] * DRGNN_H1 + c + q] = acc[q];
         }
     }
 #endif
