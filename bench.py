@@ -544,7 +544,7 @@ def main():
                                     "reads it in place, no builder workgroups" if cached else
                                     "rebuilt every step; the build of step t+1 shares step t's backward launch "
                                     "(double-buffered)" if pipeline else "rebuilt every step, own launch"),
-                       "final_loss": final_loss},
+                       "final_loss": final_loss, "host_pool_threads": torch.get_num_threads()},
         }
         if split:
             if native and oneshot is not None:
@@ -844,7 +844,8 @@ def cpu_baseline(net_name, batch_cpu, seconds):
     line with the vectorised FoutLayer (`value_vectorised`: the reference's per-node Python loop, foutnet.py:69-73, is
     what `value` times -- the vectorised form shows what the same arithmetic costs without it)."""
     from oracle import cpu_ref
-    host = os.cpu_count() or 1
+    from deeprank_gnn_amd import hostcpu
+    host = hostcpu.granted_cpus()                     # affinity mask and cgroup quota: threads beyond it are throttled, not run
 
     def make_step(**fw):
         params = {k: v.clone().requires_grad_(True) for k, v in cpu_ref.init_params(net_name, N_FEAT, 1, 1).items()}

@@ -16,7 +16,7 @@ import time
 import numpy as np
 import torch
 
-from . import _lib
+from . import _lib, hostcpu
 from .dataset import GraphDataSet
 from .resident import ResidentGraphSet
 from .topology import Topology
@@ -83,6 +83,7 @@ class NeuralNet(object):
                  shuffle=True, outdir='./', cluster_nodes='mcl', transform_sigmoid=False, device=None,
                  _api=None):
         self._api = _api
+        hostcpu.fit_torch_threads()
         self.device = torch.device(device if device is not None else ('cuda' if torch.cuda.is_available() else 'cpu'))
         if self.device.type != 'cuda' and _api is None:
             raise _lib.DrgnnError("deeprank_gnn_amd.NeuralNet needs an MI355X: there is no CPU path")

@@ -20,7 +20,7 @@ Everything is enqueued on torch's current stream and is hipGraph-capturable.
 import torch
 import torch.distributed as dist
 
-from . import _lib
+from . import _lib, hostcpu
 from .functional import H1, H2, _describe, _fill_grads, _split
 from .topology import Topology
 
@@ -45,6 +45,7 @@ class FusedTrainer(object):
 
     def __init__(self, net, lr=0.01, task="reg", class_weights=None, betas=(0.9, 0.999), eps=1e-8,
                  weight_decay=0.0, seed=None, api=None, transform_sigmoid=False):
+        hostcpu.fit_torch_threads()                           # the launching thread must not lose its CPU quota to idle pool threads
         self.net = net
         self.transform_sigmoid = bool(transform_sigmoid)      # regression: sigmoid on the output before the loss
         self.api = api or _lib.get()
