@@ -496,10 +496,18 @@ DEV void step_kernarg_touch() {
                  DRGNN_KA_LINE(0x280) "s_waitcnt lgkmcnt(0)"
                  : "=&s"(t) : "s"(__builtin_amdgcn_kernarg_segment_ptr()) : "memory");
 }
+// The step kernels read their arguments through the kernel-argument segment pointer, not through the by-value parameter:
+// with run-time indices into its arrays (dims) the compiler may keep a PRIVATE COPY of the whole 2.4 KB argument block in
+// scratch memory (2.5 KB of scratch per lane, a ~10x slower kernel).  Which instances are hit changes with unrelated edits
+// and with -O3 / -Os: in round 3 the generic-width sGAT kernels were (profiles/r03_kernarg_scratch.txt).
+DEV const StepCoLaunch& step_kernarg() {
+    return *reinterpret_cast<const StepCoLaunch*>((const char*)__builtin_amdgcn_kernarg_segment_ptr());
+}
 template <int KIND, int XF, bool GATHER>
-__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C) {
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s[];
     PHASE_BEGIN();
+    const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
     if ((int)blockIdx.x < C.n_net) step_block<KIND, XF, GATHER>(C.step, blockIdx.x, smem_s, 0);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);
@@ -507,9 +515,10 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C)
 // GINet, one workgroup per graph (both branches), + the builder's workgroups of the next mini-batch
 // PAIRED: both branches share every phase (drgnn_step1.h); instantiated for the generic and the 32-wide kernels
 template <int XF, bool GATHER, bool PAIRED>
-__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C) {
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s1[];
     PHASE_BEGIN();
+    const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
     if ((int)blockIdx.x < C.n_net) step_block_both<XF, GATHER, PAIRED>(C.step, blockIdx.x, smem_s1);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s1);
