@@ -601,7 +601,7 @@ DEV void net_cluster_max(int nc, const int* mp, const int* mem, const float* z, 
                 if (vv[j] > best) { best = vv[j]; arg = mm[j]; }
         }
         if (arg < 0) best = 0.0f;
-        out[LDO ? r * LDO + c : item] = best;
+        out[LDO ? ROW24(r, LDO) + c : item] = best;
         if (g_out) g_out[item] = best;
         g_arg[item] = (ArgT)((best > 0.0f) ? arg : -1);
     }

@@ -86,6 +86,13 @@ struct WG { int block; int nthreads; };
 typedef hipStream_t drgnn_stream_t;
 #endif
 
+// row * stride for LDS addresses (rows < 2^23): a full-rate 24-bit multiply-add instead of the quarter-rate 32-bit one the
+// compiler picks for strides that are not powers of two (the product sits between an index read and the read it addresses)
+#ifdef DRGNN_EMU
+#define ROW24(r, ld) ((r) * (ld))
+#else
+#define ROW24(r, ld) __mul24((int)(r), (int)(ld))
+#endif
 #define DRGNN_WAVE 64
 #define DRGNN_BSCALE (1024 / DRGNN_NTHREADS)   // burst capacities are quoted per 1024 lanes
 #define DRGNN_BCAP 1024

@@ -454,7 +454,7 @@ DEV void step_gather_rows(int n, const int* rp, const IdxT* col, const float* sr
         if (i < n) {
             const int lo = rp[i], hi = rp[i + 1];
             for (int k = lo + sl; k < hi; k += 4) {
-                const drgnn_f4 v = *(const drgnn_f4*)(src + col[k] * LD + c);
+                const drgnn_f4 v = *(const drgnn_f4*)(src + ROW24(col[k], LD) + c);
                 a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
             }
         }
@@ -551,7 +551,7 @@ DEV void step_pooled_gather(int n, const int* rp, const IdxT* col, const float* 
         if (i < n) {
             lo = rp[i]; hi = rp[i + 1];
             for (int k = lo + sl; k < hi; k += 4) {
-                const drgnn_f4 v = *(const drgnn_f4*)(xp + col[k] * LDX + c);
+                const drgnn_f4 v = *(const drgnn_f4*)(xp + ROW24(col[k], LDX) + c);
                 float cf = 1.0f;
                 if (KIND == DRGNN_SGAT) { cf = w[k]; asum += cf; }
                 a0 = fmaf(cf, v[0], a0); a1 = fmaf(cf, v[1], a1); a2 = fmaf(cf, v[2], a2); a3 = fmaf(cf, v[3], a3);
@@ -659,7 +659,7 @@ DEV void step_gather_scatter(int n, const int* cp, const IdxT* ridx, const float
         if (j < n) {
             const int lo = cp[j], hi = cp[j + 1];
             for (int t = lo + sl; t < hi; t += 4) {
-                const drgnn_f4 v = *(const drgnn_f4*)(src + ridx[t] * LD + c);
+                const drgnn_f4 v = *(const drgnn_f4*)(src + ROW24(ridx[t], LD) + c);
                 a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
             }
         }
@@ -781,7 +781,7 @@ DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z
                 for (int j = 0; j < 4; ++j) mm[j] = mem[(p + j < phi) ? p + j : phi - 1];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    vv[j] = z[mm[j] * LDZ + c];
+                    vv[j] = z[ROW24(mm[j], LDZ) + c];
                     if (SKIP0 && rp[mm[j] + 1] == rp[mm[j]]) vv[j] = DRGNN_NAN;      // (NaN never wins)
                 }
 #pragma unroll
@@ -1160,7 +1160,7 @@ DEV void step_head_dreadout_t(const HeadFused& hf, const float* wb, const float*
         const float v = lanes32_sum(acc) * inv;
         for (int k = q; k < C1; k += 32) {
             const int r = a1[k * DRGNN_H2 + c];
-            if (r >= 0) z2[r * ldz + c] = v;
+            if (r >= 0) z2[ROW24(r, ldz) + c] = v;
         }
     }
 #endif

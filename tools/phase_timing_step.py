@@ -15,12 +15,13 @@ from deeprank_gnn_amd.topology import Topology                # noqa: E402
 from deeprank_gnn_amd.trainer import FusedTrainer             # noqa: E402
 
 kind = sys.argv[1] if len(sys.argv) > 1 else "GINet"
-api = _lib.Api(os.path.join(os.path.dirname(_lib.LIB_PATH), "libdrgnn_prof.so"))
+api = _lib.Api(os.path.join(os.path.dirname(_lib.LIB_PATH), os.environ.get("PROF_LIB", "libdrgnn_prof.so")))
+NB = int(os.environ.get("PROF_BATCH", "64"))      # PROF_LIB=libdrgnn_prof300.so PROF_BATCH=512: a workgroup of the SECOND round (warm I-cache)
 api.lib.drgnn_debug_set_phase_buffer.argtypes = [ctypes.c_void_p]
 dev = torch.device("cuda:0")
 buf = torch.zeros(4100, dtype=torch.int64, device=dev)
 assert api.lib.drgnn_debug_set_phase_buffer(buf.data_ptr()) == 0
-batch = synth.make_batch(0, 64).to(dev)
+batch = synth.make_batch(0, NB).to(dev)
 torch.manual_seed(0)
 net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[kind](32, 1, 1).to(dev)
 tr = FusedTrainer(net, lr=1e-3, task="reg", api=api)
