@@ -1125,7 +1125,7 @@ static int update_impl(const drgnn_net_desc* net, const float* conv_partials, in
     if (u.step2) u.step2[0] = u.step2[1];
     (void)stream_; (void)head_blocks;
 #else
-    hipLaunchKernelGGL(k_update, dim3((unsigned)(u.conv_blocks + head_blocks)), dim3(256), 0, (hipStream_t)stream_, u);
+    hipLaunchKernelGGL(k_update, dim3((unsigned)(u.conv_blocks + head_blocks)), dim3(DRGNN_UPDATE_THREADS), 0, (hipStream_t)stream_, u);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

@@ -260,7 +260,18 @@ DEV double adam_ipow(double b, int t) {
 // adam_item split in two so that a caller can have the element's state and the step-dependent scalars in flight
 // while it is still computing the gradient (same arithmetic, same order -> same bits)
 struct AdamPre { float p, m, v, step_size, sqrt_bc2; bool ok; };
-DEV AdamPre adam_prefetch(const AdamArgs& a, int64_t i) {
+// the step-dependent scalars: ~35 dependent double-precision operations behind the load of the step index
+DEV void adam_bias_scalars(const AdamArgs& a, float& step_size, float& sqrt_bc2) {
+    // bias corrections in double, as the Python-side scalars of torch's reference path; beta^t by
+    // repeated squaring (t is an integer): a libm pow() in double costs more than the rest of the launch
+    const int t = a.step[0];
+    const double bc1 = 1.0 - adam_ipow((double)a.beta1, t);
+    const double bc2 = 1.0 - adam_ipow((double)a.beta2, t);
+    step_size = (float)((double)a.lr / bc1);
+    sqrt_bc2 = (float)sqrt(bc2);
+}
+// the element's state only (k_update: another wave forms the scalars meanwhile and hands them over through LDS)
+DEV AdamPre adam_prefetch_state(const AdamArgs& a, int64_t i) {
     AdamPre r;
     r.ok = i >= 0 && i < a.n;
     r.p = r.m = r.v = 0.0f; r.step_size = 0.0f; r.sqrt_bc2 = 1.0f;
@@ -268,13 +279,11 @@ DEV AdamPre adam_prefetch(const AdamArgs& a, int64_t i) {
     r.p = a.param[i];
     r.m = a.exp_avg[i];
     r.v = a.exp_avg_sq[i];
-    // bias corrections in double, as the Python-side scalars of torch's reference path; beta^t by
-    // repeated squaring (t is an integer): a libm pow() in double costs more than the rest of the launch
-    const int t = a.step[0];
-    const double bc1 = 1.0 - adam_ipow((double)a.beta1, t);
-    const double bc2 = 1.0 - adam_ipow((double)a.beta2, t);
-    r.step_size = (float)((double)a.lr / bc1);
-    r.sqrt_bc2 = (float)sqrt(bc2);
+    return r;
+}
+DEV AdamPre adam_prefetch(const AdamArgs& a, int64_t i) {
+    AdamPre r = adam_prefetch_state(a, i);
+    if (r.ok) adam_bias_scalars(a, r.step_size, r.sqrt_bc2);
     return r;
 }
 DEV void adam_apply(const AdamArgs& a, int64_t i, float g, const AdamPre& r) {

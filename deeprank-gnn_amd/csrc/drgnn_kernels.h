@@ -576,9 +576,22 @@ __global__ void __launch_bounds__(256) k_head_reduce(HeadReduceArgs a) {
 }
 // 64 gradient elements per workgroup; the 4 waves sum interleaved quarters of the partial
 // slabs, the quarter sums are combined in fixed order, then Adam is applied to that element
-__global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
+// A FIFTH wave (q == 4) forms Adam's bias corrections meanwhile -- a chain of ~35 dependent double-precision operations
+// behind the load of the step index, which used to sit in front of wave 0's slab loads -- and hands them over through LDS.
+#define DRGNN_UPDATE_THREADS 320
+__global__ void __launch_bounds__(DRGNN_UPDATE_THREADS) k_update(UpdateArgs u) {
     __shared__ float quarter[4][64];
+    __shared__ float bias_scalars[2];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    if (q == 4) {
+        if (u.apply_adam && lane == 0) {
+            float step_size, sqrt_bc2;
+            adam_bias_scalars(u.ad, step_size, sqrt_bc2);
+            bias_scalars[0] = step_size; bias_scalars[1] = sqrt_bc2;
+        }
+        __syncthreads();
+        return;
+    }
     if ((int)blockIdx.x < u.conv_blocks) {
         const ReduceArgs& a = u.r;
         const int64_t item = (int64_t)blockIdx.x * 64 + lane;
@@ -589,9 +602,10 @@ __global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
         float* d = (q == 0 && live) ? reduce_dst(a, br, p) : nullptr;
         const bool upd = d != nullptr && u.apply_adam;
         const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
-        const AdamPre pre = adam_prefetch(u.ad, idx);
+        AdamPre pre = adam_prefetch_state(u.ad, idx);
         quarter[q][lane] = live ? reduce_sum(a, br, p, q, 4) : 0.0f;
         __syncthreads();
+        pre.step_size = bias_scalars[0]; pre.sqrt_bc2 = bias_scalars[1];
         if (d) {
             const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
             *d = g;                                   // keep p.grad inspectable
@@ -604,9 +618,10 @@ __global__ void __launch_bounds__(256) k_update(UpdateArgs u) {
         float* d = (q == 0 && live && item < n_grad) ? u.h.grad + item : nullptr;
         const bool upd = d != nullptr && u.apply_adam;
         const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
-        const AdamPre pre = adam_prefetch(u.ad, idx);
+        AdamPre pre = adam_prefetch_state(u.ad, idx);
         quarter[q][lane] = live ? update_head_sum(u, item, q, 4) : 0.0f;
         __syncthreads();
+        pre.step_size = bias_scalars[0]; pre.sqrt_bc2 = bias_scalars[1];
         if (q == 0 && live) {
             const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
             if (d) {
