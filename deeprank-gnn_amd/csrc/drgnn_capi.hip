@@ -1111,7 +1111,9 @@ static int update_impl(const drgnn_net_desc* net, const float* conv_partials, in
     u.ad.lr = lr; u.ad.beta1 = beta1; u.ad.beta2 = beta2; u.ad.eps = eps; u.ad.weight_decay = 0.0f;
     u.apply_adam = apply_adam ? 1 : 0;
     const int64_t pitems = (int64_t)net->n_branch * r.n_partial;
-    u.conv_blocks = (int)((pitems + 63) / 64);
+    u.blocks_per_branch = (r.n_partial + 63) / 64;
+    u.conv_blocks = net->n_branch * u.blocks_per_branch;
+    (void)pitems;
     const int head_items = (readout ? H * R : 0) + u.h.P - 1;
     const int head_blocks = (head_items + 63) / 64;
 #ifdef DRGNN_EMU

@@ -379,6 +379,7 @@ struct UpdateArgs {
     HeadReduceArgs h;       // h.grad = flat gradient block of the FC head; h.step unused here
     AdamArgs ad;            // flat buffers; ad.grad = base of the flat gradient
     int conv_blocks;        // blocks [0, conv_blocks) reduce conv partials, the rest the head's
+    int blocks_per_branch;  // conv blocks of one branch (a block never straddles branches: the branch is block-uniform)
     int apply_adam;         // 0: only produce the flat gradient (data parallel: all-reduce comes next)
     // fused-step mode: head slabs are compact ([dhid H][dW2][db2][loss][weight], u.h.P floats each) and
     // dW_fc1[h][r] = sum_g dhid[g][h] * readout[g][r] is formed here
@@ -594,11 +595,17 @@ __global__ void __launch_bounds__(DRGNN_UPDATE_THREADS) k_update(UpdateArgs u) {
     }
     if ((int)blockIdx.x < u.conv_blocks) {
         const ReduceArgs& a = u.r;
-        const int64_t item = (int64_t)blockIdx.x * 64 + lane;
-        const bool live = item < (int64_t)a.n_branch * a.n_partial && reduce_live(a, (int)(item % a.n_partial));
-        const int br = live ? (int)(item / a.n_partial) : 0, p = live ? (int)(item % a.n_partial) : 0;
-        // wave 0 owns the element's update: its parameter / moment loads and the bias corrections are issued
-        // BEFORE the slab loads, so that Adam starts from registers once the quarter sums are in
+        // The branch of a block is UNIFORM (blocks_per_branch blocks per branch): the per-branch descriptors (gradient
+        // pointers, strides) are then scalar loads from the argument block.  With a per-lane branch (item / n_partial) the
+        // compiler fetched them with vector loads from argument memory, one dependent round trip after the other in
+        // reduce_dst's chain of cases -- microseconds in front of wave 0's slab loads.
+        int br = 0, blk = (int)blockIdx.x;
+        while (blk >= u.blocks_per_branch && br + 1 < a.n_branch) { blk -= u.blocks_per_branch; ++br; }
+        const int p_raw = blk * 64 + lane;
+        const bool live = p_raw < a.n_partial && reduce_live(a, p_raw);
+        const int p = live ? p_raw : 0;
+        // wave 0 owns the element's update: its parameter / moment loads are issued BEFORE the slab loads, so that Adam
+        // starts from registers once the quarter sums are in
         float* d = (q == 0 && live) ? reduce_dst(a, br, p) : nullptr;
         const bool upd = d != nullptr && u.apply_adam;
         const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
