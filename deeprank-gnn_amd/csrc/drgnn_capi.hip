@@ -905,8 +905,8 @@ int drgnn_net_reduce_grads(const drgnn_net_desc* net, const float* partials, int
     for (int64_t i = 0; grad_x && i < n_nodes * net->n_feat; ++i) reduce_grad_x(r, i);
     (void)stream_; (void)items;
 #else
-    const int64_t pitems = (int64_t)net->n_branch * r.n_partial;
-    hipLaunchKernelGGL(k_reduce, dim3((unsigned)((pitems + 63) / 64)), dim3(256), 0, (hipStream_t)stream_, r, items);
+    const int reduce_blocks = net->n_branch * ((r.n_partial + 63) / 64);      // (blocks do not straddle branches)
+    hipLaunchKernelGGL(k_reduce, dim3((unsigned)reduce_blocks), dim3(256), 0, (hipStream_t)stream_, r, items);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;

@@ -458,9 +458,13 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_finalize(ScanArgs a) {
 __global__ void __launch_bounds__(256) k_reduce(ReduceArgs a, int64_t n_items) {
     __shared__ float quarter[4][64];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int64_t item = (int64_t)blockIdx.x * 64 + lane;
-    const bool live = item < (int64_t)a.n_branch * a.n_partial && reduce_live(a, (int)(item % a.n_partial));
-    const int br = live ? (int)(item / a.n_partial) : 0, p = live ? (int)(item % a.n_partial) : 0;
+    // (the branch of a block is uniform, as in k_update: ceil(n_partial / 64) blocks per branch)
+    const int bpb = (a.n_partial + 63) / 64;
+    int br = 0, blk = (int)blockIdx.x;
+    while (blk >= bpb && br + 1 < a.n_branch) { blk -= bpb; ++br; }
+    const int p_raw = blk * 64 + lane;
+    const bool live = p_raw < a.n_partial && reduce_live(a, p_raw);
+    const int p = live ? p_raw : 0;
     quarter[q][lane] = live ? reduce_sum(a, br, p, q, 4) : 0.0f;
     __syncthreads();
     if (q == 0) {
