@@ -44,7 +44,7 @@ BYTES_TOPO = {"GINet": 4804 + 1800 + 5808 + 16 * 1000, "FoutNet": 4804 + 1800 + 
 HBM_PEAK_GBS = 8000.0                               # MI355X_MICROARCH.md: 8 TB/s spec
 # the K-step block is repeated until the timed region is this long: several SMI polling periods, so that an outside
 # observer (the driver's gpu_busy sampler) sees the GPU busy DURING the measurement
-MIN_TIMED_SECONDS = 6.5          # (sized from one untimed block, which runs a little slower than the timed ones: >= 6 s result)
+MIN_TIMED_SECONDS = 7.0          # (sized from one untimed block, which runs a little slower than the timed ones: >= 6 s result)
 
 
 def source_hash():
