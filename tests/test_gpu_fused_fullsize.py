@@ -262,3 +262,64 @@ def test_fused_step_random_shapes_match_oracle(net_name):
                    _grads_of(net), ref_loss, ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()}, sweep_stats)
     assert ran >= 6
     assert_arbiter_rate(sweep_stats, "%s sweep" % net_name)
+
+
+@pytest.mark.parametrize("net_name", NETS)
+def test_benchmark_schedule_is_reproducible_and_graph_replays_equal_eager_launches(net_name):
+    """Size-independent property of the benchmarked schedule (pipelined topology build, dropout ON for GINet): 240 steps run
+    (a) launch by launch, (b) launch by launch again, (c) as hipGraph replays of 20 recorded steps give the same parameters,
+    Adam moments, loss and step counter BIT FOR BIT -- fixed-order reductions everywhere, the readout exchange and the
+    double-buffered topology workspaces have no timing-dependent outcome; no fault bit is raised."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.foutnet import FoutNet
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.sGAT import sGAT
+    from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    dev = _dev()
+    Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[net_name]
+    batch = synth.make_batch(0, 64).to(dev)
+    need_w = net_name == "sGAT"
+    STEPS, CHUNK = 240, 20
+
+    def fresh():
+        torch.manual_seed(11)
+        tr = FusedTrainer(Net(32, 1, 1).to(dev), lr=1e-3, task="reg", seed=77)      # (GINet keeps its dropout of 0.4)
+        topos = [Topology.from_batch(batch, need_weights=need_w), Topology.from_batch(batch, need_weights=need_w)]
+        return tr, topos
+
+    def step(tr, topos, k):
+        tr.train_step(batch, topo=topos[k & 1], next_topo=topos[1 - (k & 1)])
+
+    def state(tr):
+        torch.cuda.synchronize()
+        assert tr.faults() == 0
+        return [t.detach().cpu().numpy().copy() for t in (tr.flat_p, tr.exp_avg, tr.exp_avg_sq, tr.loss, tr.step2[:2])]
+
+    runs = []
+    for _ in range(2):                                   # (a), (b): eager
+        tr, topos = fresh()
+        for k in range(STEPS):
+            step(tr, topos, k)
+        runs.append(state(tr))
+    tr, topos = fresh()                                  # (c): recorded
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for k in range(CHUNK):                           # the first chunk eagerly (warm-up of the capture)
+            step(tr, topos, k)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for k in range(CHUNK):
+            step(tr, topos, k)
+    # (the capture itself does not execute: 20 eager steps so far, 220 to go = 11 replays)
+    for _ in range((STEPS - CHUNK) // CHUNK):
+        g.replay()
+    runs.append(state(tr))
+    assert int(runs[0][4][0]) == STEPS
+    for other in runs[1:]:
+        for a, b, name in zip(runs[0], other, ("parameters", "exp_avg", "exp_avg_sq", "loss", "counters")):
+            np.testing.assert_array_equal(a, b, err_msg=name)
+    assert np.isfinite(runs[0][0]).all() and np.isfinite(runs[0][3]).all()
