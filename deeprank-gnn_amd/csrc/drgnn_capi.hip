@@ -707,6 +707,9 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         if (rc) return rc;
         co_ok = T.capN > 0 && T.user_nptr != nullptr && !(T.args.cluster1 != nullptr && T.args.c1_ptr == nullptr) &&
                 T.args.n_graphs > 0 && blocks > 0;
+        // the builder inside a GINet / FoutNet step launch is compiled without the edge-weight path: a request that wants
+        // weights (another kind's topology) gets a launch of its own
+        if (kind != DRGNN_SGAT && T.args.edge_attr != nullptr && T.tv.w0 != nullptr) co_ok = false;
     }
     bool one_wg = false;       // GINet: both branches of a graph in one workgroup (drgnn_step1.h)
     // The co-launched builder runs two workgroups per graph (shorter chains) or one (fewer workgroups, each ~1.6x longer):

@@ -69,7 +69,7 @@ struct TopoLaunch {
 
 // LDS is a compile-time property so that every scratch access is a ds_* instruction (a
 // run-time choice between LDS and global would make them all flat_* accesses)
-template <bool LDS>
+template <bool LDS, int WEIGHTS = -1>
 DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
     TopoScratch s;
     // Two workgroups per graph: within full groups of 8 graphs both land on XCD (graph % 8) -- workgroups are dealt
@@ -110,7 +110,7 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
         s = topo_carve(L.gscratch + topo_gscratch_base(n0, e0, g), N, E, N + E + 1, N + E + 2);
     }
     if (!L.level1_only) {
-        topo_graph(L.tv, L.args, g, n0, n1, e0, e1, s, role);
+        topo_graph<WEIGHTS>(L.tv, L.args, g, n0, n1, e0, e1, s, role);
     } else {
         // offset of this graph's ids inside cluster1 = number of depth-0 clusters before it
         FOR_TID(i, 1) { s.part[0] = 0; }
@@ -515,7 +515,7 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C_
     const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
     if ((int)blockIdx.x < C.n_net) step_block<KIND, XF, GATHER>(C.step, blockIdx.x, smem_s, 0);
-    else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);
+    else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);      // (train_step_impl keeps weighted requests of the other kinds out of the launch)
 }
 // GINet, one workgroup per graph (both branches), + the builder's workgroups of the next mini-batch
 // PAIRED: both branches share every phase (drgnn_step1.h); instantiated for the generic and the 32-wide kernels
@@ -526,7 +526,7 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C
     const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
     if ((int)blockIdx.x < C.n_net) step_block_both<XF, GATHER, PAIRED>(C.step, blockIdx.x, smem_s1);
-    else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s1);
+    else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s1);
 }
 #ifdef DRGNN_KERNELS_MAIN
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }

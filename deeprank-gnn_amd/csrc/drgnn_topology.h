@@ -164,6 +164,18 @@ DEV void topo_flag(const TopoView& tv, int bit, int graph) { ATOMIC_OR(&tv.p[DRG
 //   slot_bucket[p] bucket of sorted position p
 // Items inside a bucket keep ascending item order (rank sort on the unique item id).
 // tmp: n ints.  cur: nb+1 ints.
+
+// number of entries of a[lo, hi) below `me`, four entries per trip in flight: for LONG buckets (the 20 - 60 edges that leave one
+// cluster) -- for the 5 - 10 entries of a node's edge list the plain loop is faster (measured: +0.9 us on the unweighted builder)
+DEV int rank_below(const int* a, int lo, int hi, int me) {
+    int rank = 0, q = lo;
+    for (; q + 3 < hi; q += 4) {
+        const int a0 = a[q], a1 = a[q + 1], a2 = a[q + 2], a3 = a[q + 3];
+        rank += ((a0 < me) ? 1 : 0) + ((a1 < me) ? 1 : 0) + ((a2 < me) ? 1 : 0) + ((a3 < me) ? 1 : 0);
+    }
+    for (; q < hi; ++q) rank += (a[q] < me) ? 1 : 0;
+    return rank;
+}
 // ---------------------------------------------------------------------------------
 template <class F>
 DEV void wg_bucket_sort(int n, int nb, F bucket_of, int* ptr, int* cur, int* tmp,
@@ -591,36 +603,41 @@ DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool
         FOR_TID(e, E) { ATOMIC_ADD(&s.pp[s.cl[s.er[e]]], 1); }
         BARRIER();
         wg_exscan(s.pp, C + 1, s.part);
+        // (target cluster, edge id) packed into ONE word -- clusters < 2^15 (max_nodes <= 32767), edge ids < 2^16
+        // (max_edges <= 65535): the rank loop below then reads and compares one word per candidate.  A self loop of the
+        // pooled graph (dropped) carries the cluster field DROPPED, which sorts behind every real target and stays unique.
+        constexpr int DROPPED = 0x7FFF;
         FOR_TID(e, E) {                                   // one work item per edge
             const int r = s.cl[s.er[e]];
             const int cc = s.cl[s.ec[e]];
             const int j = s.pp[r] + ATOMIC_ADD(&s.cur[r], 1);
-            s.t1[j] = (cc == r) ? INT_MAX : cc;           // self loop of the pooled graph: dropped
-            s.t2[j] = e;
+            s.t1[j] = (((cc == r) ? DROPPED : cc) << 16) | e;
             s.t3[j] = r;
         }
         BARRIER();
-        // rank sort of every pooled row's candidates by (target cluster, edge id)
+        // rank sort of every pooled row's candidates by (target cluster, edge id).  A bucket holds the 20 - 60 edges that leave
+        // one cluster: four candidates per trip in flight (a trip was two dependent LDS round trips per candidate: the slowest
+        // lane's bucket set the pace of the whole phase, 4 us of the builder's 17 for the SYN graphs)
         FOR_TID(j, E) {
             const int r = s.t3[j];
-            const int key = s.t1[j], id = s.t2[j];
+            const int mine = s.t1[j];
             const int lo = s.pp[r], hi = s.pp[r + 1];
-            int rank = 0;
-            for (int q = lo; q < hi; ++q) {
-                const int kq = s.t1[q];
-                rank += (kq < key || (kq == key && s.t2[q] < id)) ? 1 : 0;
-            }
-            s.t4[lo + rank] = key;
-            s.t5[lo + rank] = id;
+            const int rank = rank_below(s.t1, lo, hi, mine);
+            const int key = mine >> 16;
+            s.t4[lo + rank] = (key == DROPPED) ? INT_MAX : key;
+            s.t5[lo + rank] = mine & 0xFFFF;
         }
         BARRIER();
         // heads of runs of equal target = the coalesced pooled edges, already (row, col) sorted
         // (t3[j] = pooled row of sorted position j: positions of a bucket stay inside the bucket)
+        // + the weight of every sorted position, fetched once by independent reads (the run heads below add runs of them)
+        float* const wv = reinterpret_cast<float*>(s.t2);
         FOR_TID(j, E + 1) {
             int head = 0;
             if (j < E) {
                 const int key = s.t4[j];
                 head = (key != INT_MAX && (j == s.pp[s.t3[j]] || s.t4[j - 1] != key)) ? 1 : 0;
+                if (has_w) wv[j] = s.w0[s.t5[j]];
             }
             s.t1[j] = head;
         }
@@ -635,9 +652,21 @@ DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool
                 s.seg[slot] = r;               // row of pooled CSR slot
                 g_col1[slot] = key;
                 if (has_w) {
+                    // the run's weights, summed in sorted (= edge id) order; four positions per trip in flight
                     const int hi = s.pp[r + 1];
                     float w = 0.0f;
-                    for (int q = j; q < hi && s.t4[q] == key; ++q) w += s.w0[s.t5[q]];
+                    int q = j;
+                    for (; q + 3 < hi; q += 4) {
+                        const int k0 = s.t4[q], k1 = s.t4[q + 1], k2 = s.t4[q + 2], k3 = s.t4[q + 3];
+                        const float v0 = wv[q], v1 = wv[q + 1], v2 = wv[q + 2], v3 = wv[q + 3];
+                        const bool e0 = k0 == key, e1 = e0 && k1 == key, e2 = e1 && k2 == key, e3 = e2 && k3 == key;
+                        if (e0) w += v0;
+                        if (e1) w += v1;
+                        if (e2) w += v2;
+                        if (e3) w += v3;
+                        if (!e3) { q = hi; break; }
+                    }
+                    for (; q < hi && s.t4[q] == key; ++q) w += wv[q];
                     g_w1[slot] = w;
                 }
             }
@@ -683,6 +712,10 @@ DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, in
     topo_graph_level1(tv, a, g, n0, C, src.cl1, c1_len, s, sidx, true);
 }
 
+// WEIGHTS: -1 = decided at run time (edge_attr and a weight workspace given); 0 = never (the builder co-launched with a
+// GINet / FoutNet step: the weighted pooled-edge path -- bucket ranking, run sums -- is not even compiled into those kernels,
+// whose register allocation and code layout it otherwise shapes: +0.5 us on the unweighted builder, +0.2 us on the GINet step)
+template <int WEIGHTS = -1>
 DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1, int e0, int e1,
                     TopoScratch& s, int role = TOPO_ROLE_ALL) {
     const int N = n1 - n0;
@@ -694,7 +727,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     }
     PHASE_MARK();
     const TopoSrc src = topo_src(a, g, n0, e0);
-    const bool has_w = (a.edge_attr != nullptr) && (tv.w0 != nullptr);
+    const bool has_w = (WEIGHTS != 0) && (a.edge_attr != nullptr) && (tv.w0 != nullptr);
     const bool structure = (role != TOPO_ROLE_EDGES);      // CSR0 / CSC0, member lists, node-feature gather
     const bool pool = (role != TOPO_ROLE_MEMBERS);         // pooled graph
     if (structure) topo_gather_rows(a, src, g, n0, N);
