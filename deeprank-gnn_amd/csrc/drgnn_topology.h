@@ -606,12 +606,19 @@ DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool
         // (target cluster, edge id) packed into ONE word -- clusters < 2^15 (max_nodes <= 32767), edge ids < 2^16
         // (max_edges <= 65535): the rank loop below then reads and compares one word per candidate.  A self loop of the
         // pooled graph (dropped) carries the cluster field DROPPED, which sorts behind every real target and stays unique.
+        // (graphs beyond those bounds -- only the global-scratch builder takes them -- keep two words per candidate)
         constexpr int DROPPED = 0x7FFF;
+        const bool packed = (E <= 0x10000) && (C <= DROPPED);
         FOR_TID(e, E) {                                   // one work item per edge
             const int r = s.cl[s.er[e]];
             const int cc = s.cl[s.ec[e]];
             const int j = s.pp[r] + ATOMIC_ADD(&s.cur[r], 1);
-            s.t1[j] = (((cc == r) ? DROPPED : cc) << 16) | e;
+            if (packed) {
+                s.t1[j] = (((cc == r) ? DROPPED : cc) << 16) | e;
+            } else {
+                s.t1[j] = (cc == r) ? INT_MAX : cc;       // self loop of the pooled graph: dropped
+                s.t2[j] = e;
+            }
             s.t3[j] = r;
         }
         BARRIER();
@@ -622,15 +629,27 @@ DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool
             const int r = s.t3[j];
             const int mine = s.t1[j];
             const int lo = s.pp[r], hi = s.pp[r + 1];
-            const int rank = rank_below(s.t1, lo, hi, mine);
-            const int key = mine >> 16;
-            s.t4[lo + rank] = (key == DROPPED) ? INT_MAX : key;
-            s.t5[lo + rank] = mine & 0xFFFF;
+            if (packed) {
+                const int rank = rank_below(s.t1, lo, hi, mine);
+                const int key = mine >> 16;
+                s.t4[lo + rank] = (key == DROPPED) ? INT_MAX : key;
+                s.t5[lo + rank] = mine & 0xFFFF;
+            } else {
+                const int id = s.t2[j];
+                int rank = 0;
+                for (int q = lo; q < hi; ++q) {
+                    const int kq = s.t1[q];
+                    rank += (kq < mine || (kq == mine && s.t2[q] < id)) ? 1 : 0;
+                }
+                s.t4[lo + rank] = mine;
+                s.t5[lo + rank] = id;
+            }
         }
         BARRIER();
         // heads of runs of equal target = the coalesced pooled edges, already (row, col) sorted
         // (t3[j] = pooled row of sorted position j: positions of a bucket stay inside the bucket)
-        // + the weight of every sorted position, fetched once by independent reads (the run heads below add runs of them)
+        // + the weight of every sorted position, fetched once by independent reads (the run heads below add runs of them;
+        // t2 is free again: the ranking above was its last reader)
         float* const wv = reinterpret_cast<float*>(s.t2);
         FOR_TID(j, E + 1) {
             int head = 0;

@@ -113,3 +113,17 @@ def test_finalize_scans():
     np.testing.assert_array_equal(topo.array("E1PTR").numpy()[:9], np.concatenate([[0], np.cumsum(ne1)]))
     assert topo.array("CPTR0").numpy()[8] == 244 and topo.array("E1PTR").numpy()[8] == 994
     assert topo.array("CPTR1").numpy()[8] == 83
+
+
+def test_weighted_pooling_of_a_graph_with_more_than_65536_edges():
+    """The weighted pooled-edge path ranks (target cluster, edge id) keys packed into one word while edge ids fit 16 bits; a
+    graph beyond that (only the global-scratch builder takes one) keeps two words per candidate -- same pooled graph and
+    summed weights as the oracle either way."""
+    rng = np.random.default_rng(5)
+    big = random_graph(rng, 400, 35000, 12, 3, sym=True)          # 70 000 directed edges, duplicates included
+    small = random_graph(rng, 30, 60, 6, 2, sym=True)
+    batch = Batch.from_data_list([small, big])
+    assert int(batch.edge_index.size(1)) > 70000
+    topo = Topology.from_batch(batch, api=emu(), need_weights=True)
+    assert topo.status()[0] == 0
+    check_against_oracle(topo, batch, weights=True)
