@@ -110,9 +110,10 @@ def parse():
     ap.add_argument("--graphs-per-gpu", type=int, default=GRAPHS_PER_GPU,
                     help="mini-batch per GPU; %d is BASELINE.json's configuration, other values are for the "
                          "batch-size sweep in DESIGN.md" % GRAPHS_PER_GPU)
-    ap.add_argument("--step-layout", choices=["auto", "one", "seq", "two"], default="auto",
+    ap.add_argument("--step-layout", choices=["auto", "one", "seq", "two", "noclass"], default="auto",
                     help="GINet: workgroups per graph of the fused step -- auto (default): two while every workgroup of the "
-                         "launch is resident, else one (both branches in sequence); one / two: forced, for A/B runs")
+                         "launch is resident, else one (both branches in sequence); one / two: forced, for A/B runs; noclass: "
+                         "auto without the capacity-class kernels (compile-time LDS layout for batches inside 200 / 1024 / 52)")
     ap.add_argument("--dp-selftest", action="store_true",
                     help="data-parallel self-test BEFORE timing (dropout off for the whole run): 3 steps eagerly and 3 through "
                          "the recorded schedule on every rank, each checked for (a) the all-reduced gradient == rank 0's "
@@ -182,7 +183,9 @@ def main():
     from deeprank_gnn_amd.foutnet import FoutNet
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[args.net]
 
-    if args.step_layout != "auto":
+    if args.step_layout == "noclass":                  # (A/B: the run-time LDS layout also where the capacity class applies)
+        _lib.get().set_step_layout(6)
+    elif args.step_layout != "auto":
         if args.step_layout == "seq":                  # one workgroup per graph, branch after branch (not the paired form)
             _lib.get().set_step_layout(3)
         _lib.get().set_step_layout({"one": 1, "seq": 1, "two": 2}[args.step_layout])

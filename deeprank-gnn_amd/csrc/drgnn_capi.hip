@@ -542,6 +542,7 @@ int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O) { return head_
 // 0: by residency; 1: always one workgroup per graph (tests, A/B runs); 2: always two (MEASUREMENT ONLY: beyond the
 // resident size this is the pre-round-3 schedule, whose exchange leans on in-order dispatch; bounded spin + fault bit)
 static int g_step_layout_mode = 0;
+static int g_step_class_mode = 0;          // 0: capacity-class kernels where a batch fits the class (default); 1: never (A/B runs, tests)
 static int device_cu_count() {
 #ifdef DRGNN_EMU
     return 256;
@@ -577,6 +578,7 @@ static int64_t step1_lds_bytes(int F, int capN, int capE, int capC, int H, int O
 }
 int32_t drgnn_set_step_layout(int32_t mode) {
     if (mode == 3 || mode == 4) { g_step1_paired_mode = (mode == 4); return 0; }   // (A/B: 3 = branch after branch, 4 = paired)
+    if (mode == 5 || mode == 6) { g_step_class_mode = (mode == 6) ? 1 : 0; return 0; }   // (5 = capacity-class kernels allowed, 6 = never)
     if (mode < 0 || mode > 2) return DRGNN_E_ARG;
     g_step_layout_mode = mode;
     return 0;
@@ -735,6 +737,21 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     }
     if (co_ok && T.roles == 2 && (net->n_branch != 2 || one_wg) && blocks + 2 * bn > cus && blocks + bn <= cus)
         T.roles = 1;            // one round of workgroups instead of two
+    // Capacity class (drgnn_step.h: STEP_CLS_*): a batch whose maxima lie inside the class is stepped by the kernels whose
+    // LDS layout is a compile-time constant (32-wide kernels, not the one-workgroup GINet layout)
+    bool cls = false;
+#ifndef DRGNN_EMU
+    if (!one_wg && g_step_class_mode == 0 && L.capN <= STEP_CLS_N && L.capE <= STEP_CLS_E && L.capC <= STEP_CLS_C &&
+        step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32 &&
+        step_variant(kind, x, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O) == 32) {
+        const int64_t lds_cls = step_lds_bytes(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->R, hd->H, hd->O);
+        if (lds_cls <= DRGNN_LDS_LIMIT) {
+            cls = true;
+            L.capN = STEP_CLS_N; L.capE = STEP_CLS_E; L.capC = STEP_CLS_C;
+            lds = lds_cls; L.words = lds / 4;
+        }
+    }
+#endif
     if (blocks > 0) {
 #ifdef DRGNN_EMU
         // workgroups run one after the other here: two passes (up to the readout exchange, then the
@@ -776,21 +793,22 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         int64_t both = lds;
         int extra = 0;
         if (co_ok) { C.topo = T; both = lds > tlds ? lds : tlds; extra = T.args.n_graphs * T.roles; }
-#define DRGNN_STEP_LAUNCH_G(K, XF, G)                                                                       \
+#define DRGNN_STEP_LAUNCH_G(K, XF, G) DRGNN_STEP_LAUNCH_GC(K, XF, G, 0)
+#define DRGNN_STEP_LAUNCH_GC(K, XF, G, CL)                                                                  \
     do {                                                                                                    \
         /* once per kernel instance and device: the whole 160 KiB (the call costs host time on every launch otherwise) */\
         static int lds_set_on = -1;                                                                                   \
         if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
-            if (hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G>,                                            \
+            if (hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G, CL>,                                            \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
                 lds_set_on = step_current_device();                                                                   \
             } else {      /* (profiling builds carry a static LDS word: ask for what this launch needs) */            \
                 (void)hipGetLastError();                                                                              \
-                HIP_TRY(hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G>,                                    \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G, CL>,                                    \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_step_co_topo<K, XF, G>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
+        hipLaunchKernelGGL((k_step_co_topo<K, XF, G, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
                            (size_t)both, stream, C);                                                        \
     } while (0)
 #define DRGNN_STEP_LAUNCH(K, XF)                                                                            \
@@ -801,7 +819,10 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     do {                                                                                                    \
         switch (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O)) {                          \
             case 16: DRGNN_STEP_LAUNCH(K, 16); break;                                                       \
-            case 32: DRGNN_STEP_LAUNCH(K, 32); break;                                                       \
+            case 32:                                                                                        \
+                if (cls) { if (gather_ids) DRGNN_STEP_LAUNCH_GC(K, 32, true, 1); else DRGNN_STEP_LAUNCH_GC(K, 32, false, 1); } \
+                else DRGNN_STEP_LAUNCH(K, 32);                                                              \
+                break;                                                                                      \
             case 48: DRGNN_STEP_LAUNCH(K, 48); break;                                                       \
             case 64: DRGNN_STEP_LAUNCH(K, 64); break;                                                       \
             default: DRGNN_STEP_LAUNCH(K, 0); break;                                                        \
@@ -848,6 +869,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
 #undef DRGNN_STEP_WIDTHS
 #undef DRGNN_STEP_LAUNCH
 #undef DRGNN_STEP_LAUNCH_G
+#undef DRGNN_STEP_LAUNCH_GC
 #undef DRGNN_STEP1_LAUNCH
 #undef DRGNN_STEP1_LAUNCH_G
 #undef DRGNN_STEP1_LAUNCH_GP

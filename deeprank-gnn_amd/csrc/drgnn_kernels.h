@@ -294,7 +294,7 @@ struct StepCoLaunch {
 
 // GATHER: cached-topology mode (slot g of the launch = graph gather_ids[g] of a whole-set workspace).  A template
 // parameter, not a run-time branch: the per-mini-batch kernels keep exactly the code (and register allocation) they had
-template <int KIND, int XF, bool GATHER = false>
+template <int KIND, int XF, bool GATHER = false, int CLS = 0>
 DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
     constexpr int nb = (KIND == DRGNN_GINET) ? 2 : 1;
     // Workgroups go to the 8 XCDs round robin (block id mod 8) and each XCD has its own L2.  The two
@@ -317,7 +317,7 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
         // count beyond capC can only come from malformed input, which the builder has flagged: such graphs poison
         // their outputs through the status words like any other bad graph, and the loads below stay inside LDS because
         // their bounds are clamped to the capacities)
-        net_step_graph<KIND, XF, GATHER>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, part, true, cnt_c, cnt_e1, cnt_c1);
+        net_step_graph<KIND, XF, GATHER, CLS>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, part, true, cnt_c, cnt_e1, cnt_c1);
         return;
     }
     const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;      // cached mode: graph number in the set
@@ -340,7 +340,7 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
         }
         return;
     }
-    net_step_graph<KIND, XF, GATHER>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, part);
+    net_step_graph<KIND, XF, GATHER, CLS>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, part);
 }
 
 // GINet, one workgroup per graph, both branches one after the other (drgnn_step1.h): the launch layout whenever the
@@ -508,13 +508,13 @@ DEV void step_kernarg_touch() {
 DEV const StepCoLaunch& step_kernarg() {
     return *reinterpret_cast<const StepCoLaunch*>((const char*)__builtin_amdgcn_kernarg_segment_ptr());
 }
-template <int KIND, int XF, bool GATHER>
+template <int KIND, int XF, bool GATHER, int CLS = 0>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step_block<KIND, XF, GATHER>(C.step, blockIdx.x, smem_s, 0);
+    if ((int)blockIdx.x < C.n_net) step_block<KIND, XF, GATHER, CLS>(C.step, blockIdx.x, smem_s, 0);
     else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);      // (train_step_impl keeps weighted requests of the other kinds out of the launch)
 }
 // GINet, one workgroup per graph (both branches), + the builder's workgroups of the next mini-batch
@@ -673,6 +673,14 @@ DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_GINET)
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_SGAT)
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_FOUT)
 #undef DRGNN_STEP_EXTERN
+// the capacity-class layout (net_step_graph: CLS = 1), 32-wide kernels only
+#define DRGNN_STEP_CLS_EXTERN(K)                                                      \
+    extern template __global__ void k_step_co_topo<K, 32, false, 1>(StepCoLaunch);    \
+    extern template __global__ void k_step_co_topo<K, 32, true, 1>(StepCoLaunch);
+DRGNN_STEP_CLS_EXTERN(DRGNN_GINET)
+DRGNN_STEP_CLS_EXTERN(DRGNN_SGAT)
+DRGNN_STEP_CLS_EXTERN(DRGNN_FOUT)
+#undef DRGNN_STEP_CLS_EXTERN
 #define DRGNN_STEP1_EXTERN(K, XF)                                                         \
     extern template __global__ void k_step1_co_topo<XF, false, false>(StepCoLaunch);      \
     extern template __global__ void k_step1_co_topo<XF, true, false>(StepCoLaunch);

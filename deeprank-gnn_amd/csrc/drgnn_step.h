@@ -1202,9 +1202,18 @@ static inline bool step_burst_guaranteed(int kind, const float* x, int F, int ca
 // device-computed counts (clusters of both depths, pooled edges) are still IN FLIGHT in cnt_c / cnt_e1 / cnt_c1: the
 // prologue then issues its loads with host-known bounds and resolves the counts afterwards -- one dependent memory round
 // trip less at the start of every workgroup (sizes -> arrays becomes a single wave of loads).
-template <int KIND, int XF, bool GATHER = false>
+// CLS: capacity class of the LDS layout.  0: laid out for the run-time capacities (capN, capE, capC = the maxima of the
+// batch, exact fit: that is what lets 200-node graphs into 160 KB at all).  1: the fixed layout STEP_CLS_N / _E / _C -- the
+// largest graph shape all three kinds fit at feature widths up to 32 -- with every array offset an immediate instead of
+// ~40 pinned registers and run-time address arithmetic: 0.2 - 0.4 us per step.  The host takes it whenever the
+// batch's maxima lie inside the class (train_step_impl); LDS is one workgroup per CU either way.
+#define STEP_CLS_N 200
+#define STEP_CLS_E 1024
+#define STEP_CLS_C 52
+template <int KIND, int XF, bool GATHER = false, int CLS = 0>
 DEV void net_step_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi, int br, float* scratch, int capN,
                         int capE, int capC, int part, bool late = false, int cnt_c = 0, int cnt_e1 = 0, int cnt_c1 = 0) {
+    if (CLS == 1) { capN = STEP_CLS_N; capE = STEP_CLS_E; capC = STEP_CLS_C; }
     GraphDims d = d_in;
     // bounds of the prologue's loads of the pooled level: the true counts, or (late) what the host knows they cannot
     // exceed while staying inside this graph's workspace segment and the LDS arrays

@@ -21,4 +21,7 @@ template __global__ void k_step1_co_topo<32, false, true>(StepCoLaunch);
 template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
 #else
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
+// ... and the 32-wide kernels with the capacity-class LDS layout (net_step_graph: CLS = 1)
+template __global__ void k_step_co_topo<DRGNN_TU_KIND, 32, false, 1>(StepCoLaunch);
+template __global__ void k_step_co_topo<DRGNN_TU_KIND, 32, true, 1>(StepCoLaunch);
 #endif

@@ -323,3 +323,43 @@ def test_benchmark_schedule_is_reproducible_and_graph_replays_equal_eager_launch
         for a, b, name in zip(runs[0], other, ("parameters", "exp_avg", "exp_avg_sq", "loss", "counters")):
             np.testing.assert_array_equal(a, b, err_msg=name)
     assert np.isfinite(runs[0][0]).all() and np.isfinite(runs[0][3]).all()
+
+
+@pytest.mark.parametrize("cached", [False, True])
+@pytest.mark.parametrize("net_name", NETS)
+def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, cached):
+    """A batch inside the capacity class (200 nodes / 1024 edges / 52 clusters per graph, 32 features) is stepped by kernels
+    whose LDS layout is a compile-time constant (drgnn_step.h: CLS); the layout moves arrays, not arithmetic: three training
+    steps give the same bits with the class kernels (default) and without (drgnn_set_step_layout(6)), rebuilt and cached."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.foutnet import FoutNet
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    from deeprank_gnn_amd.sGAT import sGAT
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    dev = _dev()
+    api = _lib.get()
+    Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[net_name]
+    batch = synth.make_batch(0, 64).to(dev)
+    rs = ResidentGraphSet([synth.make_graph(i) for i in range(64)], dev) if cached else None
+    cache = rs.topology_cache(need_weights=(net_name == "sGAT")) if cached else None
+    out = []
+    for mode in (5, 6):
+        api.set_step_layout(mode)
+        try:
+            torch.manual_seed(3)
+            tr = FusedTrainer(Net(32, 1, 1).to(dev), lr=1e-2, task="reg", seed=5)
+            for _ in range(3):
+                if cached:
+                    tr.train_step_cached(cache, list(range(64)))
+                else:
+                    tr.train_step(batch)
+            torch.cuda.synchronize()
+            assert tr.faults() == 0
+            out.append([t.detach().cpu().numpy().copy() for t in (tr.flat_p, tr.exp_avg_sq, tr.loss, tr.last_pred)])
+        finally:
+            api.set_step_layout(5)
+    for a, b, name in zip(out[0], out[1], ("parameters", "exp_avg_sq", "loss", "predictions")):
+        np.testing.assert_array_equal(a, b, err_msg=name)
+    assert np.isfinite(out[0][0]).all()
