@@ -738,13 +738,14 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     if (co_ok && T.roles == 2 && (net->n_branch != 2 || one_wg) && blocks + 2 * bn > cus && blocks + bn <= cus)
         T.roles = 1;            // one round of workgroups instead of two
     // Capacity class (drgnn_step.h: STEP_CLS_*): a batch whose maxima lie inside the class is stepped by the kernels whose
-    // LDS layout is a compile-time constant (32-wide kernels, not the one-workgroup GINet layout)
+    // LDS layout is a compile-time constant (32-wide kernels; of the one-workgroup GINet layouts the paired form)
     bool cls = false;
 #ifndef DRGNN_EMU
-    if (!one_wg && g_step_class_mode == 0 && L.capN <= STEP_CLS_N && L.capE <= STEP_CLS_E && L.capC <= STEP_CLS_C &&
+    if ((!one_wg || one_paired) && g_step_class_mode == 0 && L.capN <= STEP_CLS_N && L.capE <= STEP_CLS_E && L.capC <= STEP_CLS_C &&
         step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32 &&
         step_variant(kind, x, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O) == 32) {
-        const int64_t lds_cls = step_lds_bytes(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->R, hd->H, hd->O);
+        const int64_t lds_cls = one_wg ? step1_lds_bytes_form(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O, 1)
+                                       : step_lds_bytes(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->R, hd->H, hd->O);
         if (lds_cls <= DRGNN_LDS_LIMIT) {
             cls = true;
             L.capN = STEP_CLS_N; L.capE = STEP_CLS_E; L.capC = STEP_CLS_C;
@@ -829,27 +830,30 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         }                                                                                                   \
     } while (0)
 #define DRGNN_STEP1_LAUNCH_G(XF, G) DRGNN_STEP1_LAUNCH_GP(XF, G, false)
-#define DRGNN_STEP1_LAUNCH_GP(XF, G, P)                                                                         \
+#define DRGNN_STEP1_LAUNCH_GP(XF, G, P) DRGNN_STEP1_LAUNCH_GPC(XF, G, P, 0)
+#define DRGNN_STEP1_LAUNCH_GPC(XF, G, P, CL)                                                                    \
     do {                                                                                                    \
         /* once per kernel instance and device: the whole 160 KiB (the call costs host time on every launch otherwise) */\
         static int lds_set_on = -1;                                                                                   \
         if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
-            if (hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G, P>,                                              \
+            if (hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G, P, CL>,                                              \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
                 lds_set_on = step_current_device();                                                                   \
             } else {      /* (profiling builds carry a static LDS word: ask for what this launch needs) */            \
                 (void)hipGetLastError();                                                                              \
-                HIP_TRY(hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G, P>,                                      \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G, P, CL>,                                      \
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
             }                                                                                                         \
         }                                                                                                             \
-        hipLaunchKernelGGL((k_step1_co_topo<XF, G, P>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
+        hipLaunchKernelGGL((k_step1_co_topo<XF, G, P, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
                            (size_t)both, stream, C);                                                        \
     } while (0)
 #define DRGNN_STEP1_LAUNCH(XF)                                                                              \
     do { if (gather_ids) DRGNN_STEP1_LAUNCH_G(XF, true); else DRGNN_STEP1_LAUNCH_G(XF, false); } while (0)
         if (one_wg && one_paired) {
-            if (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32) {
+            if (cls) {
+                if (gather_ids) DRGNN_STEP1_LAUNCH_GPC(32, true, true, 1); else DRGNN_STEP1_LAUNCH_GPC(32, false, true, 1);
+            } else if (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32) {
                 if (gather_ids) DRGNN_STEP1_LAUNCH_GP(32, true, true); else DRGNN_STEP1_LAUNCH_GP(32, false, true);
             } else {
                 if (gather_ids) DRGNN_STEP1_LAUNCH_GP(0, true, true); else DRGNN_STEP1_LAUNCH_GP(0, false, true);
@@ -873,6 +877,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
 #undef DRGNN_STEP1_LAUNCH
 #undef DRGNN_STEP1_LAUNCH_G
 #undef DRGNN_STEP1_LAUNCH_GP
+#undef DRGNN_STEP1_LAUNCH_GPC
         HIP_TRY(hipGetLastError());
 #endif
     }

@@ -345,7 +345,7 @@ DEV void step_block(const StepLaunch& L, int blk, float* lds, int part) {
 
 // GINet, one workgroup per graph, both branches one after the other (drgnn_step1.h): the launch layout whenever the
 // two-workgroup exchange could meet a non-resident partner (2 B + builder workgroups > CUs).  No cross-workgroup wait.
-template <int XF, bool GATHER = false, bool PAIRED = false>
+template <int XF, bool GATHER = false, bool PAIRED = false, int CLS = 0>
 DEV void step_block_both(const StepLaunch& L, int g, float* lds) {
     if (g >= L.a.n_graphs) return;
     if (L.dims.count > 0) {
@@ -355,7 +355,7 @@ DEV void step_block_both(const StepLaunch& L, int g, float* lds) {
         d.rowbase = d.n0 + gi;
         d.C = 0; d.E1 = 0; d.C1 = 0;
         const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
-        net_step_graph_both<XF, GATHER, PAIRED>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
+        net_step_graph_both<XF, GATHER, PAIRED, CLS>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
         return;
     }
     const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;      // cached mode: graph number in the set
@@ -370,7 +370,7 @@ DEV void step_block_both(const StepLaunch& L, int g, float* lds) {
         FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
         return;
     }
-    net_step_graph_both<XF, GATHER, PAIRED>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC);
+    net_step_graph_both<XF, GATHER, PAIRED, CLS>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC);
 }
 
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
@@ -519,13 +519,13 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C_
 }
 // GINet, one workgroup per graph (both branches), + the builder's workgroups of the next mini-batch
 // PAIRED: both branches share every phase (drgnn_step1.h); instantiated for the generic and the 32-wide kernels
-template <int XF, bool GATHER, bool PAIRED>
+template <int XF, bool GATHER, bool PAIRED, int CLS = 0>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s1[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step_block_both<XF, GATHER, PAIRED>(C.step, blockIdx.x, smem_s1);
+    if ((int)blockIdx.x < C.n_net) step_block_both<XF, GATHER, PAIRED, CLS>(C.step, blockIdx.x, smem_s1);
     else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s1);
 }
 #ifdef DRGNN_KERNELS_MAIN
@@ -690,5 +690,7 @@ extern template __global__ void k_step1_co_topo<0, false, true>(StepCoLaunch);
 extern template __global__ void k_step1_co_topo<0, true, true>(StepCoLaunch);
 extern template __global__ void k_step1_co_topo<32, false, true>(StepCoLaunch);
 extern template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
+extern template __global__ void k_step1_co_topo<32, false, true, 1>(StepCoLaunch);      // (capacity-class LDS layout)
+extern template __global__ void k_step1_co_topo<32, true, true, 1>(StepCoLaunch);
 #endif
 #endif  // !DRGNN_EMU

@@ -183,9 +183,11 @@ DEV void step1_fc1_finish(const HeadFused& hf, int g, const float* wb, const flo
 // PAIRED: every phase works on BOTH branches (routine of branch 0, routine of branch 1, then the barrier): half the barriers
 // and twice the independent work between them -- the form taken whenever its LDS plan fits (153 KB at SYN size); the
 // branch-after-branch form (141 KB) is the fallback for larger graphs
-template <int XF, bool GATHER = false, bool PAIRED = false>
+// CLS: capacity class of the LDS layout (drgnn_step.h: net_step_graph)
+template <int XF, bool GATHER = false, bool PAIRED = false, int CLS = 0>
 DEV void net_step_graph_both(const StepArgs& a, const GraphDims& d_in, int g, int gi, float* scratch, int capN, int capE,
                              int capC, bool late = false, int cnt_c = 0, int cnt_e1 = 0, int cnt_c1 = 0) {
+    if (CLS == 1) { capN = STEP_CLS_N; capE = STEP_CLS_E; capC = STEP_CLS_C; }
     GraphDims d = d_in;
     const int bC = late ? imin(d.N, capC) : d.C, bE1 = late ? d.E : d.E1, bC1 = late ? imin(d.N, capC) : d.C1;
 #ifdef DRGNN_EMU

@@ -19,6 +19,9 @@ template __global__ void k_step1_co_topo<0, false, true>(StepCoLaunch);
 template __global__ void k_step1_co_topo<0, true, true>(StepCoLaunch);
 template __global__ void k_step1_co_topo<32, false, true>(StepCoLaunch);
 template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
+// ... and the 32-wide paired form with the capacity-class LDS layout
+template __global__ void k_step1_co_topo<32, false, true, 1>(StepCoLaunch);
+template __global__ void k_step1_co_topo<32, true, true, 1>(StepCoLaunch);
 #else
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
 // ... and the 32-wide kernels with the capacity-class LDS layout (net_step_graph: CLS = 1)

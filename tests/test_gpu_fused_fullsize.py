@@ -325,12 +325,13 @@ def test_benchmark_schedule_is_reproducible_and_graph_replays_equal_eager_launch
     assert np.isfinite(runs[0][0]).all() and np.isfinite(runs[0][3]).all()
 
 
-@pytest.mark.parametrize("cached", [False, True])
-@pytest.mark.parametrize("net_name", NETS)
-def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, cached):
+@pytest.mark.parametrize("net_name,cached,n_graphs", [(n, c, 64) for n in NETS for c in (False, True)] +
+                         [("GINet", False, 136), ("GINet", True, 136), ("sGAT", False, 136)])
+def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, cached, n_graphs):
     """A batch inside the capacity class (200 nodes / 1024 edges / 52 clusters per graph, 32 features) is stepped by kernels
     whose LDS layout is a compile-time constant (drgnn_step.h: CLS); the layout moves arrays, not arithmetic: three training
-    steps give the same bits with the class kernels (default) and without (drgnn_set_step_layout(6)), rebuilt and cached."""
+    steps give the same bits with the class kernels (default) and without (drgnn_set_step_layout(6)), rebuilt and cached;
+    136 graphs: GINet's one-workgroup (paired) layout and the other kinds beyond one round of workgroups."""
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd import _lib
     from deeprank_gnn_amd.foutnet import FoutNet
@@ -341,8 +342,8 @@ def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, c
     dev = _dev()
     api = _lib.get()
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[net_name]
-    batch = synth.make_batch(0, 64).to(dev)
-    rs = ResidentGraphSet([synth.make_graph(i) for i in range(64)], dev) if cached else None
+    batch = synth.make_batch(0, n_graphs).to(dev)
+    rs = ResidentGraphSet([synth.make_graph(i) for i in range(n_graphs)], dev) if cached else None
     cache = rs.topology_cache(need_weights=(net_name == "sGAT")) if cached else None
     out = []
     for mode in (5, 6):
@@ -352,7 +353,7 @@ def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, c
             tr = FusedTrainer(Net(32, 1, 1).to(dev), lr=1e-2, task="reg", seed=5)
             for _ in range(3):
                 if cached:
-                    tr.train_step_cached(cache, list(range(64)))
+                    tr.train_step_cached(cache, list(range(n_graphs)))
                 else:
                     tr.train_step(batch)
             torch.cuda.synchronize()
