@@ -102,7 +102,7 @@ class TopologyCacheDesc(ctypes.Structure):
 class HeadDesc(ctypes.Structure):
     _fields_ = [("R", _c_i32), ("H", _c_i32), ("O", _c_i32), ("task", _c_i32), ("train", _c_i32),
                 ("p_drop", ctypes.c_float), ("seed", ctypes.c_uint32), ("transform_sigmoid", _c_i32),
-                ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("class_w", _vp)]
+                ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("class_w", _vp), ("drop_mask", _vp)]
 
 
 TASK_REG, TASK_CLASS = 0, 1

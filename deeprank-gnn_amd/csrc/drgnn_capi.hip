@@ -513,6 +513,7 @@ int drgnn_net_backward_fused_head(const drgnn_net_desc* net, const drgnn_head_de
     HeadFused hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
     hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = -1; hf.train = 1; hf.sigmoid = hd->transform_sigmoid;
+    hf.drop_mask = hd->train ? hd->drop_mask : nullptr;
     hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
     hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
@@ -694,6 +695,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     HeadFused& hf = a.hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
     hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0; hf.train = hd->train ? 1 : 0; hf.sigmoid = hd->transform_sigmoid;
+    hf.drop_mask = hd->train ? hd->drop_mask : nullptr;
     hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
     hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;

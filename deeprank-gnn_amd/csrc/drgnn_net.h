@@ -155,7 +155,14 @@ struct HeadFused {
     int stage;                   // 1: the launch reserved LDS for W1/b1/W2/b2/readout row
     int train;                   // fused step only: 0 = inference (predictions, no loss / backward / slabs)
     int sigmoid;                 // regression: pred = sigmoid(output) before the loss (NeuralNet.py:625)
+    const float* drop_mask;      // [B][H] 0 / 1 or null: explicit dropout mask instead of the hash stream (parity tests)
 };
+// dropout decision of hidden unit h of graph g (ginet.py:138): the given mask, else the counter hash against `thresh`
+DEV bool drgnn_keep(const HeadFused& hf, uint32_t step, int g, int H, int h, uint32_t thresh) {
+    const uint32_t idx = (uint32_t)(g * H + h);
+    if (__builtin_expect(hf.drop_mask != nullptr, 0)) return hf.drop_mask[idx] != 0.0f;
+    return drgnn_hash(hf.seed, step, idx) >= thresh;
+}
 DEV float drgnn_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 HD int64_t head_stage_words(int R, int H, int O) { return (int64_t)H * (R + 1) + H + (int64_t)O * H + O + R + 16; }
 
@@ -198,7 +205,7 @@ DEV void head_graph(const HeadFused& hf, int g, int br, float* gp, float* dr_out
         float v = b1[h];
         for (int q = 0; q < 8; ++q) v += tmp[h * 8 + q];
         v = v > 0.0f ? v : 0.0f;
-        if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
+        if (thresh) v = drgnn_keep(hf, step, g, H, h, thresh) ? v * keep_scale : 0.0f;
         hid[h] = v;
     }
     BARRIER();

@@ -913,7 +913,7 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
         float v = (nb > 1) ? ((br == 0) ? p + po : po + p) : p;       // P0 + P1 in both workgroups
         v += b1[h];
         v = v > 0.0f ? v : 0.0f;
-        if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
+        if (thresh) v = drgnn_keep(hf, step, g, H, h, thresh) ? v * keep_scale : 0.0f;
         hid[h] = v;
     }
 #else
@@ -955,7 +955,7 @@ DEV void step_head_fc1_t(const HeadFused& hf, int g, int br, int nb, const float
         if (q == 0 && h < H) {
             v += b1[h];
             v = v > 0.0f ? v : 0.0f;
-            if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
+            if (thresh) v = drgnn_keep(hf, step, g, H, h, thresh) ? v * keep_scale : 0.0f;
             hid[h] = v;
         }
     }

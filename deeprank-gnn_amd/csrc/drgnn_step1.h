@@ -154,7 +154,7 @@ DEV void step1_fc1_finish(const HeadFused& hf, int g, const float* wb, const flo
         float v = p0[h] + p;
         v += b1[h];
         v = v > 0.0f ? v : 0.0f;
-        if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
+        if (thresh) v = drgnn_keep(hf, step, g, H, h, thresh) ? v * keep_scale : 0.0f;
         hid[h] = v;
     }
 #else
@@ -172,7 +172,7 @@ DEV void step1_fc1_finish(const HeadFused& hf, int g, const float* wb, const flo
             float v = p0[h] + acc;
             v += b1[h];
             v = v > 0.0f ? v : 0.0f;
-            if (thresh) v = (drgnn_hash(hf.seed, step, (uint32_t)(g * H + h)) >= thresh) ? v * keep_scale : 0.0f;
+            if (thresh) v = drgnn_keep(hf, step, g, H, h, thresh) ? v * keep_scale : 0.0f;
             hid[h] = v;
         }
     }

@@ -112,6 +112,11 @@ class FusedTrainer(object):
         hd.w1, hd.b1 = n.fc1.weight.data_ptr(), n.fc1.bias.data_ptr()
         hd.w2, hd.b2 = n.fc2.weight.data_ptr(), n.fc2.bias.data_ptr()
         hd.class_w = None if self.class_w is None else self.class_w.data_ptr()
+        # test hook (drgnn_head_desc.drop_mask): an explicit [B, H] 0 / 1 mask instead of the hash stream
+        mask = getattr(self, "drop_mask", None) if train else None
+        if mask is not None:
+            assert mask.dtype == torch.float32 and mask.is_contiguous() and mask.shape[-1] == self.H
+        hd.drop_mask = None if mask is None else mask.data_ptr()
         return hd
 
     def _body_forward(self, batch, topo, stream, step_inc=None):

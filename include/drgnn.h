@@ -276,6 +276,10 @@ typedef struct drgnn_head_desc {
                                   NeuralNet.format_output, NeuralNet.py:616-631); predictions are reported transformed */
     const float* w1; const float* b1; const float* w2; const float* b2;
     const float* class_w;     /* [O] class weights or NULL                                    */
+    const float* drop_mask;   /* NULL (product): the counter-hash dropout stream.  Otherwise float [B, H] of 0 / 1: hidden unit h
+                                 of the launch's graph g is kept iff drop_mask[g*H + h] != 0 and scaled by 1 / (1 - p_drop) --
+                                 exactly F.dropout's arithmetic (ginet.py:138) with the mask given, so that a dropout-on launch
+                                 can be compared element-wise with the oracle (tests; fused step kernels only)      */
 } drgnn_head_desc;
 
 /* The arguments of drgnn_topology_build bundled, to ask a body launch to ALSO build the topology

@@ -249,9 +249,12 @@ def _branch(data, conv1, conv2, trace, tag):
     return x2, batch2
 
 
-def ginet_forward(params, data, dropout=0.0, training=False, trace=None):
+def ginet_forward(params, data, dropout=0.0, training=False, trace=None, drop_mask=None):
     """reference ginet.py:99-141 (GINet.forward).  ``params`` maps state_dict names to
-    tensors.  The second branch convolves over the SAME edge_index."""
+    tensors.  The second branch convolves over the SAME edge_index.
+    ``drop_mask`` ([B, 128] of 0 / 1): F.dropout's arithmetic (ginet.py:138) with the Bernoulli
+    draw given instead of sampled -- ``hid * mask / (1 - p)`` -- so that a dropout-on launch of
+    the kernels (drgnn_head_desc.drop_mask) has a deterministic reference."""
     def conv(prefix):
         return lambda x, ei, ea: ginet_conv(x, ei, ea, params[prefix + ".fc.weight"],
                                             params[prefix + ".fc_edge_attr.weight"],
@@ -265,7 +268,10 @@ def ginet_forward(params, data, dropout=0.0, training=False, trace=None):
     if trace is not None:
         trace["readout"] = feat
     hid = F.relu(F.linear(feat, params["fc1.weight"], params["fc1.bias"]))
-    hid = F.dropout(hid, dropout, training=training)
+    if drop_mask is not None:
+        hid = hid * drop_mask.to(hid.dtype) / (1.0 - dropout)
+    else:
+        hid = F.dropout(hid, dropout, training=training)
     return F.linear(hid, params["fc2.weight"], params["fc2.bias"])
 
 

@@ -193,3 +193,35 @@ def test_fault_word_is_reported_once_and_cleared():
         tr.check_faults()
     assert tr.faults() == 0
     assert int(tr.step) == 1          # the step counters next to it are untouched
+
+
+def test_dropout_mask_override_matches_oracle():
+    """drgnn_head_desc.drop_mask: the fused step with dropout ON and the Bernoulli draw given as a [B, H] mask equals the
+    oracle applying F.dropout's arithmetic hid * mask / (1 - p) (ginet.py:138) with the same mask -- the element-wise
+    check of the dropout-on code path (forward scale AND d hid), CPU-emulated; tests/test_gpu_fused_fullsize.py runs
+    it on the benchmarked launch."""
+    from oracle import cpu_ref
+    torch.manual_seed(5)
+    batch = syn4_batch()
+    net = GINet(12, 1, 1)
+    assert net.dropout == 0.4
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    B = int(batch.y.shape[0])
+    mask = (torch.rand((B, 128), generator=torch.Generator().manual_seed(3)) >= 0.4).float()
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads("GINet", params, batch, batch.y, dropout=0.4, drop_mask=mask)
+    off_pred, _, _ = cpu_ref.loss_and_grads("GINet", params, batch, batch.y)
+    assert float((off_pred - ref_pred).abs().max()) > 1e-4          # the mask matters
+    for layout in (0, 1):
+        tr = FusedTrainer(copy.deepcopy(net), lr=0.01, task="reg", api=emu())
+        tr.drop_mask = mask.contiguous()
+        emu().set_step_layout(layout)
+        try:
+            loss = tr.compute_gradients(batch)
+        finally:
+            emu().set_step_layout(0)
+        np.testing.assert_allclose(float(loss), float(ref_loss), rtol=2e-5)
+        np.testing.assert_allclose(tr.last_pred.numpy(), ref_pred.numpy(), rtol=1e-4, atol=1e-5)
+        for name, p in tr.net.named_parameters():
+            r = ref_grads[name].numpy()
+            np.testing.assert_allclose(p.grad.numpy(), r, rtol=1e-4, atol=1e-5 * max(1.0, float(np.abs(r).max())),
+                                       err_msg="%s layout %d" % (name, layout))

@@ -87,6 +87,49 @@ def test_fused_step_syn64_gradients_match_oracle_elementwise(net_name, pipelined
         assert float(loss2) == float(loss)
 
 
+@pytest.mark.parametrize("layout", ["two", "one"])
+def test_fused_step_syn64_dropout_on_matches_oracle_elementwise(layout):
+    """The launch bench.py times runs GINet with dropout = 0.4 (ginet.py:97,138); the product's Bernoulli draw is a counter
+    hash, not torch's Philox, so the dropout-on code path is compared through an EXPLICIT mask: the kernels take a [B, 128]
+    0 / 1 mask (drgnn_head_desc.drop_mask) instead of the hash decision, the oracle applies F.dropout's arithmetic
+    hid * mask / (1 - p) with the same mask.  Everything else is the benchmarked launch (k_step_co_topo<GINet, 32>, p_drop =
+    0.4, keep_scale = 1 / 0.6 in the forward and in d hid).  Both GINet layouts (two branch workgroups / one per graph)."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.topology import Topology
+    dev = _dev()
+    batch_cpu = synth.make_batch(0, 64)
+    params = cpu_ref.init_params("GINet", 32, 1, 1, seed=21)
+    gen = torch.Generator().manual_seed(77)
+    mask = (torch.rand((64, 128), generator=gen) >= 0.4).float()          # keep-rate 0.6, seeded
+    assert 0.5 < float(mask.mean()) < 0.7
+    fw = dict(dropout=0.4, drop_mask=mask)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads("GINet", params, batch_cpu, batch_cpu.y, **fw)
+    lazy = Lazy64("GINet", params, batch_cpu, dropout=0.4, drop_mask=mask.double())
+    net, tr = _trainer("GINet", params)
+    net.dropout = 0.4
+    tr.drop_mask = mask.to(dev).contiguous()
+    batch = batch_cpu.clone().to(dev)
+    topo = Topology.from_batch(batch, need_weights=False)
+    assert tr._can_fuse(topo, 32)
+    api = _lib.get()
+    api.set_step_layout(1 if layout == "one" else 0)
+    try:
+        nxt = Topology.from_batch(batch, need_weights=False, build=False)
+        loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
+        torch.cuda.synchronize()
+    finally:
+        api.set_step_layout(0)
+    # the mask really bit: the dropout-off prediction differs
+    off_pred, _, _ = cpu_ref.loss_and_grads("GINet", params, batch_cpu, batch_cpu.y)
+    assert float((off_pred - ref_pred).abs().max()) > 1e-3
+    stats = new_stats()
+    check_step("GINet SYN64 dropout 0.4 (%s)" % layout, lazy, loss, tr.last_pred.cpu().numpy(), _grads_of(net), ref_loss,
+               ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()}, stats)
+    assert_arbiter_rate(stats, "GINet dropout on, layout %s" % layout)
+    tr.check_faults()
+
+
 @pytest.mark.parametrize("net_name", NETS)
 def test_fused_step_syn64_three_adam_steps_match_oracle(net_name):
     """Three optimiser steps through the benchmarked launches (k_step_co_topo + k_update, topologies
