@@ -110,7 +110,7 @@ def parse():
     ap.add_argument("--graphs-per-gpu", type=int, default=GRAPHS_PER_GPU,
                     help="mini-batch per GPU; %d is BASELINE.json's configuration, other values are for the "
                          "batch-size sweep in DESIGN.md" % GRAPHS_PER_GPU)
-    ap.add_argument("--step-layout", choices=["auto", "one", "seq", "two", "noclass"], default="auto",
+    ap.add_argument("--step-layout", choices=["auto", "one", "seq", "two", "noclass", "old", "af1"], default="auto",
                     help="GINet: workgroups per graph of the fused step -- auto (default): two while every workgroup of the "
                          "launch is resident, else one (both branches in sequence); one / two: forced, for A/B runs; noclass: "
                          "auto without the capacity-class kernels (compile-time LDS layout for batches inside 200 / 1024 / 52)")
@@ -185,6 +185,10 @@ def main():
 
     if args.step_layout == "noclass":                  # (A/B: the run-time LDS layout also where the capacity class applies)
         _lib.get().set_step_layout(6)
+    elif args.step_layout == "old":                    # (A/B, sGAT / FoutNet: the round-3 kernels, no aggregation-first step)
+        _lib.get().set_step_layout(8)
+    elif args.step_layout == "af1":                    # (A/B, sGAT / FoutNet: aggregation first, ONE workgroup per graph)
+        _lib.get().set_step_layout(10)
     elif args.step_layout != "auto":
         if args.step_layout == "seq":                  # one workgroup per graph, branch after branch (not the paired form)
             _lib.get().set_step_layout(3)
@@ -696,6 +700,10 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
     alg = fwd_b + bwd_b
     upd_bytes = (c["partials"].numel() + c["hp"].numel() + c["readout"].numel() + 7 * tr.flat_p.numel()) * 4 / B
     kname = "k_step_co_topo<%s,%d>" % (net_name, variant)
+    if net_name != "GINet" and (c["hints"][0].topo_flags & _lib.TOPO_HIER) and \
+            tr.api.net_step_family(tr.kind, batch.x.shape[1], topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O):
+        # sGAT / FoutNet training launches of this shape: the aggregation-first kernels (csrc/drgnn_step2.h)
+        kname = "k_step2_co_topo<%s,32,%s>" % (net_name, "two workgroups per graph" if c["hints"][0].split else "one workgroup per graph")
     out = {}
     first = ((kname + " (fwd + head/loss + bwd, topology read from the per-graph cache)", k_step_cached, alg) if cache else
              (kname + " (fwd + head/loss + bwd, + topology of the next batch)", k_step_co, alg))

@@ -21,7 +21,7 @@ MAX_BRANCH = 2
 TI = {name: i for i, name in enumerate([
     "NPTR", "EPTR", "ROWPTR0", "COL0", "EID0", "COLPTR0", "ROWIDX0", "TSLOT0", "CL0", "NC0",
     "MPTR0", "MEM0", "ROWPTR1", "COL1", "NE1", "COLPTR1", "ROWIDX1", "TSLOT1", "CL1", "NC1",
-    "MPTR1", "MEM1", "CPTR0", "E1PTR", "CPTR1", "ERR", "GSTAT"])}
+    "MPTR1", "MEM1", "CPTR0", "E1PTR", "CPTR1", "ERR", "GSTAT", "HORD", "HMP0", "HSPLIT"])}
 TI_COUNT = len(TI)
 TF = {"W0": 0, "W1": 1}
 TF_COUNT = 2
@@ -59,7 +59,11 @@ class TopologyRequest(ctypes.Structure):
                 ("max_nodes", _c_i32), ("max_edges", _c_i32),
                 ("ws_i32", _vp), ("ws_f32", _vp), ("scratch_i32", _vp),
                 # resident-set mode (include/drgnn.h); left NULL by the Python-level Topology
-                ("set", _vp), ("ids", _vp), ("x_out", _vp), ("y_out", _vp)]
+                ("set", _vp), ("ids", _vp), ("x_out", _vp), ("y_out", _vp),
+                ("flags", _c_i32), ("reserved", _c_i32)]
+
+
+TOPO_HIER = 1          # drgnn_topology_request.flags: also build the hierarchical node order (HORD / HMP0 / HSPLIT)
 
 
 class GraphSet(ctypes.Structure):
@@ -90,13 +94,13 @@ EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ct
 class StepHints(ctypes.Structure):
     """drgnn_step_hints: host-side offset tables of a launch's graphs (pointers to HOST memory)."""
     _fields_ = [("host_node_ptr", _vp), ("host_edge_ptr", _vp), ("set_node_ptr", _vp), ("set_edge_ptr", _vp),
-                ("host_ids", _vp)]
+                ("host_ids", _vp), ("topo_flags", _c_i32), ("split", _c_i32)]
 
 
 class TopologyCacheDesc(ctypes.Structure):
     """drgnn_topology_cache: one topology workspace over a whole resident set + its node features / targets."""
     _fields_ = [("n_graphs", _c_i64), ("n_nodes", _c_i64), ("n_edges", _c_i64),
-                ("ws_i32", _vp), ("ws_f32", _vp), ("x", _vp), ("y", _vp), ("y_bytes", _c_i32), ("reserved", _c_i32)]
+                ("ws_i32", _vp), ("ws_f32", _vp), ("x", _vp), ("y", _vp), ("y_bytes", _c_i32), ("flags", _c_i32)]
 
 
 class HeadDesc(ctypes.Structure):
@@ -176,7 +180,11 @@ class Api(object):
         lib.drgnn_step_update.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] +
                                           [ctypes.POINTER(ConvGrads)] * 2 + [_vp, _vp] + [_c_i32] * 3 +
                                           [_c_i64] + [_vp] * 4 + [_c_i64] + [_vp] * 2 +
-                                          [ctypes.c_float] * 4 + [_c_i32, _vp])
+                                          [ctypes.c_float] * 4 + [_c_i32, _c_i32, _vp])
+        lib.drgnn_net_step_xchg_elems.argtypes = [_c_i32] * 4
+        lib.drgnn_net_step_xchg_elems.restype = _c_i64
+        lib.drgnn_net_step_family.argtypes = [_c_i32] * 7
+        lib.drgnn_net_step_family.restype = _c_i32
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
                                                [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
         lib.drgnn_conv_layer_slabs.argtypes = [_c_i64]
@@ -338,12 +346,19 @@ class Api(object):
 
     def step_update(self, desc, conv_partials, n_graphs, g1, g2, head_partials, readout, R, H, O, head_offset,
                     flat_p, flat_g, exp_avg, exp_avg_sq, step2, loss, lr, beta1, beta2, eps, stream,
-                    apply_adam=True):
+                    apply_adam=True, slabs_per_graph=0):
         _check(self.lib.drgnn_step_update(
             ctypes.byref(desc), _ptr(conv_partials), n_graphs, g1, g2, _ptr(head_partials), _ptr(readout),
             R, H, O, head_offset, _ptr(flat_p), _ptr(flat_g), _ptr(exp_avg), _ptr(exp_avg_sq), flat_p.numel(),
-            _ptr(step2), _ptr(loss), lr, beta1, beta2, eps, 1 if apply_adam else 0, stream),
+            _ptr(step2), _ptr(loss), lr, beta1, beta2, eps, 1 if apply_adam else 0, int(slabs_per_graph), stream),
             "drgnn_step_update")
+
+    def net_step_family(self, kind, n_feat, max_nodes, max_edges, max_c0, H, O):
+        """1: training launches of this shape on a topology with the hierarchical order run the aggregation-first kernels."""
+        return int(self.lib.drgnn_net_step_family(kind, n_feat, max_nodes, max_edges, max_c0, H, O))
+
+    def net_step_xchg_elems(self, kind, max_nodes, max_c0, H):
+        return int(self.lib.drgnn_net_step_xchg_elems(kind, max_nodes, max_c0, H))
 
     def net_reduce_grads(self, desc, partials, n_nodes, n_graphs, g1, g2, grad_x, stream):
         _check(self.lib.drgnn_net_reduce_grads(ctypes.byref(desc), _ptr(partials), n_nodes, n_graphs,
@@ -504,7 +519,7 @@ def current_stream(ref):
     return None
 
 
-def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None):
+def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None, topo_flags=0, split=0):
     """(StepHints, keep-alive tuple) from numpy arrays: int32 per-mini-batch tables, or int64 set tables + int32 ids."""
     import numpy as np
     h = StepHints()
@@ -518,4 +533,5 @@ def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=Non
         return a.ctypes.data
     h.host_node_ptr, h.host_edge_ptr = pin(node_ptr, np.int32), pin(edge_ptr, np.int32)
     h.set_node_ptr, h.set_edge_ptr, h.host_ids = pin(set_node_ptr, np.int64), pin(set_edge_ptr, np.int64), pin(ids, np.int32)
+    h.topo_flags, h.split = int(topo_flags), int(split)
     return h, tuple(keep)

@@ -73,7 +73,7 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
                         const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* c1_ptr,
                         int64_t n_nodes, int64_t n_edges, int64_t len_cluster1, int64_t n_graphs,
                         int32_t max_nodes, int32_t max_edges, int32_t* ws_i32, float* ws_f32,
-                        int32_t* scratch_i32) {
+                        int32_t* scratch_i32, int32_t flags = DRGNN_TOPO_HIER) {
     if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !ws_i32) return DRGNN_E_ARG;
     if (!batch && !(node_ptr && edge_ptr)) return DRGNN_E_ARG;      // the offsets are derived from `batch`
     if (!cluster0 && cluster1) return DRGNN_E_ARG;
@@ -94,6 +94,7 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     L.args.set_ids = nullptr; L.args.set_node_ptr = L.args.set_edge_ptr = L.args.set_c1_ptr = nullptr;
     L.args.set_x = nullptr; L.args.set_y = nullptr; L.args.x_out = nullptr; L.args.y_out = nullptr;
     L.args.n_set = 0; L.args.n_feat = 0; L.args.y_bytes = 0;
+    L.args.flags = flags;
     L.gscratch = scratch_i32;
     L.level1_only = 0;
     L.roles = 1;
@@ -124,7 +125,7 @@ static int topo_prepare_req(TopoLaunch& T, int64_t* tlds, const drgnn_topology_r
     if (!gs)
         return topo_prepare(T, tlds, r->edge_index, r->edge_attr, r->batch, r->cluster0, r->cluster1, r->node_ptr,
                             r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs, r->max_nodes,
-                            r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32);
+                            r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags);
     if (!r->ids || !r->node_ptr || !r->edge_ptr || !gs->node_ptr || !gs->edge_ptr || !gs->cluster0) return DRGNN_E_ARG;
     if (gs->cluster1 && (!gs->c1_ptr || !r->c1_ptr)) return DRGNN_E_ARG;
     if (r->x_out && (!gs->x || gs->n_feat <= 0)) return DRGNN_E_ARG;
@@ -132,7 +133,7 @@ static int topo_prepare_req(TopoLaunch& T, int64_t* tlds, const drgnn_topology_r
     const float* attr = (r->ws_f32 && gs->edge_attr) ? gs->edge_attr : nullptr;
     const int rc = topo_prepare(T, tlds, gs->edge_index, attr, nullptr, gs->cluster0, gs->cluster1, r->node_ptr,
                                 r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs,
-                                r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32);
+                                r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags);
     if (rc) return rc;
     TopoArgs& a = T.args;
     a.n_edges = gs->n_edges;                  // row stride of the SET's edge_index
@@ -142,20 +143,18 @@ static int topo_prepare_req(TopoLaunch& T, int64_t* tlds, const drgnn_topology_r
     return 0;
 }
 
-extern "C" {
-
-int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, const int64_t* batch,
+static int topology_build_impl(const int64_t* edge_index, const float* edge_attr, const int64_t* batch,
                          const int64_t* cluster0, const int64_t* cluster1, const int32_t* node_ptr,
                          const int32_t* edge_ptr, const int32_t* c1_ptr, int64_t n_nodes,
                          int64_t n_edges, int64_t len_cluster1, int64_t n_graphs, int32_t max_nodes,
                          int32_t max_edges, int32_t* ws_i32, float* ws_f32, int32_t* scratch_i32,
-                         void* stream_) {
+                         int32_t flags, void* stream_) {
     drgnn_stream_t stream = (drgnn_stream_t)stream_;
     TopoLaunch L;
     int64_t lds = 0;
     int rc0 = topo_prepare(L, &lds, edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,
                            n_nodes, n_edges, len_cluster1, n_graphs, max_nodes, max_edges, ws_i32, ws_f32,
-                           scratch_i32);
+                           scratch_i32, flags);
     if (rc0) return rc0;
     if (L.capN == 0 && !scratch_i32) return DRGNN_E_CAPACITY;
     if (n_graphs == 0) return 0;
@@ -199,12 +198,25 @@ int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, cons
     return 0;
 }
 
+extern "C" {
+
+int drgnn_topology_build(const int64_t* edge_index, const float* edge_attr, const int64_t* batch,
+                         const int64_t* cluster0, const int64_t* cluster1, const int32_t* node_ptr,
+                         const int32_t* edge_ptr, const int32_t* c1_ptr, int64_t n_nodes,
+                         int64_t n_edges, int64_t len_cluster1, int64_t n_graphs, int32_t max_nodes,
+                         int32_t max_edges, int32_t* ws_i32, float* ws_f32, int32_t* scratch_i32,
+                         void* stream_) {
+    return topology_build_impl(edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, n_nodes, n_edges,
+                               len_cluster1, n_graphs, max_nodes, max_edges, ws_i32, ws_f32, scratch_i32, DRGNN_TOPO_HIER,
+                               stream_);
+}
+
 int drgnn_topology_build_request(const drgnn_topology_request* r, void* stream_) {
     if (!r) return DRGNN_E_ARG;
     if (!r->set)
-        return drgnn_topology_build(r->edge_index, r->edge_attr, r->batch, r->cluster0, r->cluster1, r->node_ptr,
-                                    r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs,
-                                    r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, stream_);
+        return topology_build_impl(r->edge_index, r->edge_attr, r->batch, r->cluster0, r->cluster1, r->node_ptr,
+                                   r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs,
+                                   r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags, stream_);
     TopoLaunch L;
     int64_t lds = 0;
     const int rc = topo_prepare_req(L, &lds, r);
@@ -544,6 +556,8 @@ int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O) { return head_
 // resident size this is the pre-round-3 schedule, whose exchange leans on in-order dispatch; bounded spin + fault bit)
 static int g_step_layout_mode = 0;
 static int g_step_class_mode = 0;          // 0: capacity-class kernels where a batch fits the class (default); 1: never (A/B runs, tests)
+static int g_step2_mode = 0;               // 0: sGAT / FoutNet may take the aggregation-first kernels (drgnn_step2.h); 1: never
+static int g_step2_split_mode = 0;         // 0: ... with two workgroups per graph where the plan allows; 1: never split (A/B runs)
 static int device_cu_count() {
 #ifdef DRGNN_EMU
     return 256;
@@ -577,9 +591,37 @@ static int64_t step1_lds_bytes(int F, int capN, int capE, int capC, int H, int O
     if (paired_out) *paired_out = paired;
     return paired ? p : step1_lds_bytes_form(F, capN, capE, capC, H, O, 0);
 }
+// shape conditions of the aggregation-first kernels (without the x pointer's alignment: checked at the launch)
+static bool step2_shape_ok(int kind, int F, int capN, int capE, int capC, int H, int O) {
+#ifdef DRGNN_EMU
+    (void)kind; (void)F; (void)capN; (void)capE; (void)capC; (void)H; (void)O;
+    return false;
+#else
+    if (kind == DRGNN_GINET || g_step2_mode != 0) return false;
+    if (step_pad16(F) != 32 || !step_burst_guaranteed(kind, nullptr, F, capN, capE, capC, H, O)) return false;
+    return 4 * step2_scratch_words(kind, F, capN, capE, capC, H, O) <= DRGNN_LDS_LIMIT;
+#endif
+}
+static bool step2_split_plan_ok(int kind, int F, int capN, int capE, int capC, int H, int O, int64_t n_graphs, int64_t co_built) {
+    if (g_step2_split_mode != 0 || !step2_shape_ok(kind, F, capN, capE, capC, H, O)) return false;
+    return step_two_workgroups_ok(n_graphs, co_built);      // (the builder at ONE workgroup per graph if two do not fit)
+}
+int32_t drgnn_net_step_family(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t H,
+                              int32_t O) {
+    if (max_nodes <= 0 || max_nodes > 32767 || max_edges > 65535 || n_feat > 256) return 0;
+    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    return step2_shape_ok(kind, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, H, O) ? 1 : 0;
+}
+int64_t drgnn_net_step_xchg_elems(int32_t kind, int32_t max_nodes, int32_t max_c0, int32_t H) {
+    if (kind == DRGNN_GINET) return 2 * (int64_t)(H > DRGNN_H2 ? H : DRGNN_H2);
+    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    return step2_xchg_words(capC > 0 ? capC : 1);
+}
 int32_t drgnn_set_step_layout(int32_t mode) {
     if (mode == 3 || mode == 4) { g_step1_paired_mode = (mode == 4); return 0; }   // (A/B: 3 = branch after branch, 4 = paired)
     if (mode == 5 || mode == 6) { g_step_class_mode = (mode == 6) ? 1 : 0; return 0; }   // (5 = capacity-class kernels allowed, 6 = never)
+    if (mode == 7 || mode == 8) { g_step2_mode = (mode == 8) ? 1 : 0; return 0; }          // (7 = aggregation-first kernels allowed, 8 = never)
+    if (mode == 9 || mode == 10) { g_step2_split_mode = (mode == 10) ? 1 : 0; return 0; }  // (9 = their split layout allowed, 10 = never)
     if (mode < 0 || mode > 2) return DRGNN_E_ARG;
     g_step_layout_mode = mode;
     return 0;
@@ -591,6 +633,12 @@ int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int
     const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
     const int capE = max_edges > 0 ? max_edges : 1;
     if (kind != DRGNN_GINET) {
+        // the node-split layout: two workgroups per graph while all of them (+ the co-launched builder, at two or one
+        // workgroup per graph) are resident, 32-wide specialised shape, reference head
+        if (step2_split_plan_ok(kind, n_feat, max_nodes, capE, capC, H, O, n_graphs, co_built_graphs > 0 ? co_built_graphs : 0)) {
+            if (lds_bytes) *lds_bytes = 4 * step2_scratch_words(kind, n_feat, max_nodes, capE, capC, H, O);
+            return 2;
+        }
         if (lds_bytes) *lds_bytes = step_lds_bytes(kind, n_feat, max_nodes, capE, capC, R, H, O);
         return 1;
     }
@@ -643,9 +691,30 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     L.capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
     const int kind = net->kind, F = net->n_feat;
     int64_t lds = step_lds_bytes(kind, F, L.capN, L.capE, L.capC, hd->R, hd->H, hd->O);
+    // sGAT / FoutNet: the aggregation-first kernels (drgnn_step2.h) for training launches of the 32-wide specialised shape on
+    // a topology the caller vouches to hold the hierarchical order; with two workgroups per graph when the caller asks for it
+    int af_split = 0;        // 0: the drgnn_step.h kernel; 1 / 2: drgnn_step2.h with that many workgroups per graph
+    const int capC_rt = L.capC;
+#ifndef DRGNN_EMU
+    if (kind != DRGNN_GINET) {
+        const bool want_split = hints && hints->split == 1;
+        const bool hier = hints && (hints->topo_flags & DRGNN_TOPO_HIER) != 0;
+        const bool shape = hd->train && hier && ((((uintptr_t)x) & 15) == 0) &&
+                           step2_shape_ok(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
+        if (want_split) {
+            if (!shape || !xchg) return DRGNN_E_CAPACITY;
+            af_split = 2;
+        } else if (shape) {
+            af_split = 1;
+        }
+        if (af_split) lds = 4 * step2_scratch_words(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
+    }
+#else
+    if (hints && hints->split == 1) return DRGNN_E_CAPACITY;      // (the emulation build has no node-split kernels)
+#endif
     // GINet: one workgroup per graph unless all of 2 B (+ the builder's) workgroups are resident at once; decided below,
     // once the co-launched builder's size is known
-    const bool two_alone = (net->n_branch == 2) && step_two_workgroups_ok(n_graphs, 0);
+    const bool two_alone = (net->n_branch == 2 || af_split == 2) && step_two_workgroups_ok(n_graphs, 0);
     bool one_paired = false;
     const int64_t lds1 = (net->n_branch == 2) ? step1_lds_bytes(F, L.capN, L.capE, L.capC, hd->H, hd->O, &one_paired) : 0;
     if (net->n_branch == 2 && !two_alone) {
@@ -692,6 +761,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     a.n_nodes = n_nodes; a.n_graphs = (int)n_graphs;
     a.partials = partials; a.n_partial = (int)net_partial_floats(F);
     a.xchg = (unsigned long long*)xchg; a.step2 = step2;
+    a.xchg_stride = (int)step2_xchg_words(capC_rt > 0 ? capC_rt : 1);
     HeadFused& hf = a.hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
     hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0; hf.train = hd->train ? 1 : 0; hf.sigmoid = hd->transform_sigmoid;
@@ -702,7 +772,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     hf.readout = readout; hf.step = step2; hf.pred = pred; hf.partials = head_partials; hf.stage = 0;
 
     // grid of the step part: graphs in groups of 8 x n_branch (see step_block)
-    int blocks = (net->n_branch == 2) ? (int)((n_graphs + 7) / 8) * 16 : (int)n_graphs;
+    int blocks = (net->n_branch == 2 || af_split == 2) ? (int)((n_graphs + 7) / 8) * 16 : (int)n_graphs;
     TopoLaunch T;
     int64_t tlds = 0;
     bool co_ok = false;
@@ -736,8 +806,19 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             return DRGNN_E_CAPACITY;
         }
         if (one_wg) { lds = lds1; L.words = lds / 4; blocks = (int)n_graphs; }
+    } else if (af_split == 2) {
+        // the same residency rule for the two half-graph workgroups of the split layout (the caller sized its buffers for
+        // it: no silent fallback to another layout)
+        if (step_two_workgroups_ok(n_graphs, bn * (split_ok ? 2 : 1))) {
+        } else if (split_ok && step_two_workgroups_ok(n_graphs, bn)) {
+            T.roles = 1;
+        } else if (two_alone) {
+            co_ok = false;
+        } else {
+            return DRGNN_E_CAPACITY;
+        }
     }
-    if (co_ok && T.roles == 2 && (net->n_branch != 2 || one_wg) && blocks + 2 * bn > cus && blocks + bn <= cus)
+    if (co_ok && T.roles == 2 && ((net->n_branch != 2 && af_split != 2) || one_wg) && blocks + 2 * bn > cus && blocks + bn <= cus)
         T.roles = 1;            // one round of workgroups instead of two
     // Capacity class (drgnn_step.h: STEP_CLS_*): a batch whose maxima lie inside the class is stepped by the kernels whose
     // LDS layout is a compile-time constant (32-wide kernels; of the one-workgroup GINet layouts the paired form)
@@ -747,6 +828,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32 &&
         step_variant(kind, x, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O) == 32) {
         const int64_t lds_cls = one_wg ? step1_lds_bytes_form(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O, 1)
+                                : af_split ? 4 * step2_scratch_words(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
                                        : step_lds_bytes(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->R, hd->H, hd->O);
         if (lds_cls <= DRGNN_LDS_LIMIT) {
             cls = true;
@@ -852,6 +934,35 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     } while (0)
 #define DRGNN_STEP1_LAUNCH(XF)                                                                              \
     do { if (gather_ids) DRGNN_STEP1_LAUNCH_G(XF, true); else DRGNN_STEP1_LAUNCH_G(XF, false); } while (0)
+#define DRGNN_STEP2_LAUNCH(K, G, CL, SP)                                                                            \
+    do {                                                                                                    \
+        static int lds_set_on = -1;                                                                                   \
+        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
+            if (hipFuncSetAttribute((const void*)k_step2_co_topo<K, 32, G, CL, SP>,                                       \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
+                lds_set_on = step_current_device();                                                                   \
+            } else {                                                                                                  \
+                (void)hipGetLastError();                                                                              \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_step2_co_topo<K, 32, G, CL, SP>,                               \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_step2_co_topo<K, 32, G, CL, SP>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
+                           (size_t)both, stream, C);                                                        \
+    } while (0)
+#define DRGNN_STEP2_LAUNCH_K(K)                                                                             \
+    do {                                                                                                    \
+        if (af_split == 2) {                                                                                \
+            if (cls) { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 1, 2); else DRGNN_STEP2_LAUNCH(K, false, 1, 2); } \
+            else { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 0, 2); else DRGNN_STEP2_LAUNCH(K, false, 0, 2); }     \
+        } else {                                                                                            \
+            if (cls) { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 1, 1); else DRGNN_STEP2_LAUNCH(K, false, 1, 1); } \
+            else { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 0, 1); else DRGNN_STEP2_LAUNCH(K, false, 0, 1); }     \
+        }                                                                                                   \
+    } while (0)
+        if (af_split) {
+            if (kind == DRGNN_SGAT) DRGNN_STEP2_LAUNCH_K(DRGNN_SGAT); else DRGNN_STEP2_LAUNCH_K(DRGNN_FOUT);
+        } else
         if (one_wg && one_paired) {
             if (cls) {
                 if (gather_ids) DRGNN_STEP1_LAUNCH_GPC(32, true, true, 1); else DRGNN_STEP1_LAUNCH_GPC(32, false, true, 1);
@@ -880,6 +991,8 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
 #undef DRGNN_STEP1_LAUNCH_G
 #undef DRGNN_STEP1_LAUNCH_GP
 #undef DRGNN_STEP1_LAUNCH_GPC
+#undef DRGNN_STEP2_LAUNCH
+#undef DRGNN_STEP2_LAUNCH_K
         HIP_TRY(hipGetLastError());
 #endif
     }
@@ -1111,7 +1224,8 @@ int drgnn_allreduce_oneshot(float* grad, int64_t n, void* const* peer_bufs, int3
 // `readout` null: legacy head slabs [head_slabs][head_partial_floats] (dW_fc1 inside), Adam reads step[0].
 // `readout` given (fused step): compact slabs [n_graphs][head_compact_floats] + readout [n_graphs][R];
 // `step` is then the 2-word counter of drgnn_net_train_step: Adam reads step[1], step[0] is committed.
-static int update_impl(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+// slabs_per_graph: conv slabs per graph (0: n_branch; 2 for the split layout of a single-branch net, drgnn_step2.h)
+static int update_impl(int32_t slabs_per_graph, const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
                        drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
                        int64_t head_slabs, const float* readout, int32_t R, int32_t H, int32_t O,
                        int64_t head_offset, float* flat_param,
@@ -1124,7 +1238,10 @@ static int update_impl(const drgnn_net_desc* net, const float* conv_partials, in
     if (apply_adam && (!flat_param || !exp_avg || !exp_avg_sq || !step)) return DRGNN_E_ARG;
     UpdateArgs u;
     ReduceArgs& r = u.r;
-    r.partials = conv_partials; r.n_graphs = (int)n_graphs; r.n_branch = net->n_branch;
+    if (slabs_per_graph != 0 && slabs_per_graph != net->n_branch && !(net->n_branch == 1 && slabs_per_graph == 2)) return DRGNN_E_ARG;
+    // (a single-branch net's two half-graph slabs are two more "graphs" to the fixed-order sum)
+    const int64_t conv_rows = (net->n_branch == 1 && slabs_per_graph == 2) ? 2 * n_graphs : n_graphs;
+    r.partials = conv_partials; r.n_graphs = (int)conv_rows; r.n_branch = net->n_branch;
     r.n_feat = net->n_feat; r.n_partial = (int)net_partial_floats(net->n_feat); r.kind = net->kind;
     for (int b = 0; b < DRGNN_MAX_BRANCH; ++b) {
         r.lay1[b] = net->conv1[b]; r.lay2[b] = net->conv2[b];
@@ -1175,7 +1292,7 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
                        const int32_t* step, float* loss, float lr, float beta1, float beta2, float eps,
                        int32_t apply_adam, void* stream_) {
     if (!head_partials) return DRGNN_E_ARG;
-    return update_impl(net, conv_partials, n_graphs, g_conv1, g_conv2, head_partials, head_slabs, nullptr, R, H, O,
+    return update_impl(0, net, conv_partials, n_graphs, g_conv1, g_conv2, head_partials, head_slabs, nullptr, R, H, O,
                        head_offset, flat_param, flat_grad, exp_avg, exp_avg_sq, n_param,
                        const_cast<int32_t*>(step), loss, lr, beta1, beta2, eps, apply_adam, stream_);
 }
@@ -1185,9 +1302,9 @@ int drgnn_step_update(const drgnn_net_desc* net, const float* conv_partials, int
                       const float* readout, int32_t R, int32_t H, int32_t O, int64_t head_offset,
                       float* flat_param, float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
                       int32_t* step2, float* loss, float lr, float beta1, float beta2, float eps,
-                      int32_t apply_adam, void* stream_) {
+                      int32_t apply_adam, int32_t slabs_per_graph, void* stream_) {
     if (!head_partials || !readout || !step2) return DRGNN_E_ARG;
-    return update_impl(net, conv_partials, n_graphs, g_conv1, g_conv2, head_partials, n_graphs, readout, R, H, O,
+    return update_impl(slabs_per_graph, net, conv_partials, n_graphs, g_conv1, g_conv2, head_partials, n_graphs, readout, R, H, O,
                        head_offset, flat_param, flat_grad, exp_avg, exp_avg_sq, n_param, step2, loss, lr, beta1,
                        beta2, eps, apply_adam, stream_);
 }
@@ -1478,20 +1595,45 @@ int epoch_check(const drgnn_epoch_plan* p) {
     if (p->batch_size > 4096) return DRGNN_E_CAPACITY;
     return 0;
 }
+// workgroups per graph of mini-batch b's step (co = graphs of the topology co-built by the same launch): 2 for GINet's
+// resident layout and for the node-split layout of a single-branch TRAINING step on a topology with the hierarchical order
+int epoch_step_wgs(const drgnn_epoch_plan* p, const EpochBatch& b, int64_t co, int64_t* lds) {
+    const drgnn_head_desc* hd = p->head;
+    int wgs = drgnn_net_step_plan(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O, b.B, co, lds);
+    if (wgs == 2 && p->net->kind != DRGNN_GINET) {
+        const bool hier = p->cache ? (p->cache->flags & DRGNN_TOPO_HIER) != 0 : true;      // (the loop's own builds ask for it)
+        if (p->inference || !hier) {
+            wgs = 1;
+            if (lds) *lds = drgnn_net_step_lds_bytes(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O);
+        }
+    }
+    return wgs;
+}
+int64_t epoch_next_b(const drgnn_epoch_plan* p, int64_t k) {      // graphs of mini-batch k + 1 (0: none)
+    const int64_t first = (k + 1) * p->batch_size;
+    if (first >= p->n_ids) return 0;
+    return p->n_ids - first < p->batch_size ? p->n_ids - first : p->batch_size;
+}
 // sizes the two mini-batch slots and the step slabs for the largest mini-batch of the plan
 int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
     int rc = epoch_check(p);
     if (rc) return rc;
     const int64_t nb = (p->n_ids + p->batch_size - 1) / p->batch_size;
-    int64_t capN = 1, capB = 1, ws_i = 4, ws_f = 4;
+    int64_t capN = 1, capB = 1, ws_i = 4, ws_f = 4, xchg_words = 0;
+    bool any_split = false;
     const drgnn_head_desc* hd = p->head;
     for (int64_t k = 0; k < nb; ++k) {
         EpochBatch b;
         if ((rc = epoch_batch(p, k, &b))) return rc;
         if (b.maxN <= 0) return DRGNN_E_CAPACITY;
         int64_t step_lds = 0;
-        if (drgnn_net_step_plan(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O, b.B,
-                                p->cache ? 0 : p->batch_size, &step_lds) <= 0 ||
+        const int wgs = epoch_step_wgs(p, b, p->cache ? 0 : epoch_next_b(p, k), &step_lds);
+        if (wgs == 2 && p->net->kind != DRGNN_GINET) {
+            any_split = true;
+            const int64_t xw = drgnn_net_step_xchg_elems(p->net->kind, b.maxN, b.maxC, hd->H) * b.B;
+            if (xw > xchg_words) xchg_words = xw;
+        }
+        if (wgs <= 0 ||
             step_lds > DRGNN_LDS_LIMIT || b.maxN > 32767 || b.maxE > 65535 ||
             (!p->cache && drgnn_topology_lds_bytes(b.maxN, b.maxE > 0 ? b.maxE : 1) > DRGNN_LDS_LIMIT))
             return DRGNN_E_CAPACITY;
@@ -1515,9 +1657,10 @@ int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
     }
     c->ptrs = p->cache ? nullptr : (int32_t*)take((nb > 0 ? nb : 1) * 3 * ((int64_t)p->batch_size + 1) * 4);
     c->readout = (float*)take(capB * hd->R * 4);
-    c->partials = (float*)take(capB * nbr * drgnn_net_partial_elems(p->net->kind, F) * 4);
+    c->partials = (float*)take(capB * (any_split ? 2 : nbr) * drgnn_net_partial_elems(p->net->kind, F) * 4);
     c->head_partials = (float*)take(capB * drgnn_head_compact_elems(hd->R, hd->H, hd->O) * 4);
-    c->xchg_bytes = capB * nbr * (int64_t)hd->H * 8;
+    c->xchg_bytes = capB * nbr * (int64_t)(hd->H > DRGNN_H2 ? hd->H : DRGNN_H2) * 8;
+    if (xchg_words * 8 > c->xchg_bytes) c->xchg_bytes = xchg_words * 8;
     c->xchg = (uint64_t*)take(c->xchg_bytes);
     c->bytes = o;
     return 0;
@@ -1532,12 +1675,13 @@ int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan) {
 
 // reduction of the step's slabs + optimiser update of mini-batch k: one launch, or (data parallel) gradient launch ->
 // the caller's exchange -> Adam launch
-static int epoch_update(const drgnn_epoch_plan* p, const EpochCarve& c, int64_t B, int64_t k, float* losses, void* stream) {
+static int epoch_update(const drgnn_epoch_plan* p, const EpochCarve& c, int64_t B, int64_t k, float* losses, void* stream,
+                        int slabs_per_graph = 0) {
     const drgnn_head_desc* hd = p->head;
     const int fused = p->exchange ? 0 : 1;
     int rc = drgnn_step_update(p->net, c.partials, B, p->g_conv1, p->g_conv2, c.head_partials, c.readout, hd->R, hd->H,
                                hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
-                               p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, fused, stream);
+                               p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, fused, slabs_per_graph, stream);
     if (rc || fused) return rc;
     if ((rc = p->exchange(p->exchange_user, k, B, stream))) return rc;
     return drgnn_adam_step(p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->step2, p->n_param, p->lr, p->beta1,
@@ -1572,12 +1716,14 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
             if (!train) tc.y = nullptr;
             drgnn_step_hints hints = {};
             hints.set_node_ptr = p->host_node_ptr; hints.set_edge_ptr = p->host_edge_ptr; hints.host_ids = p->host_ids + b.first;
+            const bool split = train && p->net->kind != DRGNN_GINET && epoch_step_wgs(p, b, 0, nullptr) == 2;
+            hints.topo_flags = train ? p->cache->flags : 0; hints.split = split ? 1 : 0;
             rc = drgnn_net_train_step_cached(p->net, &head, &tc, p->ids + b.first, b.B, b.maxN, b.maxE, b.maxC, p->step2,
                                              pred + b.first * hd->O, c.readout, train ? c.head_partials : nullptr,
                                              train ? c.partials : nullptr, c.xchg, &hints, stream);
             if (rc) return rc;
             if (!train) continue;
-            if ((rc = epoch_update(p, c, b.B, k, losses, stream))) return rc;
+            if ((rc = epoch_update(p, c, b.B, k, losses, stream, split ? 2 : 0))) return rc;
         }
         return 0;
     }
@@ -1593,6 +1739,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         r.max_nodes = b.maxN; r.max_edges = b.maxE;
         r.ws_i32 = u.ws_i32; r.ws_f32 = u.ws_f32; r.scratch_i32 = nullptr;
         r.set = p->set; r.ids = p->ids + b.first; r.x_out = u.x; r.y_out = train ? u.y : nullptr;
+        r.flags = (p->net->kind != DRGNN_GINET) ? DRGNN_TOPO_HIER : 0;      // (the node-split step kernels read it)
         return r;
     };
     EpochBatch cur, nxt;
@@ -1612,6 +1759,9 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         }
         // the slot offsets of this mini-batch are known here (host size tables): hand them to the launch
         drgnn_step_hints hints = {};
+        const bool split = train && p->net->kind != DRGNN_GINET && epoch_step_wgs(p, cur, more ? nxt.B : 0, nullptr) == 2;
+        hints.topo_flags = (train && p->net->kind != DRGNN_GINET) ? DRGNN_TOPO_HIER : 0;      // (what request() above asked the builder for)
+        hints.split = split ? 1 : 0;
         if (cur.B <= DRGNN_STEP_DIMS_MAX) {
             hn.resize((size_t)cur.B + 1); he.resize((size_t)cur.B + 1);
             hn[0] = 0; he[0] = 0;
@@ -1628,7 +1778,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
                                   more ? &req : nullptr, &hints, stream);
         if (rc) return rc;
         if (!train) { if (more) cur = nxt; continue; }
-        if ((rc = epoch_update(p, c, cur.B, k, losses, stream))) return rc;
+        if ((rc = epoch_update(p, c, cur.B, k, losses, stream, split ? 2 : 0))) return rc;
         if (more) cur = nxt;
     }
     return 0;

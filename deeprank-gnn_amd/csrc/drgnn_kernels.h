@@ -7,6 +7,7 @@
 #include "drgnn_head.h"
 #include "drgnn_step.h"
 #include "drgnn_step1.h"
+#include "drgnn_step2.h"
 #include "drgnn_layers.h"
 #include "drgnn_mcl.h"
 #include "drgnn_collate.h"
@@ -127,7 +128,8 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
         int len = C0;
         if (g == L.args.n_graphs - 1 && (int64_t)begin + C0 != L.args.len_cluster1) len = -1;
         if ((int64_t)begin + C0 > L.args.len_cluster1) len = -1;
-        topo_graph_level1(L.tv, L.args, g, n0, C0, L.args.cluster1 + begin, len, s, g);
+        topo_graph_level1(L.tv, L.args, g, n0, C0, L.args.cluster1 + begin, len, s, g, false,
+                          (L.args.flags & DRGNN_TOPO_HIER) ? L.tv.p[DRGNN_TI_CL0] + n0 : nullptr, N);
     }
 }
 
@@ -373,6 +375,47 @@ DEV void step_block_both(const StepLaunch& L, int g, float* lds) {
     net_step_graph_both<XF, GATHER, PAIRED, CLS>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC);
 }
 
+#ifndef DRGNN_EMU
+// sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h).  SPLIT = 2: the two halves of a graph are 8
+// block ids apart (same XCD: they read the same x tile and topology and hand each other pooled rows), graphs in groups
+// of 8 like GINet's branch workgroups.
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT>
+DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
+    int g, half;
+    if (SPLIT == 2) { g = ((blk >> 4) << 3) + (blk & 7); half = (blk >> 3) & 1; }
+    else { g = blk; half = 0; }
+    if (g >= L.a.n_graphs) return;
+    if (L.dims.count > 0) {
+        const int gi = GATHER ? L.dims.gi[g] : g;
+        GraphDims d;
+        d.n0 = L.dims.n0[g]; d.N = L.dims.n[g]; d.e0 = L.dims.e0[g]; d.E = L.dims.e[g];
+        d.rowbase = d.n0 + gi;
+        d.C = 0; d.E1 = 0; d.C1 = 0;
+        const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
+        const int32_t* hs = L.a.tv.p[DRGNN_TI_HSPLIT] + 4 * gi;
+        const int hk = (SPLIT == 2) ? hs[0] : 0, hq = (SPLIT == 2) ? hs[1] : 0, hn = (SPLIT == 2) ? hs[2] : 0;
+        net_step2_graph<KIND, XF, GATHER, CLS, SPLIT>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1,
+                                                      hk, hq, hn);
+        return;
+    }
+    const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;
+    const GraphDims d = net_dims(L.a.tv, gi);
+    const int32_t* hs = L.a.tv.p[DRGNN_TI_HSPLIT] + 4 * gi;
+    const int hk = (SPLIT == 2) ? WG_UNIFORM(hs[0]) : 0, hq = (SPLIT == 2) ? WG_UNIFORM(hs[1]) : 0, hn = (SPLIT == 2) ? WG_UNIFORM(hs[2]) : 0;
+    if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
+        // the caller's bounds were wrong: poison the outputs instead of overrunning LDS (the partner does the same: no wait)
+        if (half == 0) {
+            FOR_TID(c, L.a.hf.R) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + c] = DRGNN_NAN; }
+            float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+            FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
+        }
+        return;
+    }
+    net_step2_graph<KIND, XF, GATHER, CLS, SPLIT>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, false, 0, 0, 0, hk, hq, hn);
+}
+#endif
+
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
 struct UpdateArgs {
     ReduceArgs r;
@@ -527,6 +570,16 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
     if ((int)blockIdx.x < C.n_net) step_block_both<XF, GATHER, PAIRED, CLS>(C.step, blockIdx.x, smem_s1);
     else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s1);
+}
+// sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h) + the builder's workgroups
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step2_co_topo(StepCoLaunch C_by_value) {
+    extern __shared__ __attribute__((aligned(16))) float smem_s2[];
+    PHASE_BEGIN();
+    const StepCoLaunch& C = step_kernarg();
+    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
+    if ((int)blockIdx.x < C.n_net) step2_block<KIND, XF, GATHER, CLS, SPLIT>(C.step, blockIdx.x, smem_s2);
+    else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s2);
 }
 #ifdef DRGNN_KERNELS_MAIN
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
@@ -692,5 +745,17 @@ extern template __global__ void k_step1_co_topo<32, false, true>(StepCoLaunch);
 extern template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
 extern template __global__ void k_step1_co_topo<32, false, true, 1>(StepCoLaunch);      // (capacity-class LDS layout)
 extern template __global__ void k_step1_co_topo<32, true, true, 1>(StepCoLaunch);
+#define DRGNN_STEP2_EXTERN(K)                                                                   \
+    extern template __global__ void k_step2_co_topo<K, 32, false, 0, 1>(StepCoLaunch);          \
+    extern template __global__ void k_step2_co_topo<K, 32, true, 0, 1>(StepCoLaunch);           \
+    extern template __global__ void k_step2_co_topo<K, 32, false, 1, 1>(StepCoLaunch);          \
+    extern template __global__ void k_step2_co_topo<K, 32, true, 1, 1>(StepCoLaunch);           \
+    extern template __global__ void k_step2_co_topo<K, 32, false, 0, 2>(StepCoLaunch);          \
+    extern template __global__ void k_step2_co_topo<K, 32, true, 0, 2>(StepCoLaunch);           \
+    extern template __global__ void k_step2_co_topo<K, 32, false, 1, 2>(StepCoLaunch);          \
+    extern template __global__ void k_step2_co_topo<K, 32, true, 1, 2>(StepCoLaunch);
+DRGNN_STEP2_EXTERN(DRGNN_SGAT)
+DRGNN_STEP2_EXTERN(DRGNN_FOUT)
+#undef DRGNN_STEP2_EXTERN
 #endif
 #endif  // !DRGNN_EMU

@@ -53,6 +53,7 @@ struct StepArgs {
     int n_partial;
     HeadFused hf;                // hf.readout: [B][R] OUTPUT; hf.partials: [B][head_compact_floats]
     unsigned long long* xchg;    // [B][n_branch][H] tagged fc1 half-products (zero-initialised once by the owner)
+    int xchg_stride;             // node-split layout (drgnn_step2.h): exchange words per graph (step2_xchg_words)
     int32_t* step2;              // [0] steps completed so far (read)   [1] index of this step (written)   [2] sticky fault bits
     // cached-topology mode: slot g of the launch is graph gather_ids[g] of the workspace `tv` describes (a whole
     // resident set, ws_graphs graphs); null: slot g = graph g of a per-mini-batch workspace

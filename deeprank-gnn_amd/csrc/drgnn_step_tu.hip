@@ -22,6 +22,18 @@ template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
 // ... and the 32-wide paired form with the capacity-class LDS layout
 template __global__ void k_step1_co_topo<32, false, true, 1>(StepCoLaunch);
 template __global__ void k_step1_co_topo<32, true, true, 1>(StepCoLaunch);
+#elif DRGNN_TU_KIND == 5 || DRGNN_TU_KIND == 6
+// the node-split, aggregation-first step of sGAT (5) / FoutNet (6) (drgnn_step2.h): 32-wide, {mini-batch, cached} x
+// {run-time, capacity-class layout} x {one, two workgroups per graph}
+#define DRGNN_STEP2_K (DRGNN_TU_KIND == 5 ? DRGNN_SGAT : DRGNN_FOUT)
+template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 0, 1>(StepCoLaunch);
+template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 0, 1>(StepCoLaunch);
+template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 1, 1>(StepCoLaunch);
+template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 1, 1>(StepCoLaunch);
+template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 0, 2>(StepCoLaunch);
+template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 0, 2>(StepCoLaunch);
+template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 1, 2>(StepCoLaunch);
+template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 1, 2>(StepCoLaunch);
 #else
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
 // ... and the 32-wide kernels with the capacity-class LDS layout (net_step_graph: CLS = 1)

@@ -53,6 +53,9 @@ static inline void topo_layout(int64_t N, int64_t E, int64_t B, TopoLayout* L) {
     take(DRGNN_TI_CPTR1, B + 1);
     take(DRGNN_TI_ERR, 4);
     take(DRGNN_TI_GSTAT, 2 * B);
+    take(DRGNN_TI_HORD, N);
+    take(DRGNN_TI_HMP0, N + B);
+    take(DRGNN_TI_HSPLIT, 4 * B);
     L->i32[DRGNN_TI_COUNT] = o;
     int64_t f = 0;
     L->f32[DRGNN_TF_W0] = f; f += (E + 3) & ~(int64_t)3;
@@ -177,9 +180,10 @@ DEV int rank_below(const int* a, int lo, int hi, int me) {
     return rank;
 }
 // ---------------------------------------------------------------------------------
+// inv (optional): inv[item] = its sorted position
 template <class F>
 DEV void wg_bucket_sort(int n, int nb, F bucket_of, int* ptr, int* cur, int* tmp,
-                        int* slot_bucket, int* order, int* part, bool prezeroed = false) {
+                        int* slot_bucket, int* order, int* part, bool prezeroed = false, int* inv = nullptr) {
     if (!prezeroed) {      // callers that can clear ptr/cur in an earlier phase save this barrier
         FOR_TID(b, nb + 1) { ptr[b] = 0; cur[b] = 0; }
         BARRIER();
@@ -201,6 +205,7 @@ DEV void wg_bucket_sort(int n, int nb, F bucket_of, int* ptr, int* cur, int* tmp
         int rank = 0;
         for (int q = lo; q < hi; ++q) rank += (tmp[q] < me) ? 1 : 0;
         order[lo + rank] = me;
+        if (inv) inv[me] = lo + rank;
     }
     BARRIER();
 }
@@ -271,7 +276,7 @@ DEV void wg_rank_prepare(const int64_t* ids, int n, TopoScratch& s) {
 
 // `prepared`: the caller has run wg_rank_prepare(ids, n, s) and cleared fl[0..capF) in an earlier phase
 DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n, TopoScratch& s,
-                        bool prepared = false, bool with_members = true) {
+                        bool prepared = false, bool with_members = true, int* inv = nullptr) {
     long long mn, mx;
     if (prepared) {
         mn = LLONG_MAX; mx = LLONG_MIN;
@@ -334,7 +339,7 @@ DEV int wg_cluster_rank(const TopoView& tv, int graph, const int64_t* ids, int n
     if (with_members) {
         const int* cl = s.cl;
         wg_bucket_sort(n, C, [cl] LAMBDA_DEV(int i) { return cl[i]; }, s.mp, s.cur, s.t1, s.t2, s.mem,
-                       s.part, true);
+                       s.part, true, inv);
     }
     return C;
 }
@@ -378,6 +383,7 @@ struct TopoArgs {
     void* y_out;                  // [B]
     int64_t n_set;
     int n_feat, y_bytes;
+    int flags;                    // DRGNN_TOPO_* (include/drgnn.h)
 };
 
 // where slot g's index data lives: in the mini-batch tensors (global ids, shifted by n0) or in the resident set
@@ -435,15 +441,74 @@ DEV void topo_gather_rows(const TopoArgs& a, const TopoSrc& src, int g, int n0, 
     }
 }
 
+// ---- hierarchical node order (DRGNN_TI_HORD / HMP0 / HSPLIT; consumer: the node-split step kernels, drgnn_step2.h) ----
+// Nodes sorted by (depth-1 cluster of their depth-0 cluster, depth-0 cluster, node id) = a stable bucket sort of the nodes
+// by the POSITION q of their depth-0 cluster in the depth-1 member list (MEM1 lists the depth-0 clusters depth-1-major):
+// the bucket offsets are HMP0, the sorted items HORD.  cl0 [N]: depth-0 cluster rank of every node (scratch copy, or the
+// workspace's CL0); s.mem / s.mp: the depth-1 member lists just built; qpos = s.t4: position of every depth-0 cluster in
+// s.mem (the depth-1 sort's inverse; clusters it did not cover -- a flagged graph -- keep the initial last bucket: outputs
+// stay structurally valid, the graph is poisoned anyway).  topo_hier_init has cleared ptr = s.rp1, cur = s.nb and set
+// qpos in an earlier phase.  Four barriers: histogram | scan (2) | claim | rank.
+// Split point: the number k of leading depth-1 clusters whose node total is closest to N / 2 (smallest k on ties).
+DEV void topo_hier_init(int C, TopoScratch& s) {
+    FOR_TID(c, C + 1) { s.t4[c] = (C > 0) ? C - 1 : 0; s.rp1[c] = 0; s.nb[c] = 0; }
+}
+DEV void topo_hier(const TopoView& tv, int g, int n0, int N, int C, int C1, const int* cl0, TopoScratch& s) {
+    const int rowbase = n0 + g;
+    const int* qpos = s.t4;
+    int* ptr = s.rp1;
+    int* cur = s.nb;
+    int* tmp = s.t1;
+    int* slot_bucket = s.t2;
+    long long* best = (long long*)s.fl;      // (the depth-1 ranking is done with its flags; 16-byte aligned)
+    FOR_TID(i, N) { ATOMIC_ADD(&ptr[qpos[cl0[i]]], 1); }
+    FOR_TID(i, 1) { best[0] = LLONG_MAX; }
+    BARRIER();
+    wg_exscan(ptr, C + 1, s.part);
+    int32_t* g_hord = tv.p[DRGNN_TI_HORD] + n0;
+    int32_t* g_hmp = tv.p[DRGNN_TI_HMP0] + rowbase;
+    FOR_TID(i, N) {
+        const int b = qpos[cl0[i]];
+        const int pos = ptr[b] + ATOMIC_ADD(&cur[b], 1);
+        tmp[pos] = i;
+        slot_bucket[pos] = b;
+    }
+    FOR_TID(q, C + 1) { g_hmp[q] = ptr[q]; }
+    FOR_TID(k, C1 + 1) {
+        const int pos = ptr[imin(s.mp[k], C)];
+        int d = 2 * pos - N;
+        d = d < 0 ? -d : d;
+        ATOMIC_MIN64(&best[0], ((long long)d << 32) | (long long)k);
+    }
+    BARRIER();
+    FOR_TID(p, N) {
+        const int b = slot_bucket[p];
+        const int me = tmp[p];
+        const int lo = ptr[b], hi = ptr[b + 1];
+        int rank = 0;
+        for (int q = lo; q < hi; ++q) rank += (tmp[q] < me) ? 1 : 0;
+        g_hord[lo + rank] = me;
+    }
+    FOR_TID(i, 1) {
+        const int k = (int)(best[0] & 0xffffffffLL);
+        const int q = imin(s.mp[k], C);
+        int32_t* hs = tv.p[DRGNN_TI_HSPLIT] + 4 * g;
+        hs[0] = k; hs[1] = q; hs[2] = ptr[q]; hs[3] = C1;
+    }
+}
+
 // C0 = number of depth-0 clusters of the graph; sidx = this workgroup's status word
+// cl0: depth-0 cluster rank of every node for the hierarchical order (null: not built)
 DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0, int C0, const int64_t* ids1,
-                           int c1_len, TopoScratch& s, int sidx, bool prepared = false) {
+                           int c1_len, TopoScratch& s, int sidx, bool prepared = false, const int* cl0 = nullptr,
+                           int N = 0, bool hier_ready = false) {
     const int rowbase = n0 + g;
     if (c1_len != C0) {
         FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, sidx); }
     }
     const int n = imin(C0, imax(c1_len, 0));
-    const int C1 = wg_cluster_rank(tv, sidx, ids1, n, s, prepared);
+    if (cl0 != nullptr && !hier_ready) { topo_hier_init(C0, s); BARRIER(); }
+    const int C1 = wg_cluster_rank(tv, sidx, ids1, n, s, prepared, true, cl0 != nullptr ? s.t4 : nullptr);
     int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
     int32_t* g_mptr1 = tv.p[DRGNN_TI_MPTR1] + rowbase;
     int32_t* g_mem1 = tv.p[DRGNN_TI_MEM1] + n0;
@@ -451,6 +516,7 @@ DEV void topo_graph_level1(const TopoView& tv, const TopoArgs& a, int g, int n0,
     FOR_TID(c, C1 + 1) { g_mptr1[c] = s.mp[c]; }
     FOR_TID(i, 1) { tv.p[DRGNN_TI_NC1][g] = C1; }
     BARRIER();
+    if (cl0 != nullptr) topo_hier(tv, g, n0, N, C0, C1, cl0, s);
 }
 
 // role 0: everything in one workgroup.  With two workgroups per graph the work splits into two INDEPENDENT chains of
@@ -720,15 +786,21 @@ DEV int topo_clusters0(const TopoView& tv, int g, int n0, int N, const TopoSrc& 
     return C;
 }
 // depth-1 clusters + member lists of a graph with C depth-0 clusters (when the caller located this graph's ids)
-DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, int C, const TopoSrc& src, TopoScratch& s,
+// N: nodes of the graph; s.cl holds their depth-0 cluster ranks (saved to s.t5 here: the depth-1 ranking reuses s.cl)
+DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, int N, int C, const TopoSrc& src, TopoScratch& s,
                         int sidx) {
     if (a.cluster1 == nullptr || a.c1_ptr == nullptr) return;
+    const bool hier = (a.flags & DRGNN_TOPO_HIER) != 0;
     FOR_TID(v, s.capF) { s.fl[v] = 0; }
+    if (hier) {
+        FOR_TID(i, N) { s.t5[i] = s.cl[i]; }
+        topo_hier_init(C, s);
+    }
     const int b = a.c1_ptr[g];
     const int c1_len = a.c1_ptr[g + 1] - b;
     wg_rank_prepare(src.cl1, imin(C, imax(c1_len, 0)), s);
     BARRIER();
-    topo_graph_level1(tv, a, g, n0, C, src.cl1, c1_len, s, sidx, true);
+    topo_graph_level1(tv, a, g, n0, C, src.cl1, c1_len, s, sidx, true, hier ? s.t5 : nullptr, N, true);
 }
 
 // WEIGHTS: -1 = decided at run time (edge_attr and a weight workspace given); 0 = never (the builder co-launched with a
@@ -770,12 +842,12 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     }
     if (role == TOPO_ROLE_MEMBERS) {       // structure: only the cluster COUNT of depth 0 is needed for depth 1
         const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, false);
-        topo_clusters1(tv, a, g, n0, C, src, s, sidx);
+        topo_clusters1(tv, a, g, n0, N, C, src, s, sidx);
         return;
     }
     // pool (or everything): ranks + member lists of depth 0, then the pooled graph
     const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, true);
     BARRIER();
     topo_pool(tv, g, n0, e0, E, C, has_w, s);
-    if (role == TOPO_ROLE_ALL) topo_clusters1(tv, a, g, n0, C, src, s, g);
+    if (role == TOPO_ROLE_ALL) topo_clusters1(tv, a, g, n0, N, C, src, s, g);
 }

@@ -290,6 +290,7 @@ class ResidentGraphSet(object):
         import ctypes
         r.set = ctypes.cast(ctypes.pointer(self._desc), ctypes.c_void_p)
         r.ids, r.x_out, r.y_out = p(ids_dev), p(x), p(y)
+        r.flags = _lib.TOPO_HIER
         self.api.topology_build_request(r, _lib.current_stream(x))
         topo._inputs = None
         return topo, x, y
@@ -374,6 +375,7 @@ class TopologyCache(object):
             import ctypes
             r.set = ctypes.cast(ctypes.pointer(gset._desc), ctypes.c_void_p)
             r.ids, r.x_out, r.y_out = p(ids), None, None
+            r.flags = _lib.TOPO_HIER
             api.topology_build_request(r, _lib.current_stream(gset.x))
             topo._inputs = None
             self._keep = (ids, scratch)
@@ -381,6 +383,7 @@ class TopologyCache(object):
         d = _lib.TopologyCacheDesc()
         d.n_graphs, d.n_nodes, d.n_edges = G, N, E
         d.ws_i32, d.ws_f32, d.x = _lib._ptr(topo.ws_i32), _lib._ptr(topo.ws_f32), _lib._ptr(gset.x)
+        d.flags = int(getattr(topo, "flags", 0))
         self._desc = d
         self.refresh_targets()
 

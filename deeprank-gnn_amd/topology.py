@@ -34,6 +34,7 @@ class Topology(object):
         self.max_edges = 0
         self.max_c0 = 0
         self.has_level1 = False
+        self.flags = _lib.TOPO_HIER      # what the last build put into the workspace (drgnn_topology_request.flags)
         self._finalized = False
 
     # ---------------------------------------------------------------------------
@@ -101,7 +102,7 @@ class Topology(object):
                 topo.check()
         return topo
 
-    def request(self):
+    def request(self, flags=None):
         """The builder's arguments as a ``drgnn_topology_request`` (to have a body launch of the
         PREVIOUS mini-batch build this topology in the same launch)."""
         edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch = self._inputs
@@ -113,6 +114,8 @@ class Topology(object):
         r.len_cluster1 = 0 if cluster1 is None else cluster1.numel()
         r.max_nodes, r.max_edges = self.max_nodes, self.max_edges
         r.ws_i32, r.ws_f32, r.scratch_i32 = p(self.ws_i32), p(self.ws_f32), p(scratch)
+        r.flags = _lib.TOPO_HIER if flags is None else int(flags)
+        self.flags = int(r.flags)
         self._finalized = False
         return r
 
@@ -122,6 +125,7 @@ class Topology(object):
         depends on index tensors, never on parameters).  The input tensors captured at
         construction are re-read, so refreshing them in place refreshes the topology."""
         edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch = self._inputs
+        self.flags = _lib.TOPO_HIER          # (drgnn_topology_build always builds the hierarchical order)
         self.api.topology_build(edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,
                                 self.n_nodes, self.n_edges, 0 if cluster1 is None else cluster1.numel(),
                                 self.n_graphs, self.max_nodes, self.max_edges, self.ws_i32, self.ws_f32,

@@ -74,6 +74,8 @@ class FusedTrainer(object):
         self.step = self.step2[:1]
         self.fused_step = True       # one launch for fwd + head + bwd whenever a graph fits LDS
         self._xchg = {}              # readout exchange words of the fused step, per batch size
+        # what a co-built topology must hold: the hierarchical node order only for the nets whose step kernels read it
+        self.topo_flags = 0 if self.kind == _lib.GINET else _lib.TOPO_HIER
         self._desc_cache, self._slab_cache = {}, {}
         self._epoch_scratch = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -149,7 +151,26 @@ class FusedTrainer(object):
                                            0 if next_topo is None else next_topo.n_graphs)
         return wgs > 0 and 0 < need <= 160 * 1024
 
-    def _fused_prepare(self, batch, topo):
+    def _layout(self, n_feat, max_nodes, max_edges, max_c0, B, train, topo_flags, dev, x=None):
+        """Launch layout of a fused step: (slabs per graph, exchange buffer, split flag).  GINet: two slabs per graph in
+        every layout.  sGAT / FoutNet: the node-split layout (two workgroups = two slabs per graph, drgnn_step2.h) for
+        training launches whenever drgnn_net_step_plan offers it -- assuming a co-built topology of the same size -- and
+        the topology holds the hierarchical order."""
+        api, nb = self.api, self.n_branch
+        split = 0
+        if nb == 1 and train and (topo_flags & _lib.TOPO_HIER) and (x is None or x.data_ptr() % 16 == 0):
+            wgs, _ = api.net_step_plan(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O, B, B)
+            split = 1 if wgs == 2 else 0
+        xchg = None
+        if nb > 1 or split:
+            words = api.net_step_xchg_elems(self.kind, max_nodes, max_c0, self.H) if split else nb * max(self.H, 32)
+            key = (B, words)
+            xchg = self._xchg.get(key)
+            if xchg is None:
+                xchg = self._xchg[key] = torch.zeros((max(B, 1), words), dtype=torch.int64, device=dev)
+        return (2 if split else nb), xchg, split
+
+    def _fused_prepare(self, batch, topo, train=True):
         """Buffers and descriptors of one fused step (allocation only, no launch)."""
         api = self.api
         x = batch.x.contiguous()
@@ -159,11 +180,8 @@ class FusedTrainer(object):
         y = getattr(batch, "y", None)
         if y is not None:
             y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
-        xchg = None
-        if nb > 1:
-            xchg = self._xchg.get(B)
-            if xchg is None:
-                xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * max(self.H, 32)), dtype=torch.int64, device=dev)
+        topo_flags = int(getattr(topo, "flags", 0))
+        slabs, xchg, split = self._layout(n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, B, train, topo_flags, dev, x)
         # descriptors only depend on the (fixed) parameter storage and the feature width: built once
         ck = self._desc_cache.get(n_feat)
         if ck is None:
@@ -175,22 +193,23 @@ class FusedTrainer(object):
             ck = self._desc_cache[n_feat] = (g1, g2, _describe(self.kind, n_feat, self.live, nb))
         g1, g2, desc = ck
         # slabs are internal scratch of the step: one set per batch size (predictions stay per-step tensors)
-        bk = self._slab_cache.get((B, n_feat))
+        bk = self._slab_cache.get((B, n_feat, slabs))
         if bk is None:
-            bk = self._slab_cache[(B, n_feat)] = (
+            bk = self._slab_cache[(B, n_feat, slabs)] = (
                 torch.empty((B, H2 * nb), dtype=torch.float32, device=dev),
-                torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
+                torch.empty((max(B * slabs, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
                 torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
         readout, partials, hp = bk
         # host copies of the mini-batch's offsets (Batch.from_data_list / the resident set record them): they travel in
         # the launch arguments, so a workgroup need not fetch them from the workspace first
-        hints = None
         bd = getattr(batch, "__dict__", {})
         hn, he = bd.get("_host_node_ptr"), bd.get("_host_edge_ptr")
         if hn is not None and he is not None and len(hn) == B + 1 and B <= 64:
-            hints = _lib.step_hints(node_ptr=hn, edge_ptr=he)
+            hints = _lib.step_hints(node_ptr=hn, edge_ptr=he, topo_flags=topo_flags if train else 0, split=split)
+        else:
+            hints = _lib.step_hints(topo_flags=topo_flags if train else 0, split=split)
         return dict(
-            hints=hints,
+            hints=hints, slabs=slabs,
             x=x, y=y, topo=topo, B=B, n_nodes=n_nodes, xchg=xchg, g1=g1, g2=g2, desc=desc,
             stream=_lib.current_stream(x), pred=torch.empty((B, self.O), dtype=torch.float32, device=dev),
             readout=readout, partials=partials, hp=hp)
@@ -201,7 +220,7 @@ class FusedTrainer(object):
         self.api.net_train_step(c["desc"], self._head_desc(True), c["x"], c["y"], self.step2, t.ws_i32, t.ws_f32,
                                 c["n_nodes"], t.n_edges, c["B"], t.max_nodes, t.max_edges, t.max_c0, c["pred"],
                                 c["readout"], c["hp"], c["partials"], c["xchg"], c["stream"],
-                                next_topology=None if next_topo is None else next_topo.request(),
+                                next_topology=None if next_topo is None else next_topo.request(self.topo_flags),
                                 hints=None if c.get("hints") is None else c["hints"][0])
 
     def _fused_launch_update(self, c, apply_adam=True, lr=None):
@@ -209,7 +228,8 @@ class FusedTrainer(object):
         self.api.step_update(c["desc"], c["partials"], c["B"], c["g1"], c["g2"], c["hp"], c["readout"], self.R,
                              self.H, self.O, self.head_grad_offset, self.flat_p, self.flat_g, self.exp_avg,
                              self.exp_avg_sq, self.step2, self.loss, self.lr if lr is None else lr,
-                             self.betas[0], self.betas[1], self.eps, c["stream"], apply_adam=apply_adam)
+                             self.betas[0], self.betas[1], self.eps, c["stream"], apply_adam=apply_adam,
+                             slabs_per_graph=c.get("slabs", 0))
 
     def _fused(self, batch, topo, apply_adam, next_topo):
         c = self._fused_prepare(batch, topo)
@@ -220,7 +240,7 @@ class FusedTrainer(object):
         return self.loss
 
     # -- cached topology (declared mode): a mini-batch is a list of graph numbers of a resident set ---------------
-    def _cached_prepare(self, cache, ids, ids_dev=None):
+    def _cached_prepare(self, cache, ids, ids_dev=None, train=True):
         """Buffers of one step over the graphs ``ids`` (host numbers; ``ids_dev``: the same as int32 on the device) of
         ``cache`` (resident.TopologyCache)."""
         import numpy as np
@@ -237,11 +257,8 @@ class FusedTrainer(object):
         wgs, need = api.net_step_plan(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O, B)
         if not (wgs > 0 and 0 < need <= 160 * 1024):
             raise _lib.DrgnnError("a graph of this mini-batch does not fit the fused step kernel's LDS budget")
-        xchg = None
-        if nb > 1:
-            xchg = self._xchg.get(B)
-            if xchg is None:
-                xchg = self._xchg[B] = torch.zeros((max(B, 1), nb * max(self.H, 32)), dtype=torch.int64, device=dev)
+        topo_flags = int(getattr(cache.topo, "flags", 0))
+        slabs, xchg, split = self._layout(n_feat, max_nodes, max_edges, max_c0, B, train, topo_flags, dev, gset.x)
         ck = self._desc_cache.get(n_feat)
         if ck is None:
             g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
@@ -251,16 +268,17 @@ class FusedTrainer(object):
                 _fill_grads(g2[b], self.kind, l2, H1, H2)
             ck = self._desc_cache[n_feat] = (g1, g2, _describe(self.kind, n_feat, self.live, nb))
         g1, g2, desc = ck
-        bk = self._slab_cache.get((B, n_feat))
+        bk = self._slab_cache.get((B, n_feat, slabs))
         if bk is None:
-            bk = self._slab_cache[(B, n_feat)] = (
+            bk = self._slab_cache[(B, n_feat, slabs)] = (
                 torch.empty((B, H2 * nb), dtype=torch.float32, device=dev),
-                torch.empty((max(B * nb, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
+                torch.empty((max(B * slabs, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
                 torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
         readout, partials, hp = bk
         # (beyond 64 graphs the offsets no longer travel in the kernel arguments, but the library still range-checks the ids)
-        hints = _lib.step_hints(set_node_ptr=gset.node_ptr, set_edge_ptr=gset.edge_ptr, ids=ids)
-        return dict(hints=hints,
+        hints = _lib.step_hints(set_node_ptr=gset.node_ptr, set_edge_ptr=gset.edge_ptr, ids=ids,
+                                topo_flags=topo_flags if train else 0, split=split)
+        return dict(hints=hints, slabs=slabs,
                     cache=cache, ids_dev=ids_dev, B=B, bounds=(max_nodes, max_edges, max_c0), xchg=xchg, g1=g1, g2=g2,
                     desc=desc, stream=_lib.current_stream(gset.x), readout=readout, partials=partials, hp=hp,
                     pred=torch.empty((B, self.O), dtype=torch.float32, device=dev))
@@ -287,7 +305,7 @@ class FusedTrainer(object):
 
     @torch.no_grad()
     def predict_cached(self, cache, ids, ids_dev=None):
-        c = self._cached_prepare(cache, ids, ids_dev)
+        c = self._cached_prepare(cache, ids, ids_dev, train=False)
         self._cached_launch_step(c, False)
         return c["pred"]
 
@@ -321,7 +339,7 @@ class FusedTrainer(object):
         api.net_backward_fused_head(desc, self._head_desc(True), x, readout, y, self.step, topo.ws_i32,
                                     topo.ws_f32, n_nodes, topo.n_edges, B, topo.max_nodes, topo.max_edges,
                                     topo.max_c0, xp, arg0, arg1, pred, hp, None, partials, scratch, stream,
-                                    next_topology=None if next_topo is None else next_topo.request())
+                                    next_topology=None if next_topo is None else next_topo.request(self.topo_flags))
         api.train_update(desc, partials, B, g1, g2, hp, self.R, self.H, self.O, self.head_grad_offset,
                          self.flat_p, self.flat_g, self.exp_avg, self.exp_avg_sq, self.step, self.loss,
                          self.lr, self.betas[0], self.betas[1], self.eps, stream, apply_adam=apply_adam)
@@ -644,11 +662,11 @@ class FusedTrainer(object):
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
         if self._can_fuse(topo, batch.x.shape[1], next_topo):
-            c = self._fused_prepare(batch, topo)
+            c = self._fused_prepare(batch, topo, train=False)
             api.net_train_step(c["desc"], self._head_desc(False), c["x"], None, self.step2, topo.ws_i32, topo.ws_f32,
                                c["n_nodes"], topo.n_edges, c["B"], topo.max_nodes, topo.max_edges, topo.max_c0,
                                c["pred"], c["readout"], None, None, c["xchg"], c["stream"],
-                               next_topology=None if next_topo is None else next_topo.request(),
+                               next_topology=None if next_topo is None else next_topo.request(self.topo_flags),
                                hints=None if c.get("hints") is None else c["hints"][0])
             return c["pred"]
         if next_topo is not None:

@@ -42,6 +42,7 @@ extern "C" {
 #define DRGNN_S_CLUSTER1_LEN  8  /* len(cluster1) != number of depth-0 clusters          */
 /* fault bits of step2[2] (fused training step) */
 #define DRGNN_FAULT_EXCHANGE  1  /* a GINet branch workgroup waited in vain for its partner's half of fc1 (value = NaN) */
+#define DRGNN_FAULT_SPLIT     2  /* a half-graph workgroup of the node-split layout waited in vain for its partner's hand-off */
 
 /* layer kinds (what "conv" means) */
 #define DRGNN_GINET 0  /* z_i = sum_{e:row=i} W x_col            ginet.py:50-73 (alpha == 1)   */
@@ -84,6 +85,15 @@ enum drgnn_topo_i32 {
     DRGNN_TI_CPTR1,      /* [B+1]  exclusive scan of NC1                                     */
     DRGNN_TI_ERR,        /* [4]    [0] batch-level status bits (offset derivation)           */
     DRGNN_TI_GSTAT,      /* [2B]   per-graph status bits (edge half, member half), rewritten by every build */
+    /* Hierarchical node order (built with depth 1): nodes sorted by (depth-1 cluster of their depth-0 cluster, depth-0
+     * cluster, node id), i.e. the members of a depth-0 cluster are consecutive positions and the depth-0 clusters of a
+     * depth-1 cluster are consecutive runs, in the order of MEM1.  The node-split step kernels (csrc/drgnn_step2.h) keep
+     * their rows in this order: cluster maxima run over contiguous rows and a prefix of the depth-1 clusters is a prefix
+     * of the positions (what lets two workgroups share one graph with both poolings local). */
+    DRGNN_TI_HORD,       /* [N]    local node id at hierarchical position p                                      */
+    DRGNN_TI_HMP0,       /* [N+B]  first position of the q-th depth-0 cluster IN MEM1 ORDER, q = 0..C0            */
+    DRGNN_TI_HSPLIT,     /* [4B]   per graph {k, MPTR1[k], HMP0[MPTR1[k]], C1}: k = the number of leading depth-1
+                                   clusters whose node total is closest to N/2 (the two-workgroup split point)   */
     DRGNN_TI_COUNT
 };
 enum drgnn_topo_f32 {
@@ -308,7 +318,12 @@ typedef struct drgnn_topology_request {
      * gathers the slots' node features into x_out [n_nodes, F] and targets into y_out [n_graphs] (either may be
      * NULL).  Pooled edge weights are built when ws_f32 and set->edge_attr are both given. */
     const drgnn_graph_set* set; const int32_t* ids; float* x_out; void* y_out;
+    int32_t flags, reserved;      /* DRGNN_TOPO_* below */
 } drgnn_topology_request;
+/* request flags.  DRGNN_TOPO_HIER: also build the hierarchical node order (DRGNN_TI_HORD / HMP0 / HSPLIT; needs cluster1) --
+ * what the node-split step kernels of the single-branch nets consume (4 more phases on the builder's member-list chain, so
+ * callers that never run those kernels -- GINet -- leave it out).  drgnn_topology_build always builds it. */
+#define DRGNN_TOPO_HIER 1
 /* drgnn_topology_build from a request (either mode), own launch. */
 int drgnn_topology_build_request(const drgnn_topology_request* request, void* stream);
 /* Slot offset tables of EVERY mini-batch of an epoch in one launch: mini-batch k = ids[k*batch_size, ...) gets
@@ -377,10 +392,10 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   readout   OUT [B, 32*n_branch]; pred OUT [B, O]
  *   head_partials OUT [B][drgnn_head_compact_elems]: [dhid H][dW_fc2 O*H][db_fc2 O][loss][weight]
  *             (dW_fc1 = dhid^T readout is formed by drgnn_step_update)
- *   partials  OUT [B*n_branch][drgnn_net_partial_elems]
- *   xchg      uint64 [B, n_branch, H] (H >= 32), zero-filled ONCE by the caller and then left alone: the two
- *             branch workgroups of a GINet graph hand each other their 32 readout values through it
- *             (may be NULL when n_branch == 1)
+ *   partials  OUT [B*n_branch][drgnn_net_partial_elems]  (split layout: [B*2][...], one slab per half graph)
+ *   xchg      uint64 [B][drgnn_net_step_xchg_elems], zero-filled ONCE by the caller and then left alone: the two
+ *             branch workgroups of a GINet graph hand each other their 32 readout values through it, the two half-graph
+ *             workgroups of the split layout their pooled rows (may be NULL when n_branch == 1 and hints->split == 0)
  * head->train == 0: inference -- forward + head only (dropout off), writes pred and readout; target,
  * head_partials and partials may be NULL and the step counters are left alone.
  * Needs max_nodes/max_edges/max_c0 bounds; returns DRGNN_E_CAPACITY when a graph of that size does
@@ -394,7 +409,22 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
 typedef struct drgnn_step_hints {
     const int32_t* host_node_ptr; const int32_t* host_edge_ptr;       /* per mini-batch (drgnn_net_train_step) */
     const int64_t* set_node_ptr; const int64_t* set_edge_ptr; const int32_t* host_ids;   /* cached mode */
+    /* What the caller vouches for (both 0: the behaviour of callers that know nothing of the node-split kernels):
+     * topo_flags: the DRGNN_TOPO_* flags the topology workspace was BUILT with (DRGNN_TOPO_HIER lets sGAT / FoutNet steps run
+     *             the aggregation-first kernels, csrc/drgnn_step2.h);
+     * split:      1 = run the TWO-workgroups-per-graph layout of a single-branch net (drgnn_net_step_plan returned 2): the
+     *             caller sized `partials` for 2 slabs per graph and `xchg` for drgnn_net_step_xchg_elems words per graph and
+     *             will pass slabs_per_graph = 2 to drgnn_step_update.  DRGNN_E_CAPACITY if the launch cannot be laid out so. */
+    int32_t topo_flags, split;
 } drgnn_step_hints;
+/* uint64 exchange words per graph the fused step needs for these bounds (GINet: n_branch x max(H, 32); the split layout
+ * of sGAT / FoutNet: two hand-offs of max_c0 x 16 values per half + the partial readouts) */
+int64_t drgnn_net_step_xchg_elems(int32_t kind, int32_t max_nodes, int32_t max_c0, int32_t H);
+/* 1: TRAINING launches of this shape on a topology built with DRGNN_TOPO_HIER (drgnn_step_hints.topo_flags) are stepped by
+ * the aggregation-first kernels of csrc/drgnn_step2.h; 0: by the kernels of csrc/drgnn_step.h.  Host-side only (lets tests and
+ * bench.py state which kernel family they exercised). */
+int32_t drgnn_net_step_family(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t H,
+                              int32_t O);
 int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                  int32_t max_c0, int32_t R, int32_t H, int32_t O);
 int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O);
@@ -408,8 +438,10 @@ int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int
  * same edge_index).  Returns the workgroups per graph -- 2: GINet's branches run in two
  * workgroups that exchange their readouts, taken ONLY while all 2 * n_graphs (+ co-launched builder) workgroups are
  * resident at once (one workgroup per CU), because HIP promises nothing about dispatch order; 1: one workgroup per graph
- * (sGAT / FoutNet always; GINet beyond that size: both branches one after the other, staged once, no cross-workgroup
- * wait) -- or 0 when the bounds are outside the fused kernels (use the launch pair).  *lds_bytes: LDS one workgroup of
+ * (GINet beyond that size: both branches one after the other, staged once, no cross-workgroup wait; sGAT / FoutNet beyond
+ * that size or outside the 32-wide specialised shape) -- sGAT / FoutNet: 2 = the node-split layout (csrc/drgnn_step2.h: each
+ * workgroup owns the depth-1 clusters of one half of the graph; TRAINING launches on a topology built with DRGNN_TOPO_HIER
+ * only, requested through drgnn_step_hints.split) -- or 0 when the bounds are outside the fused kernels (use the launch pair).  *lds_bytes: LDS one workgroup of
  * that layout needs (drgnn_net_train_step returns DRGNN_E_CAPACITY beyond 160 KiB). */
 int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t R,
                             int32_t H, int32_t O, int64_t n_graphs, int64_t co_built_graphs, int64_t* lds_bytes);
@@ -418,7 +450,10 @@ int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int
  * 3 / 4 = the one-workgroup layout runs branch after branch / both branches per phase whenever that fits LDS (default 4);
  * 5 / 6 = batches whose maxima lie inside the capacity class (200 nodes, 1024 edges, 52 depth-0 clusters per graph, feature
  * widths 17 .. 32, reference head widths) are stepped by the kernels with the compile-time LDS layout / never (default 5;
- * the same arithmetic in the same order: bit-identical results, 0.2 - 0.4 us per step apart). */
+ * the same arithmetic in the same order: bit-identical results, 0.2 - 0.4 us per step apart);
+ * 7 / 8 = sGAT / FoutNet steps may take the aggregation-first kernels (drgnn_step2.h) where the caller vouches for the
+ * hierarchical order / never (default 7; 8: drgnn_net_step_plan never answers 2 for them);
+ * 9 / 10 = ... with two workgroups per graph where drgnn_net_step_plan offers it / never split (default 9). */
 int32_t drgnn_set_step_layout(int32_t mode);
 int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head, const float* x,
                          const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
@@ -430,12 +465,14 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head,
 /* drgnn_train_update for the slabs of drgnn_net_train_step: also forms dW_fc1 from head_partials'
  * dhid rows and readout, applies Adam with step index step2[1] and commits step2[0] = step2[1]
  * (also when apply_adam = 0: data parallel, all-reduce + drgnn_adam_step(step2) follow). */
+/* slabs_per_graph: conv slabs per graph in conv_partials -- 0 = n_branch (every layout but one); 2 for the split layout of a
+ * single-branch net (drgnn_step_hints.split). */
 int drgnn_step_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
                       drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
                       const float* readout, int32_t R, int32_t H, int32_t O, int64_t head_offset,
                       float* flat_param, float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
                       int32_t* step2, float* loss, float lr, float beta1, float beta2, float eps,
-                      int32_t apply_adam, void* stream);
+                      int32_t apply_adam, int32_t slabs_per_graph, void* stream);
 
 /* ---- graclus ---------------------------------------------------------------------
  * Greedy maximal matching of every graph of a built topology (CSR0), the clustering the README's custom net
@@ -502,7 +539,8 @@ typedef struct drgnn_topology_cache {
     int64_t n_graphs, n_nodes, n_edges;          /* of the WHOLE set = the shape the workspace was laid out for */
     const int32_t* ws_i32; const float* ws_f32;  /* ws_f32 may be NULL (nets without edge weights) */
     const float* x;                              /* [n_nodes, F] node features, graph-major (the set's x) */
-    const void* y; int32_t y_bytes, reserved;    /* [n_graphs] targets: 4 = float32, 8 = int64; may be NULL (inference) */
+    const void* y; int32_t y_bytes, flags;       /* [n_graphs] targets: 4 = float32, 8 = int64; may be NULL (inference);
+                                                    flags: the DRGNN_TOPO_* flags the workspace was built with */
 } drgnn_topology_cache;
 /* drgnn_net_train_step over the graphs ids[0..n_graphs) of a cached set: same outputs, same arithmetic (slot g
  * of every output = graph ids[g]); max_* bound the graphs of THIS mini-batch. */

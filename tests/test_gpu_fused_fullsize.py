@@ -182,11 +182,9 @@ def test_fused_step_batches_beyond_the_argument_table(net_name, n_graphs):
     # workgroup ever waits for another one, whatever the dispatch order
     wgs, _ = tr.api.net_step_plan(tr.kind, 32, topo.max_nodes, topo.max_edges, topo.max_c0, tr.R, tr.H, tr.O, n_graphs, n_graphs)
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    if net_name == "GINet":
-        # two workgroups per graph ONLY if they and the co-launched builder (then one workgroup per graph) are all resident
-        assert wgs == (2 if 2 * n_graphs + n_graphs <= cus else 1), (wgs, n_graphs, cus)
-    else:
-        assert wgs == 1, wgs
+    # two workgroups per graph ONLY if they and the co-launched builder (then one workgroup per graph) are all resident:
+    # GINet's branch workgroups, and the half-graph workgroups of the node-split layout of sGAT / FoutNet (drgnn_step2.h)
+    assert wgs == (2 if 2 * n_graphs + n_graphs <= cus else 1), (wgs, n_graphs, cus)
     loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
     torch.cuda.synchronize()
     assert tr.faults() == 0
@@ -407,3 +405,130 @@ def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, c
     for a, b, name in zip(out[0], out[1], ("parameters", "exp_avg_sq", "loss", "predictions")):
         np.testing.assert_array_equal(a, b, err_msg=name)
     assert np.isfinite(out[0][0]).all()
+
+
+# ---- sGAT / FoutNet: the three kernel families (round-3 kernel / aggregation first, one workgroup / node split) --------------
+AF_LAYOUTS = {"old": (8,), "af1": (7, 10), "af2": (7, 9)}
+
+
+def _with_layout(api, name):
+    for m in AF_LAYOUTS[name]:
+        api.set_step_layout(m)
+
+
+@pytest.mark.parametrize("layout", ["old", "af1", "af2"])
+@pytest.mark.parametrize("net_name", ["sGAT", "FoutNet"])
+def test_single_branch_step_families_syn64_match_oracle_elementwise(net_name, layout):
+    """sGAT / FoutNet at the benchmarked shape through every kernel family: the round-3 kernel (drgnn_step.h), the
+    aggregation-first kernel with one workgroup per graph and with the graph split between two workgroups that exchange
+    pooled rows (drgnn_step2.h; sGAT.py:62-93,114-138, foutnet.py:56-82,103-125).  Loss, predictions and EVERY gradient
+    element vs the oracle; three Adam steps through the ping-ponged launches vs torch.optim.Adam; the split launch is
+    bit-reproducible."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.topology import Topology
+    dev = _dev()
+    api = _lib.get()
+    batch_cpu = synth.make_batch(0, 64)
+    params = cpu_ref.init_params(net_name, 32, 1, 1, seed=11)
+    kw = _fw_kwargs(net_name)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **kw)
+    lazy = Lazy64(net_name, params, batch_cpu, **kw)
+    batch = batch_cpu.clone().to(dev)
+    need_w = net_name == "sGAT"
+    _with_layout(api, layout)
+    try:
+        net, tr = _trainer(net_name, params)
+        topo = Topology.from_batch(batch, need_weights=need_w)
+        nxt = Topology.from_batch(batch, need_weights=need_w, build=False)
+        c = tr._fused_prepare(batch, topo)
+        assert c["slabs"] == (2 if layout == "af2" else 1) and c["hints"][0].split == (1 if layout == "af2" else 0)
+        fam = api.net_step_family(tr.kind, 32, topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O)
+        assert fam == (0 if layout == "old" else 1)
+        loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
+        torch.cuda.synchronize()
+        stats = new_stats()
+        check_step("%s SYN64 %s" % (net_name, layout), lazy, loss, tr.last_pred.cpu().numpy(), _grads_of(net), ref_loss,
+                   ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()}, stats)
+        assert_arbiter_rate(stats, "%s %s" % (net_name, layout))
+        assert tr.faults() == 0
+        g1 = {k: v.copy() for k, v in _grads_of(net).items()}
+        loss2 = tr.compute_gradients(batch, topo=nxt)          # the co-built topology, same launch layout: bit-identical
+        assert float(loss2) == float(loss)
+        for k, v in _grads_of(net).items():
+            assert np.array_equal(v, g1[k]), k
+        # three optimiser steps
+        leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        opt = torch.optim.Adam(list(leaves.values()), lr=0.01)
+        net, tr = _trainer(net_name, params, lr=0.01)
+        topos = [topo, nxt]
+        for it in range(3):
+            opt.zero_grad()
+            pred = cpu_ref.FORWARD[net_name](leaves, batch_cpu, **kw)
+            lref = F.mse_loss(pred.reshape(-1), batch_cpu.y)
+            lref.backward()
+            opt.step()
+            got = tr.train_step(batch, topo=topos[it & 1], next_topo=topos[1 - (it & 1)])
+            np.testing.assert_allclose(float(got), float(lref.detach()), rtol=TOL)
+        sd = net.state_dict()
+        for k, v in leaves.items():
+            np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=TOL, atol=TOL, err_msg=k)
+    finally:
+        api.set_step_layout(7)
+        api.set_step_layout(9)
+
+
+@pytest.mark.parametrize("layout", ["af1", "af2"])
+@pytest.mark.parametrize("net_name", ["sGAT", "FoutNet"])
+def test_single_branch_step_families_ragged_batches(net_name, layout):
+    """The aggregation-first kernels on ragged batches (tests/step_check.py: graphs of 1 .. 49 nodes, a single-node graph
+    that leaves one half of the split EMPTY, isolated nodes -> FoutNet's NaN rows / sGAT's bias rows, self loops, duplicate
+    edges, non-consecutive cluster ids), classification and regression, feature widths 20 / 28 padded to 32: vs the round-3
+    kernel on the same inputs (itself pinned on the goldens and the oracle) within the north-star tolerance, NaN pattern
+    equal."""
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    from test_gpu_parity import build
+    dev = _dev()
+    api = _lib.get()
+    rng = np.random.default_rng(5)
+    from step_check import ragged_batch
+    for seed, (n_feat, task) in enumerate(((32, "reg"), (20, "class"), (28, "reg"))):
+        batch_cpu = ragged_batch(seed, n_feat)          # 7 graphs: 1 .. 49 nodes, a single-node graph, isolated nodes, self loops, duplicates
+        batch_cpu.y = torch.arange(batch_cpu.num_graphs, dtype=torch.float32) * 0.3 - 1.0
+        n_out = 1 if task == "reg" else 3
+        params = cpu_ref.init_params(net_name, n_feat, n_out, 1, seed=4)
+        if task == "class":
+            batch_cpu.y = torch.from_numpy(rng.integers(0, 3, size=int(batch_cpu.y.shape[0]))).long()
+        batch = batch_cpu.clone().to(dev)
+        need_w = net_name == "sGAT"
+        results = {}
+        for lay in ("old", layout):
+            _with_layout(api, lay)
+            try:
+                net = build(net_name, params, n_out)
+                tr = FusedTrainer(net, lr=0.01, task=task)
+                topo = Topology.from_batch(batch, need_weights=need_w)
+                assert tr._can_fuse(topo, n_feat)
+                fam = api.net_step_family(tr.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O)
+                assert fam == (0 if lay == "old" else 1), (lay, fam)
+                c = tr._fused_prepare(batch, topo)
+                assert c["hints"][0].split == (1 if lay == "af2" else 0)
+                loss = tr.compute_gradients(batch, topo=topo)
+                torch.cuda.synchronize()
+                assert tr.faults() == 0
+                results[lay] = (float(loss), tr.last_pred.cpu().numpy().copy(), _grads_of(net))
+            finally:
+                api.set_step_layout(7)
+                api.set_step_layout(9)
+        (l0, p0, g0), (l1, p1, g1) = results["old"], results[layout]
+        assert np.isnan(l0) == np.isnan(l1)
+        if not np.isnan(l0):
+            np.testing.assert_allclose(l1, l0, rtol=TOL)
+        assert np.array_equal(np.isnan(p0), np.isnan(p1))
+        np.testing.assert_allclose(np.nan_to_num(p1), np.nan_to_num(p0), rtol=TOL, atol=TOL)
+        for k in g0:
+            assert np.array_equal(np.isnan(g0[k]), np.isnan(g1[k])), k
+            scale = max(1.0, float(np.nanmax(np.abs(g0[k]))) if g0[k].size else 1.0)
+            np.testing.assert_allclose(np.nan_to_num(g1[k]), np.nan_to_num(g0[k]), rtol=TOL, atol=TOL * scale, err_msg=k)

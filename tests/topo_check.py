@@ -9,7 +9,7 @@ def expand(topo):
     a = {k: topo.array(k).cpu().numpy() for k in
          ("NPTR", "EPTR", "ROWPTR0", "COL0", "EID0", "COLPTR0", "ROWIDX0", "TSLOT0", "CL0", "NC0",
           "MPTR0", "MEM0", "ROWPTR1", "COL1", "NE1", "COLPTR1", "ROWIDX1", "TSLOT1", "CL1", "NC1",
-          "MPTR1", "MEM1")}
+          "MPTR1", "MEM1", "HORD", "HMP0", "HSPLIT")}
     if topo.ws_f32 is not None:
         a["W0"] = topo.weights("W0").cpu().numpy()
         a["W1"] = topo.weights("W1").cpu().numpy()
@@ -112,4 +112,17 @@ def check_against_oracle(topo, batch, level1=True, weights=True):
             mem = a["MEM1"][n0:n0 + C]
             assert mp[0] == 0 and mp[-1] == C
             np.testing.assert_array_equal(mem, np.lexsort((np.arange(C), loc)))
+            # ---- hierarchical node order: nodes by (depth-1 cluster, depth-0 cluster, node id); the depth-0 clusters in
+            # MEM1 order own consecutive runs of positions (HMP0); split = the prefix of depth-1 clusters closest to N / 2
+            N = nptr[g + 1] - n0
+            if len(loc) == C and C > 0 and (int(getattr(topo, "flags", 1)) & 1):      # (built with DRGNN_TOPO_HIER)
+                cl0 = a["CL0"][n0:n0 + N]
+                want = np.lexsort((np.arange(N), cl0, loc[cl0]))
+                np.testing.assert_array_equal(a["HORD"][n0:n0 + N], want)
+                sizes = np.bincount(cl0, minlength=C)
+                hmp = np.concatenate([[0], np.cumsum(sizes[mem])])
+                np.testing.assert_array_equal(a["HMP0"][rb:rb + C + 1], hmp)
+                pos = hmp[mp]                                   # first position of every depth-1 cluster (+ the end)
+                k = int(np.argmin(np.abs(2 * pos - N)))
+                np.testing.assert_array_equal(a["HSPLIT"][4 * g:4 * g + 4], [k, mp[k], hmp[mp[k]], C1])
     return a

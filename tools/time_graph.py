@@ -16,6 +16,8 @@ dev = torch.device("cuda:0")
 batch = synth.make_batch(0, 64).to(dev)
 torch.manual_seed(0)
 net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[name](32, 1, 1).to(dev)
+for _m in os.environ.get("DRGNN_LAYOUT_MODES", "").split():      # e.g. "8" = round-3 kernels, "10" = aggregation first without the split
+    _lib.get().set_step_layout(int(_m))
 tr = FusedTrainer(net, lr=1e-3, seed=1)
 topo = Topology.from_batch(batch, need_weights=(name == "sGAT"))
 nxt = Topology.from_batch(batch, need_weights=(name == "sGAT"), build=False)
