@@ -187,6 +187,7 @@ def main():
         _lib.get().set_step_layout(6)
     elif args.step_layout == "old":                    # (A/B, sGAT / FoutNet: the round-3 kernels, no aggregation-first step)
         _lib.get().set_step_layout(8)
+        _lib.get().set_step_layout(12)                 # (GINet: the round-3 kernels, no aggregation-first step)
     elif args.step_layout == "af1":                    # (A/B, sGAT / FoutNet: aggregation first, ONE workgroup per graph)
         _lib.get().set_step_layout(10)
     elif args.step_layout != "auto":
@@ -704,6 +705,10 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
             tr.api.net_step_family(tr.kind, batch.x.shape[1], topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O):
         # sGAT / FoutNet training launches of this shape: the aggregation-first kernels (csrc/drgnn_step2.h)
         kname = "k_step2_co_topo<%s,32,%s>" % (net_name, "two workgroups per graph" if c["hints"][0].split else "one workgroup per graph")
+    if net_name == "GINet" and (c["hints"][0].topo_flags & _lib.TOPO_HIER) and \
+            tr.api.net_step_family(tr.kind, batch.x.shape[1], topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O) and \
+            tr.api.net_step_plan(tr.kind, batch.x.shape[1], topo.max_nodes, topo.max_edges, topo.max_c0, tr.R, tr.H, tr.O, B, B)[0] == 2:
+        kname = "k_step3_co_topo<GINet,32> (aggregation first)"      # csrc/drgnn_step3.h
     out = {}
     first = ((kname + " (fwd + head/loss + bwd, topology read from the per-graph cache)", k_step_cached, alg) if cache else
              (kname + " (fwd + head/loss + bwd, + topology of the next batch)", k_step_co, alg))

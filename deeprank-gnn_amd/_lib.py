@@ -64,6 +64,7 @@ class TopologyRequest(ctypes.Structure):
 
 
 TOPO_HIER = 1          # drgnn_topology_request.flags: also build the hierarchical node order (HORD / HMP0 / HSPLIT)
+TOPO_LEAN = 2          # ... and ONLY what the aggregation-first training kernels read (no CSC0, no depth-0 member lists)
 
 
 class GraphSet(ctypes.Structure):

@@ -558,6 +558,7 @@ static int g_step_layout_mode = 0;
 static int g_step_class_mode = 0;          // 0: capacity-class kernels where a batch fits the class (default); 1: never (A/B runs, tests)
 static int g_step2_mode = 0;               // 0: sGAT / FoutNet may take the aggregation-first kernels (drgnn_step2.h); 1: never
 static int g_step2_split_mode = 0;         // 0: ... with two workgroups per graph where the plan allows; 1: never split (A/B runs)
+static int g_step3_mode = 0;               // 0: GINet may take the aggregation-first kernels (drgnn_step3.h); 1: never (A/B runs, tests)
 static int device_cu_count() {
 #ifdef DRGNN_EMU
     return 256;
@@ -602,6 +603,17 @@ static bool step2_shape_ok(int kind, int F, int capN, int capE, int capC, int H,
     return 4 * step2_scratch_words(kind, F, capN, capE, capC, H, O) <= DRGNN_LDS_LIMIT;
 #endif
 }
+// shape conditions of GINet's aggregation-first kernels (drgnn_step3.h)
+static bool step3_shape_ok(int kind, int F, int capN, int capE, int capC, int H, int O) {
+#ifdef DRGNN_EMU
+    (void)kind; (void)F; (void)capN; (void)capE; (void)capC; (void)H; (void)O;
+    return false;
+#else
+    if (kind != DRGNN_GINET || g_step3_mode != 0) return false;
+    if (step_pad16(F) != 32 || !step_burst_guaranteed(kind, nullptr, F, capN, capE, capC, H, O)) return false;
+    return 4 * step3_scratch_words(F, capN, capE, capC, H, O) <= DRGNN_LDS_LIMIT;
+#endif
+}
 static bool step2_split_plan_ok(int kind, int F, int capN, int capE, int capC, int H, int O, int64_t n_graphs, int64_t co_built) {
     if (g_step2_split_mode != 0 || !step2_shape_ok(kind, F, capN, capE, capC, H, O)) return false;
     return step_two_workgroups_ok(n_graphs, co_built);      // (the builder at ONE workgroup per graph if two do not fit)
@@ -610,6 +622,7 @@ int32_t drgnn_net_step_family(int32_t kind, int32_t n_feat, int32_t max_nodes, i
                               int32_t O) {
     if (max_nodes <= 0 || max_nodes > 32767 || max_edges > 65535 || n_feat > 256) return 0;
     const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    if (kind == DRGNN_GINET) return step3_shape_ok(kind, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, H, O) ? 1 : 0;
     return step2_shape_ok(kind, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, H, O) ? 1 : 0;
 }
 int64_t drgnn_net_step_xchg_elems(int32_t kind, int32_t max_nodes, int32_t max_c0, int32_t H) {
@@ -622,6 +635,7 @@ int32_t drgnn_set_step_layout(int32_t mode) {
     if (mode == 5 || mode == 6) { g_step_class_mode = (mode == 6) ? 1 : 0; return 0; }   // (5 = capacity-class kernels allowed, 6 = never)
     if (mode == 7 || mode == 8) { g_step2_mode = (mode == 8) ? 1 : 0; return 0; }          // (7 = aggregation-first kernels allowed, 8 = never)
     if (mode == 9 || mode == 10) { g_step2_split_mode = (mode == 10) ? 1 : 0; return 0; }  // (9 = their split layout allowed, 10 = never)
+    if (mode == 11 || mode == 12) { g_step3_mode = (mode == 12) ? 1 : 0; return 0; }       // (11 = GINet's aggregation-first kernels allowed, 12 = never)
     if (mode < 0 || mode > 2) return DRGNN_E_ARG;
     g_step_layout_mode = mode;
     return 0;
@@ -709,8 +723,16 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         }
         if (af_split) lds = 4 * step2_scratch_words(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
     }
+    // GINet: the aggregation-first kernels (drgnn_step3.h) for training launches of the 32-wide specialised shape in the
+    // two-workgroup layout on a topology that holds the hierarchical order
+    bool af3 = false;
+    if (kind == DRGNN_GINET) {
+        const bool hier = hints && (hints->topo_flags & DRGNN_TOPO_HIER) != 0;
+        af3 = hd->train && hier && ((((uintptr_t)x) & 15) == 0) && step3_shape_ok(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
+    }
 #else
     if (hints && hints->split == 1) return DRGNN_E_CAPACITY;      // (the emulation build has no node-split kernels)
+    const bool af3 = false;
 #endif
     // GINet: one workgroup per graph unless all of 2 B (+ the builder's) workgroups are resident at once; decided below,
     // once the co-launched builder's size is known
@@ -806,6 +828,9 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             return DRGNN_E_CAPACITY;
         }
         if (one_wg) { lds = lds1; L.words = lds / 4; blocks = (int)n_graphs; }
+#ifndef DRGNN_EMU
+        else if (af3) { lds = 4 * step3_scratch_words(F, L.capN, L.capE, L.capC, hd->H, hd->O); L.words = lds / 4; }
+#endif
     } else if (af_split == 2) {
         // the same residency rule for the two half-graph workgroups of the split layout (the caller sized its buffers for
         // it: no silent fallback to another layout)
@@ -828,6 +853,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32 &&
         step_variant(kind, x, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O) == 32) {
         const int64_t lds_cls = one_wg ? step1_lds_bytes_form(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O, 1)
+                                : af3 ? 4 * step3_scratch_words(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
                                 : af_split ? 4 * step2_scratch_words(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
                                        : step_lds_bytes(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->R, hd->H, hd->O);
         if (lds_cls <= DRGNN_LDS_LIMIT) {
@@ -837,6 +863,8 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         }
     }
 #endif
+    // a workspace built with DRGNN_TOPO_LEAN holds only what the aggregation-first training kernels read
+    if (hints && (hints->topo_flags & DRGNN_TOPO_LEAN) && !(af_split != 0 || (af3 && !one_wg))) return DRGNN_E_ARG;
     if (blocks > 0) {
 #ifdef DRGNN_EMU
         // workgroups run one after the other here: two passes (up to the readout exchange, then the
@@ -960,8 +988,28 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             else { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 0, 1); else DRGNN_STEP2_LAUNCH(K, false, 0, 1); }     \
         }                                                                                                   \
     } while (0)
+#define DRGNN_STEP3_LAUNCH(G, CL)                                                                            \
+    do {                                                                                                    \
+        static int lds_set_on = -1;                                                                                   \
+        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
+            if (hipFuncSetAttribute((const void*)k_step3_co_topo<32, G, CL>,                                              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
+                lds_set_on = step_current_device();                                                                   \
+            } else {                                                                                                  \
+                (void)hipGetLastError();                                                                              \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_step3_co_topo<32, G, CL>,                                      \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_step3_co_topo<32, G, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),   \
+                           (size_t)both, stream, C);                                                        \
+    } while (0)
         if (af_split) {
             if (kind == DRGNN_SGAT) DRGNN_STEP2_LAUNCH_K(DRGNN_SGAT); else DRGNN_STEP2_LAUNCH_K(DRGNN_FOUT);
+        } else
+        if (af3 && !one_wg) {
+            if (cls) { if (gather_ids) DRGNN_STEP3_LAUNCH(true, 1); else DRGNN_STEP3_LAUNCH(false, 1); }
+            else { if (gather_ids) DRGNN_STEP3_LAUNCH(true, 0); else DRGNN_STEP3_LAUNCH(false, 0); }
         } else
         if (one_wg && one_paired) {
             if (cls) {
@@ -993,6 +1041,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
 #undef DRGNN_STEP1_LAUNCH_GPC
 #undef DRGNN_STEP2_LAUNCH
 #undef DRGNN_STEP2_LAUNCH_K
+#undef DRGNN_STEP3_LAUNCH
         HIP_TRY(hipGetLastError());
 #endif
     }
@@ -1739,14 +1788,25 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         r.max_nodes = b.maxN; r.max_edges = b.maxE;
         r.ws_i32 = u.ws_i32; r.ws_f32 = u.ws_f32; r.scratch_i32 = nullptr;
         r.set = p->set; r.ids = p->ids + b.first; r.x_out = u.x; r.y_out = train ? u.y : nullptr;
-        r.flags = (p->net->kind != DRGNN_GINET) ? DRGNN_TOPO_HIER : 0;      // (the node-split step kernels read it)
+        // the hierarchical node order: read by the aggregation-first step kernels (drgnn_step2.h: every training launch of
+        // sGAT / FoutNet; drgnn_step3.h: GINet's two-workgroup layout)
+        // ... and when the step that consumes this workspace IS one of them, only what they read (DRGNN_TOPO_LEAN)
+        r.flags = 0;
+        if (train) {
+            const bool fam = drgnn_net_step_family(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->H, hd->O) == 1 &&
+                             ((((uintptr_t)u.x) & 15) == 0);
+            if (p->net->kind != DRGNN_GINET) r.flags = DRGNN_TOPO_HIER | (fam ? DRGNN_TOPO_LEAN : 0);
+            else if (fam && epoch_step_wgs(p, b, epoch_next_b(p, k), nullptr) == 2) r.flags = DRGNN_TOPO_HIER | DRGNN_TOPO_LEAN;
+        }
         return r;
     };
     EpochBatch cur, nxt;
     std::vector<int32_t> hn, he;       // (slot offset tables of the current mini-batch, reused)
     if ((rc = epoch_batch(p, 0, &cur))) return rc;
+    int32_t cur_flags = 0;
     {
         const drgnn_topology_request r0 = request(0, cur);
+        cur_flags = r0.flags;
         if ((rc = drgnn_topology_build_request(&r0, stream))) return rc;
     }
     for (int64_t k = 0; k < nb; ++k) {
@@ -1760,7 +1820,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         // the slot offsets of this mini-batch are known here (host size tables): hand them to the launch
         drgnn_step_hints hints = {};
         const bool split = train && p->net->kind != DRGNN_GINET && epoch_step_wgs(p, cur, more ? nxt.B : 0, nullptr) == 2;
-        hints.topo_flags = (train && p->net->kind != DRGNN_GINET) ? DRGNN_TOPO_HIER : 0;      // (what request() above asked the builder for)
+        hints.topo_flags = cur_flags;      // (what request() asked the builder for)
         hints.split = split ? 1 : 0;
         if (cur.B <= DRGNN_STEP_DIMS_MAX) {
             hn.resize((size_t)cur.B + 1); he.resize((size_t)cur.B + 1);
@@ -1777,6 +1837,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
                                   train ? c.head_partials : nullptr, train ? c.partials : nullptr, c.xchg,
                                   more ? &req : nullptr, &hints, stream);
         if (rc) return rc;
+        if (more) cur_flags = req.flags;
         if (!train) { if (more) cur = nxt; continue; }
         if ((rc = epoch_update(p, c, cur.B, k, losses, stream, split ? 2 : 0))) return rc;
         if (more) cur = nxt;

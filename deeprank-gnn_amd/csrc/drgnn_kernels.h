@@ -8,6 +8,7 @@
 #include "drgnn_step.h"
 #include "drgnn_step1.h"
 #include "drgnn_step2.h"
+#include "drgnn_step3.h"
 #include "drgnn_layers.h"
 #include "drgnn_mcl.h"
 #include "drgnn_collate.h"
@@ -416,6 +417,40 @@ DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
 }
 #endif
 
+#ifndef DRGNN_EMU
+// GINet, aggregation first (drgnn_step3.h): two branch workgroups per graph, placed like step_block's
+template <int XF, bool GATHER, int CLS>
+DEV void step3_block(const StepLaunch& L, int blk, float* lds) {
+    const int g = ((blk >> 4) << 3) + (blk & 7), br = (blk >> 3) & 1;
+    if (g >= L.a.n_graphs) return;
+    if (L.dims.count > 0) {
+        const int gi = GATHER ? L.dims.gi[g] : g;
+        GraphDims d;
+        d.n0 = L.dims.n0[g]; d.N = L.dims.n[g]; d.e0 = L.dims.e0[g]; d.E = L.dims.e[g];
+        d.rowbase = d.n0 + gi;
+        d.C = 0; d.E1 = 0; d.C1 = 0;
+        const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
+        net_step3_graph<XF, GATHER, CLS>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
+        return;
+    }
+    const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;
+    const GraphDims d = net_dims(L.a.tv, gi);
+    if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
+        // the caller's bounds were wrong: poison the outputs instead of overrunning LDS (as step_block does)
+        const uint32_t tag = (uint32_t)L.a.step2[0] + 1u;
+        FOR_TID(c, DRGNN_H2) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + br * DRGNN_H2 + c] = DRGNN_NAN; }
+        FOR_TID(h, L.a.hf.H) { xchg_publish(L.a.xchg + ((long)g * 2 + br) * L.a.hf.H + h, tag, DRGNN_NAN); }
+        if (br == 0) {
+            float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+            FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
+        }
+        return;
+    }
+    net_step3_graph<XF, GATHER, CLS>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
+}
+#endif
+
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
 struct UpdateArgs {
     ReduceArgs r;
@@ -580,6 +615,16 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step2_co_topo(StepCoLaunch C
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
     if ((int)blockIdx.x < C.n_net) step2_block<KIND, XF, GATHER, CLS, SPLIT>(C.step, blockIdx.x, smem_s2);
     else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s2);
+}
+// GINet, aggregation first (drgnn_step3.h) + the builder's workgroups
+template <int XF, bool GATHER, int CLS>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3_co_topo(StepCoLaunch C_by_value) {
+    extern __shared__ __attribute__((aligned(16))) float smem_s3[];
+    PHASE_BEGIN();
+    const StepCoLaunch& C = step_kernarg();
+    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
+    if ((int)blockIdx.x < C.n_net) step3_block<XF, GATHER, CLS>(C.step, blockIdx.x, smem_s3);
+    else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s3);
 }
 #ifdef DRGNN_KERNELS_MAIN
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
@@ -757,5 +802,9 @@ extern template __global__ void k_step1_co_topo<32, true, true, 1>(StepCoLaunch)
 DRGNN_STEP2_EXTERN(DRGNN_SGAT)
 DRGNN_STEP2_EXTERN(DRGNN_FOUT)
 #undef DRGNN_STEP2_EXTERN
+extern template __global__ void k_step3_co_topo<32, false, 0>(StepCoLaunch);
+extern template __global__ void k_step3_co_topo<32, true, 0>(StepCoLaunch);
+extern template __global__ void k_step3_co_topo<32, false, 1>(StepCoLaunch);
+extern template __global__ void k_step3_co_topo<32, true, 1>(StepCoLaunch);
 #endif
 #endif  // !DRGNN_EMU

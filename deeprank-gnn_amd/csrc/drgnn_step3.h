@@ -1,0 +1,358 @@
+// drgnn_step3.h -- fused training step of GINet (one workgroup per (graph, branch)), AGGREGATION FIRST at BOTH levels, node
+// rows in the hierarchical order of the topology builder.
+//
+// Why: GINetConvLayer's attention is identically 1 (ginet.py:50-73), so
+//          z_i = relu( sum_{e: row = i} W x_col(e) ) = relu( G_i W ),     G = A X
+// and x is a leaf (no d loss / d x): the backward of conv1 is ONE product  dW1 = G^T dZ1 -- the transposed aggregation of the
+// product-first form (CSC0, its staging and its 1 us phase) does not exist.  With the rows of G / Z1 kept in the hierarchical
+// order (DRGNN_TI_HORD / HMP0: the members of a depth-0 cluster are CONSECUTIVE rows) the cluster maximum runs over contiguous
+// rows without member lists.  The pooled level (conv2 aggregation first, pooling + readout, head with the partner branch's
+// readout, d readout, dS / dW2, transposed pooled gather through the depth-0 argmax) is drgnn_step.h's, row = pooled node id.
+//
+// Per branch workgroup: 13 barrier-separated phases (drgnn_step.h: 16), LDS at SYN size 111 KB (136 KB), staged index words
+// per graph 3 900 (6 300).  Same sums as the reference up to the association (G W instead of the per-edge products): parity
+// 1e-4 like every other kernel (tests/test_gpu_fused_fullsize.py).  GPU only: the host emulation steps GINet through
+// drgnn_step.h.  Launched by train_step_impl for TRAINING launches of the 32-wide specialised shape in the two-workgroup
+// layout on a topology built with DRGNN_TOPO_HIER; everything else keeps the drgnn_step.h / drgnn_step1.h kernels.
+#ifndef DRGNN_STEP3_H
+#define DRGNN_STEP3_H
+
+#include "drgnn_step2.h"
+
+// float4 per lane of the level-0 aggregation (1: eight lanes per 32-wide row; 2: four lanes per row, two row chunks each)
+#ifndef DRGNN_STEP3_VPL
+#define DRGNN_STEP3_VPL 1
+#endif
+
+#ifndef DRGNN_EMU
+struct Step3Scratch {
+    float* misc; float* xr; float* hid; float* dhid; float* hb1; float* wb;
+    float* w1t; float* w2t; float* w2n;
+    float* xs;
+    int* rp0; int* cx0; int* hord; int* hmp;
+    int* rp1; int* cx1; int* cp1; int* rx1; int* mp1; int* mem1;
+    short* a0; short* a1;
+    float* G; float* z1;
+    float* xp; float* u2; float* z2; float* p2;
+    float* hw2; float* hb2;
+    float* end; float* gp;
+};
+#define STEP3_Z2LD (DRGNN_H2 + 4)
+#define STEP3_CARVE_LIST(X)                                                                    \
+    X(misc, 128)                                                                               \
+    X(xr, 2 * DRGNN_H2)                                                                        \
+    X(hid, H)                                                                                  \
+    X(dhid, H)                                                                                 \
+    X(hb1, H)                                                                                  \
+    X(wb, step_gp_words((int)H))                                                               \
+    X(w1t, DRGNN_H1 * xld)                                                                     \
+    X(w2t, DRGNN_H2 * STEP_XPLD)                                                               \
+    X(w2n, DRGNN_H1 * (DRGNN_H2 + 4))                                                          \
+    X(xs, (long)(capN + 4) * xld)                                                              \
+    X(rp0, capN + 1)                                                                           \
+    X(cx0, capE)                                                                               \
+    X(hord, capN)                                                                              \
+    X(hmp, capC + 1)                                                                           \
+    X(rp1, capC + 1)                                                                           \
+    X(cx1, capE)                                                                               \
+    X(cp1, capC + 1)                                                                           \
+    X(rx1, capE)                                                                               \
+    X(mp1, capC + 1)                                                                           \
+    X(mem1, capC)                                                                              \
+    X(a0, ((long)capC * DRGNN_H1 + 1) / 2)                                                     \
+    X(a1, ((long)capC * DRGNN_H2 + 1) / 2)                                                     \
+    X(G, (long)(capN + 4) * xld)                                                               \
+    X(z1, (long)(capN + 4) * DRGNN_H1)                                                         \
+    X(xp, (long)(capC + 4) * STEP_XPLD)                                                        \
+    X(u2, (long)(capC + 4) * STEP_XPLD)                                                        \
+    X(z2, (long)(capC + 4) * STEP3_Z2LD)                                                       \
+    X(p2, (long)(capC + 4) * STEP_XPLD)                                                        \
+    X(hw2, (long)O * H)                                                                        \
+    X(hb2, O)
+#endif  // !DRGNN_EMU
+
+// (host + device; the emulation build answers "never")
+HD int64_t step3_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O) {
+    const int64_t xld = step_pad16((int)F) + 4;
+    int64_t w = 0;
+#ifndef DRGNN_EMU
+#define X(name, words) w += (((int64_t)(words) + 3) & ~(int64_t)3);
+    STEP3_CARVE_LIST(X)
+#undef X
+#else
+    (void)xld; (void)capN; (void)capE; (void)capC; (void)H; (void)O;
+    w = (int64_t)1 << 40;
+#endif
+    return w + 16;
+}
+
+#ifndef DRGNN_EMU
+template <int CLS>
+DEV Step3Scratch step3_carve(float* base, int F, int capN, int capE, int capC, int H, int O) {
+    const int xld = step_pad16(F) + 4;
+    Step3Scratch s;
+    int o = 0;
+#define X(name, words)                                                                          \
+    { int off = o; if (CLS == 0) { STEP_PIN(off); } s.name = (decltype(s.name))(base + off);    \
+      o = off + (int)(((long)(words) + 3) & ~3L); }
+    STEP3_CARVE_LIST(X)
+#undef X
+    s.end = base + o;
+    s.gp = s.wb;      // fc1's column block is dead after d readout: the K-split products keep their partial tiles there
+    return s;
+}
+
+// ---- phase A: G_p = sum over the CSR0 row of node hord[p] of x_col (all rows; rows of XLD floats) ------------------------
+// VPL float4 per lane: 1 = XF/4 lanes per row; 2 = XF/8 lanes per row, each with the float4 at c and at c + XF/2
+template <int XLD, int VPL>
+DEV void step3_aggregate(int n, const int* hord, const int* rp, const int* col, const float* xs, float* G) {
+    constexpr int XF = XLD - 4;
+    constexpr int LPR = XF / (4 * VPL);
+    constexpr int HALF = XF / 2;
+    FOR_TID(item, n * LPR) {
+        const int p = item / LPR, c = (item % LPR) * 4;
+        const int i = hord[p];
+        const int lo = rp[i], hi = rp[i + 1];
+        drgnn_f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k = lo; k < hi; ++k) {
+            const float* row = xs + ROW24(col[k], XLD) + c;
+            const drgnn_f4 v = *(const drgnn_f4*)row;
+            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+            if (VPL == 2) {
+                const drgnn_f4 w = *(const drgnn_f4*)(row + HALF);
+                b[0] += w[0]; b[1] += w[1]; b[2] += w[2]; b[3] += w[3];
+            }
+        }
+        *(drgnn_f4*)(G + p * XLD + c) = a;
+        if (VPL == 2) *(drgnn_f4*)(G + p * XLD + HALF + c) = b;
+    }
+    // rows [n, pad4(n)): zero (K padding of the weight-gradient product)
+    FOR_TID(e, (step_pad4(n) - n) * XLD) { G[n * XLD + e] = 0.0f; }
+}
+
+// ---- phase C: depth-0 cluster max over CONTIGUOUS rows; results filed under the pooled node id cid[q] --------------------
+// (argmax = row position of the winner, -1 where no gradient flows)
+DEV void step3_cluster_max(int nc, const int* hmp, const int* cid, const float* z, float* xp, short* a0) {
+    FOR_TID(item, nc * DRGNN_H1) {
+        const int q = item >> 4, c = item & 15;
+        const int plo = hmp[q], phi = hmp[q + 1];
+        const int j = cid[q];
+        float best = DRGNN_NEG_INF;
+        int arg = -1;
+        for (int p = plo; p < phi; p += 4) {
+            int mm[4];
+            float vv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mm[t] = (p + t < phi) ? p + t : phi - 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vv[t] = z[mm[t] * DRGNN_H1 + c];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (vv[t] > best) { best = vv[t]; arg = mm[t]; }
+        }
+        if (arg < 0) best = 0.0f;
+        xp[ROW24(j, STEP_XPLD) + c] = best;
+        a0[j * DRGNN_H1 + c] = (short)((best > 0.0f) ? arg : -1);
+    }
+}
+
+// =========================================================================================================================
+// XF: padded feature width (the host has checked step_burst_guaranteed and the reference head width 128); CLS as in
+// drgnn_step.h; `late` as in net_step_graph.
+template <int XF, bool GATHER, int CLS>
+DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi, int br, float* scratch, int capN, int capE,
+                         int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1) {
+    static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
+    if (CLS == 1) { capN = STEP_CLS_N; capE = STEP_CLS_E; capC = STEP_CLS_C; }
+    GraphDims d = d_in;
+    const int bC = late ? imin(d.N, capC) : d.C, bE1 = late ? d.E : d.E1, bC1 = late ? imin(d.N, capC) : d.C1;
+    const TopoView& tv = a.tv;
+    const HeadFused& hf = a.hf;
+    constexpr int nb = 2, R = 2 * DRGNN_H2, WREF = 128;
+    constexpr int XLD = XF + 4, Z2LD = STEP3_Z2LD, W2NLD = DRGNN_H2 + 4;
+    const int F = a.net.n_feat;
+    const int O = hf.O;
+    Step3Scratch s = step3_carve<CLS>(scratch, XF, capN, capE, capC, WREF, O);
+    EXIT_AFTER(0);
+    WBlockRegs<1> wreg, wother;
+    int* const dummy = (int*)(s.misc + 64);
+    const uint32_t done = (uint32_t)a.step2[0];
+    const uint32_t tag = done + 1u;
+    const drgnn_conv_params& c1 = a.net.conv1[br];
+    const drgnn_conv_params& c2 = a.net.conv2[br];
+
+    // ---- prologue: everything this graph needs, two register bursts requested back to back --------------------------------
+    PHASE_MARK();
+    const float* xgl = a.x + (long)d.n0 * F;
+    BurstX<4> bx;
+    BurstW<1> bw1, bw2;
+    WaveStage wst, wst2;
+    const int my_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    auto stage_job = [&](int burst, int w) -> StageJob {
+        const int32_t* const* P = tv.p;
+        StageJob j = {nullptr, 0, nullptr, 0};
+        switch (burst * 16 + w) {
+        case 16 + 0: j = StageJob{P[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1, s.rp0, 0}; break;
+        case 16 + 1: j = stage_half(StageJob{P[DRGNN_TI_COL0] + d.e0, d.E, s.cx0, 0}, 0); break;
+        case 16 + 2: j = stage_half(StageJob{P[DRGNN_TI_COL0] + d.e0, d.E, s.cx0, 0}, 1); break;
+        case 16 + 3: j = StageJob{P[DRGNN_TI_HORD] + d.n0, d.N, s.hord, 0}; break;
+        case 16 + 4: j = StageJob{P[DRGNN_TI_HMP0] + d.rowbase, bC + 1, s.hmp, 0}; break;
+        case 16 + 5: j = StageJob{P[DRGNN_TI_MEM1] + d.n0, bC, s.mem1, 0}; break;
+        case 16 + 6: j = StageJob{P[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1, s.mp1, 0}; break;
+        case 16 + 7: j = StageJob{hf.b1, WREF, s.hb1, 0}; break;
+        case 16 + 8: j = stage_half(StageJob{hf.w2, O * WREF, s.hw2, 0}, 0); break;
+        case 16 + 9: j = stage_half(StageJob{hf.w2, O * WREF, s.hw2, 0}, 1); break;
+        case 16 + 10: j = StageJob{hf.b2, O, s.hb2, 0}; break;
+
+        case 32 + 0: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
+        case 32 + 1: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 0); break;
+        case 32 + 2: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 1); break;
+        case 32 + 3: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+        case 32 + 4: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
+        case 32 + 5: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
+        default: break;
+        }
+        return j;
+    };
+    {   // every workspace pointer in one batch of scalar loads
+        const int32_t* const* P = tv.p;
+        asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR0]), "s"(P[DRGNN_TI_COL0]), "s"(P[DRGNN_TI_HORD]), "s"(P[DRGNN_TI_HMP0]),
+                     "s"(P[DRGNN_TI_MEM1]), "s"(P[DRGNN_TI_MPTR1]));
+        asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR1]), "s"(P[DRGNN_TI_COL1]), "s"(P[DRGNN_TI_COLPTR1]), "s"(P[DRGNN_TI_ROWIDX1]));
+    }
+    int m_bad = 0, m_y = 0;
+    float m_wy = 1.0f, m_denom = 1.0f;
+    if (my_wave == 0) {
+        m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
+        if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
+            m_y = __builtin_nontemporal_load((const int*)hf.y_reg + gi);
+        } else {
+            m_y = (int)hf.y_cls[gi];
+            m_wy = hf.class_w ? hf.class_w[m_y] : 1.0f;
+            m_denom = (float)hf.B;
+            if (hf.class_w && threadIdx.x < 64) {
+                float part_sum = 0.0f;
+                for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w[hf.y_cls[GATHER ? a.gather_ids[q] : q]];
+                m_denom = lanes64_sum(part_sum);
+            }
+            m_y = __builtin_amdgcn_readfirstlane(m_y);
+            m_wy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m_wy)));
+            m_bad = __builtin_amdgcn_readfirstlane(m_bad);
+        }
+    }
+    burst_load_x(bx, xgl, d.N, F);
+    burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
+    wstage_load(wst, stage_job(1, my_wave));
+    // the second burst right behind the first (filed two phases later): first touches of what the builder wrote in the
+    // previous launch, a round trip that must not start late
+    burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+    step_wblock_load(wreg, hf, br);
+    step_wblock_load(wother, hf, 1 - br);
+    wstage_load(wst2, stage_job(2, my_wave));
+    burst_store_x4(bx, s.xs, XLD);
+    burst_store_wt(bw1, s.w1t, XLD);
+    wstage_store(wst);
+    if (XF > F) {      // zero padding of the k columns [F, XF) (x tile: every row is gathered; weights)
+        const int padc = XF - F;
+        FOR_TID(e, d.N * padc) { s.xs[(e / padc) * XLD + F + e % padc] = 0.0f; }
+        FOR_TID(e, DRGNN_H1 * padc) { s.w1t[(e / padc) * XLD + F + e % padc] = 0.0f; }
+    }
+    FOR_TID(i, 1) {
+        ((int*)s.misc)[STEP_M_BAD] = m_bad;
+        ((int*)s.misc)[STEP_M_Y] = m_y;
+        s.misc[STEP_M_WY] = m_wy;
+        s.misc[STEP_M_DENOM] = m_denom;
+    }
+    BARRIER();
+    EXIT_AFTER(1);
+    if (late) { d.C = WG_UNIFORM(cnt_c); d.E1 = WG_UNIFORM(cnt_e1); d.C1 = WG_UNIFORM(cnt_c1); }
+    int bad_shape = 0;
+    if (d.C > capC || d.E1 > d.E || d.C1 > capC) {      // malformed input (flagged by the builder): stay inside LDS, poison
+        d.C = imin(d.C, capC); d.E1 = imin(d.E1, d.E); d.C1 = imin(d.C1, capC);
+        bad_shape = 1;
+    }
+
+    // ---- A: G = A X (rows in the hierarchical order) ------------------------------------------------------------------------
+    PH(1) step3_aggregate<XLD, DRGNN_STEP3_VPL>(d.N, s.hord, s.rp0, s.cx0, s.xs, s.G);
+    BARRIER();
+    EXIT_AFTER(2);
+    // ---- B: Z1 = relu(G W1); the second burst is filed ---------------------------------------------------------------------
+    PH(2) step_gemm_nn<true>(d.N, 1, XF, s.G, XLD, s.w1t, XLD, s.z1, DRGNN_H1, dummy);
+    burst_store_wt(bw2, s.w2t, STEP_XPLD);
+    burst_store_w(bw2, s.w2n, W2NLD);
+    step_wblock_store(wreg, hf, br, s.wb);
+    wstage_store(wst2);
+    FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
+    if (bad_shape) { FOR_TID(i, 1) { ((int*)s.misc)[STEP_M_BAD] = 1; } }
+    BARRIER();
+    EXIT_AFTER(3);
+    // ---- C: depth-0 cluster max over contiguous rows -----------------------------------------------------------------------
+    PH(3) step3_cluster_max(d.C, s.hmp, s.mem1, s.z1, s.xp, s.a0);
+    BARRIER();
+    EXIT_AFTER(4);
+    // ---- E: S = A1 XP (16-wide gather of pooled rows) -----------------------------------------------------------------------
+    PH(4) step_gather_rows<STEP_XPLD, int>(d.C, s.rp1, s.cx1, s.xp, s.u2);
+    FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.u2[d.C * STEP_XPLD + e] = 0.0f; }
+    FOR_TID(item, step_pad4(d.N) * DRGNN_H1) { s.z1[item] = 0.0f; }      // Z1 is consumed: becomes dZ1 (+ zero K padding)
+    BARRIER();
+    EXIT_AFTER(5);
+    // ---- F: Z2 = relu(S W2) ---------------------------------------------------------------------------------------------------
+    PH(5) step_gemm_nn<true>(d.C, 2, DRGNN_H1, s.u2, STEP_XPLD, s.w2t, STEP_XPLD, s.z2, Z2LD, dummy);
+    BARRIER();
+    EXIT_AFTER(6);
+    // ---- G: depth-1 max + readout, published to the partner branch ------------------------------------------------------------
+    PH(6) step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.a1, s.misc, s.xr,
+                                  const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2, nullptr,
+                                  a.xchg + (long)g * nb * WREF + br * DRGNN_H2, tag);
+    BARRIER();
+    EXIT_AFTER(8);
+
+    // ---- FC head + loss + their backward -----------------------------------------------------------------------------------
+    const float keep_scale = (hf.p_drop > 0.0f) ? 1.0f / (1.0f - hf.p_drop) : 1.0f;
+    const double pt = (double)hf.p_drop * 4294967296.0;
+    const uint32_t thresh = (hf.p_drop > 0.0f) ? (uint32_t)(pt > 4294967295.0 ? 4294967295.0 : pt) : 0u;
+    float* hp = hf.partials + (long)g * head_compact_floats(R, WREF, O);
+    float* p_dhid = hp;
+    float* p_hw2 = p_dhid + WREF;
+    float* p_hb2 = p_hw2 + (long)O * WREF;
+    float* p_loss = p_hb2 + O;
+    if (g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+    FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
+    PH(8) step_head_fc1<WREF, true>(hf, g, br, nb, s.wb, wother, s.hb1, s.xr, s.hid, a.xchg + (long)g * nb * WREF, tag, done,
+                                    thresh, keep_scale, a.step2 + 2);
+    BARRIER();
+    EXIT_AFTER(9);
+    PH(9) step_head_loss<WREF, true>(hf, g, br, s.hid, s.hw2, s.hb2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    BARRIER();
+    EXIT_AFTER(10);
+    PH(10) step_head_dreadout<WREF, true>(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
+    BARRIER();
+    EXIT_AFTER(11);
+
+    // ---- backward body -----------------------------------------------------------------------------------------------------
+    float* part_w = a.partials + ((long)g * nb + br) * a.n_partial;
+    float* p_w1n = part_w;
+    float* p_w2n = p_w1n + 2L * F * DRGNN_H1 + DRGNN_H1;
+    const int gp_units = step_gp_words(WREF) / 256;
+    const int KS2 = imin(DRGNN_NWAVES / 2, gp_units / 2);
+    // dS = dZ2 W2^T (rows of STEP_XPLD floats);  dW2 = S^T dZ2 (K = pooled nodes): partial tiles here, their sum behind the barrier
+    PH(11) step_gemm_nn(d.C, 1, DRGNN_H2, s.z2, Z2LD, s.w2n, W2NLD, s.p2, STEP_XPLD, dummy);
+    PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1, 1);
+    BARRIER();
+    EXIT_AFTER(12);
+    PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1, 2);
+    // dXP = A1^T dS, scattered through the depth-0 argmax (row positions) into dZ1
+    PH(13) step_gather_scatter<STEP_XPLD, int>(d.C, s.cp1, s.rx1, s.p2, s.a0, s.z1);
+    BARRIER();
+    EXIT_AFTER(14);
+    {   // dW1 = G^T dZ1: K = node rows, split in slices over the waves
+        constexpr int MT = XF / 16;
+        int KS = imin(DRGNN_NWAVES / MT, gp_units / MT);
+        if (KS < 1) KS = 1;
+        PH(16) step_gemm_tn(MT, 1, d.N, s.G, XLD, s.z1, DRGNN_H1, KS, s.gp, p_w1n, DRGNN_H1, F);
+    }
+}
+
+#endif  // !DRGNN_EMU
+#endif

@@ -34,6 +34,12 @@ template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 0, 2>(StepCoL
 template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 0, 2>(StepCoLaunch);
 template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 1, 2>(StepCoLaunch);
 template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 1, 2>(StepCoLaunch);
+#elif DRGNN_TU_KIND == 7
+// the aggregation-first GINet step (drgnn_step3.h): 32-wide, {mini-batch, cached} x {run-time, capacity-class layout}
+template __global__ void k_step3_co_topo<32, false, 0>(StepCoLaunch);
+template __global__ void k_step3_co_topo<32, true, 0>(StepCoLaunch);
+template __global__ void k_step3_co_topo<32, false, 1>(StepCoLaunch);
+template __global__ void k_step3_co_topo<32, true, 1>(StepCoLaunch);
 #else
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
 // ... and the 32-wide kernels with the capacity-class LDS layout (net_step_graph: CLS = 1)

@@ -244,34 +244,63 @@ DEV void wg_minmax64(const int64_t* ids, int n, long long* mm, bool preinit = fa
 // phase's own loads and no phase of its own is spent on the min / max): every wave leaves the min / max of the ids its
 // lanes read in mm[2 + 2w], mm[3 + 2w] and the ids' low words go to s.pp (id - min fits 32 bits whenever the flag path is
 // taken, so the low words are all that path needs).  The caller also clears fl[0..capF) and ends the phase with a barrier.
-DEV void wg_rank_prepare(const int64_t* ids, int n, TopoScratch& s) {
+DEV void wg_rank_prepare_to(const int64_t* ids, int n, int* low, long long* slots) {
 #ifdef DRGNN_EMU
     long long lo = LLONG_MAX, hi = LLONG_MIN;
     for (int i = 0; i < n; ++i) {
         const long long v = (long long)ids[i];
         lo = v < lo ? v : lo;
         hi = v > hi ? v : hi;
-        s.pp[i] = (int)(unsigned int)((unsigned long long)v & 0xffffffffull);
+        low[i] = (int)(unsigned int)((unsigned long long)v & 0xffffffffull);
     }
-    for (int w = 0; w < DRGNN_NTHREADS / DRGNN_WAVE; ++w) { s.mm[2 + 2 * w] = LLONG_MAX; s.mm[3 + 2 * w] = LLONG_MIN; }
-    s.mm[2] = lo; s.mm[3] = hi;
+    for (int w = 0; w < DRGNN_NTHREADS / DRGNN_WAVE; ++w) { slots[2 * w] = LLONG_MAX; slots[2 * w + 1] = LLONG_MIN; }
+    slots[0] = lo; slots[1] = hi;
 #else
     long long lo = LLONG_MAX, hi = LLONG_MIN;
     for (int i = threadIdx.x; i < n; i += DRGNN_NTHREADS) {
         const long long v = (long long)ids[i];
         lo = v < lo ? v : lo;
         hi = v > hi ? v : hi;
-        s.pp[i] = (int)(unsigned int)((unsigned long long)v & 0xffffffffull);
+        low[i] = (int)(unsigned int)((unsigned long long)v & 0xffffffffull);
     }
     // only the waves that read ids take part (the rank routine reads the first ceil(min(n, threads) / 64) slots)
     if ((int)(threadIdx.x & ~(DRGNN_WAVE - 1)) < n) {
         wave_minmax_i64(lo, hi);
         if ((threadIdx.x & (DRGNN_WAVE - 1)) == 0) {
-            s.mm[2 + 2 * (threadIdx.x / DRGNN_WAVE)] = lo;
-            s.mm[3 + 2 * (threadIdx.x / DRGNN_WAVE)] = hi;
+            slots[2 * (threadIdx.x / DRGNN_WAVE)] = lo;
+            slots[2 * (threadIdx.x / DRGNN_WAVE) + 1] = hi;
         }
     }
 #endif
+}
+DEV void wg_rank_prepare(const int64_t* ids, int n, TopoScratch& s) { wg_rank_prepare_to(ids, n, s.pp, s.mm + 2); }
+#ifndef DRGNN_EMU
+// the same for n <= DRGNN_NTHREADS with the ids ALREADY in registers (v = ids[threadIdx.x], requested by the caller ahead of
+// its other loads: one memory round trip for everything a phase reads instead of one per list)
+DEV void wg_rank_prepare_val(long long v, int n, int* low, long long* slots) {
+    long long lo = LLONG_MAX, hi = LLONG_MIN;
+    if ((int)threadIdx.x < n) {
+        lo = v; hi = v;
+        low[threadIdx.x] = (int)(unsigned int)((unsigned long long)v & 0xffffffffull);
+    }
+    if ((int)(threadIdx.x & ~(DRGNN_WAVE - 1)) < n) {
+        wave_minmax_i64(lo, hi);
+        if ((threadIdx.x & (DRGNN_WAVE - 1)) == 0) {
+            slots[2 * (threadIdx.x / DRGNN_WAVE)] = lo;
+            slots[2 * (threadIdx.x / DRGNN_WAVE) + 1] = hi;
+        }
+    }
+}
+#endif
+// min / max of n prepared ids from the wave slots wg_rank_prepare_to left
+DEV void wg_prepared_minmax(const long long* slots, int n, long long& mn, long long& mx) {
+    mn = LLONG_MAX; mx = LLONG_MIN;
+    const int nw = imin(DRGNN_NTHREADS / DRGNN_WAVE, (n + DRGNN_WAVE - 1) / DRGNN_WAVE);     // slots that were written
+    for (int w = 0; w < nw; ++w) {
+        const long long l = slots[2 * w], h = slots[2 * w + 1];
+        mn = l < mn ? l : mn;
+        mx = h > mx ? h : mx;
+    }
 }
 
 // `prepared`: the caller has run wg_rank_prepare(ids, n, s) and cleared fl[0..capF) in an earlier phase
@@ -771,10 +800,16 @@ DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool
 }
 
 // depth-0 cluster ranks; with_members: + member lists, both written out.  Returns C.
+// ranks_out: without member lists, still write the ranks and the count (lean build of a weighted graph)
 DEV int topo_clusters0(const TopoView& tv, int g, int n0, int N, const TopoSrc& src, TopoScratch& s, int sidx,
-                       bool with_members) {
+                       bool with_members, bool ranks_out = false) {
     const int rowbase = n0 + g;
     const int C = wg_cluster_rank(tv, sidx, src.cl0, N, s, true, with_members);
+    if (!with_members && ranks_out) {
+        int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
+        FOR_TID(i, N) { g_cl0[i] = s.cl[i]; }
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
+    }
     if (with_members) {
         int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
         int32_t* g_mptr0 = tv.p[DRGNN_TI_MPTR0] + rowbase;
@@ -803,6 +838,273 @@ DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, in
     topo_graph_level1(tv, a, g, n0, C, src.cl1, c1_len, s, sidx, true, hier ? s.t5 : nullptr, N, true);
 }
 
+// =========================================================================================================================
+// LEAN build (DRGNN_TOPO_LEAN, include/drgnn.h): only what the aggregation-first training kernels read, by two short chains.
+//   * ONE exclusive scan over the concatenation [row histogram | presence flags of the depth-0 ids | ... of the depth-1 ids]
+//     gives the CSR0 row pointers and both consecutive-cluster rankings (the old chain: three scans in three places);
+//   * orders by COUNTING instead of bucket sorts: the position of an item is the number of items with a smaller key
+//     (depth-0 clusters by (depth-1 cluster, id): C^2 comparisons; nodes by (position of their cluster, id): N^2 / lanes) --
+//     one phase each, no histogram / scan / claim / rank, deterministic by construction;
+//   * the pooled CSC from a TRANSPOSED target bitmap filled next to the forward one: both are emitted by one popcount scan.
+// Items of the counting loops are shared by G consecutive lanes that meet in DPP adds (the emulation runs items serially).
+#ifdef DRGNN_EMU
+#define TOPO_LANES(G) 1
+template <int G> DEV int topo_group_sum(int v) { return v; }
+#else
+#define TOPO_LANES(G) (G)
+template <int CTRL> DEV int dpp_take_int(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+template <int G> DEV int topo_group_sum(int v) {
+    if (G >= 2) v += dpp_take_int<0xB1>(v);      // quad_perm [1,0,3,2]
+    if (G >= 4) v += dpp_take_int<0x4E>(v);      // quad_perm [2,3,0,1]
+    if (G >= 8) v += dpp_take_int<0x141>(v);     // row_half_mirror
+    if (G >= 16) v += dpp_take_int<0x140>(v);    // row_mirror
+    return v;
+}
+#endif
+// number of keys[0 .. n) strictly below `me`: lane `sub` of the item's G lanes takes the keys sub, sub + G, ... (four per trip in
+// flight); every lane of the group gets the total
+template <int G> DEV int topo_count_below(const int* keys, int n, int me, int sub) {
+    constexpr int L = TOPO_LANES(G);
+    int cnt = 0;
+    for (int j = sub; j < n; j += 4 * L) {
+        const int j1 = j + L, j2 = j + 2 * L, j3 = j + 3 * L;
+        const int k0 = keys[j], k1 = keys[j1 < n ? j1 : j], k2 = keys[j2 < n ? j2 : j], k3 = keys[j3 < n ? j3 : j];
+        cnt += ((k0 < me) ? 1 : 0) + ((j1 < n && k1 < me) ? 1 : 0) + ((j2 < n && k2 < me) ? 1 : 0) + ((j3 < n && k3 < me) ? 1 : 0);
+    }
+    return topo_group_sum<L>(cnt);
+}
+
+// Phase 0 of a lean chain (next to the edge staging): the concatenated flag / histogram array, the cursors and the cluster
+// sizes cleared, both id lists read (their latencies overlap the edge list's), low words + wave min / max filed.
+// pre: the ids are already in registers (v0 = cl0[thread], v1 = cl1[thread]; N <= threads)
+DEV void topo_lean_prepare(const TopoSrc& src, int N, int n1, bool structure, TopoScratch& s, bool pre = false, long long v0 = 0,
+                           long long v1 = 0) {
+    FOR_TID(v, s.capT) { s.t1[v] = 0; }
+#ifndef DRGNN_EMU
+    if (pre) wg_rank_prepare_val(v0, N, s.pp, s.mm + 2);
+    else
+#endif
+    wg_rank_prepare(src.cl0, N, s);
+    if (structure) {
+        FOR_TID(i, N + 1) { s.cur[i] = 0; s.rp[i] = 0; }
+#ifndef DRGNN_EMU
+        if (pre) wg_rank_prepare_val(v1, n1, s.nb, (long long*)s.part);
+        else
+#endif
+        wg_rank_prepare_to(src.cl1, n1, s.nb, (long long*)s.part);
+    }
+    (void)pre; (void)v0; (void)v1;
+}
+
+// ---- lean "structure" chain: CSR0 (+ W0), depth-0 / depth-1 cluster ranks, MEM1 / MPTR1, HORD / HMP0 / HSPLIT ---------------
+// Needs topo_lean_prepare(structure) and the staged edges behind a barrier.  false (workgroup-uniform, nothing written yet):
+// ids too sparse for the concatenated flag array -- the caller takes the general chain.
+DEV bool topo_lean_structure(const TopoView& tv, const TopoArgs& a, int g, int n0, int e0, int N, int E, bool has_w,
+                             int c1_len, TopoScratch& s, int sidx) {
+    const int rowbase = n0 + g;
+    const int n1 = imin(N, imax(c1_len, 0));
+    long long mn0, mx0, mn1, mx1;
+    wg_prepared_minmax(s.mm + 2, N, mn0, mx0);
+    wg_prepared_minmax((const long long*)s.part, n1, mn1, mx1);
+    const long long span0 = (N > 0) ? mx0 - mn0 + 1 : 0, span1 = (n1 > 0) ? mx1 - mn1 + 1 : 0;
+    if (span0 < 0 || span1 < 0 || span0 > s.capT || span1 > s.capT || (long long)(N + 3) + span0 + span1 > (long long)s.capT ||
+        N > 0x7FFF)
+        return false;
+    int* Z = s.t1;
+    const int o0 = N + 1, o1 = o0 + (int)span0 + 1, zlen = o1 + (int)span1 + 1;
+    const unsigned int mn0_lo = (unsigned int)((unsigned long long)mn0 & 0xffffffffull);
+    const unsigned int mn1_lo = (unsigned int)((unsigned long long)mn1 & 0xffffffffull);
+    FOR_TID(e, E) { ATOMIC_ADD(&Z[s.er[e]], 1); }
+    FOR_TID(i, N) { Z[o0 + (int)((unsigned int)s.pp[i] - mn0_lo)] = 1; }
+    FOR_TID(c, n1) { Z[o1 + (int)((unsigned int)s.nb[c] - mn1_lo)] = 1; }
+    BARRIER();      // (also: every thread has read the wave slots in s.part, which the scan reuses)
+    const int total = wg_exscan(Z, zlen, s.part);
+    const int C = Z[o1] - E, C1 = total - E - C;
+    const int n = imin(C, n1);                      // depth-0 clusters the depth-1 list covers
+    if (c1_len != C) { FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, sidx); } }
+    int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
+    int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
+    int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
+    FOR_TID(e, E) { const int r = s.er[e]; s.t2[Z[r] + ATOMIC_ADD(&s.cur[r], 1)] = e; }
+    FOR_TID(i, N + 1) { g_rowptr0[i] = Z[i]; }
+    int* csize = s.rp;      // nodes per depth-0 cluster (cleared by topo_lean_prepare)
+    FOR_TID(i, N) {
+        const int c = Z[o0 + (int)((unsigned int)s.pp[i] - mn0_lo)] - E;
+        s.cl[i] = c; g_cl0[i] = c;
+        ATOMIC_ADD(&csize[c], 1);
+    }
+    FOR_TID(c, n) {
+        const int k = Z[o1 + (int)((unsigned int)s.nb[c] - mn1_lo)] - E - C;
+        s.cp[c] = k;                                // depth-1 cluster of depth-0 cluster c
+        s.mp[c] = (k << 16) | c;                    // its sort key (k < 2^15, c < 2^15)
+        g_cl1[c] = k;
+    }
+    FOR_TID(i, 1) { tv.p[DRGNN_TI_NC1][g] = C1; }
+    BARRIER();
+    {   // CSR0 slots: rank of every edge inside its row by edge id, emitted at once
+        int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
+        int32_t* g_eid0 = tv.p[DRGNN_TI_EID0] + e0;
+        float* g_w0 = tv.w0 ? tv.w0 + e0 : nullptr;
+        FOR_TID(p, E) {
+            const int e = s.t2[p];
+            const int r = s.er[e];
+            const int lo = Z[r], hi = Z[r + 1];
+            int rank = 0;
+            for (int q = lo; q < hi; ++q) rank += (s.t2[q] < e) ? 1 : 0;
+            g_col0[lo + rank] = s.ec[e];
+            g_eid0[lo + rank] = e;
+            if (has_w) g_w0[lo + rank] = s.w0[e];
+        }
+    }
+    int* qpos = s.pp;       // position of every depth-0 cluster in the depth-1-major order (clusters the list does not cover: last)
+    int* mp1 = s.rp1;
+    {
+        constexpr int G = TOPO_LANES(8);
+        FOR_TID(item, C * G) {
+            const int c = item / G, sub = item % G;
+            int q = C - 1;
+            if (c < n) q = topo_count_below<8>(s.mp, n, s.mp[c], sub);
+            if (sub == 0) qpos[c] = q;
+        }
+        int32_t* g_mptr1 = tv.p[DRGNN_TI_MPTR1] + rowbase;
+        FOR_TID(item, (C1 + 1) * G) {
+            const int k = item / G, sub = item % G;
+            const int cnt = topo_count_below<8>(s.cp, n, k, sub);
+            if (sub == 0) { mp1[k] = cnt; g_mptr1[k] = cnt; }
+        }
+        FOR_TID(c, C + 1) { s.cur[c] = 0; }      // (the CSR claim is over: the cursors of the node claim below)
+    }
+    BARRIER();
+    // Hierarchical order = nodes bucketed by the position of their cluster.  The bucket offsets are sums of cluster sizes over
+    // the clusters in front (C^2 / lanes additions, no scan); a node claims a slot of its bucket and the few nodes of a bucket
+    // are ranked by id.  (Positions by counting smaller (position, id) keys over ALL nodes -- one phase less -- cost 11.5 k
+    // ticks at N = 200: ~9 instructions per comparison, N^2 of them; this costs 3.5 k.)
+    int* hmp = s.mp;        // (the depth-1 sort keys it held are consumed)
+    {
+        int32_t* g_mem1 = tv.p[DRGNN_TI_MEM1] + n0;
+        int32_t* g_hmp = tv.p[DRGNN_TI_HMP0] + rowbase;
+        FOR_TID(c, n) { g_mem1[qpos[c]] = c; }
+        constexpr int G = TOPO_LANES(8);
+        FOR_TID(item, (C + 1) * G) {
+            const int q = item / G, sub = item % G;
+            int acc = 0;
+            for (int c = sub; c < C; c += G) acc += (qpos[c] < q) ? csize[c] : 0;
+            acc = topo_group_sum<G>(acc);
+            if (sub == 0) { hmp[q] = acc; g_hmp[q] = acc; }
+        }
+    }
+    BARRIER();
+    FOR_TID(i, N) {
+        const int c = s.cl[i], b = qpos[c];
+        const int pos = hmp[b] + ATOMIC_ADD(&s.cur[c], 1);
+        s.t2[pos] = i;
+        s.t3[pos] = b;
+    }
+    BARRIER();
+    {
+        int32_t* g_hord = tv.p[DRGNN_TI_HORD] + n0;
+        FOR_TID(p, N) {
+            const int me = s.t2[p], b = s.t3[p];
+            const int lo = hmp[b], hi = hmp[b + 1];
+            int rank = 0;
+            for (int q = lo; q < hi; ++q) rank += (s.t2[q] < me) ? 1 : 0;
+            g_hord[lo + rank] = me;
+        }
+    }
+    {   // split point: the number k of leading depth-1 clusters whose node total is closest to N / 2 (smallest k on ties)
+        int32_t* hs = tv.p[DRGNN_TI_HSPLIT] + 4 * g;
+#ifdef DRGNN_EMU
+        long long best = LLONG_MAX;
+        for (int k = 0; k <= C1; ++k) {
+            int d = 2 * hmp[imin(mp1[k], C)] - N;
+            d = d < 0 ? -d : d;
+            const long long v = ((long long)d << 32) | (long long)k;
+            best = v < best ? v : best;
+        }
+        const int kb = (int)(best & 0xffffffffLL);
+        const int qb = imin(mp1[kb], C);
+        hs[0] = kb; hs[1] = qb; hs[2] = hmp[qb]; hs[3] = C1;
+#else
+        if (threadIdx.x < DRGNN_WAVE) {
+            long long best = LLONG_MAX, other = LLONG_MIN;
+            for (int k = threadIdx.x; k <= C1; k += DRGNN_WAVE) {
+                int d = 2 * hmp[imin(mp1[k], C)] - N;
+                d = d < 0 ? -d : d;
+                const long long v = ((long long)d << 32) | (long long)k;
+                best = v < best ? v : best;
+            }
+            wave_minmax_i64(best, other);
+            if (threadIdx.x == 0) {
+                const int kb = (int)(best & 0xffffffffLL);
+                const int qb = imin(mp1[kb], C);
+                hs[0] = kb; hs[1] = qb; hs[2] = hmp[qb]; hs[3] = C1;
+            }
+        }
+#endif
+    }
+    return true;
+}
+
+// ---- lean "pool" chain without edge weights: depth-0 ranks, pooled CSR (bitmap) and pooled CSC (transposed bitmap) ------------
+// Needs topo_lean_prepare and the staged edges behind a barrier.  false (workgroup-uniform; at most CL0 / NC0 written, which the
+// general chain writes again): the caller takes the general chain.
+DEV bool topo_lean_pool(const TopoView& tv, int g, int n0, int e0, int N, int E, TopoScratch& s) {
+    const int rowbase = n0 + g;
+    long long mn0, mx0;
+    wg_prepared_minmax(s.mm + 2, N, mn0, mx0);
+    const long long span0 = (N > 0) ? mx0 - mn0 + 1 : 0;
+    if (span0 < 0 || span0 + 1 > (long long)s.capT) return false;
+    int* Z = s.t1;
+    const unsigned int mn0_lo = (unsigned int)((unsigned long long)mn0 & 0xffffffffull);
+    FOR_TID(i, N) { Z[(int)((unsigned int)s.pp[i] - mn0_lo)] = 1; }
+    BARRIER();
+    const int C = wg_exscan(Z, (int)span0 + 1, s.part);
+    const int BW = (C + 31) >> 5, CB = C * BW;
+    int* bm = s.t2;          // [C][BW] target bitmaps of the pooled rows
+    int* bmT = s.t3;         // [C][BW] source bitmaps of the pooled columns
+    int* Y = s.t4;           // [2 CB + 1] set bits before each word of [bm | bmT]
+    {
+        int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
+        FOR_TID(i, N) { const int c = Z[(int)((unsigned int)s.pp[i] - mn0_lo)]; s.cl[i] = c; g_cl0[i] = c; }
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
+    }
+    if (2L * CB + 1 > (long)s.capT) return false;      // many clusters: the general chain (ranks again: same CL0 / NC0)
+    FOR_TID(q, CB) { bm[q] = 0; bmT[q] = 0; }
+    BARRIER();
+    FOR_TID(e, E) {
+        const int r = s.cl[s.er[e]], cc = s.cl[s.ec[e]];
+        if (cc != r) {
+            ATOMIC_OR(&bm[r * BW + (cc >> 5)], (int)(1u << (cc & 31)));
+            ATOMIC_OR(&bmT[cc * BW + (r >> 5)], (int)(1u << (r & 31)));
+        }
+    }
+    BARRIER();
+    // (a thread scans the element it wrote while 2 CB + 1 <= threads: no barrier in between)
+    FOR_TID(q, 2 * CB + 1) { Y[q] = (q < CB) ? __builtin_popcount((unsigned)bm[q]) : (q < 2 * CB) ? __builtin_popcount((unsigned)bmT[q - CB]) : 0; }
+    if (2 * CB + 1 > DRGNN_NTHREADS) BARRIER();
+    const int E1 = wg_exscan(Y, 2 * CB + 1, s.part) >> 1;
+    int32_t* g_col1 = tv.p[DRGNN_TI_COL1] + e0;
+    int32_t* g_rowidx1 = tv.p[DRGNN_TI_ROWIDX1] + e0;
+    FOR_TID(q, 2 * CB) {
+        const bool tr = q >= CB;
+        const int qq = tr ? q - CB : q;
+        unsigned bits = (unsigned)(tr ? bmT[qq] : bm[qq]);
+        const int r = qq / BW, base = (qq - r * BW) << 5;
+        int slot = Y[q] - (tr ? E1 : 0);
+        int32_t* dst = tr ? g_rowidx1 : g_col1;
+        while (bits) {
+            const int b = __builtin_ctz(bits);
+            bits &= bits - 1;
+            dst[slot++] = base + b;
+        }
+    }
+    int32_t* g_rowptr1 = tv.p[DRGNN_TI_ROWPTR1] + rowbase;
+    int32_t* g_colptr1 = tv.p[DRGNN_TI_COLPTR1] + rowbase;
+    FOR_TID(r, C + 1) { g_rowptr1[r] = Y[r * BW]; g_colptr1[r] = Y[CB + r * BW] - E1; }
+    FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
+    return true;
+}
+
 // WEIGHTS: -1 = decided at run time (edge_attr and a weight workspace given); 0 = never (the builder co-launched with a
 // GINet / FoutNet step: the weighted pooled-edge path -- bucket ranking, run sums -- is not even compiled into those kernels,
 // whose register allocation and code layout it otherwise shapes: +0.5 us on the unweighted builder, +0.2 us on the GINet step)
@@ -824,7 +1126,42 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     if (structure) topo_gather_rows(a, src, g, n0, N);
 
     // ---- phase 0: stage the edge list, clear what the next phases accumulate into ----
+    // LEAN (request flag, with the hierarchical order and cluster1): the short chains above.  Two workgroups per graph: each role
+    // runs its own; one workgroup: the pool chain, then the structure chain on re-read ids.
+    const bool lean = (a.flags & DRGNN_TOPO_LEAN) != 0 && (a.flags & DRGNN_TOPO_HIER) != 0 && a.cluster0 != nullptr &&
+                      a.cluster1 != nullptr && a.c1_ptr != nullptr;
+    const int c1_len = lean ? a.c1_ptr[g + 1] - a.c1_ptr[g] : 0;
+    const int nc1 = imin(N, imax(c1_len, 0));
+    const bool lean_pool = lean && pool && !has_w;
+    const bool str_first = lean && structure && !pool;
+    // the cluster ids of a lean chain are requested AHEAD of the edge list (one round trip for all three)
+    long long pre0 = 0, pre1 = 0;
+    bool pre = false;
+#ifndef DRGNN_EMU
+    if ((lean_pool || str_first) && N <= DRGNN_NTHREADS) {
+        pre = true;
+        if ((int)threadIdx.x < N) pre0 = (long long)src.cl0[threadIdx.x];
+        if (str_first && (int)threadIdx.x < nc1) pre1 = (long long)src.cl1[threadIdx.x];
+    }
+#endif
     topo_stage_edges(tv, src, sidx, N, E, has_w, s);
+    bool pool_done = false;
+    if (lean_pool || str_first) {
+        // (one call site per chain: they are inlined)
+        bool try_structure = str_first;
+        topo_lean_prepare(src, N, nc1, str_first, s, pre, pre0, pre1);
+        BARRIER();
+        if (!str_first && topo_lean_pool(tv, g, n0, e0, N, E, s)) {
+            if (!structure) return;
+            pool_done = true;      // one workgroup per graph: the structure chain behind the pool chain, on re-read ids
+            BARRIER();
+            topo_lean_prepare(src, N, nc1, true, s);
+            BARRIER();
+            try_structure = true;
+        }
+        if (try_structure && topo_lean_structure(tv, a, g, n0, e0, N, E, has_w, c1_len, s, sidx)) return;
+        BARRIER();      // the general chain for what is left: every thread is past its reads of the prepared arrays
+    }
     if (structure) {
         FOR_TID(i, 2 * N + 2) { s.rp[i] = 0; }
         FOR_TID(i, N + 1) { s.cur[i] = 0; }
@@ -840,13 +1177,15 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
         BARRIER();
         return;
     }
-    if (role == TOPO_ROLE_MEMBERS) {       // structure: only the cluster COUNT of depth 0 is needed for depth 1
+    if (role == TOPO_ROLE_MEMBERS || pool_done) {       // structure: only the cluster COUNT of depth 0 is needed for depth 1
         const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, false);
         topo_clusters1(tv, a, g, n0, N, C, src, s, sidx);
         return;
     }
-    // pool (or everything): ranks + member lists of depth 0, then the pooled graph
-    const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, true);
+    // pool (or everything): ranks + member lists of depth 0 (lean with edge weights, two workgroups per graph: ranks only),
+    // then the pooled graph
+    const bool members0 = !(lean && role == TOPO_ROLE_EDGES);
+    const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, members0, true);
     BARRIER();
     topo_pool(tv, g, n0, e0, E, C, has_w, s);
     if (role == TOPO_ROLE_ALL) topo_clusters1(tv, a, g, n0, N, C, src, s, g);

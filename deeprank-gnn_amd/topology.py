@@ -40,7 +40,7 @@ class Topology(object):
     # ---------------------------------------------------------------------------
     @classmethod
     def from_batch(cls, data, api=None, with_level1=True, check=False, need_weights=True, graph_only=False,
-                   build=True):
+                   build=True, flags=None):
         """Build from a ``Batch``-like object (attribute access only).  ``need_weights=False``
         skips everything that involves ``edge_attr`` (GINet's attention is identically 1 and
         FoutLayer never reads it, so only sGAT needs the pooled, summed edge attributes)."""
@@ -97,7 +97,7 @@ class Topology(object):
         topo.has_level1 = cluster1 is not None
         topo._inputs = (edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch)
         if build:
-            topo.rebuild()
+            topo.rebuild(flags)
             if check:
                 topo.check()
         return topo
@@ -119,12 +119,16 @@ class Topology(object):
         self._finalized = False
         return r
 
-    def rebuild(self):
+    def rebuild(self, flags=None):
         """(Re)run the builder into this object's existing buffers, on torch's current stream --
         e.g. on a side stream while the previous mini-batch is still training (the build only
         depends on index tensors, never on parameters).  The input tensors captured at
-        construction are re-read, so refreshing them in place refreshes the topology."""
+        construction are re-read, so refreshing them in place refreshes the topology.
+        ``flags``: TOPO_* request flags (default: everything, with the hierarchical order)."""
         edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch = self._inputs
+        if flags is not None and int(flags) != _lib.TOPO_HIER:
+            self.api.topology_build_request(self.request(flags), _lib.current_stream(batch))
+            return self
         self.flags = _lib.TOPO_HIER          # (drgnn_topology_build always builds the hierarchical order)
         self.api.topology_build(edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,
                                 self.n_nodes, self.n_edges, 0 if cluster1 is None else cluster1.numel(),

@@ -74,8 +74,9 @@ class FusedTrainer(object):
         self.step = self.step2[:1]
         self.fused_step = True       # one launch for fwd + head + bwd whenever a graph fits LDS
         self._xchg = {}              # readout exchange words of the fused step, per batch size
-        # what a co-built topology must hold: the hierarchical node order only for the nets whose step kernels read it
-        self.topo_flags = 0 if self.kind == _lib.GINET else _lib.TOPO_HIER
+        # what a co-built topology must hold: the hierarchical node order, read by the aggregation-first step kernels
+        # (sGAT / FoutNet: every training launch; GINet: the two-workgroup layout only, see _flags_for)
+        self.topo_flags = _lib.TOPO_HIER
         self._desc_cache, self._slab_cache = {}, {}
         self._epoch_scratch = None
         self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -214,13 +215,41 @@ class FusedTrainer(object):
             stream=_lib.current_stream(x), pred=torch.empty((B, self.O), dtype=torch.float32, device=dev),
             readout=readout, partials=partials, hp=hp)
 
+    def _af_launch(self, topo, n_feat, n_next, x=None):
+        """True when a TRAINING launch on ``topo`` (co-building ``n_next`` graphs) runs one of the aggregation-first kernels
+        (csrc/drgnn_step2.h / drgnn_step3.h) -- the launches that accept a workspace built with TOPO_LEAN."""
+        if x is not None and x.data_ptr() % 16:
+            return False
+        if not self.api.net_step_family(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, self.H, self.O):
+            return False
+        if self.kind != _lib.GINET:
+            return True
+        wgs, _ = self.api.net_step_plan(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, self.R, self.H,
+                                        self.O, topo.n_graphs, n_next)
+        return wgs == 2
+
+    def _flags_for(self, topo, n_feat):
+        """Request flags of a topology the next launch co-builds.  The hierarchical node order where a step kernel reads it
+        (GINet's one-workgroup layout beyond the resident batch size does not, and there the builder is co-critical); and
+        ONLY what the aggregation-first kernels read (TOPO_LEAN: the builder's short chains) when the launch that will train
+        on it is one of them -- judged for a following mini-batch of the same size; _fused_launch_step rebuilds in full
+        should that turn out wrong."""
+        af = self._af_launch(topo, n_feat, topo.n_graphs)
+        if af:
+            return _lib.TOPO_HIER | _lib.TOPO_LEAN
+        return 0 if self.kind == _lib.GINET else _lib.TOPO_HIER
+
     def _fused_launch_step(self, c, next_topo=None):
         """ONE launch: body fwd + head/loss + body bwd (+ the next mini-batch's topology)."""
         t = c["topo"]
+        if (int(getattr(t, "flags", 0)) & _lib.TOPO_LEAN) and not self._af_launch(
+                t, c["x"].shape[1], 0 if next_topo is None else next_topo.n_graphs, c["x"]):
+            t.rebuild()      # a lean workspace under a launch that reads more: build the rest (own launch, same stream)
+            c["hints"][0].topo_flags = int(t.flags)
         self.api.net_train_step(c["desc"], self._head_desc(True), c["x"], c["y"], self.step2, t.ws_i32, t.ws_f32,
                                 c["n_nodes"], t.n_edges, c["B"], t.max_nodes, t.max_edges, t.max_c0, c["pred"],
                                 c["readout"], c["hp"], c["partials"], c["xchg"], c["stream"],
-                                next_topology=None if next_topo is None else next_topo.request(self.topo_flags),
+                                next_topology=None if next_topo is None else next_topo.request(self._flags_for(next_topo, c["x"].shape[1])),
                                 hints=None if c.get("hints") is None else c["hints"][0])
 
     def _fused_launch_update(self, c, apply_adam=True, lr=None):
@@ -319,6 +348,8 @@ class FusedTrainer(object):
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
         if self._can_fuse(topo, batch.x.shape[1], next_topo):
             return self._fused(batch, topo, apply_adam, next_topo)
+        if int(getattr(topo, "flags", 0)) & _lib.TOPO_LEAN:
+            topo.rebuild()       # the launch pair reads CSC0 and the member lists a lean build leaves out
         stream = _lib.current_stream(batch.x)
         x, desc, xp, arg0, arg1, readout, scratch = self._body_forward(batch, topo, stream, step_inc=self.step)
         B = topo.n_graphs
@@ -661,6 +692,8 @@ class FusedTrainer(object):
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
+        if int(getattr(topo, "flags", 0)) & _lib.TOPO_LEAN:
+            topo.rebuild()       # inference launches read the depth-0 member lists a lean build leaves out
         if self._can_fuse(topo, batch.x.shape[1], next_topo):
             c = self._fused_prepare(batch, topo, train=False)
             api.net_train_step(c["desc"], self._head_desc(False), c["x"], None, self.step2, topo.ws_i32, topo.ws_f32,

@@ -324,6 +324,15 @@ typedef struct drgnn_topology_request {
  * what the node-split step kernels of the single-branch nets consume (4 more phases on the builder's member-list chain, so
  * callers that never run those kernels -- GINet -- leave it out).  drgnn_topology_build always builds it. */
 #define DRGNN_TOPO_HIER 1
+/* DRGNN_TOPO_LEAN (with DRGNN_TOPO_HIER and cluster1): build ONLY what the aggregation-first training kernels read
+ * (csrc/drgnn_step2.h, drgnn_step3.h): ROWPTR0 / COL0 / EID0 (+ W0), CL0 / NC0, ROWPTR1 / COL1 / NE1 (+ W1), COLPTR1 / ROWIDX1
+ * (+ TSLOT1 with edge weights), CL1 / NC1 / MPTR1 / MEM1, HORD / HMP0 / HSPLIT.  NOT built: CSC0 (COLPTR0 / ROWIDX0 / TSLOT0)
+ * and the depth-0 member lists (MPTR0 / MEM0) -- those arrays keep whatever an earlier build left there.  The builder then
+ * runs two short chains (8 barrier-separated phases each instead of ~19: one concatenated scan for the row pointers and
+ * both cluster rankings, orders by counting instead of bucket sorts, the pooled CSC from a transposed bitmap), which keeps
+ * it hidden behind the step workgroups it is co-launched with.  A launch that is not an aggregation-first training step
+ * refuses a workspace built this way (drgnn_step_hints.topo_flags): DRGNN_E_ARG. */
+#define DRGNN_TOPO_LEAN 2
 /* drgnn_topology_build from a request (either mode), own launch. */
 int drgnn_topology_build_request(const drgnn_topology_request* request, void* stream);
 /* Slot offset tables of EVERY mini-batch of an epoch in one launch: mini-batch k = ids[k*batch_size, ...) gets

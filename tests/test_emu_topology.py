@@ -52,6 +52,63 @@ def test_topology_matches_oracle(make, derive, weights):
     check_against_oracle(topo, batch, weights=weights)
 
 
+@pytest.mark.parametrize("make", [lambda: fixture_batch(8), lambda: fixture_batch(10), syn4_batch,
+                                  lambda: synth.make_batch(0, 3)])
+@pytest.mark.parametrize("weights", [True, False])
+def test_lean_topology_matches_oracle_and_the_full_build(make, weights):
+    """TOPO_LEAN (what the aggregation-first training kernels read, built by the short chains: concatenated scan, orders by
+    counting, transposed bitmap): every array it promises equals the oracle's and the full build's."""
+    from deeprank_gnn_amd import _lib
+    batch = make()
+    full = Topology.from_batch(batch, api=emu(), need_weights=weights)
+    lean = Topology.from_batch(batch, api=emu(), need_weights=weights, flags=_lib.TOPO_HIER | _lib.TOPO_LEAN)
+    assert lean.status()[0] == 0 and (lean.flags & _lib.TOPO_LEAN)
+    check_against_oracle(lean, batch, weights=weights)
+    names = ["ROWPTR0", "COL0", "EID0", "CL0", "NC0", "ROWPTR1", "COL1", "NE1", "COLPTR1", "ROWIDX1", "CL1", "NC1", "MPTR1",
+             "MEM1", "HORD", "HMP0", "HSPLIT"] + (["TSLOT1"] if weights else [])
+    nptr, eptr = full.array("NPTR").numpy(), full.array("EPTR").numpy()
+    nc0, ne1 = full.array("NC0").numpy(), full.array("NE1").numpy()
+    for name in names:
+        a, b = full.array(name).numpy(), lean.array(name).numpy()
+        for g in range(full.n_graphs):
+            n0, N, e0, C, E1 = nptr[g], nptr[g + 1] - nptr[g], eptr[g], nc0[g], ne1[g]
+            seg = {"ROWPTR0": (n0 + g, N + 1), "COL0": (e0, eptr[g + 1] - e0), "EID0": (e0, eptr[g + 1] - e0), "CL0": (n0, N),
+                   "NC0": (g, 1), "ROWPTR1": (n0 + g, C + 1), "COL1": (e0, E1), "NE1": (g, 1), "COLPTR1": (n0 + g, C + 1),
+                   "ROWIDX1": (e0, E1), "TSLOT1": (e0, E1), "CL1": (n0, C), "NC1": (g, 1), "MEM1": (n0, C),
+                   "MPTR1": (n0 + g, lean.array("NC1").numpy()[g] + 1), "HORD": (n0, N), "HMP0": (n0 + g, C + 1),
+                   "HSPLIT": (4 * g, 4)}[name]
+            np.testing.assert_array_equal(a[seg[0]:seg[0] + seg[1]], b[seg[0]:seg[0] + seg[1]], err_msg="%s graph %d" % (name, g))
+    if weights:
+        np.testing.assert_array_equal(full.weights("W0").numpy()[:full.n_edges], lean.weights("W0").numpy()[:full.n_edges])
+        for g in range(full.n_graphs):
+            np.testing.assert_array_equal(full.weights("W1").numpy()[eptr[g]:eptr[g] + ne1[g]],
+                                          lean.weights("W1").numpy()[eptr[g]:eptr[g] + ne1[g]])
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_lean_topology_random_ragged(seed):
+    """Ragged random graphs (single nodes, no edges, gapped ids), both pooling paths, through the lean chains."""
+    from deeprank_gnn_amd import _lib
+    rng = np.random.default_rng(100 + seed)
+    graphs = []
+    for k in range(7):
+        n = int(rng.integers(1, 40))
+        e = int(rng.integers(0, 80))
+        graphs.append(random_graph(rng, n, e, int(rng.integers(1, n + 1)), int(rng.integers(1, 6)), dup=(k % 2 == 0)))
+    batch = Batch.from_data_list(graphs)
+    for weights in (False, True):
+        lean = Topology.from_batch(batch, api=emu(), need_weights=weights, flags=_lib.TOPO_HIER | _lib.TOPO_LEAN)
+        assert lean.status()[0] == 0
+        check_against_oracle(lean, batch, weights=weights)
+    if seed == 0:
+        # beyond 160 graphs the builder runs ONE workgroup per graph: the pool chain, then the structure chain
+        many = Batch.from_data_list([random_graph(rng, int(rng.integers(1, 12)), int(rng.integers(0, 20)), 3, 2) for _ in range(165)])
+        for weights in (False, True):
+            lean = Topology.from_batch(many, api=emu(), need_weights=weights, flags=_lib.TOPO_HIER | _lib.TOPO_LEAN)
+            assert lean.status()[0] == 0
+            check_against_oracle(lean, many, weights=weights)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_topology_random_ragged(seed):
     rng = np.random.default_rng(seed)

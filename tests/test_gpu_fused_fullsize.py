@@ -222,7 +222,14 @@ def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_s
     t64 = Topology.from_batch(small, need_weights=False)
     assert tr.api.net_step_plan(tr.kind, 32, t64.max_nodes, t64.max_edges, t64.max_c0, tr.R, tr.H, tr.O, 64)[0] == 2
     tr.compute_gradients(small, topo=t64)                  # (no update in between: same parameters)
-    pred_two = tr.last_pred.cpu().numpy()
+    pred_af = tr.last_pred.cpu().numpy().copy()            # the aggregation-first two-workgroup kernel (drgnn_step3.h)
+    np.testing.assert_allclose(pred_one, pred_af, rtol=1e-4, atol=1e-5)
+    tr.api.set_step_layout(12)                             # ... and the drgnn_step.h two-workgroup kernel:
+    try:
+        tr.compute_gradients(small, topo=t64)
+        pred_two = tr.last_pred.cpu().numpy()
+    finally:
+        tr.api.set_step_layout(11)
     np.testing.assert_array_equal(pred_one, pred_two)      # forward arithmetic is the same code in both layouts
 
 

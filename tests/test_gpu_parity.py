@@ -196,3 +196,32 @@ def test_pretrained_classifier_known_answer():
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weights", [False, True])
+def test_lean_topology_on_the_device_equals_the_full_build(weights):
+    """TOPO_LEAN (the builder's short chains: concatenated scan, orders by counting / size sums, transposed bitmap) at the
+    benchmarked shape and on a ragged batch: the oracle's topology, and bit for bit the full build's arrays."""
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.topology import Topology
+    from topo_check import check_against_oracle
+    import deeprank_gnn_amd.synthetic as synth
+    dev = torch.device("cuda:0")
+    for batch_cpu in (synth.make_batch(0, 64), synth.make_batch(3, 5, n_nodes=37, n_pairs=60, n_feat=8, n_c1=4, n_internal=10),
+                      synth.make_batch(0, 170, n_nodes=20, n_pairs=30, n_feat=4, n_c1=3, n_internal=6)):
+        batch = batch_cpu.clone().to(dev)
+        full = Topology.from_batch(batch, need_weights=weights)
+        lean = Topology.from_batch(batch, need_weights=weights, flags=_lib.TOPO_HIER | _lib.TOPO_LEAN)
+        assert lean.status()[0] == 0 and (lean.flags & _lib.TOPO_LEAN)
+        check_against_oracle(lean, batch_cpu, weights=weights)
+        nptr, eptr = full.array("NPTR").cpu().numpy(), full.array("EPTR").cpu().numpy()
+        nc0, ne1, nc1 = (full.array(k).cpu().numpy() for k in ("NC0", "NE1", "NC1"))
+        for name in ["ROWPTR0", "COL0", "CL0", "ROWPTR1", "COL1", "COLPTR1", "ROWIDX1", "CL1", "MPTR1", "MEM1", "HORD", "HMP0", "HSPLIT"]:
+            a, b = full.array(name).cpu().numpy(), lean.array(name).cpu().numpy()
+            for g in range(full.n_graphs):
+                n0, N, e0, E, C, E1 = nptr[g], nptr[g + 1] - nptr[g], eptr[g], eptr[g + 1] - eptr[g], nc0[g], ne1[g]
+                lo, n = {"ROWPTR0": (n0 + g, N + 1), "COL0": (e0, E), "CL0": (n0, N), "ROWPTR1": (n0 + g, C + 1), "COL1": (e0, E1),
+                         "COLPTR1": (n0 + g, C + 1), "ROWIDX1": (e0, E1), "CL1": (n0, C), "MPTR1": (n0 + g, nc1[g] + 1),
+                         "MEM1": (n0, C), "HORD": (n0, N), "HMP0": (n0 + g, C + 1), "HSPLIT": (4 * g, 4)}[name]
+                np.testing.assert_array_equal(a[lo:lo + n], b[lo:lo + n], err_msg="%s graph %d" % (name, g))

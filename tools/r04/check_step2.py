@@ -16,8 +16,10 @@ from test_gpu_parity import build
 dev = torch.device("cuda:0")
 api = _lib.get()
 nets = sys.argv[1:] or ["FoutNet", "sGAT"]
-LAYOUTS = [("old", (8,)), ("af1", (7, 10)), ("af2", (7, 9))]
+LAYOUTS_SINGLE = [("old", (8,)), ("af1", (7, 10)), ("af2", (7, 9))]
+LAYOUTS_GINET = [("old", (12,)), ("af", (11,))]      # GINet: drgnn_step.h vs drgnn_step3.h
 for net_name in nets:
+    LAYOUTS = LAYOUTS_GINET if net_name == "GINet" else LAYOUTS_SINGLE
     kw = {"looped": False} if net_name == "FoutNet" else {}
     batch_cpu = synth.make_batch(0, 64)
     params = cpu_ref.init_params(net_name, 32, 1, 1, seed=11)
@@ -57,12 +59,13 @@ for net_name in nets:
             tr.train_step(batch, topo=topos[it & 1], next_topo=topos[1 - (it & 1)])
         torch.cuda.synchronize()
         print("%-8s %-4s eager %.2f us/step, loss after %d steps %.6f" % (net_name, lname, (time.perf_counter() - t0) / n * 1e6, n + 20, float(tr.loss)), flush=True)
-    for m in (7, 9):
+    for m in (7, 9, 11):
         api.set_step_layout(m)
 
 # ---- several Adam steps per layout vs the oracle + torch.optim.Adam (the benchmarked ping-pong schedule) ------------------
 import torch.nn.functional as F
 for net_name in nets:
+    LAYOUTS = LAYOUTS_GINET if net_name == "GINet" else LAYOUTS_SINGLE
     kw = {"looped": False} if net_name == "FoutNet" else {}
     batch_cpu = synth.make_batch(0, 64)
     batch = batch_cpu.clone().to(dev)
@@ -91,5 +94,5 @@ for net_name in nets:
         err = max(float((sd[k].cpu() - v.detach()).abs().max()) for k, v in leaves.items())
         print("%-8s %-4s 6 Adam steps: losses %s vs ref %s  max |param - ref| %.2e" % (
             net_name, lname, ["%.4f" % v for v in got], ["%.4f" % v for v in ref_losses], err), flush=True)
-    for m in (7, 9):
+    for m in (7, 9, 11):
         api.set_step_layout(m)
