@@ -21,7 +21,7 @@ MAX_BRANCH = 2
 TI = {name: i for i, name in enumerate([
     "NPTR", "EPTR", "ROWPTR0", "COL0", "EID0", "COLPTR0", "ROWIDX0", "TSLOT0", "CL0", "NC0",
     "MPTR0", "MEM0", "ROWPTR1", "COL1", "NE1", "COLPTR1", "ROWIDX1", "TSLOT1", "CL1", "NC1",
-    "MPTR1", "MEM1", "CPTR0", "E1PTR", "CPTR1", "ERR", "GSTAT", "HORD", "HMP0", "HSPLIT"])}
+    "MPTR1", "MEM1", "CPTR0", "E1PTR", "CPTR1", "ERR", "GSTAT", "HORD", "HMP0", "HSPLIT", "IHORD"])}
 TI_COUNT = len(TI)
 TF = {"W0": 0, "W1": 1}
 TF_COUNT = 2
@@ -60,11 +60,13 @@ class TopologyRequest(ctypes.Structure):
                 ("ws_i32", _vp), ("ws_f32", _vp), ("scratch_i32", _vp),
                 # resident-set mode (include/drgnn.h); left NULL by the Python-level Topology
                 ("set", _vp), ("ids", _vp), ("x_out", _vp), ("y_out", _vp),
-                ("flags", _c_i32), ("reserved", _c_i32)]
+                ("flags", _c_i32), ("reserved", _c_i32),
+                ("x", _vp), ("tiles", _vp), ("n_feat", _c_i32), ("reserved2", _c_i32)]
 
 
 TOPO_HIER = 1          # drgnn_topology_request.flags: also build the hierarchical node order (HORD / HMP0 / HSPLIT)
 TOPO_LEAN = 2          # ... and ONLY what the aggregation-first training kernels read (no CSC0, no depth-0 member lists)
+TOPO_TILES = 4         # ... and the level-0 neighbour aggregation of every node (drgnn_topology_request.x / tiles)
 
 
 class GraphSet(ctypes.Structure):
@@ -95,13 +97,14 @@ EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ct
 class StepHints(ctypes.Structure):
     """drgnn_step_hints: host-side offset tables of a launch's graphs (pointers to HOST memory)."""
     _fields_ = [("host_node_ptr", _vp), ("host_edge_ptr", _vp), ("set_node_ptr", _vp), ("set_edge_ptr", _vp),
-                ("host_ids", _vp), ("topo_flags", _c_i32), ("split", _c_i32)]
+                ("host_ids", _vp), ("topo_flags", _c_i32), ("split", _c_i32), ("tiles", _vp)]
 
 
 class TopologyCacheDesc(ctypes.Structure):
     """drgnn_topology_cache: one topology workspace over a whole resident set + its node features / targets."""
     _fields_ = [("n_graphs", _c_i64), ("n_nodes", _c_i64), ("n_edges", _c_i64),
-                ("ws_i32", _vp), ("ws_f32", _vp), ("x", _vp), ("y", _vp), ("y_bytes", _c_i32), ("flags", _c_i32)]
+                ("ws_i32", _vp), ("ws_f32", _vp), ("x", _vp), ("y", _vp), ("y_bytes", _c_i32), ("flags", _c_i32),
+                ("tiles", _vp)]
 
 
 class HeadDesc(ctypes.Structure):
@@ -215,6 +218,11 @@ class Api(object):
         lib.drgnn_train_epoch_scratch_bytes.restype = _c_i64
         lib.drgnn_train_epoch.argtypes = [ctypes.POINTER(EpochPlan), _vp, _c_i64, _vp, _vp, _vp]
         lib.drgnn_topology_build_request.argtypes = [ctypes.POINTER(TopologyRequest), _vp]
+        lib.drgnn_topology_tiles.argtypes = [_vp, _vp, _c_i64, _c_i64, _c_i64, _vp, _c_i32, _c_i32, _vp, _vp]
+        lib.drgnn_topology_tiles_elems.restype = _c_i64
+        lib.drgnn_topology_tiles_elems.argtypes = [_c_i64, _c_i32]
+        lib.drgnn_topology_tiles_ok.restype = _c_i32
+        lib.drgnn_topology_tiles_ok.argtypes = [_c_i32, _c_i32, _c_i32]
         lib.drgnn_batch_offsets.argtypes = [ctypes.POINTER(GraphSet), _vp, _c_i64, _c_i32, _vp, _vp]
         lib.drgnn_collate.argtypes = [ctypes.POINTER(GraphSet), _vp] + [_c_i64] * 3 + [_vp] * 11
         lib.drgnn_head_partial_elems.argtypes = [_c_i32] * 3
@@ -419,6 +427,18 @@ class Api(object):
                                       _ptr(cluster1), _ptr(y), _ptr(node_ptr), _ptr(edge_ptr), _ptr(c1_ptr),
                                       stream), "drgnn_collate")
 
+    def topology_tiles(self, ws_i32, ws_f32, n_nodes, n_edges, n_graphs, x, n_feat, use_weights, tiles, stream):
+        """Aggregation tiles of an already built workspace (a second flavour for a shared cached topology)."""
+        _check(self.lib.drgnn_topology_tiles(_ptr(ws_i32), _ptr(ws_f32), int(n_nodes), int(n_edges), int(n_graphs), _ptr(x),
+                                             int(n_feat), int(bool(use_weights)), _ptr(tiles), stream), "drgnn_topology_tiles")
+
+    def topology_tiles_elems(self, n_nodes, n_feat):
+        return int(self.lib.drgnn_topology_tiles_elems(int(n_nodes), int(n_feat)))
+
+    def topology_tiles_ok(self, max_nodes, max_edges, n_feat):
+        """True when the builder can form the level-0 aggregation tiles (TOPO_TILES) for graphs of these bounds."""
+        return bool(self.lib.drgnn_topology_tiles_ok(int(max_nodes), int(max_edges), int(n_feat)))
+
     def topology_build_request(self, request, stream):
         _check(self.lib.drgnn_topology_build_request(ctypes.byref(request), stream), "drgnn_topology_build_request")
 
@@ -520,7 +540,7 @@ def current_stream(ref):
     return None
 
 
-def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None, topo_flags=0, split=0):
+def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None, topo_flags=0, split=0, tiles=None):
     """(StepHints, keep-alive tuple) from numpy arrays: int32 per-mini-batch tables, or int64 set tables + int32 ids."""
     import numpy as np
     h = StepHints()
@@ -535,4 +555,7 @@ def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=Non
     h.host_node_ptr, h.host_edge_ptr = pin(node_ptr, np.int32), pin(edge_ptr, np.int32)
     h.set_node_ptr, h.set_edge_ptr, h.host_ids = pin(set_node_ptr, np.int64), pin(set_edge_ptr, np.int64), pin(ids, np.int32)
     h.topo_flags, h.split = int(topo_flags), int(split)
+    h.tiles = _ptr(tiles)
+    if tiles is not None:
+        keep.append(tiles)
     return h, tuple(keep)

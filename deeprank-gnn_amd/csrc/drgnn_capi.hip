@@ -52,14 +52,27 @@ int64_t drgnn_topology_scratch_elems(int64_t n_nodes, int64_t n_edges, int64_t n
     return topo_gscratch_base(n_nodes, n_edges, n_graphs) + TOPO_GSCRATCH_CONST;
 }
 
-static int64_t topo_lds_bytes(int capN, int capE) {
+// tile_f > 0: + the x tile of the aggregation tiles (DRGNN_TOPO_TILES)
+static int64_t topo_lds_bytes(int capN, int capE, int tile_f = 0) {
     const int64_t capT = (capN > capE ? capN : capE) + 1;
-    return 4 * topo_scratch_ints(capN, capE, capT, (int64_t)capN + capE + 2);
+    return 4 * (topo_scratch_ints(capN, capE, capT, (int64_t)capN + capE + 2) + (tile_f > 0 ? (int64_t)capN * (tile_f + 4) : 0));
+}
+static bool topo_tiles_shape_ok(int capN, int capE, int F) {
+    if (capN <= 0 || F <= 0 || (F & 3) || F > 256 || (int64_t)capN * F > 16 * DRGNN_BCAP) return false;      // (x tile: 4 float4 per lane)
+    return topo_lds_bytes(capN, capE > 0 ? capE : 1, F) <= DRGNN_LDS_LIMIT;
 }
 
 int64_t drgnn_topology_lds_bytes(int32_t max_nodes, int32_t max_edges) {
     if (max_nodes <= 0) return 0;
     return topo_lds_bytes(max_nodes, max_edges > 0 ? max_edges : 1);
+}
+
+int64_t drgnn_topology_tiles_elems(int64_t n_nodes, int32_t n_feat) {
+    if (n_nodes < 0 || n_feat <= 0) return 0;
+    return n_nodes * ((int64_t)n_feat + 2);
+}
+int32_t drgnn_topology_tiles_ok(int32_t max_nodes, int32_t max_edges, int32_t n_feat) {
+    return topo_tiles_shape_ok(max_nodes, max_edges, n_feat) ? 1 : 0;
 }
 
 }  // extern "C"
@@ -73,7 +86,8 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
                         const int32_t* node_ptr, const int32_t* edge_ptr, const int32_t* c1_ptr,
                         int64_t n_nodes, int64_t n_edges, int64_t len_cluster1, int64_t n_graphs,
                         int32_t max_nodes, int32_t max_edges, int32_t* ws_i32, float* ws_f32,
-                        int32_t* scratch_i32, int32_t flags = DRGNN_TOPO_HIER) {
+                        int32_t* scratch_i32, int32_t flags = DRGNN_TOPO_HIER, const float* x_in = nullptr,
+                        float* tiles = nullptr, int32_t tile_f = 0) {
     if (n_nodes < 0 || n_edges < 0 || n_graphs < 0 || !ws_i32) return DRGNN_E_ARG;
     if (!batch && !(node_ptr && edge_ptr)) return DRGNN_E_ARG;      // the offsets are derived from `batch`
     if (!cluster0 && cluster1) return DRGNN_E_ARG;
@@ -95,6 +109,14 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     L.args.set_x = nullptr; L.args.set_y = nullptr; L.args.x_out = nullptr; L.args.y_out = nullptr;
     L.args.n_set = 0; L.args.n_feat = 0; L.args.y_bytes = 0;
     L.args.flags = flags;
+    L.args.x_in = nullptr; L.args.tiles = nullptr; L.args.tile_nodes = n_nodes; L.args.tile_f = 0;
+    if (flags & DRGNN_TOPO_TILES) {
+        // the aggregation tiles need the hierarchical order's companions, an output buffer and float4-loadable features
+        // (x_in null: resident-set mode, the caller fills in the set's x and checks it)
+        if (!(flags & DRGNN_TOPO_HIER) || !tiles || (x_in && (((uintptr_t)x_in) & 15)) || (((uintptr_t)tiles) & 15)) return DRGNN_E_ARG;
+        if (!topo_tiles_shape_ok(max_nodes, max_edges, tile_f)) return DRGNN_E_CAPACITY;
+        L.args.x_in = x_in; L.args.tiles = tiles; L.args.tile_f = tile_f;
+    }
     L.gscratch = scratch_i32;
     L.level1_only = 0;
     L.roles = 1;
@@ -103,10 +125,11 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     int64_t lds = 0;
     L.capN = 0; L.capE = 0;
     if (max_nodes > 0) {
-        lds = topo_lds_bytes(max_nodes, max_edges > 0 ? max_edges : 1);
+        lds = topo_lds_bytes(max_nodes, max_edges > 0 ? max_edges : 1, L.args.tile_f);
         if (lds <= DRGNN_LDS_LIMIT) { L.capN = max_nodes; L.capE = max_edges > 0 ? max_edges : 1; }
         else lds = 0;
     }
+    if (L.args.tile_f > 0 && L.capN == 0) return DRGNN_E_CAPACITY;      // (tiles are formed by the LDS builder only)
     // two independent workgroups per graph (edge structures / member lists) when nothing forces the
     // single-chain order: LDS path, clusters present, depth-1 ids located by the caller
     // ... and when the extra workgroups find idle CUs: two workgroups per graph shorten the builder's critical path
@@ -125,15 +148,17 @@ static int topo_prepare_req(TopoLaunch& T, int64_t* tlds, const drgnn_topology_r
     if (!gs)
         return topo_prepare(T, tlds, r->edge_index, r->edge_attr, r->batch, r->cluster0, r->cluster1, r->node_ptr,
                             r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs, r->max_nodes,
-                            r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags);
+                            r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags, r->x, r->tiles, r->n_feat);
     if (!r->ids || !r->node_ptr || !r->edge_ptr || !gs->node_ptr || !gs->edge_ptr || !gs->cluster0) return DRGNN_E_ARG;
     if (gs->cluster1 && (!gs->c1_ptr || !r->c1_ptr)) return DRGNN_E_ARG;
     if (r->x_out && (!gs->x || gs->n_feat <= 0)) return DRGNN_E_ARG;
     if (r->y_out && (!gs->y || (gs->y_bytes != 4 && gs->y_bytes != 8))) return DRGNN_E_ARG;
     const float* attr = (r->ws_f32 && gs->edge_attr) ? gs->edge_attr : nullptr;
+    if ((r->flags & DRGNN_TOPO_TILES) && (!gs->x || gs->n_feat <= 0 || (((uintptr_t)gs->x) & 15))) return DRGNN_E_ARG;
     const int rc = topo_prepare(T, tlds, gs->edge_index, attr, nullptr, gs->cluster0, gs->cluster1, r->node_ptr,
                                 r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs,
-                                r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags);
+                                r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags, nullptr, r->tiles,
+                                gs->n_feat);
     if (rc) return rc;
     TopoArgs& a = T.args;
     a.n_edges = gs->n_edges;                  // row stride of the SET's edge_index
@@ -148,13 +173,14 @@ static int topology_build_impl(const int64_t* edge_index, const float* edge_attr
                          const int32_t* edge_ptr, const int32_t* c1_ptr, int64_t n_nodes,
                          int64_t n_edges, int64_t len_cluster1, int64_t n_graphs, int32_t max_nodes,
                          int32_t max_edges, int32_t* ws_i32, float* ws_f32, int32_t* scratch_i32,
-                         int32_t flags, void* stream_) {
+                         int32_t flags, void* stream_, const float* x_in = nullptr, float* tiles = nullptr,
+                         int32_t tile_f = 0) {
     drgnn_stream_t stream = (drgnn_stream_t)stream_;
     TopoLaunch L;
     int64_t lds = 0;
     int rc0 = topo_prepare(L, &lds, edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,
                            n_nodes, n_edges, len_cluster1, n_graphs, max_nodes, max_edges, ws_i32, ws_f32,
-                           scratch_i32, flags);
+                           scratch_i32, flags, x_in, tiles, tile_f);
     if (rc0) return rc0;
     if (L.capN == 0 && !scratch_i32) return DRGNN_E_CAPACITY;
     if (n_graphs == 0) return 0;
@@ -216,7 +242,8 @@ int drgnn_topology_build_request(const drgnn_topology_request* r, void* stream_)
     if (!r->set)
         return topology_build_impl(r->edge_index, r->edge_attr, r->batch, r->cluster0, r->cluster1, r->node_ptr,
                                    r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs,
-                                   r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags, stream_);
+                                   r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags, stream_,
+                                   r->x, r->tiles, r->n_feat);
     TopoLaunch L;
     int64_t lds = 0;
     const int rc = topo_prepare_req(L, &lds, r);
@@ -236,6 +263,26 @@ int drgnn_topology_build_request(const drgnn_topology_request* r, void* stream_)
         HIP_TRY(hipFuncSetAttribute((const void*)k_topo<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (L.capN > 0) hipLaunchKernelGGL(k_topo<true>, dim3((unsigned)(r->n_graphs * L.roles)), dim3(DRGNN_NTHREADS), (size_t)lds, stream, L);
     else hipLaunchKernelGGL(k_topo<false>, dim3((unsigned)r->n_graphs), dim3(DRGNN_NTHREADS), 0, stream, L);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
+}
+
+int drgnn_topology_tiles(const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                         const float* x, int32_t n_feat, int32_t use_weights, float* tiles, void* stream_) {
+    if (!ws_i32 || !x || !tiles || n_nodes < 0 || n_edges < 0 || n_graphs < 0 || n_feat <= 0) return DRGNN_E_ARG;
+    if (use_weights && !ws_f32) return DRGNN_E_ARG;
+    if (n_graphs == 0) return 0;
+    TopoLayout lay;
+    topo_layout(n_nodes, n_edges, n_graphs, &lay);
+    TilesArgs a;
+    a.tv = topo_view(const_cast<int32_t*>(ws_i32), const_cast<float*>(ws_f32), lay);
+    a.x = x; a.tiles = tiles; a.n_nodes = n_nodes; a.n_feat = n_feat; a.use_weights = use_weights ? 1 : 0;
+#ifdef DRGNN_EMU
+    for (int64_t g = 0; g < n_graphs; ++g) tiles_block(a, (int)g);
+    (void)stream_;
+#else
+    hipLaunchKernelGGL(k_tiles, dim3((unsigned)n_graphs), dim3(DRGNN_NTHREADS), 0, (hipStream_t)stream_, a);
     HIP_TRY(hipGetLastError());
 #endif
     return 0;
@@ -713,7 +760,9 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     if (kind != DRGNN_GINET) {
         const bool want_split = hints && hints->split == 1;
         const bool hier = hints && (hints->topo_flags & DRGNN_TOPO_HIER) != 0;
-        const bool shape = hd->train && hier && ((((uintptr_t)x) & 15) == 0) &&
+        const bool tiles = hints && (hints->topo_flags & DRGNN_TOPO_TILES) && hints->tiles && ((((uintptr_t)hints->tiles) & 15) == 0);
+        // (the caller vouches for the tiles' flavour: weighted sums for sGAT, plain sums for FoutNet / GINet)
+        const bool shape = hd->train && hier && tiles && ((((uintptr_t)x) & 15) == 0) &&
                            step2_shape_ok(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
         if (want_split) {
             if (!shape || !xchg) return DRGNN_E_CAPACITY;
@@ -728,7 +777,8 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     bool af3 = false;
     if (kind == DRGNN_GINET) {
         const bool hier = hints && (hints->topo_flags & DRGNN_TOPO_HIER) != 0;
-        af3 = hd->train && hier && ((((uintptr_t)x) & 15) == 0) && step3_shape_ok(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
+        const bool tiles = hints && (hints->topo_flags & DRGNN_TOPO_TILES) && hints->tiles && ((((uintptr_t)hints->tiles) & 15) == 0);
+        af3 = hd->train && hier && tiles && step3_shape_ok(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
     }
 #else
     if (hints && hints->split == 1) return DRGNN_E_CAPACITY;      // (the emulation build has no node-split kernels)
@@ -747,6 +797,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     topo_layout(n_nodes, n_edges, ws_graphs, &lay);
     StepArgs& a = L.a;
     a.gather_ids = gather_ids; a.ws_graphs = (int)ws_graphs;
+    a.tiles = (hints && (hints->topo_flags & DRGNN_TOPO_TILES)) ? hints->tiles : nullptr; a.tile_nodes = n_nodes;
     L.dims.count = 0;
     // host-known graph numbers of a cached-topology launch are range-checked whatever the batch size: the kernel reads the
     // set's tables at gather_ids[g] as is
@@ -1592,7 +1643,7 @@ int drgnn_collate(const drgnn_graph_set* set, const int32_t* ids, int64_t n_grap
 // ---- one training epoch, driven from here ---------------------------------------------------------
 namespace {
 struct EpochBatch { int64_t first, B, N, E, C; int maxN, maxE, maxC; };
-struct EpochSlot { float* x; void* y; int32_t* ws_i32; float* ws_f32; };
+struct EpochSlot { float* x; void* y; int32_t* ws_i32; float* ws_f32; float* tiles; };
 struct EpochCarve {
     EpochSlot slot[2];
     int32_t* ptrs;                 // [n_batches][3][batch_size + 1]
@@ -1650,7 +1701,10 @@ int epoch_step_wgs(const drgnn_epoch_plan* p, const EpochBatch& b, int64_t co, i
     const drgnn_head_desc* hd = p->head;
     int wgs = drgnn_net_step_plan(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O, b.B, co, lds);
     if (wgs == 2 && p->net->kind != DRGNN_GINET) {
-        const bool hier = p->cache ? (p->cache->flags & DRGNN_TOPO_HIER) != 0 : true;      // (the loop's own builds ask for it)
+        // (the node-split kernels start from the aggregation tiles: a cache built with them, or the loop's own builds)
+        const bool hier = p->cache ? ((p->cache->flags & DRGNN_TOPO_HIER) != 0 && (p->cache->flags & DRGNN_TOPO_TILES) != 0 &&
+                                      p->cache->tiles != nullptr)
+                                   : drgnn_topology_tiles_ok(b.maxN, b.maxE, p->net->n_feat) != 0;
         if (p->inference || !hier) {
             wgs = 1;
             if (lds) *lds = drgnn_net_step_lds_bytes(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O);
@@ -1698,8 +1752,9 @@ int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
     const int F = p->net->n_feat, nbr = p->net->n_branch;
     for (int s = 0; s < 2; ++s) {
         EpochSlot& t = c->slot[s];
-        if (p->cache) { t.x = nullptr; t.y = nullptr; t.ws_i32 = nullptr; t.ws_f32 = nullptr; continue; }   // nothing to build
+        if (p->cache) { t.x = nullptr; t.y = nullptr; t.ws_i32 = nullptr; t.ws_f32 = nullptr; t.tiles = nullptr; continue; }   // nothing to build
         t.x = (float*)take(capN * F * 4);
+        t.tiles = (float*)take(drgnn_topology_tiles_elems(capN, F) * 4);      // (aggregation tiles of the slot's mini-batch)
         t.y = take(capB * 8);
         t.ws_i32 = (int32_t*)take(ws_i * 4);
         t.ws_f32 = p->need_weights ? (float*)take(ws_f * 4) : nullptr;
@@ -1767,6 +1822,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
             hints.set_node_ptr = p->host_node_ptr; hints.set_edge_ptr = p->host_edge_ptr; hints.host_ids = p->host_ids + b.first;
             const bool split = train && p->net->kind != DRGNN_GINET && epoch_step_wgs(p, b, 0, nullptr) == 2;
             hints.topo_flags = train ? p->cache->flags : 0; hints.split = split ? 1 : 0;
+            hints.tiles = train ? p->cache->tiles : nullptr;
             rc = drgnn_net_train_step_cached(p->net, &head, &tc, p->ids + b.first, b.B, b.maxN, b.maxE, b.maxC, p->step2,
                                              pred + b.first * hd->O, c.readout, train ? c.head_partials : nullptr,
                                              train ? c.partials : nullptr, c.xchg, &hints, stream);
@@ -1794,9 +1850,12 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         r.flags = 0;
         if (train) {
             const bool fam = drgnn_net_step_family(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->H, hd->O) == 1 &&
-                             ((((uintptr_t)u.x) & 15) == 0);
-            if (p->net->kind != DRGNN_GINET) r.flags = DRGNN_TOPO_HIER | (fam ? DRGNN_TOPO_LEAN : 0);
-            else if (fam && epoch_step_wgs(p, b, epoch_next_b(p, k), nullptr) == 2) r.flags = DRGNN_TOPO_HIER | DRGNN_TOPO_LEAN;
+                             ((((uintptr_t)u.x) & 15) == 0) && drgnn_topology_tiles_ok(b.maxN, b.maxE, p->net->n_feat) != 0 &&
+                             p->set->x != nullptr && ((((uintptr_t)p->set->x) & 15) == 0);
+            const int32_t af = DRGNN_TOPO_HIER | DRGNN_TOPO_LEAN | DRGNN_TOPO_TILES;
+            if (p->net->kind != DRGNN_GINET) r.flags = fam ? af : DRGNN_TOPO_HIER;
+            else if (fam && epoch_step_wgs(p, b, epoch_next_b(p, k), nullptr) == 2) r.flags = af;
+            if (r.flags & DRGNN_TOPO_TILES) { r.tiles = u.tiles; r.n_feat = p->net->n_feat; }
         }
         return r;
     };
@@ -1821,6 +1880,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         drgnn_step_hints hints = {};
         const bool split = train && p->net->kind != DRGNN_GINET && epoch_step_wgs(p, cur, more ? nxt.B : 0, nullptr) == 2;
         hints.topo_flags = cur_flags;      // (what request() asked the builder for)
+        hints.tiles = (cur_flags & DRGNN_TOPO_TILES) ? t.tiles : nullptr;
         hints.split = split ? 1 : 0;
         if (cur.B <= DRGNN_STEP_DIMS_MAX) {
             hn.resize((size_t)cur.B + 1); he.resize((size_t)cur.B + 1);

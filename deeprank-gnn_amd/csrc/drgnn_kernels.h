@@ -103,6 +103,9 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
     if (LDS) {
         const int capT = imax(L.capN, L.capE) + 1;
         s = topo_carve(lds, L.capN, L.capE, capT, L.capN + L.capE + 2);
+        // the x tile of the aggregation tiles sits behind the carve (topo_lds_bytes counts it)
+        if (L.args.tile_f > 0 && L.args.tiles != nullptr)
+            s.xs = (float*)(lds + topo_scratch_ints(L.capN, L.capE, capT, (int64_t)L.capN + L.capE + 2));
         if (N > L.capN || E > L.capE) {   // caller's bound was wrong: refuse loudly
             FOR_TID(i, 1) { topo_flag(L.tv, DRGNN_S_EDGE_RANGE, sidx); }
             return;
@@ -131,6 +134,45 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
         if ((int64_t)begin + C0 > L.args.len_cluster1) len = -1;
         topo_graph_level1(L.tv, L.args, g, n0, C0, L.args.cluster1 + begin, len, s, g, false,
                           (L.args.flags & DRGNN_TOPO_HIER) ? L.tv.p[DRGNN_TI_CL0] + n0 : nullptr, N);
+    }
+}
+
+// aggregation tiles from a built workspace (drgnn_topology_tiles): one workgroup per graph, everything read from global memory
+struct TilesArgs { TopoView tv; const float* x; float* tiles; int64_t n_nodes; int n_feat, use_weights; };
+DEV void tiles_block(const TilesArgs& a, int g) {
+    const int n0 = a.tv.p[DRGNN_TI_NPTR][g], N = a.tv.p[DRGNN_TI_NPTR][g + 1] - n0;
+    const int e0 = a.tv.p[DRGNN_TI_EPTR][g];
+    const int32_t* rp = a.tv.p[DRGNN_TI_ROWPTR0] + n0 + g;
+    const int32_t* col = a.tv.p[DRGNN_TI_COL0] + e0;
+    const float* w = (a.use_weights && a.tv.w0) ? a.tv.w0 + e0 : nullptr;
+    const int F = a.n_feat;
+    const float* x = a.x + (long long)n0 * F;
+    float* ts = a.tiles + (long long)n0 * F;
+    float* td = a.tiles + a.n_nodes * F + n0;
+    float* tc = td + a.n_nodes;
+    FOR_TID(item, N * F) {
+        const int i = item / F, f = item - i * F;
+        const int lo = rp[i], hi = rp[i + 1], deg = hi - lo;
+        float acc = 0.0f, asum = 0.0f;
+        if (w != nullptr) {
+            // (the builder's order: batches of four products, the last one padded under a zero coefficient -- same bits)
+            for (int k = lo; k < hi; k += 4)
+                for (int j = 0; j < 4; ++j) {
+                    const int kk = (k + j < hi) ? k + j : hi - 1;
+                    const float cf = ((k + j < hi) ? 1.0f : 0.0f) * w[kk];
+                    asum += cf;
+                    acc = fmaf(cf, x[(long long)col[kk] * F + f], acc);
+                }
+        } else {
+            for (int k = lo; k < hi; ++k) acc += x[(long long)col[k] * F + f];
+        }
+        ts[(long long)i * F + f] = acc;
+        if (f == 0) {
+            float d, sc;
+            if (w != nullptr) { d = 1.0f / (float)(deg > 0 ? deg : 1); sc = asum * d; }
+            else { d = deg > 0 ? 1.0f / (float)deg : 0.0f; sc = 1.0f; }
+            td[i] = d; tc[i] = sc;
+        }
     }
 }
 
@@ -527,6 +569,7 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_topo(TopoLaunch L) {
     topo_block<LDS>(L, blockIdx.x, smem_i);
 }
 #ifdef DRGNN_KERNELS_MAIN
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_tiles(TilesArgs a) { tiles_block(a, blockIdx.x); }
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_finalize(ScanArgs a) {
     __shared__ int part[DRGNN_NTHREADS + 4];
     finalize_block(a, part);

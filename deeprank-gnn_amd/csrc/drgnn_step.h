@@ -59,6 +59,9 @@ struct StepArgs {
     // resident set, ws_graphs graphs); null: slot g = graph g of a per-mini-batch workspace
     const int32_t* gather_ids;
     int ws_graphs;
+    // aggregation tiles of the workspace (DRGNN_TOPO_TILES): S [tile_nodes][F] | D [tile_nodes] | C [tile_nodes], node order
+    const float* tiles;
+    int64_t tile_nodes;
 };
 
 HD int64_t head_compact_floats(int R, int H, int O) { (void)R; return (int64_t)H + (int64_t)O * H + O + 2; }

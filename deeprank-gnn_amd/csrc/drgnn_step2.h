@@ -11,6 +11,11 @@
 //      computes.  And because x is a leaf (no d loss / d x), the backward of conv1 needs NO transposed aggregation at all:
 //          dWn = G^T dZ1,   dWs = X^T (s . dZ1),   db = colsum dZ1
 //      -- CSC0, its slot map and the per-entry coefficient array disappear from the step (and from LDS).
+//      G itself depends on the inputs only (edge_attr is data, sGAT.py:76): the topology builder forms the raw sums S_i =
+//      sum_e c_e x_col(e), D_i = d_i and C_i = s_i (DRGNN_TOPO_TILES, include/drgnn.h) in the workgroups co-launched with the
+//      PREVIOUS step (cached topology: once per graph), and this kernel's prologue loads the S and x rows of its nodes, filing
+//      row i at its hierarchical position (IHORD); conv1 is then Z1 = relu(D . (S Wn) + C . (x Ws) + b) and its backward
+//      dWn = S^T (D . dZ1), dWs = X^T (C . dZ1).
 //  (2) rows are kept in the HIERARCHICAL node order the topology builder emits (DRGNN_TI_HORD / HMP0 / HSPLIT): members of a
 //      depth-0 cluster are consecutive rows, the depth-0 clusters of a depth-1 cluster consecutive runs.  Both poolings are
 //      maxima over CONTIGUOUS rows (no member lists), and a prefix of the depth-1 clusters -- the split point the builder
@@ -40,8 +45,7 @@ struct Step2Scratch {
     float* misc; float* xr; float* hid; float* dhid; float* hb1; float* bsum; float* wb;
     float* w1t; float* ws1t; float* b1; float* wc2t; float* wc2n; float* b2;
     float* xs;
-    int* rp0; int* cx0; float* ew0;
-    int* hord; int* hmp; int* cid; int* mp1;
+    int* hmp; int* cid; int* mp1;
     int* rp1; int* cx1; float* ew1; int* cp1; int* rx1; int* ts1;
     short* a0; short* a1;
     float* G; float* z1; float* dv0; float* sc0;
@@ -66,10 +70,6 @@ struct Step2Scratch {
     X(wc2n, DRGNN_H2 * STEP2_TSLD, 1)                                                          \
     X(b2, DRGNN_H2, 1)                                                                         \
     X(xs, (long)(capN + 4) * xld, 1)                                                           \
-    X(rp0, capN + 1, 1)                                                                        \
-    X(cx0, (sg ? (capE + 1) / 2 : capE), 1)                                                    \
-    X(ew0, capE, sg)                                                                           \
-    X(hord, capN, 1)                                                                           \
     X(hmp, capC + 1, 1)                                                                        \
     X(cid, capC, 1)                                                                            \
     X(mp1, capC + 1, 1)                                                                        \
@@ -118,6 +118,34 @@ HD int64_t step2_xchg_words(int64_t capC) { return 4 * capC * DRGNN_H1 + 2 * DRG
 
 #ifndef DRGNN_EMU
 
+// ---- prologue: the S rows of the graph (node order, global) -> G rows at their hierarchical positions -------------------------
+// The position of every row travels with the burst: lane l's j-th float4 belongs to node row (l + j * threads) / (F / 4).
+template <int J> struct BurstRowMap { int r[J * DRGNN_BSCALE]; };
+template <int J> DEV void burst_load_rowmap(BurstRowMap<J>& m, const BurstX<J>& b, const int32_t* map, int nrows) {
+    const FastDiv fd = fastdiv_make(b.F >> 2);
+#pragma unroll
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        if (j > 0 && b.n4 <= j * DRGNN_NTHREADS) break;
+        const int q = threadIdx.x + j * DRGNN_NTHREADS;
+        int v = (q < b.n4) ? map[fastdiv(fd, q)] : 0;
+        m.r[j] = ((unsigned)v < (unsigned)nrows) ? v : 0;      // (a position outside the graph can only come from a workspace the builder refused: stay inside LDS)
+    }
+}
+// rows whose position lies in [base, base + count) go to LDS row (position - base); the others are not this workgroup's
+template <int J> DEV void burst_store_x4_rows(const BurstX<J>& b, const BurstRowMap<J>& m, float* dst, int ld, int base = 0,
+                                              int count = 0x7fffffff) {
+    const FastDiv fd = fastdiv_make(b.F >> 2);
+#pragma unroll
+    for (int j = 0; j < J * DRGNN_BSCALE; ++j) {
+        if (j > 0 && b.n4 <= j * DRGNN_NTHREADS) break;
+        const int q = threadIdx.x + j * DRGNN_NTHREADS;
+        if (q < b.n4 && (unsigned)(m.r[j] - base) < (unsigned)count) {
+            const int row = fastdiv(fd, q);
+            *(drgnn_f4*)(dst + (m.r[j] - base) * ld + 4 * fastmod(fd, q, row)) = b.v[j];
+        }
+    }
+}
+
 template <int CLS>
 DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, int capC, int H, int O) {
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
@@ -135,67 +163,19 @@ DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, i
     return s;
 }
 
-// ---- phase A: G_i = d_i sum_e c_e x_col(e) over the own rows (hierarchical positions), coefficients filed for later ----
-// XLD - 4 = padded feature width: (XLD - 4) / 4 lanes per row, one float4 of the row each
-template <int KIND, int XLD, class IdxT>
-DEV void step2_aggregate(int n, const int* hord, int nbase, const int* rp, const IdxT* col, const float* w, const float* xs,
-                         float* G, float* dv, float* sc) {
-    constexpr int LPR = (XLD - 4) / 4;
-    FOR_TID(item, n * LPR) {
-        const int p = item / LPR, c = (item % LPR) * 4;
-        const int i = hord[nbase + p];
-        const int lo = rp[i], hi = rp[i + 1];
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, asum = 0.f;
-        if (KIND == DRGNN_SGAT) {
-            // batches of four independent (index -> row) chains, the last one padded under a zero coefficient (drgnn_net.h)
-            for (int k = lo; k < hi; k += 4) {
-                int kk[4];
-                float cf[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { kk[j] = (k + j < hi) ? k + j : hi - 1; cf[j] = (k + j < hi) ? 1.0f : 0.0f; }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { cf[j] *= w[kk[j]]; asum += cf[j]; }
-                const float* xj[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) xj[j] = xs + ROW24(col[kk[j]], XLD) + c;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const drgnn_f4 v = *(const drgnn_f4*)xj[j];
-                    a0 = fmaf(cf[j], v[0], a0); a1 = fmaf(cf[j], v[1], a1); a2 = fmaf(cf[j], v[2], a2); a3 = fmaf(cf[j], v[3], a3);
-                }
-            }
-        } else {
-#pragma unroll 4
-            for (int k = lo; k < hi; ++k) {
-                const drgnn_f4 v = *(const drgnn_f4*)(xs + ROW24(col[k], XLD) + c);
-                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
-            }
-        }
-        const int deg = hi - lo;
-        float d, s;
-        if (KIND == DRGNN_SGAT) { d = 1.0f / (float)(deg > 0 ? deg : 1); s = asum * d; }
-        else { d = deg > 0 ? 1.0f / (float)deg : 0.0f; s = 1.0f; }      // d == 0 <=> no out-edges (FoutNet: NaN row)
-        *(drgnn_f4*)(G + p * XLD + c) = drgnn_f4{a0 * d, a1 * d, a2 * d, a3 * d};
-        if (c == 0) { dv[p] = d; sc[p] = s; }
-    }
-    // rows [n, pad4(n)): zero (K padding of the weight-gradient product)
-    FOR_TID(e, (step_pad4(n) - n) * XLD) { G[n * XLD + e] = 0.0f; }
-    FOR_TID(e, step_pad4(n) - n) { sc[n + e] = 0.0f; dv[n + e] = 1.0f; }
-}
-
-// ---- phase B: Z1 = relu(G Wn + s . (X Ws) + b) over the own rows; X rows through the hierarchical order ----------------
+// ---- phase B: Z1 = relu(D . (S Wn) + C . (X Ws) + b) over the own rows (S, X rows at their local positions) ---------------
 template <int KIND, int XF>
-DEV void step2_conv1(int n, int nmax, const int* hord, int nbase, const float* G, const float* xs, const float* w1t,
-                     const float* ws1t, const float* b1, const float* dv, const float* sc, float* z1, int* dummy) {
+DEV void step2_conv1(int n, int nmax, const float* G, const float* xs, const float* w1t, const float* ws1t, const float* b1,
+                     const float* dv, const float* sc, float* z1, int* dummy) {
     constexpr int XLD = XF + 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
     const int units = (n + 15) >> 4;
     for (int ti = wave; ti < units; ti += DRGNN_NWAVES) {
         const int prow = ti * 16 + lr;
-        const int node = hord[nbase + (prow < nmax ? prow : nmax - 1)];      // rows past the own range: any valid row (results discarded)
-        const float* ag = G + prow * XLD + 4 * lq;
-        const float* ax = xs + ROW24(node, XLD) + 4 * lq;
+        const int row = prow < nmax ? prow : nmax - 1;      // rows past the own range: any valid row (results discarded)
+        const float* ag = G + row * XLD + 4 * lq;
+        const float* ax = xs + row * XLD + 4 * lq;
         const float* bn = w1t + lr * XLD + 4 * lq;
         const float* bs = ws1t + lr * XLD + 4 * lq;
         drgnn_f32x4 accn = {0.f, 0.f, 0.f, 0.f}, accs = {0.f, 0.f, 0.f, 0.f};
@@ -214,10 +194,10 @@ DEV void step2_conv1(int n, int nmax, const int* hord, int nbase, const float* G
         for (int r = 0; r < 4; ++r) {
             const int ci = ti * 16 + lq * 4 + r;
             const bool ok = ci < n;
-            const float s = ok ? sc[ci] : 0.0f;
-            float v = fmaf(s, accs[r], accn[r]) + bias;
-            if (KIND == DRGNN_FOUT && ok && dv[ci] == 0.0f) v = DRGNN_NAN;      // mean over an empty neighbourhood
-            v = (v < 0.0f) ? 0.0f : v;                                           // relu that lets NaN through
+            const float s = ok ? sc[ci] : 0.0f, d = ok ? dv[ci] : 0.0f;
+            float v = fmaf(s, accs[r], d * accn[r]) + bias;
+            if (KIND == DRGNN_FOUT && ok && d == 0.0f) v = DRGNN_NAN;      // mean over an empty neighbourhood
+            v = (v < 0.0f) ? 0.0f : v;                                      // relu that lets NaN through
             float* p = ok ? z1 + ci * DRGNN_H1 + lr : (float*)dummy + lane;
             *p = v;
         }
@@ -475,43 +455,32 @@ DEV void step2_pooled_gather_bwd(int n, const int* cid, int qbase, const int* cp
     }
 }
 
-// ---- phase N: [dWn ; dWs] = [G | X]^T [dZ1 | s . dZ1] over the own rows (K = rows, split in KS slices over the waves) ------
-// units (tile, slice): tiles 0 .. MT-1 = dWn (A = G), MT .. 2 MT-1 = dWs (A = x rows through the order, B scaled by sc).
+// ---- phase N: [dWn ; dWs] = [S | X]^T [D . dZ1 | C . dZ1] over the own rows (K = rows, split in KS slices over the waves) ---
+// units (tile, slice): tiles 0 .. MT-1 = dWn (A = S rows, B scaled by D), MT .. 2 MT-1 = dWs (A = x rows, B scaled by C).
 // The operands of a 32-row chunk are requested in ONE batch per kind (a per-operand branch made eight dependent LDS round
 // trips of them: 3 us for this product).  stage 1: partial tiles -> part; stage 2 (behind the caller's barrier): their
 // sums -> the slab (dWn at C, dWs at C + chalf)
 template <int XF, bool SELF>
-DEV drgnn_f32x4 step2_dw1_unit(int kbeg, int kend, int ti, int nmax, const int* hord, int nbase, const float* G, const float* xs,
+DEV drgnn_f32x4 step2_dw1_unit(int kbeg, int kend, int ti, int nmax, const float* G, const float* xs, const float* dv,
                                const float* sc, const float* dz) {
     constexpr int XLD = XF + 4;
     const int lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
+    const float* A = SELF ? xs : G;
+    const float* coef = SELF ? sc : dv;
     drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        float a[8], b[8];
-        if (SELF) {
-            int node[8];
-            float sv[8];
+        float a[8], b[8], cf[8];
 #pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) {
-                const int k = k0 + lq + 4 * s2;      // rows [K, K4): sc zero, dz zero; beyond K4: not used
-                node[s2] = hord[nbase + (k < nmax ? k : nmax - 1)];
-                sv[s2] = sc[k];
-                b[s2] = dz[k * DRGNN_H1 + lr];
-            }
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) {
-                a[s2] = xs[ROW24(node[s2], XLD) + ti * 16 + lr];
-                b[s2] *= sv[s2];
-            }
-        } else {
-#pragma unroll
-            for (int s2 = 0; s2 < 8; ++s2) {
-                const int k = k0 + lq + 4 * s2;
-                a[s2] = G[k * XLD + ti * 16 + lr];
-                b[s2] = dz[k * DRGNN_H1 + lr];
-            }
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const int k = k0 + lq + 4 * s2;      // rows [K, K4): coefficient zero, dz zero; beyond K4: not used
+            const int row = k < nmax ? k : nmax - 1;      // (the A operand of a padding row: any valid row)
+            a[s2] = A[row * XLD + ti * 16 + lr];
+            cf[s2] = coef[k];
+            b[s2] = dz[k * DRGNN_H1 + lr];
         }
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) b[s2] *= cf[s2];
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2)
             if (k0 + 4 * s2 < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2], b[s2], acc, 0, 0, 0);
@@ -519,7 +488,7 @@ DEV drgnn_f32x4 step2_dw1_unit(int kbeg, int kend, int ti, int nmax, const int* 
     return acc;
 }
 template <int XF>
-DEV void step2_gemm_dw1(int K, int nmax, const int* hord, int nbase, const float* G, const float* xs, const float* sc,
+DEV void step2_gemm_dw1(int K, int nmax, const float* G, const float* xs, const float* dv, const float* sc,
                         const float* dz, int KS, float* part, float* C, int chalf, int Mrows, int stage) {
     constexpr int MT = XF / 16;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
@@ -533,8 +502,8 @@ DEV void step2_gemm_dw1(int K, int nmax, const int* hord, int nbase, const float
             const int ks = u / tiles, t = u - ks * tiles;
             const int kbeg = ks * kslice, kend = imin(K4, kbeg + kslice);
             drgnn_f32x4 acc;
-            if (t >= MT) acc = step2_dw1_unit<XF, true>(kbeg, kend, t - MT, nmax, hord, nbase, G, xs, sc, dz);
-            else acc = step2_dw1_unit<XF, false>(kbeg, kend, t, nmax, hord, nbase, G, xs, sc, dz);
+            if (t >= MT) acc = step2_dw1_unit<XF, true>(kbeg, kend, t - MT, nmax, G, xs, dv, sc, dz);
+            else acc = step2_dw1_unit<XF, false>(kbeg, kend, t, nmax, G, xs, dv, sc, dz);
             *(drgnn_f4*)(part + (u * 64 + lane) * 4) = drgnn_f4{acc[0], acc[1], acc[2], acc[3]};
         }
         return;
@@ -596,8 +565,13 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
 
     // ---- prologue: one burst of independent loads ----------------------------------------------------------------------
     PHASE_MARK();
-    const float* xgl = a.x + (long)d.n0 * F;
-    BurstX<4> bx;
+    constexpr int BJ = (CLS == 1) ? 2 : 4;                 // float4 per lane of a row tile (capacity class: 200 x 32 floats)
+    const float* xgl = a.x + (long)d.n0 * F;                // the graph's x rows and aggregation tiles (node order)
+    const float* sgl = a.tiles + (long)d.n0 * F;
+    const float* tdg = a.tiles + a.tile_nodes * F + d.n0;
+    const float* tcg = tdg + a.tile_nodes;
+    BurstX<BJ> bx, bsum;
+    BurstRowMap<BJ> brow;
     BurstW<1> bw1, bs1, bw2, bs2;
     WaveStage wst, wst2;
     const int my_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -606,39 +580,32 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
         const int nar = NARROW ? 1 : 0;
         StageJob j = {nullptr, 0, nullptr, 0};
         switch (burst * 16 + w) {
-        case 16 + 0: j = StageJob{P[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1, s.rp0, 0}; break;
-        case 16 + 1: j = stage_half(StageJob{P[DRGNN_TI_COL0] + d.e0, d.E, s.cx0, nar}, 0); break;
-        case 16 + 2: j = stage_half(StageJob{P[DRGNN_TI_COL0] + d.e0, d.E, s.cx0, nar}, 1); break;
-        case 16 + 3: j = StageJob{P[DRGNN_TI_HORD] + d.n0, d.N, s.hord, 0}; break;
-        case 16 + 4: j = StageJob{P[DRGNN_TI_HMP0] + d.rowbase, bC + 1, s.hmp, 0}; break;
-        case 16 + 5: j = StageJob{P[DRGNN_TI_MEM1] + d.n0, bC, s.cid, 0}; break;
-        case 16 + 6: j = StageJob{P[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1, s.mp1, 0}; break;
-        case 16 + 7: j = StageJob{c1.bias, DRGNN_H1, s.b1, 0}; break;
-        case 16 + 8: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w0 + d.e0, d.E, s.ew0, 0}, 0); break;
-        case 16 + 9: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w0 + d.e0, d.E, s.ew0, 0}, 1); break;
+        case 16 + 0: j = StageJob{P[DRGNN_TI_HMP0] + d.rowbase, bC + 1, s.hmp, 0}; break;
+        case 16 + 1: j = StageJob{P[DRGNN_TI_MEM1] + d.n0, bC, s.cid, 0}; break;
+        case 16 + 2: j = StageJob{P[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1, s.mp1, 0}; break;
+        case 16 + 3: j = StageJob{c1.bias, DRGNN_H1, s.b1, 0}; break;
+        case 16 + 4: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
+        case 16 + 5: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, nar}, 0); break;
+        case 16 + 6: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, nar}, 1); break;
+        case 16 + 7: j = StageJob{hf.b1, WREF, s.hb1, 0}; break;
+        case 16 + 8: j = StageJob{hf.w2, O * WREF, s.hw2, 0}; break;
+        case 16 + 9: j = StageJob{hf.b2, O, s.hb2, 0}; break;
+        case 16 + 10: j = StageJob{c2.bias, DRGNN_H2, s.b2, 0}; break;
+        case 16 + 11: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+        case 16 + 12: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 0); break;
+        case 16 + 13: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 1); break;
 
-        case 32 + 0: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
-        case 32 + 1: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, nar}, 0); break;
-        case 32 + 2: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, nar}, 1); break;
-        case 32 + 3: j = StageJob{hf.b1, WREF, s.hb1, 0}; break;
-        case 32 + 4: j = StageJob{hf.w2, O * WREF, s.hw2, 0}; break;
-        case 32 + 5: j = StageJob{hf.b2, O, s.hb2, 0}; break;
-        case 32 + 6: j = StageJob{c2.bias, DRGNN_H2, s.b2, 0}; break;
-        case 32 + 7: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
-        case 32 + 8: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 0); break;
-        case 32 + 9: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 1); break;
-        case 32 + 10: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 0); break;
-        case 32 + 11: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 1); break;
-        case 32 + 12: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 0); break;
-        case 32 + 13: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 1); break;
+        case 32 + 0: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 0); break;
+        case 32 + 1: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 1); break;
+        case 32 + 2: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 0); break;
+        case 32 + 3: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 1); break;
         default: break;
         }
         return j;
     };
     {   // every workspace pointer in one batch of scalar loads
         const int32_t* const* P = tv.p;
-        asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR0]), "s"(P[DRGNN_TI_COL0]), "s"(P[DRGNN_TI_HORD]), "s"(P[DRGNN_TI_HMP0]),
-                     "s"(P[DRGNN_TI_MEM1]), "s"(P[DRGNN_TI_MPTR1]));
+        asm volatile("" :: "s"(P[DRGNN_TI_IHORD]), "s"(P[DRGNN_TI_HMP0]), "s"(P[DRGNN_TI_MEM1]), "s"(P[DRGNN_TI_MPTR1]));
         asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR1]), "s"(P[DRGNN_TI_COL1]), "s"(P[DRGNN_TI_COLPTR1]), "s"(P[DRGNN_TI_ROWIDX1]));
     }
     int m_bad = 0, m_y = 0;
@@ -661,33 +628,21 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
             m_bad = __builtin_amdgcn_readfirstlane(m_bad);
         }
     }
+    burst_load_x(bsum, sgl, d.N, F);
     burst_load_x(bx, xgl, d.N, F);
+    burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
+    // per-node coefficients D, C and the node's position (one node per lane: d.N <= threads, step_burst_guaranteed)
+    float n_d = 0.0f, n_c = 0.0f;
+    int n_pos = -1;
+    if ((int)threadIdx.x < d.N) { n_d = tdg[threadIdx.x]; n_c = tcg[threadIdx.x]; n_pos = tv.p[DRGNN_TI_IHORD][d.n0 + threadIdx.x]; }
     burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
     burst_load_w(bs1, c1.w_self, c1.self_sk, c1.self_sh, F, DRGNN_H1);
     wstage_load(wst, stage_job(1, my_wave));
-    // the second burst (pooled level, head, conv2 weights) right behind the first: it is filed two phases later -- these are
-    // first touches of what the builder wrote in the previous launch, a round trip of ~2 us that must not start late
     burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
     burst_load_w(bs2, c2.w_self, c2.self_sk, c2.self_sh, DRGNN_H1, DRGNN_H2);
     step_wblock_load(wreg, hf, 0);
     wstage_load(wst2, stage_job(2, my_wave));
-    burst_store_x4(bx, s.xs, XLD);
-    burst_store_wt(bw1, s.w1t, XLD);
-    burst_store_wt(bs1, s.ws1t, XLD);
-    wstage_store(wst);
-    if (XF > F) {      // zero padding of the k columns [F, XF) (x tile: ALL rows are gathered; weights)
-        const int padc = XF - F;
-        FOR_TID(e, d.N * padc) { s.xs[(e / padc) * XLD + F + e % padc] = 0.0f; }
-        FOR_TID(e, DRGNN_H1 * padc) { s.w1t[(e / padc) * XLD + F + e % padc] = 0.0f; s.ws1t[(e / padc) * XLD + F + e % padc] = 0.0f; }
-    }
-    FOR_TID(i, 1) {
-        ((int*)s.misc)[STEP_M_BAD] = m_bad;
-        ((int*)s.misc)[STEP_M_Y] = m_y;
-        s.misc[STEP_M_WY] = m_wy;
-        s.misc[STEP_M_DENOM] = m_denom;
-    }
-    BARRIER();
-    EXIT_AFTER(1);
+    // the device-computed counts and the split point have been in flight since the kernel's first instructions
     if (late) {
         d.C = WG_UNIFORM(cnt_c); d.E1 = WG_UNIFORM(cnt_e1); d.C1 = WG_UNIFORM(cnt_c1);
         hs_k = WG_UNIFORM(hs_k); hs_q = WG_UNIFORM(hs_q); hs_n = WG_UNIFORM(hs_n);
@@ -707,16 +662,32 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     const int Ch = (SPLIT == 2) ? (half == 0 ? hs_q : d.C - hs_q) : d.C;
     const int Nh = (SPLIT == 2) ? (half == 0 ? hs_n : d.N - hs_n) : d.N;
     const int Co = d.C - Ch, qbase_o = (SPLIT == 2 && half == 0) ? hs_q : 0;      // the partner's pooled rows
-    const int nmax = imax(d.N - nbase, 1);
-
-    // ---- A: aggregation first -----------------------------------------------------------------------------------------
-    PH(1) step2_aggregate<KIND, XLD, EIdx>(Nh, s.hord, nbase, s.rp0, (const EIdx*)s.cx0, s.ew0, s.xs, s.G, s.dv0, s.sc0);
+    const int nmax = imax(Nh, 1);
+    // the S and x rows of the OWN positions -> LDS row (position - nbase); D, C likewise
+    burst_store_x4_rows(bsum, brow, s.G, XLD, nbase, Nh);
+    burst_store_x4_rows(bx, brow, s.xs, XLD, nbase, Nh);
+    if ((unsigned)(n_pos - nbase) < (unsigned)Nh) { s.dv0[n_pos - nbase] = n_d; s.sc0[n_pos - nbase] = n_c; }
+    FOR_TID(e, step_pad4(Nh) - Nh) { s.dv0[Nh + e] = 0.0f; s.sc0[Nh + e] = 0.0f; }      // (coefficients of the K padding rows)
+    burst_store_wt(bw1, s.w1t, XLD);
+    burst_store_wt(bs1, s.ws1t, XLD);
+    wstage_store(wst);
+    if (XF > F) {      // zero padding of the k columns [F, XF) (row tiles; weights)
+        const int padc = XF - F;
+        FOR_TID(e, Nh * padc) { s.xs[(e / padc) * XLD + F + e % padc] = 0.0f; s.G[(e / padc) * XLD + F + e % padc] = 0.0f; }
+        FOR_TID(e, DRGNN_H1 * padc) { s.w1t[(e / padc) * XLD + F + e % padc] = 0.0f; s.ws1t[(e / padc) * XLD + F + e % padc] = 0.0f; }
+    }
+    FOR_TID(i, 1) {
+        ((int*)s.misc)[STEP_M_BAD] = m_bad | bad_shape;
+        ((int*)s.misc)[STEP_M_Y] = m_y;
+        s.misc[STEP_M_WY] = m_wy;
+        s.misc[STEP_M_DENOM] = m_denom;
+    }
     BARRIER();
+    EXIT_AFTER(1);
     EXIT_AFTER(2);
     // ---- B: conv1's product ------------------------------------------------------------------------------------------------
-    PH(2) step2_conv1<KIND, XF>(Nh, nmax, s.hord, nbase, s.G, s.xs, s.w1t, s.ws1t, s.b1, s.dv0, s.sc0, s.z1, dummy);
+    PH(2) step2_conv1<KIND, XF>(Nh, nmax, s.G, s.xs, s.w1t, s.ws1t, s.b1, s.dv0, s.sc0, s.z1, dummy);
     FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
-    if (bad_shape) { FOR_TID(i, 1) { ((int*)s.misc)[STEP_M_BAD] = 1; } }
     BARRIER();
     EXIT_AFTER(3);
     // ---- C: depth-0 cluster max over contiguous rows, published to the partner; the second burst is filed -----------------
@@ -809,11 +780,11 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
         int KS = imin(DRGNN_NWAVES / (2 * MT), gp_units / (2 * MT));
         if (KS < 1) KS = 1;
         KS = 1 << (31 - __builtin_clz((unsigned)KS));
-        PH(16) step2_gemm_dw1<XF>(Nh, nmax, s.hord, nbase, s.G, s.xs, s.sc0, s.z1, KS, s.gp, p_w1n, F * DRGNN_H1, F, 1);
+        PH(16) step2_gemm_dw1<XF>(Nh, nmax, s.G, s.xs, s.dv0, s.sc0, s.z1, KS, s.gp, p_w1n, F * DRGNN_H1, F, 1);
         step_colsum_partial<DRGNN_H1>(Nh, s.z1, s.bsum);
         BARRIER();
         EXIT_AFTER(15);
-        PH(16) step2_gemm_dw1<XF>(Nh, nmax, s.hord, nbase, s.G, s.xs, s.sc0, s.z1, KS, s.gp, p_w1n, F * DRGNN_H1, F, 2);
+        PH(16) step2_gemm_dw1<XF>(Nh, nmax, s.G, s.xs, s.dv0, s.sc0, s.z1, KS, s.gp, p_w1n, F * DRGNN_H1, F, 2);
         step_colsum_finish<DRGNN_H1>(s.bsum, p_b1);
     }
 }

@@ -9,8 +9,12 @@
 // rows without member lists.  The pooled level (conv2 aggregation first, pooling + readout, head with the partner branch's
 // readout, d readout, dS / dW2, transposed pooled gather through the depth-0 argmax) is drgnn_step.h's, row = pooled node id.
 //
-// Per branch workgroup: 13 barrier-separated phases (drgnn_step.h: 16), LDS at SYN size 111 KB (136 KB), staged index words
-// per graph 3 900 (6 300).  Same sums as the reference up to the association (G W instead of the per-edge products): parity
+// The aggregation itself is not formed here: G = A X depends on the inputs only, so the topology builder forms it together with
+// the topology (DRGNN_TOPO_TILES: S rows in node order + the inverse hierarchical order; include/drgnn.h) -- in the workgroups
+// co-launched with the PREVIOUS step, or once per graph in cached-topology mode -- and this kernel's prologue loads the S rows
+// of the graph, filing row i at its hierarchical position.
+// Per branch workgroup: 12 barrier-separated phases (drgnn_step.h: 16), LDS at SYN size 77 KB (136 KB), staged index words
+// per graph 2 500 (6 300).  Same sums as the reference up to the association (G W instead of the per-edge products): parity
 // 1e-4 like every other kernel (tests/test_gpu_fused_fullsize.py).  GPU only: the host emulation steps GINet through
 // drgnn_step.h.  Launched by train_step_impl for TRAINING launches of the 32-wide specialised shape in the two-workgroup
 // layout on a topology built with DRGNN_TOPO_HIER; everything else keeps the drgnn_step.h / drgnn_step1.h kernels.
@@ -19,17 +23,11 @@
 
 #include "drgnn_step2.h"
 
-// float4 per lane of the level-0 aggregation (1: eight lanes per 32-wide row; 2: four lanes per row, two row chunks each)
-#ifndef DRGNN_STEP3_VPL
-#define DRGNN_STEP3_VPL 1
-#endif
-
 #ifndef DRGNN_EMU
 struct Step3Scratch {
     float* misc; float* xr; float* hid; float* dhid; float* hb1; float* wb;
     float* w1t; float* w2t; float* w2n;
-    float* xs;
-    int* rp0; int* cx0; int* hord; int* hmp;
+    int* hmp;
     int* rp1; int* cx1; int* cp1; int* rx1; int* mp1; int* mem1;
     short* a0; short* a1;
     float* G; float* z1;
@@ -48,10 +46,6 @@ struct Step3Scratch {
     X(w1t, DRGNN_H1 * xld)                                                                     \
     X(w2t, DRGNN_H2 * STEP_XPLD)                                                               \
     X(w2n, DRGNN_H1 * (DRGNN_H2 + 4))                                                          \
-    X(xs, (long)(capN + 4) * xld)                                                              \
-    X(rp0, capN + 1)                                                                           \
-    X(cx0, capE)                                                                               \
-    X(hord, capN)                                                                              \
     X(hmp, capC + 1)                                                                           \
     X(rp1, capC + 1)                                                                           \
     X(cx1, capE)                                                                               \
@@ -100,35 +94,6 @@ DEV Step3Scratch step3_carve(float* base, int F, int capN, int capE, int capC, i
     s.end = base + o;
     s.gp = s.wb;      // fc1's column block is dead after d readout: the K-split products keep their partial tiles there
     return s;
-}
-
-// ---- phase A: G_p = sum over the CSR0 row of node hord[p] of x_col (all rows; rows of XLD floats) ------------------------
-// VPL float4 per lane: 1 = XF/4 lanes per row; 2 = XF/8 lanes per row, each with the float4 at c and at c + XF/2
-template <int XLD, int VPL>
-DEV void step3_aggregate(int n, const int* hord, const int* rp, const int* col, const float* xs, float* G) {
-    constexpr int XF = XLD - 4;
-    constexpr int LPR = XF / (4 * VPL);
-    constexpr int HALF = XF / 2;
-    FOR_TID(item, n * LPR) {
-        const int p = item / LPR, c = (item % LPR) * 4;
-        const int i = hord[p];
-        const int lo = rp[i], hi = rp[i + 1];
-        drgnn_f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-        for (int k = lo; k < hi; ++k) {
-            const float* row = xs + ROW24(col[k], XLD) + c;
-            const drgnn_f4 v = *(const drgnn_f4*)row;
-            a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
-            if (VPL == 2) {
-                const drgnn_f4 w = *(const drgnn_f4*)(row + HALF);
-                b[0] += w[0]; b[1] += w[1]; b[2] += w[2]; b[3] += w[3];
-            }
-        }
-        *(drgnn_f4*)(G + p * XLD + c) = a;
-        if (VPL == 2) *(drgnn_f4*)(G + p * XLD + HALF + c) = b;
-    }
-    // rows [n, pad4(n)): zero (K padding of the weight-gradient product)
-    FOR_TID(e, (step_pad4(n) - n) * XLD) { G[n * XLD + e] = 0.0f; }
 }
 
 // ---- phase C: depth-0 cluster max over CONTIGUOUS rows; results filed under the pooled node id cid[q] --------------------
@@ -184,41 +149,37 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
 
     // ---- prologue: everything this graph needs, two register bursts requested back to back --------------------------------
     PHASE_MARK();
-    const float* xgl = a.x + (long)d.n0 * F;
+    const float* sgl = a.tiles + (long)d.n0 * F;      // the graph's S rows (node order)
     BurstX<4> bx;
+    BurstRowMap<4> brow;
     BurstW<1> bw1, bw2;
-    WaveStage wst, wst2;
+    WaveStage wst;
     const int my_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     auto stage_job = [&](int burst, int w) -> StageJob {
         const int32_t* const* P = tv.p;
         StageJob j = {nullptr, 0, nullptr, 0};
         switch (burst * 16 + w) {
-        case 16 + 0: j = StageJob{P[DRGNN_TI_ROWPTR0] + d.rowbase, d.N + 1, s.rp0, 0}; break;
-        case 16 + 1: j = stage_half(StageJob{P[DRGNN_TI_COL0] + d.e0, d.E, s.cx0, 0}, 0); break;
-        case 16 + 2: j = stage_half(StageJob{P[DRGNN_TI_COL0] + d.e0, d.E, s.cx0, 0}, 1); break;
-        case 16 + 3: j = StageJob{P[DRGNN_TI_HORD] + d.n0, d.N, s.hord, 0}; break;
-        case 16 + 4: j = StageJob{P[DRGNN_TI_HMP0] + d.rowbase, bC + 1, s.hmp, 0}; break;
-        case 16 + 5: j = StageJob{P[DRGNN_TI_MEM1] + d.n0, bC, s.mem1, 0}; break;
-        case 16 + 6: j = StageJob{P[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1, s.mp1, 0}; break;
-        case 16 + 7: j = StageJob{hf.b1, WREF, s.hb1, 0}; break;
-        case 16 + 8: j = stage_half(StageJob{hf.w2, O * WREF, s.hw2, 0}, 0); break;
-        case 16 + 9: j = stage_half(StageJob{hf.w2, O * WREF, s.hw2, 0}, 1); break;
-        case 16 + 10: j = StageJob{hf.b2, O, s.hb2, 0}; break;
-
-        case 32 + 0: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
-        case 32 + 1: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 0); break;
-        case 32 + 2: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 1); break;
-        case 32 + 3: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
-        case 32 + 4: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
-        case 32 + 5: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
+        // (thirteen small arrays: ONE burst, one array per wave)
+        case 16 + 0: j = StageJob{P[DRGNN_TI_HMP0] + d.rowbase, bC + 1, s.hmp, 0}; break;
+        case 16 + 1: j = StageJob{P[DRGNN_TI_MEM1] + d.n0, bC, s.mem1, 0}; break;
+        case 16 + 2: j = StageJob{P[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1, s.mp1, 0}; break;
+        case 16 + 3: j = StageJob{hf.b1, WREF, s.hb1, 0}; break;
+        case 16 + 4: j = stage_half(StageJob{hf.w2, O * WREF, s.hw2, 0}, 0); break;
+        case 16 + 5: j = stage_half(StageJob{hf.w2, O * WREF, s.hw2, 0}, 1); break;
+        case 16 + 6: j = StageJob{hf.b2, O, s.hb2, 0}; break;
+        case 16 + 7: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
+        case 16 + 8: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 0); break;
+        case 16 + 9: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 1); break;
+        case 16 + 10: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+        case 16 + 11: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
+        case 16 + 12: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
         default: break;
         }
         return j;
     };
     {   // every workspace pointer in one batch of scalar loads
         const int32_t* const* P = tv.p;
-        asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR0]), "s"(P[DRGNN_TI_COL0]), "s"(P[DRGNN_TI_HORD]), "s"(P[DRGNN_TI_HMP0]),
-                     "s"(P[DRGNN_TI_MEM1]), "s"(P[DRGNN_TI_MPTR1]));
+        asm volatile("" :: "s"(P[DRGNN_TI_IHORD]), "s"(P[DRGNN_TI_HMP0]), "s"(P[DRGNN_TI_MEM1]), "s"(P[DRGNN_TI_MPTR1]));
         asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR1]), "s"(P[DRGNN_TI_COL1]), "s"(P[DRGNN_TI_COLPTR1]), "s"(P[DRGNN_TI_ROWIDX1]));
     }
     int m_bad = 0, m_y = 0;
@@ -241,21 +202,21 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
             m_bad = __builtin_amdgcn_readfirstlane(m_bad);
         }
     }
-    burst_load_x(bx, xgl, d.N, F);
+    burst_load_x(bx, sgl, d.N, F);
+    burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
     burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
     wstage_load(wst, stage_job(1, my_wave));
-    // the second burst right behind the first (filed two phases later): first touches of what the builder wrote in the
-    // previous launch, a round trip that must not start late
     burst_load_w(bw2, c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
     step_wblock_load(wreg, hf, br);
     step_wblock_load(wother, hf, 1 - br);
-    wstage_load(wst2, stage_job(2, my_wave));
-    burst_store_x4(bx, s.xs, XLD);
+    burst_store_x4_rows(bx, brow, s.G, XLD);
     burst_store_wt(bw1, s.w1t, XLD);
     wstage_store(wst);
-    if (XF > F) {      // zero padding of the k columns [F, XF) (x tile: every row is gathered; weights)
+    // zero padding the predicate-free products rely on: G rows [N, pad4(N)) and (F < XF) the k columns [F, XF)
+    FOR_TID(e, (step_pad4(d.N) - d.N) * XLD) { s.G[d.N * XLD + e] = 0.0f; }
+    if (XF > F) {
         const int padc = XF - F;
-        FOR_TID(e, d.N * padc) { s.xs[(e / padc) * XLD + F + e % padc] = 0.0f; }
+        FOR_TID(e, d.N * padc) { s.G[(e / padc) * XLD + F + e % padc] = 0.0f; }
         FOR_TID(e, DRGNN_H1 * padc) { s.w1t[(e / padc) * XLD + F + e % padc] = 0.0f; }
     }
     FOR_TID(i, 1) {
@@ -273,16 +234,12 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
         bad_shape = 1;
     }
 
-    // ---- A: G = A X (rows in the hierarchical order) ------------------------------------------------------------------------
-    PH(1) step3_aggregate<XLD, DRGNN_STEP3_VPL>(d.N, s.hord, s.rp0, s.cx0, s.xs, s.G);
-    BARRIER();
     EXIT_AFTER(2);
     // ---- B: Z1 = relu(G W1); the second burst is filed ---------------------------------------------------------------------
     PH(2) step_gemm_nn<true>(d.N, 1, XF, s.G, XLD, s.w1t, XLD, s.z1, DRGNN_H1, dummy);
     burst_store_wt(bw2, s.w2t, STEP_XPLD);
     burst_store_w(bw2, s.w2n, W2NLD);
     step_wblock_store(wreg, hf, br, s.wb);
-    wstage_store(wst2);
     FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
     if (bad_shape) { FOR_TID(i, 1) { ((int*)s.misc)[STEP_M_BAD] = 1; } }
     BARRIER();
@@ -335,7 +292,11 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     float* p_w1n = part_w;
     float* p_w2n = p_w1n + 2L * F * DRGNN_H1 + DRGNN_H1;
     const int gp_units = step_gp_words(WREF) / 256;
+#ifdef DRGNN_STEP3_KS2
+    const int KS2 = DRGNN_STEP3_KS2;
+#else
     const int KS2 = imin(DRGNN_NWAVES / 2, gp_units / 2);
+#endif
     // dS = dZ2 W2^T (rows of STEP_XPLD floats);  dW2 = S^T dZ2 (K = pooled nodes): partial tiles here, their sum behind the barrier
     PH(11) step_gemm_nn(d.C, 1, DRGNN_H2, s.z2, Z2LD, s.w2n, W2NLD, s.p2, STEP_XPLD, dummy);
     PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1, 1);
@@ -350,6 +311,9 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
         constexpr int MT = XF / 16;
         int KS = imin(DRGNN_NWAVES / MT, gp_units / MT);
         if (KS < 1) KS = 1;
+#ifdef DRGNN_STEP3_KS1
+        KS = DRGNN_STEP3_KS1;
+#endif
         PH(16) step_gemm_tn(MT, 1, d.N, s.G, XLD, s.z1, DRGNN_H1, KS, s.gp, p_w1n, DRGNN_H1, F);
     }
 }

@@ -56,6 +56,7 @@ static inline void topo_layout(int64_t N, int64_t E, int64_t B, TopoLayout* L) {
     take(DRGNN_TI_HORD, N);
     take(DRGNN_TI_HMP0, N + B);
     take(DRGNN_TI_HSPLIT, 4 * B);
+    take(DRGNN_TI_IHORD, N);
     L->i32[DRGNN_TI_COUNT] = o;
     int64_t f = 0;
     L->f32[DRGNN_TF_W0] = f; f += (E + 3) & ~(int64_t)3;
@@ -104,15 +105,18 @@ struct TopoScratch {
     int* t4;
     int* t5;
     int* fl;         // [capF]
+    float* xs;       // x tile of the graph for the aggregation tiles ([capN][tile_f + 4] floats behind the carve; null: none)
     int capF;
     int capT;        // ints in each of t1..t5
 };
 
 #define TOPO_PAD4(n) (((n) + 3) & ~3LL)
 // mm[0], mm[1]: min / max of the ids being ranked; mm[2 + 2w], mm[3 + 2w]: wave w's partial min / max (wg_rank_prepare)
-#define TOPO_MM_INTS (4 + 4 * (DRGNN_NTHREADS / DRGNN_WAVE))
+// (+ a second set of wave slots, mm[2 + 2 NW + 2w ..]: the depth-1 ids of the lean clusters chain, prepared in the same phase)
+#define TOPO_MM_INTS (4 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
+#define TOPO_MM1(s) ((s).mm + 2 + 2 * (DRGNN_NTHREADS / DRGNN_WAVE))
 // number of ints: linear in (capN, capE, capT, capF) -- keep in sync with topo_carve
-static inline int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT, int64_t capF) {
+HD int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT, int64_t capF) {
     return TOPO_MM_INTS + TOPO_PAD4(DRGNN_NTHREADS + 1) + 6 * TOPO_PAD4(capN + 1) + 3 * TOPO_PAD4(capN) +
            6 * TOPO_PAD4(capE) + 5 * TOPO_PAD4(capT) + TOPO_PAD4(capF);
 }
@@ -121,7 +125,7 @@ static inline int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT
 // capT = N+E+1 and capF = N+E+2 the carve needs at most 15*N + 12*E + TOPO_GSCRATCH_CONST ints
 // (the constant absorbs the fixed arrays and every PAD4 rounding), so regions placed at
 // 15*n0 + 12*e0 + CONST*g (rounded up to even for the 64-bit min/max slot) never overlap.
-#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 176 + 4 * (DRGNN_NTHREADS / DRGNN_WAVE))
+#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 176 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
 HD int64_t topo_gscratch_base(int64_t n0, int64_t e0, int64_t g) {
     return ((15 * n0 + 12 * e0 + (int64_t)TOPO_GSCRATCH_CONST * g) + 1) & ~(int64_t)1;
 }
@@ -153,6 +157,7 @@ DEV TopoScratch topo_carve(IntPtr base, int capN, int capE, int capT, int capF) 
     s.t4 = base + o;   o += (int)TOPO_PAD4(capT);
     s.t5 = base + o;   o += (int)TOPO_PAD4(capT);
     s.fl = base + o;   o += (int)TOPO_PAD4(capF);
+    s.xs = nullptr;
     s.capF = capF;
     s.capT = capT;
     return s;
@@ -296,6 +301,7 @@ DEV void wg_rank_prepare_val(long long v, int n, int* low, long long* slots) {
 DEV void wg_prepared_minmax(const long long* slots, int n, long long& mn, long long& mx) {
     mn = LLONG_MAX; mx = LLONG_MIN;
     const int nw = imin(DRGNN_NTHREADS / DRGNN_WAVE, (n + DRGNN_WAVE - 1) / DRGNN_WAVE);     // slots that were written
+    if (nw == 1) { mn = slots[0]; mx = slots[1]; return; }
     for (int w = 0; w < nw; ++w) {
         const long long l = slots[2 * w], h = slots[2 * w + 1];
         mn = l < mn ? l : mn;
@@ -413,6 +419,12 @@ struct TopoArgs {
     int64_t n_set;
     int n_feat, y_bytes;
     int flags;                    // DRGNN_TOPO_* (include/drgnn.h)
+    // DRGNN_TOPO_TILES: x_in = the mini-batch's node features (null in resident-set mode: set_x), tiles = output
+    // (S [tile_nodes][tile_f] | D [tile_nodes] | C [tile_nodes]); tile_f = 0: no tiles
+    const float* x_in;
+    float* tiles;
+    int64_t tile_nodes;
+    int tile_f;
 };
 
 // where slot g's index data lives: in the mini-batch tensors (global ids, shifted by n0) or in the resident set
@@ -495,6 +507,7 @@ DEV void topo_hier(const TopoView& tv, int g, int n0, int N, int C, int C1, cons
     BARRIER();
     wg_exscan(ptr, C + 1, s.part);
     int32_t* g_hord = tv.p[DRGNN_TI_HORD] + n0;
+    int32_t* g_ihord = tv.p[DRGNN_TI_IHORD] + n0;
     int32_t* g_hmp = tv.p[DRGNN_TI_HMP0] + rowbase;
     FOR_TID(i, N) {
         const int b = qpos[cl0[i]];
@@ -517,6 +530,7 @@ DEV void topo_hier(const TopoView& tv, int g, int n0, int N, int C, int C1, cons
         int rank = 0;
         for (int q = lo; q < hi; ++q) rank += (tmp[q] < me) ? 1 : 0;
         g_hord[lo + rank] = me;
+        g_ihord[me] = lo + rank;
     }
     FOR_TID(i, 1) {
         const int k = (int)(best[0] & 0xffffffffLL);
@@ -622,6 +636,8 @@ DEV void topo_csr0(const TopoView& tv, int g, int n0, int e0, int N, int E, bool
     FOR_TID(k, E) {
         const int e = s.t3[k];
         s.t5[e] = k;                                   // edge -> CSR0 slot
+        s.col[k] = s.ec[e];                            // (column / weight by slot stay in LDS for topo_tiles_rows)
+        if (has_w) ((float*)s.seg)[k] = s.w0[e];
         g_col0[k] = s.ec[e];
         g_eid0[k] = e;
         if (has_w) g_w0[k] = s.w0[e];
@@ -839,13 +855,89 @@ DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, in
 }
 
 // =========================================================================================================================
+// Level-0 aggregation tiles (DRGNN_TOPO_TILES, include/drgnn.h): S_i = sum over the CSR0 row of node i of [w_k] x_col(k), D, C
+// -- what conv1 of every net starts from, formed HERE because it depends on the inputs only.  The x tile of the graph was
+// requested in phase 0 and sits in LDS (rows of F + 4 floats); rp / col_s / w_s: CSR0 of the graph in LDS (slot order =
+// edge-id order).  F / 4 lanes per node, each with one float4 of the row; results go straight to global memory (node order).
+struct TopoTile { const float* x; float* ts; float* td; float* tc; float* xs; int F; };
+DEV TopoTile topo_tile_of(const TopoArgs& a, const TopoSrc& src, int n0, float* xs) {
+    TopoTile t;
+    t.F = (a.tiles != nullptr) ? a.tile_f : 0;
+    const float* xsrc = a.set_ids ? a.set_x : a.x_in;
+    if (xsrc == nullptr || xs == nullptr) t.F = 0;
+    t.x = (t.F > 0) ? xsrc + src.x_row * t.F : nullptr;
+    t.ts = (t.F > 0) ? a.tiles + (long long)n0 * t.F : nullptr;
+    t.td = (t.F > 0) ? a.tiles + a.tile_nodes * t.F + n0 : nullptr;
+    t.tc = (t.F > 0) ? t.td + a.tile_nodes : nullptr;
+    t.xs = xs;
+    return t;
+}
+#ifdef DRGNN_EMU
+struct TopoTileRegs { int dummy; };
+DEV void topo_tile_load(TopoTileRegs&, const TopoTile&, int) {}
+DEV void topo_tile_store(const TopoTileRegs&, const TopoTile& t, int N) {
+    for (int i = 0; i < N && t.F > 0; ++i) for (int f = 0; f < t.F; ++f) t.xs[i * (t.F + 4) + f] = t.x[(long long)i * t.F + f];
+}
+#else
+struct TopoTileRegs { BurstX<4> bx; };
+DEV void topo_tile_load(TopoTileRegs& r, const TopoTile& t, int N) { if (t.F > 0) burst_load_x(r.bx, t.x, N, t.F); }
+DEV void topo_tile_store(const TopoTileRegs& r, const TopoTile& t, int N) { (void)N; if (t.F > 0) burst_store_x4(r.bx, t.xs, t.F + 4); }
+#endif
+DEV void topo_tiles_rows(const TopoTile& t, int N, const int* rp, const int* col_s, const float* w_s) {
+    if (t.F <= 0) return;
+    const int F = t.F, G4 = F >> 2, XLD = F + 4;
+    const FastDiv fd = fastdiv_make(G4);
+    FOR_TID(item, N * G4) {
+        const int i = fastdiv(fd, item), c = fastmod(fd, item, i) * 4;
+        const int lo = rp[i], hi = rp[i + 1], deg = hi - lo;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, asum = 0.f;
+        if (w_s != nullptr) {
+            // batches of four independent (index -> row) chains, the last one padded under a zero coefficient
+            for (int k = lo; k < hi; k += 4) {
+                int kk[4];
+                float cf[4];
+                for (int j = 0; j < 4; ++j) { kk[j] = (k + j < hi) ? k + j : hi - 1; cf[j] = (k + j < hi) ? 1.0f : 0.0f; }
+                for (int j = 0; j < 4; ++j) { cf[j] *= w_s[kk[j]]; asum += cf[j]; }
+                const float* xj[4];
+                for (int j = 0; j < 4; ++j) xj[j] = t.xs + ROW24(col_s[kk[j]], XLD) + c;
+                for (int j = 0; j < 4; ++j) {
+                    a0 = fmaf(cf[j], xj[j][0], a0); a1 = fmaf(cf[j], xj[j][1], a1);
+                    a2 = fmaf(cf[j], xj[j][2], a2); a3 = fmaf(cf[j], xj[j][3], a3);
+                }
+            }
+        } else {
+#ifndef DRGNN_EMU
+#pragma unroll 4
+#endif
+            for (int k = lo; k < hi; ++k) {
+                const float* xj = t.xs + ROW24(col_s[k], XLD) + c;
+                a0 += xj[0]; a1 += xj[1]; a2 += xj[2]; a3 += xj[3];
+            }
+        }
+        float* dst = t.ts + (long long)i * F + c;
+        dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+        if (c == 0) {
+            float d, sc;
+            if (w_s != nullptr) { d = 1.0f / (float)(deg > 0 ? deg : 1); sc = asum * d; }
+            else { d = deg > 0 ? 1.0f / (float)deg : 0.0f; sc = 1.0f; }
+            t.td[i] = d; t.tc[i] = sc;
+        }
+    }
+}
+
+// =========================================================================================================================
 // LEAN build (DRGNN_TOPO_LEAN, include/drgnn.h): only what the aggregation-first training kernels read, by two short chains.
-//   * ONE exclusive scan over the concatenation [row histogram | presence flags of the depth-0 ids | ... of the depth-1 ids]
-//     gives the CSR0 row pointers and both consecutive-cluster rankings (the old chain: three scans in three places);
-//   * orders by COUNTING instead of bucket sorts: the position of an item is the number of items with a smaller key
-//     (depth-0 clusters by (depth-1 cluster, id): C^2 comparisons; nodes by (position of their cluster, id): N^2 / lanes) --
-//     one phase each, no histogram / scan / claim / rank, deterministic by construction;
-//   * the pooled CSC from a TRANSPOSED target bitmap filled next to the forward one: both are emitted by one popcount scan.
+//   rows chain     : CSR0 (+ W0) -- histogram, scan, claim, rank by edge id -- and the aggregation tiles;
+//   clusters chain : both consecutive-cluster rankings from ONE exclusive scan over the concatenated presence flags, the
+//                    pooled CSR and CSC from a target bitmap and its TRANSPOSE (both emitted behind one popcount scan), the
+//                    depth-1 member lists and the hierarchical node order by COUNTING and size sums instead of bucket sorts:
+//                    position of a cluster = number of smaller (depth-1 cluster, id) keys (C^2 comparisons), first position of
+//                    its nodes = sum of the sizes of the clusters in front (C^2 additions), a node claims a slot of its
+//                    cluster's run and the few nodes of a run are ranked by id.
+// Two workgroups per graph: without edge weights the "structure" workgroup runs the rows chain and the "pool" workgroup the
+// clusters chain (19 k / 22 k clock ticks at SYN size; the general chains: 33 k / 41 k); with edge weights the pool workgroup
+// keeps the general pooled-edge routine (sorted runs, summed weights) and the structure workgroup runs rows + clusters without
+// the pooled graph.  One workgroup per graph (no weights): rows, then clusters.
 // Items of the counting loops are shared by G consecutive lanes that meet in DPP adds (the emulation runs items serially).
 #ifdef DRGNN_EMU
 #define TOPO_LANES(G) 1
@@ -874,74 +966,39 @@ template <int G> DEV int topo_count_below(const int* keys, int n, int me, int su
     return topo_group_sum<L>(cnt);
 }
 
-// Phase 0 of a lean chain (next to the edge staging): the concatenated flag / histogram array, the cursors and the cluster
-// sizes cleared, both id lists read (their latencies overlap the edge list's), low words + wave min / max filed.
-// pre: the ids are already in registers (v0 = cl0[thread], v1 = cl1[thread]; N <= threads)
-DEV void topo_lean_prepare(const TopoSrc& src, int N, int n1, bool structure, TopoScratch& s, bool pre = false, long long v0 = 0,
-                           long long v1 = 0) {
-    FOR_TID(v, s.capT) { s.t1[v] = 0; }
+// Phase 0 of the lean chains (next to the edge staging; ends with the caller's barrier).  rows: histogram and cursors cleared.
+// clusters: the flag array cleared, both id lists read (`pre`: already in registers, requested ahead of the edge list), low
+// words + wave min / max filed (depth 0: s.pp, s.mm + 2; depth 1: s.nb, TOPO_MM1).
+DEV void topo_lean_prepare(const TopoSrc& src, int N, int n1, bool rows, bool clusters, TopoScratch& s, bool pre = false,
+                           long long v0 = 0, long long v1 = 0) {
+    if (rows) { FOR_TID(i, N + 1) { s.rp[i] = 0; s.cur[i] = 0; } }
+    if (clusters) {
+        FOR_TID(v, s.capT) { s.t1[v] = 0; }
+        FOR_TID(i, N + 1) { s.cp[i] = 0; }
 #ifndef DRGNN_EMU
-    if (pre) wg_rank_prepare_val(v0, N, s.pp, s.mm + 2);
-    else
-#endif
-    wg_rank_prepare(src.cl0, N, s);
-    if (structure) {
-        FOR_TID(i, N + 1) { s.cur[i] = 0; s.rp[i] = 0; }
-#ifndef DRGNN_EMU
-        if (pre) wg_rank_prepare_val(v1, n1, s.nb, (long long*)s.part);
+        if (pre) { wg_rank_prepare_val(v0, N, s.pp, s.mm + 2); wg_rank_prepare_val(v1, n1, s.nb, TOPO_MM1(s)); }
         else
 #endif
-        wg_rank_prepare_to(src.cl1, n1, s.nb, (long long*)s.part);
+        { wg_rank_prepare(src.cl0, N, s); wg_rank_prepare_to(src.cl1, n1, s.nb, TOPO_MM1(s)); }
     }
     (void)pre; (void)v0; (void)v1;
 }
 
-// ---- lean "structure" chain: CSR0 (+ W0), depth-0 / depth-1 cluster ranks, MEM1 / MPTR1, HORD / HMP0 / HSPLIT ---------------
-// Needs topo_lean_prepare(structure) and the staged edges behind a barrier.  false (workgroup-uniform, nothing written yet):
-// ids too sparse for the concatenated flag array -- the caller takes the general chain.
-DEV bool topo_lean_structure(const TopoView& tv, const TopoArgs& a, int g, int n0, int e0, int N, int E, bool has_w,
-                             int c1_len, TopoScratch& s, int sidx) {
+// ---- rows chain: CSR0 (+ W0) and the aggregation tiles.  Needs the staged edges and topo_lean_prepare(rows) behind a barrier;
+// leaves no barrier behind its last phase.
+DEV void topo_lean_rows(const TopoView& tv, int g, int n0, int e0, int N, int E, bool has_w, TopoScratch& s, const TopoTile& tile) {
     const int rowbase = n0 + g;
-    const int n1 = imin(N, imax(c1_len, 0));
-    long long mn0, mx0, mn1, mx1;
-    wg_prepared_minmax(s.mm + 2, N, mn0, mx0);
-    wg_prepared_minmax((const long long*)s.part, n1, mn1, mx1);
-    const long long span0 = (N > 0) ? mx0 - mn0 + 1 : 0, span1 = (n1 > 0) ? mx1 - mn1 + 1 : 0;
-    if (span0 < 0 || span1 < 0 || span0 > s.capT || span1 > s.capT || (long long)(N + 3) + span0 + span1 > (long long)s.capT ||
-        N > 0x7FFF)
-        return false;
-    int* Z = s.t1;
-    const int o0 = N + 1, o1 = o0 + (int)span0 + 1, zlen = o1 + (int)span1 + 1;
-    const unsigned int mn0_lo = (unsigned int)((unsigned long long)mn0 & 0xffffffffull);
-    const unsigned int mn1_lo = (unsigned int)((unsigned long long)mn1 & 0xffffffffull);
+    int* Z = s.rp;
     FOR_TID(e, E) { ATOMIC_ADD(&Z[s.er[e]], 1); }
-    FOR_TID(i, N) { Z[o0 + (int)((unsigned int)s.pp[i] - mn0_lo)] = 1; }
-    FOR_TID(c, n1) { Z[o1 + (int)((unsigned int)s.nb[c] - mn1_lo)] = 1; }
-    BARRIER();      // (also: every thread has read the wave slots in s.part, which the scan reuses)
-    const int total = wg_exscan(Z, zlen, s.part);
-    const int C = Z[o1] - E, C1 = total - E - C;
-    const int n = imin(C, n1);                      // depth-0 clusters the depth-1 list covers
-    if (c1_len != C) { FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, sidx); } }
-    int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
-    int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
-    int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
-    FOR_TID(e, E) { const int r = s.er[e]; s.t2[Z[r] + ATOMIC_ADD(&s.cur[r], 1)] = e; }
-    FOR_TID(i, N + 1) { g_rowptr0[i] = Z[i]; }
-    int* csize = s.rp;      // nodes per depth-0 cluster (cleared by topo_lean_prepare)
-    FOR_TID(i, N) {
-        const int c = Z[o0 + (int)((unsigned int)s.pp[i] - mn0_lo)] - E;
-        s.cl[i] = c; g_cl0[i] = c;
-        ATOMIC_ADD(&csize[c], 1);
-    }
-    FOR_TID(c, n) {
-        const int k = Z[o1 + (int)((unsigned int)s.nb[c] - mn1_lo)] - E - C;
-        s.cp[c] = k;                                // depth-1 cluster of depth-0 cluster c
-        s.mp[c] = (k << 16) | c;                    // its sort key (k < 2^15, c < 2^15)
-        g_cl1[c] = k;
-    }
-    FOR_TID(i, 1) { tv.p[DRGNN_TI_NC1][g] = C1; }
     BARRIER();
-    {   // CSR0 slots: rank of every edge inside its row by edge id, emitted at once
+    wg_exscan(Z, N + 1, s.part);
+    {
+        int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
+        FOR_TID(e, E) { const int r = s.er[e]; s.t2[Z[r] + ATOMIC_ADD(&s.cur[r], 1)] = e; }
+        FOR_TID(i, N + 1) { g_rowptr0[i] = Z[i]; }
+    }
+    BARRIER();
+    {   // rank of every edge inside its row by edge id, emitted at once; column / weight by slot stay in LDS for the tiles
         int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
         int32_t* g_eid0 = tv.p[DRGNN_TI_EID0] + e0;
         float* g_w0 = tv.w0 ? tv.w0 + e0 : nullptr;
@@ -951,41 +1008,104 @@ DEV bool topo_lean_structure(const TopoView& tv, const TopoArgs& a, int g, int n
             const int lo = Z[r], hi = Z[r + 1];
             int rank = 0;
             for (int q = lo; q < hi; ++q) rank += (s.t2[q] < e) ? 1 : 0;
-            g_col0[lo + rank] = s.ec[e];
+            const int cc = s.ec[e];
+            g_col0[lo + rank] = cc;
             g_eid0[lo + rank] = e;
-            if (has_w) g_w0[lo + rank] = s.w0[e];
+            s.col[lo + rank] = cc;
+            if (has_w) { const float w = s.w0[e]; g_w0[lo + rank] = w; ((float*)s.seg)[lo + rank] = w; }
         }
     }
+    if (tile.F > 0) {
+        BARRIER();
+        topo_tiles_rows(tile, N, Z, s.col, has_w ? (const float*)s.seg : nullptr);
+    }
+}
+
+// ---- clusters chain: depth-0 / depth-1 cluster ranks, MEM1 / MPTR1, HORD / IHORD / HMP0 / HSPLIT and (with_pool, no edge
+// weights) the pooled CSR + CSC.  Needs the staged edges and topo_lean_prepare(clusters) behind a barrier.  false
+// (workgroup-uniform; at most ranks and counts written, which the general chain writes again): ids too sparse for the flag
+// array or too many clusters for the bitmaps -- the caller takes the general chain.
+DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, int E, int c1_len, bool with_pool, TopoScratch& s,
+                            int sidx) {
+    const int rowbase = n0 + g;
+    const int n1 = imin(N, imax(c1_len, 0));
+    long long mn0, mx0, mn1, mx1;
+    wg_prepared_minmax(s.mm + 2, N, mn0, mx0);
+    wg_prepared_minmax(TOPO_MM1(s), n1, mn1, mx1);
+    const long long span0 = (N > 0) ? mx0 - mn0 + 1 : 0, span1 = (n1 > 0) ? mx1 - mn1 + 1 : 0;
+    if (span0 < 0 || span1 < 0 || span0 > s.capT || span1 > s.capT || span0 + span1 + 2 > (long long)s.capT || N > 0x7FFF)
+        return false;
+    int* Z = s.t1;
+    const int o1 = (int)span0 + 1, zlen = o1 + (int)span1 + 1;
+    const unsigned int mn0_lo = (unsigned int)((unsigned long long)mn0 & 0xffffffffull);
+    const unsigned int mn1_lo = (unsigned int)((unsigned long long)mn1 & 0xffffffffull);
+    FOR_TID(i, N) { Z[(int)((unsigned int)s.pp[i] - mn0_lo)] = 1; }
+    FOR_TID(c, n1) { Z[o1 + (int)((unsigned int)s.nb[c] - mn1_lo)] = 1; }
+    BARRIER();
+    const int total = wg_exscan(Z, zlen, s.part);
+    const int C = Z[o1], C1 = total - C;
+    const int n = imin(C, n1);                      // depth-0 clusters the depth-1 list covers
+    const int BW = (C + 31) >> 5, CB = C * BW;
+    if (with_pool && 2L * CB + 1 > (long)s.capT) return false;
+    if (c1_len != C) { FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, sidx); } }
+    int* csize = s.cp;      // nodes per depth-0 cluster (cleared by topo_lean_prepare)
+    int* cl1 = s.mem;       // depth-1 cluster of every depth-0 cluster
+    int* key1 = s.mp;       // ... its sort key (depth-1 cluster, id)
+    int* bm = s.t2;         // [C][BW] target bitmaps of the pooled rows
+    int* bmT = s.t3;        // [C][BW] source bitmaps of the pooled columns
+    {
+        int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
+        int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
+        FOR_TID(i, N) {
+            const int c = Z[(int)((unsigned int)s.pp[i] - mn0_lo)];
+            s.cl[i] = c; g_cl0[i] = c;
+            ATOMIC_ADD(&csize[c], 1);
+        }
+        FOR_TID(c, n) {
+            const int k = Z[o1 + (int)((unsigned int)s.nb[c] - mn1_lo)] - C;
+            cl1[c] = k;
+            key1[c] = (k << 16) | c;                // (k < 2^15, c < 2^15)
+            g_cl1[c] = k;
+        }
+        if (with_pool) { FOR_TID(q, CB) { bm[q] = 0; bmT[q] = 0; } }
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; tv.p[DRGNN_TI_NC1][g] = C1; }
+    }
+    BARRIER();
     int* qpos = s.pp;       // position of every depth-0 cluster in the depth-1-major order (clusters the list does not cover: last)
     int* mp1 = s.rp1;
     {
+        if (with_pool) {
+            FOR_TID(e, E) {
+                const int r = s.cl[s.er[e]], cc = s.cl[s.ec[e]];
+                if (cc != r) {
+                    ATOMIC_OR(&bm[r * BW + (cc >> 5)], (int)(1u << (cc & 31)));
+                    ATOMIC_OR(&bmT[cc * BW + (r >> 5)], (int)(1u << (r & 31)));
+                }
+            }
+        }
         constexpr int G = TOPO_LANES(8);
         FOR_TID(item, C * G) {
             const int c = item / G, sub = item % G;
             int q = C - 1;
-            if (c < n) q = topo_count_below<8>(s.mp, n, s.mp[c], sub);
+            if (c < n) q = topo_count_below<8>(key1, n, key1[c], sub);
             if (sub == 0) qpos[c] = q;
         }
         int32_t* g_mptr1 = tv.p[DRGNN_TI_MPTR1] + rowbase;
         FOR_TID(item, (C1 + 1) * G) {
             const int k = item / G, sub = item % G;
-            const int cnt = topo_count_below<8>(s.cp, n, k, sub);
+            const int cnt = topo_count_below<8>(cl1, n, k, sub);
             if (sub == 0) { mp1[k] = cnt; g_mptr1[k] = cnt; }
         }
-        FOR_TID(c, C + 1) { s.cur[c] = 0; }      // (the CSR claim is over: the cursors of the node claim below)
+        FOR_TID(c, C + 1) { s.cur[c] = 0; }      // cursors of the node claim below
     }
     BARRIER();
-    // Hierarchical order = nodes bucketed by the position of their cluster.  The bucket offsets are sums of cluster sizes over
-    // the clusters in front (C^2 / lanes additions, no scan); a node claims a slot of its bucket and the few nodes of a bucket
-    // are ranked by id.  (Positions by counting smaller (position, id) keys over ALL nodes -- one phase less -- cost 11.5 k
-    // ticks at N = 200: ~9 instructions per comparison, N^2 of them; this costs 3.5 k.)
-    int* hmp = s.mp;        // (the depth-1 sort keys it held are consumed)
+    int* hmp = s.fl;        // [C + 1] <= capN + 1 <= capF
     {
         int32_t* g_mem1 = tv.p[DRGNN_TI_MEM1] + n0;
         int32_t* g_hmp = tv.p[DRGNN_TI_HMP0] + rowbase;
         FOR_TID(c, n) { g_mem1[qpos[c]] = c; }
         constexpr int G = TOPO_LANES(8);
-        FOR_TID(item, (C + 1) * G) {
+        FOR_TID(item, (C + 1) * G) {       // first position of the q-th cluster = sizes of the clusters in front of it
             const int q = item / G, sub = item % G;
             int acc = 0;
             for (int c = sub; c < C; c += G) acc += (qpos[c] < q) ? csize[c] : 0;
@@ -993,22 +1113,52 @@ DEV bool topo_lean_structure(const TopoView& tv, const TopoArgs& a, int g, int n
             if (sub == 0) { hmp[q] = acc; g_hmp[q] = acc; }
         }
     }
-    BARRIER();
+    if (with_pool) {
+        int* Y = s.t4;           // [2 CB + 1] set bits before each word of [bm | bmT]
+        // (a thread scans the element it wrote while 2 CB + 1 <= threads: no barrier in between)
+        FOR_TID(q, 2 * CB + 1) { Y[q] = (q < CB) ? __builtin_popcount((unsigned)bm[q]) : (q < 2 * CB) ? __builtin_popcount((unsigned)bmT[q - CB]) : 0; }
+        if (2 * CB + 1 > DRGNN_NTHREADS) BARRIER();
+        const int E1 = wg_exscan(Y, 2 * CB + 1, s.part) >> 1;
+        int32_t* g_col1 = tv.p[DRGNN_TI_COL1] + e0;
+        int32_t* g_rowidx1 = tv.p[DRGNN_TI_ROWIDX1] + e0;
+        FOR_TID(q, 2 * CB) {
+            const bool tr = q >= CB;
+            const int qq = tr ? q - CB : q;
+            unsigned bits = (unsigned)(tr ? bmT[qq] : bm[qq]);
+            const int r = qq / BW, base = (qq - r * BW) << 5;
+            int slot = Y[q] - (tr ? E1 : 0);
+            int32_t* dst = tr ? g_rowidx1 : g_col1;
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1;
+                dst[slot++] = base + b;
+            }
+        }
+        int32_t* g_rowptr1 = tv.p[DRGNN_TI_ROWPTR1] + rowbase;
+        int32_t* g_colptr1 = tv.p[DRGNN_TI_COLPTR1] + rowbase;
+        FOR_TID(r, C + 1) { g_rowptr1[r] = Y[r * BW]; g_colptr1[r] = Y[CB + r * BW] - E1; }
+        FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
+    } else {
+        BARRIER();
+    }
+    // (the barriers inside the popcount scan have made the run offsets visible: the node claim needs no phase of its own)
     FOR_TID(i, N) {
         const int c = s.cl[i], b = qpos[c];
         const int pos = hmp[b] + ATOMIC_ADD(&s.cur[c], 1);
-        s.t2[pos] = i;
-        s.t3[pos] = b;
+        s.t5[pos] = i;
+        s.nb[pos] = b;
     }
     BARRIER();
     {
         int32_t* g_hord = tv.p[DRGNN_TI_HORD] + n0;
+        int32_t* g_ihord = tv.p[DRGNN_TI_IHORD] + n0;
         FOR_TID(p, N) {
-            const int me = s.t2[p], b = s.t3[p];
+            const int me = s.t5[p], b = s.nb[p];
             const int lo = hmp[b], hi = hmp[b + 1];
             int rank = 0;
-            for (int q = lo; q < hi; ++q) rank += (s.t2[q] < me) ? 1 : 0;
+            for (int q = lo; q < hi; ++q) rank += (s.t5[q] < me) ? 1 : 0;
             g_hord[lo + rank] = me;
+            g_ihord[me] = lo + rank;
         }
     }
     {   // split point: the number k of leading depth-1 clusters whose node total is closest to N / 2 (smallest k on ties)
@@ -1045,66 +1195,6 @@ DEV bool topo_lean_structure(const TopoView& tv, const TopoArgs& a, int g, int n
     return true;
 }
 
-// ---- lean "pool" chain without edge weights: depth-0 ranks, pooled CSR (bitmap) and pooled CSC (transposed bitmap) ------------
-// Needs topo_lean_prepare and the staged edges behind a barrier.  false (workgroup-uniform; at most CL0 / NC0 written, which the
-// general chain writes again): the caller takes the general chain.
-DEV bool topo_lean_pool(const TopoView& tv, int g, int n0, int e0, int N, int E, TopoScratch& s) {
-    const int rowbase = n0 + g;
-    long long mn0, mx0;
-    wg_prepared_minmax(s.mm + 2, N, mn0, mx0);
-    const long long span0 = (N > 0) ? mx0 - mn0 + 1 : 0;
-    if (span0 < 0 || span0 + 1 > (long long)s.capT) return false;
-    int* Z = s.t1;
-    const unsigned int mn0_lo = (unsigned int)((unsigned long long)mn0 & 0xffffffffull);
-    FOR_TID(i, N) { Z[(int)((unsigned int)s.pp[i] - mn0_lo)] = 1; }
-    BARRIER();
-    const int C = wg_exscan(Z, (int)span0 + 1, s.part);
-    const int BW = (C + 31) >> 5, CB = C * BW;
-    int* bm = s.t2;          // [C][BW] target bitmaps of the pooled rows
-    int* bmT = s.t3;         // [C][BW] source bitmaps of the pooled columns
-    int* Y = s.t4;           // [2 CB + 1] set bits before each word of [bm | bmT]
-    {
-        int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
-        FOR_TID(i, N) { const int c = Z[(int)((unsigned int)s.pp[i] - mn0_lo)]; s.cl[i] = c; g_cl0[i] = c; }
-        FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; }
-    }
-    if (2L * CB + 1 > (long)s.capT) return false;      // many clusters: the general chain (ranks again: same CL0 / NC0)
-    FOR_TID(q, CB) { bm[q] = 0; bmT[q] = 0; }
-    BARRIER();
-    FOR_TID(e, E) {
-        const int r = s.cl[s.er[e]], cc = s.cl[s.ec[e]];
-        if (cc != r) {
-            ATOMIC_OR(&bm[r * BW + (cc >> 5)], (int)(1u << (cc & 31)));
-            ATOMIC_OR(&bmT[cc * BW + (r >> 5)], (int)(1u << (r & 31)));
-        }
-    }
-    BARRIER();
-    // (a thread scans the element it wrote while 2 CB + 1 <= threads: no barrier in between)
-    FOR_TID(q, 2 * CB + 1) { Y[q] = (q < CB) ? __builtin_popcount((unsigned)bm[q]) : (q < 2 * CB) ? __builtin_popcount((unsigned)bmT[q - CB]) : 0; }
-    if (2 * CB + 1 > DRGNN_NTHREADS) BARRIER();
-    const int E1 = wg_exscan(Y, 2 * CB + 1, s.part) >> 1;
-    int32_t* g_col1 = tv.p[DRGNN_TI_COL1] + e0;
-    int32_t* g_rowidx1 = tv.p[DRGNN_TI_ROWIDX1] + e0;
-    FOR_TID(q, 2 * CB) {
-        const bool tr = q >= CB;
-        const int qq = tr ? q - CB : q;
-        unsigned bits = (unsigned)(tr ? bmT[qq] : bm[qq]);
-        const int r = qq / BW, base = (qq - r * BW) << 5;
-        int slot = Y[q] - (tr ? E1 : 0);
-        int32_t* dst = tr ? g_rowidx1 : g_col1;
-        while (bits) {
-            const int b = __builtin_ctz(bits);
-            bits &= bits - 1;
-            dst[slot++] = base + b;
-        }
-    }
-    int32_t* g_rowptr1 = tv.p[DRGNN_TI_ROWPTR1] + rowbase;
-    int32_t* g_colptr1 = tv.p[DRGNN_TI_COLPTR1] + rowbase;
-    FOR_TID(r, C + 1) { g_rowptr1[r] = Y[r * BW]; g_colptr1[r] = Y[CB + r * BW] - E1; }
-    FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
-    return true;
-}
-
 // WEIGHTS: -1 = decided at run time (edge_attr and a weight workspace given); 0 = never (the builder co-launched with a
 // GINet / FoutNet step: the weighted pooled-edge path -- bucket ranking, run sums -- is not even compiled into those kernels,
 // whose register allocation and code layout it otherwise shapes: +0.5 us on the unweighted builder, +0.2 us on the GINet step)
@@ -1126,43 +1216,45 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     if (structure) topo_gather_rows(a, src, g, n0, N);
 
     // ---- phase 0: stage the edge list, clear what the next phases accumulate into ----
-    // LEAN (request flag, with the hierarchical order and cluster1): the short chains above.  Two workgroups per graph: each role
-    // runs its own; one workgroup: the pool chain, then the structure chain on re-read ids.
+    // LEAN (request flag, with the hierarchical order and cluster1): the short chains above (which role runs which: see there).
     const bool lean = (a.flags & DRGNN_TOPO_LEAN) != 0 && (a.flags & DRGNN_TOPO_HIER) != 0 && a.cluster0 != nullptr &&
                       a.cluster1 != nullptr && a.c1_ptr != nullptr;
     const int c1_len = lean ? a.c1_ptr[g + 1] - a.c1_ptr[g] : 0;
     const int nc1 = imin(N, imax(c1_len, 0));
-    const bool lean_pool = lean && pool && !has_w;
-    const bool str_first = lean && structure && !pool;
-    // the cluster ids of a lean chain are requested AHEAD of the edge list (one round trip for all three)
+    const bool run_rows = lean && structure && !(pool && has_w);
+    const bool run_clusters = lean && (has_w ? (structure && !pool) : pool);
+    // the aggregation tiles (DRGNN_TOPO_TILES): the x tile of the graph is requested first of all
+    const TopoTile tile = topo_tile_of(a, src, n0, structure ? s.xs : nullptr);
+    TopoTileRegs treg;
+    topo_tile_load(treg, tile, N);
+    // the cluster ids of the clusters chain are requested AHEAD of the edge list (one round trip for all three)
     long long pre0 = 0, pre1 = 0;
     bool pre = false;
 #ifndef DRGNN_EMU
-    if ((lean_pool || str_first) && N <= DRGNN_NTHREADS) {
+    if (run_clusters && N <= DRGNN_NTHREADS) {
         pre = true;
         if ((int)threadIdx.x < N) pre0 = (long long)src.cl0[threadIdx.x];
-        if (str_first && (int)threadIdx.x < nc1) pre1 = (long long)src.cl1[threadIdx.x];
+        if ((int)threadIdx.x < nc1) pre1 = (long long)src.cl1[threadIdx.x];
     }
 #endif
     topo_stage_edges(tv, src, sidx, N, E, has_w, s);
-    bool pool_done = false;
-    if (lean_pool || str_first) {
+    topo_tile_store(treg, tile, N);
+    bool rows_done = false, need_c1 = false;
+    if (run_rows || run_clusters) {
         // (one call site per chain: they are inlined)
-        bool try_structure = str_first;
-        topo_lean_prepare(src, N, nc1, str_first, s, pre, pre0, pre1);
+        topo_lean_prepare(src, N, nc1, run_rows, run_clusters, s, pre, pre0, pre1);
         BARRIER();
-        if (!str_first && topo_lean_pool(tv, g, n0, e0, N, E, s)) {
-            if (!structure) return;
-            pool_done = true;      // one workgroup per graph: the structure chain behind the pool chain, on re-read ids
+        if (run_rows) {
+            topo_lean_rows(tv, g, n0, e0, N, E, has_w, s, tile);
+            rows_done = true;
+            if (!run_clusters) return;
             BARRIER();
-            topo_lean_prepare(src, N, nc1, true, s);
-            BARRIER();
-            try_structure = true;
         }
-        if (try_structure && topo_lean_structure(tv, a, g, n0, e0, N, E, has_w, c1_len, s, sidx)) return;
-        BARRIER();      // the general chain for what is left: every thread is past its reads of the prepared arrays
+        if (topo_lean_clusters(tv, g, n0, e0, N, E, c1_len, !has_w, s, sidx)) return;
+        need_c1 = true;     // the general chain for the clusters: this workgroup builds depth 1 and the hierarchical order too
+        BARRIER();          // (every thread is past its reads of the prepared arrays)
     }
-    if (structure) {
+    if (structure && !rows_done) {
         FOR_TID(i, 2 * N + 2) { s.rp[i] = 0; }
         FOR_TID(i, N + 1) { s.cur[i] = 0; }
         FOR_TID(i, N) { s.nb[i] = 0; }
@@ -1171,13 +1263,16 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     if (a.cluster0 != nullptr) wg_rank_prepare(src.cl0, N, s);
     BARRIER();
 
-    if (structure) topo_csr0(tv, g, n0, e0, N, E, has_w, s);
+    if (structure && !rows_done) {
+        topo_csr0(tv, g, n0, e0, N, E, has_w, s);
+        topo_tiles_rows(tile, N, s.rp, s.col, has_w ? (const float*)s.seg : nullptr);
+    }
     if (a.cluster0 == nullptr) {          // graph-only build (stand-alone conv layers): no pooling
         FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = 0; tv.p[DRGNN_TI_NE1][g] = 0; tv.p[DRGNN_TI_NC1][g] = 0; }
         BARRIER();
         return;
     }
-    if (role == TOPO_ROLE_MEMBERS || pool_done) {       // structure: only the cluster COUNT of depth 0 is needed for depth 1
+    if (role == TOPO_ROLE_MEMBERS) {       // structure: only the cluster COUNT of depth 0 is needed for depth 1
         const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, false);
         topo_clusters1(tv, a, g, n0, N, C, src, s, sidx);
         return;
@@ -1188,5 +1283,5 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     const int C = topo_clusters0(tv, g, n0, N, src, s, sidx, members0, true);
     BARRIER();
     topo_pool(tv, g, n0, e0, E, C, has_w, s);
-    if (role == TOPO_ROLE_ALL) topo_clusters1(tv, a, g, n0, N, C, src, s, g);
+    if (role == TOPO_ROLE_ALL || need_c1) topo_clusters1(tv, a, g, n0, N, C, src, s, sidx);
 }

@@ -168,7 +168,9 @@ class ResidentGraphSet(object):
             sec["topo/ws_i32"] = cache.topo.ws_i32.cpu().numpy()
             if cache.topo.ws_f32 is not None:
                 sec["topo/ws_f32"] = cache.topo.ws_f32.cpu().numpy()
-            meta["topology"] = {"n_nodes": cache.topo.n_nodes, "n_edges": cache.topo.n_edges, "n_graphs": cache.topo.n_graphs,
+            if getattr(cache.topo, "tiles", None) is not None:
+                sec["topo/tiles"] = cache.topo.tiles.cpu().numpy()      # the set's level-0 aggregation tiles (TOPO_TILES)
+            meta["topology"] = {"flags": int(cache.topo.flags),"n_nodes": cache.topo.n_nodes, "n_edges": cache.topo.n_edges, "n_graphs": cache.topo.n_graphs,
                                 "with_weights": cache.topo.ws_f32 is not None,
                                 "off_i32": [int(v) for v in cache.topo.off_i32], "off_f32": [int(v) for v in cache.topo.off_f32],
                                 "arrays_i32": sorted(_lib.TI, key=_lib.TI.get), "arrays_f32": sorted(_lib.TF, key=_lib.TF.get)}
@@ -203,9 +205,16 @@ class ResidentGraphSet(object):
                     topo.ws_f32.copy_(torch.from_numpy(a["topo/ws_f32"]))
                 topo.max_nodes, topo.max_edges = int(self.n_nodes.max()), int(self.n_edges.max())
                 topo.max_c0, topo.has_level1, topo._inputs = int(self.n_c1.max()), True, None
+                topo.flags = int(t.get("flags", _lib.TOPO_HIER)) & ~_lib.TOPO_TILES
+                if "topo/tiles" in a and a["topo/tiles"].size >= self.api.topology_tiles_elems(t["n_nodes"], self.n_feat) and \
+                        (int(t.get("flags", 0)) & _lib.TOPO_TILES):
+                    topo.tiles = torch.from_numpy(a["topo/tiles"]).to(self.device)
+                    topo.n_feat = self.n_feat
+                    topo.flags |= _lib.TOPO_TILES
                 self._topo_cache = {bool(t["with_weights"]): TopologyCache(self, bool(t["with_weights"]), topo=topo)}
-                if t["with_weights"]:
-                    # a weighted workspace serves the nets that ignore the weights as well
+                if t["with_weights"] and topo.tiles is None:
+                    # a weighted workspace serves the nets that ignore the weights as well -- unless it carries aggregation
+                    # tiles: those are WEIGHTED sums, the other nets get a cache (and tiles) of their own, built on demand
                     self._topo_cache[False] = self._topo_cache[True]
         return self
 
@@ -291,8 +300,21 @@ class ResidentGraphSet(object):
         r.set = ctypes.cast(ctypes.pointer(self._desc), ctypes.c_void_p)
         r.ids, r.x_out, r.y_out = p(ids_dev), p(x), p(y)
         r.flags = _lib.TOPO_HIER
+        # the level-0 aggregation tiles of the mini-batch (formed from the set's x by the builder), where it can
+        if scratch is None and self.has_c1 and self.x.data_ptr() % 16 == 0 and \
+                self.api.topology_tiles_ok(topo.max_nodes, topo.max_edges, self.n_feat):
+            need = self.api.topology_tiles_elems(N, self.n_feat)
+            if topo.tiles is None or topo.tiles.numel() < need or topo.n_feat != self.n_feat:
+                topo.tiles = torch.empty(max(need, 4), dtype=torch.float32, device=self.device)
+            topo.n_feat = self.n_feat
+            r.tiles, r.n_feat = p(topo.tiles), self.n_feat
+            r.flags |= _lib.TOPO_TILES
+        else:
+            topo.tiles = None
+        topo.flags = int(r.flags)
         self.api.topology_build_request(r, _lib.current_stream(x))
         topo._inputs = None
+        topo.x = x
         return topo, x, y
 
     def batch(self, ids, ids_dev=None):
@@ -376,6 +398,13 @@ class TopologyCache(object):
             r.set = ctypes.cast(ctypes.pointer(gset._desc), ctypes.c_void_p)
             r.ids, r.x_out, r.y_out = p(ids), None, None
             r.flags = _lib.TOPO_HIER
+            # the set's level-0 aggregation tiles: formed ONCE here, read by every training step on the cache
+            if scratch is None and gset.x.data_ptr() % 16 == 0 and api.topology_tiles_ok(self.max_nodes, self.max_edges, gset.n_feat):
+                topo.tiles = torch.empty(max(api.topology_tiles_elems(N, gset.n_feat), 4), dtype=torch.float32, device=dev)
+                topo.n_feat = gset.n_feat
+                r.tiles, r.n_feat = p(topo.tiles), gset.n_feat
+                r.flags |= _lib.TOPO_TILES
+            topo.flags = int(r.flags)
             api.topology_build_request(r, _lib.current_stream(gset.x))
             topo._inputs = None
             self._keep = (ids, scratch)
@@ -384,13 +413,48 @@ class TopologyCache(object):
         d.n_graphs, d.n_nodes, d.n_edges = G, N, E
         d.ws_i32, d.ws_f32, d.x = _lib._ptr(topo.ws_i32), _lib._ptr(topo.ws_f32), _lib._ptr(gset.x)
         d.flags = int(getattr(topo, "flags", 0))
+        d.tiles = _lib._ptr(getattr(topo, "tiles", None) if (d.flags & _lib.TOPO_TILES) else None)
         self._desc = d
         self.refresh_targets()
 
     def refresh_targets(self):
         y = self.set.y
-        self._desc.y = None if y is None else y.data_ptr()
-        self._desc.y_bytes = 0 if y is None else y.element_size()
+        for d in [self._desc] + list(getattr(self, "_flavour", {}).values()):
+            d.y = None if y is None else y.data_ptr()
+            d.y_bytes = 0 if y is None else y.element_size()
+
+    def tiles_for(self, weighted):
+        """The set's level-0 aggregation tiles in the flavour a net needs -- weighted sums for sGAT, plain sums for GINet /
+        FoutNet -- or None.  The cache's own tiles have the flavour of its workspace; the other one is formed on first use
+        from the built workspace (drgnn_topology_tiles)."""
+        own = getattr(self.topo, "tiles", None)
+        if own is None or not (int(self.topo.flags) & _lib.TOPO_TILES):
+            return None
+        weighted = bool(weighted and self.with_weights)
+        if weighted == self.with_weights:
+            return own
+        alt = getattr(self, "_alt_tiles", None)
+        if alt is None:
+            s, t = self.set, self.topo
+            alt = self._alt_tiles = torch.empty_like(own)
+            s.api.topology_tiles(t.ws_i32, t.ws_f32, t.n_nodes, t.n_edges, t.n_graphs, s.x, s.n_feat, weighted, alt,
+                                 _lib.current_stream(s.x))
+        return alt
+
+    def desc_for(self, weighted):
+        """drgnn_topology_cache descriptor whose tiles have the flavour a net needs."""
+        tiles = self.tiles_for(weighted)
+        if tiles is getattr(self.topo, "tiles", None):
+            return self._desc
+        fl = self.__dict__.setdefault("_flavour", {})
+        d = fl.get(bool(weighted))
+        if d is None:
+            d = _lib.TopologyCacheDesc()
+            for name, _ in _lib.TopologyCacheDesc._fields_:
+                setattr(d, name, getattr(self._desc, name))
+            d.tiles = _lib._ptr(tiles)
+            fl[bool(weighted)] = d
+        return d
 
     def bounds(self, ids):
         """(max_nodes, max_edges, max_c0) over the graphs ``ids`` (host numbers)."""

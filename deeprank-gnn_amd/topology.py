@@ -35,12 +35,17 @@ class Topology(object):
         self.max_c0 = 0
         self.has_level1 = False
         self.flags = _lib.TOPO_HIER      # what the last build put into the workspace (drgnn_topology_request.flags)
+        # level-0 aggregation tiles (TOPO_TILES): the node features they are formed from and the output buffer
+        # ([S n x F | D n | C n], include/drgnn.h); None: not available for this batch
+        self.x = None
+        self.tiles = None
+        self.n_feat = 0
         self._finalized = False
 
     # ---------------------------------------------------------------------------
     @classmethod
     def from_batch(cls, data, api=None, with_level1=True, check=False, need_weights=True, graph_only=False,
-                   build=True, flags=None):
+                   build=True, flags=None, with_tiles=True):
         """Build from a ``Batch``-like object (attribute access only).  ``need_weights=False``
         skips everything that involves ``edge_attr`` (GINet's attention is identically 1 and
         FoutLayer never reads it, so only sGAT needs the pooled, summed edge attributes)."""
@@ -96,6 +101,13 @@ class Topology(object):
                                   dtype=torch.int32, device=device)
         topo.has_level1 = cluster1 is not None
         topo._inputs = (edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch)
+        x = getattr(data, "x", None) if (with_tiles and cluster1 is not None) else None
+        if x is not None and x.dim() == 2 and x.dtype == torch.float32 and x.device == device and scratch is None:
+            x = x.contiguous()
+            F = int(x.shape[1])
+            if x.shape[0] == n_nodes and F > 0 and x.data_ptr() % 16 == 0 and api.topology_tiles_ok(max_nodes, max_edges, F):
+                topo.x, topo.n_feat = x, F
+                topo.tiles = torch.empty(max(api.topology_tiles_elems(n_nodes, F), 4), dtype=torch.float32, device=device)
         if build:
             topo.rebuild(flags)
             if check:
@@ -114,10 +126,18 @@ class Topology(object):
         r.len_cluster1 = 0 if cluster1 is None else cluster1.numel()
         r.max_nodes, r.max_edges = self.max_nodes, self.max_edges
         r.ws_i32, r.ws_f32, r.scratch_i32 = p(self.ws_i32), p(self.ws_f32), p(scratch)
-        r.flags = _lib.TOPO_HIER if flags is None else int(flags)
+        r.flags = self.full_flags() if flags is None else int(flags)
+        if r.flags & _lib.TOPO_TILES:
+            if self.tiles is None:
+                raise ValueError("this topology has no aggregation tiles (no 16-byte aligned float32 x with F % 4 == 0)")
+            r.x, r.tiles, r.n_feat = p(self.x), p(self.tiles), self.n_feat
         self.flags = int(r.flags)
         self._finalized = False
         return r
+
+    def full_flags(self):
+        """Everything the builder can put into this workspace."""
+        return _lib.TOPO_HIER | (_lib.TOPO_TILES if self.tiles is not None else 0)
 
     def rebuild(self, flags=None):
         """(Re)run the builder into this object's existing buffers, on torch's current stream --
@@ -126,7 +146,9 @@ class Topology(object):
         construction are re-read, so refreshing them in place refreshes the topology.
         ``flags``: TOPO_* request flags (default: everything, with the hierarchical order)."""
         edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch = self._inputs
-        if flags is not None and int(flags) != _lib.TOPO_HIER:
+        if flags is None:
+            flags = self.full_flags()
+        if int(flags) != _lib.TOPO_HIER:
             self.api.topology_build_request(self.request(flags), _lib.current_stream(batch))
             return self
         self.flags = _lib.TOPO_HIER          # (drgnn_topology_build always builds the hierarchical order)
@@ -167,6 +189,12 @@ class Topology(object):
         """View of one int32 array of the workspace (enum drgnn_topo_i32)."""
         k = _lib.TI[name]
         return self.ws_i32[self.off_i32[k]:self.off_i32[k + 1]]
+
+    def tile_arrays(self):
+        """(S [n, F], D [n], C [n]) views of the level-0 aggregation tiles (include/drgnn.h, DRGNN_TOPO_TILES)."""
+        n, F = self.n_nodes, self.n_feat
+        t = self.tiles
+        return t[:n * F].view(n, F), t[n * F:n * F + n], t[n * F + n:n * F + 2 * n]
 
     def weights(self, name):
         k = _lib.TF[name]

@@ -159,7 +159,8 @@ class FusedTrainer(object):
         the topology holds the hierarchical order."""
         api, nb = self.api, self.n_branch
         split = 0
-        if nb == 1 and train and (topo_flags & _lib.TOPO_HIER) and (x is None or x.data_ptr() % 16 == 0):
+        if nb == 1 and train and (topo_flags & _lib.TOPO_HIER) and (topo_flags & _lib.TOPO_TILES) and \
+                (x is None or x.data_ptr() % 16 == 0):
             wgs, _ = api.net_step_plan(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O, B, B)
             split = 1 if wgs == 2 else 0
         xchg = None
@@ -182,6 +183,8 @@ class FusedTrainer(object):
         if y is not None:
             y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
         topo_flags = int(getattr(topo, "flags", 0))
+        if not (getattr(topo, "tiles", None) is not None and self._tiles_match(topo)):
+            topo_flags &= ~_lib.TOPO_TILES       # (no tiles, or tiles of the other flavour: stepped without them)
         slabs, xchg, split = self._layout(n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, B, train, topo_flags, dev, x)
         # descriptors only depend on the (fixed) parameter storage and the feature width: built once
         ck = self._desc_cache.get(n_feat)
@@ -205,20 +208,27 @@ class FusedTrainer(object):
         # the launch arguments, so a workgroup need not fetch them from the workspace first
         bd = getattr(batch, "__dict__", {})
         hn, he = bd.get("_host_node_ptr"), bd.get("_host_edge_ptr")
+        tiles = getattr(topo, "tiles", None) if (train and (topo_flags & _lib.TOPO_TILES)) else None
         if hn is not None and he is not None and len(hn) == B + 1 and B <= 64:
-            hints = _lib.step_hints(node_ptr=hn, edge_ptr=he, topo_flags=topo_flags if train else 0, split=split)
+            hints = _lib.step_hints(node_ptr=hn, edge_ptr=he, topo_flags=topo_flags if train else 0, split=split, tiles=tiles)
         else:
-            hints = _lib.step_hints(topo_flags=topo_flags if train else 0, split=split)
+            hints = _lib.step_hints(topo_flags=topo_flags if train else 0, split=split, tiles=tiles)
         return dict(
             hints=hints, slabs=slabs,
             x=x, y=y, topo=topo, B=B, n_nodes=n_nodes, xchg=xchg, g1=g1, g2=g2, desc=desc,
             stream=_lib.current_stream(x), pred=torch.empty((B, self.O), dtype=torch.float32, device=dev),
             readout=readout, partials=partials, hp=hp)
 
-    def _af_launch(self, topo, n_feat, n_next, x=None):
+    def _tiles_match(self, topo):
+        """The aggregation tiles of a workspace built WITH edge weights are weighted sums (what sGAT starts from); GINet /
+        FoutNet start from plain sums: a workspace of the other flavour is stepped without its tiles."""
+        return (getattr(topo, "ws_f32", None) is not None) == (self.kind == _lib.SGAT)
+
+    def _af_launch(self, topo, n_feat, n_next):
         """True when a TRAINING launch on ``topo`` (co-building ``n_next`` graphs) runs one of the aggregation-first kernels
-        (csrc/drgnn_step2.h / drgnn_step3.h) -- the launches that accept a workspace built with TOPO_LEAN."""
-        if x is not None and x.data_ptr() % 16:
+        (csrc/drgnn_step2.h / drgnn_step3.h): they start from the aggregation tiles the builder forms (TOPO_TILES) and are
+        the launches that accept a workspace built with TOPO_LEAN."""
+        if getattr(topo, "tiles", None) is None or not self._tiles_match(topo):
             return False
         if not self.api.net_step_family(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, self.H, self.O):
             return False
@@ -229,23 +239,23 @@ class FusedTrainer(object):
         return wgs == 2
 
     def _flags_for(self, topo, n_feat):
-        """Request flags of a topology the next launch co-builds.  The hierarchical node order where a step kernel reads it
-        (GINet's one-workgroup layout beyond the resident batch size does not, and there the builder is co-critical); and
-        ONLY what the aggregation-first kernels read (TOPO_LEAN: the builder's short chains) when the launch that will train
-        on it is one of them -- judged for a following mini-batch of the same size; _fused_launch_step rebuilds in full
-        should that turn out wrong."""
-        af = self._af_launch(topo, n_feat, topo.n_graphs)
-        if af:
-            return _lib.TOPO_HIER | _lib.TOPO_LEAN
+        """Request flags of a topology the next launch co-builds.  When the launch that will train on it is one of the
+        aggregation-first kernels: the hierarchical node order, the aggregation tiles, and nothing those kernels do not read
+        (TOPO_LEAN: the builder's short chains) -- judged for a following mini-batch of the same size; _fused_launch_step
+        rebuilds in full should that turn out wrong.  Otherwise the plain build (GINet's one-workgroup layout beyond the
+        resident batch size reads no hierarchical order, and there the builder is co-critical)."""
+        if self._af_launch(topo, n_feat, topo.n_graphs):
+            return _lib.TOPO_HIER | _lib.TOPO_LEAN | _lib.TOPO_TILES
         return 0 if self.kind == _lib.GINET else _lib.TOPO_HIER
 
     def _fused_launch_step(self, c, next_topo=None):
         """ONE launch: body fwd + head/loss + body bwd (+ the next mini-batch's topology)."""
         t = c["topo"]
         if (int(getattr(t, "flags", 0)) & _lib.TOPO_LEAN) and not self._af_launch(
-                t, c["x"].shape[1], 0 if next_topo is None else next_topo.n_graphs, c["x"]):
+                t, c["x"].shape[1], 0 if next_topo is None else next_topo.n_graphs):
             t.rebuild()      # a lean workspace under a launch that reads more: build the rest (own launch, same stream)
             c["hints"][0].topo_flags = int(t.flags)
+            c["hints"][0].tiles = _lib._ptr(t.tiles if (int(t.flags) & _lib.TOPO_TILES) else None)
         self.api.net_train_step(c["desc"], self._head_desc(True), c["x"], c["y"], self.step2, t.ws_i32, t.ws_f32,
                                 c["n_nodes"], t.n_edges, c["B"], t.max_nodes, t.max_edges, t.max_c0, c["pred"],
                                 c["readout"], c["hp"], c["partials"], c["xchg"], c["stream"],
@@ -306,7 +316,8 @@ class FusedTrainer(object):
         readout, partials, hp = bk
         # (beyond 64 graphs the offsets no longer travel in the kernel arguments, but the library still range-checks the ids)
         hints = _lib.step_hints(set_node_ptr=gset.node_ptr, set_edge_ptr=gset.edge_ptr, ids=ids,
-                                topo_flags=topo_flags if train else 0, split=split)
+                                topo_flags=topo_flags if train else 0, split=split,
+                                tiles=cache.tiles_for(self.kind == _lib.SGAT) if (train and (topo_flags & _lib.TOPO_TILES)) else None)
         return dict(hints=hints, slabs=slabs,
                     cache=cache, ids_dev=ids_dev, B=B, bounds=(max_nodes, max_edges, max_c0), xchg=xchg, g1=g1, g2=g2,
                     desc=desc, stream=_lib.current_stream(gset.x), readout=readout, partials=partials, hp=hp,
@@ -314,7 +325,7 @@ class FusedTrainer(object):
 
     def _cached_launch_step(self, c, train=True):
         mn, me, mc = c["bounds"]
-        self.api.net_train_step_cached(c["desc"], self._head_desc(train), c["cache"]._desc, c["ids_dev"], c["B"], mn, me, mc,
+        self.api.net_train_step_cached(c["desc"], self._head_desc(train), c["cache"].desc_for(self.kind == _lib.SGAT), c["ids_dev"], c["B"], mn, me, mc,
                                        self.step2, c["pred"], c["readout"], c["hp"] if train else None,
                                        c["partials"] if train else None, c["xchg"], c["stream"],
                                        hints=None if c.get("hints") is None else c["hints"][0])
@@ -585,7 +596,7 @@ class FusedTrainer(object):
         plan.lr, plan.beta1, plan.beta2, plan.eps = self.lr, self.betas[0], self.betas[1], self.eps
         if cached:
             cache = gset.topology_cache(need_weights=need_w)
-            plan.cache = ctypes.cast(ctypes.pointer(cache._desc), vp)
+            plan.cache = ctypes.cast(ctypes.pointer(cache.desc_for(self.kind == _lib.SGAT)), vp)
         callback = None
         if not inference and getattr(self, "_dp", None) is not None:
             sizes, group = self._dp

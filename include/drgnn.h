@@ -94,6 +94,7 @@ enum drgnn_topo_i32 {
     DRGNN_TI_HMP0,       /* [N+B]  first position of the q-th depth-0 cluster IN MEM1 ORDER, q = 0..C0            */
     DRGNN_TI_HSPLIT,     /* [4B]   per graph {k, MPTR1[k], HMP0[MPTR1[k]], C1}: k = the number of leading depth-1
                                    clusters whose node total is closest to N/2 (the two-workgroup split point)   */
+    DRGNN_TI_IHORD,      /* [N]    hierarchical position of local node i (the inverse of HORD)                    */
     DRGNN_TI_COUNT
 };
 enum drgnn_topo_f32 {
@@ -319,6 +320,10 @@ typedef struct drgnn_topology_request {
      * NULL).  Pooled edge weights are built when ws_f32 and set->edge_attr are both given. */
     const drgnn_graph_set* set; const int32_t* ids; float* x_out; void* y_out;
     int32_t flags, reserved;      /* DRGNN_TOPO_* below */
+    /* DRGNN_TOPO_TILES: node features the level-0 aggregation is formed from -- x [n_nodes, n_feat] of the mini-batch (NULL in
+     * resident-set mode: the set's x) -- and where it goes: tiles [drgnn_topology_tiles_elems(n_nodes, n_feat)] */
+    const float* x; float* tiles;
+    int32_t n_feat, reserved2;
 } drgnn_topology_request;
 /* request flags.  DRGNN_TOPO_HIER: also build the hierarchical node order (DRGNN_TI_HORD / HMP0 / HSPLIT; needs cluster1) --
  * what the node-split step kernels of the single-branch nets consume (4 more phases on the builder's member-list chain, so
@@ -333,6 +338,25 @@ typedef struct drgnn_topology_request {
  * it hidden behind the step workgroups it is co-launched with.  A launch that is not an aggregation-first training step
  * refuses a workspace built this way (drgnn_step_hints.topo_flags): DRGNN_E_ARG. */
 #define DRGNN_TOPO_LEAN 2
+/* DRGNN_TOPO_TILES (with DRGNN_TOPO_HIER): the builder also forms the LEVEL-0 NEIGHBOUR AGGREGATION of every node -- it depends
+ * on the inputs only (node features, edges, edge weights), not on a parameter -- so that the training step of the mini-batch
+ * starts from it instead of gathering x rows over edge_index inside the step kernel: the aggregation rides in the builder's
+ * workgroups of the PREVIOUS launch like the topology itself (cached-topology mode: it is formed once per graph).  Layout of
+ * `tiles` (node order, n = n_nodes of the workspace, F = n_feat):
+ *     S [n][F]   S_i = sum over the edges e = (i, j) in edge-id order of [w_e] x_j     (w_e: with edge weights only)
+ *     D [n]      1 / deg_i (without weights: 0 for an isolated node; with weights: 1 / max(deg_i, 1))
+ *     C [n]      with weights: mean edge weight of the row (sum_e w_e) D_i; without: 1
+ * GINetConvLayer (ginet.py:50-73) is relu(S W); FoutLayer (foutnet.py:56-82) relu(D (S Wn) + x Wc + b); sGraphAttentionLayer
+ * (sGAT.py:62-93) relu(D (S Wn) + C (x Ws) + b).  Needs n_feat % 4 == 0, 16-byte aligned x and drgnn_topology_tiles_ok(). */
+#define DRGNN_TOPO_TILES 4
+/* elements of a tiles buffer / 1 when the builder can form tiles for graphs of these bounds (its LDS holds an x tile then) */
+int64_t drgnn_topology_tiles_elems(int64_t n_nodes, int32_t n_feat);
+int32_t drgnn_topology_tiles_ok(int32_t max_nodes, int32_t max_edges, int32_t n_feat);
+/* The same tiles from a workspace that is already built (its CSR0, and with use_weights its W0): a second flavour for a
+ * workspace shared by nets with and without edge weights (a resident set's cached topology).  x [n_nodes, n_feat]: the node
+ * features the workspace's graphs are laid out over.  Own launch; not a hot path. */
+int drgnn_topology_tiles(const int32_t* ws_i32, const float* ws_f32, int64_t n_nodes, int64_t n_edges, int64_t n_graphs,
+                         const float* x, int32_t n_feat, int32_t use_weights, float* tiles, void* stream);
 /* drgnn_topology_build from a request (either mode), own launch. */
 int drgnn_topology_build_request(const drgnn_topology_request* request, void* stream);
 /* Slot offset tables of EVERY mini-batch of an epoch in one launch: mini-batch k = ids[k*batch_size, ...) gets
@@ -425,6 +449,9 @@ typedef struct drgnn_step_hints {
      *             caller sized `partials` for 2 slabs per graph and `xchg` for drgnn_net_step_xchg_elems words per graph and
      *             will pass slabs_per_graph = 2 to drgnn_step_update.  DRGNN_E_CAPACITY if the launch cannot be laid out so. */
     int32_t topo_flags, split;
+    /* DRGNN_TOPO_TILES in topo_flags: the aggregation tiles the builder formed for this workspace (DEVICE memory, laid out
+     * for the workspace's node count): the aggregation-first kernels start conv1 from them. */
+    const float* tiles;
 } drgnn_step_hints;
 /* uint64 exchange words per graph the fused step needs for these bounds (GINet: n_branch x max(H, 32); the split layout
  * of sGAT / FoutNet: two hand-offs of max_c0 x 16 values per half + the partial readouts) */
@@ -550,6 +577,7 @@ typedef struct drgnn_topology_cache {
     const float* x;                              /* [n_nodes, F] node features, graph-major (the set's x) */
     const void* y; int32_t y_bytes, flags;       /* [n_graphs] targets: 4 = float32, 8 = int64; may be NULL (inference);
                                                     flags: the DRGNN_TOPO_* flags the workspace was built with */
+    const float* tiles;                          /* flags & DRGNN_TOPO_TILES: the set's aggregation tiles (n_nodes rows), else NULL */
 } drgnn_topology_cache;
 /* drgnn_net_train_step over the graphs ids[0..n_graphs) of a cached set: same outputs, same arithmetic (slot g
  * of every output = graph ids[g]); max_* bound the graphs of THIS mini-batch. */

@@ -5,7 +5,7 @@ import torch
 
 from helpers import fixture_batch, fixture_graphs, syn4_batch
 from emu_api import emu
-from topo_check import check_against_oracle
+from topo_check import check_against_oracle, check_tiles
 from deeprank_gnn_amd.data import Batch, Data
 from deeprank_gnn_amd.topology import Topology
 import deeprank_gnn_amd.synthetic as synth
@@ -83,6 +83,26 @@ def test_lean_topology_matches_oracle_and_the_full_build(make, weights):
         for g in range(full.n_graphs):
             np.testing.assert_array_equal(full.weights("W1").numpy()[eptr[g]:eptr[g] + ne1[g]],
                                           lean.weights("W1").numpy()[eptr[g]:eptr[g] + ne1[g]])
+
+
+@pytest.mark.parametrize("weights", [True, False])
+@pytest.mark.parametrize("lean", [False, True])
+def test_aggregation_tiles(weights, lean):
+    """TOPO_TILES: the builder forms the level-0 neighbour sums (+ 1 / deg, mean edge weight) of every node and the inverse of
+    the hierarchical order -- by the general chains and by the lean ones, with and without edge weights."""
+    from deeprank_gnn_amd import _lib
+    flags = _lib.TOPO_HIER | _lib.TOPO_TILES | (_lib.TOPO_LEAN if lean else 0)
+    for batch in (synth.make_batch(0, 3), synth.make_batch(5, 4, n_nodes=30, n_pairs=50, n_feat=8, n_c1=3, n_internal=8)):
+        topo = Topology.from_batch(batch, api=emu(), need_weights=weights, flags=flags)
+        assert topo.status()[0] == 0 and topo.tiles is not None
+        check_against_oracle(topo, batch, weights=weights)
+        check_tiles(topo, batch, weights)
+    rng = np.random.default_rng(7)
+    many = Batch.from_data_list([random_graph(rng, int(rng.integers(1, 12)), int(rng.integers(0, 20)), 3, 2) for _ in range(165)])
+    many.x = torch.cat([many.x, many.x[:, :3]], dim=1).contiguous()      # F = 8
+    topo = Topology.from_batch(many, api=emu(), need_weights=weights, flags=flags)
+    check_against_oracle(topo, many, weights=weights)
+    check_tiles(topo, many, weights)
 
 
 @pytest.mark.parametrize("seed", range(6))

@@ -225,3 +225,23 @@ def test_lean_topology_on_the_device_equals_the_full_build(weights):
                          "COLPTR1": (n0 + g, C + 1), "ROWIDX1": (e0, E1), "CL1": (n0, C), "MPTR1": (n0 + g, nc1[g] + 1),
                          "MEM1": (n0, C), "HORD": (n0, N), "HMP0": (n0 + g, C + 1), "HSPLIT": (4 * g, 4)}[name]
                 np.testing.assert_array_equal(a[lo:lo + n], b[lo:lo + n], err_msg="%s graph %d" % (name, g))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weights", [False, True])
+@pytest.mark.parametrize("lean", [False, True])
+def test_aggregation_tiles_on_the_device(weights, lean):
+    """TOPO_TILES at the benchmarked shape, on a ragged batch and beyond 160 graphs (one builder workgroup per graph)."""
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.topology import Topology
+    from topo_check import check_against_oracle, check_tiles
+    import deeprank_gnn_amd.synthetic as synth
+    dev = torch.device("cuda:0")
+    flags = _lib.TOPO_HIER | _lib.TOPO_TILES | (_lib.TOPO_LEAN if lean else 0)
+    for batch_cpu in (synth.make_batch(0, 64), synth.make_batch(3, 5, n_nodes=37, n_pairs=60, n_feat=8, n_c1=4, n_internal=10),
+                      synth.make_batch(0, 170, n_nodes=20, n_pairs=30, n_feat=4, n_c1=3, n_internal=6)):
+        batch = batch_cpu.clone().to(dev)
+        topo = Topology.from_batch(batch, need_weights=weights, flags=flags)
+        assert topo.status()[0] == 0 and topo.tiles is not None
+        check_against_oracle(topo, batch_cpu, weights=weights)
+        check_tiles(topo, batch_cpu, weights)

@@ -132,3 +132,31 @@ def check_against_oracle(topo, batch, level1=True, weights=True):
                 k = int(np.argmin(np.abs(2 * pos - N)))
                 np.testing.assert_array_equal(a["HSPLIT"][4 * g:4 * g + 4], [k, mp[k], hmp[mp[k]], C1])
     return a
+
+
+def check_tiles(topo, batch, weights):
+    """Level-0 aggregation tiles (TOPO_TILES) against a plain restatement: S_i = sum over the edges (i, j) of [w_e] x_j, D, C."""
+    assert topo.tiles is not None and (int(topo.flags) & 4)
+    S, D, C = (t.cpu().numpy() for t in topo.tile_arrays())
+    x = batch.x.cpu().numpy().astype(np.float64)
+    ei = batch.edge_index.cpu().numpy()
+    n = x.shape[0]
+    w = batch.edge_attr.cpu().numpy().reshape(-1).astype(np.float64) if weights else np.ones(ei.shape[1])
+    want = np.zeros_like(x)
+    np.add.at(want, ei[0], w[:, None] * x[ei[1]])
+    deg = np.bincount(ei[0], minlength=n).astype(np.float64)
+    np.testing.assert_allclose(S, want, rtol=1e-5, atol=1e-5)
+    if weights:
+        d = 1.0 / np.maximum(deg, 1.0)
+        asum = np.bincount(ei[0], weights=w, minlength=n)
+        np.testing.assert_allclose(D, d, rtol=1e-6)
+        np.testing.assert_allclose(C, asum * d, rtol=1e-5, atol=1e-6)
+    else:
+        np.testing.assert_allclose(D, np.where(deg > 0, 1.0 / np.maximum(deg, 1.0), 0.0), rtol=1e-6)
+        np.testing.assert_array_equal(C, np.ones(n, dtype=np.float32))
+    # IHORD is the inverse of HORD, graph by graph
+    nptr = topo.array("NPTR").cpu().numpy()
+    hord, ihord = topo.array("HORD").cpu().numpy(), topo.array("IHORD").cpu().numpy()
+    for g in range(topo.n_graphs):
+        h = hord[nptr[g]:nptr[g + 1]]
+        np.testing.assert_array_equal(ihord[nptr[g]:nptr[g + 1]][h], np.arange(len(h)))

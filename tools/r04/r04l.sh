@@ -1,12 +1,7 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04l; mkdir -p $O
 for lib in libdrgnn_prof.so libdrgnn_prof8.so; do
-  PROF_LIB=$lib timeout 300 python tools/r04/topo_phases.py 0 3 > $O/topo_lean_$lib.txt 2>&1
+  PROF_LIB=$lib timeout 300 python tools/r04/topo_phases.py 0 7 > $O/topo_lean_$lib.txt 2>&1
+  PROF_LIB=$lib timeout 300 python tools/r04/topo_phases.py 1 7 > $O/topo_lean_w_$lib.txt 2>&1
 done
-tail -n 40 $O/topo_lean_lib*.txt
-timeout 600 python tools/r04/time_topo.py 64 128 256 2>&1 | grep k_topo | tee $O/time_topo.txt
-for net in GINet sGAT FoutNet; do
-python bench.py --no-cpu-baseline --epoch-graphs 0 --min-seconds 1 --net $net 2>$O/err_$net.txt | python -c "
-import json,sys;d=json.loads(sys.stdin.read());k=d.get('roofline',{}).get('kernels',{})
-print('$net', 'us/step', round(d['ms_per_step']*1000,2), 'kernels', [round(v['avg_us'],2) for v in k.values()], 'loss', d['config']['final_loss'])" | tee -a $O/ab.txt
-done
+tail -n 40 $O/topo_lean_*lib*.txt

@@ -45,8 +45,7 @@ for B in [int(a) for a in sys.argv[1:]] or [64]:
     for w in (False, True):
         topo = Topology.from_batch(batch, need_weights=w)
         out = []
-        for name, flags in (("full", None), ("hier-only", _lib.TOPO_HIER), ("no-hier", 0), ("lean", _lib.TOPO_HIER | _lib.TOPO_LEAN)):
-            if flags == _lib.TOPO_HIER:
-                continue
+        for name, flags in (("full", _lib.TOPO_HIER), ("full+tiles", _lib.TOPO_HIER | _lib.TOPO_TILES), ("no-hier", 0),
+                            ("lean", _lib.TOPO_HIER | _lib.TOPO_LEAN), ("lean+tiles", _lib.TOPO_HIER | _lib.TOPO_LEAN | _lib.TOPO_TILES)):
             out.append("%s %.2f us" % (name, timed(graph_of(lambda: topo.rebuild(flags)))))
         print("k_topo B=%d weights=%d: %s" % (B, w, "   ".join(out)), flush=True)
