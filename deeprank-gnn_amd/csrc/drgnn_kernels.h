@@ -88,6 +88,17 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
     const int32_t* EP = L.user_eptr ? L.user_eptr : L.tv.p[DRGNN_TI_EPTR];
     const int n0 = NP[g], n1 = NP[g + 1], N = n1 - n0;
     const int e0 = EP[g], e1 = EP[g + 1], E = e1 - e0;
+    if (LDS) {
+        const int capT = imax(L.capN, L.capE) + 1;
+        s = topo_carve(lds, L.capN, L.capE, capT, L.capN + L.capE + 2);
+        // the x tile of the aggregation tiles sits behind the carve (topo_lds_bytes counts it)
+        if (L.args.tile_f > 0 && L.args.tiles != nullptr)
+            s.xs = (float*)(lds + topo_scratch_ints(L.capN, L.capE, capT, (int64_t)L.capN + L.capE + 2));
+    } else {
+        // linear placement (see topo_gscratch_base): disjoint regions without a scan
+        s = topo_carve(L.gscratch + topo_gscratch_base(n0, e0, g), N, E, N + E + 1, N + E + 2);
+    }
+    const bool fits = !LDS || (N <= L.capN && E <= L.capE);
     if (!L.level1_only) {
         FOR_TID(i, 1) {
             L.tv.p[DRGNN_TI_GSTAT][sidx] = 0;
@@ -98,21 +109,13 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
                 if (g == 0) L.tv.p[DRGNN_TI_ERR][0] = 0;
             }
         }
+        // (the lean clusters chain sets its presence flags in the builder's first phase: cleared here, before this barrier)
+        if (fits && (L.args.flags & DRGNN_TOPO_LEAN) && role != TOPO_ROLE_MEMBERS) topo_lean_preclear(N, s);
         BARRIER();
     }
-    if (LDS) {
-        const int capT = imax(L.capN, L.capE) + 1;
-        s = topo_carve(lds, L.capN, L.capE, capT, L.capN + L.capE + 2);
-        // the x tile of the aggregation tiles sits behind the carve (topo_lds_bytes counts it)
-        if (L.args.tile_f > 0 && L.args.tiles != nullptr)
-            s.xs = (float*)(lds + topo_scratch_ints(L.capN, L.capE, capT, (int64_t)L.capN + L.capE + 2));
-        if (N > L.capN || E > L.capE) {   // caller's bound was wrong: refuse loudly
-            FOR_TID(i, 1) { topo_flag(L.tv, DRGNN_S_EDGE_RANGE, sidx); }
-            return;
-        }
-    } else {
-        // linear placement (see topo_gscratch_base): disjoint regions without a scan
-        s = topo_carve(L.gscratch + topo_gscratch_base(n0, e0, g), N, E, N + E + 1, N + E + 2);
+    if (!fits) {   // caller's bound was wrong: refuse loudly
+        FOR_TID(i, 1) { topo_flag(L.tv, DRGNN_S_EDGE_RANGE, sidx); }
+        return;
     }
     if (!L.level1_only) {
         topo_graph<WEIGHTS>(L.tv, L.args, g, n0, n1, e0, e1, s, role);

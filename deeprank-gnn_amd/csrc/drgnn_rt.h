@@ -23,6 +23,7 @@
 #define DEV static inline
 #define HD static inline
 #define FOR_TID(i, n) for (int i = 0; i < (int)(n); ++i)
+#define FOR_TID_FROM(i, n, first) for (int i = 0; i < (int)(n); ++i)
 #define BARRIER() ((void)0)
 #define PHASE_MARK() ((void)0)
 #define PHASE_BEGIN() ((void)0)
@@ -37,6 +38,10 @@ DEV void emu_atomic_max64(long long* p, long long v) { if (v > *p) *p = v; }
 #define ATOMIC_OR(p, v) emu_atomic_or((p), (v))
 #define ATOMIC_MIN64(p, v) emu_atomic_min64((p), (v))
 #define ATOMIC_MAX64(p, v) emu_atomic_max64((p), (v))
+DEV void emu_atomic_add64(long long* p, long long v) { *p += v; }
+DEV void emu_atomic_max(int* p, int v) { if (v > *p) *p = v; }
+#define ATOMIC_ADD64(p, v) emu_atomic_add64((p), (v))
+#define ATOMIC_MAX(p, v) emu_atomic_max((p), (v))
 typedef void* drgnn_stream_t;
 #else
 // ---------------------------------------------------------------- gfx950
@@ -49,6 +54,10 @@ typedef void* drgnn_stream_t;
 #endif
 // (nounroll: these loops run once per workgroup with 1 - 3 trips; unrolled copies and their remainder loops are instructions for nothing)
 #define FOR_TID(i, n) _Pragma("nounroll") for (int i = (int)threadIdx.x; i < (int)(n); i += DRGNN_NTHREADS)
+// the same with item 0 on thread `first` (a multiple of the wave size): several short loops of one phase land on different
+// waves instead of queueing up on waves 0, 1, ..
+#define FOR_TID_FROM(i, n, first) _Pragma("nounroll") \
+    for (int i = (int)((threadIdx.x + DRGNN_NTHREADS - (first)) & (DRGNN_NTHREADS - 1)); i < (int)(n); i += DRGNN_NTHREADS)
 #ifdef DRGNN_PHASE_TIMING
 // profiling build only (libdrgnn_prof.so, tools/phase_timing.py): thread 0 of workgroup 0
 // stamps (source line, shader clock) after every barrier into a global buffer.
@@ -83,6 +92,8 @@ struct WG { int block; int nthreads; };
 #define ATOMIC_OR(p, v) atomicOr((p), (v))
 #define ATOMIC_MIN64(p, v) atomicMin((p), (long long)(v))
 #define ATOMIC_MAX64(p, v) atomicMax((p), (long long)(v))
+#define ATOMIC_ADD64(p, v) atomicAdd((unsigned long long*)(p), (unsigned long long)(v))
+#define ATOMIC_MAX(p, v) atomicMax((p), (v))
 typedef hipStream_t drgnn_stream_t;
 #endif
 

@@ -113,8 +113,12 @@ struct TopoScratch {
 #define TOPO_PAD4(n) (((n) + 3) & ~3LL)
 // mm[0], mm[1]: min / max of the ids being ranked; mm[2 + 2w], mm[3 + 2w]: wave w's partial min / max (wg_rank_prepare)
 // (+ a second set of wave slots, mm[2 + 2 NW + 2w ..]: the depth-1 ids of the lean clusters chain, prepared in the same phase)
-#define TOPO_MM_INTS (4 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
+// (+ one word: bits of the largest |edge weight| of the graph, the fixed-point scale of the pooled weight sums)
+#define TOPO_MM_INTS (8 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
 #define TOPO_MM1(s) ((s).mm + 2 + 2 * (DRGNN_NTHREADS / DRGNN_WAVE))
+#define TOPO_WMAX(s) ((int*)(s).mm + 4 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
+// (+ one word: a cluster id of the lean clusters chain lay outside its flag array)
+#define TOPO_OVF(s) ((int*)(s).mm + 5 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
 // number of ints: linear in (capN, capE, capT, capF) -- keep in sync with topo_carve
 HD int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT, int64_t capF) {
     return TOPO_MM_INTS + TOPO_PAD4(DRGNN_NTHREADS + 1) + 6 * TOPO_PAD4(capN + 1) + 3 * TOPO_PAD4(capN) +
@@ -125,7 +129,7 @@ HD int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT, int64_t c
 // capT = N+E+1 and capF = N+E+2 the carve needs at most 15*N + 12*E + TOPO_GSCRATCH_CONST ints
 // (the constant absorbs the fixed arrays and every PAD4 rounding), so regions placed at
 // 15*n0 + 12*e0 + CONST*g (rounded up to even for the 64-bit min/max slot) never overlap.
-#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 176 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
+#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 184 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
 HD int64_t topo_gscratch_base(int64_t n0, int64_t e0, int64_t g) {
     return ((15 * n0 + 12 * e0 + (int64_t)TOPO_GSCRATCH_CONST * g) + 1) & ~(int64_t)1;
 }
@@ -162,6 +166,20 @@ DEV TopoScratch topo_carve(IntPtr base, int capN, int capE, int capT, int capF) 
     s.capT = capT;
     return s;
 }
+
+DEV int topo_f2i(float v) { int b; memcpy(&b, &v, 4); return b; }
+DEV float topo_i2f(int b) { float v; memcpy(&v, &b, 4); return v; }
+// Pooled edge weights are sums of raw edge weights; they are formed in 64-bit FIXED POINT at a scale set by the largest |w|
+// of the graph (2^40 steps per binade of it: < 2^-40 of that weight per addend, no overflow below 2^16 edges): exact, hence
+// independent of the order of the addends -- the lean chain adds with atomics, the general chain along sorted runs, both
+// get the same bits.
+DEV double topo_wscale(int wmax_bits, double* inv) {
+    int ex = 0;
+    (void)frexpf(topo_i2f(wmax_bits), &ex);
+    *inv = ldexp(1.0, ex - 40);
+    return ldexp(1.0, 40 - ex);
+}
+DEV long long topo_wfix(float w, double scale) { return (long long)rint((double)w * scale); }
 
 // per-graph status word: cleared by the graph's own workgroup at the start of every build
 DEV void topo_flag(const TopoView& tv, int bit, int graph) { ATOMIC_OR(&tv.p[DRGNN_TI_GSTAT][graph], bit); }
@@ -710,8 +728,24 @@ DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool
         BARRIER();
     } else {
         FOR_TID(r, C + 1) { s.pp[r] = 0; s.cur[r] = 0; }
+        FOR_TID(i, 1) { TOPO_WMAX(s)[0] = 0; }
         BARRIER();
-        FOR_TID(e, E) { ATOMIC_ADD(&s.pp[s.cl[s.er[e]]], 1); }
+        {
+            int mine = 0;
+            FOR_TID(e, E) {
+                ATOMIC_ADD(&s.pp[s.cl[s.er[e]]], 1);
+                if (has_w) { const int b = topo_f2i(fabsf(s.w0[e])) & 0x7fffffff; mine = b > mine ? b : mine; }
+            }
+#ifdef DRGNN_EMU
+            if (has_w) ATOMIC_MAX(TOPO_WMAX(s), mine);
+#else
+            if (has_w && (int)(threadIdx.x & ~(DRGNN_WAVE - 1)) < E) {      // (one atomic per wave)
+#pragma unroll
+                for (int m = 1; m < DRGNN_WAVE; m <<= 1) { const int o = __shfl_xor(mine, m, DRGNN_WAVE); mine = o > mine ? o : mine; }
+                if ((threadIdx.x & (DRGNN_WAVE - 1)) == 0) ATOMIC_MAX(TOPO_WMAX(s), mine);
+            }
+#endif
+        }
         BARRIER();
         wg_exscan(s.pp, C + 1, s.part);
         // (target cluster, edge id) packed into ONE word -- clusters < 2^15 (max_nodes <= 32767), edge ids < 2^16
@@ -773,6 +807,8 @@ DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool
         }
         BARRIER();
         E1 = wg_exscan(s.t1, E + 1, s.part);
+        double winv = 1.0;
+        const double wsc = has_w ? topo_wscale(TOPO_WMAX(s)[0], &winv) : 1.0;
         FOR_TID(j, E) {
             const int key = s.t4[j];
             const int r = s.t3[j];
@@ -782,22 +818,23 @@ DEV void topo_pool(const TopoView& tv, int g, int n0, int e0, int E, int C, bool
                 s.seg[slot] = r;               // row of pooled CSR slot
                 g_col1[slot] = key;
                 if (has_w) {
-                    // the run's weights, summed in sorted (= edge id) order; four positions per trip in flight
+                    // the run's weights in fixed point (topo_wscale: exact, the same bits as the lean chain's atomics); four
+                    // positions per trip in flight
                     const int hi = s.pp[r + 1];
-                    float w = 0.0f;
+                    long long w = 0;
                     int q = j;
                     for (; q + 3 < hi; q += 4) {
                         const int k0 = s.t4[q], k1 = s.t4[q + 1], k2 = s.t4[q + 2], k3 = s.t4[q + 3];
                         const float v0 = wv[q], v1 = wv[q + 1], v2 = wv[q + 2], v3 = wv[q + 3];
                         const bool e0 = k0 == key, e1 = e0 && k1 == key, e2 = e1 && k2 == key, e3 = e2 && k3 == key;
-                        if (e0) w += v0;
-                        if (e1) w += v1;
-                        if (e2) w += v2;
-                        if (e3) w += v3;
+                        if (e0) w += topo_wfix(v0, wsc);
+                        if (e1) w += topo_wfix(v1, wsc);
+                        if (e2) w += topo_wfix(v2, wsc);
+                        if (e3) w += topo_wfix(v3, wsc);
                         if (!e3) { q = hi; break; }
                     }
-                    for (; q < hi && s.t4[q] == key; ++q) w += wv[q];
-                    g_w1[slot] = w;
+                    for (; q < hi && s.t4[q] == key; ++q) w += topo_wfix(wv[q], wsc);
+                    g_w1[slot] = (float)((double)w * winv);
                 }
             }
         }
@@ -934,10 +971,11 @@ DEV void topo_tiles_rows(const TopoTile& t, int N, const int* rp, const int* col
 //                    position of a cluster = number of smaller (depth-1 cluster, id) keys (C^2 comparisons), first position of
 //                    its nodes = sum of the sizes of the clusters in front (C^2 additions), a node claims a slot of its
 //                    cluster's run and the few nodes of a run are ranked by id.
-// Two workgroups per graph: without edge weights the "structure" workgroup runs the rows chain and the "pool" workgroup the
-// clusters chain (19 k / 22 k clock ticks at SYN size; the general chains: 33 k / 41 k); with edge weights the pool workgroup
-// keeps the general pooled-edge routine (sorted runs, summed weights) and the structure workgroup runs rows + clusters without
-// the pooled graph.  One workgroup per graph (no weights): rows, then clusters.
+//                    With edge weights the pooled weights are sums over the raw edges of a (row, column) pair: accumulated by
+//                    64-bit fixed-point atomics (exact, order independent -- no sorting; the general chain sorts every pooled
+//                    row's edges by (target, id) and adds runs).
+// Two workgroups per graph: the "structure" workgroup runs the rows chain and the "pool" workgroup the clusters chain
+// (20 k / 29 k clock ticks at SYN size; the general chains: 33 k / 41 k).  One workgroup per graph: rows, then clusters.
 // Items of the counting loops are shared by G consecutive lanes that meet in DPP adds (the emulation runs items serially).
 #ifdef DRGNN_EMU
 #define TOPO_LANES(G) 1
@@ -967,19 +1005,35 @@ template <int G> DEV int topo_count_below(const int* keys, int n, int me, int su
 }
 
 // Phase 0 of the lean chains (next to the edge staging; ends with the caller's barrier).  rows: histogram and cursors cleared.
-// clusters: the flag array cleared, both id lists read (`pre`: already in registers, requested ahead of the edge list), low
-// words + wave min / max filed (depth 0: s.pp, s.mm + 2; depth 1: s.nb, TOPO_MM1).
+// clusters: the presence flags of both id lists are set HERE -- depth-0 ids in Z[0, R), depth-1 ids in Z[R, 2 R), R = N + 1,
+// Z = s.fl, the id itself as the index (cluster ids are labels in [0, N): the reference's are node or cluster numbers;
+// anything else raises TOPO_OVF and the caller takes the general chain) -- so the ranking needs no min / max pass and no flag
+// phase of its own.  Z and TOPO_OVF were cleared BEFORE the previous barrier (topo_lean_preclear, from topo_block).
+// `pre`: the ids are already in registers, requested ahead of the edge list.
+DEV void topo_lean_preclear(int N, TopoScratch& s) {
+    FOR_TID(v, imin(2 * N + 2, s.capF)) { s.fl[v] = 0; }
+    FOR_TID(i, 1) { TOPO_OVF(s)[0] = (2 * N + 2 > s.capF) ? 1 : 0; TOPO_WMAX(s)[0] = 0; }
+}
+DEV void topo_lean_flag(long long v, int i, int* Z, int N, int* key, TopoScratch& s) {
+    if ((unsigned long long)v < (unsigned long long)N) { Z[(int)v] = 1; key[i] = (int)v; }
+    else { TOPO_OVF(s)[0] = 1; key[i] = 0; }
+}
 DEV void topo_lean_prepare(const TopoSrc& src, int N, int n1, bool rows, bool clusters, TopoScratch& s, bool pre = false,
                            long long v0 = 0, long long v1 = 0) {
     if (rows) { FOR_TID(i, N + 1) { s.rp[i] = 0; s.cur[i] = 0; } }
-    if (clusters) {
-        FOR_TID(v, s.capT) { s.t1[v] = 0; }
+    if (clusters && 2 * N + 2 <= s.capF) {
+        const int R = N + 1;
         FOR_TID(i, N + 1) { s.cp[i] = 0; }
 #ifndef DRGNN_EMU
-        if (pre) { wg_rank_prepare_val(v0, N, s.pp, s.mm + 2); wg_rank_prepare_val(v1, n1, s.nb, TOPO_MM1(s)); }
-        else
+        if (pre) {
+            if ((int)threadIdx.x < N) topo_lean_flag(v0, threadIdx.x, s.fl, N, s.pp, s);
+            if ((int)threadIdx.x < n1) topo_lean_flag(v1, threadIdx.x, s.fl + R, N, s.nb, s);
+        } else
 #endif
-        { wg_rank_prepare(src.cl0, N, s); wg_rank_prepare_to(src.cl1, n1, s.nb, TOPO_MM1(s)); }
+        {
+            FOR_TID(i, N) { topo_lean_flag((long long)src.cl0[i], i, s.fl, N, s.pp, s); }
+            FOR_TID(c, n1) { topo_lean_flag((long long)src.cl1[c], c, s.fl + R, N, s.nb, s); }
+        }
     }
     (void)pre; (void)v0; (void)v1;
 }
@@ -1025,25 +1079,31 @@ DEV void topo_lean_rows(const TopoView& tv, int g, int n0, int e0, int N, int E,
 // weights) the pooled CSR + CSC.  Needs the staged edges and topo_lean_prepare(clusters) behind a barrier.  false
 // (workgroup-uniform; at most ranks and counts written, which the general chain writes again): ids too sparse for the flag
 // array or too many clusters for the bitmaps -- the caller takes the general chain.
-DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, int E, int c1_len, bool with_pool, TopoScratch& s,
-                            int sidx) {
+DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, int E, int c1_len, bool with_pool, bool has_w,
+                            TopoScratch& s, int sidx) {
     const int rowbase = n0 + g;
     const int n1 = imin(N, imax(c1_len, 0));
-    long long mn0, mx0, mn1, mx1;
-    wg_prepared_minmax(s.mm + 2, N, mn0, mx0);
-    wg_prepared_minmax(TOPO_MM1(s), n1, mn1, mx1);
-    const long long span0 = (N > 0) ? mx0 - mn0 + 1 : 0, span1 = (n1 > 0) ? mx1 - mn1 + 1 : 0;
-    if (span0 < 0 || span1 < 0 || span0 > s.capT || span1 > s.capT || span0 + span1 + 2 > (long long)s.capT || N > 0x7FFF)
-        return false;
-    int* Z = s.t1;
-    const int o1 = (int)span0 + 1, zlen = o1 + (int)span1 + 1;
-    const unsigned int mn0_lo = (unsigned int)((unsigned long long)mn0 & 0xffffffffull);
-    const unsigned int mn1_lo = (unsigned int)((unsigned long long)mn1 & 0xffffffffull);
-    FOR_TID(i, N) { Z[(int)((unsigned int)s.pp[i] - mn0_lo)] = 1; }
-    FOR_TID(c, n1) { Z[o1 + (int)((unsigned int)s.nb[c] - mn1_lo)] = 1; }
-    BARRIER();
-    const int total = wg_exscan(Z, zlen, s.part);
-    const int C = Z[o1], C1 = total - C;
+    if (TOPO_OVF(s)[0] != 0 || N > 0x7FFF) return false;
+    int* Z = s.fl;
+    const int H = N + 1;
+    const int total = wg_exscan(Z, 2 * H, s.part);
+    const int C = Z[H], C1 = total - C;
+    int* wmax_bits = TOPO_WMAX(s);
+    if (with_pool && has_w) {
+        // the largest |w| of the graph, for the fixed-point scale of the pooled sums below (non-negative floats order like
+        // their bit patterns; one atomic per wave: same-address LDS atomics serialise)
+        int mine = 0;
+        FOR_TID(e, E) { const int b = topo_f2i(fabsf(s.w0[e])) & 0x7fffffff; mine = b > mine ? b : mine; }
+#ifdef DRGNN_EMU
+        ATOMIC_MAX(wmax_bits, mine);
+#else
+        if ((int)(threadIdx.x & ~(DRGNN_WAVE - 1)) < E) {
+#pragma unroll
+            for (int m = 1; m < DRGNN_WAVE; m <<= 1) { const int o = __shfl_xor(mine, m, DRGNN_WAVE); mine = o > mine ? o : mine; }
+            if ((threadIdx.x & (DRGNN_WAVE - 1)) == 0) ATOMIC_MAX(wmax_bits, mine);
+        }
+#endif
+    }
     const int n = imin(C, n1);                      // depth-0 clusters the depth-1 list covers
     const int BW = (C + 31) >> 5, CB = C * BW;
     if (with_pool && 2L * CB + 1 > (long)s.capT) return false;
@@ -1057,17 +1117,18 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
         int32_t* g_cl0 = tv.p[DRGNN_TI_CL0] + n0;
         int32_t* g_cl1 = tv.p[DRGNN_TI_CL1] + n0;
         FOR_TID(i, N) {
-            const int c = Z[(int)((unsigned int)s.pp[i] - mn0_lo)];
+            const int c = Z[s.pp[i]];
             s.cl[i] = c; g_cl0[i] = c;
             ATOMIC_ADD(&csize[c], 1);
         }
         FOR_TID(c, n) {
-            const int k = Z[o1 + (int)((unsigned int)s.nb[c] - mn1_lo)] - C;
+            const int k = Z[H + s.nb[c]] - C;
             cl1[c] = k;
             key1[c] = (k << 16) | c;                // (k < 2^15, c < 2^15)
             g_cl1[c] = k;
         }
         if (with_pool) { FOR_TID(q, CB) { bm[q] = 0; bmT[q] = 0; } }
+        if (with_pool && has_w) { FOR_TID(q, 2 * E) { s.seg[q] = 0; } }      // 64-bit accumulators of the pooled weights: [seg | col1]
         FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; tv.p[DRGNN_TI_NC1][g] = C1; }
     }
     BARRIER();
@@ -1083,15 +1144,16 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
                 }
             }
         }
+        // (the counting loops start on wave 8: the edge loop above keeps every wave busy, its first trip ends on waves 0 - 7 last)
         constexpr int G = TOPO_LANES(8);
-        FOR_TID(item, C * G) {
+        FOR_TID_FROM(item, C * G, 512) {
             const int c = item / G, sub = item % G;
             int q = C - 1;
             if (c < n) q = topo_count_below<8>(key1, n, key1[c], sub);
             if (sub == 0) qpos[c] = q;
         }
         int32_t* g_mptr1 = tv.p[DRGNN_TI_MPTR1] + rowbase;
-        FOR_TID(item, (C1 + 1) * G) {
+        FOR_TID_FROM(item, (C1 + 1) * G, 384) {
             const int k = item / G, sub = item % G;
             const int cnt = topo_count_below<8>(cl1, n, k, sub);
             if (sub == 0) { mp1[k] = cnt; g_mptr1[k] = cnt; }
@@ -1121,7 +1183,8 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
         const int E1 = wg_exscan(Y, 2 * CB + 1, s.part) >> 1;
         int32_t* g_col1 = tv.p[DRGNN_TI_COL1] + e0;
         int32_t* g_rowidx1 = tv.p[DRGNN_TI_ROWIDX1] + e0;
-        FOR_TID(q, 2 * CB) {
+        int32_t* g_tslot1 = tv.p[DRGNN_TI_TSLOT1] + e0;
+        FOR_TID_FROM(q, 2 * CB, 512) {      // (waves 8 ..: waves 0 .. 6 formed the run offsets, every wave takes part in the scan)
             const bool tr = q >= CB;
             const int qq = tr ? q - CB : q;
             unsigned bits = (unsigned)(tr ? bmT[qq] : bm[qq]);
@@ -1131,7 +1194,28 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
             while (bits) {
                 const int b = __builtin_ctz(bits);
                 bits &= bits - 1;
-                dst[slot++] = base + b;
+                dst[slot] = base + b;
+                if (tr && has_w) {      // CSR1 slot of this CSC1 entry (column r, row base + b): the set bits of row's bitmap in front of it
+                    const int row = base + b, w_ = row * BW + (r >> 5);
+                    g_tslot1[slot] = Y[w_] + __builtin_popcount((unsigned)bm[w_] & ((1u << (r & 31)) - 1u));
+                }
+                ++slot;
+            }
+        }
+        if (has_w) {
+            // Pooled weights: the sum of the raw weights of every (row cluster, column cluster) pair.  Order-independent and
+            // exact: 64-bit fixed-point atomics at a scale set by the graph's largest |w| (2^40 steps per binade of it: < 2^-40
+            // relative to that weight per addend, no overflow below 2^16 edges) -- deterministic without sorting the edges.
+            double inv_unused;
+            const double scale = topo_wscale(wmax_bits[0], &inv_unused);
+            long long* acc = (long long*)s.seg;
+            FOR_TID(e, E) {
+                const int r = s.cl[s.er[e]], cc = s.cl[s.ec[e]];
+                if (cc != r) {
+                    const int w_ = r * BW + (cc >> 5);
+                    const int slot = Y[w_] + __builtin_popcount((unsigned)bm[w_] & ((1u << (cc & 31)) - 1u));
+                    ATOMIC_ADD64(&acc[slot], topo_wfix(s.w0[e], scale));
+                }
             }
         }
         int32_t* g_rowptr1 = tv.p[DRGNN_TI_ROWPTR1] + rowbase;
@@ -1142,13 +1226,21 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
         BARRIER();
     }
     // (the barriers inside the popcount scan have made the run offsets visible: the node claim needs no phase of its own)
-    FOR_TID(i, N) {
+    FOR_TID_FROM(i, N, 768) {
         const int c = s.cl[i], b = qpos[c];
         const int pos = hmp[b] + ATOMIC_ADD(&s.cur[c], 1);
         s.t5[pos] = i;
         s.nb[pos] = b;
     }
     BARRIER();
+    if (with_pool && has_w) {
+        double inv;
+        (void)topo_wscale(wmax_bits[0], &inv);
+        const long long* acc = (const long long*)s.seg;
+        float* g_w1 = tv.w1 + e0;
+        const int E1 = s.t4[CB];      // (= Y[CB]: the pooled edge count)
+        FOR_TID(q, E1) { g_w1[q] = (float)((double)acc[q] * inv); }
+    }
     {
         int32_t* g_hord = tv.p[DRGNN_TI_HORD] + n0;
         int32_t* g_ihord = tv.p[DRGNN_TI_IHORD] + n0;
@@ -1221,8 +1313,8 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
                       a.cluster1 != nullptr && a.c1_ptr != nullptr;
     const int c1_len = lean ? a.c1_ptr[g + 1] - a.c1_ptr[g] : 0;
     const int nc1 = imin(N, imax(c1_len, 0));
-    const bool run_rows = lean && structure && !(pool && has_w);
-    const bool run_clusters = lean && (has_w ? (structure && !pool) : pool);
+    const bool run_rows = lean && structure;
+    const bool run_clusters = lean && pool;
     // the aggregation tiles (DRGNN_TOPO_TILES): the x tile of the graph is requested first of all
     const TopoTile tile = topo_tile_of(a, src, n0, structure ? s.xs : nullptr);
     TopoTileRegs treg;
@@ -1250,7 +1342,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
             if (!run_clusters) return;
             BARRIER();
         }
-        if (topo_lean_clusters(tv, g, n0, e0, N, E, c1_len, !has_w, s, sidx)) return;
+        if (topo_lean_clusters(tv, g, n0, e0, N, E, c1_len, true, has_w, s, sidx)) return;
         need_c1 = true;     // the general chain for the clusters: this workgroup builds depth 1 and the hierarchical order too
         BARRIER();          // (every thread is past its reads of the prepared arrays)
     }

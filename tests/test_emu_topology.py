@@ -81,8 +81,9 @@ def test_lean_topology_matches_oracle_and_the_full_build(make, weights):
     if weights:
         np.testing.assert_array_equal(full.weights("W0").numpy()[:full.n_edges], lean.weights("W0").numpy()[:full.n_edges])
         for g in range(full.n_graphs):
-            np.testing.assert_array_equal(full.weights("W1").numpy()[eptr[g]:eptr[g] + ne1[g]],
-                                          lean.weights("W1").numpy()[eptr[g]:eptr[g] + ne1[g]])
+            # (the lean chain sums the pooled weights in exact fixed point, the general chain in float32 in sorted order)
+            np.testing.assert_allclose(full.weights("W1").numpy()[eptr[g]:eptr[g] + ne1[g]],
+                                       lean.weights("W1").numpy()[eptr[g]:eptr[g] + ne1[g]], rtol=1e-6, atol=1e-7)
 
 
 @pytest.mark.parametrize("weights", [True, False])
