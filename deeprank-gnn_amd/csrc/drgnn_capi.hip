@@ -606,18 +606,29 @@ static int g_step_class_mode = 0;          // 0: capacity-class kernels where a 
 static int g_step2_mode = 0;               // 0: sGAT / FoutNet may take the aggregation-first kernels (drgnn_step2.h); 1: never
 static int g_step2_split_mode = 0;         // 0: ... with two workgroups per graph where the plan allows; 1: never split (A/B runs)
 static int g_step3_mode = 0;               // 0: GINet may take the aggregation-first kernels (drgnn_step3.h); 1: never (A/B runs, tests)
+// CUs this process may count on for co-residency of a launch's workgroups: the device's CU count, per device id (ADVICE r03:
+// a process may drive devices of different sizes).  DRGNN_RESIDENT_CUS=<n> overrides it (a CU mask -- HSA_CU_MASK /
+// ROC_GLOBAL_CU_MASK -- or a share of the GPU leaves fewer CUs than the attribute says); DRGNN_SHARED_GPU=1 means "assume
+// nothing": every layout that waits for a partner workgroup is off (one workgroup per graph).
 static int device_cu_count() {
 #ifdef DRGNN_EMU
     return 256;
 #else
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) cus = n;
-        else cus = 1;      // unknown device: never assume co-residency
+    static int cus[64];
+    static int env_cus = -2;
+    if (env_cus == -2) {
+        const char* sh = getenv("DRGNN_SHARED_GPU");
+        const char* lim = getenv("DRGNN_RESIDENT_CUS");
+        env_cus = (sh && sh[0] == '1') ? 0 : (lim && atoi(lim) > 0) ? atoi(lim) : -1;
     }
-    return cus;
+    if (env_cus >= 0) return env_cus;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;      // unknown device: never assume co-residency
+    if (cus[dev] == 0) {
+        int n = 0;
+        cus[dev] = (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 1;
+    }
+    return cus[dev];
 #endif
 }
 #ifndef DRGNN_EMU
@@ -706,7 +717,7 @@ int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int
     // builder workgroups of the topology co-built by the same launch
     // (the builder takes ONE workgroup per graph when two would push the launch past the device: train_step_impl)
     const int64_t extra = co_built_graphs > 0 ? co_built_graphs : 0;
-    if (step_two_workgroups_ok(n_graphs, extra)) {
+    if (H >= DRGNN_H2 && step_two_workgroups_ok(n_graphs, extra)) {
         if (lds_bytes) *lds_bytes = step_lds_bytes(kind, n_feat, max_nodes, capE, capC, R, H, O);
         return 2;
     }
@@ -741,7 +752,9 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         return DRGNN_E_ARG;
     if (hd->train && (!target || !head_partials || !partials)) return DRGNN_E_ARG;      // inference needs neither
     if (net->n_branch > 1 && !xchg) return DRGNN_E_ARG;
-    if (net->n_branch > 1 && hd->H < DRGNN_H2) return DRGNN_E_WIDTH;      // the exchange words of a graph: n_branch x DRGNN_H2 of its n_branch x H
+    // (the exchange words of a graph are n_branch x DRGNN_H2 of its n_branch x H: a GINet head narrower than that is stepped by
+    // the one-workgroup layout, which exchanges nothing -- drgnn_net_step_plan says so too)
+    const bool narrow_head = net->n_branch > 1 && hd->H < DRGNN_H2;
     if (net->kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
     if (hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
         return DRGNN_E_WIDTH;
@@ -786,7 +799,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
 #endif
     // GINet: one workgroup per graph unless all of 2 B (+ the builder's) workgroups are resident at once; decided below,
     // once the co-launched builder's size is known
-    const bool two_alone = (net->n_branch == 2 || af_split == 2) && step_two_workgroups_ok(n_graphs, 0);
+    const bool two_alone = (net->n_branch == 2 || af_split == 2) && !narrow_head && step_two_workgroups_ok(n_graphs, 0);
     bool one_paired = false;
     const int64_t lds1 = (net->n_branch == 2) ? step1_lds_bytes(F, L.capN, L.capE, L.capC, hd->H, hd->O, &one_paired) : 0;
     if (net->n_branch == 2 && !two_alone) {
@@ -868,8 +881,8 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     if (net->n_branch == 2) {
         // two workgroups per graph only while every workgroup of the launch is resident -- with the builder at two
         // workgroups per graph if that fits, else at one
-        if (step_two_workgroups_ok(n_graphs, bn * (split_ok ? 2 : 1))) {
-        } else if (split_ok && step_two_workgroups_ok(n_graphs, bn)) {
+        if (!narrow_head && step_two_workgroups_ok(n_graphs, bn * (split_ok ? 2 : 1))) {
+        } else if (!narrow_head && split_ok && step_two_workgroups_ok(n_graphs, bn)) {
             T.roles = 1;
         } else if (lds1 <= DRGNN_LDS_LIMIT) {
             one_wg = true;

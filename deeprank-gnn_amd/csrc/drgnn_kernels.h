@@ -732,16 +732,22 @@ __global__ void __launch_bounds__(DRGNN_UPDATE_THREADS) k_update(UpdateArgs u) {
     __shared__ float quarter[4][64];
     __shared__ float bias_scalars[2];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const bool conv = (int)blockIdx.x < u.conv_blocks;
+    // ONE textual barrier for all five waves: before it the four quarter waves issue their loads and sums and the
+    // fifth forms Adam's two scalars; behind it wave 0 owns the element's update.
+    float* d = nullptr;
+    bool upd = false, live = false;
+    int64_t idx = -1;
+    int item = 0, n_grad = 0;
+    AdamPre pre;
+    pre.ok = false; pre.p = pre.m = pre.v = 0.0f; pre.step_size = 0.0f; pre.sqrt_bc2 = 1.0f;
     if (q == 4) {
-        if (u.apply_adam && lane == 0) {
-            float step_size, sqrt_bc2;
-            adam_bias_scalars(u.ad, step_size, sqrt_bc2);
+        if (lane == 0) {
+            float step_size = 0.0f, sqrt_bc2 = 1.0f;
+            if (u.apply_adam) adam_bias_scalars(u.ad, step_size, sqrt_bc2);
             bias_scalars[0] = step_size; bias_scalars[1] = sqrt_bc2;
         }
-        __syncthreads();
-        return;
-    }
-    if ((int)blockIdx.x < u.conv_blocks) {
+    } else if (conv) {
         const ReduceArgs& a = u.r;
         // The branch of a block is UNIFORM (blocks_per_branch blocks per branch): the per-branch descriptors (gradient
         // pointers, strides) are then scalar loads from the argument block.  With a per-lane branch (item / n_partial) the
@@ -750,41 +756,34 @@ __global__ void __launch_bounds__(DRGNN_UPDATE_THREADS) k_update(UpdateArgs u) {
         int br = 0, blk = (int)blockIdx.x;
         while (blk >= u.blocks_per_branch && br + 1 < a.n_branch) { blk -= u.blocks_per_branch; ++br; }
         const int p_raw = blk * 64 + lane;
-        const bool live = p_raw < a.n_partial && reduce_live(a, p_raw);
+        live = p_raw < a.n_partial && reduce_live(a, p_raw);
         const int p = live ? p_raw : 0;
         // wave 0 owns the element's update: its parameter / moment loads are issued BEFORE the slab loads, so that Adam
         // starts from registers once the quarter sums are in
-        float* d = (q == 0 && live) ? reduce_dst(a, br, p) : nullptr;
-        const bool upd = d != nullptr && u.apply_adam;
-        const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
-        AdamPre pre = adam_prefetch_state(u.ad, idx);
+        d = (q == 0 && live) ? reduce_dst(a, br, p) : nullptr;
+        upd = d != nullptr && u.apply_adam;
+        idx = upd ? (int64_t)(d - u.ad.grad) : -1;
+        pre = adam_prefetch_state(u.ad, idx);
         quarter[q][lane] = live ? reduce_sum(a, br, p, q, 4) : 0.0f;
-        __syncthreads();
+    } else {
+        item = ((int)blockIdx.x - u.conv_blocks) * 64 + lane;
+        live = item < update_head_items(u);
+        n_grad = update_head_items(u) - 1;
+        d = (q == 0 && live && item < n_grad) ? u.h.grad + item : nullptr;
+        upd = d != nullptr && u.apply_adam;
+        idx = upd ? (int64_t)(d - u.ad.grad) : -1;
+        pre = adam_prefetch_state(u.ad, idx);
+        quarter[q][lane] = live ? update_head_sum(u, item, q, 4) : 0.0f;
+    }
+    __syncthreads();
+    if (q == 0) {
         pre.step_size = bias_scalars[0]; pre.sqrt_bc2 = bias_scalars[1];
+        const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
         if (d) {
-            const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
             *d = g;                                   // keep p.grad inspectable
             if (upd) adam_apply(u.ad, idx, g, pre);
-        }
-    } else {
-        const int item = ((int)blockIdx.x - u.conv_blocks) * 64 + lane;
-        const bool live = item < update_head_items(u);
-        const int n_grad = update_head_items(u) - 1;
-        float* d = (q == 0 && live && item < n_grad) ? u.h.grad + item : nullptr;
-        const bool upd = d != nullptr && u.apply_adam;
-        const int64_t idx = upd ? (int64_t)(d - u.ad.grad) : -1;
-        AdamPre pre = adam_prefetch_state(u.ad, idx);
-        quarter[q][lane] = live ? update_head_sum(u, item, q, 4) : 0.0f;
-        __syncthreads();
-        pre.step_size = bias_scalars[0]; pre.sqrt_bc2 = bias_scalars[1];
-        if (q == 0 && live) {
-            const float g = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
-            if (d) {
-                *d = g;
-                if (upd) adam_apply(u.ad, idx, g, pre);
-            } else if (item == n_grad && u.h.loss) {
-                u.h.loss[0] = g;
-            }
+        } else if (!conv && live && item == n_grad && u.h.loss) {
+            u.h.loss[0] = g;
         }
     }
     // nobody reads step2[0] in this launch (Adam reads step2[1]): safe to commit it here

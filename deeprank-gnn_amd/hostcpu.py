@@ -56,8 +56,26 @@ def fit_torch_threads(force=False):
     _done = True
     if os.environ.get("OMP_NUM_THREADS") or os.environ.get("DRGNN_KEEP_TORCH_THREADS") == "1":
         return torch.get_num_threads()
-    local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    local_world = local_world_size()
     want = max(1, granted_cpus() // (2 * local_world))
-    if torch.get_num_threads() > want:
+    have = torch.get_num_threads()
+    if have > want:
         torch.set_num_threads(want)
+        # a process-wide side effect: say so once
+        import logging
+        logging.getLogger("deeprank_gnn_amd").info(
+            "torch intra-op pool %d -> %d threads (%d CPUs granted, %d rank(s) on this node); OMP_NUM_THREADS or "
+            "DRGNN_KEEP_TORCH_THREADS=1 keeps the pool", have, want, granted_cpus(), local_world)
     return torch.get_num_threads()
+
+
+def local_world_size():
+    """Ranks of this job on this node: torchrun's LOCAL_WORLD_SIZE, else what Open MPI / Slurm launchers export."""
+    for name in ("LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE"):
+        v = os.environ.get(name, "")
+        try:
+            if int(v.split("(")[0] or 0) > 0:
+                return int(v.split("(")[0])
+        except ValueError:
+            continue
+    return 1

@@ -167,6 +167,43 @@ def test_native_epoch_loop_under_data_parallel(cached):
     np.testing.assert_allclose(p[0], tr.flat_p.numpy(), rtol=1e-4, atol=1e-5)
 
 
+def _worker_epoch_chunked(rank, world, init_file, out_dir):
+    """ONE train_epoch call over five mini-batches with FusedTrainer.EPOCH_CHUNK = 2 (the native loop is entered three times)
+    and a ragged LAST global mini-batch (4, 4, 4, 4, 3 graphs): the exchange's n_local / n_global weight must take the
+    global size of mini-batch (piece offset + k) -- ADVICE r03."""
+    from emu_api import emu
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", init_method="file://" + init_file, rank=rank, world_size=world)
+    rs = ResidentGraphSet(_graphs(19), "cpu", api=emu())
+    tr = FusedTrainer(_make_net("sGAT"), lr=0.01, api=emu(), seed=5)
+    tr.EPOCH_CHUNK = 2
+    mine = [g for lo in range(0, 19, 4) for g in range(lo, min(lo + 4, 19))[2 * rank:2 * rank + 2]]
+    assert len(mine) == (10 if rank == 0 else 9)
+    tr.train_epoch(rs, mine, 2, dp_global_sizes=[4, 4, 4, 4, 3])
+    np.save(os.path.join(out_dir, "p%d.npy" % rank), tr.flat_p.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_native_epoch_under_data_parallel_weights_the_ragged_last_batch():
+    from emu_api import emu
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    emu()
+    with tempfile.TemporaryDirectory() as tmp:
+        init_file = os.path.join(tmp, "rendezvous")
+        mp.spawn(_worker_epoch_chunked, args=(2, init_file, tmp), nprocs=2, join=True)
+        p = [np.load(os.path.join(tmp, "p%d.npy" % r)) for r in range(2)]
+    np.testing.assert_array_equal(p[0], p[1])
+    graphs = _graphs(19)
+    tr = FusedTrainer(_make_net("sGAT"), lr=0.01, api=emu(), seed=5)
+    for lo in range(0, 19, 4):
+        tr.train_step(Batch.from_data_list(graphs[lo:lo + 4]))
+    np.testing.assert_allclose(p[0], tr.flat_p.numpy(), rtol=1e-4, atol=1e-5)
+
+
 def _worker_nn(rank, world, init_file, out_dir):
     from emu_api import emu
     from helpers import GOLDEN, NODE_FEATURES
