@@ -893,6 +893,10 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         }
         if (one_wg) { lds = lds1; L.words = lds / 4; blocks = (int)n_graphs; }
 #ifndef DRGNN_EMU
+        if (one_wg && af3) {      // both branches of a graph in one workgroup, from the tiles (net_step3_graph_both)
+            const int64_t lb = 4 * step3b_scratch_words(F, L.capN, L.capE, L.capC, hd->H, hd->O);
+            if (lb <= DRGNN_LDS_LIMIT) { lds = lb; L.words = lds / 4; } else af3 = false;
+        }
         else if (af3) { lds = 4 * step3_scratch_words(F, L.capN, L.capE, L.capC, hd->H, hd->O); L.words = lds / 4; }
 #endif
     } else if (af_split == 2) {
@@ -913,10 +917,11 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     // LDS layout is a compile-time constant (32-wide kernels; of the one-workgroup GINet layouts the paired form)
     bool cls = false;
 #ifndef DRGNN_EMU
-    if ((!one_wg || one_paired) && g_step_class_mode == 0 && L.capN <= STEP_CLS_N && L.capE <= STEP_CLS_E && L.capC <= STEP_CLS_C &&
+    if ((!one_wg || one_paired || af3) && g_step_class_mode == 0 && L.capN <= STEP_CLS_N && L.capE <= STEP_CLS_E && L.capC <= STEP_CLS_C &&
         step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32 &&
         step_variant(kind, x, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O) == 32) {
-        const int64_t lds_cls = one_wg ? step1_lds_bytes_form(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O, 1)
+        const int64_t lds_cls = (one_wg && af3) ? 4 * step3b_scratch_words(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
+                                : one_wg ? step1_lds_bytes_form(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O, 1)
                                 : af3 ? 4 * step3_scratch_words(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
                                 : af_split ? 4 * step2_scratch_words(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
                                        : step_lds_bytes(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->R, hd->H, hd->O);
@@ -928,7 +933,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     }
 #endif
     // a workspace built with DRGNN_TOPO_LEAN holds only what the aggregation-first training kernels read
-    if (hints && (hints->topo_flags & DRGNN_TOPO_LEAN) && !(af_split != 0 || (af3 && !one_wg))) return DRGNN_E_ARG;
+    if (hints && (hints->topo_flags & DRGNN_TOPO_LEAN) && !(af_split != 0 || af3)) return DRGNN_E_ARG;
     if (blocks > 0) {
 #ifdef DRGNN_EMU
         // workgroups run one after the other here: two passes (up to the readout exchange, then the
@@ -1068,10 +1073,30 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         hipLaunchKernelGGL((k_step3_co_topo<32, G, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),   \
                            (size_t)both, stream, C);                                                        \
     } while (0)
+#define DRGNN_STEP3B_LAUNCH(G, CL)                                                                            \
+    do {                                                                                                    \
+        static int lds_set_on = -1;                                                                                   \
+        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
+            if (hipFuncSetAttribute((const void*)k_step3b_co_topo<32, G, CL>,                                              \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
+                lds_set_on = step_current_device();                                                                   \
+            } else {                                                                                                  \
+                (void)hipGetLastError();                                                                              \
+                HIP_TRY(hipFuncSetAttribute((const void*)k_step3b_co_topo<32, G, CL>,                                      \
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
+            }                                                                                                         \
+        }                                                                                                             \
+        hipLaunchKernelGGL((k_step3b_co_topo<32, G, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),   \
+                           (size_t)both, stream, C);                                                        \
+    } while (0)
         if (af_split) {
             if (kind == DRGNN_SGAT) DRGNN_STEP2_LAUNCH_K(DRGNN_SGAT); else DRGNN_STEP2_LAUNCH_K(DRGNN_FOUT);
         } else
-        if (af3 && !one_wg) {
+        if (af3 && one_wg) {
+            if (cls) { if (gather_ids) DRGNN_STEP3B_LAUNCH(true, 1); else DRGNN_STEP3B_LAUNCH(false, 1); }
+            else { if (gather_ids) DRGNN_STEP3B_LAUNCH(true, 0); else DRGNN_STEP3B_LAUNCH(false, 0); }
+        } else
+        if (af3) {
             if (cls) { if (gather_ids) DRGNN_STEP3_LAUNCH(true, 1); else DRGNN_STEP3_LAUNCH(false, 1); }
             else { if (gather_ids) DRGNN_STEP3_LAUNCH(true, 0); else DRGNN_STEP3_LAUNCH(false, 0); }
         } else
@@ -1106,6 +1131,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
 #undef DRGNN_STEP2_LAUNCH
 #undef DRGNN_STEP2_LAUNCH_K
 #undef DRGNN_STEP3_LAUNCH
+#undef DRGNN_STEP3B_LAUNCH
         HIP_TRY(hipGetLastError());
 #endif
     }
@@ -1867,7 +1893,7 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
                              p->set->x != nullptr && ((((uintptr_t)p->set->x) & 15) == 0);
             const int32_t af = DRGNN_TOPO_HIER | DRGNN_TOPO_LEAN | DRGNN_TOPO_TILES;
             if (p->net->kind != DRGNN_GINET) r.flags = fam ? af : DRGNN_TOPO_HIER;
-            else if (fam && epoch_step_wgs(p, b, epoch_next_b(p, k), nullptr) == 2) r.flags = af;
+            else if (fam) r.flags = af;      // (both GINet layouts have an aggregation-first kernel: drgnn_step3.h)
             if (r.flags & DRGNN_TOPO_TILES) { r.tiles = u.tiles; r.n_feat = p->net->n_feat; }
         }
         return r;

@@ -496,6 +496,35 @@ DEV void step3_block(const StepLaunch& L, int blk, float* lds) {
 }
 #endif
 
+#ifndef DRGNN_EMU
+// GINet, aggregation first, both branches of a graph in one workgroup (drgnn_step3.h, net_step3_graph_both)
+template <int XF, bool GATHER, int CLS>
+DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
+    if (g >= L.a.n_graphs) return;
+    if (L.dims.count > 0) {
+        const int gi = GATHER ? L.dims.gi[g] : g;
+        GraphDims d;
+        d.n0 = L.dims.n0[g]; d.N = L.dims.n[g]; d.e0 = L.dims.e0[g]; d.E = L.dims.e[g];
+        d.rowbase = d.n0 + gi;
+        d.C = 0; d.E1 = 0; d.C1 = 0;
+        const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
+        net_step3_graph_both<XF, GATHER, CLS>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
+        return;
+    }
+    const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;
+    const GraphDims d = net_dims(L.a.tv, gi);
+    if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
+        // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
+        FOR_TID(c, L.a.hf.R) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + c] = DRGNN_NAN; }
+        float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+        FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+        FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
+        return;
+    }
+    net_step3_graph_both<XF, GATHER, CLS>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
+}
+#endif
+
 // ---- single-launch parameter update: reduce the conv + head partials and apply Adam --------
 struct UpdateArgs {
     ReduceArgs r;
@@ -671,6 +700,16 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3_co_topo(StepCoLaunch C
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
     if ((int)blockIdx.x < C.n_net) step3_block<XF, GATHER, CLS>(C.step, blockIdx.x, smem_s3);
     else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s3);
+}
+// ... its form with both branches of a graph in one workgroup (beyond the resident batch size)
+template <int XF, bool GATHER, int CLS>
+__global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3b_co_topo(StepCoLaunch C_by_value) {
+    extern __shared__ __attribute__((aligned(16))) float smem_s3b[];
+    PHASE_BEGIN();
+    const StepCoLaunch& C = step_kernarg();
+    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
+    if ((int)blockIdx.x < C.n_net) step3b_block<XF, GATHER, CLS>(C.step, blockIdx.x, smem_s3b);
+    else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s3b);
 }
 #ifdef DRGNN_KERNELS_MAIN
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }
@@ -851,5 +890,9 @@ extern template __global__ void k_step3_co_topo<32, false, 0>(StepCoLaunch);
 extern template __global__ void k_step3_co_topo<32, true, 0>(StepCoLaunch);
 extern template __global__ void k_step3_co_topo<32, false, 1>(StepCoLaunch);
 extern template __global__ void k_step3_co_topo<32, true, 1>(StepCoLaunch);
+extern template __global__ void k_step3b_co_topo<32, false, 0>(StepCoLaunch);
+extern template __global__ void k_step3b_co_topo<32, true, 0>(StepCoLaunch);
+extern template __global__ void k_step3b_co_topo<32, false, 1>(StepCoLaunch);
+extern template __global__ void k_step3b_co_topo<32, true, 1>(StepCoLaunch);
 #endif
 #endif  // !DRGNN_EMU

@@ -366,10 +366,13 @@ DEV void step2_head_fc1(const HeadFused& hf, int g, int half, const float* wb, c
     }
 }
 
-// ---- phase J: d readout = dhid W1, scattered through the depth-1 argmax of the OWN clusters into dZ2 (factor 1 / C1) ------
+// ---- phase J: d readout = dhid W1, scattered through the depth-1 argmax of the OWN clusters into dZ2 (factor 1 / C1), and
+// the weight / bias gradients of conv2, which are SPARSE sums (dZ2 is non-zero only in the rows that won a depth-1 cluster,
+// every entry of column c equal to v_c):   d[Wnbr ; Wself][f][c] = v_c sum_k [S | T][a1[k][c]][f],   db2[c] = v_c #winners.
+// 32 lanes per column: 8 float4 groups of the 32 [S | T] columns x 4 slices of the clusters (drgnn_step3.h has GINet's)
 template <int HC>
 DEV void step2_head_dreadout(const HeadFused& hf, const float* wb, const float* dhid, const short* a1, int nk, float inv,
-                             float* z2) {
+                             const float* st, float* z2, float* g_dw2, float* g_db2) {
     const int H = HC ? HC : hf.H;
     for (int t = threadIdx.x; t < DRGNN_H2 * 32; t += DRGNN_NTHREADS) {
         const int c = t >> 5, q = t & 31;
@@ -379,6 +382,25 @@ DEV void step2_head_dreadout(const HeadFused& hf, const float* wb, const float* 
         for (int k = q; k < nk; k += 32) {
             const int r = a1[k * DRGNN_H2 + c];
             if (r >= 0) z2[ROW24(r, STEP2_TSLD) + c] = v;
+        }
+        const int sl = q & 3, f4 = q >> 2;
+        drgnn_f4 sum = {0.f, 0.f, 0.f, 0.f};
+        float cnt = 0.0f;
+        for (int k = sl; k < nk; k += 4) {
+            const int r = a1[k * DRGNN_H2 + c];
+            if (r >= 0) {
+                const drgnn_f4 row = *(const drgnn_f4*)(st + ROW24(r, STEP2_TSLD) + 4 * f4);
+                sum[0] += row[0]; sum[1] += row[1]; sum[2] += row[2]; sum[3] += row[3];
+                cnt += 1.0f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sum[i] += dpp_take<0xB1>(sum[i]); sum[i] += dpp_take<0x4E>(sum[i]); }
+        cnt += dpp_take<0xB1>(cnt); cnt += dpp_take<0x4E>(cnt);
+        if (sl == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g_dw2[(4 * f4 + i) * DRGNN_H2 + c] = v * sum[i];
+            if (f4 == 0) g_db2[c] = v * cnt;
         }
     }
 }
@@ -419,12 +441,12 @@ DEV void step2_gemm_dst(int M, const float* dz, const float* wn, const int* cid,
     (void)dummy;
 }
 
-// ---- phase M: d xp_j = s_j dT_j + sum over CSC1 entries t of column j of c_t (d dS)_row(t), own pooled rows, scattered ----
-// straight through the depth-0 argmax (own rows) into dZ1
+// ---- phase M: d xp_j = s_j dT_j + sum over CSC1 entries t of column j of c_t (d dS)_row(t), own pooled rows: dense rows
+// dxp[q] (the weight gradients of conv1 read them through the depth-0 argmax, step2_dw1_sparse)
 template <int KIND, class IdxT>
 DEV void step2_pooled_gather_bwd(int n, const int* cid, int qbase, const int* cp, const IdxT* ridx, const IdxT* tslot,
                                  const float* w, const float* dv, const float* sc, const float* dsf, const float* dt,
-                                 const short* arg, float* dz) {
+                                 float* dxp) {
     const int items = ((n * 16) + 63) & ~63;
     for (int item = threadIdx.x; item < items; item += DRGNN_NTHREADS) {
         const int q = item >> 4, sl = (item >> 2) & 3, c = (item & 3) * 4;
@@ -445,13 +467,50 @@ DEV void step2_pooled_gather_bwd(int n, const int* cid, int qbase, const int* cp
             float sv = sc[q];
             if (KIND == DRGNN_FOUT && dv[q] == 0.0f) sv = 0.0f;      // its NaN row never won a max
             const drgnn_f4 d4 = *(const drgnn_f4*)(dt + q * STEP_XPLD + c);
-            const float acc[4] = {fmaf(sv, d4[0], a0), fmaf(sv, d4[1], a1), fmaf(sv, d4[2], a2), fmaf(sv, d4[3], a3)};
-            const drgnn_u2 packed = *(const drgnn_u2*)(arg + q * DRGNN_H1 + c);
-            const int m4[4] = {(short)(packed[0] & 0xffffu), (short)(packed[0] >> 16), (short)(packed[1] & 0xffffu), (short)(packed[1] >> 16)};
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if (m4[k] >= 0) dz[m4[k] * DRGNN_H1 + c + k] = acc[k];
+            *(drgnn_f4*)(dxp + q * STEP_XPLD + c) = drgnn_f4{fmaf(sv, d4[0], a0), fmaf(sv, d4[1], a1), fmaf(sv, d4[2], a2), fmaf(sv, d4[3], a3)};
         }
+    }
+}
+// ---- phase N: the weight / bias gradients of conv1 through the depth-0 argmax (dZ1 is non-zero only in the rows p = a0[q][h]
+// that won a depth-0 cluster):  dWn[f][h] = sum_q D_p dxp[q][h] S[p][f],  dWs[f][h] = sum_q C_p dxp[q][h] X[p][f],
+// db1[h] = sum_q dxp[q][h].  Wave = channel h; in a wave 8 feature chunks (float4) x 8 slices of the own pooled rows
+template <int XF>
+DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float* G, const float* xs, const float* dv,
+                          const float* sc, float* g_dwn, float* g_dws, float* g_db1, int F) {
+    static_assert(XF == 32, "16 waves x 64 lanes = 16 channels x 8 chunks x 8 slices");
+    constexpr int XLD = XF + 4;
+    const int h = threadIdx.x >> 6, fc = (threadIdx.x >> 3) & 7, sl = threadIdx.x & 7;
+    drgnn_f4 an = {0.f, 0.f, 0.f, 0.f}, as = {0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.0f;
+    for (int q = sl; q < Ch; q += 16) {      // two pooled rows per trip in flight
+        int arg[2];
+        float d[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int qq = q + 8 * u;
+            arg[u] = (qq < Ch) ? (int)a0[qq * DRGNN_H1 + h] : -1;
+            d[u] = (qq < Ch) ? dxp[qq * STEP_XPLD + h] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (arg[u] >= 0) {
+                const float dn = d[u] * dv[arg[u]], ds = d[u] * sc[arg[u]];
+                const drgnn_f4 g = *(const drgnn_f4*)(G + ROW24(arg[u], XLD) + 4 * fc);
+                const drgnn_f4 x = *(const drgnn_f4*)(xs + ROW24(arg[u], XLD) + 4 * fc);
+                an[0] = fmaf(dn, g[0], an[0]); an[1] = fmaf(dn, g[1], an[1]); an[2] = fmaf(dn, g[2], an[2]); an[3] = fmaf(dn, g[3], an[3]);
+                as[0] = fmaf(ds, x[0], as[0]); as[1] = fmaf(ds, x[1], as[1]); as[2] = fmaf(ds, x[2], as[2]); as[3] = fmaf(ds, x[3], as[3]);
+                bsum += d[u];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { an[i] = lanes8_sum(an[i]); as[i] = lanes8_sum(as[i]); }
+    bsum = lanes8_sum(bsum);
+    if (sl == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * fc + i < F) { g_dwn[(4 * fc + i) * DRGNN_H1 + h] = an[i]; g_dws[(4 * fc + i) * DRGNN_H1 + h] = as[i]; }
+        if (fc == 0) g_db1[h] = bsum;
     }
 }
 
@@ -711,7 +770,6 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     // ---- E: [S | T] of the own pooled rows ---------------------------------------------------------------------------------
     PH(5) step2_pooled_gather<KIND, EIdx>(Ch, s.cid, qbase, s.rp1, (const EIdx*)s.cx1, s.ew1, s.dv1, s.sc1, s.xp, s.u2);
     FOR_TID(e, (step_pad4(Ch) - Ch) * STEP2_TSLD) { s.u2[Ch * STEP2_TSLD + e] = 0.0f; }
-    FOR_TID(item, step_pad4(Nh) * DRGNN_H1) { s.z1[item] = 0.0f; }      // Z1 is consumed: becomes dZ1 (+ zero K padding)
     BARRIER();
     EXIT_AFTER(6);
     // ---- F: Z2 = relu([S | T] [Wnbr ; Wself] + b) ---------------------------------------------------------------------------
@@ -744,49 +802,35 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     PH(9) step_head_loss<WREF, true>(hf, g, half, s.hid, s.hw2, s.hb2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
     BARRIER();
     EXIT_AFTER(10);
-    PH(10) step2_head_dreadout<WREF>(hf, s.wb, s.dhid, s.a1, Kh, inv_c1, s.z2);
-    BARRIER();
-    EXIT_AFTER(11);
-
-    // ---- backward body -----------------------------------------------------------------------------------------------------
     float* part_w = a.partials + ((long)g * SPLIT + half) * a.n_partial;
     float* p_w1n = part_w;
     float* p_b1 = p_w1n + 2L * F * DRGNN_H1;
     float* p_w2n = p_b1 + DRGNN_H1;
     float* p_b2 = p_w2n + 2 * DRGNN_H1 * DRGNN_H2;
-    const int gp_units = step_gp_words(WREF) / 256;
-    const int KS2 = imin(DRGNN_NWAVES / 4, gp_units / 4);
-    // ---- K: d[S | T] (dS published, pre-multiplied by d_i), partial tiles of dWc2, column sums of dZ2 -----------------------
+    // ---- J: d readout -> dZ2, d[Wnbr ; Wself] and db2 (sparse sums) -------------------------------------------------------------
+    PH(10) step2_head_dreadout<WREF>(hf, s.wb, s.dhid, s.a1, Kh, inv_c1, s.u2, s.z2, p_w2n, p_b2);
+    BARRIER();
+    EXIT_AFTER(11);
+
+    // ---- backward body -----------------------------------------------------------------------------------------------------
+    // ---- K: d[S | T] (dS published, pre-multiplied by d_i) ---------------------------------------------------------------------
     PH(11) step2_gemm_dst(Ch, s.z2, s.wc2n, s.cid, qbase, s.dv1, s.dsf, s.dt, (SPLIT == 2) ? x_ds_own : nullptr, tag, dummy);
-    PH(12) step_gemm_tn(2, 2, Ch, s.u2, STEP2_TSLD, s.z2, STEP2_TSLD, KS2, s.gp, p_w2n, DRGNN_H2, 2 * DRGNN_H1, 1);
-    step_colsum_partial<DRGNN_H2, STEP2_TSLD>(Ch, s.z2, s.bsum);
     if (SPLIT == 2) { w_first = ((int)threadIdx.x < Co * DRGNN_H1) ? xchg_peek(x_ds_oth + threadIdx.x) : 0ull; }
     BARRIER();
     EXIT_AFTER(12);
-    // ---- L: dWc2 / db2 to the slab; the partner's d dS ------------------------------------------------------------------------
-    PH(12) step_gemm_tn(2, 2, Ch, s.u2, STEP2_TSLD, s.z2, STEP2_TSLD, KS2, s.gp, p_w2n, DRGNN_H2, 2 * DRGNN_H1, 2);
-    step_colsum_finish<DRGNN_H2>(s.bsum, p_b2);
-    if (SPLIT == 2) { PH(4) step2_receive(Co, s.cid, qbase_o, x_ds_oth, w_first, tag, fault, s.dsf); }
-    BARRIER();
+    if (SPLIT == 2) {
+        // ---- L: the partner's d dS ---------------------------------------------------------------------------------------------
+        PH(4) step2_receive(Co, s.cid, qbase_o, x_ds_oth, w_first, tag, fault, s.dsf);
+        BARRIER();
+    }
     EXIT_AFTER(13);
-    // ---- M: d xp of the own pooled rows, scattered through the depth-0 argmax into dZ1 ------------------------------------
+    // ---- M: d xp of the own pooled rows (dense rows; xp's own rows are dead: kept apart in u2's place? no -- in dt's rows) ----
     PH(13) step2_pooled_gather_bwd<KIND, EIdx>(Ch, s.cid, qbase, s.cp1, (const EIdx*)s.rx1, (const EIdx*)s.ts1, s.ew1, s.dv1, s.sc1,
-                                               s.dsf, s.dt, s.a0, s.z1);
+                                               s.dsf, s.dt, s.z2);
     BARRIER();
     EXIT_AFTER(14);
-    // ---- N: [dWn ; dWs] = [G | X]^T [dZ1 | s dZ1], db1 -----------------------------------------------------------------------
-    {
-        constexpr int MT = XF / 16;
-        int KS = imin(DRGNN_NWAVES / (2 * MT), gp_units / (2 * MT));
-        if (KS < 1) KS = 1;
-        KS = 1 << (31 - __builtin_clz((unsigned)KS));
-        PH(16) step2_gemm_dw1<XF>(Nh, nmax, s.G, s.xs, s.dv0, s.sc0, s.z1, KS, s.gp, p_w1n, F * DRGNN_H1, F, 1);
-        step_colsum_partial<DRGNN_H1>(Nh, s.z1, s.bsum);
-        BARRIER();
-        EXIT_AFTER(15);
-        PH(16) step2_gemm_dw1<XF>(Nh, nmax, s.G, s.xs, s.dv0, s.sc0, s.z1, KS, s.gp, p_w1n, F * DRGNN_H1, F, 2);
-        step_colsum_finish<DRGNN_H1>(s.bsum, p_b1);
-    }
+    // ---- N: dWn, dWs, db1 through the depth-0 argmax ------------------------------------------------------------------------------
+    PH(16) step2_dw1_sparse<XF>(Ch, s.a0, s.z2, s.G, s.xs, s.dv0, s.sc0, p_w1n, p_w1n + (long)F * DRGNN_H1, p_b1, F);
 }
 
 #endif  // !DRGNN_EMU

@@ -22,6 +22,7 @@
 #define DRGNN_STEP3_H
 
 #include "drgnn_step2.h"
+#include <type_traits>
 
 #ifndef DRGNN_EMU
 struct Step3Scratch {
@@ -119,6 +120,100 @@ DEV void step3_cluster_max(int nc, const int* hmp, const int* cid, const float* 
         if (arg < 0) best = 0.0f;
         xp[ROW24(j, STEP_XPLD) + c] = best;
         a0[j * DRGNN_H1 + c] = (short)((best > 0.0f) ? arg : -1);
+    }
+}
+
+// ---- sparse weight gradients -----------------------------------------------------------------------------------------------
+// The gradients that reach a convolution through a max-pool are SPARSE: dZ2 is non-zero only in the rows that won a depth-1
+// cluster (C1 x 32 entries of C x 32, all of a column equal to that column's d readout), dZ1 only in the rows that won a
+// depth-0 cluster (C x 16 of N x 16).  The weight gradients are therefore short sums of gathered operand rows,
+//      dW2[f][c] = v_c  sum_k S2[a1[k][c]][f]              dW1[f][h] = sum_j dXP[j][h] G[a0[j][h]][f]
+// formed by lane groups in registers and stored at once -- no dense K = rows product, no partial tiles through LDS, no
+// barrier of their own, no zeroed dZ1 array and no scatter into it (skip-phase builds: dW2 0.74 us, dW1 1.31 us as products).
+// d readout (this branch's 32 columns) scattered through the depth-1 argmax into dZ2 (for dS) + dW2; 32 lanes per column:
+// 4 float4 groups of the 16 S2 columns x 8 slices of the clusters
+template <int HC>
+DEV void step3_dreadout_dw2(const float* wb, const float* dhid, const short* a1, int C1, const float* s2, float* z2,
+                            float* g_dw2) {
+    const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
+    for (int t = threadIdx.x; t < DRGNN_H2 * 32; t += DRGNN_NTHREADS) {
+        const int c = t >> 5, q = t & 31;
+        float acc = 0.0f;
+#pragma unroll
+        for (int h = q; h < HC; h += 32) acc = fmaf(dhid[h], wb[h * STEP_WBLD + c], acc);
+        const float v = lanes32_sum(acc) * inv;
+        for (int k = q; k < C1; k += 32) {
+            const int r = a1[k * DRGNN_H2 + c];
+            if (r >= 0) z2[ROW24(r, STEP3_Z2LD) + c] = v;
+        }
+        const int sl = q & 7, f4 = q >> 3;
+        drgnn_f4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int k = sl; k < C1; k += 8) {
+            const int r = a1[k * DRGNN_H2 + c];
+            if (r >= 0) {
+                const drgnn_f4 row = *(const drgnn_f4*)(s2 + ROW24(r, STEP_XPLD) + 4 * f4);
+                sum[0] += row[0]; sum[1] += row[1]; sum[2] += row[2]; sum[3] += row[3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sum[i] = lanes8_sum(sum[i]);
+        if (sl == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g_dw2[(4 * f4 + i) * DRGNN_H2 + c] = v * sum[i];
+        }
+    }
+}
+// dXP[j][0:16] = sum over the CSC1 column of j of dS rows (dense rows of LD floats; 16 lanes per pooled node as step_gather_rows)
+template <int LD>
+DEV void step3_gather_dxp(int n, const int* cp, const int* ridx, const float* src, float* dst) {
+    const int items = ((n * 16) + 63) & ~63;
+    for (int item = threadIdx.x; item < items; item += DRGNN_NTHREADS) {
+        const int j = item >> 4, sl = (item >> 2) & 3, c = (item & 3) * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (j < n) {
+            const int lo = cp[j], hi = cp[j + 1];
+            for (int t = lo + sl; t < hi; t += 4) {
+                const drgnn_f4 v = *(const drgnn_f4*)(src + ROW24(ridx[t], LD) + c);
+                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            }
+        }
+        a0 += dpp_take<0x128>(a0); a1 += dpp_take<0x128>(a1); a2 += dpp_take<0x128>(a2); a3 += dpp_take<0x128>(a3);
+        a0 += dpp_take<0x124>(a0); a1 += dpp_take<0x124>(a1); a2 += dpp_take<0x124>(a2); a3 += dpp_take<0x124>(a3);
+        if (sl == 0 && j < n) *(drgnn_f4*)(dst + j * LD + c) = drgnn_f4{a0, a1, a2, a3};
+    }
+}
+// dW1[f][h] = sum over the pooled nodes j of dXP[j][h] G[a0[j][h]][f].  Wave = channel h; in a wave 8 feature chunks (float4) x
+// 8 slices of the pooled nodes (consecutive lanes: the slice sums meet in DPP adds)
+template <int XF>
+DEV void step3_dw1_sparse(int C, const short* a0, const float* dxp, const float* G, float* g_dw1, int F) {
+    static_assert(XF == 32, "16 waves x 64 lanes = 16 channels x 8 chunks x 8 slices");
+    constexpr int XLD = XF + 4;
+    const int h = threadIdx.x >> 6, fc = (threadIdx.x >> 3) & 7, sl = threadIdx.x & 7;
+    drgnn_f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j = sl; j < C; j += 32) {      // four pooled nodes per trip in flight
+        int arg[4];
+        float d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int jj = j + 8 * u;
+            arg[u] = (jj < C) ? (int)a0[jj * DRGNN_H1 + h] : -1;
+            d[u] = (jj < C) ? dxp[jj * STEP_XPLD + h] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (arg[u] >= 0) {
+                const drgnn_f4 g = *(const drgnn_f4*)(G + ROW24(arg[u], XLD) + 4 * fc);
+                acc[0] = fmaf(d[u], g[0], acc[0]); acc[1] = fmaf(d[u], g[1], acc[1]);
+                acc[2] = fmaf(d[u], g[2], acc[2]); acc[3] = fmaf(d[u], g[3], acc[3]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = lanes8_sum(acc[i]);
+    if (sl == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (4 * fc + i < F) g_dw1[(4 * fc + i) * DRGNN_H1 + h] = acc[i];
     }
 }
 
@@ -251,7 +346,6 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     // ---- E: S = A1 XP (16-wide gather of pooled rows) -----------------------------------------------------------------------
     PH(4) step_gather_rows<STEP_XPLD, int>(d.C, s.rp1, s.cx1, s.xp, s.u2);
     FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.u2[d.C * STEP_XPLD + e] = 0.0f; }
-    FOR_TID(item, step_pad4(d.N) * DRGNN_H1) { s.z1[item] = 0.0f; }      // Z1 is consumed: becomes dZ1 (+ zero K padding)
     BARRIER();
     EXIT_AFTER(5);
     // ---- F: Z2 = relu(S W2) ---------------------------------------------------------------------------------------------------
@@ -283,40 +377,316 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     PH(9) step_head_loss<WREF, true>(hf, g, br, s.hid, s.hw2, s.hb2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
     BARRIER();
     EXIT_AFTER(10);
-    PH(10) step_head_dreadout<WREF, true>(hf, s.wb, s.dhid, s.a1, d.C1, s.z2, Z2LD);
+    float* part_w = a.partials + ((long)g * nb + br) * a.n_partial;
+    float* p_w1n = part_w;
+    float* p_w2n = p_w1n + 2L * F * DRGNN_H1 + DRGNN_H1;
+    // d readout scattered into dZ2 + dW2 (sparse: see step3_dreadout_dw2)
+    PH(10) step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1, d.C1, s.u2, s.z2, p_w2n);
     BARRIER();
     EXIT_AFTER(11);
 
     // ---- backward body -----------------------------------------------------------------------------------------------------
-    float* part_w = a.partials + ((long)g * nb + br) * a.n_partial;
-    float* p_w1n = part_w;
-    float* p_w2n = p_w1n + 2L * F * DRGNN_H1 + DRGNN_H1;
-    const int gp_units = step_gp_words(WREF) / 256;
-#ifdef DRGNN_STEP3_KS2
-    const int KS2 = DRGNN_STEP3_KS2;
-#else
-    const int KS2 = imin(DRGNN_NWAVES / 2, gp_units / 2);
-#endif
-    // dS = dZ2 W2^T (rows of STEP_XPLD floats);  dW2 = S^T dZ2 (K = pooled nodes): partial tiles here, their sum behind the barrier
+    // dS = dZ2 W2^T (rows of STEP_XPLD floats)
     PH(11) step_gemm_nn(d.C, 1, DRGNN_H2, s.z2, Z2LD, s.w2n, W2NLD, s.p2, STEP_XPLD, dummy);
-    PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1, 1);
     BARRIER();
     EXIT_AFTER(12);
-    PH(12) step_gemm_tn(1, 2, d.C, s.u2, STEP_XPLD, s.z2, Z2LD, KS2, s.gp, p_w2n, DRGNN_H2, DRGNN_H1, 2);
-    // dXP = A1^T dS, scattered through the depth-0 argmax (row positions) into dZ1
-    PH(13) step_gather_scatter<STEP_XPLD, int>(d.C, s.cp1, s.rx1, s.p2, s.a0, s.z1);
+    // dXP = A1^T dS (dense rows; xp is dead)
+    PH(13) step3_gather_dxp<STEP_XPLD>(d.C, s.cp1, s.rx1, s.p2, s.xp);
     BARRIER();
     EXIT_AFTER(14);
-    {   // dW1 = G^T dZ1: K = node rows, split in slices over the waves
-        constexpr int MT = XF / 16;
-        int KS = imin(DRGNN_NWAVES / MT, gp_units / MT);
-        if (KS < 1) KS = 1;
-#ifdef DRGNN_STEP3_KS1
-        KS = DRGNN_STEP3_KS1;
+    // dW1 through the depth-0 argmax (sparse)
+    PH(16) step3_dw1_sparse<XF>(d.C, s.a0, s.xp, s.G, p_w1n, F);
+}
+
+
+// =========================================================================================================================
+// The same step with BOTH branches of a graph in ONE workgroup, one after the other: the launch layout beyond the resident
+// batch size (2 B + builder workgroups > CUs), where a workgroup must never wait for a partner (drgnn_step1.h's role for the
+// product-first kernels).  The branches convolve over the same edge_index (ginet.py:101-128), so G = A X -- the S rows of the
+// tiles -- is SHARED: loaded once, multiplied with either branch's W1, and the K operand of both dW1.  Per-branch state kept
+// from the forward to the backward: the argmax of both depths, S2 = A1 XP (dW2's operand) and dZ2; Z1 / XP / dS are
+// reused.  fc1's column block of branch 0 sits in LDS, branch 1's in registers until branch 0's d readout is done.
+// 25 barrier-separated phases, 101 KB of LDS at SYN size.
+struct Step3BScratch {
+    float* misc; float* xr; float* hid; float* dhid; float* hb1; float* wb;
+    float* w1t[2]; float* w2t[2]; float* w2n[2];
+    int* hmp;
+    int* rp1; int* cx1; int* cp1; int* rx1; int* mp1; int* mem1;
+    short* a0[2]; short* a1[2];
+    float* G; float* z1;
+    float* xp; float* u2[2]; float* z2[2]; float* p2;
+    float* hw2; float* hb2;
+    float* end; float* gp;
+};
+#define STEP3B_CARVE_LIST(X)                                                                   \
+    X(misc, 128)                                                                               \
+    X(xr, 2 * DRGNN_H2)                                                                        \
+    X(hid, H)                                                                                  \
+    X(dhid, H)                                                                                 \
+    X(hb1, H)                                                                                  \
+    X(wb, step_gp_words((int)H))                                                               \
+    X(w1t[0], DRGNN_H1 * xld)                                                                  \
+    X(w1t[1], DRGNN_H1 * xld)                                                                  \
+    X(w2t[0], DRGNN_H2 * STEP_XPLD)                                                            \
+    X(w2t[1], DRGNN_H2 * STEP_XPLD)                                                            \
+    X(w2n[0], DRGNN_H1 * (DRGNN_H2 + 4))                                                       \
+    X(w2n[1], DRGNN_H1 * (DRGNN_H2 + 4))                                                       \
+    X(hmp, capC + 1)                                                                           \
+    X(rp1, capC + 1)                                                                           \
+    X(cx1, capE)                                                                               \
+    X(cp1, capC + 1)                                                                           \
+    X(rx1, capE)                                                                               \
+    X(mp1, capC + 1)                                                                           \
+    X(mem1, capC)                                                                              \
+    X(a0[0], ((long)capC * DRGNN_H1 + 1) / 2)                                                  \
+    X(a0[1], ((long)capC * DRGNN_H1 + 1) / 2)                                                  \
+    X(a1[0], ((long)capC * DRGNN_H2 + 1) / 2)                                                  \
+    X(a1[1], ((long)capC * DRGNN_H2 + 1) / 2)                                                  \
+    X(G, (long)(capN + 4) * xld)                                                               \
+    X(z1, (long)(capN + 4) * DRGNN_H1)                                                         \
+    X(xp, (long)(capC + 4) * STEP_XPLD)                                                        \
+    X(u2[0], (long)(capC + 4) * STEP_XPLD)                                                     \
+    X(u2[1], (long)(capC + 4) * STEP_XPLD)                                                     \
+    X(z2[0], (long)(capC + 4) * STEP3_Z2LD)                                                    \
+    X(z2[1], (long)(capC + 4) * STEP3_Z2LD)                                                    \
+    X(p2, (long)(capC + 4) * STEP_XPLD)                                                        \
+    X(hw2, (long)O * H)                                                                        \
+    X(hb2, O)
+#endif  // !DRGNN_EMU
+
+HD int64_t step3b_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O) {
+    const int64_t xld = step_pad16((int)F) + 4;
+    int64_t w = 0;
+#ifndef DRGNN_EMU
+#define X(name, words) w += (((int64_t)(words) + 3) & ~(int64_t)3);
+    STEP3B_CARVE_LIST(X)
+#undef X
+#else
+    (void)xld; (void)capN; (void)capE; (void)capC; (void)H; (void)O;
+    w = (int64_t)1 << 40;
 #endif
-        PH(16) step_gemm_tn(MT, 1, d.N, s.G, XLD, s.z1, DRGNN_H1, KS, s.gp, p_w1n, DRGNN_H1, F);
+    return w + 16;
+}
+
+#ifndef DRGNN_EMU
+template <int CLS>
+DEV Step3BScratch step3b_carve(float* base, int F, int capN, int capE, int capC, int H, int O) {
+    const int xld = step_pad16(F) + 4;
+    Step3BScratch s;
+    int o = 0;
+#define X(name, words)                                                                          \
+    { int off = o; if (CLS == 0) { STEP_PIN(off); }                                             \
+      s.name = (typename std::remove_reference<decltype(s.name)>::type)(base + off);            \
+      o = off + (int)(((long)(words) + 3) & ~3L); }
+    STEP3B_CARVE_LIST(X)
+#undef X
+    s.end = base + o;
+    s.gp = s.wb;
+    return s;
+}
+
+// hid = dropout(relu(b1 + W1[:, 0:32] readout_0 + W1[:, 32:64] readout_1)): branch 0's column block from LDS, branch 1's from
+// registers (the lane's float4 of its hidden unit's row, step_wblock_load's layout); 8 lanes per hidden unit
+template <int HC>
+DEV void step3b_head_fc1(const HeadFused& hf, int g, const float* wb, const WBlockRegs<1>& w1r, const float* b1, const float* xr,
+                         float* hid, uint32_t step, uint32_t thresh, float keep_scale) {
+    static_assert(HC * 8 <= DRGNN_NTHREADS, "one pass: 8 lanes per hidden unit");
+    if ((int)(threadIdx.x & ~63u) >= HC * 8) return;
+    const int t = threadIdx.x, h = t >> 3, q = t & 7;
+    const drgnn_f4 w0 = *(const drgnn_f4*)(wb + h * STEP_WBLD + 4 * q);
+    const drgnn_f4 x0 = *(const drgnn_f4*)(xr + 4 * q), x1 = *(const drgnn_f4*)(xr + DRGNN_H2 + 4 * q);
+    const drgnn_f4 w1 = w1r.v[0];
+    float p0 = fmaf(w0[0], x0[0], fmaf(w0[1], x0[1], fmaf(w0[2], x0[2], w0[3] * x0[3])));
+    float p1 = fmaf(w1[0], x1[0], fmaf(w1[1], x1[1], fmaf(w1[2], x1[2], w1[3] * x1[3])));
+    p0 = lanes8_sum(p0);
+    p1 = lanes8_sum(p1);
+    if (q == 0) {
+        float v = (p0 + p1) + b1[h];
+        v = v > 0.0f ? v : 0.0f;
+        if (thresh) v = drgnn_keep(hf, step, g, HC, h, thresh) ? v * keep_scale : 0.0f;
+        hid[h] = v;
     }
 }
 
+template <int XF, bool GATHER, int CLS>
+DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, int gi, float* scratch, int capN, int capE,
+                              int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1) {
+    static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
+    if (CLS == 1) { capN = STEP_CLS_N; capE = STEP_CLS_E; capC = STEP_CLS_C; }
+    GraphDims d = d_in;
+    const int bC = late ? imin(d.N, capC) : d.C, bE1 = late ? d.E : d.E1, bC1 = late ? imin(d.N, capC) : d.C1;
+    const TopoView& tv = a.tv;
+    const HeadFused& hf = a.hf;
+    constexpr int nb = 2, R = 2 * DRGNN_H2, WREF = 128;
+    constexpr int XLD = XF + 4, Z2LD = STEP3_Z2LD, W2NLD = DRGNN_H2 + 4;
+    const int F = a.net.n_feat;
+    const int O = hf.O;
+    Step3BScratch s = step3b_carve<CLS>(scratch, XF, capN, capE, capC, WREF, O);
+    WBlockRegs<1> wreg, wother;
+    int* const dummy = (int*)(s.misc + 64);
+    const uint32_t done = (uint32_t)a.step2[0];
+    const uint32_t tag = done + 1u;
+
+    // ---- prologue ----------------------------------------------------------------------------------------------------------
+    PHASE_MARK();
+    const float* sgl = a.tiles + (long)d.n0 * F;
+    BurstX<4> bx;
+    BurstRowMap<4> brow;
+    BurstW<1> bw1[2], bw2[2];
+    WaveStage wst;
+    const int my_wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    auto stage_job = [&](int w) -> StageJob {
+        const int32_t* const* P = tv.p;
+        StageJob j = {nullptr, 0, nullptr, 0};
+        switch (w) {
+        case 0: j = StageJob{P[DRGNN_TI_HMP0] + d.rowbase, bC + 1, s.hmp, 0}; break;
+        case 1: j = StageJob{P[DRGNN_TI_MEM1] + d.n0, bC, s.mem1, 0}; break;
+        case 2: j = StageJob{P[DRGNN_TI_MPTR1] + d.rowbase, bC1 + 1, s.mp1, 0}; break;
+        case 3: j = StageJob{hf.b1, WREF, s.hb1, 0}; break;
+        case 4: j = stage_half(StageJob{hf.w2, O * WREF, s.hw2, 0}, 0); break;
+        case 5: j = stage_half(StageJob{hf.w2, O * WREF, s.hw2, 0}, 1); break;
+        case 6: j = StageJob{hf.b2, O, s.hb2, 0}; break;
+        case 7: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
+        case 8: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 0); break;
+        case 9: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 1); break;
+        case 10: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+        case 11: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
+        case 12: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
+        default: break;
+        }
+        return j;
+    };
+    {
+        const int32_t* const* P = tv.p;
+        asm volatile("" :: "s"(P[DRGNN_TI_IHORD]), "s"(P[DRGNN_TI_HMP0]), "s"(P[DRGNN_TI_MEM1]), "s"(P[DRGNN_TI_MPTR1]));
+        asm volatile("" :: "s"(P[DRGNN_TI_ROWPTR1]), "s"(P[DRGNN_TI_COL1]), "s"(P[DRGNN_TI_COLPTR1]), "s"(P[DRGNN_TI_ROWIDX1]));
+    }
+    int m_bad = 0, m_y = 0;
+    float m_wy = 1.0f, m_denom = 1.0f;
+    if (my_wave == 0) {
+        m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
+        if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
+            m_y = __builtin_nontemporal_load((const int*)hf.y_reg + gi);
+        } else {
+            m_y = (int)hf.y_cls[gi];
+            m_wy = hf.class_w ? hf.class_w[m_y] : 1.0f;
+            m_denom = (float)hf.B;
+            if (hf.class_w && threadIdx.x < 64) {
+                float part_sum = 0.0f;
+                for (int q = threadIdx.x; q < hf.B; q += 64) part_sum += hf.class_w[hf.y_cls[GATHER ? a.gather_ids[q] : q]];
+                m_denom = lanes64_sum(part_sum);
+            }
+            m_y = __builtin_amdgcn_readfirstlane(m_y);
+            m_wy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m_wy)));
+            m_bad = __builtin_amdgcn_readfirstlane(m_bad);
+        }
+    }
+    burst_load_x(bx, sgl, d.N, F);
+    burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        const drgnn_conv_params& c1 = a.net.conv1[br];
+        const drgnn_conv_params& c2 = a.net.conv2[br];
+        burst_load_w(bw1[br], c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
+        burst_load_w(bw2[br], c2.w_nbr, c2.nbr_sk, c2.nbr_sh, DRGNN_H1, DRGNN_H2);
+    }
+    wstage_load(wst, stage_job(my_wave));
+    step_wblock_load(wreg, hf, 0);
+    step_wblock_load(wother, hf, 1);
+    burst_store_x4_rows(bx, brow, s.G, XLD);
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        burst_store_wt(bw1[br], s.w1t[br], XLD);
+        burst_store_wt(bw2[br], s.w2t[br], STEP_XPLD);
+        burst_store_w(bw2[br], s.w2n[br], W2NLD);
+    }
+    step_wblock_store(wreg, hf, 0, s.wb);
+    wstage_store(wst);
+    FOR_TID(e, (step_pad4(d.N) - d.N) * XLD) { s.G[d.N * XLD + e] = 0.0f; }
+    if (XF > F) {
+        const int padc = XF - F;
+        FOR_TID(e, d.N * padc) { s.G[(e / padc) * XLD + F + e % padc] = 0.0f; }
+        FOR_TID(e, DRGNN_H1 * padc) { s.w1t[0][(e / padc) * XLD + F + e % padc] = 0.0f; s.w1t[1][(e / padc) * XLD + F + e % padc] = 0.0f; }
+    }
+    BARRIER();
+    if (late) { d.C = WG_UNIFORM(cnt_c); d.E1 = WG_UNIFORM(cnt_e1); d.C1 = WG_UNIFORM(cnt_c1); }
+    if (d.C > capC || d.E1 > d.E || d.C1 > capC) {      // malformed input (flagged by the builder): stay inside LDS, poison
+        d.C = imin(d.C, capC); d.E1 = imin(d.E1, d.E); d.C1 = imin(d.C1, capC);
+        m_bad |= 1;
+    }
+    FOR_TID(i, 1) {
+        ((int*)s.misc)[STEP_M_BAD] = m_bad;
+        ((int*)s.misc)[STEP_M_Y] = m_y;
+        s.misc[STEP_M_WY] = m_wy;
+        s.misc[STEP_M_DENOM] = m_denom;
+    }
+    FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
+
+    // ---- forward, branch after branch (misc is read in the readout phases: four barriers away) -------------------------------
+    // (the per-branch arrays are picked by selects on constant indices: a run-time index into the struct's pointer arrays
+    // would put them in scratch memory)
+#pragma unroll 1
+    for (int br = 0; br < 2; ++br) {
+        const bool b1 = br != 0;
+        float* const w1t = b1 ? s.w1t[1] : s.w1t[0];
+        float* const w2t = b1 ? s.w2t[1] : s.w2t[0];
+        float* const u2 = b1 ? s.u2[1] : s.u2[0];
+        float* const z2 = b1 ? s.z2[1] : s.z2[0];
+        short* const a0 = b1 ? s.a0[1] : s.a0[0];
+        short* const a1 = b1 ? s.a1[1] : s.a1[0];
+        step_gemm_nn<true>(d.N, 1, XF, s.G, XLD, w1t, XLD, s.z1, DRGNN_H1, dummy);
+        BARRIER();
+        step3_cluster_max(d.C, s.hmp, s.mem1, s.z1, s.xp, a0);
+        BARRIER();
+        step_gather_rows<STEP_XPLD, int>(d.C, s.rp1, s.cx1, s.xp, u2);
+        FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { u2[d.C * STEP_XPLD + e] = 0.0f; }
+        BARRIER();
+        step_gemm_nn<true>(d.C, 2, DRGNN_H1, u2, STEP_XPLD, w2t, STEP_XPLD, z2, Z2LD, dummy);
+        BARRIER();
+        step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, z2, a1, s.misc, s.xr + br * DRGNN_H2,
+                                const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2);
+        BARRIER();
+    }
+
+    // ---- FC head + loss + their backward -----------------------------------------------------------------------------------
+    const float keep_scale = (hf.p_drop > 0.0f) ? 1.0f / (1.0f - hf.p_drop) : 1.0f;
+    const double pt = (double)hf.p_drop * 4294967296.0;
+    const uint32_t thresh = (hf.p_drop > 0.0f) ? (uint32_t)(pt > 4294967295.0 ? 4294967295.0 : pt) : 0u;
+    float* hp = hf.partials + (long)g * head_compact_floats(R, WREF, O);
+    float* p_dhid = hp;
+    float* p_hw2 = p_dhid + WREF;
+    float* p_hb2 = p_hw2 + (long)O * WREF;
+    float* p_loss = p_hb2 + O;
+    if (g == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+    FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[0][item] = 0.0f; s.z2[1][item] = 0.0f; }      // become dZ2 (+ zero K padding)
+    step3b_head_fc1<WREF>(hf, g, s.wb, wother, s.hb1, s.xr, s.hid, done, thresh, keep_scale);
+    BARRIER();
+    step_head_loss<WREF, true>(hf, g, 0, s.hid, s.hw2, s.hb2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    BARRIER();
+    // d readout scattered into dZ2 + dW2 (sparse sums: step3_dreadout_dw2), branch after branch
+    float* const p_w1n0 = a.partials + ((long)g * nb) * a.n_partial;
+    float* const p_w1n1 = p_w1n0 + a.n_partial;
+    const long w2off = 2L * F * DRGNN_H1 + DRGNN_H1;
+    step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1[0], d.C1, s.u2[0], s.z2[0], p_w1n0 + w2off);
+    BARRIER();
+    step_wblock_store(wother, hf, 1, s.wb);      // branch 1's column block of fc1 takes branch 0's place
+    BARRIER();
+    step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1[1], d.C1, s.u2[1], s.z2[1], p_w1n1 + w2off);
+    BARRIER();
+
+    // ---- backward body, branch after branch: dS = dZ2 W2^T, dXP through CSC1 (dense rows), dW1 through the depth-0 argmax ---
+#pragma unroll 1
+    for (int br = 0; br < 2; ++br) {
+        const bool b1 = br != 0;
+        float* const w2n = b1 ? s.w2n[1] : s.w2n[0];
+        float* const z2 = b1 ? s.z2[1] : s.z2[0];
+        short* const a0 = b1 ? s.a0[1] : s.a0[0];
+        step_gemm_nn(d.C, 1, DRGNN_H2, z2, Z2LD, w2n, W2NLD, s.p2, STEP_XPLD, dummy);
+        BARRIER();
+        step3_gather_dxp<STEP_XPLD>(d.C, s.cp1, s.rx1, s.p2, s.xp);
+        BARRIER();
+        step3_dw1_sparse<XF>(d.C, a0, s.xp, s.G, b1 ? p_w1n1 : p_w1n0, F);      // (the next branch's first two phases leave xp, a0, G alone)
+    }
+}
 #endif  // !DRGNN_EMU
 #endif

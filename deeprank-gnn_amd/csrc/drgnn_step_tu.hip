@@ -40,6 +40,12 @@ template __global__ void k_step3_co_topo<32, false, 0>(StepCoLaunch);
 template __global__ void k_step3_co_topo<32, true, 0>(StepCoLaunch);
 template __global__ void k_step3_co_topo<32, false, 1>(StepCoLaunch);
 template __global__ void k_step3_co_topo<32, true, 1>(StepCoLaunch);
+#elif DRGNN_TU_KIND == 8
+// ... with both branches of a graph in one workgroup (net_step3_graph_both)
+template __global__ void k_step3b_co_topo<32, false, 0>(StepCoLaunch);
+template __global__ void k_step3b_co_topo<32, true, 0>(StepCoLaunch);
+template __global__ void k_step3b_co_topo<32, false, 1>(StepCoLaunch);
+template __global__ void k_step3b_co_topo<32, true, 1>(StepCoLaunch);
 #else
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
 // ... and the 32-wide kernels with the capacity-class LDS layout (net_step_graph: CLS = 1)

@@ -230,20 +230,13 @@ class FusedTrainer(object):
         the launches that accept a workspace built with TOPO_LEAN."""
         if getattr(topo, "tiles", None) is None or not self._tiles_match(topo):
             return False
-        if not self.api.net_step_family(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, self.H, self.O):
-            return False
-        if self.kind != _lib.GINET:
-            return True
-        wgs, _ = self.api.net_step_plan(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, self.R, self.H,
-                                        self.O, topo.n_graphs, n_next)
-        return wgs == 2
+        return bool(self.api.net_step_family(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, self.H, self.O))
 
     def _flags_for(self, topo, n_feat):
         """Request flags of a topology the next launch co-builds.  When the launch that will train on it is one of the
         aggregation-first kernels: the hierarchical node order, the aggregation tiles, and nothing those kernels do not read
         (TOPO_LEAN: the builder's short chains) -- judged for a following mini-batch of the same size; _fused_launch_step
-        rebuilds in full should that turn out wrong.  Otherwise the plain build (GINet's one-workgroup layout beyond the
-        resident batch size reads no hierarchical order, and there the builder is co-critical)."""
+        rebuilds in full should that turn out wrong.  Otherwise the plain build."""
         if self._af_launch(topo, n_feat, topo.n_graphs):
             return _lib.TOPO_HIER | _lib.TOPO_LEAN | _lib.TOPO_TILES
         return 0 if self.kind == _lib.GINET else _lib.TOPO_HIER

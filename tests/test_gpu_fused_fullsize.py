@@ -197,7 +197,7 @@ def test_fused_step_batches_beyond_the_argument_table(net_name, n_graphs):
 
 def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_step():
     """BASELINE-shaped graphs (200 nodes, ~1000 edges, 32 features), 130 of them: past the resident size, so the launch
-    is one workgroup per graph (both branches in sequence, drgnn_step1.h).  Element-wise against the oracle; the first 64
+    is one workgroup per graph (both branches in sequence: drgnn_step3.h's net_step3_graph_both, from the aggregation tiles).  Element-wise against the oracle; the first 64
     graphs' predictions equal what the two-workgroup layout gives on them alone (same arithmetic per branch)."""
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd.topology import Topology
@@ -222,15 +222,15 @@ def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_s
     t64 = Topology.from_batch(small, need_weights=False)
     assert tr.api.net_step_plan(tr.kind, 32, t64.max_nodes, t64.max_edges, t64.max_c0, tr.R, tr.H, tr.O, 64)[0] == 2
     tr.compute_gradients(small, topo=t64)                  # (no update in between: same parameters)
-    pred_af = tr.last_pred.cpu().numpy().copy()            # the aggregation-first two-workgroup kernel (drgnn_step3.h)
-    np.testing.assert_allclose(pred_one, pred_af, rtol=1e-4, atol=1e-5)
-    tr.api.set_step_layout(12)                             # ... and the drgnn_step.h two-workgroup kernel:
+    pred_af = tr.last_pred.cpu().numpy().copy()            # the two-workgroup kernel of the same family (drgnn_step3.h)
+    np.testing.assert_array_equal(pred_one, pred_af)       # forward arithmetic is the same code in both layouts
+    tr.api.set_step_layout(12)                             # ... and the product-first kernels (drgnn_step.h): same numbers to rounding
     try:
         tr.compute_gradients(small, topo=t64)
         pred_two = tr.last_pred.cpu().numpy()
     finally:
         tr.api.set_step_layout(11)
-    np.testing.assert_array_equal(pred_one, pred_two)      # forward arithmetic is the same code in both layouts
+    np.testing.assert_allclose(pred_one, pred_two, rtol=1e-4, atol=1e-5)
 
 
 @pytest.mark.parametrize("paired", [True, False])

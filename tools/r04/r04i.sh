@@ -1,12 +1,9 @@
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/r04i; mkdir -p $O
-timeout 600 python tools/r04/check_step2.py FoutNet sGAT 2>&1 | grep -v "^$" | grep -v "Warn\|detach\|ref_losses" > $O/check.log
+timeout 600 python tools/r04/check_step2.py GINet 2>&1 | grep -v "^$" | grep -v "Warn\|detach\|ref_losses" > $O/check.log
 cat $O/check.log
 for r in 1 2; do
-for net in sGAT FoutNet; do
-for lay in old af1 auto; do
-python bench.py --no-cpu-baseline --epoch-graphs 0 --min-seconds 1 --net $net --step-layout $lay 2>$O/err_$lay.txt | python -c "
+python bench.py --no-cpu-baseline --epoch-graphs 0 --min-seconds 1 --net GINet 2>$O/err.txt | python -c "
 import json,sys;d=json.loads(sys.stdin.read());k=d.get('roofline',{}).get('kernels',{})
-print('$lay $net', 'us/step', round(d['ms_per_step']*1000,2), 'kernels', [round(v['avg_us'],2) for v in k.values()], 'loss', d['config']['final_loss'])" | tee -a $O/ab.txt
-done; done; done
-tail -n 3 $O/err_auto.txt
+print('GINet', 'us/step', round(d['ms_per_step']*1000,2), 'kernels', [round(v['avg_us'],2) for v in k.values()], 'loss', d['config']['final_loss'])" | tee -a $O/ab.txt
+done
