@@ -19,5 +19,5 @@ build() {
   /opt/rocm/bin/hipcc $FLAGS $d -DDRGNN_TU_KIND=$TU -c -o /tmp/abl_k${TU}_$name.o $C/drgnn_step_tu.hip 2>/dev/null && xz -3 -c /tmp/abl_k${TU}_$name.o > $OUT/step_k${TU}_$name.o.xz && rm /tmp/abl_k${TU}_$name.o
 }
 for k in $KS; do build $k & while [ $(jobs -r | wc -l) -ge 7 ]; do sleep 1; done; done; wait
-for o in capi step_k0 step_k1 step_k2 step_k3 step_k4 step_k5 step_k6 step_k7; do xz -3 -c $C/build/$o.o > $OUT/base_$o.o.xz; done
+for o in capi step_k0 step_k1 step_k2 step_k3 step_k4 step_k5 step_k6 step_k7 step_k8; do xz -3 -c $C/build/$o.o > $OUT/base_$o.o.xz; done
 ls $OUT | wc -l
