@@ -552,6 +552,8 @@ def main():
                                     "reads it in place, no builder workgroups" if cached else
                                     "rebuilt every step; the build of step t+1 shares step t's backward launch "
                                     "(double-buffered)" if pipeline else "rebuilt every step, own launch"),
+                       "input": "ONE synthetic mini-batch replayed every step (its graphs stay in the XCDs' L2 between steps: "
+                                "`distinct_batches` and `epoch_loop` in this line are the figures without that)",
                        "final_loss": final_loss, "host_pool_threads": torch.get_num_threads()},
         }
         if split:
@@ -569,6 +571,10 @@ def main():
             result["roofline"] = measure_roofline(net, args.net, batch, dev, value / world,
                                                   cache=(cache, ids_host, ids_dev) if cached else None)
         if world == 1 and native and args.epoch_graphs > 0:
+            try:
+                result["distinct_batches"] = measure_distinct_batches(Net, args.net, dev)
+            except Exception as exc:                      # secondary figure: never lose the bench line over it
+                result["distinct_batches"] = {"error": repr(exc)[:200]}
             try:
                 result["epoch_loop"] = measure_epoch_loop(Net, args.net, args.epoch_graphs, dev)
             except Exception as exc:                      # secondary figure: never lose the bench line over it
@@ -780,6 +786,54 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
                                      "edge_index + clusters read, CSR0 + pooled CSR written); not SURVEY 8(d)'s figure"},
             "whole_step_frac": graphs_per_s * alg / 1e9 / HBM_PEAK_GBS,
             "kernels": out}
+
+
+def measure_distinct_batches(Net, net_name, dev, n_batches=32, steps=32):
+    """Secondary figure (not `value`): the same pipelined step replayed from a hipGraph, but every step on a DIFFERENT
+    host-collated synthetic mini-batch (a cycle of `n_batches`, every one with a topology workspace of its own built by the
+    previous step's launch).  `value` replays ONE mini-batch, whose graphs stay in the L2 of the XCD that worked on them a step
+    earlier; this is what that residency is worth."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    need_w = net_name == "sGAT"
+    torch.manual_seed(0)
+    tr = FusedTrainer(Net(N_FEAT, 1, 1).to(dev), lr=1e-3, task="reg")
+
+    def timed(batches):
+        n = len(batches)
+        topos = [Topology.from_batch(b, need_weights=need_w, build=(i == 0)) for i, b in enumerate(batches)]
+
+        def chunk():
+            for k in range(steps):
+                tr.train_step(batches[k % n], topo=topos[k % n], next_topo=topos[(k + 1) % n])
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            chunk()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            chunk()
+        for _ in range(3):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        reps = 200
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / (reps * steps)
+    one = synth.make_batch(0, GRAPHS_PER_GPU).to(dev)
+    us_same = timed([one, one])
+    us_distinct = timed([synth.make_batch(GRAPHS_PER_GPU * (i + 1), GRAPHS_PER_GPU).to(dev) for i in range(n_batches)])
+    return {"us_per_step_same_batch": us_same, "us_per_step": us_distinct, "graphs_per_s": GRAPHS_PER_GPU / (us_distinct * 1e-6),
+            "distinct_batches": n_batches, "batch": GRAPHS_PER_GPU, "net": net_name,
+            "what": "the pipelined step (topology of step t+1 built inside step t's launch) replayed from a hipGraph over a cycle "
+                    "of %d different synthetic mini-batches, against the same replay of one mini-batch" % n_batches}
 
 
 def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=4):
