@@ -87,6 +87,40 @@ def test_fused_step_syn64_gradients_match_oracle_elementwise(net_name, pipelined
         assert float(loss2) == float(loss)
 
 
+@pytest.mark.parametrize("net_name", NETS)
+def test_fused_step_syn128_gradients_match_oracle_elementwise(net_name):
+    """The reference's shipped training batch size (128 graphs) in the launches it takes by itself: beyond the
+    resident workgroup count GINet runs both branches of a graph in ONE workgroup from the aggregation tiles
+    (k_step3b_co_topo, drgnn_step3.h: net_step3_graph_both), sGAT / FoutNet one workgroup per graph (k_step2_co_topo<.., 1>),
+    and the co-launched builder one workgroup per graph (rows chain, then clusters chain).  Element-wise against the oracle,
+    and the topology that launch built for the next step is the one a plain build gives."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    from topo_check import check_against_oracle
+    dev = _dev()
+    batch_cpu = synth.make_batch(0, 128)
+    params = cpu_ref.init_params(net_name, 32, 1, 1, seed=13)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **_fw_kwargs(net_name))
+    lazy = Lazy64(net_name, params, batch_cpu, **_fw_kwargs(net_name))
+    net, tr = _trainer(net_name, params)
+    batch = batch_cpu.clone().to(dev)
+    need_w = net_name == "sGAT"
+    topo = Topology.from_batch(batch, need_weights=need_w)
+    assert tr._can_fuse(topo, 32)
+    nxt = Topology.from_batch(batch, need_weights=need_w, build=False)
+    loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
+    torch.cuda.synchronize()
+    stats = new_stats()
+    check_step("%s SYN128" % net_name, lazy, loss, tr.last_pred.cpu().numpy(), _grads_of(net), ref_loss, ref_pred.numpy(),
+               {k: v.numpy() for k, v in ref_grads.items()}, stats)
+    assert_arbiter_rate(stats, "%s batch 128" % net_name)
+    assert nxt.status()[0] == 0
+    check_against_oracle(nxt, batch_cpu, weights=need_w)
+    loss2 = tr.compute_gradients(batch, topo=nxt)          # (the co-built, lean workspace under the same kind of launch)
+    assert float(loss2) == float(loss)
+    tr.check_faults()
+
+
 @pytest.mark.parametrize("layout", ["two", "one"])
 def test_fused_step_syn64_dropout_on_matches_oracle_elementwise(layout):
     """The launch bench.py times runs GINet with dropout = 0.4 (ginet.py:97,138); the product's Bernoulli draw is a counter
