@@ -110,7 +110,7 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
             }
         }
         // (the lean clusters chain sets its presence flags in the builder's first phase: cleared here, before this barrier)
-        if (fits && (L.args.flags & DRGNN_TOPO_LEAN) && role != TOPO_ROLE_MEMBERS) topo_lean_preclear(N, s);
+        if (fits && (L.args.flags & DRGNN_TOPO_LEAN)) topo_lean_preclear(N, s, role != TOPO_ROLE_EDGES, role != TOPO_ROLE_MEMBERS);
         BARRIER();
     }
     if (!fits) {   // caller's bound was wrong: refuse loudly

@@ -142,6 +142,11 @@ DEV int wg_exscan(int* a, int n, int* part) {
     part[DRGNN_NTHREADS] = run;
     return run;
 }
+// two independent exclusive scans in the barrier intervals of one (totals: *ta, *tb)
+DEV void wg_exscan2(int* a, int na, int* b, int nb, int* part, int* ta, int* tb) {
+    *ta = wg_exscan(a, na, part);
+    *tb = wg_exscan(b, nb, part);
+}
 #else
 // inclusive scan over the 64 lanes of a wave on the DPP path (no LDS round trips): Hillis-Steele inside the rows of 16
 // lanes (row_shr 1, 2, 4, 8; lanes without a source add 0), then lane 15 / lane 31 broadcast into the following rows
@@ -212,6 +217,30 @@ DEV int wg_exscan(int* a, int n, int* part) {
     const int total = part[DRGNN_NTHREADS];
     __syncthreads();
     return total;
+}
+// two independent exclusive scans in the barrier intervals of one (totals: *ta, *tb): array a on the waves from 0, array b on the
+// waves from DRGNN_NWAVES / 2 (both at most half a workgroup of elements; anything longer: one scan after the other)
+DEV void wg_exscan2(int* a, int na, int* b, int nb, int* part, int* ta, int* tb) {
+    constexpr int HALF = DRGNN_NTHREADS / 2, HW = HALF / DRGNN_WAVE;
+    if (na > HALF || nb > HALF) { *ta = wg_exscan(a, na, part); *tb = wg_exscan(b, nb, part); return; }
+    const int t = threadIdx.x, lane = t & (DRGNN_WAVE - 1), wave = t >> 6;
+    const bool second = t >= HALF;
+    int* arr = second ? b : a;
+    const int n = second ? nb : na, i = second ? t - HALF : t;
+    const int nwa = (na + DRGNN_WAVE - 1) / DRGNN_WAVE, nwb = (nb + DRGNN_WAVE - 1) / DRGNN_WAVE;
+    int v = 0, inc = 0;
+    if (i < ((n + DRGNN_WAVE - 1) & ~(DRGNN_WAVE - 1))) {
+        v = (i < n) ? arr[i] : 0;
+        inc = wave_incl_scan(v);
+        if (lane == DRGNN_WAVE - 1) part[wave] = inc;
+    }
+    __syncthreads();
+    int base = 0, tot_a = 0, tot_b = 0;
+    for (int w = 0; w < nwa; ++w) { const int tw = part[w]; base += (!second && w < wave) ? tw : 0; tot_a += tw; }
+    for (int w = 0; w < nwb; ++w) { const int tw = part[HW + w]; base += (second && HW + w < wave) ? tw : 0; tot_b += tw; }
+    if (i < n) arr[i] = base + inc - v;
+    __syncthreads();
+    *ta = tot_a; *tb = tot_b;
 }
 #endif
 

@@ -99,6 +99,7 @@ struct TopoScratch {
     int* er;         // [capE] local row of every edge (staged once from the int64 edge_index)
     int* ec;         // [capE] local col
     float* w0;       // [capE] edge_attr in CSR0 slot order
+    float* wr;       // [capE] lean rows chain: edge weight by CSR0 slot (for the aggregation tiles)
     int* t1;         // [capT] x5
     int* t2;
     int* t3;
@@ -122,16 +123,16 @@ struct TopoScratch {
 // number of ints: linear in (capN, capE, capT, capF) -- keep in sync with topo_carve
 HD int64_t topo_scratch_ints(int64_t capN, int64_t capE, int64_t capT, int64_t capF) {
     return TOPO_MM_INTS + TOPO_PAD4(DRGNN_NTHREADS + 1) + 6 * TOPO_PAD4(capN + 1) + 3 * TOPO_PAD4(capN) +
-           6 * TOPO_PAD4(capE) + 5 * TOPO_PAD4(capT) + TOPO_PAD4(capF);
+           7 * TOPO_PAD4(capE) + 5 * TOPO_PAD4(capT) + TOPO_PAD4(capF);
 }
 
 // Global-memory placement of graph g's scratch when it does not live in LDS.  With
-// capT = N+E+1 and capF = N+E+2 the carve needs at most 15*N + 12*E + TOPO_GSCRATCH_CONST ints
+// capT = N+E+1 and capF = N+E+2 the carve needs at most 15*N + 13*E + TOPO_GSCRATCH_CONST ints
 // (the constant absorbs the fixed arrays and every PAD4 rounding), so regions placed at
-// 15*n0 + 12*e0 + CONST*g (rounded up to even for the 64-bit min/max slot) never overlap.
-#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 184 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
+// 15*n0 + 13*e0 + CONST*g (rounded up to even for the 64-bit min/max slot) never overlap.
+#define TOPO_GSCRATCH_CONST (DRGNN_NTHREADS + 188 + 8 * (DRGNN_NTHREADS / DRGNN_WAVE))
 HD int64_t topo_gscratch_base(int64_t n0, int64_t e0, int64_t g) {
-    return ((15 * n0 + 12 * e0 + (int64_t)TOPO_GSCRATCH_CONST * g) + 1) & ~(int64_t)1;
+    return ((15 * n0 + 13 * e0 + (int64_t)TOPO_GSCRATCH_CONST * g) + 1) & ~(int64_t)1;
 }
 
 template <class IntPtr>
@@ -155,6 +156,7 @@ DEV TopoScratch topo_carve(IntPtr base, int capN, int capE, int capT, int capF) 
     s.er = base + o;   o += (int)TOPO_PAD4(capE);
     s.ec = base + o;   o += (int)TOPO_PAD4(capE);
     s.w0 = (float*)(base + o); o += (int)TOPO_PAD4(capE);
+    s.wr = (float*)(base + o); o += (int)TOPO_PAD4(capE);
     s.t1 = base + o;   o += (int)TOPO_PAD4(capT);
     s.t2 = base + o;   o += (int)TOPO_PAD4(capT);
     s.t3 = base + o;   o += (int)TOPO_PAD4(capT);
@@ -1010,17 +1012,23 @@ template <int G> DEV int topo_count_below(const int* keys, int n, int me, int su
 // anything else raises TOPO_OVF and the caller takes the general chain) -- so the ranking needs no min / max pass and no flag
 // phase of its own.  Z and TOPO_OVF were cleared BEFORE the previous barrier (topo_lean_preclear, from topo_block).
 // `pre`: the ids are already in registers, requested ahead of the edge list.
-DEV void topo_lean_preclear(int N, TopoScratch& s) {
-    FOR_TID(v, imin(2 * N + 2, s.capF)) { s.fl[v] = 0; }
-    FOR_TID(i, 1) { TOPO_OVF(s)[0] = (2 * N + 2 > s.capF) ? 1 : 0; TOPO_WMAX(s)[0] = 0; }
+// `rows` / `clusters`: which chains this workgroup will run (the rows chain's histogram and cursors are cleared here too: its
+// histogram is formed by the lanes that stage the edges, in the builder's first phase)
+DEV void topo_lean_preclear(int N, TopoScratch& s, bool rows, bool clusters) {
+    if (rows) { FOR_TID(i, N + 1) { s.rp[i] = 0; s.cur[i] = 0; } }
+    if (clusters) {
+        FOR_TID(v, imin(2 * N + 2, s.capF)) { s.fl[v] = 0; }
+        FOR_TID(i, 1) { TOPO_OVF(s)[0] = (2 * N + 2 > s.capF) ? 1 : 0; TOPO_WMAX(s)[0] = 0; }
+    }
 }
 DEV void topo_lean_flag(long long v, int i, int* Z, int N, int* key, TopoScratch& s) {
     if ((unsigned long long)v < (unsigned long long)N) { Z[(int)v] = 1; key[i] = (int)v; }
     else { TOPO_OVF(s)[0] = 1; key[i] = 0; }
 }
-DEV void topo_lean_prepare(const TopoSrc& src, int N, int n1, bool rows, bool clusters, TopoScratch& s, bool pre = false,
+DEV void topo_lean_prepare(const TopoSrc& src, int N, int E, int n1, bool rows, bool clusters, TopoScratch& s, bool pre = false,
                            long long v0 = 0, long long v1 = 0) {
-    if (rows) { FOR_TID(i, N + 1) { s.rp[i] = 0; s.cur[i] = 0; } }
+    // (the rows chain's histogram: every lane counts the edges it has just staged itself, topo_stage_edges' loop)
+    if (rows) { FOR_TID(e, E) { ATOMIC_ADD(&s.rp[s.er[e]], 1); } }
     if (clusters && 2 * N + 2 <= s.capF) {
         const int R = N + 1;
         FOR_TID(i, N + 1) { s.cp[i] = 0; }
@@ -1038,55 +1046,67 @@ DEV void topo_lean_prepare(const TopoSrc& src, int N, int n1, bool rows, bool cl
     (void)pre; (void)v0; (void)v1;
 }
 
-// ---- rows chain: CSR0 (+ W0) and the aggregation tiles.  Needs the staged edges and topo_lean_prepare(rows) behind a barrier;
-// leaves no barrier behind its last phase.
-DEV void topo_lean_rows(const TopoView& tv, int g, int n0, int e0, int N, int E, bool has_w, TopoScratch& s, const TopoTile& tile) {
-    const int rowbase = n0 + g;
-    int* Z = s.rp;
-    FOR_TID(e, E) { ATOMIC_ADD(&Z[s.er[e]], 1); }
-    BARRIER();
-    wg_exscan(Z, N + 1, s.part);
-    {
-        int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + rowbase;
-        FOR_TID(e, E) { const int r = s.er[e]; s.t2[Z[r] + ATOMIC_ADD(&s.cur[r], 1)] = e; }
-        FOR_TID(i, N + 1) { g_rowptr0[i] = Z[i]; }
+// ---- rows chain: CSR0 (+ W0) and the aggregation tiles.  Needs the staged edges and the row histogram (topo_lean_prepare(rows))
+// behind a barrier.  In pieces, one per barrier interval, so that a workgroup that runs BOTH chains (one workgroup per graph:
+// batches beyond the resident size) can work them off in the clusters chain's intervals (topo_lean_clusters, `rows`):
+//   scan of the histogram | claim | rank + emit | tiles.     Scratch of its own: rp (Z), cur (until the claim is over), t1, col, wr.
+DEV void topo_lean_rows_claim(const TopoView& tv, int g, int n0, int N, int E, TopoScratch& s) {
+    const int* Z = s.rp;
+    int32_t* g_rowptr0 = tv.p[DRGNN_TI_ROWPTR0] + (n0 + g);
+    FOR_TID(e, E) { const int r = s.er[e]; s.t1[Z[r] + ATOMIC_ADD(&s.cur[r], 1)] = e; }
+    FOR_TID(i, N + 1) { g_rowptr0[i] = Z[i]; }
+}
+// rank of every edge inside its row by edge id, emitted at once; column / weight by slot stay in LDS for the tiles
+DEV void topo_lean_rows_emit(const TopoView& tv, int e0, int E, bool has_w, TopoScratch& s) {
+    const int* Z = s.rp;
+    int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
+    int32_t* g_eid0 = tv.p[DRGNN_TI_EID0] + e0;
+    float* g_w0 = tv.w0 ? tv.w0 + e0 : nullptr;
+    FOR_TID(p, E) {
+        const int e = s.t1[p];
+        const int r = s.er[e];
+        const int lo = Z[r], hi = Z[r + 1];
+        int rank = 0;
+        for (int q = lo; q < hi; ++q) rank += (s.t1[q] < e) ? 1 : 0;
+        const int cc = s.ec[e];
+        g_col0[lo + rank] = cc;
+        g_eid0[lo + rank] = e;
+        s.col[lo + rank] = cc;
+        if (has_w) { const float w = s.w0[e]; g_w0[lo + rank] = w; s.wr[lo + rank] = w; }
     }
+}
+// from the claim on (the histogram is scanned); leaves no barrier behind its last phase
+DEV void topo_lean_rows_tail(const TopoView& tv, int g, int n0, int e0, int N, int E, bool has_w, TopoScratch& s, const TopoTile& tile) {
+    topo_lean_rows_claim(tv, g, n0, N, E, s);
     BARRIER();
-    {   // rank of every edge inside its row by edge id, emitted at once; column / weight by slot stay in LDS for the tiles
-        int32_t* g_col0 = tv.p[DRGNN_TI_COL0] + e0;
-        int32_t* g_eid0 = tv.p[DRGNN_TI_EID0] + e0;
-        float* g_w0 = tv.w0 ? tv.w0 + e0 : nullptr;
-        FOR_TID(p, E) {
-            const int e = s.t2[p];
-            const int r = s.er[e];
-            const int lo = Z[r], hi = Z[r + 1];
-            int rank = 0;
-            for (int q = lo; q < hi; ++q) rank += (s.t2[q] < e) ? 1 : 0;
-            const int cc = s.ec[e];
-            g_col0[lo + rank] = cc;
-            g_eid0[lo + rank] = e;
-            s.col[lo + rank] = cc;
-            if (has_w) { const float w = s.w0[e]; g_w0[lo + rank] = w; ((float*)s.seg)[lo + rank] = w; }
-        }
-    }
+    topo_lean_rows_emit(tv, e0, E, has_w, s);
     if (tile.F > 0) {
         BARRIER();
-        topo_tiles_rows(tile, N, Z, s.col, has_w ? (const float*)s.seg : nullptr);
+        topo_tiles_rows(tile, N, s.rp, s.col, has_w ? (const float*)s.wr : nullptr);
     }
+}
+DEV void topo_lean_rows(const TopoView& tv, int g, int n0, int e0, int N, int E, bool has_w, TopoScratch& s, const TopoTile& tile) {
+    wg_exscan(s.rp, N + 1, s.part);
+    topo_lean_rows_tail(tv, g, n0, e0, N, E, has_w, s, tile);
 }
 
 // ---- clusters chain: depth-0 / depth-1 cluster ranks, MEM1 / MPTR1, HORD / IHORD / HMP0 / HSPLIT and (with_pool, no edge
 // weights) the pooled CSR + CSC.  Needs the staged edges and topo_lean_prepare(clusters) behind a barrier.  false
 // (workgroup-uniform; at most ranks and counts written, which the general chain writes again): ids too sparse for the flag
 // array or too many clusters for the bitmaps -- the caller takes the general chain.
-DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, int E, int c1_len, bool with_pool, bool has_w,
-                            TopoScratch& s, int sidx) {
+// `rows` (one workgroup per graph): the rows chain's pieces are worked off in this chain's barrier intervals (its scan shares
+// the first scan's two barriers, wg_exscan2).  Returns 0: done.  Otherwise the caller takes the general chain for the clusters
+// and, with `rows`, finishes the rows chain itself: 1 = its histogram is not scanned yet, 2 = scanned (topo_lean_rows_tail).
+DEV int topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, int E, int c1_len, bool with_pool, bool has_w,
+                           TopoScratch& s, int sidx, bool rows, const TopoTile& tile) {
     const int rowbase = n0 + g;
     const int n1 = imin(N, imax(c1_len, 0));
-    if (TOPO_OVF(s)[0] != 0 || N > 0x7FFF) return false;
+    if (TOPO_OVF(s)[0] != 0 || N > 0x7FFF) return 1;
     int* Z = s.fl;
     const int H = N + 1;
-    const int total = wg_exscan(Z, 2 * H, s.part);
+    int total = 0, rows_total = 0;
+    if (rows) wg_exscan2(Z, 2 * H, s.rp, N + 1, s.part, &total, &rows_total);
+    else total = wg_exscan(Z, 2 * H, s.part);
     const int C = Z[H], C1 = total - C;
     int* wmax_bits = TOPO_WMAX(s);
     if (with_pool && has_w) {
@@ -1106,7 +1126,7 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
     }
     const int n = imin(C, n1);                      // depth-0 clusters the depth-1 list covers
     const int BW = (C + 31) >> 5, CB = C * BW;
-    if (with_pool && 2L * CB + 1 > (long)s.capT) return false;
+    if (with_pool && 2L * CB + 1 > (long)s.capT) return 2;
     if (c1_len != C) { FOR_TID(i, 1) { topo_flag(tv, DRGNN_S_CLUSTER1_LEN, sidx); } }
     int* csize = s.cp;      // nodes per depth-0 cluster (cleared by topo_lean_prepare)
     int* cl1 = s.mem;       // depth-1 cluster of every depth-0 cluster
@@ -1131,6 +1151,7 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
         if (with_pool && has_w) { FOR_TID(q, 2 * E) { s.seg[q] = 0; } }      // 64-bit accumulators of the pooled weights: [seg | col1]
         FOR_TID(i, 1) { tv.p[DRGNN_TI_NC0][g] = C; tv.p[DRGNN_TI_NC1][g] = C1; }
     }
+    if (rows) topo_lean_rows_claim(tv, g, n0, N, E, s);      // (its cursors, s.cur, are this chain's only from the next interval on)
     BARRIER();
     int* qpos = s.pp;       // position of every depth-0 cluster in the depth-1-major order (clusters the list does not cover: last)
     int* mp1 = s.rp1;
@@ -1160,6 +1181,7 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
         }
         FOR_TID(c, C + 1) { s.cur[c] = 0; }      // cursors of the node claim below
     }
+    if (rows) topo_lean_rows_emit(tv, e0, E, has_w, s);
     BARRIER();
     int* hmp = s.fl;        // [C + 1] <= capN + 1 <= capF
     {
@@ -1175,6 +1197,7 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
             if (sub == 0) { hmp[q] = acc; g_hmp[q] = acc; }
         }
     }
+    if (rows && tile.F > 0) topo_tiles_rows(tile, N, s.rp, s.col, has_w ? (const float*)s.wr : nullptr);
     if (with_pool) {
         int* Y = s.t4;           // [2 CB + 1] set bits before each word of [bm | bmT]
         // (a thread scans the element it wrote while 2 CB + 1 <= threads: no barrier in between)
@@ -1284,7 +1307,7 @@ DEV bool topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, in
         }
 #endif
     }
-    return true;
+    return 0;
 }
 
 // WEIGHTS: -1 = decided at run time (edge_attr and a weight workspace given); 0 = never (the builder co-launched with a
@@ -1334,15 +1357,20 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     bool rows_done = false, need_c1 = false;
     if (run_rows || run_clusters) {
         // (one call site per chain: they are inlined)
-        topo_lean_prepare(src, N, nc1, run_rows, run_clusters, s, pre, pre0, pre1);
+        topo_lean_prepare(src, N, E, nc1, run_rows, run_clusters, s, pre, pre0, pre1);
         BARRIER();
-        if (run_rows) {
+        if (run_rows && !run_clusters) {
             topo_lean_rows(tv, g, n0, e0, N, E, has_w, s, tile);
-            rows_done = true;
-            if (!run_clusters) return;
-            BARRIER();
+            return;
         }
-        if (topo_lean_clusters(tv, g, n0, e0, N, E, c1_len, true, has_w, s, sidx)) return;
+        // (one workgroup per graph: the rows chain rides in the clusters chain's barrier intervals)
+        const int rc = topo_lean_clusters(tv, g, n0, e0, N, E, c1_len, true, has_w, s, sidx, run_rows, tile);
+        if (rc == 0) return;
+        if (run_rows) {
+            if (rc == 1) topo_lean_rows(tv, g, n0, e0, N, E, has_w, s, tile);
+            else topo_lean_rows_tail(tv, g, n0, e0, N, E, has_w, s, tile);
+            rows_done = true;
+        }
         need_c1 = true;     // the general chain for the clusters: this workgroup builds depth 1 and the hierarchical order too
         BARRIER();          // (every thread is past its reads of the prepared arrays)
     }
