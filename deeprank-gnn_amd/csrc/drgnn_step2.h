@@ -514,74 +514,6 @@ DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float
     }
 }
 
-// ---- phase N: [dWn ; dWs] = [S | X]^T [D . dZ1 | C . dZ1] over the own rows (K = rows, split in KS slices over the waves) ---
-// units (tile, slice): tiles 0 .. MT-1 = dWn (A = S rows, B scaled by D), MT .. 2 MT-1 = dWs (A = x rows, B scaled by C).
-// The operands of a 32-row chunk are requested in ONE batch per kind (a per-operand branch made eight dependent LDS round
-// trips of them: 3 us for this product).  stage 1: partial tiles -> part; stage 2 (behind the caller's barrier): their
-// sums -> the slab (dWn at C, dWs at C + chalf)
-template <int XF, bool SELF>
-DEV drgnn_f32x4 step2_dw1_unit(int kbeg, int kend, int ti, int nmax, const float* G, const float* xs, const float* dv,
-                               const float* sc, const float* dz) {
-    constexpr int XLD = XF + 4;
-    const int lane = threadIdx.x & 63;
-    const int lr = lane & 15, lq = lane >> 4;
-    const float* A = SELF ? xs : G;
-    const float* coef = SELF ? sc : dv;
-    drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kbeg; k0 < kend; k0 += 32) {
-        float a[8], b[8], cf[8];
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) {
-            const int k = k0 + lq + 4 * s2;      // rows [K, K4): coefficient zero, dz zero; beyond K4: not used
-            const int row = k < nmax ? k : nmax - 1;      // (the A operand of a padding row: any valid row)
-            a[s2] = A[row * XLD + ti * 16 + lr];
-            cf[s2] = coef[k];
-            b[s2] = dz[k * DRGNN_H1 + lr];
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2) b[s2] *= cf[s2];
-#pragma unroll
-        for (int s2 = 0; s2 < 8; ++s2)
-            if (k0 + 4 * s2 < kend) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s2], b[s2], acc, 0, 0, 0);
-    }
-    return acc;
-}
-template <int XF>
-DEV void step2_gemm_dw1(int K, int nmax, const float* G, const float* xs, const float* dv, const float* sc,
-                        const float* dz, int KS, float* part, float* C, int chalf, int Mrows, int stage) {
-    constexpr int MT = XF / 16;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int K4 = step_pad4(K);
-    const int ks_log = 31 - __builtin_clz((unsigned)KS);
-    const int kslice = (((K4 >> 2) + KS - 1) >> ks_log) << 2;
-    constexpr int tiles = 2 * MT;
-    const int units = tiles * KS;
-    if (stage == 1) {
-        for (int u = wave; u < units; u += DRGNN_NWAVES) {
-            const int ks = u / tiles, t = u - ks * tiles;
-            const int kbeg = ks * kslice, kend = imin(K4, kbeg + kslice);
-            drgnn_f32x4 acc;
-            if (t >= MT) acc = step2_dw1_unit<XF, true>(kbeg, kend, t - MT, nmax, G, xs, dv, sc, dz);
-            else acc = step2_dw1_unit<XF, false>(kbeg, kend, t, nmax, G, xs, dv, sc, dz);
-            *(drgnn_f4*)(part + (u * 64 + lane) * 4) = drgnn_f4{acc[0], acc[1], acc[2], acc[3]};
-        }
-        return;
-    }
-    for (int e = threadIdx.x; e < tiles * 64; e += DRGNN_NTHREADS) {
-        const int t = e >> 6, l = e & 63;
-        drgnn_f4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int ks = 0; ks < KS; ++ks) {
-            const drgnn_f4 v = *(const drgnn_f4*)(part + ((ks * tiles + t) * 64 + l) * 4);
-            sum[0] += v[0]; sum[1] += v[1]; sum[2] += v[2]; sum[3] += v[3];
-        }
-        const bool self = t >= MT;
-        const int ti = self ? t - MT : t;
-        const int row = ti * 16 + (l >> 4) * 4;
-        float* c = C + (self ? chalf : 0) + row * DRGNN_H1 + (l & 15);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (row + r < Mrows) c[r * DRGNN_H1] = sum[r];
-    }
-}
 
 // =========================================================================================================================
 // XF: padded feature width (16 / 32 / 48 / 64; the host has checked step_burst_guaranteed: register-burst prologue, reference
