@@ -48,6 +48,37 @@ def iso3_batch():
                                                   isolate_node=(7 if i == 1 else None)) for i in range(3)])
 
 
+def wide4_graphs(n_feat=52):
+    """the graphs of wide4_* (52 features: padded width 64) / mid4_* (their first 44 features: padded width 48)"""
+    import deeprank_gnn_amd.synthetic as synth
+    gs = [synth.make_graph(i, n_nodes=40, n_pairs=70, n_feat=52, n_c1=4, n_internal=40) for i in range(4)]
+    for g in gs:
+        g.x = g.x[:, :n_feat].contiguous()
+    return gs
+
+
+def wide4_batch():
+    from deeprank_gnn_amd.data import Batch
+    return Batch.from_data_list(wide4_graphs(52))
+
+
+def mid4_batch():
+    from deeprank_gnn_amd.data import Batch
+    return Batch.from_data_list(wide4_graphs(44))
+
+
+def treg_graphs():
+    """the six 48-feature graphs pretrained_treg.npz was recorded on (tests/golden/gen/make_width_golden.py)"""
+    import deeprank_gnn_amd.synthetic as synth
+    return [synth.make_graph(i, n_nodes=40 + 9 * i, n_pairs=70 + 11 * i, n_feat=48, n_c1=4, n_internal=40)
+            for i in range(6)]
+
+
+def treg_batch():
+    from deeprank_gnn_amd.data import Batch
+    return Batch.from_data_list(treg_graphs())
+
+
 CASES = {
     # golden file            net       batch factory                task
     "fix8_GINet.npz": ("GINet", lambda: fixture_batch(8), "reg"),
@@ -61,4 +92,16 @@ CASES = {
     "iso3_GINet.npz": ("GINet", iso3_batch, "reg"),
     "iso3_sGAT.npz": ("sGAT", iso3_batch, "reg"),
     "iso3_FoutNet.npz": ("FoutNet", iso3_batch, "reg"),
+    # round 5: the other feature-width classes of the fused kernels (52 features -> 64, 44 -> 48; syn4 / iso3 are 12 -> 16,
+    # fix8 is 28 -> 32) and the reference's shipped regression model (48 features) in a training step
+    "wide4_GINet.npz": ("GINet", wide4_batch, "reg"),
+    "wide4_sGAT.npz": ("sGAT", wide4_batch, "reg"),
+    "wide4_FoutNet.npz": ("FoutNet", wide4_batch, "reg"),
+    "mid4_GINet.npz": ("GINet", mid4_batch, "reg"),
+    "mid4_sGAT.npz": ("sGAT", mid4_batch, "reg"),
+    "mid4_FoutNet.npz": ("FoutNet", mid4_batch, "reg"),
+}
+# cases with out / loss / every gradient but without the per-stage trace
+STEP_ONLY_CASES = {
+    "pretrained_treg.npz": ("GINet", treg_batch, "reg"),
 }

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import CASES, golden, params_of, fixture_graphs, fixture_batch
+from helpers import CASES, golden, params_of, fixture_graphs, fixture_batch, treg_graphs
 from oracle import cpu_ref
 
 TOL = dict(rtol=2e-5, atol=2e-5)
@@ -87,6 +87,28 @@ def test_pretrained_classifier_known_answer():
     np.testing.assert_allclose(out.numpy(), g["logits_batched"], rtol=1e-4, atol=1e-4)
     one = torch.cat([cpu_ref.ginet_forward(params, Batch.from_data_list([gr])) for gr in graphs])
     np.testing.assert_allclose(one.numpy(), g["logits_single"], rtol=1e-4, atol=1e-4)
+
+
+def test_pretrained_regression_model_known_answer():
+    """The reference's shipped regression model (paper_pretrained_models/scoring_of_docking_models/treg_yfnat_b128_*, GINet
+    with 48 node features) on six synthetic 48-feature graphs: eval-mode predictions and one training step's loss and
+    gradients recorded from the reference's own GINet (tests/golden/gen/make_width_golden.py)."""
+    g = golden("pretrained_treg.npz")
+    params = params_of(g)
+    assert params["conv1.fc.weight"].shape == (16, 48)
+    graphs = treg_graphs()
+    from deeprank_gnn_amd.data import Batch
+    out = cpu_ref.ginet_forward(params, Batch.from_data_list(graphs))
+    np.testing.assert_allclose(out.numpy(), g["pred_batched"], rtol=1e-4, atol=1e-4)
+    one = torch.cat([cpu_ref.ginet_forward(params, Batch.from_data_list([gr])) for gr in graphs])
+    np.testing.assert_allclose(one.numpy(), g["pred_single"], rtol=1e-4, atol=1e-4)
+    pred, loss, grads = cpu_ref.loss_and_grads("GINet", params, Batch.from_data_list(graphs), torch.from_numpy(g["target"]))
+    np.testing.assert_allclose(pred.numpy(), g["out"], **TOL)
+    np.testing.assert_allclose(loss.numpy(), g["loss"], rtol=2e-5)
+    for name in params:
+        ref = g["grad/" + name]
+        np.testing.assert_allclose(grads[name].numpy(), ref, rtol=1e-4, atol=2e-5 * max(1.0, float(np.abs(ref).max())),
+                                   err_msg=name)
 
 
 def test_toy_pooling():
