@@ -121,6 +121,8 @@ def parse():
                          "over the ranks; the result (ranks, backend, exchange, fallback taken) goes into config.dp_selftest "
                          "and to stderr.  Works with --gpus N (RCCL) and with --gpus N --backend gloo on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-nets", action="store_true",
+                    help="skip the secondary sGAT / FoutNet figures of the default GINet line (`other_nets`)")
     ap.add_argument("--epoch-graphs", type=int, default=4096,
                     help="size of the resident graph set of the secondary whole-epoch measurement (0: skip it)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -183,17 +185,13 @@ def main():
     from deeprank_gnn_amd.foutnet import FoutNet
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[args.net]
 
-    if args.step_layout == "noclass":                  # (A/B: the run-time LDS layout also where the capacity class applies)
-        _lib.get().set_step_layout(6)
-    elif args.step_layout == "old":                    # (A/B, sGAT / FoutNet: the round-3 kernels, no aggregation-first step)
-        _lib.get().set_step_layout(8)
-        _lib.get().set_step_layout(12)                 # (GINet: the round-3 kernels, no aggregation-first step)
-    elif args.step_layout == "af1":                    # (A/B, sGAT / FoutNet: aggregation first, ONE workgroup per graph)
-        _lib.get().set_step_layout(10)
-    elif args.step_layout != "auto":
-        if args.step_layout == "seq":                  # one workgroup per graph, branch after branch (not the paired form)
-            _lib.get().set_step_layout(3)
-        _lib.get().set_step_layout({"one": 1, "seq": 1, "two": 2}[args.step_layout])
+    # same-box A/B runs of the whole program: the process default of the launch plan's overrides (drgnn_step_plan; the library
+    # reads DRGNN_STEP_PLAN once, at its first plan query -- none has been made yet).  noclass: the run-time LDS layout also
+    # where the capacity class applies; old: the product-first kernels (round 3) everywhere; af1: sGAT / FoutNet aggregation
+    # first with ONE workgroup per graph; one / two: workgroups per graph; seq: one workgroup, branch after branch
+    if args.step_layout != "auto":
+        os.environ["DRGNN_STEP_PLAN"] = {"noclass": "noclass", "old": "product", "af1": "nosplit", "one": "one",
+                                         "seq": "one,seq", "two": "two"}[args.step_layout]
     batch_cpu = synth.make_batch(rank * GRAPHS_PER_GPU, GRAPHS_PER_GPU)
     batch = batch_cpu.clone().to(dev)
     torch.manual_seed(0)
@@ -579,6 +577,14 @@ def main():
                 result["epoch_loop"] = measure_epoch_loop(Net, args.net, args.epoch_graphs, dev)
             except Exception as exc:                      # secondary figure: never lose the bench line over it
                 result["epoch_loop"] = {"error": repr(exc)[:200]}
+        if world == 1 and native and args.net == "GINet" and not args.no_other_nets:
+            # BASELINE.json configs[2] / configs[3] in the same line (driver evidence for the single-branch nets)
+            result["other_nets"] = {}
+            for other in ("sGAT", "FoutNet"):
+                try:
+                    result["other_nets"][other] = measure_other_net(other, batch, dev)
+                except Exception as exc:                  # secondary figure: never lose the bench line over it
+                    result["other_nets"][other] = {"error": repr(exc)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args.net, batch_cpu, args.cpu_seconds)
     if world > 1:
@@ -678,7 +684,7 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
     assert tr._can_fuse(topo, batch.x.shape[1]), "SYN graphs must take the fused-step path"
     variant = tr.api.step_is_specialised(tr.kind, batch.x, batch.x.shape[1], topo.max_nodes, topo.max_edges,
                                          topo.max_c0, tr.H, tr.O)
-    c = tr._fused_prepare(batch, topo)
+    c = tr._fused_prepare(batch, topo, True, nxt)
     B = c["B"]
 
     def k_topo():
@@ -706,15 +712,15 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
     fwd_b, bwd_b = ALG_BYTES[net_name]
     alg = fwd_b + bwd_b
     upd_bytes = (c["partials"].numel() + c["hp"].numel() + c["readout"].numel() + 7 * tr.flat_p.numel()) * 4 / B
-    kname = "k_step_co_topo<%s,%d>" % (net_name, variant)
-    if net_name != "GINet" and (c["hints"][0].topo_flags & _lib.TOPO_HIER) and \
-            tr.api.net_step_family(tr.kind, batch.x.shape[1], topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O):
-        # sGAT / FoutNet training launches of this shape: the aggregation-first kernels (csrc/drgnn_step2.h)
-        kname = "k_step2_co_topo<%s,32,%s>" % (net_name, "two workgroups per graph" if c["hints"][0].split else "one workgroup per graph")
-    if net_name == "GINet" and (c["hints"][0].topo_flags & _lib.TOPO_HIER) and \
-            tr.api.net_step_family(tr.kind, batch.x.shape[1], topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O) and \
-            tr.api.net_step_plan(tr.kind, batch.x.shape[1], topo.max_nodes, topo.max_edges, topo.max_c0, tr.R, tr.H, tr.O, B, B)[0] == 2:
-        kname = "k_step3_co_topo<GINet,32> (aggregation first)"      # csrc/drgnn_step3.h
+    # which kernel the launch is: the plan the prepared step carries (the same decision procedure the launch runs)
+    plan = c["plan"]
+    wg_txt = "two workgroups per graph" if plan.wgs_per_graph == 2 else "one workgroup per graph"
+    if plan.family == _lib.STEP_FAMILY_AGGREGATE and net_name != "GINet":
+        kname = "k_step2_co_topo<%s,%d,%s>" % (net_name, plan.width, wg_txt)      # csrc/drgnn_step2.h
+    elif plan.family == _lib.STEP_FAMILY_AGGREGATE:
+        kname = "k_step3%s_co_topo<GINet,%d> (aggregation first, %s)" % ("" if plan.wgs_per_graph == 2 else "b", plan.width, wg_txt)
+    else:
+        kname = "k_step_co_topo<%s,%d> (product first, %s)" % (net_name, variant, wg_txt)
     out = {}
     first = ((kname + " (fwd + head/loss + bwd, topology read from the per-graph cache)", k_step_cached, alg) if cache else
              (kname + " (fwd + head/loss + bwd, + topology of the next batch)", k_step_co, alg))
@@ -776,7 +782,7 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
                     # busy cycles summed over SIMDs / (1024 SIMDs x kernel cycles at the 2.28 GHz shader clock)
                     mfma = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (step_us * 1e3 * 2.28 * 1024.0)
                     mfma_note = "SQ_VALU_MFMA_BUSY_CYCLES from profiles/%s (same sources as this build)" % where
-    return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": dom, "kernel_us": out[dom]["avg_us"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
             "mfma_util": mfma, "mfma_note": mfma_note,
             "alg_bytes_per_graph": alg, "graphs_per_launch": B, "source_hash": source_hash(),
@@ -786,6 +792,53 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
                                      "edge_index + clusters read, CSR0 + pooled CSR written); not SURVEY 8(d)'s figure"},
             "whole_step_frac": graphs_per_s * alg / 1e9 / HBM_PEAK_GBS,
             "kernels": out}
+
+
+def measure_other_net(net_name, batch, dev, steps=20):
+    """Secondary figure (not `value`): the SAME pipelined training step for another net of the path (BASELINE.json configs[2] /
+    configs[3]: sGAT, FoutNet + community_pooling on the same synthetic graphs, batch 64) -- us per step of 20-step hipGraph
+    replays (topology of step t+1 built inside step t's launch, update launch included) and the step launch against the HBM
+    roofline by SURVEY 8(d)'s bytes of that net."""
+    import time as _time
+    from deeprank_gnn_amd.topology import Topology
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    from deeprank_gnn_amd.sGAT import sGAT
+    from deeprank_gnn_amd.foutnet import FoutNet
+    Net = {"sGAT": sGAT, "FoutNet": FoutNet}[net_name]
+    need_w = net_name == "sGAT"
+    torch.manual_seed(0)
+    net = Net(N_FEAT, 1, 1).to(dev)
+    net.train()
+    tr = FusedTrainer(net, lr=1e-3, task="reg", seed=1234)
+    topos = [Topology.from_batch(batch, need_weights=need_w), Topology.from_batch(batch, need_weights=need_w)]
+
+    def chunk():
+        for k in range(steps):
+            tr.train_step(batch, topo=topos[k & 1], next_topo=topos[1 - (k & 1)])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chunk()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        chunk()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = _time.perf_counter()
+    reps = 0
+    while _time.perf_counter() - t0 < 1.5:
+        for _ in range(50):
+            g.replay()
+        reps += 50
+        torch.cuda.synchronize()
+    us = (_time.perf_counter() - t0) / (reps * steps) * 1e6
+    rf = measure_roofline(net, net_name, batch, dev, GRAPHS_PER_GPU / (us * 1e-6), iters=200)
+    return {"us_per_step": us, "graphs_per_s": GRAPHS_PER_GPU / (us * 1e-6), "kernel": rf["kernel"], "kernel_us": rf["kernel_us"],
+            "frac": rf["frac"], "achieved": rf["achieved"], "alg_bytes_per_graph": rf["alg_bytes_per_graph"],
+            "whole_step_frac": rf["whole_step_frac"], "final_loss": float(tr.loss.item())}
 
 
 def measure_distinct_batches(Net, net_name, dev, n_batches=32, steps=32):

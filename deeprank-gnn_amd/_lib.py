@@ -88,16 +88,35 @@ class EpochPlan(ctypes.Structure):
                 ("flat_param", _vp), ("flat_grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("n_param", _c_i64),
                 ("step2", _vp),
                 ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
-                ("cache", _vp), ("exchange", _vp), ("exchange_user", _vp)]
+                ("cache", _vp), ("exchange", _vp), ("exchange_user", _vp), ("step_overrides", _vp)]
 
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p)
 
 
+class StepPlan(ctypes.Structure):
+    """drgnn_step_plan (include/drgnn.h): the launch (in), the overrides (in), the layout (out)."""
+    _fields_ = [("kind", _c_i32), ("n_feat", _c_i32), ("max_nodes", _c_i32), ("max_edges", _c_i32), ("max_c0", _c_i32),
+                ("R", _c_i32), ("H", _c_i32), ("O", _c_i32),
+                ("n_graphs", _c_i64), ("co_built_graphs", _c_i64),
+                ("train", _c_i32), ("topo_flags", _c_i32),
+                ("force_wgs", _c_i32), ("no_class", _c_i32), ("no_aggregate", _c_i32), ("no_split", _c_i32),
+                ("no_paired", _c_i32),
+                ("family", _c_i32), ("wgs_per_graph", _c_i32), ("slabs_per_graph", _c_i32), ("width", _c_i32),
+                ("cls", _c_i32), ("lean_ok", _c_i32), ("builder_wgs_per_graph", _c_i32),
+                ("lds_bytes", _c_i64), ("xchg_words", _c_i64)]
+
+    OVERRIDES = ("force_wgs", "no_class", "no_aggregate", "no_split", "no_paired")
+
+
+STEP_FAMILY_NONE, STEP_FAMILY_PRODUCT, STEP_FAMILY_AGGREGATE = 0, 1, 2
+
+
 class StepHints(ctypes.Structure):
-    """drgnn_step_hints: host-side offset tables of a launch's graphs (pointers to HOST memory)."""
+    """drgnn_step_hints: host-side offset tables of a launch's graphs (pointers to HOST memory), what the workspace holds,
+    the plan the caller sized its buffers from."""
     _fields_ = [("host_node_ptr", _vp), ("host_edge_ptr", _vp), ("set_node_ptr", _vp), ("set_edge_ptr", _vp),
-                ("host_ids", _vp), ("topo_flags", _c_i32), ("split", _c_i32), ("tiles", _vp)]
+                ("host_ids", _vp), ("topo_flags", _c_i32), ("reserved", _c_i32), ("tiles", _vp), ("plan", _vp)]
 
 
 class TopologyCacheDesc(ctypes.Structure):
@@ -169,10 +188,8 @@ class Api(object):
         lib.drgnn_net_step_lds_bytes.restype = _c_i64
         lib.drgnn_net_step_variant.argtypes = [_c_i32, _vp] + [_c_i32] * 6
         lib.drgnn_net_step_variant.restype = _c_i32
-        lib.drgnn_net_step_plan.argtypes = [_c_i32] * 8 + [_c_i64, _c_i64, ctypes.POINTER(_c_i64)]
+        lib.drgnn_net_step_plan.argtypes = [ctypes.POINTER(StepPlan)]
         lib.drgnn_net_step_plan.restype = _c_i32
-        lib.drgnn_set_step_layout.argtypes = [_c_i32]
-        lib.drgnn_set_step_layout.restype = _c_i32
         lib.drgnn_head_compact_elems.argtypes = [_c_i32] * 3
         lib.drgnn_head_compact_elems.restype = _c_i64
         lib.drgnn_net_train_step.argtypes = ([ctypes.POINTER(NetDesc), ctypes.POINTER(HeadDesc)] + [_vp] * 5 +
@@ -187,8 +204,6 @@ class Api(object):
                                           [ctypes.c_float] * 4 + [_c_i32, _c_i32, _vp])
         lib.drgnn_net_step_xchg_elems.argtypes = [_c_i32] * 4
         lib.drgnn_net_step_xchg_elems.restype = _c_i64
-        lib.drgnn_net_step_family.argtypes = [_c_i32] * 7
-        lib.drgnn_net_step_family.restype = _c_i32
         lib.drgnn_net_reduce_grads.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64, _c_i64] +
                                                [ctypes.POINTER(ConvGrads)] * 2 + [_vp] * 2)
         lib.drgnn_conv_layer_slabs.argtypes = [_c_i64]
@@ -232,7 +247,7 @@ class Api(object):
         lib.drgnn_head_step.argtypes = [ctypes.POINTER(HeadDesc), _vp, _vp, _c_i64] + [_vp] * 5
         lib.drgnn_head_reduce.argtypes = [_vp, _c_i64, _c_i32, _c_i32, _c_i32] + [_vp] * 4
         lib.drgnn_adam_step.argtypes = [_vp] * 5 + [_c_i64] + [ctypes.c_float] * 5 + [_vp]
-        if lib.drgnn_abi_version() != 1:
+        if lib.drgnn_abi_version() != 2:
             raise DrgnnError("ABI mismatch in %s" % path)
 
     # -- topology ---------------------------------------------------------------
@@ -313,16 +328,30 @@ class Api(object):
             "drgnn_train_update")
 
     # -- fused training step ------------------------------------------------------
-    def net_step_plan(self, kind, n_feat, max_nodes, max_edges, max_c0, R, H, O, n_graphs, co_built_graphs=0):
-        """(workgroups per graph, LDS bytes per workgroup) of the fused step launch for ``n_graphs`` graphs with these
-        bounds, the same launch building the topology of ``co_built_graphs`` graphs; (0, 0): outside the fused kernels."""
-        need = _c_i64(0)
-        wgs = int(self.lib.drgnn_net_step_plan(kind, n_feat, max_nodes, max_edges, max_c0, R, H, O, int(n_graphs),
-                                               int(co_built_graphs), ctypes.byref(need)))
-        return wgs, int(need.value)
+    def step_plan(self, kind, n_feat, max_nodes, max_edges, max_c0, R, H, O, n_graphs, co_built_graphs=0, train=True,
+                  topo_flags=0, overrides=None):
+        """The launch plan (StepPlan, ``out`` members filled) of a fused step of ``n_graphs`` graphs with these bounds on a
+        workspace built with ``topo_flags``, the same launch building the topology of ``co_built_graphs`` graphs.
+        ``overrides``: dict over StepPlan.OVERRIDES (tests, A/B runs).  ``family == 0``: outside the fused kernels."""
+        p = StepPlan()
+        p.kind, p.n_feat, p.max_nodes, p.max_edges, p.max_c0 = int(kind), int(n_feat), int(max_nodes), int(max_edges), int(max_c0)
+        p.R, p.H, p.O = int(R), int(H), int(O)
+        p.n_graphs, p.co_built_graphs = int(n_graphs), int(co_built_graphs)
+        p.train, p.topo_flags = int(bool(train)), int(topo_flags)
+        for k, v in (overrides or {}).items():
+            if k not in StepPlan.OVERRIDES:
+                raise KeyError("unknown step-plan override %r" % (k,))
+            setattr(p, k, int(v))
+        self.lib.drgnn_net_step_plan(ctypes.byref(p))
+        return p
 
-    def set_step_layout(self, mode):
-        _check(self.lib.drgnn_set_step_layout(int(mode)), "drgnn_set_step_layout")
+    def net_step_plan(self, kind, n_feat, max_nodes, max_edges, max_c0, R, H, O, n_graphs, co_built_graphs=0, train=True,
+                      topo_flags=TOPO_HIER | TOPO_TILES, overrides=None):
+        """(workgroups per graph, LDS bytes per workgroup) of ``step_plan`` -- by default for a training launch on a workspace
+        with the hierarchical order and aggregation tiles (what the trainers build); (0, 0): outside the fused kernels."""
+        p = self.step_plan(kind, n_feat, max_nodes, max_edges, max_c0, R, H, O, n_graphs, co_built_graphs, train, topo_flags,
+                           overrides)
+        return int(p.wgs_per_graph), int(p.lds_bytes)
 
     def net_step_lds_bytes(self, kind, n_feat, max_nodes, max_edges, max_c0, R, H, O):
         return int(self.lib.drgnn_net_step_lds_bytes(kind, n_feat, max_nodes, max_edges, max_c0, R, H, O))
@@ -361,10 +390,6 @@ class Api(object):
             R, H, O, head_offset, _ptr(flat_p), _ptr(flat_g), _ptr(exp_avg), _ptr(exp_avg_sq), flat_p.numel(),
             _ptr(step2), _ptr(loss), lr, beta1, beta2, eps, 1 if apply_adam else 0, int(slabs_per_graph), stream),
             "drgnn_step_update")
-
-    def net_step_family(self, kind, n_feat, max_nodes, max_edges, max_c0, H, O):
-        """1: training launches of this shape on a topology with the hierarchical order run the aggregation-first kernels."""
-        return int(self.lib.drgnn_net_step_family(kind, n_feat, max_nodes, max_edges, max_c0, H, O))
 
     def net_step_xchg_elems(self, kind, max_nodes, max_c0, H):
         return int(self.lib.drgnn_net_step_xchg_elems(kind, max_nodes, max_c0, H))
@@ -540,8 +565,9 @@ def current_stream(ref):
     return None
 
 
-def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None, topo_flags=0, split=0, tiles=None):
-    """(StepHints, keep-alive tuple) from numpy arrays: int32 per-mini-batch tables, or int64 set tables + int32 ids."""
+def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None, topo_flags=0, tiles=None, plan=None):
+    """(StepHints, keep-alive tuple) from numpy arrays: int32 per-mini-batch tables, or int64 set tables + int32 ids;
+    ``plan``: the StepPlan the caller sized its buffers from."""
     import numpy as np
     h = StepHints()
     keep = []
@@ -554,8 +580,11 @@ def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=Non
         return a.ctypes.data
     h.host_node_ptr, h.host_edge_ptr = pin(node_ptr, np.int32), pin(edge_ptr, np.int32)
     h.set_node_ptr, h.set_edge_ptr, h.host_ids = pin(set_node_ptr, np.int64), pin(set_edge_ptr, np.int64), pin(ids, np.int32)
-    h.topo_flags, h.split = int(topo_flags), int(split)
+    h.topo_flags = int(topo_flags)
     h.tiles = _ptr(tiles)
     if tiles is not None:
         keep.append(tiles)
+    if plan is not None:
+        h.plan = ctypes.addressof(plan)
+        keep.append(plan)
     return h, tuple(keep)

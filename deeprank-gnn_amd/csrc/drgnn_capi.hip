@@ -596,16 +596,7 @@ int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes
 
 int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O) { return head_compact_floats(R, H, O); }
 
-// ---- launch layout of the GINet step: two workgroups per graph (branches in parallel, readouts exchanged) only while
-// EVERY workgroup of the launch is resident -- these kernels use more than half a CU's LDS, i.e. one workgroup per CU --
-// otherwise one workgroup per graph runs both branches (drgnn_step1.h), which never waits for another workgroup.
-// 0: by residency; 1: always one workgroup per graph (tests, A/B runs); 2: always two (MEASUREMENT ONLY: beyond the
-// resident size this is the pre-round-3 schedule, whose exchange leans on in-order dispatch; bounded spin + fault bit)
-static int g_step_layout_mode = 0;
-static int g_step_class_mode = 0;          // 0: capacity-class kernels where a batch fits the class (default); 1: never (A/B runs, tests)
-static int g_step2_mode = 0;               // 0: sGAT / FoutNet may take the aggregation-first kernels (drgnn_step2.h); 1: never
-static int g_step2_split_mode = 0;         // 0: ... with two workgroups per graph where the plan allows; 1: never split (A/B runs)
-static int g_step3_mode = 0;               // 0: GINet may take the aggregation-first kernels (drgnn_step3.h); 1: never (A/B runs, tests)
+// ---- launch plan of the fused step (include/drgnn.h: drgnn_step_plan) ---------------------------------------------------
 // CUs this process may count on for co-residency of a launch's workgroups: the device's CU count, per device id (ADVICE r03:
 // a process may drive devices of different sizes).  DRGNN_RESIDENT_CUS=<n> overrides it (a CU mask -- HSA_CU_MASK /
 // ROC_GLOBAL_CU_MASK -- or a share of the GPU leaves fewer CUs than the attribute says); DRGNN_SHARED_GPU=1 means "assume
@@ -634,101 +625,194 @@ static int device_cu_count() {
 #ifndef DRGNN_EMU
 static int step_current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess ? dev : 0; }
 #endif
-static bool step_two_workgroups_ok(int64_t n_graphs, int64_t other_workgroups) {
-    if (g_step_layout_mode == 1) return false;
-    if (g_step_layout_mode == 2) return true;
-    return 2 * n_graphs + other_workgroups <= device_cu_count();
+
+// the overrides of a plan (all 0 = automatic).  DRGNN_STEP_PLAN=<one|two|noclass|product|nosplit|seq>[,...] (read once) gives
+// the defaults of a process for launches whose plan overrides nothing: same-box A/B runs of whole programs
+struct StepOverrides { int force_wgs, no_class, no_aggregate, no_split, no_paired; };
+static StepOverrides step_env_overrides() {
+    static int parsed = 0;
+    static StepOverrides env = {0, 0, 0, 0, 0};
+    if (!parsed) {
+        StepOverrides o = {0, 0, 0, 0, 0};
+        const char* v = getenv("DRGNN_STEP_PLAN");
+        if (v) {
+            if (strstr(v, "one")) o.force_wgs = 1;
+            if (strstr(v, "two")) o.force_wgs = 2;
+            if (strstr(v, "noclass")) o.no_class = 1;
+            if (strstr(v, "product")) o.no_aggregate = 1;
+            if (strstr(v, "nosplit")) o.no_split = 1;
+            if (strstr(v, "seq")) o.no_paired = 1;
+        }
+        env = o;
+        parsed = 1;
+    }
+    return env;
 }
-static int g_step1_paired_mode = 1;         // 1: both branches per phase whenever its LDS plan fits (default); 0: never (A/B runs)
+static StepOverrides step_overrides_of(const drgnn_step_plan* p) {
+    if (p && (p->force_wgs || p->no_class || p->no_aggregate || p->no_split || p->no_paired))
+        return StepOverrides{p->force_wgs, p->no_class, p->no_aggregate, p->no_split, p->no_paired};
+    return step_env_overrides();
+}
+
 static int64_t step1_lds_bytes_form(int F, int capN, int capE, int capC, int H, int O, int paired) {
     return 4 * step1_scratch_words(F, capN, capE, capC, H, O, paired);
 }
-// the one-workgroup layout's LDS need: its paired form if that fits, else the branch-after-branch form
-static int64_t step1_lds_bytes(int F, int capN, int capE, int capC, int H, int O, bool* paired_out = nullptr) {
-    const int64_t p = step1_lds_bytes_form(F, capN, capE, capC, H, O, 1);
-    const bool paired = g_step1_paired_mode != 0 && p <= DRGNN_LDS_LIMIT;
-    if (paired_out) *paired_out = paired;
-    return paired ? p : step1_lds_bytes_form(F, capN, capE, capC, H, O, 0);
-}
-// shape conditions of the aggregation-first kernels (without the x pointer's alignment: checked at the launch)
-static bool step2_shape_ok(int kind, int F, int capN, int capE, int capC, int H, int O) {
-#ifdef DRGNN_EMU
-    (void)kind; (void)F; (void)capN; (void)capE; (void)capC; (void)H; (void)O;
-    return false;
-#else
-    if (kind == DRGNN_GINET || g_step2_mode != 0) return false;
-    if (step_pad16(F) != 32 || !step_burst_guaranteed(kind, nullptr, F, capN, capE, capC, H, O)) return false;
-    return 4 * step2_scratch_words(kind, F, capN, capE, capC, H, O) <= DRGNN_LDS_LIMIT;
-#endif
-}
-// shape conditions of GINet's aggregation-first kernels (drgnn_step3.h)
-static bool step3_shape_ok(int kind, int F, int capN, int capE, int capC, int H, int O) {
-#ifdef DRGNN_EMU
-    (void)kind; (void)F; (void)capN; (void)capE; (void)capC; (void)H; (void)O;
-    return false;
-#else
-    if (kind != DRGNN_GINET || g_step3_mode != 0) return false;
-    if (step_pad16(F) != 32 || !step_burst_guaranteed(kind, nullptr, F, capN, capE, capC, H, O)) return false;
-    return 4 * step3_scratch_words(F, capN, capE, capC, H, O) <= DRGNN_LDS_LIMIT;
-#endif
-}
-static bool step2_split_plan_ok(int kind, int F, int capN, int capE, int capC, int H, int O, int64_t n_graphs, int64_t co_built) {
-    if (g_step2_split_mode != 0 || !step2_shape_ok(kind, F, capN, capE, capC, H, O)) return false;
-    return step_two_workgroups_ok(n_graphs, co_built);      // (the builder at ONE workgroup per graph if two do not fit)
-}
-int32_t drgnn_net_step_family(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t H,
-                              int32_t O) {
-    if (max_nodes <= 0 || max_nodes > 32767 || max_edges > 65535 || n_feat > 256) return 0;
-    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
-    if (kind == DRGNN_GINET) return step3_shape_ok(kind, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, H, O) ? 1 : 0;
-    return step2_shape_ok(kind, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, H, O) ? 1 : 0;
-}
-int64_t drgnn_net_step_xchg_elems(int32_t kind, int32_t max_nodes, int32_t max_c0, int32_t H) {
-    if (kind == DRGNN_GINET) return 2 * (int64_t)(H > DRGNN_H2 ? H : DRGNN_H2);
-    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
-    return step2_xchg_words(capC > 0 ? capC : 1);
-}
-int32_t drgnn_set_step_layout(int32_t mode) {
-    if (mode == 3 || mode == 4) { g_step1_paired_mode = (mode == 4); return 0; }   // (A/B: 3 = branch after branch, 4 = paired)
-    if (mode == 5 || mode == 6) { g_step_class_mode = (mode == 6) ? 1 : 0; return 0; }   // (5 = capacity-class kernels allowed, 6 = never)
-    if (mode == 7 || mode == 8) { g_step2_mode = (mode == 8) ? 1 : 0; return 0; }          // (7 = aggregation-first kernels allowed, 8 = never)
-    if (mode == 9 || mode == 10) { g_step2_split_mode = (mode == 10) ? 1 : 0; return 0; }  // (9 = their split layout allowed, 10 = never)
-    if (mode == 11 || mode == 12) { g_step3_mode = (mode == 12) ? 1 : 0; return 0; }       // (11 = GINet's aggregation-first kernels allowed, 12 = never)
-    if (mode < 0 || mode > 2) return DRGNN_E_ARG;
-    g_step_layout_mode = mode;
-    return 0;
-}
-int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t R,
-                            int32_t H, int32_t O, int64_t n_graphs, int64_t co_built_graphs, int64_t* lds_bytes) {
-    if (lds_bytes) *lds_bytes = 0;
-    if (max_nodes <= 0 || max_nodes > 32767 || max_edges > 65535 || n_feat > 256 || n_graphs < 0) return 0;   // the launch pair
-    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
-    const int capE = max_edges > 0 ? max_edges : 1;
-    if (kind != DRGNN_GINET) {
-        // the node-split layout: two workgroups per graph while all of them (+ the co-launched builder, at two or one
-        // workgroup per graph) are resident, 32-wide specialised shape, reference head
-        if (step2_split_plan_ok(kind, n_feat, max_nodes, capE, capC, H, O, n_graphs, co_built_graphs > 0 ? co_built_graphs : 0)) {
-            if (lds_bytes) *lds_bytes = 4 * step2_scratch_words(kind, n_feat, max_nodes, capE, capC, H, O);
-            return 2;
-        }
-        if (lds_bytes) *lds_bytes = step_lds_bytes(kind, n_feat, max_nodes, capE, capC, R, H, O);
-        return 1;
-    }
-    // builder workgroups of the topology co-built by the same launch
-    // (the builder takes ONE workgroup per graph when two would push the launch past the device: train_step_impl)
-    const int64_t extra = co_built_graphs > 0 ? co_built_graphs : 0;
-    if (H >= DRGNN_H2 && step_two_workgroups_ok(n_graphs, extra)) {
-        if (lds_bytes) *lds_bytes = step_lds_bytes(kind, n_feat, max_nodes, capE, capC, R, H, O);
-        return 2;
-    }
-    if (lds_bytes) *lds_bytes = step1_lds_bytes(n_feat, max_nodes, capE, capC, H, O);
-    return 1;
-}
-
+// padded feature width of the width-specialised kernels a launch of these bounds may take (16 / 32 / 48 / 64), 0 = generic.
+// x == nullptr: alignment not judged here
 static int step_variant(int kind, const float* x, int F, int capN, int capE, int capC, int H, int O) {
     if (!step_burst_guaranteed(kind, x, F, capN, capE, capC, H, O)) return 0;
     const int f16 = step_pad16(F);
     return (f16 == 16 || f16 == 32 || f16 == 48 || f16 == 64) ? f16 : 0;
+}
+
+// what a launch is, as far as its layout goes
+struct StepAsk {
+    int kind, F, capN, capE, capC, R, H, O;
+    int64_t B;
+    int64_t co;             // graphs of the topology the launch co-builds (0: none, or not co-launchable)
+    int co_roles;           // workgroups per graph that builder may take: 2 or 1
+    bool train;
+    bool x_ok;              // x is 16-byte aligned (or not known to be otherwise)
+    int topo_flags;         // HIER / TILES (tiles usable) / LEAN of the workspace the launch reads
+    int commit_wgs;         // single-branch nets: workgroups per graph the caller sized its buffers for (0: free choice)
+    StepOverrides ov;
+};
+enum { SK_STEP = 0, SK_STEP1 = 1, SK_AF2 = 2, SK_AF3 = 3, SK_AF3B = 4 };
+struct StepPick {
+    int rc;                 // 0, or the error a launch of this shape returns (family NONE)
+    int family, kernel, wgs, slabs, width, cls, paired, lean_ok, builder_roles;
+    int64_t lds, xchg_words;
+    int capN, capE, capC;   // the LDS capacities the kernel is launched with (the class's when cls)
+};
+static const int64_t STEP_LDS_NEVER = (int64_t)1 << 50;
+
+static StepPick step_pick(const StepAsk& q) {
+    StepPick k;
+    memset(&k, 0, sizeof(k));
+    k.capN = q.capN; k.capE = q.capE; k.capC = q.capC;
+    k.builder_roles = q.co > 0 ? q.co_roles : 0;
+    k.slabs = (q.kind == DRGNN_GINET) ? 2 : 1;
+    const int cus = device_cu_count();
+    const int64_t co = q.co > 0 ? q.co : 0;
+    auto two_ok = [&](int64_t extra) {
+        if (q.ov.force_wgs == 1) return false;
+        if (q.ov.force_wgs == 2) return true;
+        return 2 * q.B + extra <= cus;
+    };
+    // the aggregation-first family: a workspace with the hierarchical order and usable tiles, a width class, the reference head
+    k.width = step_variant(q.kind, nullptr, q.F, q.capN, q.capE, q.capC, q.H, q.O);
+    if (!q.x_ok) k.width = 0;
+#ifdef DRGNN_EMU
+    const bool af_shape = false;
+#else
+    const bool af_shape = !q.ov.no_aggregate && (q.topo_flags & DRGNN_TOPO_HIER) && (q.topo_flags & DRGNN_TOPO_TILES) && k.width != 0;
+#endif
+    if (q.kind == DRGNN_GINET) {
+        const bool narrow = q.H < DRGNN_H2;      // (the exchange words of a graph are 2 x 32 of its 2 x H: a narrower head runs one workgroup per graph)
+        const int64_t l2af = af_shape ? 4 * step3_scratch_words(q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
+        const int64_t l2old = step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O);
+        const int64_t l1af = af_shape ? 4 * step3b_scratch_words(q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
+        const int64_t l1p = step1_lds_bytes_form(q.F, q.capN, q.capE, q.capC, q.H, q.O, 1);
+        const bool paired = !q.ov.no_paired && l1p <= DRGNN_LDS_LIMIT;
+        const int64_t l1old = paired ? l1p : step1_lds_bytes_form(q.F, q.capN, q.capE, q.capC, q.H, q.O, 0);
+        const bool af_two = l2af <= DRGNN_LDS_LIMIT, af_one = l1af <= DRGNN_LDS_LIMIT;
+        const bool can_two = !narrow && (af_two || l2old <= DRGNN_LDS_LIMIT);
+        const bool can_one = af_one || l1old <= DRGNN_LDS_LIMIT;
+        // two workgroups per graph only while every workgroup of the launch is resident -- with the builder at two
+        // workgroups per graph if that fits, else at one; else one workgroup per graph; else two with the builder on its own
+        int wgs = 0;
+        if (can_two && two_ok(co * k.builder_roles)) wgs = 2;
+        else if (can_two && k.builder_roles == 2 && two_ok(co)) { wgs = 2; k.builder_roles = 1; }
+        else if (can_one) wgs = 1;
+        else if (can_two && two_ok(0)) { wgs = 2; k.builder_roles = 0; }
+        else { k.rc = DRGNN_E_CAPACITY; return k; }
+        k.wgs = wgs;
+        if (wgs == 2) { k.kernel = af_two ? SK_AF3 : SK_STEP; k.lds = af_two ? l2af : l2old; }
+        else { k.kernel = af_one ? SK_AF3B : SK_STEP1; k.lds = af_one ? l1af : l1old; k.paired = (!af_one && paired) ? 1 : 0; }
+        k.xchg_words = 2 * (int64_t)(q.H > DRGNN_H2 ? q.H : DRGNN_H2);
+    } else {
+        const int64_t laf = af_shape ? 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
+        const int64_t lold = step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O);
+        const bool af_ok = laf <= DRGNN_LDS_LIMIT;
+        // the node-split layout: training launches of the aggregation-first kernels under GINet's residency rule
+        int wgs = 1;
+        const bool may_split = q.train && af_ok && !q.ov.no_split;
+        if (q.commit_wgs == 2) {
+            // the caller sized its buffers for two workgroups per graph: no silent fallback to another layout
+            if (!may_split) { k.rc = DRGNN_E_CAPACITY; return k; }
+            if (two_ok(co * k.builder_roles)) wgs = 2;
+            else if (k.builder_roles == 2 && two_ok(co)) { wgs = 2; k.builder_roles = 1; }
+            else if (two_ok(0)) { wgs = 2; k.builder_roles = 0; }
+            else { k.rc = DRGNN_E_CAPACITY; return k; }
+        } else if (q.commit_wgs == 0 && may_split) {
+            if (two_ok(co * k.builder_roles)) wgs = 2;
+            else if (k.builder_roles == 2 && two_ok(co)) { wgs = 2; k.builder_roles = 1; }
+        }
+        k.wgs = wgs;
+        if (af_ok) { k.kernel = SK_AF2; k.lds = laf; }
+        else if (lold <= DRGNN_LDS_LIMIT) { k.kernel = SK_STEP; k.lds = lold; }
+        else { k.rc = DRGNN_E_CAPACITY; return k; }
+        k.slabs = wgs;
+        k.xchg_words = (wgs == 2) ? step2_xchg_words(q.capC > 0 ? q.capC : 1) : 0;
+    }
+    // one round of workgroups instead of two: the builder at ONE workgroup per graph when that makes the launch resident
+    // (measured, tools/r03_split_sweep.sh: sGAT at batch 128, 128 step + 256 builder workgroups = two rounds, 37.2 us per
+    // step; 128 + 128 = one round, 29.0 us)
+    if (k.builder_roles == 2 && k.wgs == 1 && q.B + 2 * co > cus && q.B + co <= cus) k.builder_roles = 1;
+    k.lean_ok = (k.kernel == SK_AF2 || k.kernel == SK_AF3 || k.kernel == SK_AF3B) ? 1 : 0;
+    k.family = k.lean_ok ? DRGNN_STEP_FAMILY_AGGREGATE : DRGNN_STEP_FAMILY_PRODUCT;
+    // Capacity class (drgnn_step.h: STEP_CLS_*): a batch whose maxima lie inside the class is stepped by the 32-wide kernels
+    // whose LDS layout is a compile-time constant (of the one-workgroup product-first GINet layouts the paired form; of the
+    // aggregation-first kernels the training instances)
+#ifndef DRGNN_EMU
+    if (!q.ov.no_class && k.width == 32 && q.capN <= STEP_CLS_N && q.capE <= STEP_CLS_E && q.capC <= STEP_CLS_C &&
+        !(k.kernel == SK_STEP1 && !k.paired) && !(k.lean_ok && !q.train) &&
+        step_variant(q.kind, nullptr, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O) == 32) {
+        const int64_t lc = k.kernel == SK_AF3B ? 4 * step3b_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
+                         : k.kernel == SK_AF3 ? 4 * step3_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
+                         : k.kernel == SK_AF2 ? 4 * step2_scratch_words(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
+                         : k.kernel == SK_STEP1 ? step1_lds_bytes_form(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O, 1)
+                                                : step_lds_bytes(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.R, q.H, q.O);
+        if (lc <= DRGNN_LDS_LIMIT) {
+            k.cls = 1;
+            k.capN = STEP_CLS_N; k.capE = STEP_CLS_E; k.capC = STEP_CLS_C;
+            k.lds = lc;
+        }
+    }
+#endif
+    return k;
+}
+
+static bool step_bounds_ok(int32_t max_nodes, int32_t max_edges, int32_t n_feat) {
+    return max_nodes > 0 && max_nodes <= 32767 && max_edges <= 65535 && n_feat <= 256;
+}
+
+int32_t drgnn_net_step_plan(drgnn_step_plan* p) {
+    if (!p) return 0;
+    p->family = DRGNN_STEP_FAMILY_NONE; p->wgs_per_graph = 0; p->slabs_per_graph = 0; p->width = 0; p->cls = 0; p->lean_ok = 0;
+    p->builder_wgs_per_graph = 0; p->lds_bytes = 0; p->xchg_words = 0;
+    if (!step_bounds_ok(p->max_nodes, p->max_edges, p->n_feat) || p->n_graphs < 0 || p->H < 1 || p->H > 512 || p->O < 1 ||
+        p->O > DRGNN_MAX_OUT || p->kind < 0 || p->kind > DRGNN_FOUT)
+        return 0;
+    StepAsk q;
+    q.kind = p->kind; q.F = p->n_feat; q.capN = p->max_nodes; q.capE = p->max_edges > 0 ? p->max_edges : 1;
+    q.capC = (p->max_c0 > 0 && p->max_c0 < p->max_nodes) ? p->max_c0 : p->max_nodes;
+    q.R = p->R; q.H = p->H; q.O = p->O; q.B = p->n_graphs;
+    q.co = p->co_built_graphs > 0 ? p->co_built_graphs : 0;
+    q.co_roles = (q.co > 0 && q.co <= DRGNN_TOPO_SPLIT_MAX_GRAPHS) ? 2 : 1;
+    q.train = p->train != 0; q.x_ok = true; q.topo_flags = p->topo_flags; q.commit_wgs = 0;
+    q.ov = step_overrides_of(p);
+    const StepPick k = step_pick(q);
+    if (k.rc) return 0;
+    p->family = k.family; p->wgs_per_graph = k.wgs; p->slabs_per_graph = k.slabs; p->width = k.width; p->cls = k.cls;
+    p->lean_ok = k.lean_ok; p->builder_wgs_per_graph = k.builder_roles; p->lds_bytes = k.lds; p->xchg_words = k.xchg_words;
+    return k.wgs;
+}
+
+int64_t drgnn_net_step_xchg_elems(int32_t kind, int32_t max_nodes, int32_t max_c0, int32_t H) {
+    if (kind == DRGNN_GINET) return 2 * (int64_t)(H > DRGNN_H2 ? H : DRGNN_H2);
+    const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    return step2_xchg_words(capC > 0 ? capC : 1);
 }
 
 int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
@@ -736,6 +820,68 @@ int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int
     const int capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
     return step_variant(kind, x, n_feat, max_nodes, max_edges > 0 ? max_edges : 1, capC, H, O);
 }
+
+#ifndef DRGNN_EMU
+// the product-first kernels (drgnn_step.h / drgnn_step1.h) by template arguments
+static drgnn_step_kernel_t step_old_kernel(int kind, int width, bool gather, int cls) {
+#define DRGNN_OLD_G(K, XF, CL) (gather ? (drgnn_step_kernel_t)k_step_co_topo<K, XF, true, CL> : (drgnn_step_kernel_t)k_step_co_topo<K, XF, false, CL>)
+#define DRGNN_OLD_W(K)                                                          \
+    switch (width) {                                                            \
+        case 16: return DRGNN_OLD_G(K, 16, 0);                                  \
+        case 32: return cls ? DRGNN_OLD_G(K, 32, 1) : DRGNN_OLD_G(K, 32, 0);    \
+        case 48: return DRGNN_OLD_G(K, 48, 0);                                  \
+        case 64: return DRGNN_OLD_G(K, 64, 0);                                  \
+        default: return DRGNN_OLD_G(K, 0, 0);                                   \
+    }
+    if (kind == DRGNN_GINET) { DRGNN_OLD_W(DRGNN_GINET) }
+    if (kind == DRGNN_SGAT) { DRGNN_OLD_W(DRGNN_SGAT) }
+    DRGNN_OLD_W(DRGNN_FOUT)
+#undef DRGNN_OLD_W
+#undef DRGNN_OLD_G
+}
+static drgnn_step_kernel_t step_old1_kernel(int width, bool gather, bool paired, int cls) {
+#define DRGNN_OLD1(XF, P, CL) (gather ? (drgnn_step_kernel_t)k_step1_co_topo<XF, true, P, CL> : (drgnn_step_kernel_t)k_step1_co_topo<XF, false, P, CL>)
+    if (paired) {
+        if (cls) return DRGNN_OLD1(32, true, 1);
+        return width == 32 ? DRGNN_OLD1(32, true, 0) : DRGNN_OLD1(0, true, 0);
+    }
+    switch (width) {
+        case 16: return DRGNN_OLD1(16, false, 0);
+        case 32: return DRGNN_OLD1(32, false, 0);
+        case 48: return DRGNN_OLD1(48, false, 0);
+        case 64: return DRGNN_OLD1(64, false, 0);
+        default: return DRGNN_OLD1(0, false, 0);
+    }
+#undef DRGNN_OLD1
+}
+// One launch of a step kernel instance (+ the co-launched builder's workgroups).  These kernels use up to the whole 160 KiB of
+// LDS: the attribute is raised once per kernel instance and device (the call costs host time on every launch otherwise).
+static int step_launch(drgnn_step_kernel_t kern, int64_t lds_bytes, unsigned grid, hipStream_t stream, const StepCoLaunch& C) {
+    if (!kern) return DRGNN_E_ARG;
+    if (lds_bytes > 64 * 1024) {
+        struct Seen { const void* fn; int dev; };
+        static Seen seen[256];
+        static int n_seen = 0;
+        const int dev = step_current_device();
+        bool known = false;
+        const int n = __atomic_load_n(&n_seen, __ATOMIC_ACQUIRE);
+        for (int i = 0; i < n && !known; ++i) known = seen[i].fn == (const void*)kern && seen[i].dev == dev;
+        if (!known) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) != hipSuccess) {
+                (void)hipGetLastError();      // (profiling builds carry a static LDS word: ask for what this launch needs)
+                HIP_TRY(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            } else {
+                // (a cache, not state: a lost race only repeats the idempotent call above)
+                const int slot = __atomic_fetch_add(&n_seen, 0, __ATOMIC_RELAXED);
+                if (slot < 256) { seen[slot].fn = (const void*)kern; seen[slot].dev = dev; __atomic_store_n(&n_seen, slot + 1, __ATOMIC_RELEASE); }
+            }
+        }
+    }
+    void* args[] = {const_cast<StepCoLaunch*>(&C)};
+    HIP_TRY(hipLaunchKernel((const void*)kern, dim3(grid), dim3(DRGNN_NTHREADS), args, (size_t)lds_bytes, stream));
+    return 0;
+}
+#endif
 
 // n_graphs graphs of the launch; (n_nodes, n_edges, ws_graphs): the shape the workspace was laid out for (the
 // mini-batch itself, or a whole cached set whose graphs gather_ids[0..n_graphs) are stepped)
@@ -752,65 +898,56 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         return DRGNN_E_ARG;
     if (hd->train && (!target || !head_partials || !partials)) return DRGNN_E_ARG;      // inference needs neither
     if (net->n_branch > 1 && !xchg) return DRGNN_E_ARG;
-    // (the exchange words of a graph are n_branch x DRGNN_H2 of its n_branch x H: a GINet head narrower than that is stepped by
-    // the one-workgroup layout, which exchanges nothing -- drgnn_net_step_plan says so too)
-    const bool narrow_head = net->n_branch > 1 && hd->H < DRGNN_H2;
     if (net->kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
     if (hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
         return DRGNN_E_WIDTH;
-    if (max_nodes <= 0 || max_nodes > 32767 || max_edges > 65535 || net->n_feat > 256) return DRGNN_E_CAPACITY;
-    StepLaunch L;
-    L.capN = max_nodes;
-    L.capE = max_edges > 0 ? max_edges : 1;
-    L.capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    if (!step_bounds_ok(max_nodes, max_edges, net->n_feat)) return DRGNN_E_CAPACITY;
     const int kind = net->kind, F = net->n_feat;
-    int64_t lds = step_lds_bytes(kind, F, L.capN, L.capE, L.capC, hd->R, hd->H, hd->O);
-    // sGAT / FoutNet: the aggregation-first kernels (drgnn_step2.h) for training launches of the 32-wide specialised shape on
-    // a topology the caller vouches to hold the hierarchical order; with two workgroups per graph when the caller asks for it
-    int af_split = 0;        // 0: the drgnn_step.h kernel; 1 / 2: drgnn_step2.h with that many workgroups per graph
-    const int capC_rt = L.capC;
-#ifndef DRGNN_EMU
-    if (kind != DRGNN_GINET) {
-        const bool want_split = hints && hints->split == 1;
-        const bool hier = hints && (hints->topo_flags & DRGNN_TOPO_HIER) != 0;
-        const bool tiles = hints && (hints->topo_flags & DRGNN_TOPO_TILES) && hints->tiles && ((((uintptr_t)hints->tiles) & 15) == 0);
-        // (the caller vouches for the tiles' flavour: weighted sums for sGAT, plain sums for FoutNet / GINet)
-        const bool shape = hd->train && hier && tiles && ((((uintptr_t)x) & 15) == 0) &&
-                           step2_shape_ok(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
-        if (want_split) {
-            if (!shape || !xchg) return DRGNN_E_CAPACITY;
-            af_split = 2;
-        } else if (shape) {
-            af_split = 1;
-        }
-        if (af_split) lds = 4 * step2_scratch_words(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
+    // the co-launched builder of the next mini-batch's topology
+    TopoLaunch T;
+    int64_t tlds = 0;
+    bool co_ok = false;
+    if (next) {
+        rc = topo_prepare_req(T, &tlds, next);
+        if (rc) return rc;
+        co_ok = T.capN > 0 && T.user_nptr != nullptr && !(T.args.cluster1 != nullptr && T.args.c1_ptr == nullptr) &&
+                T.args.n_graphs > 0 && n_graphs > 0;
+        // the builder inside a GINet / FoutNet step launch is compiled without the edge-weight path: a request that wants
+        // weights (another kind's topology) gets a launch of its own
+        if (kind != DRGNN_SGAT && T.args.edge_attr != nullptr && T.tv.w0 != nullptr) co_ok = false;
     }
-    // GINet: the aggregation-first kernels (drgnn_step3.h) for training launches of the 32-wide specialised shape in the
-    // two-workgroup layout on a topology that holds the hierarchical order
-    bool af3 = false;
-    if (kind == DRGNN_GINET) {
-        const bool hier = hints && (hints->topo_flags & DRGNN_TOPO_HIER) != 0;
-        const bool tiles = hints && (hints->topo_flags & DRGNN_TOPO_TILES) && hints->tiles && ((((uintptr_t)hints->tiles) & 15) == 0);
-        af3 = hd->train && hier && tiles && step3_shape_ok(kind, F, L.capN, L.capE, L.capC, hd->H, hd->O);
-    }
-#else
-    if (hints && hints->split == 1) return DRGNN_E_CAPACITY;      // (the emulation build has no node-split kernels)
-    const bool af3 = false;
-#endif
-    // GINet: one workgroup per graph unless all of 2 B (+ the builder's) workgroups are resident at once; decided below,
-    // once the co-launched builder's size is known
-    const bool two_alone = (net->n_branch == 2 || af_split == 2) && !narrow_head && step_two_workgroups_ok(n_graphs, 0);
-    bool one_paired = false;
-    const int64_t lds1 = (net->n_branch == 2) ? step1_lds_bytes(F, L.capN, L.capE, L.capC, hd->H, hd->O, &one_paired) : 0;
-    if (net->n_branch == 2 && !two_alone) {
-        if (lds1 > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
-    } else if (lds > DRGNN_LDS_LIMIT) return DRGNN_E_CAPACITY;
-    L.words = lds / 4;
+    // ---- the layout: one decision procedure for this launch and for drgnn_net_step_plan ----------------------------------
+    StepAsk q;
+    q.kind = kind; q.F = F; q.capN = max_nodes; q.capE = max_edges > 0 ? max_edges : 1;
+    q.capC = (max_c0 > 0 && max_c0 < max_nodes) ? max_c0 : max_nodes;
+    q.R = hd->R; q.H = hd->H; q.O = hd->O; q.B = n_graphs;
+    q.co = co_ok ? (int64_t)T.args.n_graphs : 0;
+    q.co_roles = co_ok ? T.roles : 1;
+    q.train = hd->train != 0;
+    q.x_ok = (((uintptr_t)x) & 15) == 0;
+    q.topo_flags = hints ? hints->topo_flags : 0;
+    // (the caller vouches for the tiles' flavour: weighted sums for sGAT, plain sums for FoutNet / GINet)
+    if (!(hints && hints->tiles && ((((uintptr_t)hints->tiles) & 15) == 0))) q.topo_flags &= ~DRGNN_TOPO_TILES;
+    const drgnn_step_plan* plan = hints ? hints->plan : nullptr;
+    q.ov = step_overrides_of(plan);
+    q.commit_wgs = (kind == DRGNN_GINET) ? 0 : (plan && plan->wgs_per_graph == 2) ? 2 : 1;
+    if (q.commit_wgs == 2 && !xchg) return DRGNN_E_CAPACITY;
+    const StepPick k = step_pick(q);
+    if (k.rc) return k.rc;
+    // a workspace built with DRGNN_TOPO_LEAN holds only what the aggregation-first kernels read
+    if (hints && (hints->topo_flags & DRGNN_TOPO_LEAN) && !k.lean_ok) return DRGNN_E_ARG;
+    if (co_ok && k.builder_roles == 0) co_ok = false;      // the builder gets a launch of its own
+    if (co_ok) T.roles = k.builder_roles;
+    const bool one_wg = (kind == DRGNN_GINET) && k.wgs == 1;
+
+    StepLaunch L;
+    L.capN = k.capN; L.capE = k.capE; L.capC = k.capC;
+    L.words = k.lds / 4;
     TopoLayout lay;
     topo_layout(n_nodes, n_edges, ws_graphs, &lay);
     StepArgs& a = L.a;
     a.gather_ids = gather_ids; a.ws_graphs = (int)ws_graphs;
-    a.tiles = (hints && (hints->topo_flags & DRGNN_TOPO_TILES)) ? hints->tiles : nullptr; a.tile_nodes = n_nodes;
+    a.tiles = (q.topo_flags & DRGNN_TOPO_TILES) ? hints->tiles : nullptr; a.tile_nodes = n_nodes;
     L.dims.count = 0;
     // host-known graph numbers of a cached-topology launch are range-checked whatever the batch size: the kernel reads the
     // set's tables at gather_ids[g] as is
@@ -825,7 +962,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
                 D.n0[g] = hints->host_node_ptr[g]; D.n[g] = hints->host_node_ptr[g + 1] - hints->host_node_ptr[g];
                 D.e0[g] = hints->host_edge_ptr[g]; D.e[g] = hints->host_edge_ptr[g + 1] - hints->host_edge_ptr[g];
                 D.gi[g] = g;
-                ok = ok && D.n[g] >= 0 && D.e[g] >= 0 && D.n[g] <= L.capN && D.e[g] <= L.capE;
+                ok = ok && D.n[g] >= 0 && D.e[g] >= 0 && D.n[g] <= q.capN && D.e[g] <= q.capE;
             }
             if (ok && (hints->host_node_ptr[n_graphs] != n_nodes || hints->host_edge_ptr[n_graphs] != n_edges)) ok = false;
         } else if (gather_ids && hints->host_ids && hints->set_node_ptr && hints->set_edge_ptr) {
@@ -835,7 +972,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
                 D.n0[g] = (int32_t)hints->set_node_ptr[id]; D.n[g] = (int32_t)(hints->set_node_ptr[id + 1] - hints->set_node_ptr[id]);
                 D.e0[g] = (int32_t)hints->set_edge_ptr[id]; D.e[g] = (int32_t)(hints->set_edge_ptr[id + 1] - hints->set_edge_ptr[id]);
                 D.gi[g] = (int32_t)id;
-                ok = ok && D.n[g] <= L.capN && D.e[g] <= L.capE;
+                ok = ok && D.n[g] <= q.capN && D.e[g] <= q.capE;
             }
         } else {
             ok = false;
@@ -847,7 +984,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     a.n_nodes = n_nodes; a.n_graphs = (int)n_graphs;
     a.partials = partials; a.n_partial = (int)net_partial_floats(F);
     a.xchg = (unsigned long long*)xchg; a.step2 = step2;
-    a.xchg_stride = (int)step2_xchg_words(capC_rt > 0 ? capC_rt : 1);
+    a.xchg_stride = (int)step2_xchg_words(q.capC > 0 ? q.capC : 1);
     HeadFused& hf = a.hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
     hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0; hf.train = hd->train ? 1 : 0; hf.sigmoid = hd->transform_sigmoid;
@@ -857,83 +994,8 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
     hf.readout = readout; hf.step = step2; hf.pred = pred; hf.partials = head_partials; hf.stage = 0;
 
-    // grid of the step part: graphs in groups of 8 x n_branch (see step_block)
-    int blocks = (net->n_branch == 2 || af_split == 2) ? (int)((n_graphs + 7) / 8) * 16 : (int)n_graphs;
-    TopoLaunch T;
-    int64_t tlds = 0;
-    bool co_ok = false;
-    if (next) {
-        rc = topo_prepare_req(T, &tlds, next);
-        if (rc) return rc;
-        co_ok = T.capN > 0 && T.user_nptr != nullptr && !(T.args.cluster1 != nullptr && T.args.c1_ptr == nullptr) &&
-                T.args.n_graphs > 0 && blocks > 0;
-        // the builder inside a GINet / FoutNet step launch is compiled without the edge-weight path: a request that wants
-        // weights (another kind's topology) gets a launch of its own
-        if (kind != DRGNN_SGAT && T.args.edge_attr != nullptr && T.tv.w0 != nullptr) co_ok = false;
-    }
-    bool one_wg = false;       // GINet: both branches of a graph in one workgroup (drgnn_step1.h)
-    // The co-launched builder runs two workgroups per graph (shorter chains) or one (fewer workgroups, each ~1.6x longer):
-    // what counts is whether the WHOLE launch is resident at once.  Measured (tools/r03_split_sweep.sh): sGAT at batch 128,
-    // 128 step + 256 builder workgroups on 256 CUs = two rounds, 37.2 us per step; 128 + 128 = one round, 29.0 us.
-    const int cus = device_cu_count();
-    const int64_t bn = co_ok ? (int64_t)T.args.n_graphs : 0;
-    const bool split_ok = co_ok && T.roles == 2;
-    if (net->n_branch == 2) {
-        // two workgroups per graph only while every workgroup of the launch is resident -- with the builder at two
-        // workgroups per graph if that fits, else at one
-        if (!narrow_head && step_two_workgroups_ok(n_graphs, bn * (split_ok ? 2 : 1))) {
-        } else if (!narrow_head && split_ok && step_two_workgroups_ok(n_graphs, bn)) {
-            T.roles = 1;
-        } else if (lds1 <= DRGNN_LDS_LIMIT) {
-            one_wg = true;
-        } else if (two_alone) {
-            co_ok = false;      // the builder gets a launch of its own; 2 B workgroups are resident
-        } else {
-            return DRGNN_E_CAPACITY;
-        }
-        if (one_wg) { lds = lds1; L.words = lds / 4; blocks = (int)n_graphs; }
-#ifndef DRGNN_EMU
-        if (one_wg && af3) {      // both branches of a graph in one workgroup, from the tiles (net_step3_graph_both)
-            const int64_t lb = 4 * step3b_scratch_words(F, L.capN, L.capE, L.capC, hd->H, hd->O);
-            if (lb <= DRGNN_LDS_LIMIT) { lds = lb; L.words = lds / 4; } else af3 = false;
-        }
-        else if (af3) { lds = 4 * step3_scratch_words(F, L.capN, L.capE, L.capC, hd->H, hd->O); L.words = lds / 4; }
-#endif
-    } else if (af_split == 2) {
-        // the same residency rule for the two half-graph workgroups of the split layout (the caller sized its buffers for
-        // it: no silent fallback to another layout)
-        if (step_two_workgroups_ok(n_graphs, bn * (split_ok ? 2 : 1))) {
-        } else if (split_ok && step_two_workgroups_ok(n_graphs, bn)) {
-            T.roles = 1;
-        } else if (two_alone) {
-            co_ok = false;
-        } else {
-            return DRGNN_E_CAPACITY;
-        }
-    }
-    if (co_ok && T.roles == 2 && ((net->n_branch != 2 && af_split != 2) || one_wg) && blocks + 2 * bn > cus && blocks + bn <= cus)
-        T.roles = 1;            // one round of workgroups instead of two
-    // Capacity class (drgnn_step.h: STEP_CLS_*): a batch whose maxima lie inside the class is stepped by the kernels whose
-    // LDS layout is a compile-time constant (32-wide kernels; of the one-workgroup GINet layouts the paired form)
-    bool cls = false;
-#ifndef DRGNN_EMU
-    if ((!one_wg || one_paired || af3) && g_step_class_mode == 0 && L.capN <= STEP_CLS_N && L.capE <= STEP_CLS_E && L.capC <= STEP_CLS_C &&
-        step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32 &&
-        step_variant(kind, x, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O) == 32) {
-        const int64_t lds_cls = (one_wg && af3) ? 4 * step3b_scratch_words(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
-                                : one_wg ? step1_lds_bytes_form(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O, 1)
-                                : af3 ? 4 * step3_scratch_words(F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
-                                : af_split ? 4 * step2_scratch_words(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->H, hd->O)
-                                       : step_lds_bytes(kind, F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, hd->R, hd->H, hd->O);
-        if (lds_cls <= DRGNN_LDS_LIMIT) {
-            cls = true;
-            L.capN = STEP_CLS_N; L.capE = STEP_CLS_E; L.capC = STEP_CLS_C;
-            lds = lds_cls; L.words = lds / 4;
-        }
-    }
-#endif
-    // a workspace built with DRGNN_TOPO_LEAN holds only what the aggregation-first training kernels read
-    if (hints && (hints->topo_flags & DRGNN_TOPO_LEAN) && !(af_split != 0 || af3)) return DRGNN_E_ARG;
+    // grid of the step part: graphs in groups of 8 x 2 when a graph has two workgroups (see step_block)
+    const int blocks = (k.wgs == 2) ? (int)((n_graphs + 7) / 8) * 16 : (int)n_graphs;
     if (blocks > 0) {
 #ifdef DRGNN_EMU
         // workgroups run one after the other here: two passes (up to the readout exchange, then the
@@ -941,7 +1003,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         std::vector<float> slabs((size_t)blocks * (size_t)(L.words + 16));
         if (one_wg) {
             for (int b = 0; b < blocks; ++b) {
-                if (one_paired) {
+                if (k.paired) {
                     if (gather_ids) step_block_both<0, true, true>(L, b, slabs.data());
                     else step_block_both<0, false, true>(L, b, slabs.data());
                 } else {
@@ -969,170 +1031,21 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         }
         (void)stream_;
 #else
-        hipStream_t stream = (hipStream_t)stream_;
         StepCoLaunch C;
         C.step = L; C.n_net = blocks;
-        int64_t both = lds;
+        int64_t both = k.lds;
         int extra = 0;
-        if (co_ok) { C.topo = T; both = lds > tlds ? lds : tlds; extra = T.args.n_graphs * T.roles; }
-#define DRGNN_STEP_LAUNCH_G(K, XF, G) DRGNN_STEP_LAUNCH_GC(K, XF, G, 0)
-#define DRGNN_STEP_LAUNCH_GC(K, XF, G, CL)                                                                  \
-    do {                                                                                                    \
-        /* once per kernel instance and device: the whole 160 KiB (the call costs host time on every launch otherwise) */\
-        static int lds_set_on = -1;                                                                                   \
-        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
-            if (hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G, CL>,                                            \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
-                lds_set_on = step_current_device();                                                                   \
-            } else {      /* (profiling builds carry a static LDS word: ask for what this launch needs) */            \
-                (void)hipGetLastError();                                                                              \
-                HIP_TRY(hipFuncSetAttribute((const void*)k_step_co_topo<K, XF, G, CL>,                                    \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
-            }                                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL((k_step_co_topo<K, XF, G, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
-                           (size_t)both, stream, C);                                                        \
-    } while (0)
-#define DRGNN_STEP_LAUNCH(K, XF)                                                                            \
-    do { if (gather_ids) DRGNN_STEP_LAUNCH_G(K, XF, true); else DRGNN_STEP_LAUNCH_G(K, XF, false); } while (0)
-        // instantiated feature widths: F16 in {16, 32, 48, 64} (burst prologue guaranteed for the whole batch);
-        // anything else runs the generic kernel
-#define DRGNN_STEP_WIDTHS(K)                                                                                \
-    do {                                                                                                    \
-        switch (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O)) {                          \
-            case 16: DRGNN_STEP_LAUNCH(K, 16); break;                                                       \
-            case 32:                                                                                        \
-                if (cls) { if (gather_ids) DRGNN_STEP_LAUNCH_GC(K, 32, true, 1); else DRGNN_STEP_LAUNCH_GC(K, 32, false, 1); } \
-                else DRGNN_STEP_LAUNCH(K, 32);                                                              \
-                break;                                                                                      \
-            case 48: DRGNN_STEP_LAUNCH(K, 48); break;                                                       \
-            case 64: DRGNN_STEP_LAUNCH(K, 64); break;                                                       \
-            default: DRGNN_STEP_LAUNCH(K, 0); break;                                                        \
-        }                                                                                                   \
-    } while (0)
-#define DRGNN_STEP1_LAUNCH_G(XF, G) DRGNN_STEP1_LAUNCH_GP(XF, G, false)
-#define DRGNN_STEP1_LAUNCH_GP(XF, G, P) DRGNN_STEP1_LAUNCH_GPC(XF, G, P, 0)
-#define DRGNN_STEP1_LAUNCH_GPC(XF, G, P, CL)                                                                    \
-    do {                                                                                                    \
-        /* once per kernel instance and device: the whole 160 KiB (the call costs host time on every launch otherwise) */\
-        static int lds_set_on = -1;                                                                                   \
-        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
-            if (hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G, P, CL>,                                              \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
-                lds_set_on = step_current_device();                                                                   \
-            } else {      /* (profiling builds carry a static LDS word: ask for what this launch needs) */            \
-                (void)hipGetLastError();                                                                              \
-                HIP_TRY(hipFuncSetAttribute((const void*)k_step1_co_topo<XF, G, P, CL>,                                      \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
-            }                                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL((k_step1_co_topo<XF, G, P, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
-                           (size_t)both, stream, C);                                                        \
-    } while (0)
-#define DRGNN_STEP1_LAUNCH(XF)                                                                              \
-    do { if (gather_ids) DRGNN_STEP1_LAUNCH_G(XF, true); else DRGNN_STEP1_LAUNCH_G(XF, false); } while (0)
-#define DRGNN_STEP2_LAUNCH(K, G, CL, SP)                                                                            \
-    do {                                                                                                    \
-        static int lds_set_on = -1;                                                                                   \
-        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
-            if (hipFuncSetAttribute((const void*)k_step2_co_topo<K, 32, G, CL, SP>,                                       \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
-                lds_set_on = step_current_device();                                                                   \
-            } else {                                                                                                  \
-                (void)hipGetLastError();                                                                              \
-                HIP_TRY(hipFuncSetAttribute((const void*)k_step2_co_topo<K, 32, G, CL, SP>,                               \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
-            }                                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL((k_step2_co_topo<K, 32, G, CL, SP>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),\
-                           (size_t)both, stream, C);                                                        \
-    } while (0)
-#define DRGNN_STEP2_LAUNCH_K(K)                                                                             \
-    do {                                                                                                    \
-        if (af_split == 2) {                                                                                \
-            if (cls) { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 1, 2); else DRGNN_STEP2_LAUNCH(K, false, 1, 2); } \
-            else { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 0, 2); else DRGNN_STEP2_LAUNCH(K, false, 0, 2); }     \
-        } else {                                                                                            \
-            if (cls) { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 1, 1); else DRGNN_STEP2_LAUNCH(K, false, 1, 1); } \
-            else { if (gather_ids) DRGNN_STEP2_LAUNCH(K, true, 0, 1); else DRGNN_STEP2_LAUNCH(K, false, 0, 1); }     \
-        }                                                                                                   \
-    } while (0)
-#define DRGNN_STEP3_LAUNCH(G, CL)                                                                            \
-    do {                                                                                                    \
-        static int lds_set_on = -1;                                                                                   \
-        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
-            if (hipFuncSetAttribute((const void*)k_step3_co_topo<32, G, CL>,                                              \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
-                lds_set_on = step_current_device();                                                                   \
-            } else {                                                                                                  \
-                (void)hipGetLastError();                                                                              \
-                HIP_TRY(hipFuncSetAttribute((const void*)k_step3_co_topo<32, G, CL>,                                      \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
-            }                                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL((k_step3_co_topo<32, G, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),   \
-                           (size_t)both, stream, C);                                                        \
-    } while (0)
-#define DRGNN_STEP3B_LAUNCH(G, CL)                                                                            \
-    do {                                                                                                    \
-        static int lds_set_on = -1;                                                                                   \
-        if (both > 64 * 1024 && lds_set_on != step_current_device()) {                                                \
-            if (hipFuncSetAttribute((const void*)k_step3b_co_topo<32, G, CL>,                                              \
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)DRGNN_LDS_LIMIT) == hipSuccess) {\
-                lds_set_on = step_current_device();                                                                   \
-            } else {                                                                                                  \
-                (void)hipGetLastError();                                                                              \
-                HIP_TRY(hipFuncSetAttribute((const void*)k_step3b_co_topo<32, G, CL>,                                      \
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)both));                  \
-            }                                                                                                         \
-        }                                                                                                             \
-        hipLaunchKernelGGL((k_step3b_co_topo<32, G, CL>), dim3((unsigned)(blocks + extra)), dim3(DRGNN_NTHREADS),   \
-                           (size_t)both, stream, C);                                                        \
-    } while (0)
-        if (af_split) {
-            if (kind == DRGNN_SGAT) DRGNN_STEP2_LAUNCH_K(DRGNN_SGAT); else DRGNN_STEP2_LAUNCH_K(DRGNN_FOUT);
-        } else
-        if (af3 && one_wg) {
-            if (cls) { if (gather_ids) DRGNN_STEP3B_LAUNCH(true, 1); else DRGNN_STEP3B_LAUNCH(false, 1); }
-            else { if (gather_ids) DRGNN_STEP3B_LAUNCH(true, 0); else DRGNN_STEP3B_LAUNCH(false, 0); }
-        } else
-        if (af3) {
-            if (cls) { if (gather_ids) DRGNN_STEP3_LAUNCH(true, 1); else DRGNN_STEP3_LAUNCH(false, 1); }
-            else { if (gather_ids) DRGNN_STEP3_LAUNCH(true, 0); else DRGNN_STEP3_LAUNCH(false, 0); }
-        } else
-        if (one_wg && one_paired) {
-            if (cls) {
-                if (gather_ids) DRGNN_STEP1_LAUNCH_GPC(32, true, true, 1); else DRGNN_STEP1_LAUNCH_GPC(32, false, true, 1);
-            } else if (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O) == 32) {
-                if (gather_ids) DRGNN_STEP1_LAUNCH_GP(32, true, true); else DRGNN_STEP1_LAUNCH_GP(32, false, true);
-            } else {
-                if (gather_ids) DRGNN_STEP1_LAUNCH_GP(0, true, true); else DRGNN_STEP1_LAUNCH_GP(0, false, true);
-            }
-        } else if (one_wg) {
-            switch (step_variant(kind, x, F, L.capN, L.capE, L.capC, hd->H, hd->O)) {
-                case 16: DRGNN_STEP1_LAUNCH(16); break;
-                case 32: DRGNN_STEP1_LAUNCH(32); break;
-                case 48: DRGNN_STEP1_LAUNCH(48); break;
-                case 64: DRGNN_STEP1_LAUNCH(64); break;
-                default: DRGNN_STEP1_LAUNCH(0); break;
-            }
-        } else
-        if (kind == DRGNN_GINET) DRGNN_STEP_WIDTHS(DRGNN_GINET);
-        else if (kind == DRGNN_SGAT) DRGNN_STEP_WIDTHS(DRGNN_SGAT);
-        else DRGNN_STEP_WIDTHS(DRGNN_FOUT);
-#undef DRGNN_STEP_WIDTHS
-#undef DRGNN_STEP_LAUNCH
-#undef DRGNN_STEP_LAUNCH_G
-#undef DRGNN_STEP_LAUNCH_GC
-#undef DRGNN_STEP1_LAUNCH
-#undef DRGNN_STEP1_LAUNCH_G
-#undef DRGNN_STEP1_LAUNCH_GP
-#undef DRGNN_STEP1_LAUNCH_GPC
-#undef DRGNN_STEP2_LAUNCH
-#undef DRGNN_STEP2_LAUNCH_K
-#undef DRGNN_STEP3_LAUNCH
-#undef DRGNN_STEP3B_LAUNCH
-        HIP_TRY(hipGetLastError());
+        if (co_ok) { C.topo = T; both = k.lds > tlds ? k.lds : tlds; extra = T.args.n_graphs * T.roles; }
+        drgnn_step_kernel_t kern = nullptr;
+        const bool gather = gather_ids != nullptr;
+        switch (k.kernel) {
+            case SK_AF3: kern = af_step_kernel(DRGNN_AF_GINET_TWO, k.width, gather, k.cls, 1, q.train); break;
+            case SK_AF3B: kern = af_step_kernel(DRGNN_AF_GINET_ONE, k.width, gather, k.cls, 1, q.train); break;
+            case SK_AF2: kern = af_step_kernel(kind == DRGNN_SGAT ? DRGNN_AF_SGAT : DRGNN_AF_FOUT, k.width, gather, k.cls, k.wgs, q.train); break;
+            case SK_STEP1: kern = step_old1_kernel(k.width, gather, k.paired != 0, k.cls); break;
+            default: kern = step_old_kernel(kind, k.width, gather, k.cls); break;
+        }
+        if ((rc = step_launch(kern, both, (unsigned)(blocks + extra), (hipStream_t)stream_, C))) return rc;
 #endif
     }
     if (next && (!co_ok || blocks == 0))
@@ -1734,22 +1647,37 @@ int epoch_check(const drgnn_epoch_plan* p) {
     if (p->batch_size > 4096) return DRGNN_E_CAPACITY;
     return 0;
 }
-// workgroups per graph of mini-batch b's step (co = graphs of the topology co-built by the same launch): 2 for GINet's
-// resident layout and for the node-split layout of a single-branch TRAINING step on a topology with the hierarchical order
-int epoch_step_wgs(const drgnn_epoch_plan* p, const EpochBatch& b, int64_t co, int64_t* lds) {
+// the plan of mini-batch b's step launch on a workspace with `topo_flags` (co = graphs of the topology co-built by the same
+// launch); family NONE: a graph does not fit the fused kernels
+drgnn_step_plan epoch_plan_of(const drgnn_epoch_plan* p, const EpochBatch& b, int64_t co, int32_t topo_flags) {
     const drgnn_head_desc* hd = p->head;
-    int wgs = drgnn_net_step_plan(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O, b.B, co, lds);
-    if (wgs == 2 && p->net->kind != DRGNN_GINET) {
-        // (the node-split kernels start from the aggregation tiles: a cache built with them, or the loop's own builds)
-        const bool hier = p->cache ? ((p->cache->flags & DRGNN_TOPO_HIER) != 0 && (p->cache->flags & DRGNN_TOPO_TILES) != 0 &&
-                                      p->cache->tiles != nullptr)
-                                   : drgnn_topology_tiles_ok(b.maxN, b.maxE, p->net->n_feat) != 0;
-        if (p->inference || !hier) {
-            wgs = 1;
-            if (lds) *lds = drgnn_net_step_lds_bytes(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->R, hd->H, hd->O);
-        }
+    drgnn_step_plan pl;
+    memset(&pl, 0, sizeof(pl));
+    pl.kind = p->net->kind; pl.n_feat = p->net->n_feat; pl.max_nodes = b.maxN; pl.max_edges = b.maxE; pl.max_c0 = b.maxC;
+    pl.R = hd->R; pl.H = hd->H; pl.O = hd->O; pl.n_graphs = b.B; pl.co_built_graphs = co;
+    pl.train = p->inference ? 0 : 1; pl.topo_flags = topo_flags;
+    if (p->step_overrides) {
+        const drgnn_step_plan* o = p->step_overrides;
+        pl.force_wgs = o->force_wgs; pl.no_class = o->no_class; pl.no_aggregate = o->no_aggregate; pl.no_split = o->no_split;
+        pl.no_paired = o->no_paired;
     }
-    return wgs;
+    drgnn_net_step_plan(&pl);
+    return pl;
+}
+// what the workspace of mini-batch b holds when its step is launched: the cache's flags, or what the loop asks its own builder
+// for -- the hierarchical order, the aggregation tiles and nothing else (DRGNN_TOPO_LEAN) when the step that consumes it is one
+// of the aggregation-first kernels, else the plain build (+ the order for the single-branch nets)
+int32_t epoch_topo_flags(const drgnn_epoch_plan* p, const EpochBatch& b, int64_t co, const float* slot_x) {
+    if (p->cache) {
+        int32_t f = p->cache->flags;
+        if (!p->cache->tiles) f &= ~DRGNN_TOPO_TILES;
+        return f;
+    }
+    const bool tiles_ok = drgnn_topology_tiles_ok(b.maxN, b.maxE, p->net->n_feat) != 0 && p->set->x != nullptr &&
+                          ((((uintptr_t)p->set->x) & 15) == 0) && ((((uintptr_t)slot_x) & 15) == 0);
+    const int32_t af = DRGNN_TOPO_HIER | DRGNN_TOPO_LEAN | DRGNN_TOPO_TILES;
+    if (tiles_ok && epoch_plan_of(p, b, co, af).lean_ok) return af;
+    return (p->net->kind != DRGNN_GINET && !p->inference) ? DRGNN_TOPO_HIER : 0;
 }
 int64_t epoch_next_b(const drgnn_epoch_plan* p, int64_t k) {      // graphs of mini-batch k + 1 (0: none)
     const int64_t first = (k + 1) * p->batch_size;
@@ -1768,15 +1696,13 @@ int epoch_carve(const drgnn_epoch_plan* p, char* base, EpochCarve* c) {
         EpochBatch b;
         if ((rc = epoch_batch(p, k, &b))) return rc;
         if (b.maxN <= 0) return DRGNN_E_CAPACITY;
-        int64_t step_lds = 0;
-        const int wgs = epoch_step_wgs(p, b, p->cache ? 0 : epoch_next_b(p, k), &step_lds);
-        if (wgs == 2 && p->net->kind != DRGNN_GINET) {
-            any_split = true;
-            const int64_t xw = drgnn_net_step_xchg_elems(p->net->kind, b.maxN, b.maxC, hd->H) * b.B;
-            if (xw > xchg_words) xchg_words = xw;
-        }
-        if (wgs <= 0 ||
-            step_lds > DRGNN_LDS_LIMIT || b.maxN > 32767 || b.maxE > 65535 ||
+        // (slot buffers are 256-byte aligned: the alignment of x does not depend on the slot)
+        const int64_t co = p->cache ? 0 : epoch_next_b(p, k);
+        const drgnn_step_plan pl = epoch_plan_of(p, b, co, epoch_topo_flags(p, b, co, nullptr));
+        if (pl.slabs_per_graph == 2 && p->net->kind != DRGNN_GINET) any_split = true;
+        if (pl.xchg_words * b.B > xchg_words) xchg_words = pl.xchg_words * b.B;
+        if (pl.family == DRGNN_STEP_FAMILY_NONE ||
+            pl.lds_bytes > DRGNN_LDS_LIMIT || b.maxN > 32767 || b.maxE > 65535 ||
             (!p->cache && drgnn_topology_lds_bytes(b.maxN, b.maxE > 0 ? b.maxE : 1) > DRGNN_LDS_LIMIT))
             return DRGNN_E_CAPACITY;
         TopoLayout lay;
@@ -1859,9 +1785,10 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
             if (!train) tc.y = nullptr;
             drgnn_step_hints hints = {};
             hints.set_node_ptr = p->host_node_ptr; hints.set_edge_ptr = p->host_edge_ptr; hints.host_ids = p->host_ids + b.first;
-            const bool split = train && p->net->kind != DRGNN_GINET && epoch_step_wgs(p, b, 0, nullptr) == 2;
-            hints.topo_flags = train ? p->cache->flags : 0; hints.split = split ? 1 : 0;
-            hints.tiles = train ? p->cache->tiles : nullptr;
+            const drgnn_step_plan pl = epoch_plan_of(p, b, 0, epoch_topo_flags(p, b, 0, nullptr));
+            const bool split = pl.slabs_per_graph == 2 && p->net->kind != DRGNN_GINET;
+            hints.topo_flags = pl.topo_flags; hints.plan = &pl;
+            hints.tiles = p->cache->tiles;
             rc = drgnn_net_train_step_cached(p->net, &head, &tc, p->ids + b.first, b.B, b.maxN, b.maxE, b.maxC, p->step2,
                                              pred + b.first * hd->O, c.readout, train ? c.head_partials : nullptr,
                                              train ? c.partials : nullptr, c.xchg, &hints, stream);
@@ -1883,19 +1810,9 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         r.max_nodes = b.maxN; r.max_edges = b.maxE;
         r.ws_i32 = u.ws_i32; r.ws_f32 = u.ws_f32; r.scratch_i32 = nullptr;
         r.set = p->set; r.ids = p->ids + b.first; r.x_out = u.x; r.y_out = train ? u.y : nullptr;
-        // the hierarchical node order: read by the aggregation-first step kernels (drgnn_step2.h: every training launch of
-        // sGAT / FoutNet; drgnn_step3.h: GINet's two-workgroup layout)
-        // ... and when the step that consumes this workspace IS one of them, only what they read (DRGNN_TOPO_LEAN)
-        r.flags = 0;
-        if (train) {
-            const bool fam = drgnn_net_step_family(p->net->kind, p->net->n_feat, b.maxN, b.maxE, b.maxC, hd->H, hd->O) == 1 &&
-                             ((((uintptr_t)u.x) & 15) == 0) && drgnn_topology_tiles_ok(b.maxN, b.maxE, p->net->n_feat) != 0 &&
-                             p->set->x != nullptr && ((((uintptr_t)p->set->x) & 15) == 0);
-            const int32_t af = DRGNN_TOPO_HIER | DRGNN_TOPO_LEAN | DRGNN_TOPO_TILES;
-            if (p->net->kind != DRGNN_GINET) r.flags = fam ? af : DRGNN_TOPO_HIER;
-            else if (fam) r.flags = af;      // (both GINet layouts have an aggregation-first kernel: drgnn_step3.h)
-            if (r.flags & DRGNN_TOPO_TILES) { r.tiles = u.tiles; r.n_feat = p->net->n_feat; }
-        }
+        // (what the step that consumes this workspace reads: epoch_topo_flags)
+        r.flags = epoch_topo_flags(p, b, epoch_next_b(p, k), u.x);
+        if (r.flags & DRGNN_TOPO_TILES) { r.tiles = u.tiles; r.n_feat = p->net->n_feat; }
         return r;
     };
     EpochBatch cur, nxt;
@@ -1917,10 +1834,11 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
         }
         // the slot offsets of this mini-batch are known here (host size tables): hand them to the launch
         drgnn_step_hints hints = {};
-        const bool split = train && p->net->kind != DRGNN_GINET && epoch_step_wgs(p, cur, more ? nxt.B : 0, nullptr) == 2;
-        hints.topo_flags = cur_flags;      // (what request() asked the builder for)
+        const drgnn_step_plan pl = epoch_plan_of(p, cur, more ? nxt.B : 0, cur_flags);      // (cur_flags: what request() asked the builder for)
+        const bool split = pl.slabs_per_graph == 2 && p->net->kind != DRGNN_GINET;
+        hints.topo_flags = cur_flags;
         hints.tiles = (cur_flags & DRGNN_TOPO_TILES) ? t.tiles : nullptr;
-        hints.split = split ? 1 : 0;
+        hints.plan = &pl;
         if (cur.B <= DRGNN_STEP_DIMS_MAX) {
             hn.resize((size_t)cur.B + 1); he.resize((size_t)cur.B + 1);
             hn[0] = 0; he[0] = 0;

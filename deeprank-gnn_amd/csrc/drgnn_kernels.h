@@ -425,7 +425,7 @@ DEV void step_block_both(const StepLaunch& L, int g, float* lds) {
 // sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h).  SPLIT = 2: the two halves of a graph are 8
 // block ids apart (same XCD: they read the same x tile and topology and hand each other pooled rows), graphs in groups
 // of 8 like GINet's branch workgroups.
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT>
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN>
 DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
     int g, half;
     if (SPLIT == 2) { g = ((blk >> 4) << 3) + (blk & 7); half = (blk >> 3) & 1; }
@@ -440,8 +440,8 @@ DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
         const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
         const int32_t* hs = L.a.tv.p[DRGNN_TI_HSPLIT] + 4 * gi;
         const int hk = (SPLIT == 2) ? hs[0] : 0, hq = (SPLIT == 2) ? hs[1] : 0, hn = (SPLIT == 2) ? hs[2] : 0;
-        net_step2_graph<KIND, XF, GATHER, CLS, SPLIT>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1,
-                                                      hk, hq, hn);
+        net_step2_graph<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1,
+                                                             cnt_c1, hk, hq, hn);
         return;
     }
     const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;
@@ -452,19 +452,21 @@ DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
         // the caller's bounds were wrong: poison the outputs instead of overrunning LDS (the partner does the same: no wait)
         if (half == 0) {
             FOR_TID(c, L.a.hf.R) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + c] = DRGNN_NAN; }
-            float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
-            FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            if (TRAIN) {
+                float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+                FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            }
             FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
         }
         return;
     }
-    net_step2_graph<KIND, XF, GATHER, CLS, SPLIT>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, false, 0, 0, 0, hk, hq, hn);
+    net_step2_graph<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, false, 0, 0, 0, hk, hq, hn);
 }
 #endif
 
 #ifndef DRGNN_EMU
 // GINet, aggregation first (drgnn_step3.h): two branch workgroups per graph, placed like step_block's
-template <int XF, bool GATHER, int CLS>
+template <int XF, bool GATHER, int CLS, bool TRAIN>
 DEV void step3_block(const StepLaunch& L, int blk, float* lds) {
     const int g = ((blk >> 4) << 3) + (blk & 7), br = (blk >> 3) & 1;
     if (g >= L.a.n_graphs) return;
@@ -475,7 +477,7 @@ DEV void step3_block(const StepLaunch& L, int blk, float* lds) {
         d.rowbase = d.n0 + gi;
         d.C = 0; d.E1 = 0; d.C1 = 0;
         const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
-        net_step3_graph<XF, GATHER, CLS>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
+        net_step3_graph<XF, GATHER, CLS, TRAIN>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
         return;
     }
     const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;
@@ -486,19 +488,21 @@ DEV void step3_block(const StepLaunch& L, int blk, float* lds) {
         FOR_TID(c, DRGNN_H2) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + br * DRGNN_H2 + c] = DRGNN_NAN; }
         FOR_TID(h, L.a.hf.H) { xchg_publish(L.a.xchg + ((long)g * 2 + br) * L.a.hf.H + h, tag, DRGNN_NAN); }
         if (br == 0) {
-            float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
-            FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            if (TRAIN) {
+                float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+                FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+            }
             FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
         }
         return;
     }
-    net_step3_graph<XF, GATHER, CLS>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
+    net_step3_graph<XF, GATHER, CLS, TRAIN>(L.a, d, g, gi, br, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
 }
 #endif
 
 #ifndef DRGNN_EMU
 // GINet, aggregation first, both branches of a graph in one workgroup (drgnn_step3.h, net_step3_graph_both)
-template <int XF, bool GATHER, int CLS>
+template <int XF, bool GATHER, int CLS, bool TRAIN>
 DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
     if (g >= L.a.n_graphs) return;
     if (L.dims.count > 0) {
@@ -508,7 +512,7 @@ DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
         d.rowbase = d.n0 + gi;
         d.C = 0; d.E1 = 0; d.C1 = 0;
         const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
-        net_step3_graph_both<XF, GATHER, CLS>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
+        net_step3_graph_both<XF, GATHER, CLS, TRAIN>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
         return;
     }
     const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;
@@ -516,12 +520,14 @@ DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
     if (d.N > L.capN || d.E > L.capE || d.C > L.capC) {
         // the caller's bounds were wrong: poison the outputs instead of overrunning LDS
         FOR_TID(c, L.a.hf.R) { const_cast<float*>(L.a.hf.readout)[(long)g * L.a.hf.R + c] = DRGNN_NAN; }
-        float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
-        FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+        if (TRAIN) {
+            float* hp = L.a.hf.partials + (long)g * head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O);
+            FOR_TID(i, (int)head_compact_floats(L.a.hf.R, L.a.hf.H, L.a.hf.O)) { hp[i] = DRGNN_NAN; }
+        }
         FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
         return;
     }
-    net_step3_graph_both<XF, GATHER, CLS>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
+    net_step3_graph_both<XF, GATHER, CLS, TRAIN>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
 }
 #endif
 
@@ -682,33 +688,33 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C
     else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s1);
 }
 // sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h) + the builder's workgroups
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT>
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step2_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s2[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step2_block<KIND, XF, GATHER, CLS, SPLIT>(C.step, blockIdx.x, smem_s2);
+    if ((int)blockIdx.x < C.n_net) step2_block<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(C.step, blockIdx.x, smem_s2);
     else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s2);
 }
 // GINet, aggregation first (drgnn_step3.h) + the builder's workgroups
-template <int XF, bool GATHER, int CLS>
+template <int XF, bool GATHER, int CLS, bool TRAIN>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s3[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step3_block<XF, GATHER, CLS>(C.step, blockIdx.x, smem_s3);
+    if ((int)blockIdx.x < C.n_net) step3_block<XF, GATHER, CLS, TRAIN>(C.step, blockIdx.x, smem_s3);
     else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s3);
 }
 // ... its form with both branches of a graph in one workgroup (beyond the resident batch size)
-template <int XF, bool GATHER, int CLS>
+template <int XF, bool GATHER, int CLS, bool TRAIN>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3b_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s3b[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
     if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step3b_block<XF, GATHER, CLS>(C.step, blockIdx.x, smem_s3b);
+    if ((int)blockIdx.x < C.n_net) step3b_block<XF, GATHER, CLS, TRAIN>(C.step, blockIdx.x, smem_s3b);
     else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s3b);
 }
 #ifdef DRGNN_KERNELS_MAIN
@@ -874,25 +880,6 @@ extern template __global__ void k_step1_co_topo<32, false, true>(StepCoLaunch);
 extern template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
 extern template __global__ void k_step1_co_topo<32, false, true, 1>(StepCoLaunch);      // (capacity-class LDS layout)
 extern template __global__ void k_step1_co_topo<32, true, true, 1>(StepCoLaunch);
-#define DRGNN_STEP2_EXTERN(K)                                                                   \
-    extern template __global__ void k_step2_co_topo<K, 32, false, 0, 1>(StepCoLaunch);          \
-    extern template __global__ void k_step2_co_topo<K, 32, true, 0, 1>(StepCoLaunch);           \
-    extern template __global__ void k_step2_co_topo<K, 32, false, 1, 1>(StepCoLaunch);          \
-    extern template __global__ void k_step2_co_topo<K, 32, true, 1, 1>(StepCoLaunch);           \
-    extern template __global__ void k_step2_co_topo<K, 32, false, 0, 2>(StepCoLaunch);          \
-    extern template __global__ void k_step2_co_topo<K, 32, true, 0, 2>(StepCoLaunch);           \
-    extern template __global__ void k_step2_co_topo<K, 32, false, 1, 2>(StepCoLaunch);          \
-    extern template __global__ void k_step2_co_topo<K, 32, true, 1, 2>(StepCoLaunch);
-DRGNN_STEP2_EXTERN(DRGNN_SGAT)
-DRGNN_STEP2_EXTERN(DRGNN_FOUT)
-#undef DRGNN_STEP2_EXTERN
-extern template __global__ void k_step3_co_topo<32, false, 0>(StepCoLaunch);
-extern template __global__ void k_step3_co_topo<32, true, 0>(StepCoLaunch);
-extern template __global__ void k_step3_co_topo<32, false, 1>(StepCoLaunch);
-extern template __global__ void k_step3_co_topo<32, true, 1>(StepCoLaunch);
-extern template __global__ void k_step3b_co_topo<32, false, 0>(StepCoLaunch);
-extern template __global__ void k_step3b_co_topo<32, true, 0>(StepCoLaunch);
-extern template __global__ void k_step3b_co_topo<32, false, 1>(StepCoLaunch);
-extern template __global__ void k_step3b_co_topo<32, true, 1>(StepCoLaunch);
 #endif
 #endif  // !DRGNN_EMU
+#include "drgnn_step_af.h"

@@ -473,22 +473,36 @@ DEV void step2_pooled_gather_bwd(int n, const int* cid, int qbase, const int* cp
 }
 // ---- phase N: the weight / bias gradients of conv1 through the depth-0 argmax (dZ1 is non-zero only in the rows p = a0[q][h]
 // that won a depth-0 cluster):  dWn[f][h] = sum_q D_p dxp[q][h] S[p][f],  dWs[f][h] = sum_q C_p dxp[q][h] X[p][f],
-// db1[h] = sum_q dxp[q][h].  Wave = channel h; in a wave 8 feature chunks (float4) x 8 slices of the own pooled rows
+// db1[h] = sum_q dxp[q][h].  Wave = channel h; in a wave NCH feature chunks (float4) x NSL slices of the own pooled rows
+// (consecutive lanes: the slice sums meet in DPP adds).  16-wide: 4 chunks x 16 slices, 32-wide: 8 x 8, 64-wide: 16 x 4;
+// 48-wide: the sixteen chunk slots of the 64-wide form, twelve in use
+template <int XF> struct Dw1Shape {
+    static constexpr int NCH = (XF == 16) ? 4 : (XF == 32) ? 8 : 16;
+    static constexpr int NSL = 64 / NCH;
+};
+template <int NSL> DEV float step_slices_sum(float v) {
+    static_assert(NSL == 4 || NSL == 8 || NSL == 16, "aligned groups of 4 / 8 / 16 consecutive lanes");
+    v += dpp_take<0xB1>(v);     // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E>(v);     // quad_perm [2,3,0,1]
+    if (NSL >= 8) v += dpp_take<0x141>(v);    // row_half_mirror
+    if (NSL >= 16) v += dpp_take<0x140>(v);   // row_mirror
+    return v;
+}
 template <int XF>
 DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float* G, const float* xs, const float* dv,
                           const float* sc, float* g_dwn, float* g_dws, float* g_db1, int F) {
-    static_assert(XF == 32, "16 waves x 64 lanes = 16 channels x 8 chunks x 8 slices");
-    constexpr int XLD = XF + 4;
-    const int h = threadIdx.x >> 6, fc = (threadIdx.x >> 3) & 7, sl = threadIdx.x & 7;
+    constexpr int XLD = XF + 4, NSL = Dw1Shape<XF>::NSL;
+    const int h = threadIdx.x >> 6, fc = (threadIdx.x & 63) / NSL, sl = threadIdx.x & (NSL - 1);
+    const bool live = 4 * fc < XF;
     drgnn_f4 an = {0.f, 0.f, 0.f, 0.f}, as = {0.f, 0.f, 0.f, 0.f};
     float bsum = 0.0f;
-    for (int q = sl; q < Ch; q += 16) {      // two pooled rows per trip in flight
+    for (int q = sl; q < Ch; q += 2 * NSL) {      // two pooled rows per trip in flight
         int arg[2];
         float d[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            const int qq = q + 8 * u;
-            arg[u] = (qq < Ch) ? (int)a0[qq * DRGNN_H1 + h] : -1;
+            const int qq = q + NSL * u;
+            arg[u] = (qq < Ch && live) ? (int)a0[qq * DRGNN_H1 + h] : -1;
             d[u] = (qq < Ch) ? dxp[qq * STEP_XPLD + h] : 0.0f;
         }
 #pragma unroll
@@ -504,8 +518,8 @@ DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { an[i] = lanes8_sum(an[i]); as[i] = lanes8_sum(as[i]); }
-    bsum = lanes8_sum(bsum);
+    for (int i = 0; i < 4; ++i) { an[i] = step_slices_sum<NSL>(an[i]); as[i] = step_slices_sum<NSL>(as[i]); }
+    bsum = step_slices_sum<NSL>(bsum);
     if (sl == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -519,11 +533,13 @@ DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float
 // XF: padded feature width (16 / 32 / 48 / 64; the host has checked step_burst_guaranteed: register-burst prologue, reference
 // head width); CLS as in drgnn_step.h; SPLIT: workgroups per graph; half: which one.  `late` as in net_step_graph: sizes and
 // offsets came with the launch arguments, the device-computed counts (clusters, pooled edges, split point) are in flight.
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT>
+// TRAIN = false: the inference launch (forward + head, predictions only; one workgroup per graph).
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN = true>
 DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi, int half, float* scratch, int capN, int capE,
                          int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1, int hs_k, int hs_q, int hs_n) {
     static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
     static_assert(KIND != DRGNN_GINET, "single-branch nets");
+    static_assert(TRAIN || SPLIT == 1, "inference launches run one workgroup per graph");
     if (CLS == 1) { capN = STEP_CLS_N; capE = STEP_CLS_E; capC = STEP_CLS_C; }
     GraphDims d = d_in;
     const int bC = late ? imin(d.N, capC) : d.C, bE1 = late ? d.E : d.E1, bC1 = late ? imin(d.N, capC) : d.C1;
@@ -582,14 +598,14 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
         case 16 + 8: j = StageJob{hf.w2, O * WREF, s.hw2, 0}; break;
         case 16 + 9: j = StageJob{hf.b2, O, s.hb2, 0}; break;
         case 16 + 10: j = StageJob{c2.bias, DRGNN_H2, s.b2, 0}; break;
-        case 16 + 11: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
-        case 16 + 12: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 0); break;
-        case 16 + 13: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 1); break;
+        case 16 + 11: if (TRAIN) j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+        case 16 + 12: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 0); break;
+        case 16 + 13: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 1); break;
 
         case 32 + 0: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 0); break;
         case 32 + 1: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 1); break;
-        case 32 + 2: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 0); break;
-        case 32 + 3: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 1); break;
+        case 32 + 2: if (KIND == DRGNN_SGAT && TRAIN) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 0); break;
+        case 32 + 3: if (KIND == DRGNN_SGAT && TRAIN) j = stage_half(StageJob{P[DRGNN_TI_TSLOT1] + d.e0, bE1, s.ts1, nar}, 1); break;
         default: break;
         }
         return j;
@@ -603,7 +619,8 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     float m_wy = 1.0f, m_denom = 1.0f;
     if (my_wave == 0) {
         m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
-        if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
+        if (!TRAIN) {
+        } else if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
             m_y = __builtin_nontemporal_load((const int*)hf.y_reg + gi);
         } else {
             m_y = (int)hf.y_cls[gi];
@@ -684,9 +701,9 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     // ---- C: depth-0 cluster max over contiguous rows, published to the partner; the second burst is filed -----------------
     PH(3) step2_cluster_max(Ch, s.hmp, qbase, nbase, s.cid, s.z1, s.xp, s.a0, (SPLIT == 2) ? x_xp_own : nullptr, tag);
     burst_store_wt(bw2, s.wc2t, STEP2_TSLD);
-    burst_store_w(bw2, s.wc2n, STEP2_TSLD);
+    if (TRAIN) burst_store_w(bw2, s.wc2n, STEP2_TSLD);
     burst_store_wt(bs2, s.wc2t + DRGNN_H1, STEP2_TSLD);
-    burst_store_w(bs2, s.wc2n + DRGNN_H1 * STEP2_TSLD, STEP2_TSLD);
+    if (TRAIN) burst_store_w(bs2, s.wc2n + DRGNN_H1 * STEP2_TSLD, STEP2_TSLD);
     step_wblock_store(wreg, hf, 0, s.wb);
     wstage_store(wst2);
     unsigned long long w_first = 0ull;
@@ -723,8 +740,8 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     float* p_hw2 = p_dhid + WREF;
     float* p_hb2 = p_hw2 + (long)O * WREF;
     float* p_loss = p_hb2 + O;
-    if (g == 0 && half == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
-    FOR_TID(item, step_pad4(Ch) * STEP2_TSLD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
+    if (TRAIN && g == 0 && half == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+    if (TRAIN) { FOR_TID(item, step_pad4(Ch) * STEP2_TSLD) { s.z2[item] = 0.0f; } }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
     const float inv_c1 = 1.0f / (float)(d.C1 > 0 ? d.C1 : 1);
     int bad; memcpy(&bad, &s.misc[STEP_M_BAD], 4);
     PH(8) step2_head_fc1<WREF, SPLIT>(hf, g, half, s.wb, s.hb1, s.xr, s.hid, x_ro_oth, tag, done, thresh, keep_scale, inv_c1,
@@ -732,6 +749,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     BARRIER();
     EXIT_AFTER(9);
     PH(9) step_head_loss<WREF, true>(hf, g, half, s.hid, s.hw2, s.hb2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    if (!TRAIN) return;
     BARRIER();
     EXIT_AFTER(10);
     float* part_w = a.partials + ((long)g * SPLIT + half) * a.n_partial;

@@ -182,21 +182,21 @@ DEV void step3_gather_dxp(int n, const int* cp, const int* ridx, const float* sr
         if (sl == 0 && j < n) *(drgnn_f4*)(dst + j * LD + c) = drgnn_f4{a0, a1, a2, a3};
     }
 }
-// dW1[f][h] = sum over the pooled nodes j of dXP[j][h] G[a0[j][h]][f].  Wave = channel h; in a wave 8 feature chunks (float4) x
-// 8 slices of the pooled nodes (consecutive lanes: the slice sums meet in DPP adds)
+// dW1[f][h] = sum over the pooled nodes j of dXP[j][h] G[a0[j][h]][f].  Wave = channel h; in a wave NCH feature chunks (float4)
+// x NSL slices of the pooled nodes (consecutive lanes: the slice sums meet in DPP adds; Dw1Shape, drgnn_step2.h)
 template <int XF>
 DEV void step3_dw1_sparse(int C, const short* a0, const float* dxp, const float* G, float* g_dw1, int F) {
-    static_assert(XF == 32, "16 waves x 64 lanes = 16 channels x 8 chunks x 8 slices");
-    constexpr int XLD = XF + 4;
-    const int h = threadIdx.x >> 6, fc = (threadIdx.x >> 3) & 7, sl = threadIdx.x & 7;
+    constexpr int XLD = XF + 4, NSL = Dw1Shape<XF>::NSL;
+    const int h = threadIdx.x >> 6, fc = (threadIdx.x & 63) / NSL, sl = threadIdx.x & (NSL - 1);
+    const bool live = 4 * fc < XF;
     drgnn_f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int j = sl; j < C; j += 32) {      // four pooled nodes per trip in flight
+    for (int j = sl; j < C; j += 4 * NSL) {      // four pooled nodes per trip in flight
         int arg[4];
         float d[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int jj = j + 8 * u;
-            arg[u] = (jj < C) ? (int)a0[jj * DRGNN_H1 + h] : -1;
+            const int jj = j + NSL * u;
+            arg[u] = (jj < C && live) ? (int)a0[jj * DRGNN_H1 + h] : -1;
             d[u] = (jj < C) ? dxp[jj * STEP_XPLD + h] : 0.0f;
         }
 #pragma unroll
@@ -209,7 +209,7 @@ DEV void step3_dw1_sparse(int C, const short* a0, const float* dxp, const float*
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[i] = lanes8_sum(acc[i]);
+    for (int i = 0; i < 4; ++i) acc[i] = step_slices_sum<NSL>(acc[i]);
     if (sl == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -219,8 +219,9 @@ DEV void step3_dw1_sparse(int C, const short* a0, const float* dxp, const float*
 
 // =========================================================================================================================
 // XF: padded feature width (the host has checked step_burst_guaranteed and the reference head width 128); CLS as in
-// drgnn_step.h; `late` as in net_step_graph.
-template <int XF, bool GATHER, int CLS>
+// drgnn_step.h; `late` as in net_step_graph.  TRAIN = false: the inference launch (forward + head, predictions only: the
+// arrays only the backward reads are not staged, the kernel returns behind the head).
+template <int XF, bool GATHER, int CLS, bool TRAIN = true>
 DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi, int br, float* scratch, int capN, int capE,
                          int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1) {
     static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
@@ -265,9 +266,9 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
         case 16 + 7: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
         case 16 + 8: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 0); break;
         case 16 + 9: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 1); break;
-        case 16 + 10: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
-        case 16 + 11: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
-        case 16 + 12: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
+        case 16 + 10: if (TRAIN) j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+        case 16 + 11: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
+        case 16 + 12: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
         default: break;
         }
         return j;
@@ -281,7 +282,8 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     float m_wy = 1.0f, m_denom = 1.0f;
     if (my_wave == 0) {
         m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
-        if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
+        if (!TRAIN) {
+        } else if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
             m_y = __builtin_nontemporal_load((const int*)hf.y_reg + gi);
         } else {
             m_y = (int)hf.y_cls[gi];
@@ -333,7 +335,7 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     // ---- B: Z1 = relu(G W1); the second burst is filed ---------------------------------------------------------------------
     PH(2) step_gemm_nn<true>(d.N, 1, XF, s.G, XLD, s.w1t, XLD, s.z1, DRGNN_H1, dummy);
     burst_store_wt(bw2, s.w2t, STEP_XPLD);
-    burst_store_w(bw2, s.w2n, W2NLD);
+    if (TRAIN) burst_store_w(bw2, s.w2n, W2NLD);
     step_wblock_store(wreg, hf, br, s.wb);
     FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
     if (bad_shape) { FOR_TID(i, 1) { ((int*)s.misc)[STEP_M_BAD] = 1; } }
@@ -368,13 +370,21 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     float* p_hw2 = p_dhid + WREF;
     float* p_hb2 = p_hw2 + (long)O * WREF;
     float* p_loss = p_hb2 + O;
-    if (g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
-    FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
+    if (TRAIN && g == 0 && br == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+    if (TRAIN) { FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[item] = 0.0f; } }      // Z2 is consumed: becomes dZ2 (+ zero K padding)
     PH(8) step_head_fc1<WREF, true>(hf, g, br, nb, s.wb, wother, s.hb1, s.xr, s.hid, a.xchg + (long)g * nb * WREF, tag, done,
                                     thresh, keep_scale, a.step2 + 2);
     BARRIER();
     EXIT_AFTER(9);
+    if (!TRAIN) {
+        // inference launches all carry the same tag (the step counter does not move): the reader clears the words it
+        // consumed (all 16 waves have, past the barrier), so that the next launch cannot pick up this one's values
+        FOR_TID(c, DRGNN_H2) {
+            __hip_atomic_store(a.xchg + (long)g * nb * WREF + (1 - br) * DRGNN_H2 + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     PH(9) step_head_loss<WREF, true>(hf, g, br, s.hid, s.hw2, s.hb2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    if (!TRAIN) return;
     BARRIER();
     EXIT_AFTER(10);
     float* part_w = a.partials + ((long)g * nb + br) * a.n_partial;
@@ -508,7 +518,7 @@ DEV void step3b_head_fc1(const HeadFused& hf, int g, const float* wb, const WBlo
     }
 }
 
-template <int XF, bool GATHER, int CLS>
+template <int XF, bool GATHER, int CLS, bool TRAIN = true>
 DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, int gi, float* scratch, int capN, int capE,
                               int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1) {
     static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
@@ -549,9 +559,9 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
         case 7: j = StageJob{P[DRGNN_TI_ROWPTR1] + d.rowbase, bC + 1, s.rp1, 0}; break;
         case 8: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 0); break;
         case 9: j = stage_half(StageJob{P[DRGNN_TI_COL1] + d.e0, bE1, s.cx1, 0}, 1); break;
-        case 10: j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
-        case 11: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
-        case 12: j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
+        case 10: if (TRAIN) j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
+        case 11: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
+        case 12: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
         default: break;
         }
         return j;
@@ -565,7 +575,8 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     float m_wy = 1.0f, m_denom = 1.0f;
     if (my_wave == 0) {
         m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
-        if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
+        if (!TRAIN) {
+        } else if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
             m_y = __builtin_nontemporal_load((const int*)hf.y_reg + gi);
         } else {
             m_y = (int)hf.y_cls[gi];
@@ -598,7 +609,7 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     for (int br = 0; br < 2; ++br) {
         burst_store_wt(bw1[br], s.w1t[br], XLD);
         burst_store_wt(bw2[br], s.w2t[br], STEP_XPLD);
-        burst_store_w(bw2[br], s.w2n[br], W2NLD);
+        if (TRAIN) burst_store_w(bw2[br], s.w2n[br], W2NLD);
     }
     step_wblock_store(wreg, hf, 0, s.wb);
     wstage_store(wst);
@@ -657,11 +668,12 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     float* p_hw2 = p_dhid + WREF;
     float* p_hb2 = p_hw2 + (long)O * WREF;
     float* p_loss = p_hb2 + O;
-    if (g == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
-    FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[0][item] = 0.0f; s.z2[1][item] = 0.0f; }      // become dZ2 (+ zero K padding)
+    if (TRAIN && g == 0) { FOR_TID(i, 1) { a.step2[1] = (int32_t)tag; } }     // Adam's step index
+    if (TRAIN) { FOR_TID(item, step_pad4(d.C) * Z2LD) { s.z2[0][item] = 0.0f; s.z2[1][item] = 0.0f; } }      // become dZ2 (+ zero K padding)
     step3b_head_fc1<WREF>(hf, g, s.wb, wother, s.hb1, s.xr, s.hid, done, thresh, keep_scale);
     BARRIER();
     step_head_loss<WREF, true>(hf, g, 0, s.hid, s.hw2, s.hb2, s.misc, keep_scale, s.dhid, p_dhid, p_hw2, p_hb2, p_loss);
+    if (!TRAIN) return;
     BARRIER();
     // d readout scattered into dZ2 + dW2 (sparse sums: step3_dreadout_dw2), branch after branch
     float* const p_w1n0 = a.partials + ((long)g * nb) * a.n_partial;

@@ -1,0 +1,100 @@
+// drgnn_step_af.h -- which __global__ instance of the AGGREGATION-FIRST step families (drgnn_step2.h: sGAT / FoutNet;
+// drgnn_step3.h: GINet) a launch takes.  The families are instantiated per padded feature width 16 / 32 / 48 / 64,
+// {per-mini-batch, cached whole-set workspace}, {training, inference}; training launches of the 32-wide kernels also with the
+// capacity-class LDS layout (CLS = 1, drgnn_step.h), the single-branch nets with one or two workgroups per graph.
+//
+// One lookup function per (family, width).  In the library build (Makefile: DRGNN_SPLIT_TU) each is DEFINED in the translation
+// unit that thereby instantiates the kernels it names (drgnn_step_tu.hip with -DDRGNN_AF_FAM=<family> -DDRGNN_AF_W=<width>) and
+// only declared everywhere else, so the kernels are compiled once, in parallel, and no list of them has to be kept in two
+// places; a single-unit build (profiling / ablation variants) defines all of them in drgnn_capi.hip.
+#ifndef DRGNN_STEP_AF_H
+#define DRGNN_STEP_AF_H
+#ifndef DRGNN_EMU
+
+typedef void (*drgnn_step_kernel_t)(StepCoLaunch);
+
+#define DRGNN_AF_GINET_TWO 1      // k_step3_co_topo: one workgroup per (graph, branch)
+#define DRGNN_AF_GINET_ONE 2      // k_step3b_co_topo: both branches of a graph in one workgroup
+#define DRGNN_AF_SGAT 3           // k_step2_co_topo<DRGNN_SGAT>
+#define DRGNN_AF_FOUT 4           // k_step2_co_topo<DRGNN_FOUT>
+
+// (cls: 1 = capacity-class layout, honoured for training launches of the 32-wide kernels only -- the host asks for nothing else)
+template <int XF> drgnn_step_kernel_t af_pick_ginet_two(bool gather, int cls, bool train) {
+    constexpr int C1 = (XF == 32) ? 1 : 0;
+    if (!train) return gather ? k_step3_co_topo<XF, true, 0, false> : k_step3_co_topo<XF, false, 0, false>;
+    if (cls && C1) return gather ? k_step3_co_topo<XF, true, C1, true> : k_step3_co_topo<XF, false, C1, true>;
+    return gather ? k_step3_co_topo<XF, true, 0, true> : k_step3_co_topo<XF, false, 0, true>;
+}
+template <int XF> drgnn_step_kernel_t af_pick_ginet_one(bool gather, int cls, bool train) {
+    constexpr int C1 = (XF == 32) ? 1 : 0;
+    if (!train) return gather ? k_step3b_co_topo<XF, true, 0, false> : k_step3b_co_topo<XF, false, 0, false>;
+    if (cls && C1) return gather ? k_step3b_co_topo<XF, true, C1, true> : k_step3b_co_topo<XF, false, C1, true>;
+    return gather ? k_step3b_co_topo<XF, true, 0, true> : k_step3b_co_topo<XF, false, 0, true>;
+}
+// split: workgroups per graph (2: training launches only)
+template <int KIND, int XF> drgnn_step_kernel_t af_pick_single(bool gather, int cls, int split, bool train) {
+    constexpr int C1 = (XF == 32) ? 1 : 0;
+    if (!train) return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, false> : k_step2_co_topo<KIND, XF, false, 0, 1, false>;
+    if (split == 2) {
+        if (cls && C1) return gather ? k_step2_co_topo<KIND, XF, true, C1, 2, true> : k_step2_co_topo<KIND, XF, false, C1, 2, true>;
+        return gather ? k_step2_co_topo<KIND, XF, true, 0, 2, true> : k_step2_co_topo<KIND, XF, false, 0, 2, true>;
+    }
+    if (cls && C1) return gather ? k_step2_co_topo<KIND, XF, true, C1, 1, true> : k_step2_co_topo<KIND, XF, false, C1, 1, true>;
+    return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, true> : k_step2_co_topo<KIND, XF, false, 0, 1, true>;
+}
+
+#define DRGNN_AF_DECLARE(W)                                                                     \
+    drgnn_step_kernel_t af_ginet_two_##W(bool gather, int cls, bool train);                    \
+    drgnn_step_kernel_t af_ginet_one_##W(bool gather, int cls, bool train);                    \
+    drgnn_step_kernel_t af_sgat_##W(bool gather, int cls, int split, bool train);              \
+    drgnn_step_kernel_t af_fout_##W(bool gather, int cls, int split, bool train);
+DRGNN_AF_DECLARE(16) DRGNN_AF_DECLARE(32) DRGNN_AF_DECLARE(48) DRGNN_AF_DECLARE(64)
+#undef DRGNN_AF_DECLARE
+
+// (two levels: the width may itself be a macro -- the translation units pass DRGNN_AF_W)
+#define DRGNN_AF_DEFINE_GINET_TWO(W) DRGNN_AF_DEFINE_GINET_TWO_X(W)
+#define DRGNN_AF_DEFINE_GINET_ONE(W) DRGNN_AF_DEFINE_GINET_ONE_X(W)
+#define DRGNN_AF_DEFINE_SGAT(W) DRGNN_AF_DEFINE_SGAT_X(W)
+#define DRGNN_AF_DEFINE_FOUT(W) DRGNN_AF_DEFINE_FOUT_X(W)
+#define DRGNN_AF_DEFINE_GINET_TWO_X(W) \
+    drgnn_step_kernel_t af_ginet_two_##W(bool gather, int cls, bool train) { return af_pick_ginet_two<W>(gather, cls, train); }
+#define DRGNN_AF_DEFINE_GINET_ONE_X(W) \
+    drgnn_step_kernel_t af_ginet_one_##W(bool gather, int cls, bool train) { return af_pick_ginet_one<W>(gather, cls, train); }
+#define DRGNN_AF_DEFINE_SGAT_X(W)                                                    \
+    drgnn_step_kernel_t af_sgat_##W(bool gather, int cls, int split, bool train) {   \
+        return af_pick_single<DRGNN_SGAT, W>(gather, cls, split, train);              \
+    }
+#define DRGNN_AF_DEFINE_FOUT_X(W)                                                    \
+    drgnn_step_kernel_t af_fout_##W(bool gather, int cls, int split, bool train) {   \
+        return af_pick_single<DRGNN_FOUT, W>(gather, cls, split, train);              \
+    }
+#define DRGNN_AF_FOR_WIDTHS(X) X(16) X(32) X(48) X(64)
+
+#if defined(DRGNN_KERNELS_MAIN)
+#if !defined(DRGNN_SPLIT_TU)
+DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_GINET_TWO)
+DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_GINET_ONE)
+DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT)
+DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_FOUT)
+#endif
+// family: DRGNN_AF_*; width: 16 / 32 / 48 / 64.  nullptr: no such instance
+static drgnn_step_kernel_t af_step_kernel(int family, int width, bool gather, int cls, int split, bool train) {
+#define DRGNN_AF_CASE(W)                                                                       \
+    case W:                                                                                     \
+        switch (family) {                                                                       \
+        case DRGNN_AF_GINET_TWO: return af_ginet_two_##W(gather, cls, train);                   \
+        case DRGNN_AF_GINET_ONE: return af_ginet_one_##W(gather, cls, train);                   \
+        case DRGNN_AF_SGAT: return af_sgat_##W(gather, cls, split, train);                      \
+        case DRGNN_AF_FOUT: return af_fout_##W(gather, cls, split, train);                      \
+        default: return nullptr;                                                                \
+        }
+    switch (width) {
+        DRGNN_AF_FOR_WIDTHS(DRGNN_AF_CASE)
+    default: return nullptr;
+    }
+#undef DRGNN_AF_CASE
+}
+#endif  // DRGNN_KERNELS_MAIN
+
+#endif  // !DRGNN_EMU
+#endif

@@ -1,8 +1,24 @@
-// drgnn_step_tu.hip -- explicit instantiations of the fused step kernel for ONE kind of net (-DDRGNN_TU_KIND=0|1|2; 3 = the one-workgroup GINet step):
-// five feature widths x {per-mini-batch workspace, cached whole-set workspace}.  See drgnn_kernels.h.
+// drgnn_step_tu.hip -- one translation unit of the fused step kernels' instantiations.
+//   -DDRGNN_AF_FAM=<1..4> -DDRGNN_AF_W=<16|32|48|64>: one (family, width) of the aggregation-first kernels (drgnn_step_af.h:
+//       the unit defines that family's kernel lookup, which instantiates the kernels);
+//   -DDRGNN_TU_KIND=0|1|2: the product-first kernels of one kind of net (drgnn_step.h; five feature widths x {per-mini-batch
+//       workspace, cached whole-set workspace}); 3 / 4: the one-workgroup product-first GINet step (drgnn_step1.h).
 #include "drgnn_kernels.h"
+#if defined(DRGNN_AF_FAM)
+#if DRGNN_AF_FAM == DRGNN_AF_GINET_TWO
+DRGNN_AF_DEFINE_GINET_TWO(DRGNN_AF_W)
+#elif DRGNN_AF_FAM == DRGNN_AF_GINET_ONE
+DRGNN_AF_DEFINE_GINET_ONE(DRGNN_AF_W)
+#elif DRGNN_AF_FAM == DRGNN_AF_SGAT
+DRGNN_AF_DEFINE_SGAT(DRGNN_AF_W)
+#elif DRGNN_AF_FAM == DRGNN_AF_FOUT
+DRGNN_AF_DEFINE_FOUT(DRGNN_AF_W)
+#else
+#error "DRGNN_AF_FAM: 1 .. 4"
+#endif
+#else
 #ifndef DRGNN_TU_KIND
-#error "compile with -DDRGNN_TU_KIND=<kind>"
+#error "compile with -DDRGNN_TU_KIND=<kind> or -DDRGNN_AF_FAM=<family> -DDRGNN_AF_W=<width>"
 #endif
 #define DRGNN_STEP_INST(K, XF)                                              \
     template __global__ void k_step_co_topo<K, XF, false>(StepCoLaunch);    \
@@ -22,33 +38,10 @@ template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
 // ... and the 32-wide paired form with the capacity-class LDS layout
 template __global__ void k_step1_co_topo<32, false, true, 1>(StepCoLaunch);
 template __global__ void k_step1_co_topo<32, true, true, 1>(StepCoLaunch);
-#elif DRGNN_TU_KIND == 5 || DRGNN_TU_KIND == 6
-// the node-split, aggregation-first step of sGAT (5) / FoutNet (6) (drgnn_step2.h): 32-wide, {mini-batch, cached} x
-// {run-time, capacity-class layout} x {one, two workgroups per graph}
-#define DRGNN_STEP2_K (DRGNN_TU_KIND == 5 ? DRGNN_SGAT : DRGNN_FOUT)
-template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 0, 1>(StepCoLaunch);
-template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 0, 1>(StepCoLaunch);
-template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 1, 1>(StepCoLaunch);
-template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 1, 1>(StepCoLaunch);
-template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 0, 2>(StepCoLaunch);
-template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 0, 2>(StepCoLaunch);
-template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, false, 1, 2>(StepCoLaunch);
-template __global__ void k_step2_co_topo<DRGNN_STEP2_K, 32, true, 1, 2>(StepCoLaunch);
-#elif DRGNN_TU_KIND == 7
-// the aggregation-first GINet step (drgnn_step3.h): 32-wide, {mini-batch, cached} x {run-time, capacity-class layout}
-template __global__ void k_step3_co_topo<32, false, 0>(StepCoLaunch);
-template __global__ void k_step3_co_topo<32, true, 0>(StepCoLaunch);
-template __global__ void k_step3_co_topo<32, false, 1>(StepCoLaunch);
-template __global__ void k_step3_co_topo<32, true, 1>(StepCoLaunch);
-#elif DRGNN_TU_KIND == 8
-// ... with both branches of a graph in one workgroup (net_step3_graph_both)
-template __global__ void k_step3b_co_topo<32, false, 0>(StepCoLaunch);
-template __global__ void k_step3b_co_topo<32, true, 0>(StepCoLaunch);
-template __global__ void k_step3b_co_topo<32, false, 1>(StepCoLaunch);
-template __global__ void k_step3b_co_topo<32, true, 1>(StepCoLaunch);
 #else
 DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_INST, DRGNN_TU_KIND)
 // ... and the 32-wide kernels with the capacity-class LDS layout (net_step_graph: CLS = 1)
 template __global__ void k_step_co_topo<DRGNN_TU_KIND, 32, false, 1>(StepCoLaunch);
 template __global__ void k_step_co_topo<DRGNN_TU_KIND, 32, true, 1>(StepCoLaunch);
 #endif
+#endif  // DRGNN_AF_FAM

@@ -212,9 +212,10 @@ class ResidentGraphSet(object):
                     topo.n_feat = self.n_feat
                     topo.flags |= _lib.TOPO_TILES
                 self._topo_cache = {bool(t["with_weights"]): TopologyCache(self, bool(t["with_weights"]), topo=topo)}
-                if t["with_weights"] and topo.tiles is None:
-                    # a weighted workspace serves the nets that ignore the weights as well -- unless it carries aggregation
-                    # tiles: those are WEIGHTED sums, the other nets get a cache (and tiles) of their own, built on demand
+                if t["with_weights"]:
+                    # a weighted workspace serves the nets that ignore the weights as well; its aggregation tiles are WEIGHTED
+                    # sums -- the other flavour is formed from the same workspace on first use (TopologyCache.tiles_for /
+                    # desc_for), not by building a second workspace
                     self._topo_cache[False] = self._topo_cache[True]
         return self
 
@@ -315,6 +316,7 @@ class ResidentGraphSet(object):
         self.api.topology_build_request(r, _lib.current_stream(x))
         topo._inputs = None
         topo.x = x
+        topo._tiles_x_version = x._version      # (the tiles are sums of exactly these rows: the builder gathered both)
         return topo, x, y
 
     def batch(self, ids, ids_dev=None):

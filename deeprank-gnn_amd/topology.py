@@ -37,8 +37,12 @@ class Topology(object):
         self.flags = _lib.TOPO_HIER      # what the last build put into the workspace (drgnn_topology_request.flags)
         # level-0 aggregation tiles (TOPO_TILES): the node features they are formed from and the output buffer
         # ([S n x F | D n | C n], include/drgnn.h); None: not available for this batch
+        # CONTRACT: with TOPO_TILES a build reads the VALUES of x (S = sums of x rows over the neighbours); a launch may use
+        # the tiles only for that same tensor, unmodified since (FusedTrainer checks storage and version and forms the
+        # tiles again otherwise).  Everything else in the workspace depends on the index tensors only.
         self.x = None
         self.tiles = None
+        self._tiles_x_version = None
         self.n_feat = 0
         self._finalized = False
 
@@ -131,6 +135,8 @@ class Topology(object):
             if self.tiles is None:
                 raise ValueError("this topology has no aggregation tiles (no 16-byte aligned float32 x with F % 4 == 0)")
             r.x, r.tiles, r.n_feat = p(self.x), p(self.tiles), self.n_feat
+            # the tiles bake values of x in: what x was when the builder read it (trainer._usable_flags compares)
+            self._tiles_x_version = self.x._version
         self.flags = int(r.flags)
         self._finalized = False
         return r
@@ -142,8 +148,9 @@ class Topology(object):
     def rebuild(self, flags=None):
         """(Re)run the builder into this object's existing buffers, on torch's current stream --
         e.g. on a side stream while the previous mini-batch is still training (the build only
-        depends on index tensors, never on parameters).  The input tensors captured at
-        construction are re-read, so refreshing them in place refreshes the topology.
+        depends on the inputs, never on parameters).  The input tensors captured at
+        construction are re-read (with TOPO_TILES also the node features ``self.x``), so refreshing them in place refreshes
+        the topology.
         ``flags``: TOPO_* request flags (default: everything, with the hierarchical order)."""
         edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr, scratch = self._inputs
         if flags is None:

@@ -39,6 +39,12 @@ def _net_layout(net):
     raise TypeError("FusedTrainer drives GINet / sGAT / FoutNet, not %s" % name)
 
 
+class _BatchView(object):
+    """the two members of a batch _fused_prepare reads"""
+    def __init__(self, x, y):
+        self.x, self.y = x, y
+
+
 class FusedTrainer(object):
     EPOCH_CHUNK = 128            # mini-batches per call of the native epoch loop (see _run_epoch)
     _dp_first_batch = 0
@@ -73,7 +79,10 @@ class FusedTrainer(object):
         self.step2 = torch.zeros(4, dtype=torch.int32, device=dev)
         self.step = self.step2[:1]
         self.fused_step = True       # one launch for fwd + head + bwd whenever a graph fits LDS
-        self._xchg = {}              # readout exchange words of the fused step, per batch size
+        # overrides of the fused step's launch plan (drgnn_step_plan: force_wgs / no_class / no_aggregate / no_split /
+        # no_paired; tests and A/B runs) -- per trainer, handed to every plan query and every launch
+        self.plan_overrides = {}
+        self._xchg = {}              # exchange words of the fused step, one grow-only buffer per batch size
         # what a co-built topology must hold: the hierarchical node order, read by the aggregation-first step kernels
         # (sGAT / FoutNet: every training launch; GINet: the two-workgroup layout only, see _flags_for)
         self.topo_flags = _lib.TOPO_HIER
@@ -144,49 +153,59 @@ class FusedTrainer(object):
                         topo.max_edges, topo.max_c0, xp, arg0, arg1, readout, scratch, stream, step_inc=step_inc)
         return x, desc, xp, arg0, arg1, readout, scratch
 
-    def _can_fuse(self, topo, n_feat, next_topo=None):
+    # -- launch plan ------------------------------------------------------------------------------------------------
+    def _tiles_match(self, topo):
+        """The aggregation tiles of a workspace built WITH edge weights are weighted sums (what sGAT starts from); GINet /
+        FoutNet start from plain sums: a workspace of the other flavour is stepped without its tiles."""
+        return (getattr(topo, "ws_f32", None) is not None) == (self.kind == _lib.SGAT)
+
+    def _usable_flags(self, topo, x=None):
+        """The TOPO_* flags of ``topo`` as a launch of this net may rely on them: TILES only with tiles of this kind's
+        flavour that were formed from the ``x`` the launch steps (a Topology bakes the neighbour sums of its ``x`` in at
+        build time: another tensor, or the same one modified in place since, makes them stale) in 16-byte aligned memory."""
+        flags = int(getattr(topo, "flags", 0))
+        tiles = getattr(topo, "tiles", None)
+        ok = tiles is not None and (flags & _lib.TOPO_TILES) and self._tiles_match(topo)
+        if ok and x is not None:
+            tx = getattr(topo, "x", None)
+            ok = (tx is not None and tx.data_ptr() == x.data_ptr() and tuple(tx.shape) == tuple(x.shape) and
+                  x.data_ptr() % 16 == 0 and getattr(topo, "_tiles_x_version", None) == x._version)
+        if not ok:
+            flags &= ~_lib.TOPO_TILES
+        return flags
+
+    def _plan(self, n_feat, max_nodes, max_edges, max_c0, B, co=0, train=True, topo_flags=0):
+        return self.api.step_plan(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O, B, co, train,
+                                  topo_flags, self.plan_overrides)
+
+    def _plan_for(self, topo, n_feat, next_topo=None, train=True, x=None, flags=None):
+        return self._plan(n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, topo.n_graphs,
+                          0 if next_topo is None else next_topo.n_graphs, train,
+                          self._usable_flags(topo, x) if flags is None else flags)
+
+    def _can_fuse(self, topo, n_feat, next_topo=None, train=True, x=None):
+        """True when the launch on ``topo`` (what it holds NOW, for the ``x`` given) is one of the fused step kernels --
+        judged by the plan of exactly that launch (kernel family, layout and LDS need: drgnn_net_step_plan)."""
         if not self.fused_step or topo.max_nodes <= 0:
             return False
-        wgs, need = self.api.net_step_plan(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0,
-                                           self.R, self.H, self.O, topo.n_graphs,
-                                           0 if next_topo is None else next_topo.n_graphs)
-        return wgs > 0 and 0 < need <= 160 * 1024
+        p = self._plan_for(topo, n_feat, next_topo, train, x)
+        return p.family != _lib.STEP_FAMILY_NONE and 0 < p.lds_bytes <= 160 * 1024
 
-    def _layout(self, n_feat, max_nodes, max_edges, max_c0, B, train, topo_flags, dev, x=None):
-        """Launch layout of a fused step: (slabs per graph, exchange buffer, split flag).  GINet: two slabs per graph in
-        every layout.  sGAT / FoutNet: the node-split layout (two workgroups = two slabs per graph, drgnn_step2.h) for
-        training launches whenever drgnn_net_step_plan offers it -- assuming a co-built topology of the same size -- and
-        the topology holds the hierarchical order."""
-        api, nb = self.api, self.n_branch
-        split = 0
-        if nb == 1 and train and (topo_flags & _lib.TOPO_HIER) and (topo_flags & _lib.TOPO_TILES) and \
-                (x is None or x.data_ptr() % 16 == 0):
-            wgs, _ = api.net_step_plan(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O, B, B)
-            split = 1 if wgs == 2 else 0
-        xchg = None
-        if nb > 1 or split:
-            words = api.net_step_xchg_elems(self.kind, max_nodes, max_c0, self.H) if split else nb * max(self.H, 32)
-            key = (B, words)
-            xchg = self._xchg.get(key)
-            if xchg is None:
-                xchg = self._xchg[key] = torch.zeros((max(B, 1), words), dtype=torch.int64, device=dev)
-        return (2 if split else nb), xchg, split
+    def _xchg_for(self, plan, B, dev):
+        """Exchange words of a launch with this plan: ONE buffer per batch size, grown to the largest need seen (the words
+        carry the step index as a tag, so stale ones are harmless; the launch is told the stride through its bounds)."""
+        words = int(plan.xchg_words)
+        if words <= 0 and self.n_branch == 1:
+            return None
+        words = max(words, self.n_branch * max(self.H, 32))
+        buf = self._xchg.get(B)
+        if buf is None or buf.shape[1] < words:
+            buf = self._xchg[B] = torch.zeros((max(B, 1), words), dtype=torch.int64, device=dev)
+        return buf
 
-    def _fused_prepare(self, batch, topo, train=True):
-        """Buffers and descriptors of one fused step (allocation only, no launch)."""
-        api = self.api
-        x = batch.x.contiguous()
-        n_nodes, n_feat = x.shape
-        dev = x.device
-        B, nb = topo.n_graphs, self.n_branch
-        y = getattr(batch, "y", None)
-        if y is not None:
-            y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
-        topo_flags = int(getattr(topo, "flags", 0))
-        if not (getattr(topo, "tiles", None) is not None and self._tiles_match(topo)):
-            topo_flags &= ~_lib.TOPO_TILES       # (no tiles, or tiles of the other flavour: stepped without them)
-        slabs, xchg, split = self._layout(n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, B, train, topo_flags, dev, x)
-        # descriptors only depend on the (fixed) parameter storage and the feature width: built once
+    def _step_buffers(self, plan, n_feat, B, dev):
+        """descriptors (per feature width) and slabs (per batch size and layout) of a fused step"""
+        nb = self.n_branch
         ck = self._desc_cache.get(n_feat)
         if ck is None:
             g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
@@ -195,60 +214,69 @@ class FusedTrainer(object):
                 _fill_grads(g1[b], self.kind, l1, n_feat, H1)
                 _fill_grads(g2[b], self.kind, l2, H1, H2)
             ck = self._desc_cache[n_feat] = (g1, g2, _describe(self.kind, n_feat, self.live, nb))
-        g1, g2, desc = ck
-        # slabs are internal scratch of the step: one set per batch size (predictions stay per-step tensors)
+        slabs = max(int(plan.slabs_per_graph), nb)
         bk = self._slab_cache.get((B, n_feat, slabs))
         if bk is None:
             bk = self._slab_cache[(B, n_feat, slabs)] = (
                 torch.empty((B, H2 * nb), dtype=torch.float32, device=dev),
-                torch.empty((max(B * slabs, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
-                torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
-        readout, partials, hp = bk
+                torch.empty((max(B * slabs, 1), self.api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
+                torch.empty((max(B, 1), self.api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
+        return ck, bk, slabs
+
+    def _fused_prepare(self, batch, topo, train=True, next_topo=None):
+        """Buffers and descriptors of one fused step (allocation only, no launch)."""
+        x = batch.x.contiguous()
+        n_nodes, n_feat = x.shape
+        dev = x.device
+        B = topo.n_graphs
+        y = getattr(batch, "y", None)
+        if y is not None:
+            y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
+        topo_flags = self._usable_flags(topo, x)
+        if (int(getattr(topo, "flags", 0)) & _lib.TOPO_TILES) and not (topo_flags & _lib.TOPO_TILES) and \
+                self._tiles_match(topo) and getattr(topo, "tiles", None) is not None and x.data_ptr() % 16 == 0 and \
+                tuple(x.shape) == tuple(topo.x.shape):
+            # the tiles were formed from other node features than the ones being stepped (x replaced or modified in place
+            # since the build): form them again from this x (own launch, same stream)
+            topo.x = x
+            topo.rebuild()
+            topo_flags = self._usable_flags(topo, x)
+        plan = self._plan_for(topo, n_feat, next_topo, train, x, flags=topo_flags)
+        (g1, g2, desc), (readout, partials, hp), slabs = self._step_buffers(plan, n_feat, B, dev)
+        xchg = self._xchg_for(plan, B, dev)
         # host copies of the mini-batch's offsets (Batch.from_data_list / the resident set record them): they travel in
         # the launch arguments, so a workgroup need not fetch them from the workspace first
         bd = getattr(batch, "__dict__", {})
         hn, he = bd.get("_host_node_ptr"), bd.get("_host_edge_ptr")
-        tiles = getattr(topo, "tiles", None) if (train and (topo_flags & _lib.TOPO_TILES)) else None
+        tiles = getattr(topo, "tiles", None) if (topo_flags & _lib.TOPO_TILES) else None
         if hn is not None and he is not None and len(hn) == B + 1 and B <= 64:
-            hints = _lib.step_hints(node_ptr=hn, edge_ptr=he, topo_flags=topo_flags if train else 0, split=split, tiles=tiles)
+            hints = _lib.step_hints(node_ptr=hn, edge_ptr=he, topo_flags=topo_flags, tiles=tiles, plan=plan)
         else:
-            hints = _lib.step_hints(topo_flags=topo_flags if train else 0, split=split, tiles=tiles)
+            hints = _lib.step_hints(topo_flags=topo_flags, tiles=tiles, plan=plan)
         return dict(
-            hints=hints, slabs=slabs,
+            hints=hints, slabs=slabs, plan=plan,
             x=x, y=y, topo=topo, B=B, n_nodes=n_nodes, xchg=xchg, g1=g1, g2=g2, desc=desc,
             stream=_lib.current_stream(x), pred=torch.empty((B, self.O), dtype=torch.float32, device=dev),
             readout=readout, partials=partials, hp=hp)
 
-    def _tiles_match(self, topo):
-        """The aggregation tiles of a workspace built WITH edge weights are weighted sums (what sGAT starts from); GINet /
-        FoutNet start from plain sums: a workspace of the other flavour is stepped without its tiles."""
-        return (getattr(topo, "ws_f32", None) is not None) == (self.kind == _lib.SGAT)
-
-    def _af_launch(self, topo, n_feat, n_next):
-        """True when a TRAINING launch on ``topo`` (co-building ``n_next`` graphs) runs one of the aggregation-first kernels
-        (csrc/drgnn_step2.h / drgnn_step3.h): they start from the aggregation tiles the builder forms (TOPO_TILES) and are
-        the launches that accept a workspace built with TOPO_LEAN."""
-        if getattr(topo, "tiles", None) is None or not self._tiles_match(topo):
-            return False
-        return bool(self.api.net_step_family(self.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, self.H, self.O))
-
-    def _flags_for(self, topo, n_feat):
-        """Request flags of a topology the next launch co-builds.  When the launch that will train on it is one of the
-        aggregation-first kernels: the hierarchical node order, the aggregation tiles, and nothing those kernels do not read
-        (TOPO_LEAN: the builder's short chains) -- judged for a following mini-batch of the same size; _fused_launch_step
-        rebuilds in full should that turn out wrong.  Otherwise the plain build."""
-        if self._af_launch(topo, n_feat, topo.n_graphs):
-            return _lib.TOPO_HIER | _lib.TOPO_LEAN | _lib.TOPO_TILES
+    def _flags_for(self, topo, n_feat, train=True):
+        """Request flags of a topology the next launch co-builds.  When the launch that will step it is one of the
+        aggregation-first kernels (judged by its plan, for a following mini-batch of the same size): the hierarchical node
+        order, the aggregation tiles, and nothing those kernels do not read (TOPO_LEAN: the builder's short chains);
+        _fused_launch_step rebuilds in full should that turn out wrong.  Otherwise the plain build."""
+        if getattr(topo, "tiles", None) is not None and self._tiles_match(topo):
+            af = _lib.TOPO_HIER | _lib.TOPO_LEAN | _lib.TOPO_TILES
+            if self._plan(n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, topo.n_graphs, topo.n_graphs, train, af).lean_ok:
+                return af
         return 0 if self.kind == _lib.GINET else _lib.TOPO_HIER
 
     def _fused_launch_step(self, c, next_topo=None):
         """ONE launch: body fwd + head/loss + body bwd (+ the next mini-batch's topology)."""
         t = c["topo"]
-        if (int(getattr(t, "flags", 0)) & _lib.TOPO_LEAN) and not self._af_launch(
-                t, c["x"].shape[1], 0 if next_topo is None else next_topo.n_graphs):
-            t.rebuild()      # a lean workspace under a launch that reads more: build the rest (own launch, same stream)
-            c["hints"][0].topo_flags = int(t.flags)
-            c["hints"][0].tiles = _lib._ptr(t.tiles if (int(t.flags) & _lib.TOPO_TILES) else None)
+        if (int(getattr(t, "flags", 0)) & _lib.TOPO_LEAN) and not c["plan"].lean_ok:
+            # a lean workspace under a launch that reads more: build the rest (own launch, same stream), plan again
+            t.rebuild()
+            c.update(self._fused_prepare(_BatchView(c["x"], c["y"]), t, True, next_topo))
         self.api.net_train_step(c["desc"], self._head_desc(True), c["x"], c["y"], self.step2, t.ws_i32, t.ws_f32,
                                 c["n_nodes"], t.n_edges, c["B"], t.max_nodes, t.max_edges, t.max_c0, c["pred"],
                                 c["readout"], c["hp"], c["partials"], c["xchg"], c["stream"],
@@ -264,7 +292,7 @@ class FusedTrainer(object):
                              slabs_per_graph=c.get("slabs", 0))
 
     def _fused(self, batch, topo, apply_adam, next_topo):
-        c = self._fused_prepare(batch, topo)
+        c = self._fused_prepare(batch, topo, True, next_topo)
         self._fused_launch_step(c, next_topo)
         self._fused_launch_update(c, apply_adam)
         self.last_pred = c["pred"]
@@ -286,32 +314,20 @@ class FusedTrainer(object):
         if self.kind == _lib.SGAT and not cache.with_weights:
             raise ValueError("sGAT needs a topology cache built with edge weights (topology_cache(need_weights=True))")
         max_nodes, max_edges, max_c0 = cache.bounds(ids)
-        wgs, need = api.net_step_plan(self.kind, n_feat, max_nodes, max_edges, max_c0, self.R, self.H, self.O, B)
-        if not (wgs > 0 and 0 < need <= 160 * 1024):
-            raise _lib.DrgnnError("a graph of this mini-batch does not fit the fused step kernel's LDS budget")
         topo_flags = int(getattr(cache.topo, "flags", 0))
-        slabs, xchg, split = self._layout(n_feat, max_nodes, max_edges, max_c0, B, train, topo_flags, dev, gset.x)
-        ck = self._desc_cache.get(n_feat)
-        if ck is None:
-            g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-            g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-            for b, (l1, l2) in enumerate(_split(self.kind, self.live_grads, nb)):
-                _fill_grads(g1[b], self.kind, l1, n_feat, H1)
-                _fill_grads(g2[b], self.kind, l2, H1, H2)
-            ck = self._desc_cache[n_feat] = (g1, g2, _describe(self.kind, n_feat, self.live, nb))
-        g1, g2, desc = ck
-        bk = self._slab_cache.get((B, n_feat, slabs))
-        if bk is None:
-            bk = self._slab_cache[(B, n_feat, slabs)] = (
-                torch.empty((B, H2 * nb), dtype=torch.float32, device=dev),
-                torch.empty((max(B * slabs, 1), api.net_partial_elems(self.kind, n_feat)), dtype=torch.float32, device=dev),
-                torch.empty((max(B, 1), api.head_compact_elems(self.R, self.H, self.O)), dtype=torch.float32, device=dev))
-        readout, partials, hp = bk
+        tiles = cache.tiles_for(self.kind == _lib.SGAT) if (topo_flags & _lib.TOPO_TILES) else None
+        if tiles is None or gset.x.data_ptr() % 16 != 0:
+            topo_flags &= ~_lib.TOPO_TILES
+            tiles = None
+        plan = self._plan(n_feat, max_nodes, max_edges, max_c0, B, 0, train, topo_flags)
+        if not (plan.family != _lib.STEP_FAMILY_NONE and 0 < plan.lds_bytes <= 160 * 1024):
+            raise _lib.DrgnnError("a graph of this mini-batch does not fit the fused step kernel's LDS budget")
+        (g1, g2, desc), (readout, partials, hp), slabs = self._step_buffers(plan, n_feat, B, dev)
+        xchg = self._xchg_for(plan, B, dev)
         # (beyond 64 graphs the offsets no longer travel in the kernel arguments, but the library still range-checks the ids)
         hints = _lib.step_hints(set_node_ptr=gset.node_ptr, set_edge_ptr=gset.edge_ptr, ids=ids,
-                                topo_flags=topo_flags if train else 0, split=split,
-                                tiles=cache.tiles_for(self.kind == _lib.SGAT) if (train and (topo_flags & _lib.TOPO_TILES)) else None)
-        return dict(hints=hints, slabs=slabs,
+                                topo_flags=topo_flags, tiles=tiles, plan=plan)
+        return dict(hints=hints, slabs=slabs, plan=plan,
                     cache=cache, ids_dev=ids_dev, B=B, bounds=(max_nodes, max_edges, max_c0), xchg=xchg, g1=g1, g2=g2,
                     desc=desc, stream=_lib.current_stream(gset.x), readout=readout, partials=partials, hp=hp,
                     pred=torch.empty((B, self.O), dtype=torch.float32, device=dev))
@@ -350,7 +366,7 @@ class FusedTrainer(object):
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
-        if self._can_fuse(topo, batch.x.shape[1], next_topo):
+        if self._can_fuse(topo, batch.x.shape[1], next_topo, True, batch.x):
             return self._fused(batch, topo, apply_adam, next_topo)
         if int(getattr(topo, "flags", 0)) & _lib.TOPO_LEAN:
             topo.rebuild()       # the launch pair reads CSC0 and the member lists a lean build leaves out
@@ -590,6 +606,12 @@ class FusedTrainer(object):
         if cached:
             cache = gset.topology_cache(need_weights=need_w)
             plan.cache = ctypes.cast(ctypes.pointer(cache.desc_for(self.kind == _lib.SGAT)), vp)
+        ov = None
+        if self.plan_overrides:
+            ov = _lib.StepPlan()
+            for key, val in self.plan_overrides.items():
+                setattr(ov, key, int(val))
+            plan.step_overrides = ctypes.addressof(ov)
         callback = None
         if not inference and getattr(self, "_dp", None) is not None:
             sizes, group = self._dp
@@ -644,7 +666,7 @@ class FusedTrainer(object):
             raise
         finally:
             self._dp_first_batch = 0
-        del callback
+        del callback, ov
         if not inference:
             self.last_pred = pred[(nb - 1) * batch_size:]
             self.last_batch_size = n - (nb - 1) * batch_size
@@ -696,16 +718,20 @@ class FusedTrainer(object):
         api = self.api
         if topo is None:
             topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
-        if int(getattr(topo, "flags", 0)) & _lib.TOPO_LEAN:
-            topo.rebuild()       # inference launches read the depth-0 member lists a lean build leaves out
-        if self._can_fuse(topo, batch.x.shape[1], next_topo):
-            c = self._fused_prepare(batch, topo, train=False)
+        if self._can_fuse(topo, batch.x.shape[1], next_topo, False, batch.x):
+            c = self._fused_prepare(batch, topo, False, next_topo)
+            if (int(getattr(topo, "flags", 0)) & _lib.TOPO_LEAN) and not c["plan"].lean_ok:
+                topo.rebuild()       # this inference launch reads the depth-0 member lists a lean build leaves out
+                c = self._fused_prepare(batch, topo, False, next_topo)
             api.net_train_step(c["desc"], self._head_desc(False), c["x"], None, self.step2, topo.ws_i32, topo.ws_f32,
                                c["n_nodes"], topo.n_edges, c["B"], topo.max_nodes, topo.max_edges, topo.max_c0,
                                c["pred"], c["readout"], None, None, c["xchg"], c["stream"],
-                               next_topology=None if next_topo is None else next_topo.request(self.topo_flags),
+                               next_topology=None if next_topo is None else next_topo.request(
+                                   self._flags_for(next_topo, c["x"].shape[1], train=False)),
                                hints=None if c.get("hints") is None else c["hints"][0])
             return c["pred"]
+        if int(getattr(topo, "flags", 0)) & _lib.TOPO_LEAN:
+            topo.rebuild()       # the forward launch reads the depth-0 member lists a lean build leaves out
         if next_topo is not None:
             next_topo.rebuild()
         stream = _lib.current_stream(batch.x)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DRGNN_ABI_VERSION 1
+#define DRGNN_ABI_VERSION 2
 
 /* host-side argument errors */
 #define DRGNN_E_ARG      (-1)   /* null pointer / negative size / bad mode            */
@@ -428,69 +428,87 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   partials  OUT [B*n_branch][drgnn_net_partial_elems]  (split layout: [B*2][...], one slab per half graph)
  *   xchg      uint64 [B][drgnn_net_step_xchg_elems], zero-filled ONCE by the caller and then left alone: the two
  *             branch workgroups of a GINet graph hand each other their 32 readout values through it, the two half-graph
- *             workgroups of the split layout their pooled rows (may be NULL when n_branch == 1 and hints->split == 0)
+ *             workgroups of the split layout their pooled rows (may be NULL when n_branch == 1 and no plan with wgs_per_graph == 2 is passed)
  * head->train == 0: inference -- forward + head only (dropout off), writes pred and readout; target,
  * head_partials and partials may be NULL and the step counters are left alone.
  * Needs max_nodes/max_edges/max_c0 bounds; returns DRGNN_E_CAPACITY when a graph of that size does
  * not fit the 160 KiB LDS (drgnn_net_step_lds_bytes): use drgnn_net_forward +
  * drgnn_net_backward_fused_head + drgnn_train_update then. */
-/* Optional host-side knowledge about the graphs of a launch (all pointers HOST memory, read during the call):
- * host_node_ptr / host_edge_ptr [n_graphs + 1] = the mini-batch's node / edge offsets (the tables the topology was built
- * with); cached mode: host_ids [n_graphs] = the graph numbers and host_node_ptr / host_edge_ptr [set graphs + 1] = the
- * SET's int64 offset tables.  For up to 64 graphs the offsets then travel in the kernel arguments and a workgroup does
- * not fetch them from the workspace before it can address its loads (one dependent memory round trip less). */
+/* ---- launch plan of the fused step ---------------------------------------------------------------------------------------
+ * Which kernel family and launch layout a fused step of a given shape takes, as ONE function of the launch's description:
+ * drgnn_net_step_plan() fills the `out` members from the `in` members, drgnn_net_train_step* and drgnn_train_epoch decide
+ * through the same code, so a caller that sizes its buffers from a plan and passes that plan along (drgnn_step_hints.plan)
+ * gets the layout it planned or an error, never a silent third one.
+ *   family   DRGNN_STEP_FAMILY_AGGREGATE: csrc/drgnn_step2.h (sGAT / FoutNet) / drgnn_step3.h (GINet) -- conv1 starts from the
+ *            aggregation tiles the topology builder formed (DRGNN_TOPO_TILES), rows in the builder's hierarchical order
+ *            (DRGNN_TOPO_HIER); padded feature widths 16 / 32 / 48 / 64, the reference heads (fc1 width 128 / 64), training and
+ *            inference launches.  DRGNN_STEP_FAMILY_PRODUCT: csrc/drgnn_step.h / drgnn_step1.h -- any feature width <= 256, any
+ *            head, any built topology.  DRGNN_STEP_FAMILY_NONE: a graph does not fit the fused kernels' LDS budget (use
+ *            drgnn_net_forward + drgnn_net_backward_fused_head).
+ *   wgs_per_graph  GINet (ginet.py:99-141: two branches over the same edge_index): 2 = one workgroup per branch, readouts
+ *            exchanged, taken ONLY while all 2 * n_graphs (+ the co-launched builder's) workgroups are resident at once (one
+ *            workgroup per CU: HIP promises nothing about dispatch order); 1 = both branches in one workgroup, no cross-workgroup
+ *            wait.  sGAT / FoutNet: 2 = the node-split layout (each workgroup owns the depth-1 clusters of one half of the graph;
+ *            training launches of the aggregation-first family under the same residency rule); 1 otherwise.
+ *   slabs_per_graph  conv gradient slabs per graph in `partials` (what drgnn_step_update must be told)
+ *   width    the padded feature width of the specialised kernel instance, 0 = the generic instance
+ *   cls      1: the instance with the compile-time LDS layout of the capacity class (200 nodes, 1024 edges, 52 depth-0 clusters
+ *            per graph; 32-wide kernels) -- the same arithmetic in the same order, bit-identical results
+ *   lean_ok  1: the launch reads nothing a DRGNN_TOPO_LEAN build leaves out
+ *   builder_wgs_per_graph  of the topology the same launch builds: 2 / 1; 0 = it gets a launch of its own
+ *   lds_bytes  LDS one workgroup needs (<= 160 KiB whenever family != NONE); xchg_words: uint64 exchange words per graph
+ * Overrides (0 = automatic; tests and same-box A/B runs): force_wgs 1 / 2 = always that many workgroups per graph (2 beyond the
+ * resident size is MEASUREMENT ONLY: the exchange then leans on in-order dispatch; bounded wait + fault bit); no_class;
+ * no_aggregate (the product-first family everywhere); no_split (sGAT / FoutNet never divided); no_paired (the one-workgroup
+ * product-first GINet kernel runs branch after branch).  The environment variable DRGNN_STEP_PLAN (comma list of one, two,
+ * noclass, product, nosplit, seq; read once) sets the defaults of a process for plans that override nothing. */
+#define DRGNN_STEP_FAMILY_NONE 0
+#define DRGNN_STEP_FAMILY_PRODUCT 1
+#define DRGNN_STEP_FAMILY_AGGREGATE 2
+typedef struct drgnn_step_plan {
+    /* in: the launch */
+    int32_t kind, n_feat, max_nodes, max_edges, max_c0, R, H, O;
+    int64_t n_graphs;
+    int64_t co_built_graphs;   /* graphs of the topology the same launch builds for the next mini-batch (0: none) */
+    int32_t train;             /* 1: training launch; 0: inference */
+    int32_t topo_flags;        /* DRGNN_TOPO_* flags of the workspace the launch READS.  DRGNN_TOPO_TILES only if it comes with
+                                  tiles of this kind's flavour (sGAT: weighted sums) and x is 16-byte aligned */
+    /* in: overrides */
+    int32_t force_wgs, no_class, no_aggregate, no_split, no_paired;
+    /* out */
+    int32_t family, wgs_per_graph, slabs_per_graph, width, cls, lean_ok, builder_wgs_per_graph;
+    int64_t lds_bytes, xchg_words;
+} drgnn_step_plan;
+/* Returns wgs_per_graph (0: family NONE).  Host-side only. */
+int32_t drgnn_net_step_plan(drgnn_step_plan* plan);
+
+/* Host-known offsets / sizes of the mini-batch's graphs (Batch.from_data_list and the resident set record them): for up to
+ * 64 graphs they travel in the kernel arguments, so a workgroup need not fetch them from the workspace
+ * first (one dependent memory round trip less).  All members optional. */
 typedef struct drgnn_step_hints {
     const int32_t* host_node_ptr; const int32_t* host_edge_ptr;       /* per mini-batch (drgnn_net_train_step) */
     const int64_t* set_node_ptr; const int64_t* set_edge_ptr; const int32_t* host_ids;   /* cached mode */
-    /* What the caller vouches for (both 0: the behaviour of callers that know nothing of the node-split kernels):
-     * topo_flags: the DRGNN_TOPO_* flags the topology workspace was BUILT with (DRGNN_TOPO_HIER lets sGAT / FoutNet steps run
-     *             the aggregation-first kernels, csrc/drgnn_step2.h);
-     * split:      1 = run the TWO-workgroups-per-graph layout of a single-branch net (drgnn_net_step_plan returned 2): the
-     *             caller sized `partials` for 2 slabs per graph and `xchg` for drgnn_net_step_xchg_elems words per graph and
-     *             will pass slabs_per_graph = 2 to drgnn_step_update.  DRGNN_E_CAPACITY if the launch cannot be laid out so. */
-    int32_t topo_flags, split;
+    /* topo_flags: the DRGNN_TOPO_* flags the topology workspace was BUILT with -- what the caller vouches for (0: a caller
+     *             that knows nothing of the hierarchical order: the product-first family) */
+    int32_t topo_flags, reserved;
     /* DRGNN_TOPO_TILES in topo_flags: the aggregation tiles the builder formed for this workspace (DEVICE memory, laid out
      * for the workspace's node count): the aggregation-first kernels start conv1 from them. */
     const float* tiles;
+    /* the plan the caller sized `partials` (slabs_per_graph) and `xchg` (xchg_words) from, and its overrides.  NULL: no
+     * overrides, and a single-branch net is never divided between two workgroups (one slab per graph).  A launch that
+     * cannot take the plan's wgs_per_graph returns DRGNN_E_CAPACITY. */
+    const drgnn_step_plan* plan;
 } drgnn_step_hints;
 /* uint64 exchange words per graph the fused step needs for these bounds (GINet: n_branch x max(H, 32); the split layout
  * of sGAT / FoutNet: two hand-offs of max_c0 x 16 values per half + the partial readouts) */
 int64_t drgnn_net_step_xchg_elems(int32_t kind, int32_t max_nodes, int32_t max_c0, int32_t H);
-/* 1: TRAINING launches of this shape on a topology built with DRGNN_TOPO_HIER (drgnn_step_hints.topo_flags) are stepped by
- * the aggregation-first kernels of csrc/drgnn_step2.h; 0: by the kernels of csrc/drgnn_step.h.  Host-side only (lets tests and
- * bench.py state which kernel family they exercised). */
-int32_t drgnn_net_step_family(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t H,
-                              int32_t O);
 int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                  int32_t max_c0, int32_t R, int32_t H, int32_t O);
 int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O);
-/* Which instantiation of the fused step kernel drgnn_net_train_step launches for these bounds: the padded
- * feature width (16/32/48/64) of the width-specialised kernel, or 0 for the generic one.  Host-side only
- * (lets tests and bench.py state which kernel instance they exercised). */
+/* Which instantiation of the PRODUCT-FIRST step kernel a launch of these bounds takes: the padded feature width
+ * (16/32/48/64) of the width-specialised kernel, or 0 for the generic one.  Host-side only. */
 int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                int32_t max_c0, int32_t H, int32_t O);
-/* Launch layout of the fused step for a mini-batch of n_graphs graphs with these bounds, co_built_graphs = graphs of the
- * topology the same launch builds for the next mini-batch (0: none) (ginet.py:99-141: the two branches convolve over the
- * same edge_index).  Returns the workgroups per graph -- 2: GINet's branches run in two
- * workgroups that exchange their readouts, taken ONLY while all 2 * n_graphs (+ co-launched builder) workgroups are
- * resident at once (one workgroup per CU), because HIP promises nothing about dispatch order; 1: one workgroup per graph
- * (GINet beyond that size: both branches one after the other, staged once, no cross-workgroup wait; sGAT / FoutNet beyond
- * that size or outside the 32-wide specialised shape) -- sGAT / FoutNet: 2 = the node-split layout (csrc/drgnn_step2.h: each
- * workgroup owns the depth-1 clusters of one half of the graph; TRAINING launches on a topology built with DRGNN_TOPO_HIER
- * only, requested through drgnn_step_hints.split) -- or 0 when the bounds are outside the fused kernels (use the launch pair).  *lds_bytes: LDS one workgroup of
- * that layout needs (drgnn_net_train_step returns DRGNN_E_CAPACITY beyond 160 KiB). */
-int32_t drgnn_net_step_plan(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges, int32_t max_c0, int32_t R,
-                            int32_t H, int32_t O, int64_t n_graphs, int64_t co_built_graphs, int64_t* lds_bytes);
-/* Process-wide override of that choice: 0 = by residency (default), 1 = always one workgroup per graph (tests, A/B runs),
- * 2 = always two (measurement only: beyond the resident size the exchange then leans on in-order dispatch);
- * 3 / 4 = the one-workgroup layout runs branch after branch / both branches per phase whenever that fits LDS (default 4);
- * 5 / 6 = batches whose maxima lie inside the capacity class (200 nodes, 1024 edges, 52 depth-0 clusters per graph, feature
- * widths 17 .. 32, reference head widths) are stepped by the kernels with the compile-time LDS layout / never (default 5;
- * the same arithmetic in the same order: bit-identical results, 0.2 - 0.4 us per step apart);
- * 7 / 8 = sGAT / FoutNet steps may take the aggregation-first kernels (drgnn_step2.h) where the caller vouches for the
- * hierarchical order / never (default 7; 8: drgnn_net_step_plan never answers 2 for them);
- * 9 / 10 = ... with two workgroups per graph where drgnn_net_step_plan offers it / never split (default 9). */
-int32_t drgnn_set_step_layout(int32_t mode);
 int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head, const float* x,
                          const void* target, int32_t* step2, const int32_t* ws_i32, const float* ws_f32,
                          int64_t n_nodes, int64_t n_edges, int64_t n_graphs, int32_t max_nodes,
@@ -612,6 +630,8 @@ typedef struct drgnn_epoch_plan {
     /* data parallel (non-NULL): per mini-batch  gradient launches -> exchange(...) -> Adam launch  instead of the fused
      * reduce+Adam launch; every rank must run the same number of mini-batches */
     drgnn_exchange_fn exchange; void* exchange_user;
+    /* optional: the override members of this plan apply to every step launch of the loop (tests, A/B runs) */
+    const drgnn_step_plan* step_overrides;
 } drgnn_epoch_plan;
 int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan);
 int drgnn_train_epoch(const drgnn_epoch_plan* plan, void* scratch, int64_t scratch_bytes, float* pred,

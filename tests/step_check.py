@@ -100,26 +100,29 @@ def check_fused_predict(Net, n_feat, task, device, api=None, seed=0):
     np.testing.assert_allclose(pa, tb.predict(batch).cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
-class one_workgroup_layout(object):
-    """``with one_workgroup_layout(api):`` every GINet fused-step launch inside runs both branches of a graph in ONE
-    workgroup (drgnn_set_step_layout(1)), the layout the library takes by itself beyond the resident batch size."""
+class plan_overrides(object):
+    """``with plan_overrides(trainer, force_wgs=1):`` every fused-step launch of THAT trainer inside the block is planned
+    with these overrides of drgnn_step_plan (force_wgs / no_class / no_aggregate / no_split / no_paired); other trainers of the
+    process are not affected (the overrides travel with the plan, there is no process-wide switch)."""
 
-    def __init__(self, api=None, paired=True):
-        """paired: both branches share every phase (the default form); False: branch after branch (the form graphs too
-        large for the paired LDS plan take)"""
-        from deeprank_gnn_amd import _lib
-        self.api = api or _lib.get()
-        self.paired = paired
+    def __init__(self, trainer, **ov):
+        self.trainer, self.ov = trainer, ov
 
     def __enter__(self):
-        self.api.set_step_layout(4 if self.paired else 3)
-        self.api.set_step_layout(1)
+        self.saved = dict(self.trainer.plan_overrides)
+        self.trainer.plan_overrides = dict(self.saved, **self.ov)
         return self
 
     def __exit__(self, *exc):
-        self.api.set_step_layout(0)
-        self.api.set_step_layout(4)
+        self.trainer.plan_overrides = self.saved
         return False
+
+
+def one_workgroup_layout(trainer, paired=True):
+    """every GINet fused-step launch of ``trainer`` runs both branches of a graph in ONE workgroup, the layout the library
+    takes by itself beyond the resident batch size.  paired: both branches share every phase (the default form of the
+    product-first kernel); False: branch after branch (the form graphs too large for the paired LDS plan take)"""
+    return plan_overrides(trainer, force_wgs=1, no_paired=0 if paired else 1)
 
 
 def check_one_workgroup_layout(n_feat, task, device, api=None, seed=0, paired=True):
@@ -147,13 +150,12 @@ def check_one_workgroup_layout(n_feat, task, device, api=None, seed=0, paired=Tr
     tb = FusedTrainer(b.to(device), lr=0.01, task=task, class_weights=cw, **kw)
     topo = Topology.from_batch(batch, need_weights=False, **kw)
     assert ta._can_fuse(topo, n_feat)
-    wgs, _ = api.net_step_plan(ta.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, ta.R, ta.H, ta.O, topo.n_graphs)
-    assert wgs == 2                                  # a handful of graphs: resident, two workgroups per graph
-    with one_workgroup_layout(api, paired):
-        assert api.net_step_plan(ta.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, ta.R, ta.H, ta.O,
-                                 topo.n_graphs)[0] == 1
+    assert ta._plan_for(topo, n_feat).wgs_per_graph == 2      # a handful of graphs: resident, two workgroups per graph
+    with one_workgroup_layout(ta, paired):
+        assert ta._plan_for(topo, n_feat).wgs_per_graph == 1
+        assert tb._plan_for(topo, n_feat).wgs_per_graph == 2      # (the other trainer of the process keeps its own plan)
     for it in range(2):
-        with one_workgroup_layout(api, paired):
+        with one_workgroup_layout(ta, paired):
             pa = ta.predict(batch).cpu().numpy()
             la = ta.train_step(batch)
         pb = tb.predict(batch).cpu().numpy()

@@ -214,11 +214,8 @@ def test_dropout_mask_override_matches_oracle():
     for layout in (0, 1):
         tr = FusedTrainer(copy.deepcopy(net), lr=0.01, task="reg", api=emu())
         tr.drop_mask = mask.contiguous()
-        emu().set_step_layout(layout)
-        try:
-            loss = tr.compute_gradients(batch)
-        finally:
-            emu().set_step_layout(0)
+        tr.plan_overrides = {"force_wgs": layout}      # (1: both branches of a graph in one workgroup)
+        loss = tr.compute_gradients(batch)
         np.testing.assert_allclose(float(loss), float(ref_loss), rtol=2e-5)
         np.testing.assert_allclose(tr.last_pred.numpy(), ref_pred.numpy(), rtol=1e-4, atol=1e-5)
         for name, p in tr.net.named_parameters():

@@ -146,14 +146,10 @@ def test_fused_step_syn64_dropout_on_matches_oracle_elementwise(layout):
     batch = batch_cpu.clone().to(dev)
     topo = Topology.from_batch(batch, need_weights=False)
     assert tr._can_fuse(topo, 32)
-    api = _lib.get()
-    api.set_step_layout(1 if layout == "one" else 0)
-    try:
-        nxt = Topology.from_batch(batch, need_weights=False, build=False)
-        loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
-        torch.cuda.synchronize()
-    finally:
-        api.set_step_layout(0)
+    tr.plan_overrides = {"force_wgs": 1} if layout == "one" else {}
+    nxt = Topology.from_batch(batch, need_weights=False, build=False)
+    loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
+    torch.cuda.synchronize()
     # the mask really bit: the dropout-off prediction differs
     off_pred, _, _ = cpu_ref.loss_and_grads("GINet", params, batch_cpu, batch_cpu.y)
     assert float((off_pred - ref_pred).abs().max()) > 1e-3
@@ -234,6 +230,7 @@ def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_s
     is one workgroup per graph (both branches in sequence: drgnn_step3.h's net_step3_graph_both, from the aggregation tiles).  Element-wise against the oracle; the first 64
     graphs' predictions equal what the two-workgroup layout gives on them alone (same arithmetic per branch)."""
     import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
     from deeprank_gnn_amd.topology import Topology
     dev = _dev()
     n_graphs = 130
@@ -258,12 +255,11 @@ def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_s
     tr.compute_gradients(small, topo=t64)                  # (no update in between: same parameters)
     pred_af = tr.last_pred.cpu().numpy().copy()            # the two-workgroup kernel of the same family (drgnn_step3.h)
     np.testing.assert_array_equal(pred_one, pred_af)       # forward arithmetic is the same code in both layouts
-    tr.api.set_step_layout(12)                             # ... and the product-first kernels (drgnn_step.h): same numbers to rounding
-    try:
-        tr.compute_gradients(small, topo=t64)
-        pred_two = tr.last_pred.cpu().numpy()
-    finally:
-        tr.api.set_step_layout(11)
+    tr.plan_overrides = {"no_aggregate": 1}                # ... and the product-first kernels (drgnn_step.h): same numbers to rounding
+    assert tr._plan_for(t64, 32).family == _lib.STEP_FAMILY_PRODUCT
+    tr.compute_gradients(small, topo=t64)
+    pred_two = tr.last_pred.cpu().numpy()
+    tr.plan_overrides = {}
     np.testing.assert_allclose(pred_one, pred_two, rtol=1e-4, atol=1e-5)
 
 
@@ -412,7 +408,7 @@ def test_benchmark_schedule_is_reproducible_and_graph_replays_equal_eager_launch
 def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, cached, n_graphs):
     """A batch inside the capacity class (200 nodes / 1024 edges / 52 clusters per graph, 32 features) is stepped by kernels
     whose LDS layout is a compile-time constant (drgnn_step.h: CLS); the layout moves arrays, not arithmetic: three training
-    steps give the same bits with the class kernels (default) and without (drgnn_set_step_layout(6)), rebuilt and cached;
+    steps give the same bits with the class kernels (default) and without (plan override no_class), rebuilt and cached;
     136 graphs: GINet's one-workgroup (paired) layout and the other kinds beyond one round of workgroups."""
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd import _lib
@@ -428,33 +424,39 @@ def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, c
     rs = ResidentGraphSet([synth.make_graph(i) for i in range(n_graphs)], dev) if cached else None
     cache = rs.topology_cache(need_weights=(net_name == "sGAT")) if cached else None
     out = []
-    for mode in (5, 6):
-        api.set_step_layout(mode)
-        try:
-            torch.manual_seed(3)
-            tr = FusedTrainer(Net(32, 1, 1).to(dev), lr=1e-2, task="reg", seed=5)
-            for _ in range(3):
-                if cached:
-                    tr.train_step_cached(cache, list(range(n_graphs)))
-                else:
-                    tr.train_step(batch)
-            torch.cuda.synchronize()
-            assert tr.faults() == 0
-            out.append([t.detach().cpu().numpy().copy() for t in (tr.flat_p, tr.exp_avg_sq, tr.loss, tr.last_pred)])
-        finally:
-            api.set_step_layout(5)
+    for no_class in (0, 1):
+        torch.manual_seed(3)
+        tr = FusedTrainer(Net(32, 1, 1).to(dev), lr=1e-2, task="reg", seed=5)
+        tr.plan_overrides = {"no_class": no_class}
+        if cached:
+            assert tr._cached_prepare(cache, list(range(n_graphs)))["plan"].cls == 1 - no_class
+        else:
+            from deeprank_gnn_amd.topology import Topology
+            assert tr._plan_for(Topology.from_batch(batch, need_weights=(net_name == "sGAT")), 32).cls == 1 - no_class
+        for _ in range(3):
+            if cached:
+                tr.train_step_cached(cache, list(range(n_graphs)))
+            else:
+                tr.train_step(batch)
+        torch.cuda.synchronize()
+        assert tr.faults() == 0
+        out.append([t.detach().cpu().numpy().copy() for t in (tr.flat_p, tr.exp_avg_sq, tr.loss, tr.last_pred)])
     for a, b, name in zip(out[0], out[1], ("parameters", "exp_avg_sq", "loss", "predictions")):
         np.testing.assert_array_equal(a, b, err_msg=name)
     assert np.isfinite(out[0][0]).all()
 
 
 # ---- sGAT / FoutNet: the three kernel families (round-3 kernel / aggregation first, one workgroup / node split) --------------
-AF_LAYOUTS = {"old": (8,), "af1": (7, 10), "af2": (7, 9)}
+AF_LAYOUTS = {"old": {"no_aggregate": 1}, "af1": {"no_split": 1}, "af2": {}}
 
 
-def _with_layout(api, name):
-    for m in AF_LAYOUTS[name]:
-        api.set_step_layout(m)
+def _check_family(tr, c, layout):
+    """the plan a prepared step carries is the family / layout the test means to exercise"""
+    from deeprank_gnn_amd import _lib
+    plan = c["plan"]
+    assert plan.family == (_lib.STEP_FAMILY_PRODUCT if layout == "old" else _lib.STEP_FAMILY_AGGREGATE), (layout, plan.family)
+    assert c["slabs"] == plan.slabs_per_graph == (2 if layout == "af2" else 1), (layout, plan.slabs_per_graph)
+    assert plan.wgs_per_graph == (2 if layout == "af2" else 1)
 
 
 @pytest.mark.parametrize("layout", ["old", "af1", "af2"])
@@ -477,15 +479,12 @@ def test_single_branch_step_families_syn64_match_oracle_elementwise(net_name, la
     lazy = Lazy64(net_name, params, batch_cpu, **kw)
     batch = batch_cpu.clone().to(dev)
     need_w = net_name == "sGAT"
-    _with_layout(api, layout)
-    try:
+    if True:
         net, tr = _trainer(net_name, params)
+        tr.plan_overrides = dict(AF_LAYOUTS[layout])
         topo = Topology.from_batch(batch, need_weights=need_w)
         nxt = Topology.from_batch(batch, need_weights=need_w, build=False)
-        c = tr._fused_prepare(batch, topo)
-        assert c["slabs"] == (2 if layout == "af2" else 1) and c["hints"][0].split == (1 if layout == "af2" else 0)
-        fam = api.net_step_family(tr.kind, 32, topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O)
-        assert fam == (0 if layout == "old" else 1)
+        _check_family(tr, tr._fused_prepare(batch, topo, True, nxt), layout)
         loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
         torch.cuda.synchronize()
         stats = new_stats()
@@ -502,6 +501,7 @@ def test_single_branch_step_families_syn64_match_oracle_elementwise(net_name, la
         leaves = {k: v.clone().requires_grad_(True) for k, v in params.items()}
         opt = torch.optim.Adam(list(leaves.values()), lr=0.01)
         net, tr = _trainer(net_name, params, lr=0.01)
+        tr.plan_overrides = dict(AF_LAYOUTS[layout])
         topos = [topo, nxt]
         for it in range(3):
             opt.zero_grad()
@@ -514,62 +514,56 @@ def test_single_branch_step_families_syn64_match_oracle_elementwise(net_name, la
         sd = net.state_dict()
         for k, v in leaves.items():
             np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=TOL, atol=TOL, err_msg=k)
-    finally:
-        api.set_step_layout(7)
-        api.set_step_layout(9)
 
 
-@pytest.mark.parametrize("layout", ["af1", "af2"])
-@pytest.mark.parametrize("net_name", ["sGAT", "FoutNet"])
-def test_single_branch_step_families_ragged_batches(net_name, layout):
-    """The aggregation-first kernels on ragged batches (tests/step_check.py: graphs of 1 .. 49 nodes, a single-node graph
-    that leaves one half of the split EMPTY, isolated nodes -> FoutNet's NaN rows / sGAT's bias rows, self loops, duplicate
-    edges, non-consecutive cluster ids), classification and regression, feature widths 20 / 28 padded to 32: vs the round-3
-    kernel on the same inputs (itself pinned on the goldens and the oracle) within the north-star tolerance, NaN pattern
-    equal."""
+@pytest.mark.parametrize("layout", ["old", "af1", "af2"])
+@pytest.mark.parametrize("net_name", ["sGAT", "FoutNet", "GINet"])
+def test_step_families_ragged_batches_vs_oracle(net_name, layout):
+    """Every kernel family on ragged batches (tests/step_check.py: graphs of 1 .. 49 nodes, a single-node graph that leaves
+    one half of the split EMPTY, isolated nodes -> FoutNet's NaN rows / sGAT's bias rows (sGAT.py:62-93, foutnet.py:71-73),
+    self loops, duplicate edges, non-consecutive cluster ids), classification and regression, feature widths 32 / 20 / 28 /
+    12 / 44 / 60 (padded 32, 32, 32, 16, 48, 64): loss, predictions and EVERY gradient element vs the ORACLE on the same
+    inputs (tests/elementwise.py: 1e-4 + 1e-4 |ref|, float64 arbiter), NaN pattern equal.  GINet: the product-first family
+    ("old"), the aggregation-first one-workgroup ("af1") and two-workgroup ("af2") layouts."""
     from deeprank_gnn_amd import _lib
     from deeprank_gnn_amd.topology import Topology
     from deeprank_gnn_amd.trainer import FusedTrainer
     from test_gpu_parity import build
     dev = _dev()
-    api = _lib.get()
     rng = np.random.default_rng(5)
     from step_check import ragged_batch
-    for seed, (n_feat, task) in enumerate(((32, "reg"), (20, "class"), (28, "reg"))):
+    kw = _fw_kwargs(net_name)
+    for seed, (n_feat, task) in enumerate(((32, "reg"), (20, "class"), (28, "reg"), (12, "reg"), (44, "class"), (60, "reg"))):
         batch_cpu = ragged_batch(seed, n_feat)          # 7 graphs: 1 .. 49 nodes, a single-node graph, isolated nodes, self loops, duplicates
         batch_cpu.y = torch.arange(batch_cpu.num_graphs, dtype=torch.float32) * 0.3 - 1.0
         n_out = 1 if task == "reg" else 3
         params = cpu_ref.init_params(net_name, n_feat, n_out, 1, seed=4)
         if task == "class":
             batch_cpu.y = torch.from_numpy(rng.integers(0, 3, size=int(batch_cpu.y.shape[0]))).long()
+        ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, task=task, **kw)
+        lazy = Lazy64(net_name, params, batch_cpu, task=task, **kw)
         batch = batch_cpu.clone().to(dev)
         need_w = net_name == "sGAT"
-        results = {}
-        for lay in ("old", layout):
-            _with_layout(api, lay)
-            try:
-                net = build(net_name, params, n_out)
-                tr = FusedTrainer(net, lr=0.01, task=task)
-                topo = Topology.from_batch(batch, need_weights=need_w)
-                assert tr._can_fuse(topo, n_feat)
-                fam = api.net_step_family(tr.kind, n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, tr.H, tr.O)
-                assert fam == (0 if lay == "old" else 1), (lay, fam)
-                c = tr._fused_prepare(batch, topo)
-                assert c["hints"][0].split == (1 if lay == "af2" else 0)
-                loss = tr.compute_gradients(batch, topo=topo)
-                torch.cuda.synchronize()
-                assert tr.faults() == 0
-                results[lay] = (float(loss), tr.last_pred.cpu().numpy().copy(), _grads_of(net))
-            finally:
-                api.set_step_layout(7)
-                api.set_step_layout(9)
-        (l0, p0, g0), (l1, p1, g1) = results["old"], results[layout]
-        assert np.isnan(l0) == np.isnan(l1)
-        if not np.isnan(l0):
-            np.testing.assert_allclose(l1, l0, rtol=TOL)
-        assert np.array_equal(np.isnan(p0), np.isnan(p1))
-        np.testing.assert_allclose(np.nan_to_num(p1), np.nan_to_num(p0), rtol=TOL, atol=TOL)
-        for k in g0:
-            assert np.array_equal(np.isnan(g0[k]), np.isnan(g1[k])), k
-            scale = max(1.0, float(np.nanmax(np.abs(g0[k]))) if g0[k].size else 1.0)
-            np.testing.assert_allclose(np.nan_to_num(g1[k]), np.nan_to_num(g0[k]), rtol=TOL, atol=TOL * scale, err_msg=k)
+        net = build(net_name, params, n_out)
+        tr = FusedTrainer(net, lr=0.01, task=task)
+        if net_name == "GINet":
+            tr.plan_overrides = {"old": {"no_aggregate": 1}, "af1": {"force_wgs": 1}, "af2": {}}[layout]
+        else:
+            tr.plan_overrides = dict(AF_LAYOUTS[layout])
+        topo = Topology.from_batch(batch, need_weights=need_w)
+        assert tr._can_fuse(topo, n_feat, None, True, batch.x)
+        c = tr._fused_prepare(batch, topo)
+        if net_name == "GINet":
+            assert c["plan"].family == (_lib.STEP_FAMILY_PRODUCT if layout == "old" else _lib.STEP_FAMILY_AGGREGATE)
+            assert c["plan"].wgs_per_graph == (1 if layout == "af1" else 2)
+        else:
+            _check_family(tr, c, layout)
+        assert c["plan"].width == ((n_feat + 15) // 16) * 16
+        loss = tr.compute_gradients(batch, topo=topo)
+        torch.cuda.synchronize()
+        assert tr.faults() == 0
+        stats = new_stats()
+        check_step("%s ragged F=%d %s %s" % (net_name, n_feat, task, layout), lazy, float(loss), tr.last_pred.cpu().numpy(),
+                   _grads_of(net), ref_loss.detach(), ref_pred.detach().numpy(), {k: v.numpy() for k, v in ref_grads.items()}, stats)
+        # (ragged batches are a few thousand elements: the 0.1 % arbiter budget would be a handful)
+        assert stats["arbiter"] <= max(3, stats["elements"] // 200), stats

@@ -16,12 +16,11 @@ dev = torch.device("cuda:0")
 batch = synth.make_batch(0, 64).to(dev)
 torch.manual_seed(0)
 net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[name](32, 1, 1).to(dev)
-for _m in os.environ.get("DRGNN_LAYOUT_MODES", "").split():      # e.g. "8" = round-3 kernels, "10" = aggregation first without the split
-    _lib.get().set_step_layout(int(_m))
+# (layout A/Bs: DRGNN_STEP_PLAN=product|nosplit|one|two|noclass|seq, read by the library at its first plan query)
 tr = FusedTrainer(net, lr=1e-3, seed=1)
 topo = Topology.from_batch(batch, need_weights=(name == "sGAT"))
 nxt = Topology.from_batch(batch, need_weights=(name == "sGAT"), build=False)
-c = tr._fused_prepare(batch, topo)
+c = tr._fused_prepare(batch, topo, True, nxt)
 N = 20
 
 
