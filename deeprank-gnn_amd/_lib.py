@@ -116,7 +116,8 @@ class StepHints(ctypes.Structure):
     """drgnn_step_hints: host-side offset tables of a launch's graphs (pointers to HOST memory), what the workspace holds,
     the plan the caller sized its buffers from."""
     _fields_ = [("host_node_ptr", _vp), ("host_edge_ptr", _vp), ("set_node_ptr", _vp), ("set_edge_ptr", _vp),
-                ("host_ids", _vp), ("topo_flags", _c_i32), ("reserved", _c_i32), ("tiles", _vp), ("plan", _vp)]
+                ("host_ids", _vp), ("topo_flags", _c_i32), ("reserved", _c_i32), ("tiles", _vp), ("plan", _vp),
+                ("next_ids", _vp), ("n_next", _c_i64)]
 
 
 class TopologyCacheDesc(ctypes.Structure):
@@ -565,7 +566,8 @@ def current_stream(ref):
     return None
 
 
-def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None, topo_flags=0, tiles=None, plan=None):
+def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=None, ids=None, topo_flags=0, tiles=None, plan=None,
+               next_ids=None):
     """(StepHints, keep-alive tuple) from numpy arrays: int32 per-mini-batch tables, or int64 set tables + int32 ids;
     ``plan``: the StepPlan the caller sized its buffers from."""
     import numpy as np
@@ -587,4 +589,7 @@ def step_hints(node_ptr=None, edge_ptr=None, set_node_ptr=None, set_edge_ptr=Non
     if plan is not None:
         h.plan = ctypes.addressof(plan)
         keep.append(plan)
+    if next_ids is not None and next_ids.numel() > 0:      # (device int32 tensor: the next mini-batch's graph numbers)
+        h.next_ids, h.n_next = next_ids.data_ptr(), int(next_ids.numel())
+        keep.append(next_ids)
     return h, tuple(keep)

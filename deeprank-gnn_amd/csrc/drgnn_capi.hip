@@ -120,6 +120,7 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     L.gscratch = scratch_i32;
     L.level1_only = 0;
     L.roles = 1;
+    L.pf_ids = nullptr; L.pf_n = 0;
     L.user_nptr = (node_ptr && edge_ptr) ? node_ptr : nullptr;
     L.user_eptr = (node_ptr && edge_ptr) ? edge_ptr : nullptr;
     int64_t lds = 0;
@@ -1035,7 +1036,22 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         C.step = L; C.n_net = blocks;
         int64_t both = k.lds;
         int extra = 0;
+        C.topo.pf_ids = nullptr; C.topo.pf_n = 0;
         if (co_ok) { C.topo = T; both = k.lds > tlds ? k.lds : tlds; extra = T.args.n_graphs * T.roles; }
+        else if (gather_ids && hints && hints->next_ids && hints->n_next > 0 && (blocks % 8) == 0 &&
+                 blocks + hints->n_next <= device_cu_count() && getenv("DRGNN_NO_PREFETCH") == nullptr) {
+            // cached topology, CUs to spare: one extra workgroup per graph of the NEXT mini-batch warms the L2 of the XCD that
+            // will step it (prefetch_block; beyond the resident size the workgroups would only queue behind the step's)
+            TopoLaunch& Q = C.topo;
+            memset(&Q, 0, sizeof(Q));
+            Q.tv = a.tv;
+            Q.pf_ids = hints->next_ids; Q.pf_n = (int)hints->n_next;
+            Q.pf_tiles = a.tiles; Q.pf_f = F; Q.pf_tile_nodes = n_nodes;
+            Q.pf_x = (kind != DRGNN_GINET) ? x : nullptr;
+            Q.pf_coef = (kind != DRGNN_GINET) ? 1 : 0;
+            Q.pf_y = hd->train ? target : nullptr; Q.pf_y_bytes = (hd->task == DRGNN_TASK_REG) ? 4 : 8;
+            if (Q.pf_tiles != nullptr && (F & 3) == 0) extra = Q.pf_n; else Q.pf_ids = nullptr;
+        }
         drgnn_step_kernel_t kern = nullptr;
         const bool gather = gather_ids != nullptr;
         switch (k.kernel) {
@@ -1789,6 +1805,8 @@ int drgnn_train_epoch(const drgnn_epoch_plan* p, void* scratch, int64_t scratch_
             const bool split = pl.slabs_per_graph == 2 && p->net->kind != DRGNN_GINET;
             hints.topo_flags = pl.topo_flags; hints.plan = &pl;
             hints.tiles = p->cache->tiles;
+            // the graphs of mini-batch k + 1: prefetched by spare workgroups of this launch
+            if (k + 1 < nb) { hints.next_ids = p->ids + b.first + b.B; hints.n_next = epoch_next_b(p, k); }
             rc = drgnn_net_train_step_cached(p->net, &head, &tc, p->ids + b.first, b.B, b.maxN, b.maxE, b.maxC, p->step2,
                                              pred + b.first * hd->O, c.readout, train ? c.head_partials : nullptr,
                                              train ? c.partials : nullptr, c.xchg, &hints, stream);

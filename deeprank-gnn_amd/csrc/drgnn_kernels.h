@@ -67,7 +67,62 @@ struct TopoLaunch {
     int capN, capE;        // LDS capacities (0 = use global scratch)
     int level1_only;       // second pass: only depth-1 clusters, c1 offsets from NC0
     int roles;             // 1: one workgroup per graph; 2: edge structures / member lists split
+    // Cached-topology launches build nothing: the extra workgroups of the launch (CUs the step leaves idle) instead PREFETCH
+    // the graphs of the NEXT mini-batch into the L2 of the XCD that will step them (prefetch_block).  pf_ids: their numbers in
+    // the cached set (DEVICE memory), null = a builder launch
+    const int32_t* pf_ids; int pf_n;
+    const float* pf_tiles; const float* pf_x; int pf_f; int pf_coef;      // tiles / x rows of the set (x: nets that read it), F, D / C too
+    long long pf_tile_nodes;
+    const void* pf_y; int pf_y_bytes;
 };
+
+// ---- L2 prefetch of one graph of a cached set (the launch's workgroup n_net + g: XCD g % 8, where slot g of the next launch
+// runs, step_block).  A step on graphs that are not cache-resident waits 1.6 - 1.7 us longer in its prologue than a replayed one
+// (profiles/r05_cold_path.txt: the aggregation tiles 1.05 us, the index arrays 0.45 us): first-byte latency, not bandwidth.  In
+// cached mode half the CUs are idle: one workgroup per graph of the NEXT mini-batch requests everything that graph's step
+// workgroups will stage -- tile rows, (x rows, D, C), the hierarchical order, the pooled level's arrays, counts, target -- and
+// drops it; the lines stay in the XCD's L2 across the kernel boundary (that residency is what a replayed mini-batch lives on).
+// Reads of valid addresses only; no LDS, no barrier, no effect on any result.
+#ifdef DRGNN_EMU
+DEV void prefetch_block(const TopoLaunch&, int) {}
+#else
+DEV void prefetch_block(const TopoLaunch& L, int g) {
+    if (g >= L.pf_n) return;
+    const int32_t* const* P = L.tv.p;
+    const int id = __builtin_amdgcn_readfirstlane(L.pf_ids[g]);
+    const int n0 = P[DRGNN_TI_NPTR][id], n1 = P[DRGNN_TI_NPTR][id + 1];
+    const int e0 = P[DRGNN_TI_EPTR][id], e1 = P[DRGNN_TI_EPTR][id + 1];
+    const int N = n1 - n0, E = e1 - e0, rowbase = n0 + id, t = threadIdx.x;
+    int acc = P[DRGNN_TI_NC0][id] ^ P[DRGNN_TI_NE1][id] ^ P[DRGNN_TI_NC1][id] ^ P[DRGNN_TI_GSTAT][id] ^ P[DRGNN_TI_HSPLIT][4 * id];
+    if (L.pf_y) acc ^= (L.pf_y_bytes == 8) ? (int)((const long long*)L.pf_y)[id] : ((const int*)L.pf_y)[id];
+    drgnn_f4 f = {0.f, 0.f, 0.f, 0.f};
+    const int n4 = (N * L.pf_f) >> 2;
+    const drgnn_f4* s4 = (const drgnn_f4*)(L.pf_tiles + (long long)n0 * L.pf_f);
+    const drgnn_f4* x4 = L.pf_x ? (const drgnn_f4*)(L.pf_x + (long long)n0 * L.pf_f) : nullptr;
+    for (int q = t; q < n4; q += DRGNN_NTHREADS) {
+        const drgnn_f4 v = s4[q];
+        f[0] += v[0]; f[1] += v[1]; f[2] += v[2]; f[3] += v[3];
+        if (x4) { const drgnn_f4 u = x4[q]; f[0] += u[0]; f[1] += u[1]; f[2] += u[2]; f[3] += u[3]; }
+    }
+    for (int i = t; i <= N; i += DRGNN_NTHREADS) {
+        acc ^= P[DRGNN_TI_HMP0][rowbase + i] ^ P[DRGNN_TI_MPTR1][rowbase + i] ^ P[DRGNN_TI_ROWPTR1][rowbase + i] ^
+               P[DRGNN_TI_COLPTR1][rowbase + i];
+        if (i < N) {
+            acc ^= P[DRGNN_TI_IHORD][n0 + i] ^ P[DRGNN_TI_MEM1][n0 + i];
+            if (L.pf_coef) {
+                const float* td = L.pf_tiles + L.pf_tile_nodes * L.pf_f + n0;
+                f[0] += td[i] + td[L.pf_tile_nodes + i];
+            }
+        }
+    }
+    for (int e = t; e < E; e += DRGNN_NTHREADS) {
+        acc ^= P[DRGNN_TI_COL1][e0 + e] ^ P[DRGNN_TI_ROWIDX1][e0 + e];
+        if (L.pf_coef && L.tv.w1) { acc ^= P[DRGNN_TI_TSLOT1][e0 + e]; f[1] += L.tv.w1[e0 + e]; }
+    }
+    // (keeps the loads: a value no data produces)
+    if (acc == 0x7fc12345 && f[0] + f[1] + f[2] + f[3] == 12345.678f) { const_cast<int32_t*>(P[DRGNN_TI_ERR])[1] = acc; }
+}
+#endif
 
 // LDS is a compile-time property so that every scratch access is a ds_* instruction (a
 // run-time choice between LDS and global would make them all flat_* accesses)
@@ -77,6 +132,7 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
     // Two workgroups per graph: within full groups of 8 graphs both land on XCD (graph % 8) -- workgroups are dealt
     // round-robin to the 8 XCDs and the step kernels put graph g there too (step_block), so what the builder writes
     // is read back through the same L2 by the launch that trains on it.
+    if (L.pf_ids != nullptr) { prefetch_block(L, blk); return; }      // (cached-topology launch: nothing to build)
     int g = blk, role = TOPO_ROLE_ALL;
     if (L.roles == 2) {
         const int full = (L.args.n_graphs >> 3) << 4;

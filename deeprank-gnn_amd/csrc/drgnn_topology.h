@@ -899,6 +899,27 @@ DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, in
 // requested in phase 0 and sits in LDS (rows of F + 4 floats); rp / col_s / w_s: CSR0 of the graph in LDS (slot order =
 // edge-id order).  F / 4 lanes per node, each with one float4 of the row; results go straight to global memory (node order).
 struct TopoTile { const float* x; float* ts; float* td; float* tc; float* xs; int F; };
+// L2 touch of an output range (see topo_graph): up to 4 float4 per lane, requested with the phase's other loads, dropped unread
+#ifdef DRGNN_EMU
+struct TopoTouch { int dummy; };
+DEV void topo_touch_load(TopoTouch&, const float*, int) {}
+DEV void topo_touch_done(const TopoTouch&) {}
+#else
+struct TopoTouch { drgnn_f4 v[4]; };
+DEV void topo_touch_load(TopoTouch& t, const float* p, int words) {
+    const int n4 = p ? (words >> 2) : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = threadIdx.x + j * DRGNN_NTHREADS;
+        t.v[j] = drgnn_f4{0.f, 0.f, 0.f, 0.f};
+        if (q < n4) t.v[j] = ((const drgnn_f4*)p)[q];
+    }
+}
+DEV void topo_touch_done(const TopoTouch& t) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" :: "v"(t.v[j]));
+}
+#endif
 DEV TopoTile topo_tile_of(const TopoArgs& a, const TopoSrc& src, int n0, float* xs) {
     TopoTile t;
     t.F = (a.tiles != nullptr) ? a.tile_f : 0;
@@ -1342,6 +1363,14 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     const TopoTile tile = topo_tile_of(a, src, n0, structure ? s.xs : nullptr);
     TopoTileRegs treg;
     topo_tile_load(treg, tile, N);
+    // L2 touch of the tile rows this workgroup is going to WRITE: a store that misses the XCD's L2 does not allocate the line
+    // (profiles/r04_epoch_loop_probes.txt, 6), so the step workgroups of the next launch -- placed on the same XCD -- would read
+    // freshly written tiles from memory; a load of the (stale) destination lines allocates them, the stores then update them in
+    // place.  Values discarded.  Worth 0.35 us per step over rotating workspaces (profiles/r05_cold_path.txt); nothing where two
+    // workspaces alternate (the epoch loop's slots: their lines are resident from two launches ago).  The same for the index
+    // arrays the clusters chain writes did not pay (17.78 vs 17.81 us, and +0.1 us on the replayed step).
+    TopoTouch touch;
+    topo_touch_load(touch, (run_rows || (structure && !lean)) ? tile.ts : nullptr, N * tile.F);
     // the cluster ids of the clusters chain are requested AHEAD of the edge list (one round trip for all three)
     long long pre0 = 0, pre1 = 0;
     bool pre = false;
@@ -1354,6 +1383,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
 #endif
     topo_stage_edges(tv, src, sidx, N, E, has_w, s);
     topo_tile_store(treg, tile, N);
+    topo_touch_done(touch);
     bool rows_done = false, need_c1 = false;
     if (run_rows || run_clusters) {
         // (one call site per chain: they are inlined)

@@ -300,9 +300,10 @@ class FusedTrainer(object):
         return self.loss
 
     # -- cached topology (declared mode): a mini-batch is a list of graph numbers of a resident set ---------------
-    def _cached_prepare(self, cache, ids, ids_dev=None, train=True):
+    def _cached_prepare(self, cache, ids, ids_dev=None, train=True, next_ids_dev=None):
         """Buffers of one step over the graphs ``ids`` (host numbers; ``ids_dev``: the same as int32 on the device) of
-        ``cache`` (resident.TopologyCache)."""
+        ``cache`` (resident.TopologyCache).  ``next_ids_dev``: the NEXT mini-batch's graph numbers (device int32): spare
+        workgroups of this launch prefetch them (drgnn_step_hints.next_ids)."""
         import numpy as np
         api = self.api
         ids = np.asarray(ids, dtype=np.int64).reshape(-1)
@@ -326,7 +327,7 @@ class FusedTrainer(object):
         xchg = self._xchg_for(plan, B, dev)
         # (beyond 64 graphs the offsets no longer travel in the kernel arguments, but the library still range-checks the ids)
         hints = _lib.step_hints(set_node_ptr=gset.node_ptr, set_edge_ptr=gset.edge_ptr, ids=ids,
-                                topo_flags=topo_flags, tiles=tiles, plan=plan)
+                                topo_flags=topo_flags, tiles=tiles, plan=plan, next_ids=next_ids_dev)
         return dict(hints=hints, slabs=slabs, plan=plan,
                     cache=cache, ids_dev=ids_dev, B=B, bounds=(max_nodes, max_edges, max_c0), xchg=xchg, g1=g1, g2=g2,
                     desc=desc, stream=_lib.current_stream(gset.x), readout=readout, partials=partials, hp=hp,
@@ -339,10 +340,10 @@ class FusedTrainer(object):
                                        c["partials"] if train else None, c["xchg"], c["stream"],
                                        hints=None if c.get("hints") is None else c["hints"][0])
 
-    def train_step_cached(self, cache, ids, ids_dev=None, apply_adam=True):
+    def train_step_cached(self, cache, ids, ids_dev=None, apply_adam=True, next_ids_dev=None):
         """One optimisation step on the graphs ``ids`` of a cached set: the fused step launch reading the cached
         topology in place + the update launch.  Same arithmetic as ``train_step`` on the collated mini-batch."""
-        c = self._cached_prepare(cache, ids, ids_dev)
+        c = self._cached_prepare(cache, ids, ids_dev, True, next_ids_dev)
         want = torch.float32 if self.task == _lib.TASK_REG else torch.int64
         if cache.set.y is None or cache.set.y.dtype != want:
             raise ValueError("the set's targets must be %s for this task" % want)
