@@ -723,14 +723,29 @@ DEV void step_kernarg_touch() {
 DEV const StepCoLaunch& step_kernarg() {
     return *reinterpret_cast<const StepCoLaunch*>((const char*)__builtin_amdgcn_kernarg_segment_ptr());
 }
+// Which workgroups of a co-launch are the step's and which the builder's (or, cached mode, the prefetcher's).
+// DRGNN_TOPO_FIRST (experiment switch): the builder's workgroups take the FIRST block ids -- they are dispatched first, and
+// the builder's chain is what a rebuilt launch ends with (profiles/r05_builder_first.txt).  Block ids keep their XCD (id % 8)
+// as long as the builder's workgroup count is a multiple of 8.
+#ifdef DRGNN_TOPO_FIRST
+#define STEP_CO_ROLES(C)                                                       \
+    const int co_extra_ = (int)gridDim.x - (C).n_net;                          \
+    const bool co_is_step_ = (int)blockIdx.x >= co_extra_;                     \
+    const int co_step_blk_ = (int)blockIdx.x - co_extra_, co_topo_blk_ = (int)blockIdx.x
+#else
+#define STEP_CO_ROLES(C)                                                       \
+    const bool co_is_step_ = (int)blockIdx.x < (C).n_net;                      \
+    const int co_step_blk_ = (int)blockIdx.x, co_topo_blk_ = (int)blockIdx.x - (C).n_net
+#endif
 template <int KIND, int XF, bool GATHER, int CLS = 0>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
-    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step_block<KIND, XF, GATHER, CLS>(C.step, blockIdx.x, smem_s, 0);
-    else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s);      // (train_step_impl keeps weighted requests of the other kinds out of the launch)
+    STEP_CO_ROLES(C);
+    if (co_is_step_) step_kernarg_touch();
+    if (co_is_step_) step_block<KIND, XF, GATHER, CLS>(C.step, co_step_blk_, smem_s, 0);
+    else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, co_topo_blk_, (int*)smem_s);      // (train_step_impl keeps weighted requests of the other kinds out of the launch)
 }
 // GINet, one workgroup per graph (both branches), + the builder's workgroups of the next mini-batch
 // PAIRED: both branches share every phase (drgnn_step1.h); instantiated for the generic and the 32-wide kernels
@@ -739,9 +754,10 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C
     extern __shared__ __attribute__((aligned(16))) float smem_s1[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
-    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step_block_both<XF, GATHER, PAIRED, CLS>(C.step, blockIdx.x, smem_s1);
-    else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s1);
+    STEP_CO_ROLES(C);
+    if (co_is_step_) step_kernarg_touch();
+    if (co_is_step_) step_block_both<XF, GATHER, PAIRED, CLS>(C.step, co_step_blk_, smem_s1);
+    else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s1);
 }
 // sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h) + the builder's workgroups
 template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN>
@@ -749,9 +765,10 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step2_co_topo(StepCoLaunch C
     extern __shared__ __attribute__((aligned(16))) float smem_s2[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
-    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step2_block<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(C.step, blockIdx.x, smem_s2);
-    else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s2);
+    STEP_CO_ROLES(C);
+    if (co_is_step_) step_kernarg_touch();
+    if (co_is_step_) step2_block<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(C.step, co_step_blk_, smem_s2);
+    else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, co_topo_blk_, (int*)smem_s2);
 }
 // GINet, aggregation first (drgnn_step3.h) + the builder's workgroups
 template <int XF, bool GATHER, int CLS, bool TRAIN>
@@ -759,9 +776,10 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3_co_topo(StepCoLaunch C
     extern __shared__ __attribute__((aligned(16))) float smem_s3[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
-    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step3_block<XF, GATHER, CLS, TRAIN>(C.step, blockIdx.x, smem_s3);
-    else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s3);
+    STEP_CO_ROLES(C);
+    if (co_is_step_) step_kernarg_touch();
+    if (co_is_step_) step3_block<XF, GATHER, CLS, TRAIN>(C.step, co_step_blk_, smem_s3);
+    else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s3);
 }
 // ... its form with both branches of a graph in one workgroup (beyond the resident batch size)
 template <int XF, bool GATHER, int CLS, bool TRAIN>
@@ -769,9 +787,10 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3b_co_topo(StepCoLaunch 
     extern __shared__ __attribute__((aligned(16))) float smem_s3b[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
-    if ((int)blockIdx.x < C.n_net) step_kernarg_touch();
-    if ((int)blockIdx.x < C.n_net) step3b_block<XF, GATHER, CLS, TRAIN>(C.step, blockIdx.x, smem_s3b);
-    else topo_block<true, 0>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_s3b);
+    STEP_CO_ROLES(C);
+    if (co_is_step_) step_kernarg_touch();
+    if (co_is_step_) step3b_block<XF, GATHER, CLS, TRAIN>(C.step, co_step_blk_, smem_s3b);
+    else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s3b);
 }
 #ifdef DRGNN_KERNELS_MAIN
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_conv_gemm(ConvLayerArgs a) { conv_gemm_block(a, blockIdx.x); }

@@ -65,11 +65,9 @@ __device__ unsigned long long* g_phase_buf = nullptr;
 // the mark counter lives in LDS (set by PHASE_BEGIN at kernel entry) so that a mark costs one
 // scalar pointer load + s_memtime + a fire-and-forget store, not two global round trips
 __shared__ unsigned int drgnn_phase_k;
-#ifndef DRGNN_PHASE_BLOCK
-#define DRGNN_PHASE_BLOCK 0      // which workgroup of a launch stamps (e.g. 8: the second builder workgroup of graph 0)
-#endif
+// which workgroup of a launch stamps: word 1 of the buffer, set by the host (e.g. 8: the second builder workgroup of graph 0)
 __device__ __forceinline__ void phase_mark(int line) {
-    if (threadIdx.x == 0 && blockIdx.x == DRGNN_PHASE_BLOCK && g_phase_buf != nullptr) {
+    if (threadIdx.x == 0 && g_phase_buf != nullptr && blockIdx.x == (unsigned)g_phase_buf[1]) {
         const unsigned int k = drgnn_phase_k;
         if (k < 2000) {
             g_phase_buf[2 + 2 * k] = (unsigned long long)line;

@@ -739,10 +739,13 @@ DEV void step_colsum_finish(const float* wpart, float* out) {
 // pub: (GINet) this branch's DRGNN_H2 exchange words -- every readout value is published to the partner branch's workgroup
 // the moment it exists (tag = index of this step), so that it travels while both workgroups pass the phase's barrier
 DEV void xchg_publish(unsigned long long* slot, uint32_t tag, float v);
+// a1ld: layout of the argmax array.  0: arg[k][32] (cluster-major: every kernel family but one); > 0: arg[c][a1ld] (column-major,
+// a1ld >= C1: drgnn_step3.h -- its readers walk the clusters of ONE column with consecutive lanes, which in the cluster-major
+// layout lands 16 lanes on two LDS banks, profiles/r05_lds_conflicts.txt)
 template <int LDZ, bool SKIP0 = false>
 DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z, short* arg, const float* misc,
                            float* xr, float* g_readout, const int* rp = nullptr, unsigned long long* pub = nullptr,
-                           uint32_t tag = 0u) {
+                           uint32_t tag = 0u, int a1ld = 0) {
     int bad; memcpy(&bad, &misc[STEP_M_BAD], 4);
     const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
 #ifdef DRGNN_EMU
@@ -793,7 +796,7 @@ DEV void step_pool_readout(int C1, const int* mp, const int* mem, const float* z
                     if (vv[j] > best) { best = vv[j]; am = mm[j]; }
             }
             if (am < 0) best = 0.0f;
-            arg[k * DRGNN_H2 + c] = (short)((best > 0.0f) ? am : -1);
+            arg[a1ld ? c * a1ld + k : k * DRGNN_H2 + c] = (short)((best > 0.0f) ? am : -1);
             acc += best;
         }
         acc = lanes16_sum(acc) * inv;

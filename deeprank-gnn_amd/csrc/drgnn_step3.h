@@ -37,6 +37,8 @@ struct Step3Scratch {
     float* end; float* gp;
 };
 #define STEP3_Z2LD (DRGNN_H2 + 4)
+// the depth-1 argmax is kept COLUMN-major here: a1[c][STEP3_A1LD(capC)] (an even stride: columns start on word boundaries)
+#define STEP3_A1LD(capC) (((capC) + 1) & ~1)
 #define STEP3_CARVE_LIST(X)                                                                    \
     X(misc, 128)                                                                               \
     X(xr, 2 * DRGNN_H2)                                                                        \
@@ -54,8 +56,8 @@ struct Step3Scratch {
     X(rx1, capE)                                                                               \
     X(mp1, capC + 1)                                                                           \
     X(mem1, capC)                                                                              \
-    X(a0, ((long)capC * DRGNN_H1 + 1) / 2)                                                     \
-    X(a1, ((long)capC * DRGNN_H2 + 1) / 2)                                                     \
+    X(a0, ((long)STEP3_A1LD(capC) * DRGNN_H1 + 1) / 2)                                         \
+    X(a1, ((long)STEP3_A1LD(capC) * DRGNN_H2 + 1) / 2)                                         \
     X(G, (long)(capN + 4) * xld)                                                               \
     X(z1, (long)(capN + 4) * DRGNN_H1)                                                         \
     X(xp, (long)(capC + 4) * STEP_XPLD)                                                        \
@@ -98,8 +100,8 @@ DEV Step3Scratch step3_carve(float* base, int F, int capN, int capE, int capC, i
 }
 
 // ---- phase C: depth-0 cluster max over CONTIGUOUS rows; results filed under the pooled node id cid[q] --------------------
-// (argmax = row position of the winner, -1 where no gradient flows)
-DEV void step3_cluster_max(int nc, const int* hmp, const int* cid, const float* z, float* xp, short* a0) {
+// (argmax = row position of the winner, -1 where no gradient flows; kept COLUMN-major: a0[c][a0ld], as the depth-1 argmax)
+DEV void step3_cluster_max(int nc, const int* hmp, const int* cid, const float* z, float* xp, short* a0, int a0ld) {
     FOR_TID(item, nc * DRGNN_H1) {
         const int q = item >> 4, c = item & 15;
         const int plo = hmp[q], phi = hmp[q + 1];
@@ -119,7 +121,7 @@ DEV void step3_cluster_max(int nc, const int* hmp, const int* cid, const float* 
         }
         if (arg < 0) best = 0.0f;
         xp[ROW24(j, STEP_XPLD) + c] = best;
-        a0[j * DRGNN_H1 + c] = (short)((best > 0.0f) ? arg : -1);
+        a0[c * a0ld + j] = (short)((best > 0.0f) ? arg : -1);
     }
 }
 
@@ -133,7 +135,7 @@ DEV void step3_cluster_max(int nc, const int* hmp, const int* cid, const float* 
 // d readout (this branch's 32 columns) scattered through the depth-1 argmax into dZ2 (for dS) + dW2; 32 lanes per column:
 // 4 float4 groups of the 16 S2 columns x 8 slices of the clusters
 template <int HC>
-DEV void step3_dreadout_dw2(const float* wb, const float* dhid, const short* a1, int C1, const float* s2, float* z2,
+DEV void step3_dreadout_dw2(const float* wb, const float* dhid, const short* a1, int a1ld, int C1, const float* s2, float* z2,
                             float* g_dw2) {
     const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
     for (int t = threadIdx.x; t < DRGNN_H2 * 32; t += DRGNN_NTHREADS) {
@@ -142,14 +144,15 @@ DEV void step3_dreadout_dw2(const float* wb, const float* dhid, const short* a1,
 #pragma unroll
         for (int h = q; h < HC; h += 32) acc = fmaf(dhid[h], wb[h * STEP_WBLD + c], acc);
         const float v = lanes32_sum(acc) * inv;
+        const short* a1c = a1 + c * a1ld;
         for (int k = q; k < C1; k += 32) {
-            const int r = a1[k * DRGNN_H2 + c];
+            const int r = a1c[k];
             if (r >= 0) z2[ROW24(r, STEP3_Z2LD) + c] = v;
         }
         const int sl = q & 7, f4 = q >> 3;
         drgnn_f4 sum = {0.f, 0.f, 0.f, 0.f};
         for (int k = sl; k < C1; k += 8) {
-            const int r = a1[k * DRGNN_H2 + c];
+            const int r = a1c[k];
             if (r >= 0) {
                 const drgnn_f4 row = *(const drgnn_f4*)(s2 + ROW24(r, STEP_XPLD) + 4 * f4);
                 sum[0] += row[0]; sum[1] += row[1]; sum[2] += row[2]; sum[3] += row[3];
@@ -185,7 +188,7 @@ DEV void step3_gather_dxp(int n, const int* cp, const int* ridx, const float* sr
 // dW1[f][h] = sum over the pooled nodes j of dXP[j][h] G[a0[j][h]][f].  Wave = channel h; in a wave NCH feature chunks (float4)
 // x NSL slices of the pooled nodes (consecutive lanes: the slice sums meet in DPP adds; Dw1Shape, drgnn_step2.h)
 template <int XF>
-DEV void step3_dw1_sparse(int C, const short* a0, const float* dxp, const float* G, float* g_dw1, int F) {
+DEV void step3_dw1_sparse(int C, const short* a0, int a0ld, const float* dxp, const float* G, float* g_dw1, int F) {
     constexpr int XLD = XF + 4, NSL = Dw1Shape<XF>::NSL;
     const int h = threadIdx.x >> 6, fc = (threadIdx.x & 63) / NSL, sl = threadIdx.x & (NSL - 1);
     const bool live = 4 * fc < XF;
@@ -196,7 +199,7 @@ DEV void step3_dw1_sparse(int C, const short* a0, const float* dxp, const float*
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int jj = j + NSL * u;
-            arg[u] = (jj < C && live) ? (int)a0[jj * DRGNN_H1 + h] : -1;
+            arg[u] = (jj < C && live) ? (int)a0[h * a0ld + jj] : -1;
             d[u] = (jj < C) ? dxp[jj * STEP_XPLD + h] : 0.0f;
         }
 #pragma unroll
@@ -342,7 +345,7 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     BARRIER();
     EXIT_AFTER(3);
     // ---- C: depth-0 cluster max over contiguous rows -----------------------------------------------------------------------
-    PH(3) step3_cluster_max(d.C, s.hmp, s.mem1, s.z1, s.xp, s.a0);
+    PH(3) step3_cluster_max(d.C, s.hmp, s.mem1, s.z1, s.xp, s.a0, STEP3_A1LD(capC));
     BARRIER();
     EXIT_AFTER(4);
     // ---- E: S = A1 XP (16-wide gather of pooled rows) -----------------------------------------------------------------------
@@ -357,7 +360,7 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     // ---- G: depth-1 max + readout, published to the partner branch ------------------------------------------------------------
     PH(6) step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, s.z2, s.a1, s.misc, s.xr,
                                   const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2, nullptr,
-                                  a.xchg + (long)g * nb * WREF + br * DRGNN_H2, tag);
+                                  a.xchg + (long)g * nb * WREF + br * DRGNN_H2, tag, STEP3_A1LD(capC));
     BARRIER();
     EXIT_AFTER(8);
 
@@ -391,7 +394,7 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     float* p_w1n = part_w;
     float* p_w2n = p_w1n + 2L * F * DRGNN_H1 + DRGNN_H1;
     // d readout scattered into dZ2 + dW2 (sparse: see step3_dreadout_dw2)
-    PH(10) step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1, d.C1, s.u2, s.z2, p_w2n);
+    PH(10) step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1, STEP3_A1LD(capC), d.C1, s.u2, s.z2, p_w2n);
     BARRIER();
     EXIT_AFTER(11);
 
@@ -405,7 +408,7 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     BARRIER();
     EXIT_AFTER(14);
     // dW1 through the depth-0 argmax (sparse)
-    PH(16) step3_dw1_sparse<XF>(d.C, s.a0, s.xp, s.G, p_w1n, F);
+    PH(16) step3_dw1_sparse<XF>(d.C, s.a0, STEP3_A1LD(capC), s.xp, s.G, p_w1n, F);
 }
 
 
@@ -448,10 +451,10 @@ struct Step3BScratch {
     X(rx1, capE)                                                                               \
     X(mp1, capC + 1)                                                                           \
     X(mem1, capC)                                                                              \
-    X(a0[0], ((long)capC * DRGNN_H1 + 1) / 2)                                                  \
-    X(a0[1], ((long)capC * DRGNN_H1 + 1) / 2)                                                  \
-    X(a1[0], ((long)capC * DRGNN_H2 + 1) / 2)                                                  \
-    X(a1[1], ((long)capC * DRGNN_H2 + 1) / 2)                                                  \
+    X(a0[0], ((long)STEP3_A1LD(capC) * DRGNN_H1 + 1) / 2)                                      \
+    X(a0[1], ((long)STEP3_A1LD(capC) * DRGNN_H1 + 1) / 2)                                      \
+    X(a1[0], ((long)STEP3_A1LD(capC) * DRGNN_H2 + 1) / 2)                                      \
+    X(a1[1], ((long)STEP3_A1LD(capC) * DRGNN_H2 + 1) / 2)                                      \
     X(G, (long)(capN + 4) * xld)                                                               \
     X(z1, (long)(capN + 4) * DRGNN_H1)                                                         \
     X(xp, (long)(capC + 4) * STEP_XPLD)                                                        \
@@ -647,7 +650,7 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
         short* const a1 = b1 ? s.a1[1] : s.a1[0];
         step_gemm_nn<true>(d.N, 1, XF, s.G, XLD, w1t, XLD, s.z1, DRGNN_H1, dummy);
         BARRIER();
-        step3_cluster_max(d.C, s.hmp, s.mem1, s.z1, s.xp, a0);
+        step3_cluster_max(d.C, s.hmp, s.mem1, s.z1, s.xp, a0, STEP3_A1LD(capC));
         BARRIER();
         step_gather_rows<STEP_XPLD, int>(d.C, s.rp1, s.cx1, s.xp, u2);
         FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { u2[d.C * STEP_XPLD + e] = 0.0f; }
@@ -655,7 +658,7 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
         step_gemm_nn<true>(d.C, 2, DRGNN_H1, u2, STEP_XPLD, w2t, STEP_XPLD, z2, Z2LD, dummy);
         BARRIER();
         step_pool_readout<Z2LD>(d.C1, s.mp1, s.mem1, z2, a1, s.misc, s.xr + br * DRGNN_H2,
-                                const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2);
+                                const_cast<float*>(hf.readout) + (long)g * R + br * DRGNN_H2, nullptr, nullptr, 0u, STEP3_A1LD(capC));
         BARRIER();
     }
 
@@ -679,11 +682,11 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     float* const p_w1n0 = a.partials + ((long)g * nb) * a.n_partial;
     float* const p_w1n1 = p_w1n0 + a.n_partial;
     const long w2off = 2L * F * DRGNN_H1 + DRGNN_H1;
-    step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1[0], d.C1, s.u2[0], s.z2[0], p_w1n0 + w2off);
+    step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1[0], STEP3_A1LD(capC), d.C1, s.u2[0], s.z2[0], p_w1n0 + w2off);
     BARRIER();
     step_wblock_store(wother, hf, 1, s.wb);      // branch 1's column block of fc1 takes branch 0's place
     BARRIER();
-    step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1[1], d.C1, s.u2[1], s.z2[1], p_w1n1 + w2off);
+    step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1[1], STEP3_A1LD(capC), d.C1, s.u2[1], s.z2[1], p_w1n1 + w2off);
     BARRIER();
 
     // ---- backward body, branch after branch: dS = dZ2 W2^T, dXP through CSC1 (dense rows), dW1 through the depth-0 argmax ---
@@ -697,7 +700,7 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
         BARRIER();
         step3_gather_dxp<STEP_XPLD>(d.C, s.cp1, s.rx1, s.p2, s.xp);
         BARRIER();
-        step3_dw1_sparse<XF>(d.C, a0, s.xp, s.G, b1 ? p_w1n1 : p_w1n0, F);      // (the next branch's first two phases leave xp, a0, G alone)
+        step3_dw1_sparse<XF>(d.C, a0, STEP3_A1LD(capC), s.xp, s.G, b1 ? p_w1n1 : p_w1n0, F);      // (the next branch's first two phases leave xp, a0, G alone)
     }
 }
 #endif  // !DRGNN_EMU

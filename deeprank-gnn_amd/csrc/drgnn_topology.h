@@ -1219,12 +1219,8 @@ DEV int topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, int
         }
     }
     if (rows && tile.F > 0) topo_tiles_rows(tile, N, s.rp, s.col, has_w ? (const float*)s.wr : nullptr);
-    if (with_pool) {
-        int* Y = s.t4;           // [2 CB + 1] set bits before each word of [bm | bmT]
-        // (a thread scans the element it wrote while 2 CB + 1 <= threads: no barrier in between)
-        FOR_TID(q, 2 * CB + 1) { Y[q] = (q < CB) ? __builtin_popcount((unsigned)bm[q]) : (q < 2 * CB) ? __builtin_popcount((unsigned)bmT[q - CB]) : 0; }
-        if (2 * CB + 1 > DRGNN_NTHREADS) BARRIER();
-        const int E1 = wg_exscan(Y, 2 * CB + 1, s.part) >> 1;
+    // the three pieces the end of the chain is made of
+    auto emit_pooled = [&](const int* Y, const int E1) {
         int32_t* g_col1 = tv.p[DRGNN_TI_COL1] + e0;
         int32_t* g_rowidx1 = tv.p[DRGNN_TI_ROWIDX1] + e0;
         int32_t* g_tslot1 = tv.p[DRGNN_TI_TSLOT1] + e0;
@@ -1266,25 +1262,16 @@ DEV int topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, int
         int32_t* g_colptr1 = tv.p[DRGNN_TI_COLPTR1] + rowbase;
         FOR_TID(r, C + 1) { g_rowptr1[r] = Y[r * BW]; g_colptr1[r] = Y[CB + r * BW] - E1; }
         FOR_TID(i, 1) { tv.p[DRGNN_TI_NE1][g] = E1; }
-    } else {
-        BARRIER();
-    }
-    // (the barriers inside the popcount scan have made the run offsets visible: the node claim needs no phase of its own)
+    };
+    auto node_claim = [&]() {
     FOR_TID_FROM(i, N, 768) {
         const int c = s.cl[i], b = qpos[c];
         const int pos = hmp[b] + ATOMIC_ADD(&s.cur[c], 1);
         s.t5[pos] = i;
         s.nb[pos] = b;
     }
-    BARRIER();
-    if (with_pool && has_w) {
-        double inv;
-        (void)topo_wscale(wmax_bits[0], &inv);
-        const long long* acc = (const long long*)s.seg;
-        float* g_w1 = tv.w1 + e0;
-        const int E1 = s.t4[CB];      // (= Y[CB]: the pooled edge count)
-        FOR_TID(q, E1) { g_w1[q] = (float)((double)acc[q] * inv); }
-    }
+    };
+    auto hier_tail = [&]() {
     {
         int32_t* g_hord = tv.p[DRGNN_TI_HORD] + n0;
         int32_t* g_ihord = tv.p[DRGNN_TI_IHORD] + n0;
@@ -1328,6 +1315,60 @@ DEV int topo_lean_clusters(const TopoView& tv, int g, int n0, int e0, int N, int
         }
 #endif
     }
+    };
+#ifndef DRGNN_EMU
+    if (with_pool && !has_w && 2 * CB + 1 <= DRGNN_NTHREADS) {
+        // Without edge weights the chain ENDS inside the popcount scan's own two barriers (one element per lane): behind the
+        // first one the cluster positions (hmp) are visible -> the node claim runs next to the scan's second half; behind
+        // the second one the claims are visible -> the rank inside the runs (HORD / IHORD) and the split point are formed
+        // next to the pooled graph's emission.  One barrier interval less than scan | emit + claim | barrier | rank
+        // (profiles/r05_builder_phases.txt).
+        int* Y = s.t4;
+        const int t = threadIdx.x, ny = 2 * CB + 1;
+        const int lane = t & (DRGNN_WAVE - 1), wave = t >> 6, nw = (ny + DRGNN_WAVE - 1) / DRGNN_WAVE;
+        int v = 0, inc = 0;
+        if (wave < nw) {
+            v = (t < CB) ? __builtin_popcount((unsigned)bm[t]) : (t < 2 * CB) ? __builtin_popcount((unsigned)bmT[t - CB]) : 0;
+            inc = wave_incl_scan(v);
+            if (lane == DRGNN_WAVE - 1) s.part[wave] = inc;
+        }
+        BARRIER();
+        int base = 0, total = 0;
+        for (int w = 0; w < nw; ++w) {
+            const int tw = s.part[w];
+            base += (w < wave) ? tw : 0;
+            total += tw;
+        }
+        if (t < ny) Y[t] = base + inc - v;
+        node_claim();
+        BARRIER();
+        emit_pooled(Y, total >> 1);
+        hier_tail();
+        return 0;
+    }
+#endif
+    if (with_pool) {
+        int* Y = s.t4;           // [2 CB + 1] set bits before each word of [bm | bmT]
+        // (a thread scans the element it wrote while 2 CB + 1 <= threads: no barrier in between)
+        FOR_TID(q, 2 * CB + 1) { Y[q] = (q < CB) ? __builtin_popcount((unsigned)bm[q]) : (q < 2 * CB) ? __builtin_popcount((unsigned)bmT[q - CB]) : 0; }
+        if (2 * CB + 1 > DRGNN_NTHREADS) BARRIER();
+        const int E1 = wg_exscan(Y, 2 * CB + 1, s.part) >> 1;
+        emit_pooled(Y, E1);
+    } else {
+        BARRIER();
+    }
+    // (the barriers inside the popcount scan have made the run offsets visible: the node claim needs no phase of its own)
+    node_claim();
+    BARRIER();
+    if (with_pool && has_w) {
+        double inv;
+        (void)topo_wscale(wmax_bits[0], &inv);
+        const long long* acc = (const long long*)s.seg;
+        float* g_w1 = tv.w1 + e0;
+        const int E1 = s.t4[CB];      // (= Y[CB]: the pooled edge count)
+        FOR_TID(q, E1) { g_w1[q] = (float)((double)acc[q] * inv); }
+    }
+    hier_tail();
     return 0;
 }
 

@@ -1,6 +1,6 @@
-"""Per-barrier clock stamps of ONE builder workgroup (profiling builds of the library: -DDRGNN_PHASE_TIMING
--DDRGNN_PHASE_BLOCK=<workgroup>; block 0 = the "pool" role of graph 0, block 8 = its "structure" role).
-usage: PROF_LIB=libdrgnn_prof8.so python tools/r04/topo_phases.py [weights] [flags]"""
+"""Per-barrier clock stamps of ONE builder workgroup (profiling build of the library: -DDRGNN_PHASE_TIMING; the stamping
+workgroup is word 1 of the stamp buffer: PHASE_BLOCK=0 = the "pool" role of graph 0, 8 = its "structure" role).
+usage: PROF_LIB=variants/libdrgnn_prof.so PHASE_BLOCK=8 python tools/r04/topo_phases.py [weights] [flags]"""
 import ctypes
 import os
 import sys
@@ -21,6 +21,7 @@ assert api.lib.drgnn_debug_set_phase_buffer(buf.data_ptr()) == 0
 batch = synth.make_batch(0, 64).to(dev)
 for rep in range(3):
     buf.zero_()
+    buf[1] = int(os.environ.get("PHASE_BLOCK", "0"))
     torch.cuda.synchronize()
     topo = Topology.from_batch(batch, api=api, need_weights=need_w, flags=flags)
     torch.cuda.synchronize()
