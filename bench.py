@@ -120,6 +120,9 @@ def parse():
                          "recompute on the union of the shards (1e-5 relative, SURVEY 8(e)) and (b) parameters in sync "
                          "over the ranks; the result (ranks, backend, exchange, fallback taken) goes into config.dp_selftest "
                          "and to stderr.  Works with --gpus N (RCCL) and with --gpus N --backend gloo on one GPU")
+    ap.add_argument("--dp-distinct", action="store_true",
+                    help="also time the same (data-parallel) schedule over a cycle of 32 DIFFERENT synthetic mini-batches per rank "
+                         "(`dp_distinct` in the line): the figure without the L2 residency of a replayed mini-batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-nets", action="store_true",
                     help="skip the secondary sGAT / FoutNet figures of the default GINet line (`other_nets`)")
@@ -528,6 +531,13 @@ def main():
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         in_sync = bool(torch.equal(hi, lo))
 
+    dp_distinct = None
+    if args.dp_distinct and native and not cached:
+        try:
+            dp_distinct = measure_dp_distinct(trainer, dev, rank, world, need_w, all_reduce, update_part, dp_path,
+                                              dist.is_initialized() and dist.get_backend() == "nccl")
+        except Exception as exc:                          # secondary figure
+            dp_distinct = {"error": repr(exc)[:200]}
     result = None
     if rank == 0:
         # wall clock over `repeats` back-to-back blocks of K steps (barrier + synchronize on both sides, max over
@@ -565,6 +575,8 @@ def main():
             result["config"]["dp_ranks"] = dist.get_world_size() if dist.is_initialized() else 1
         if selftest is not None:
             result["config"]["dp_selftest"] = selftest
+        if dp_distinct is not None:
+            result["dp_distinct"] = dp_distinct
         if native:
             result["roofline"] = measure_roofline(net, args.net, batch, dev, value / world,
                                                   cache=(cache, ids_host, ids_dev) if cached else None)
@@ -599,6 +611,62 @@ def main():
         except Exception:
             pass
         print(json.dumps(result), flush=True)
+
+
+def measure_dp_distinct(trainer, dev, rank, world, need_w, all_reduce, update_part, dp_path, rccl, n_batches=32):
+    """Secondary figure (not `value`): the run's own schedule -- [gradient launch (+ the next mini-batch's topology); all-reduce;
+    Adam] data parallel, the fused step + update on one GPU -- over a cycle of `n_batches` DIFFERENT synthetic mini-batches per
+    rank (every one with a topology workspace of its own, built by the previous step's launch), one hipGraph of `n_batches`
+    steps where the collective can be recorded (RCCL / single rank), eager steps otherwise.  Max over the ranks."""
+    import torch.distributed as dist
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.topology import Topology
+    first = 100000 + rank * n_batches * GRAPHS_PER_GPU
+    batches = [synth.make_batch(first + i * GRAPHS_PER_GPU, GRAPHS_PER_GPU).to(dev) for i in range(n_batches)]
+    topos = [Topology.from_batch(b, need_weights=need_w, build=(i == 0)) for i, b in enumerate(batches)]
+    n = n_batches
+
+    def chunk():
+        for k in range(n):
+            if dp_path:
+                trainer.compute_gradients(batches[k], topo=topos[k], next_topo=topos[(k + 1) % n])
+                all_reduce()
+                update_part()
+            else:
+                trainer.train_step(batches[k], topo=topos[k], next_topo=topos[(k + 1) % n])
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chunk()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    run, how = chunk, "eager steps"
+    if not dp_path or world == 1 or rccl:
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if (dp_path and rccl) else {})):
+                chunk()
+            run, how = g.replay, "hipGraph of %d steps" % n
+        except Exception:
+            run, how = chunk, "eager steps (recording failed)"
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    reps = 60 if run is not chunk else 8
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    us = (time.perf_counter() - t0) / (reps * n) * 1e6
+    if world > 1:
+        t = torch.tensor([us], dtype=torch.float64, device=dev if rccl else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        us = float(t.item())
+    return {"us_per_step": us, "graphs_per_s": GRAPHS_PER_GPU * world / (us * 1e-6), "distinct_batches_per_rank": n, "how": how}
 
 
 def dp_selftest(trainer, net, Net, dev, rank, world, eager_step, run_steps, state, two_flavours, info):

@@ -133,6 +133,9 @@ DEV void topo_block(const TopoLaunch& L, int blk, int* lds) {
     // round-robin to the 8 XCDs and the step kernels put graph g there too (step_block), so what the builder writes
     // is read back through the same L2 by the launch that trains on it.
     if (L.pf_ids != nullptr) { prefetch_block(L, blk); return; }      // (cached-topology launch: nothing to build)
+#ifdef DRGNN_TOPO_EXIT0
+    return;      // (experiment: the builder's workgroups are dispatched and return at once)
+#endif
     int g = blk, role = TOPO_ROLE_ALL;
     if (L.roles == 2) {
         const int full = (L.args.n_graphs >> 3) << 4;
