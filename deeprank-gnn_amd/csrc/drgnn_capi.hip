@@ -55,10 +55,12 @@ int64_t drgnn_topology_scratch_elems(int64_t n_nodes, int64_t n_edges, int64_t n
 // tile_f > 0: + the x tile of the aggregation tiles (DRGNN_TOPO_TILES)
 static int64_t topo_lds_bytes(int capN, int capE, int tile_f = 0) {
     const int64_t capT = (capN > capE ? capN : capE) + 1;
-    return 4 * (topo_scratch_ints(capN, capE, capT, (int64_t)capN + capE + 2) + (tile_f > 0 ? (int64_t)capN * (tile_f + 4) : 0));
+    // (the x tile's rows are padded to pad4(F) + 4 floats)
+    return 4 * (topo_scratch_ints(capN, capE, capT, (int64_t)capN + capE + 2) + (tile_f > 0 ? (int64_t)capN * (((tile_f + 3) & ~3) + 4) : 0));
 }
 static bool topo_tiles_shape_ok(int capN, int capE, int F) {
-    if (capN <= 0 || F <= 0 || (F & 3) || F > 256 || (int64_t)capN * F > 16 * DRGNN_BCAP) return false;      // (x tile: 4 float4 per lane)
+    const int TF = (F + 3) & ~3;
+    if (capN <= 0 || F <= 0 || F > 256 || (int64_t)capN * TF > 16 * DRGNN_BCAP) return false;      // (x tile: 4 float4 per lane)
     return topo_lds_bytes(capN, capE > 0 ? capE : 1, F) <= DRGNN_LDS_LIMIT;
 }
 
@@ -69,7 +71,8 @@ int64_t drgnn_topology_lds_bytes(int32_t max_nodes, int32_t max_edges) {
 
 int64_t drgnn_topology_tiles_elems(int64_t n_nodes, int32_t n_feat) {
     if (n_nodes < 0 || n_feat <= 0) return 0;
-    return n_nodes * ((int64_t)n_feat + 2);
+    const int64_t TF = ((int64_t)n_feat + 3) & ~(int64_t)3;      // S [n][TF] | D [n] | C [n] | (F % 4 != 0) X [n][TF]
+    return n_nodes * (TF + 2) + ((n_feat & 3) ? n_nodes * TF : 0);
 }
 int32_t drgnn_topology_tiles_ok(int32_t max_nodes, int32_t max_edges, int32_t n_feat) {
     return topo_tiles_shape_ok(max_nodes, max_edges, n_feat) ? 1 : 0;
@@ -113,7 +116,7 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     if (flags & DRGNN_TOPO_TILES) {
         // the aggregation tiles need the hierarchical order's companions, an output buffer and float4-loadable features
         // (x_in null: resident-set mode, the caller fills in the set's x and checks it)
-        if (!(flags & DRGNN_TOPO_HIER) || !tiles || (x_in && (((uintptr_t)x_in) & 15)) || (((uintptr_t)tiles) & 15)) return DRGNN_E_ARG;
+        if (!(flags & DRGNN_TOPO_HIER) || !tiles || (x_in && !(tile_f & 3) && (((uintptr_t)x_in) & 15)) || (((uintptr_t)tiles) & 15)) return DRGNN_E_ARG;
         if (!topo_tiles_shape_ok(max_nodes, max_edges, tile_f)) return DRGNN_E_CAPACITY;
         L.args.x_in = x_in; L.args.tiles = tiles; L.args.tile_f = tile_f;
     }
@@ -155,7 +158,7 @@ static int topo_prepare_req(TopoLaunch& T, int64_t* tlds, const drgnn_topology_r
     if (r->x_out && (!gs->x || gs->n_feat <= 0)) return DRGNN_E_ARG;
     if (r->y_out && (!gs->y || (gs->y_bytes != 4 && gs->y_bytes != 8))) return DRGNN_E_ARG;
     const float* attr = (r->ws_f32 && gs->edge_attr) ? gs->edge_attr : nullptr;
-    if ((r->flags & DRGNN_TOPO_TILES) && (!gs->x || gs->n_feat <= 0 || (((uintptr_t)gs->x) & 15))) return DRGNN_E_ARG;
+    if ((r->flags & DRGNN_TOPO_TILES) && (!gs->x || gs->n_feat <= 0 || (!(gs->n_feat & 3) && (((uintptr_t)gs->x) & 15)))) return DRGNN_E_ARG;
     const int rc = topo_prepare(T, tlds, gs->edge_index, attr, nullptr, gs->cluster0, gs->cluster1, r->node_ptr,
                                 r->edge_ptr, r->c1_ptr, r->n_nodes, r->n_edges, r->len_cluster1, r->n_graphs,
                                 r->max_nodes, r->max_edges, r->ws_i32, r->ws_f32, r->scratch_i32, r->flags, nullptr, r->tiles,
@@ -666,6 +669,17 @@ static int step_variant(int kind, const float* x, int F, int capN, int capE, int
     return (f16 == 16 || f16 == 32 || f16 == 48 || f16 == 64) ? f16 : 0;
 }
 
+// ... of the AGGREGATION-FIRST kernels: they read padded tile rows, so any feature count up to 64 has a width class; what
+// remains of step_burst_guaranteed are the head width and the burst capacities
+static int step_af_width(int kind, int F, int capN, int capE, int capC, int H, int O) {
+    if (H != ((kind == DRGNN_GINET) ? 128 : 64) || F < 1 || F > 64) return 0;
+    const int TF = (F + 3) & ~3;
+    const bool ok = (F * DRGNN_H1 <= DRGNN_BCAP) && ((long)capN * TF <= 16L * DRGNN_BCAP) && (capN + 1 <= DRGNN_BCAP) &&
+                    (capE <= 2 * DRGNN_BCAP) && (capC * DRGNN_H1 <= 4 * DRGNN_BCAP) && O * H <= 2 * DRGNN_BCAP &&
+                    H * 8 <= STEP_WB_J * DRGNN_BCAP;
+    return ok ? step_pad16(F) : 0;
+}
+
 // what a launch is, as far as its layout goes
 struct StepAsk {
     int kind, F, capN, capE, capC, R, H, O;
@@ -703,10 +717,16 @@ static StepPick step_pick(const StepAsk& q) {
     // the aggregation-first family: a workspace with the hierarchical order and usable tiles, a width class, the reference head
     k.width = step_variant(q.kind, nullptr, q.F, q.capN, q.capE, q.capC, q.H, q.O);
     if (!q.x_ok) k.width = 0;
+    const int old_width = k.width;
 #ifdef DRGNN_EMU
     const bool af_shape = false;
+    const int af_w = 0;
 #else
-    const bool af_shape = !q.ov.no_aggregate && (q.topo_flags & DRGNN_TOPO_HIER) && (q.topo_flags & DRGNN_TOPO_TILES) && k.width != 0;
+    // (the single-branch nets read x rows next to the tiles: the input's when F % 4 == 0 -- 16-byte aligned then --, else the
+    // tiles' padded copy; GINet reads the tiles only)
+    const int af_w = step_af_width(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O);
+    const bool af_shape = !q.ov.no_aggregate && (q.topo_flags & DRGNN_TOPO_HIER) && (q.topo_flags & DRGNN_TOPO_TILES) && af_w != 0 &&
+                          (q.kind == DRGNN_GINET || (q.F & 3) != 0 || q.x_ok);
 #endif
     if (q.kind == DRGNN_GINET) {
         const bool narrow = q.H < DRGNN_H2;      // (the exchange words of a graph are 2 x 32 of its 2 x H: a narrower head runs one workgroup per graph)
@@ -761,6 +781,7 @@ static StepPick step_pick(const StepAsk& q) {
     // step; 128 + 128 = one round, 29.0 us)
     if (k.builder_roles == 2 && k.wgs == 1 && q.B + 2 * co > cus && q.B + co <= cus) k.builder_roles = 1;
     k.lean_ok = (k.kernel == SK_AF2 || k.kernel == SK_AF3 || k.kernel == SK_AF3B) ? 1 : 0;
+    k.width = k.lean_ok ? af_w : old_width;
     k.family = k.lean_ok ? DRGNN_STEP_FAMILY_AGGREGATE : DRGNN_STEP_FAMILY_PRODUCT;
     // Capacity class (drgnn_step.h: STEP_CLS_*): a batch whose maxima lie inside the class is stepped by the 32-wide kernels
     // whose LDS layout is a compile-time constant (of the one-workgroup product-first GINet layouts the paired form; of the
@@ -768,7 +789,8 @@ static StepPick step_pick(const StepAsk& q) {
 #ifndef DRGNN_EMU
     if (!q.ov.no_class && k.width == 32 && q.capN <= STEP_CLS_N && q.capE <= STEP_CLS_E && q.capC <= STEP_CLS_C &&
         !(k.kernel == SK_STEP1 && !k.paired) && !(k.lean_ok && !q.train) &&
-        step_variant(q.kind, nullptr, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O) == 32) {
+        (k.lean_ok ? step_af_width(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
+                   : step_variant(q.kind, nullptr, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)) == 32) {
         const int64_t lc = k.kernel == SK_AF3B ? 4 * step3b_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                          : k.kernel == SK_AF3 ? 4 * step3_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                          : k.kernel == SK_AF2 ? 4 * step2_scratch_words(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
@@ -1046,11 +1068,12 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             memset(&Q, 0, sizeof(Q));
             Q.tv = a.tv;
             Q.pf_ids = hints->next_ids; Q.pf_n = (int)hints->n_next;
-            Q.pf_tiles = a.tiles; Q.pf_f = F; Q.pf_tile_nodes = n_nodes;
-            Q.pf_x = (kind != DRGNN_GINET) ? x : nullptr;
+            const int TF = (F + 3) & ~3;
+            Q.pf_tiles = a.tiles; Q.pf_f = TF; Q.pf_tile_nodes = n_nodes;
+            Q.pf_x = (kind == DRGNN_GINET) ? nullptr : (F & 3) ? a.tiles + n_nodes * (TF + 2) : x;
             Q.pf_coef = (kind != DRGNN_GINET) ? 1 : 0;
             Q.pf_y = hd->train ? target : nullptr; Q.pf_y_bytes = (hd->task == DRGNN_TASK_REG) ? 4 : 8;
-            if (Q.pf_tiles != nullptr && (F & 3) == 0) extra = Q.pf_n; else Q.pf_ids = nullptr;
+            if (Q.pf_tiles != nullptr) extra = Q.pf_n; else Q.pf_ids = nullptr;
         }
         drgnn_step_kernel_t kern = nullptr;
         const bool gather = gather_ids != nullptr;
@@ -1689,8 +1712,9 @@ int32_t epoch_topo_flags(const drgnn_epoch_plan* p, const EpochBatch& b, int64_t
         if (!p->cache->tiles) f &= ~DRGNN_TOPO_TILES;
         return f;
     }
+    const bool f4 = (p->net->n_feat & 3) == 0;      // (16-byte aligned rows are only needed where rows ARE multiples of 16 bytes)
     const bool tiles_ok = drgnn_topology_tiles_ok(b.maxN, b.maxE, p->net->n_feat) != 0 && p->set->x != nullptr &&
-                          ((((uintptr_t)p->set->x) & 15) == 0) && ((((uintptr_t)slot_x) & 15) == 0);
+                          (!f4 || (((((uintptr_t)p->set->x) & 15) == 0) && ((((uintptr_t)slot_x) & 15) == 0)));
     const int32_t af = DRGNN_TOPO_HIER | DRGNN_TOPO_LEAN | DRGNN_TOPO_TILES;
     if (tiles_ok && epoch_plan_of(p, b, co, af).lean_ok) return af;
     return (p->net->kind != DRGNN_GINET && !p->inference) ? DRGNN_TOPO_HIER : 0;

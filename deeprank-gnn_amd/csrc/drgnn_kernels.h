@@ -96,6 +96,7 @@ DEV void prefetch_block(const TopoLaunch& L, int g) {
     int acc = P[DRGNN_TI_NC0][id] ^ P[DRGNN_TI_NE1][id] ^ P[DRGNN_TI_NC1][id] ^ P[DRGNN_TI_GSTAT][id] ^ P[DRGNN_TI_HSPLIT][4 * id];
     if (L.pf_y) acc ^= (L.pf_y_bytes == 8) ? (int)((const long long*)L.pf_y)[id] : ((const int*)L.pf_y)[id];
     drgnn_f4 f = {0.f, 0.f, 0.f, 0.f};
+    // (pf_f: the padded row length pad4(F); pf_x: the rows the step kernels read -- the input's, or the tiles' padded copy)
     const int n4 = (N * L.pf_f) >> 2;
     const drgnn_f4* s4 = (const drgnn_f4*)(L.pf_tiles + (long long)n0 * L.pf_f);
     const drgnn_f4* x4 = L.pf_x ? (const drgnn_f4*)(L.pf_x + (long long)n0 * L.pf_f) : nullptr;
@@ -207,13 +208,20 @@ DEV void tiles_block(const TilesArgs& a, int g) {
     const int32_t* rp = a.tv.p[DRGNN_TI_ROWPTR0] + n0 + g;
     const int32_t* col = a.tv.p[DRGNN_TI_COL0] + e0;
     const float* w = (a.use_weights && a.tv.w0) ? a.tv.w0 + e0 : nullptr;
-    const int F = a.n_feat;
+    const int F = a.n_feat, TF = (F + 3) & ~3;      // (rows of the tiles are padded to TF floats: drgnn_topology.h, TopoTile)
     const float* x = a.x + (long long)n0 * F;
-    float* ts = a.tiles + (long long)n0 * F;
-    float* td = a.tiles + a.n_nodes * F + n0;
+    float* ts = a.tiles + (long long)n0 * TF;
+    float* td = a.tiles + a.n_nodes * TF + n0;
     float* tc = td + a.n_nodes;
+    float* tx = (F & 3) ? a.tiles + a.n_nodes * (TF + 2) + (long long)n0 * TF : nullptr;
+    FOR_TID(pad, N * (TF - F)) {
+        const int i = pad / (TF - F), f = F + pad % (TF - F);
+        ts[(long long)i * TF + f] = 0.0f;
+        tx[(long long)i * TF + f] = 0.0f;
+    }
     FOR_TID(item, N * F) {
         const int i = item / F, f = item - i * F;
+        if (tx) tx[(long long)i * TF + f] = x[(long long)i * F + f];
         const int lo = rp[i], hi = rp[i + 1], deg = hi - lo;
         float acc = 0.0f, asum = 0.0f;
         if (w != nullptr) {
@@ -228,7 +236,7 @@ DEV void tiles_block(const TilesArgs& a, int g) {
         } else {
             for (int k = lo; k < hi; ++k) acc += x[(long long)col[k] * F + f];
         }
-        ts[(long long)i * F + f] = acc;
+        ts[(long long)i * TF + f] = acc;
         if (f == 0) {
             float d, sc;
             if (w != nullptr) { d = 1.0f / (float)(deg > 0 ? deg : 1); sc = asum * d; }

@@ -573,9 +573,12 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     // ---- prologue: one burst of independent loads ----------------------------------------------------------------------
     PHASE_MARK();
     constexpr int BJ = (CLS == 1) ? 2 : 4;                 // float4 per lane of a row tile (capacity class: 200 x 32 floats)
-    const float* xgl = a.x + (long)d.n0 * F;                // the graph's x rows and aggregation tiles (node order)
-    const float* sgl = a.tiles + (long)d.n0 * F;
-    const float* tdg = a.tiles + a.tile_nodes * F + d.n0;
+    // the graph's x rows and aggregation tiles (node order).  Rows of the tiles are TF = pad4(F) floats long (zero padded by the
+    // builder); with F % 4 != 0 the x rows come from the tiles' padded copy instead of the (unaligned) input
+    const int TF = (F + 3) & ~3;
+    const float* xgl = (F & 3) ? a.tiles + a.tile_nodes * (TF + 2) + (long)d.n0 * TF : a.x + (long)d.n0 * F;
+    const float* sgl = a.tiles + (long)d.n0 * TF;
+    const float* tdg = a.tiles + a.tile_nodes * TF + d.n0;
     const float* tcg = tdg + a.tile_nodes;
     BurstX<BJ> bx, bsum;
     BurstRowMap<BJ> brow;
@@ -636,8 +639,8 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
             m_bad = __builtin_amdgcn_readfirstlane(m_bad);
         }
     }
-    burst_load_x(bsum, sgl, d.N, F);
-    burst_load_x(bx, xgl, d.N, F);
+    burst_load_x(bsum, sgl, d.N, TF);
+    burst_load_x(bx, xgl, d.N, TF);
     burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
     // per-node coefficients D, C and the node's position (one node per lane: d.N <= threads, step_burst_guaranteed)
     float n_d = 0.0f, n_c = 0.0f;
@@ -679,9 +682,12 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     burst_store_wt(bw1, s.w1t, XLD);
     burst_store_wt(bs1, s.ws1t, XLD);
     wstage_store(wst);
-    if (XF > F) {      // zero padding of the k columns [F, XF) (row tiles; weights)
+    if (XF > TF) {     // zero padding of the k columns [TF, XF) of the row tiles ...
+        const int padg = XF - TF;
+        FOR_TID(e, Nh * padg) { s.xs[(e / padg) * XLD + TF + e % padg] = 0.0f; s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+    }
+    if (XF > F) {      // ... and [F, XF) of the weights
         const int padc = XF - F;
-        FOR_TID(e, Nh * padc) { s.xs[(e / padc) * XLD + F + e % padc] = 0.0f; s.G[(e / padc) * XLD + F + e % padc] = 0.0f; }
         FOR_TID(e, DRGNN_H1 * padc) { s.w1t[(e / padc) * XLD + F + e % padc] = 0.0f; s.ws1t[(e / padc) * XLD + F + e % padc] = 0.0f; }
     }
     FOR_TID(i, 1) {

@@ -248,7 +248,8 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
 
     // ---- prologue: everything this graph needs, two register bursts requested back to back --------------------------------
     PHASE_MARK();
-    const float* sgl = a.tiles + (long)d.n0 * F;      // the graph's S rows (node order)
+    const int TF = (F + 3) & ~3;                       // row length of the tiles (padded with zeros by the builder)
+    const float* sgl = a.tiles + (long)d.n0 * TF;     // the graph's S rows (node order)
     BurstX<4> bx;
     BurstRowMap<4> brow;
     BurstW<1> bw1, bw2;
@@ -302,7 +303,7 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
             m_bad = __builtin_amdgcn_readfirstlane(m_bad);
         }
     }
-    burst_load_x(bx, sgl, d.N, F);
+    burst_load_x(bx, sgl, d.N, TF);
     burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
     burst_load_w(bw1, c1.w_nbr, c1.nbr_sk, c1.nbr_sh, F, DRGNN_H1);
     wstage_load(wst, stage_job(1, my_wave));
@@ -314,9 +315,12 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     wstage_store(wst);
     // zero padding the predicate-free products rely on: G rows [N, pad4(N)) and (F < XF) the k columns [F, XF)
     FOR_TID(e, (step_pad4(d.N) - d.N) * XLD) { s.G[d.N * XLD + e] = 0.0f; }
+    if (XF > TF) {
+        const int padg = XF - TF;
+        FOR_TID(e, d.N * padg) { s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+    }
     if (XF > F) {
         const int padc = XF - F;
-        FOR_TID(e, d.N * padc) { s.G[(e / padc) * XLD + F + e % padc] = 0.0f; }
         FOR_TID(e, DRGNN_H1 * padc) { s.w1t[(e / padc) * XLD + F + e % padc] = 0.0f; }
     }
     FOR_TID(i, 1) {
@@ -542,7 +546,8 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
 
     // ---- prologue ----------------------------------------------------------------------------------------------------------
     PHASE_MARK();
-    const float* sgl = a.tiles + (long)d.n0 * F;
+    const int TF = (F + 3) & ~3;
+    const float* sgl = a.tiles + (long)d.n0 * TF;
     BurstX<4> bx;
     BurstRowMap<4> brow;
     BurstW<1> bw1[2], bw2[2];
@@ -595,7 +600,7 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
             m_bad = __builtin_amdgcn_readfirstlane(m_bad);
         }
     }
-    burst_load_x(bx, sgl, d.N, F);
+    burst_load_x(bx, sgl, d.N, TF);
     burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
@@ -617,9 +622,12 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     step_wblock_store(wreg, hf, 0, s.wb);
     wstage_store(wst);
     FOR_TID(e, (step_pad4(d.N) - d.N) * XLD) { s.G[d.N * XLD + e] = 0.0f; }
+    if (XF > TF) {
+        const int padg = XF - TF;
+        FOR_TID(e, d.N * padg) { s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+    }
     if (XF > F) {
         const int padc = XF - F;
-        FOR_TID(e, d.N * padc) { s.G[(e / padc) * XLD + F + e % padc] = 0.0f; }
         FOR_TID(e, DRGNN_H1 * padc) { s.w1t[0][(e / padc) * XLD + F + e % padc] = 0.0f; s.w1t[1][(e / padc) * XLD + F + e % padc] = 0.0f; }
     }
     BARRIER();

@@ -898,7 +898,10 @@ DEV void topo_clusters1(const TopoView& tv, const TopoArgs& a, int g, int n0, in
 // -- what conv1 of every net starts from, formed HERE because it depends on the inputs only.  The x tile of the graph was
 // requested in phase 0 and sits in LDS (rows of F + 4 floats); rp / col_s / w_s: CSR0 of the graph in LDS (slot order =
 // edge-id order).  F / 4 lanes per node, each with one float4 of the row; results go straight to global memory (node order).
-struct TopoTile { const float* x; float* ts; float* td; float* tc; float* xs; int F; };
+// Rows of S are padded to TF = pad4(F) floats (zeros), so that the step kernels load them with 128-bit requests whatever the
+// feature count; with F % 4 != 0 the tiles also carry a padded copy of the node features (tx: what sGAT / FoutNet multiply with
+// their self weights), the kernels then never touch the unaligned input rows.
+struct TopoTile { const float* x; float* ts; float* td; float* tc; float* tx; float* xs; int F, TF; };
 // L2 touch of an output range (see topo_graph): up to 4 float4 per lane, requested with the phase's other loads, dropped unread
 #ifdef DRGNN_EMU
 struct TopoTouch { int dummy; };
@@ -926,9 +929,11 @@ DEV TopoTile topo_tile_of(const TopoArgs& a, const TopoSrc& src, int n0, float* 
     const float* xsrc = a.set_ids ? a.set_x : a.x_in;
     if (xsrc == nullptr || xs == nullptr) t.F = 0;
     t.x = (t.F > 0) ? xsrc + src.x_row * t.F : nullptr;
-    t.ts = (t.F > 0) ? a.tiles + (long long)n0 * t.F : nullptr;
-    t.td = (t.F > 0) ? a.tiles + a.tile_nodes * t.F + n0 : nullptr;
+    t.TF = (t.F + 3) & ~3;
+    t.ts = (t.F > 0) ? a.tiles + (long long)n0 * t.TF : nullptr;
+    t.td = (t.F > 0) ? a.tiles + a.tile_nodes * t.TF + n0 : nullptr;
     t.tc = (t.F > 0) ? t.td + a.tile_nodes : nullptr;
+    t.tx = (t.F > 0 && (t.F & 3)) ? a.tiles + a.tile_nodes * (t.TF + 2) + (long long)n0 * t.TF : nullptr;
     t.xs = xs;
     return t;
 }
@@ -936,16 +941,26 @@ DEV TopoTile topo_tile_of(const TopoArgs& a, const TopoSrc& src, int n0, float* 
 struct TopoTileRegs { int dummy; };
 DEV void topo_tile_load(TopoTileRegs&, const TopoTile&, int) {}
 DEV void topo_tile_store(const TopoTileRegs&, const TopoTile& t, int N) {
-    for (int i = 0; i < N && t.F > 0; ++i) for (int f = 0; f < t.F; ++f) t.xs[i * (t.F + 4) + f] = t.x[(long long)i * t.F + f];
+    for (int i = 0; i < N && t.F > 0; ++i)
+        for (int f = 0; f < t.TF; ++f) t.xs[i * (t.TF + 4) + f] = (f < t.F) ? t.x[(long long)i * t.F + f] : 0.0f;
 }
 #else
 struct TopoTileRegs { BurstX<4> bx; };
-DEV void topo_tile_load(TopoTileRegs& r, const TopoTile& t, int N) { if (t.F > 0) burst_load_x(r.bx, t.x, N, t.F); }
-DEV void topo_tile_store(const TopoTileRegs& r, const TopoTile& t, int N) { (void)N; if (t.F > 0) burst_store_x4(r.bx, t.xs, t.F + 4); }
+DEV void topo_tile_load(TopoTileRegs& r, const TopoTile& t, int N) { if (t.F > 0 && !(t.F & 3)) burst_load_x(r.bx, t.x, N, t.F); }
+DEV void topo_tile_store(const TopoTileRegs& r, const TopoTile& t, int N) {
+    if (t.F <= 0) return;
+    if (!(t.F & 3)) { burst_store_x4(r.bx, t.xs, t.F + 4); return; }
+    // feature counts that are not a multiple of 4: word by word, rows padded with zeros
+    const FastDiv fd = fastdiv_make(t.TF);
+    FOR_TID(e, N * t.TF) {
+        const int i = fastdiv(fd, e), f = fastmod(fd, e, i);
+        t.xs[i * (t.TF + 4) + f] = (f < t.F) ? t.x[(long long)i * t.F + f] : 0.0f;
+    }
+}
 #endif
 DEV void topo_tiles_rows(const TopoTile& t, int N, const int* rp, const int* col_s, const float* w_s) {
     if (t.F <= 0) return;
-    const int F = t.F, G4 = F >> 2, XLD = F + 4;
+    const int F = t.TF, G4 = F >> 2, XLD = F + 4;      // (F: the padded row length from here on)
     const FastDiv fd = fastdiv_make(G4);
     FOR_TID(item, N * G4) {
         const int i = fastdiv(fd, item), c = fastmod(fd, item, i) * 4;
@@ -976,6 +991,11 @@ DEV void topo_tiles_rows(const TopoTile& t, int N, const int* rp, const int* col
         }
         float* dst = t.ts + (long long)i * F + c;
         dst[0] = a0; dst[1] = a1; dst[2] = a2; dst[3] = a3;
+        if (t.tx != nullptr) {
+            const float* xi = t.xs + ROW24(i, XLD) + c;
+            float* dx = t.tx + (long long)i * F + c;
+            dx[0] = xi[0]; dx[1] = xi[1]; dx[2] = xi[2]; dx[3] = xi[3];
+        }
         if (c == 0) {
             float d, sc;
             if (w_s != nullptr) { d = 1.0f / (float)(deg > 0 ? deg : 1); sc = asum * d; }
@@ -1411,7 +1431,7 @@ DEV void topo_graph(const TopoView& tv, const TopoArgs& a, int g, int n0, int n1
     // workspaces alternate (the epoch loop's slots: their lines are resident from two launches ago).  The same for the index
     // arrays the clusters chain writes did not pay (17.78 vs 17.81 us, and +0.1 us on the replayed step).
     TopoTouch touch;
-    topo_touch_load(touch, (run_rows || (structure && !lean)) ? tile.ts : nullptr, N * tile.F);
+    topo_touch_load(touch, (run_rows || (structure && !lean)) ? tile.ts : nullptr, N * tile.TF);
     // the cluster ids of the clusters chain are requested AHEAD of the edge list (one round trip for all three)
     long long pre0 = 0, pre1 = 0;
     bool pre = false;

@@ -302,7 +302,7 @@ class ResidentGraphSet(object):
         r.ids, r.x_out, r.y_out = p(ids_dev), p(x), p(y)
         r.flags = _lib.TOPO_HIER
         # the level-0 aggregation tiles of the mini-batch (formed from the set's x by the builder), where it can
-        if scratch is None and self.has_c1 and self.x.data_ptr() % 16 == 0 and \
+        if scratch is None and self.has_c1 and (self.n_feat % 4 != 0 or self.x.data_ptr() % 16 == 0) and \
                 self.api.topology_tiles_ok(topo.max_nodes, topo.max_edges, self.n_feat):
             need = self.api.topology_tiles_elems(N, self.n_feat)
             if topo.tiles is None or topo.tiles.numel() < need or topo.n_feat != self.n_feat:
@@ -401,7 +401,8 @@ class TopologyCache(object):
             r.ids, r.x_out, r.y_out = p(ids), None, None
             r.flags = _lib.TOPO_HIER
             # the set's level-0 aggregation tiles: formed ONCE here, read by every training step on the cache
-            if scratch is None and gset.x.data_ptr() % 16 == 0 and api.topology_tiles_ok(self.max_nodes, self.max_edges, gset.n_feat):
+            if scratch is None and (gset.n_feat % 4 != 0 or gset.x.data_ptr() % 16 == 0) and \
+                    api.topology_tiles_ok(self.max_nodes, self.max_edges, gset.n_feat):
                 topo.tiles = torch.empty(max(api.topology_tiles_elems(N, gset.n_feat), 4), dtype=torch.float32, device=dev)
                 topo.n_feat = gset.n_feat
                 r.tiles, r.n_feat = p(topo.tiles), gset.n_feat

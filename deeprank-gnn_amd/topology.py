@@ -109,7 +109,9 @@ class Topology(object):
         if x is not None and x.dim() == 2 and x.dtype == torch.float32 and x.device == device and scratch is None:
             x = x.contiguous()
             F = int(x.shape[1])
-            if x.shape[0] == n_nodes and F > 0 and x.data_ptr() % 16 == 0 and api.topology_tiles_ok(max_nodes, max_edges, F):
+            # (float4 loads of the rows where rows are multiples of 16 bytes; any other feature count is staged word by word)
+            if x.shape[0] == n_nodes and F > 0 and (F % 4 != 0 or x.data_ptr() % 16 == 0) and \
+                    api.topology_tiles_ok(max_nodes, max_edges, F):
                 topo.x, topo.n_feat = x, F
                 topo.tiles = torch.empty(max(api.topology_tiles_elems(n_nodes, F), 4), dtype=torch.float32, device=device)
         if build:
@@ -133,7 +135,7 @@ class Topology(object):
         r.flags = self.full_flags() if flags is None else int(flags)
         if r.flags & _lib.TOPO_TILES:
             if self.tiles is None:
-                raise ValueError("this topology has no aggregation tiles (no 16-byte aligned float32 x with F % 4 == 0)")
+                raise ValueError("this topology has no aggregation tiles (no float32 x the builder's LDS holds a tile of)")
             r.x, r.tiles, r.n_feat = p(self.x), p(self.tiles), self.n_feat
             # the tiles bake values of x in: what x was when the builder read it (trainer._usable_flags compares)
             self._tiles_x_version = self.x._version
@@ -198,10 +200,12 @@ class Topology(object):
         return self.ws_i32[self.off_i32[k]:self.off_i32[k + 1]]
 
     def tile_arrays(self):
-        """(S [n, F], D [n], C [n]) views of the level-0 aggregation tiles (include/drgnn.h, DRGNN_TOPO_TILES)."""
+        """(S [n, F], D [n], C [n]) views of the level-0 aggregation tiles (include/drgnn.h, DRGNN_TOPO_TILES; the rows of S
+        are stored padded to a multiple of 4 floats)."""
         n, F = self.n_nodes, self.n_feat
+        TF = (F + 3) // 4 * 4
         t = self.tiles
-        return t[:n * F].view(n, F), t[n * F:n * F + n], t[n * F + n:n * F + 2 * n]
+        return t[:n * TF].view(n, TF)[:, :F], t[n * TF:n * TF + n], t[n * TF + n:n * TF + 2 * n]
 
     def weights(self, name):
         k = _lib.TF[name]

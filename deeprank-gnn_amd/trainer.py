@@ -169,7 +169,7 @@ class FusedTrainer(object):
         if ok and x is not None:
             tx = getattr(topo, "x", None)
             ok = (tx is not None and tx.data_ptr() == x.data_ptr() and tuple(tx.shape) == tuple(x.shape) and
-                  x.data_ptr() % 16 == 0 and getattr(topo, "_tiles_x_version", None) == x._version)
+                  (x.shape[1] % 4 != 0 or x.data_ptr() % 16 == 0) and getattr(topo, "_tiles_x_version", None) == x._version)
         if not ok:
             flags &= ~_lib.TOPO_TILES
         return flags
@@ -234,8 +234,8 @@ class FusedTrainer(object):
             y = y.to(torch.float32).contiguous() if self.task == _lib.TASK_REG else y.to(torch.int64).contiguous()
         topo_flags = self._usable_flags(topo, x)
         if (int(getattr(topo, "flags", 0)) & _lib.TOPO_TILES) and not (topo_flags & _lib.TOPO_TILES) and \
-                self._tiles_match(topo) and getattr(topo, "tiles", None) is not None and x.data_ptr() % 16 == 0 and \
-                tuple(x.shape) == tuple(topo.x.shape):
+                self._tiles_match(topo) and getattr(topo, "tiles", None) is not None and \
+                (x.shape[1] % 4 != 0 or x.data_ptr() % 16 == 0) and tuple(x.shape) == tuple(topo.x.shape):
             # the tiles were formed from other node features than the ones being stepped (x replaced or modified in place
             # since the build): form them again from this x (own launch, same stream)
             topo.x = x
@@ -317,7 +317,7 @@ class FusedTrainer(object):
         max_nodes, max_edges, max_c0 = cache.bounds(ids)
         topo_flags = int(getattr(cache.topo, "flags", 0))
         tiles = cache.tiles_for(self.kind == _lib.SGAT) if (topo_flags & _lib.TOPO_TILES) else None
-        if tiles is None or gset.x.data_ptr() % 16 != 0:
+        if tiles is None or (n_feat % 4 == 0 and gset.x.data_ptr() % 16 != 0):
             topo_flags &= ~_lib.TOPO_TILES
             tiles = None
         plan = self._plan(n_feat, max_nodes, max_edges, max_c0, B, 0, train, topo_flags)

@@ -342,12 +342,14 @@ typedef struct drgnn_topology_request {
  * on the inputs only (node features, edges, edge weights), not on a parameter -- so that the training step of the mini-batch
  * starts from it instead of gathering x rows over edge_index inside the step kernel: the aggregation rides in the builder's
  * workgroups of the PREVIOUS launch like the topology itself (cached-topology mode: it is formed once per graph).  Layout of
- * `tiles` (node order, n = n_nodes of the workspace, F = n_feat):
- *     S [n][F]   S_i = sum over the edges e = (i, j) in edge-id order of [w_e] x_j     (w_e: with edge weights only)
+ * `tiles` (node order, n = n_nodes of the workspace, F = n_feat, TF = F rounded up to a multiple of 4: rows are zero padded so
+ * that the step kernels load them with 128-bit requests whatever the feature count):
+ *     S [n][TF]  S_i = sum over the edges e = (i, j) in edge-id order of [w_e] x_j     (w_e: with edge weights only)
  *     D [n]      1 / deg_i (without weights: 0 for an isolated node; with weights: 1 / max(deg_i, 1))
  *     C [n]      with weights: mean edge weight of the row (sum_e w_e) D_i; without: 1
+ *     X [n][TF]  only when F % 4 != 0: the node features, rows zero padded (what sGAT / FoutNet multiply with their self weights)
  * GINetConvLayer (ginet.py:50-73) is relu(S W); FoutLayer (foutnet.py:56-82) relu(D (S Wn) + x Wc + b); sGraphAttentionLayer
- * (sGAT.py:62-93) relu(D (S Wn) + C (x Ws) + b).  Needs n_feat % 4 == 0, 16-byte aligned x and drgnn_topology_tiles_ok(). */
+ * (sGAT.py:62-93) relu(D (S Wn) + C (x Ws) + b).  Needs drgnn_topology_tiles_ok() and, when F % 4 == 0, 16-byte aligned x. */
 #define DRGNN_TOPO_TILES 4
 /* elements of a tiles buffer / 1 when the builder can form tiles for graphs of these bounds (its LDS holds an x tile then) */
 int64_t drgnn_topology_tiles_elems(int64_t n_nodes, int32_t n_feat);

@@ -93,7 +93,10 @@ def test_aggregation_tiles(weights, lean):
     the hierarchical order -- by the general chains and by the lean ones, with and without edge weights."""
     from deeprank_gnn_amd import _lib
     flags = _lib.TOPO_HIER | _lib.TOPO_TILES | (_lib.TOPO_LEAN if lean else 0)
-    for batch in (synth.make_batch(0, 3), synth.make_batch(5, 4, n_nodes=30, n_pairs=50, n_feat=8, n_c1=3, n_internal=8)):
+    # (feature counts that are not a multiple of 4 -- 7, 26 -- : the tile rows are padded to 8 / 28 floats)
+    for batch in (synth.make_batch(0, 3), synth.make_batch(5, 4, n_nodes=30, n_pairs=50, n_feat=8, n_c1=3, n_internal=8),
+                  synth.make_batch(9, 3, n_nodes=30, n_pairs=50, n_feat=7, n_c1=3, n_internal=8),
+                  synth.make_batch(2, 2, n_nodes=40, n_pairs=70, n_feat=26, n_c1=4, n_internal=20)):
         topo = Topology.from_batch(batch, api=emu(), need_weights=weights, flags=flags)
         assert topo.status()[0] == 0 and topo.tiles is not None
         check_against_oracle(topo, batch, weights=weights)

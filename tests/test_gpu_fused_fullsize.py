@@ -522,7 +522,7 @@ def test_step_families_ragged_batches_vs_oracle(net_name, layout):
     """Every kernel family on ragged batches (tests/step_check.py: graphs of 1 .. 49 nodes, a single-node graph that leaves
     one half of the split EMPTY, isolated nodes -> FoutNet's NaN rows / sGAT's bias rows (sGAT.py:62-93, foutnet.py:71-73),
     self loops, duplicate edges, non-consecutive cluster ids), classification and regression, feature widths 32 / 20 / 28 /
-    12 / 44 / 60 (padded 32, 32, 32, 16, 48, 64): loss, predictions and EVERY gradient element vs the ORACLE on the same
+    12 / 44 / 60 / 7 / 26 / 33 (padded 32, 32, 32, 16, 48, 64, 16, 32, 48): loss, predictions and EVERY gradient element vs the ORACLE on the same
     inputs (tests/elementwise.py: 1e-4 + 1e-4 |ref|, float64 arbiter), NaN pattern equal.  GINet: the product-first family
     ("old"), the aggregation-first one-workgroup ("af1") and two-workgroup ("af2") layouts."""
     from deeprank_gnn_amd import _lib
@@ -533,7 +533,9 @@ def test_step_families_ragged_batches_vs_oracle(net_name, layout):
     rng = np.random.default_rng(5)
     from step_check import ragged_batch
     kw = _fw_kwargs(net_name)
-    for seed, (n_feat, task) in enumerate(((32, "reg"), (20, "class"), (28, "reg"), (12, "reg"), (44, "class"), (60, "reg"))):
+    # (7 / 26 / 33: feature counts that are not multiples of 4 -- the aggregation-first kernels read padded tile rows)
+    for seed, (n_feat, task) in enumerate(((32, "reg"), (20, "class"), (28, "reg"), (12, "reg"), (44, "class"), (60, "reg"),
+                                           (7, "reg"), (26, "class"), (33, "reg"))):
         batch_cpu = ragged_batch(seed, n_feat)          # 7 graphs: 1 .. 49 nodes, a single-node graph, isolated nodes, self loops, duplicates
         batch_cpu.y = torch.arange(batch_cpu.num_graphs, dtype=torch.float32) * 0.3 - 1.0
         n_out = 1 if task == "reg" else 3
@@ -558,7 +560,8 @@ def test_step_families_ragged_batches_vs_oracle(net_name, layout):
             assert c["plan"].wgs_per_graph == (1 if layout == "af1" else 2)
         else:
             _check_family(tr, c, layout)
-        assert c["plan"].width == ((n_feat + 15) // 16) * 16
+        # (the product-first kernels are width-specialised for multiples of 4 only: the generic instance otherwise)
+        assert c["plan"].width == (0 if (layout == "old" and n_feat % 4) else ((n_feat + 15) // 16) * 16)
         loss = tr.compute_gradients(batch, topo=topo)
         torch.cuda.synchronize()
         assert tr.faults() == 0

@@ -239,7 +239,9 @@ def test_aggregation_tiles_on_the_device(weights, lean):
     dev = torch.device("cuda:0")
     flags = _lib.TOPO_HIER | _lib.TOPO_TILES | (_lib.TOPO_LEAN if lean else 0)
     for batch_cpu in (synth.make_batch(0, 64), synth.make_batch(3, 5, n_nodes=37, n_pairs=60, n_feat=8, n_c1=4, n_internal=10),
-                      synth.make_batch(0, 170, n_nodes=20, n_pairs=30, n_feat=4, n_c1=3, n_internal=6)):
+                      synth.make_batch(0, 170, n_nodes=20, n_pairs=30, n_feat=4, n_c1=3, n_internal=6),
+                      synth.make_batch(7, 6, n_nodes=45, n_pairs=80, n_feat=7, n_c1=4, n_internal=10),      # (rows padded to 8 floats)
+                      synth.make_batch(1, 9, n_nodes=132, n_pairs=300, n_feat=26, n_c1=9, n_internal=60)):  # (... to 28)
         batch = batch_cpu.clone().to(dev)
         topo = Topology.from_batch(batch, need_weights=weights, flags=flags)
         assert topo.status()[0] == 0 and topo.tiles is not None
