@@ -55,6 +55,11 @@ struct Step2Scratch {
 };
 
 #define STEP2_TSLD (DRGNN_H2 + 4)
+// Z1 (conv1's activations, [capN + 4][16]) is dead once the depth-0 cluster max is formed; [S | T] (u2) and Z2 / dZ2 (z2),
+// [capC + 4][36] each, are first written one barrier later: they share one region (13 KB at SYN size -- what lets 200-node
+// graphs with 48 features into the 160 KB)
+#define STEP2_Z1U_WORDS(capN, capC) \
+    ((long)((capN) + 4) * DRGNN_H1 > 2L * ((capC) + 4) * STEP2_TSLD ? (long)((capN) + 4) * DRGNN_H1 : 2L * ((capC) + 4) * STEP2_TSLD)
 #define STEP2_CARVE_LIST(X)                                                                    \
     X(misc, 128, 1)                                                                            \
     X(xr, 2 * DRGNN_H2, 1)                                                                     \
@@ -82,13 +87,11 @@ struct Step2Scratch {
     X(a0, ((long)capC * DRGNN_H1 + 1) / 2, 1)                                                  \
     X(a1, ((long)capC * DRGNN_H2 + 1) / 2, 1)                                                  \
     X(G, (long)(capN + 4) * xld, 1)                                                            \
-    X(z1, (long)(capN + 4) * DRGNN_H1, 1)                                                      \
+    X(z1, STEP2_Z1U_WORDS(capN, capC), 1)                                                      \
     X(dv0, capN + 4, 1)                                                                        \
     X(sc0, capN + 4, 1)                                                                        \
     X(xp, (long)(capC + 4) * STEP_XPLD, 1)                                                     \
     X(dsf, (long)(capC + 4) * STEP_XPLD, 1)                                                    \
-    X(u2, (long)(capC + 4) * STEP2_TSLD, 1)                                                    \
-    X(z2, (long)(capC + 4) * STEP2_TSLD, 1)                                                    \
     X(dt, (long)(capC + 4) * STEP_XPLD, 1)                                                     \
     X(dv1, capC + 4, 1)                                                                        \
     X(sc1, capC + 4, 1)                                                                        \
@@ -160,6 +163,8 @@ DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, i
 #undef X
     s.end = base + o;
     s.gp = s.wb;      // fc1's weights are dead after d readout: the K-split products keep their partial tiles there
+    s.u2 = s.z1;      // (see STEP2_Z1U_WORDS)
+    s.z2 = s.z1 + (long)(capC + 4) * STEP2_TSLD;
     return s;
 }
 
