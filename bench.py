@@ -120,6 +120,9 @@ def parse():
                          "recompute on the union of the shards (1e-5 relative, SURVEY 8(e)) and (b) parameters in sync "
                          "over the ranks; the result (ranks, backend, exchange, fallback taken) goes into config.dp_selftest "
                          "and to stderr.  Works with --gpus N (RCCL) and with --gpus N --backend gloo on one GPU")
+    ap.add_argument("--n-feat", type=int, default=N_FEAT,
+                    help="node features of the synthetic graphs (default 32 = BASELINE.json; 48 = the reference's shipped regression "
+                         "models); the algorithmic bytes follow SURVEY 8(d)'s accounting: + 4 N bytes per feature and pass over x")
     ap.add_argument("--dp-distinct", action="store_true",
                     help="also time the same (data-parallel) schedule over a cycle of 32 DIFFERENT synthetic mini-batches per rank "
                          "(`dp_distinct` in the line): the figure without the L2 residency of a replayed mini-batch")
@@ -136,13 +139,14 @@ def parse():
 
 
 def main():
-    global GRAPHS_PER_GPU
+    global GRAPHS_PER_GPU, N_FEAT
     args = parse()
     # RCCL writes its version banner to STDOUT (NCCL_DEBUG unset or =VERSION, as this image exports it); stdout
     # carries the ONE json line.  Other NCCL_DEBUG levels are left as the user set them.
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
         os.environ["NCCL_DEBUG"] = "NONE"
     GRAPHS_PER_GPU = args.graphs_per_gpu
+    N_FEAT = args.n_feat
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not launched by torch.distributed.run: spawn the N ranks ourselves (same command line) instead of
         # silently measuring one GPU
@@ -195,7 +199,7 @@ def main():
     if args.step_layout != "auto":
         os.environ["DRGNN_STEP_PLAN"] = {"noclass": "noclass", "old": "product", "af1": "nosplit", "one": "one",
                                          "seq": "one,seq", "two": "two"}[args.step_layout]
-    batch_cpu = synth.make_batch(rank * GRAPHS_PER_GPU, GRAPHS_PER_GPU)
+    batch_cpu = synth.make_batch(rank * GRAPHS_PER_GPU, GRAPHS_PER_GPU, n_feat=N_FEAT)
     batch = batch_cpu.clone().to(dev)
     torch.manual_seed(0)
     net = Net(N_FEAT, 1, 1).to(dev)            # dropout stays 0.4 for GINet (training mode)
@@ -226,7 +230,7 @@ def main():
         cache = None
         if cached:
             from deeprank_gnn_amd.resident import ResidentGraphSet
-            rs = ResidentGraphSet([synth.make_graph(rank * GRAPHS_PER_GPU + i) for i in range(GRAPHS_PER_GPU)], dev)
+            rs = ResidentGraphSet([synth.make_graph(rank * GRAPHS_PER_GPU + i, n_feat=N_FEAT) for i in range(GRAPHS_PER_GPU)], dev)
             cache = rs.topology_cache(need_weights=need_w)
             ids_host = list(range(GRAPHS_PER_GPU))
             ids_dev = rs.upload_ids(ids_host)
@@ -552,8 +556,8 @@ def main():
             "ms_per_step_median_block": block_med_ms / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s train step (topology + body fwd + FC head/MSE + bwd + grad all-reduce + Adam) on SYN graphs: "
-                                   "200 nodes, ~1000 directed edges, 32 node feats, 50->16 clusters "
-                                   "(BASELINE.json configs[1])" % args.net,
+                                   "200 nodes, ~1000 directed edges, %d node feats, 50->16 clusters "
+                                   "(BASELINE.json configs[1]%s)" % (args.net, N_FEAT, "" if N_FEAT == 32 else " but for the feature count"),
                        "graphs_per_gpu": GRAPHS_PER_GPU, "global_batch": GRAPHS_PER_GPU * world,
                        "parallelism": "dp%d" % world, "mode": args.mode, "step_layout": args.step_layout,
                        "topology": ("cached per graph (declared): built once at upload of the resident set, the step "
@@ -589,7 +593,7 @@ def main():
                 result["epoch_loop"] = measure_epoch_loop(Net, args.net, args.epoch_graphs, dev)
             except Exception as exc:                      # secondary figure: never lose the bench line over it
                 result["epoch_loop"] = {"error": repr(exc)[:200]}
-        if world == 1 and native and args.net == "GINet" and not args.no_other_nets:
+        if world == 1 and native and args.net == "GINet" and not args.no_other_nets and N_FEAT == 32:
             # BASELINE.json configs[2] / configs[3] in the same line (driver evidence for the single-branch nets)
             result["other_nets"] = {}
             for other in ("sGAT", "FoutNet"):
@@ -622,7 +626,7 @@ def measure_dp_distinct(trainer, dev, rank, world, need_w, all_reduce, update_pa
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd.topology import Topology
     first = 100000 + rank * n_batches * GRAPHS_PER_GPU
-    batches = [synth.make_batch(first + i * GRAPHS_PER_GPU, GRAPHS_PER_GPU).to(dev) for i in range(n_batches)]
+    batches = [synth.make_batch(first + i * GRAPHS_PER_GPU, GRAPHS_PER_GPU, n_feat=N_FEAT).to(dev) for i in range(n_batches)]
     topos = [Topology.from_batch(b, need_weights=need_w, build=(i == 0)) for i, b in enumerate(batches)]
     n = n_batches
 
@@ -681,7 +685,7 @@ def dp_selftest(trainer, net, Net, dev, rank, world, eager_step, run_steps, stat
     ref = None
     if rank == 0:
         ref = FusedTrainer(copy.deepcopy(net), lr=1e-3, task="reg", seed=1)
-        union = synth.make_batch(0, GRAPHS_PER_GPU * world).to(dev)
+        union = synth.make_batch(0, GRAPHS_PER_GPU * world, n_feat=N_FEAT).to(dev)
     out = {"ranks": world, "rccl_ranks": (world if info["backend"] == "nccl" else 0), "backend": info["backend"],
            "dp_exchange": info["dp_exchange"] if info["split_schedule"] else "single process: reduce + Adam in one launch",
            "oneshot_allreduce": info["oneshot"], "graphs_per_rank": GRAPHS_PER_GPU, "steps": []}
@@ -778,7 +782,8 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
         fn()
 
     fwd_b, bwd_b = ALG_BYTES[net_name]
-    alg = fwd_b + bwd_b
+    # (SURVEY 8(d) counts x [N, F] once in the forward and once per branch in the backward: N = 200, 4-byte words)
+    alg = fwd_b + bwd_b + (N_FEAT - 32) * 200 * 4 * (3 if net_name == "GINet" else 2)
     upd_bytes = (c["partials"].numel() + c["hp"].numel() + c["readout"].numel() + 7 * tr.flat_p.numel()) * 4 / B
     # which kernel the launch is: the plan the prepared step carries (the same decision procedure the launch runs)
     plan = c["plan"]
@@ -948,9 +953,9 @@ def measure_distinct_batches(Net, net_name, dev, n_batches=32, steps=32):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / (reps * steps)
-    one = synth.make_batch(0, GRAPHS_PER_GPU).to(dev)
+    one = synth.make_batch(0, GRAPHS_PER_GPU, n_feat=N_FEAT).to(dev)
     us_same = timed([one, one])
-    us_distinct = timed([synth.make_batch(GRAPHS_PER_GPU * (i + 1), GRAPHS_PER_GPU).to(dev) for i in range(n_batches)])
+    us_distinct = timed([synth.make_batch(GRAPHS_PER_GPU * (i + 1), GRAPHS_PER_GPU, n_feat=N_FEAT).to(dev) for i in range(n_batches)])
     return {"us_per_step_same_batch": us_same, "us_per_step": us_distinct, "graphs_per_s": GRAPHS_PER_GPU / (us_distinct * 1e-6),
             "distinct_batches": n_batches, "batch": GRAPHS_PER_GPU, "net": net_name,
             "what": "the pipelined step (topology of step t+1 built inside step t's launch) replayed from a hipGraph over a cycle "
@@ -967,7 +972,7 @@ def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=4):
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd.resident import ResidentGraphSet
     from deeprank_gnn_amd.trainer import FusedTrainer
-    graphs = [synth.make_graph(GRAPHS_PER_GPU + i) for i in range(n_graphs)]
+    graphs = [synth.make_graph(GRAPHS_PER_GPU + i, n_feat=N_FEAT) for i in range(n_graphs)]
     torch.manual_seed(0)
     tr = FusedTrainer(Net(N_FEAT, 1, 1).to(dev), lr=1e-3, task="reg")
     rs = ResidentGraphSet(graphs, dev)

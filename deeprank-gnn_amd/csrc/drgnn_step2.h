@@ -34,6 +34,8 @@
 //
 // Gradient slabs: one per (graph, half); the update kernel sums 2 B slabs (fixed order).  Half 0 writes the head slab,
 // the predictions and the readout.  GPU only: the host emulation keeps stepping these nets through drgnn_step.h.
+// Instantiated per padded feature width 16 / 32 / 48 / 64 (any feature count up to 64: padded tile rows, and with F % 4 != 0 a
+// padded copy of x in the tiles), SPLIT 1 / 2 for training, SPLIT 1 for inference launches (TRAIN = false).
 #ifndef DRGNN_STEP2_H
 #define DRGNN_STEP2_H
 

@@ -15,9 +15,12 @@
 // of the graph, filing row i at its hierarchical position.
 // Per branch workgroup: 12 barrier-separated phases (drgnn_step.h: 16), LDS at SYN size 77 KB (136 KB), staged index words
 // per graph 2 500 (6 300).  Same sums as the reference up to the association (G W instead of the per-edge products): parity
-// 1e-4 like every other kernel (tests/test_gpu_fused_fullsize.py).  GPU only: the host emulation steps GINet through
-// drgnn_step.h.  Launched by train_step_impl for TRAINING launches of the 32-wide specialised shape in the two-workgroup
-// layout on a topology built with DRGNN_TOPO_HIER; everything else keeps the drgnn_step.h / drgnn_step1.h kernels.
+// 1e-4 like every other kernel (tests/test_gpu_fused_fullsize.py, test_gpu_width_classes.py: the reference's goldens directly).
+// GPU only: the host emulation steps GINet through drgnn_step.h.  Instantiated per padded feature width 16 / 32 / 48 / 64
+// (any feature count up to 64: the tiles' rows are padded), for training and for inference launches (TRAIN = false: forward +
+// head), with one workgroup per (graph, branch) or both branches in one workgroup (net_step3_graph_both); launched by
+// train_step_impl whenever the workspace holds the hierarchical order and the tiles and the head is the reference's
+// (step_pick); everything else keeps the drgnn_step.h / drgnn_step1.h kernels.
 #ifndef DRGNN_STEP3_H
 #define DRGNN_STEP3_H
 

@@ -526,7 +526,7 @@ int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head,
  * dhid rows and readout, applies Adam with step index step2[1] and commits step2[0] = step2[1]
  * (also when apply_adam = 0: data parallel, all-reduce + drgnn_adam_step(step2) follow). */
 /* slabs_per_graph: conv slabs per graph in conv_partials -- 0 = n_branch (every layout but one); 2 for the split layout of a
- * single-branch net (drgnn_step_hints.split). */
+ * single-branch net (drgnn_step_plan.slabs_per_graph of the plan the launch was given). */
 int drgnn_step_update(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
                       drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
                       const float* readout, int32_t R, int32_t H, int32_t O, int64_t head_offset,

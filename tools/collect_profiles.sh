@@ -4,6 +4,7 @@
 # usage: tools/collect_profiles.sh <tag> [net]   -> gpurun_out/<tag>/{stats,fetch,write,sq1,sq2}/..., benchline.json
 #        then here: python tools/summarize_profile.py <name> gpurun_out/<tag> [net]   (writes profiles/<name>_*)
 set -e
+# (every rocprofv3 run under `timeout` with stdin closed: a profiler waiting on a terminal once cost a whole gpurun call)
 TAG=${1:-prof}
 NET=${2:-GINet}
 export TMPDIR=/tmp
@@ -11,13 +12,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python bench.py --net $NET --min-seconds 1 --no-cpu-baseline --epoch-graphs 0 > $OUT/stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/write.log 2>&1
+timeout 240 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run --output-format csv -- python bench.py --net $NET --min-seconds 1 --no-cpu-baseline --epoch-graphs 0 > $OUT/stats.log 2>&1 < /dev/null || true
+timeout 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/fetch.log 2>&1 < /dev/null || true
+timeout 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/write.log 2>&1 < /dev/null || true
 # SQ counters (own passes, kernel trace only): MFMA busy, wave-cycle breakdown, LDS conflicts
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/sq1 -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/sq1.log 2>&1 || true
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace -d $OUT/sq2 -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/sq2.log 2>&1 || true
-python bench.py --net $NET > $OUT/benchline.json 2> $OUT/bench.err
-python bench.py --net $NET --steps 20 --warmup 5 --no-cpu-baseline --epoch-graphs 0 > $OUT/benchline_driver_args.json 2>> $OUT/bench.err
+timeout 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $OUT/sq1 -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/sq1.log 2>&1 < /dev/null || true
+timeout 240 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVES --kernel-trace -d $OUT/sq2 -o run --output-format csv -- python bench.py --net $NET --steps 40 --warmup 20 --min-seconds 0 --no-cpu-baseline --epoch-graphs 0 > $OUT/sq2.log 2>&1 < /dev/null || true
+timeout 300 python bench.py --net $NET > $OUT/benchline.json 2> $OUT/bench.err
+timeout 200 python bench.py --net $NET --steps 20 --warmup 5 --no-cpu-baseline --epoch-graphs 0 > $OUT/benchline_driver_args.json 2>> $OUT/bench.err
 find $OUT -name "*.csv" | head -20
 tail -c 400 $OUT/benchline.json
