@@ -766,7 +766,11 @@ static StepPick step_pick(const StepAsk& q) {
             else if (two_ok(0)) { wgs = 2; k.builder_roles = 0; }
             else { k.rc = DRGNN_E_CAPACITY; return k; }
         } else if (q.commit_wgs == 0 && may_split) {
-            if (two_ok(co * k.builder_roles)) wgs = 2;
+            // (a launch without a builder counts one idle CU per graph all the same: with every CU holding a half graph the
+            // hand-offs cost more than the halved phases give and k_update sums twice the slabs -- cached topology at batch
+            // 128, us per step, split / whole: sGAT 20.7 / 19.2, FoutNet 20.5 / 19.5; profiles/r05_batch_sweep.txt)
+            if (co == 0) { if (two_ok(q.B)) wgs = 2; }
+            else if (two_ok(co * k.builder_roles)) wgs = 2;
             else if (k.builder_roles == 2 && two_ok(co)) { wgs = 2; k.builder_roles = 1; }
         }
         k.wgs = wgs;

@@ -17,6 +17,7 @@ typedef void (*drgnn_step_kernel_t)(StepCoLaunch);
 #define DRGNN_AF_GINET_ONE 2      // k_step3b_co_topo: both branches of a graph in one workgroup
 #define DRGNN_AF_SGAT 3           // k_step2_co_topo<DRGNN_SGAT>
 #define DRGNN_AF_FOUT 4           // k_step2_co_topo<DRGNN_FOUT>
+#define DRGNN_AF_SGAT_WHOLE 5     // k_step2_co_topo<DRGNN_SGAT, ., false, ., 1, true>: a unit of its own, see af_pick_single
 
 // (cls: 1 = capacity-class layout, honoured for training launches of the 32-wide kernels only -- the host asks for nothing else)
 template <int XF> drgnn_step_kernel_t af_pick_ginet_two(bool gather, int cls, bool train) {
@@ -31,6 +32,16 @@ template <int XF> drgnn_step_kernel_t af_pick_ginet_one(bool gather, int cls, bo
     if (cls && C1) return gather ? k_step3b_co_topo<XF, true, C1, true> : k_step3b_co_topo<XF, false, C1, true>;
     return gather ? k_step3b_co_topo<XF, true, 0, true> : k_step3b_co_topo<XF, false, 0, true>;
 }
+// sGAT's training launches with one workgroup per graph on a per-mini-batch workspace are the ones whose co-launched builder --
+// one workgroup per graph working BOTH chains off, with edge weights -- bounds the launch (batch 128 and beyond, topology
+// rebuilt).  The single-branch units are compiled at -Os (Makefile), which suits the step's phases and costs that builder chain
+// 1 us (profiles/r05_ab_opt_level.txt): these instances live in a unit of their own, compiled at -O3.
+template <int XF> drgnn_step_kernel_t af_pick_sgat_whole(int cls) {
+    constexpr int C1 = (XF == 32) ? 1 : 0;
+    if (cls && C1) return k_step2_co_topo<DRGNN_SGAT, XF, false, C1, 1, true>;
+    return k_step2_co_topo<DRGNN_SGAT, XF, false, 0, 1, true>;
+}
+template <int XF> drgnn_step_kernel_t af_sgat_whole(int cls);      // (defined per width below: af_sgat_whole_<W>)
 // split: workgroups per graph (2: training launches only)
 template <int KIND, int XF> drgnn_step_kernel_t af_pick_single(bool gather, int cls, int split, bool train) {
     constexpr int C1 = (XF == 32) ? 1 : 0;
@@ -39,15 +50,23 @@ template <int KIND, int XF> drgnn_step_kernel_t af_pick_single(bool gather, int 
         if (cls && C1) return gather ? k_step2_co_topo<KIND, XF, true, C1, 2, true> : k_step2_co_topo<KIND, XF, false, C1, 2, true>;
         return gather ? k_step2_co_topo<KIND, XF, true, 0, 2, true> : k_step2_co_topo<KIND, XF, false, 0, 2, true>;
     }
-    if (cls && C1) return gather ? k_step2_co_topo<KIND, XF, true, C1, 1, true> : k_step2_co_topo<KIND, XF, false, C1, 1, true>;
-    return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, true> : k_step2_co_topo<KIND, XF, false, 0, 1, true>;
+    if constexpr (KIND == DRGNN_SGAT) {
+        if (!gather) return af_sgat_whole<XF>(cls);
+        if (cls && C1) return k_step2_co_topo<KIND, XF, true, C1, 1, true>;
+        return k_step2_co_topo<KIND, XF, true, 0, 1, true>;
+    } else {
+        if (cls && C1) return gather ? k_step2_co_topo<KIND, XF, true, C1, 1, true> : k_step2_co_topo<KIND, XF, false, C1, 1, true>;
+        return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, true> : k_step2_co_topo<KIND, XF, false, 0, 1, true>;
+    }
 }
 
 #define DRGNN_AF_DECLARE(W)                                                                     \
     drgnn_step_kernel_t af_ginet_two_##W(bool gather, int cls, bool train);                    \
     drgnn_step_kernel_t af_ginet_one_##W(bool gather, int cls, bool train);                    \
     drgnn_step_kernel_t af_sgat_##W(bool gather, int cls, int split, bool train);              \
-    drgnn_step_kernel_t af_fout_##W(bool gather, int cls, int split, bool train);
+    drgnn_step_kernel_t af_fout_##W(bool gather, int cls, int split, bool train);              \
+    drgnn_step_kernel_t af_sgat_whole_##W(int cls);                                            \
+    template <> inline drgnn_step_kernel_t af_sgat_whole<W>(int cls) { return af_sgat_whole_##W(cls); }
 DRGNN_AF_DECLARE(16) DRGNN_AF_DECLARE(32) DRGNN_AF_DECLARE(48) DRGNN_AF_DECLARE(64)
 #undef DRGNN_AF_DECLARE
 
@@ -56,6 +75,9 @@ DRGNN_AF_DECLARE(16) DRGNN_AF_DECLARE(32) DRGNN_AF_DECLARE(48) DRGNN_AF_DECLARE(
 #define DRGNN_AF_DEFINE_GINET_ONE(W) DRGNN_AF_DEFINE_GINET_ONE_X(W)
 #define DRGNN_AF_DEFINE_SGAT(W) DRGNN_AF_DEFINE_SGAT_X(W)
 #define DRGNN_AF_DEFINE_FOUT(W) DRGNN_AF_DEFINE_FOUT_X(W)
+#define DRGNN_AF_DEFINE_SGAT_WHOLE(W) DRGNN_AF_DEFINE_SGAT_WHOLE_X(W)
+#define DRGNN_AF_DEFINE_SGAT_WHOLE_X(W) \
+    drgnn_step_kernel_t af_sgat_whole_##W(int cls) { return af_pick_sgat_whole<W>(cls); }
 #define DRGNN_AF_DEFINE_GINET_TWO_X(W) \
     drgnn_step_kernel_t af_ginet_two_##W(bool gather, int cls, bool train) { return af_pick_ginet_two<W>(gather, cls, train); }
 #define DRGNN_AF_DEFINE_GINET_ONE_X(W) \
@@ -76,6 +98,7 @@ DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_GINET_TWO)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_GINET_ONE)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_FOUT)
+DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT_WHOLE)
 #endif
 // family: DRGNN_AF_*; width: 16 / 32 / 48 / 64.  nullptr: no such instance
 static drgnn_step_kernel_t af_step_kernel(int family, int width, bool gather, int cls, int split, bool train) {

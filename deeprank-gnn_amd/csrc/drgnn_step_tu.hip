@@ -1,5 +1,5 @@
 // drgnn_step_tu.hip -- one translation unit of the fused step kernels' instantiations.
-//   -DDRGNN_AF_FAM=<1..4> -DDRGNN_AF_W=<16|32|48|64>: one (family, width) of the aggregation-first kernels (drgnn_step_af.h:
+//   -DDRGNN_AF_FAM=<1..5> -DDRGNN_AF_W=<16|32|48|64>: one (family, width) of the aggregation-first kernels (drgnn_step_af.h:
 //       the unit defines that family's kernel lookup, which instantiates the kernels);
 //   -DDRGNN_TU_KIND=0|1|2: the product-first kernels of one kind of net (drgnn_step.h; five feature widths x {per-mini-batch
 //       workspace, cached whole-set workspace}); 3 / 4: the one-workgroup product-first GINet step (drgnn_step1.h).
@@ -13,8 +13,10 @@ DRGNN_AF_DEFINE_GINET_ONE(DRGNN_AF_W)
 DRGNN_AF_DEFINE_SGAT(DRGNN_AF_W)
 #elif DRGNN_AF_FAM == DRGNN_AF_FOUT
 DRGNN_AF_DEFINE_FOUT(DRGNN_AF_W)
+#elif DRGNN_AF_FAM == DRGNN_AF_SGAT_WHOLE
+DRGNN_AF_DEFINE_SGAT_WHOLE(DRGNN_AF_W)
 #else
-#error "DRGNN_AF_FAM: 1 .. 4"
+#error "DRGNN_AF_FAM: 1 .. 5"
 #endif
 #else
 #ifndef DRGNN_TU_KIND

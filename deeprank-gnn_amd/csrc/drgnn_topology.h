@@ -910,7 +910,11 @@ DEV void topo_touch_done(const TopoTouch&) {}
 #else
 struct TopoTouch { drgnn_f4 v[4]; };
 DEV void topo_touch_load(TopoTouch& t, const float* p, int words) {
+#ifdef DRGNN_NO_TOUCH      // (A/B switch: tools/r05/build_af_variant.sh)
+    const int n4 = 0;
+#else
     const int n4 = p ? (words >> 2) : 0;
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int q = threadIdx.x + j * DRGNN_NTHREADS;
