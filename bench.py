@@ -762,6 +762,14 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
     def k_topo():
         topo.rebuild()
 
+    # the build the pipelined step launch actually carries (lean chains + aggregation tiles), as a launch of its own into a
+    # third workspace
+    lean_flags = tr._flags_for(nxt, batch.x.shape[1])
+    lean_t = Topology.from_batch(batch, need_weights=need_w, build=False) if lean_flags & _lib.TOPO_LEAN else None
+
+    def k_topo_lean():
+        lean_t.rebuild(lean_flags)
+
     def k_step_co():
         tr._fused_launch_step(c, nxt)
 
@@ -801,7 +809,10 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
             first,
             ("k_update (partials reduction + Adam)", k_update, upd_bytes),
             ("k_topo (own launch; not on the pipelined path)", k_topo, BYTES_TOPO[net_name]),
+            ("k_topo, lean chains + tiles: what the step launch co-builds (own launch here)", k_topo_lean, BYTES_TOPO[net_name]),
             (kname + " without the co-launched topology (not on the pipelined path)", k_step, alg)):
+        if fn is k_topo_lean and lean_t is None:
+            continue
         # 20 back-to-back launches per hipGraph replay: the device-side duration, not the host's launch rate
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
