@@ -667,10 +667,36 @@ __global__ void __launch_bounds__(256) k_ptrs(PtrArgs a) {
     ptr_item(a, i);
 }
 #endif  // DRGNN_KERNELS_MAIN
+// One batch of scalar loads over a range of the kernel-argument segment (as co_kernarg_touch below does for the co-launch's
+// arguments): one word of each of the N 64-byte lines from byte offset off0 (rounded down to a line) on, results discarded.  The co-launched BUILDER's workgroups read the topo part of StepCoLaunch (0x230 bytes behind 2 KB of step
+// arguments) in five or six dependent rounds of scalar loads -- first touches of a line each; when the argument block is not
+// cache-resident (every launch of an epoch loop, a long recorded graph: the block was written by the host or last read
+// milliseconds ago) each round is a trip to memory, on the chain that is the launch's tail (tools/r05/cached_prefetch_probe.py:
+// steps on the SAME graphs cost 16.8 us inside a long graph against 15.6 in a short one).
+template <int N>
+DEV void kernarg_touch_lines(int off0) {
+    static_assert(N >= 1 && N <= 12, "lines per call");
+    const char* base = (const char*)__builtin_amdgcn_kernarg_segment_ptr() + (off0 & ~63);
+    int t;
+    // ONE asm statement with its own wait: the compiler does not know that the destination is written late
+    // (lines past N - 1 touch line N - 1 again)
+#define DRGNN_KA_OFF(k) "i"(64 * ((k) < N ? (k) : N - 1))
+    asm volatile("s_load_dword %0, %1, %2\n s_load_dword %0, %1, %3\n s_load_dword %0, %1, %4\n s_load_dword %0, %1, %5\n"
+                 "s_load_dword %0, %1, %6\n s_load_dword %0, %1, %7\n s_load_dword %0, %1, %8\n s_load_dword %0, %1, %9\n"
+                 "s_load_dword %0, %1, %10\n s_load_dword %0, %1, %11\n s_load_dword %0, %1, %12\n s_load_dword %0, %1, %13\n"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t)
+                 : "s"(base), DRGNN_KA_OFF(0), DRGNN_KA_OFF(1), DRGNN_KA_OFF(2), DRGNN_KA_OFF(3), DRGNN_KA_OFF(4), DRGNN_KA_OFF(5),
+                   DRGNN_KA_OFF(6), DRGNN_KA_OFF(7), DRGNN_KA_OFF(8), DRGNN_KA_OFF(9), DRGNN_KA_OFF(10), DRGNN_KA_OFF(11)
+                 : "memory");
+#undef DRGNN_KA_OFF
+}
+#define DRGNN_KA_LINES(first_byte, end_byte) ((((end_byte) - 1) >> 6) - ((first_byte) >> 6) + 1)
 template <bool LDS>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_topo(TopoLaunch L) {
     extern __shared__ __attribute__((aligned(16))) int smem_i[];
     PHASE_BEGIN();
+    kernarg_touch_lines<DRGNN_KA_LINES(0, (int)sizeof(TopoLaunch))>(0);
     topo_block<LDS>(L, blockIdx.x, smem_i);
 }
 #ifdef DRGNN_KERNELS_MAIN
@@ -715,24 +741,49 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_net_co_topo(CoLaunch C) {
     if ((int)blockIdx.x < C.n_net) net_block<KIND, BWD, true>(C.net, blockIdx.x, smem_c);
     else topo_block<true>(C.topo, (int)blockIdx.x - C.n_net, (int*)smem_c);
 }
-// The step workgroups read ~0.7 KB of kernel arguments (descriptors, pointers, strides) in the order the prologue's code
+// The step workgroups read ~0.8 KB of kernel arguments (descriptors, pointers, strides) in the order the prologue's code
 // happens to need them: every first touch of a 64-byte line is a scalar-cache miss the next instructions wait for, one
-// after the other.  One batch of scalar loads (one word of every line, results discarded) makes it a single miss time.
-#define DRGNN_KA_LINE(off) "s_load_dword %0, %1, " #off "\n"
-DEV void step_kernarg_touch() {
-    static_assert(offsetof(StepLaunch, dims) + sizeof(int) >= 0x2c0, "the touched lines lie inside the step arguments");
-    int t;
-    asm volatile(DRGNN_KA_LINE(0x0) DRGNN_KA_LINE(0x40) DRGNN_KA_LINE(0x80) DRGNN_KA_LINE(0xc0) DRGNN_KA_LINE(0x100)
-                 DRGNN_KA_LINE(0x140) DRGNN_KA_LINE(0x180) DRGNN_KA_LINE(0x1c0) DRGNN_KA_LINE(0x200) DRGNN_KA_LINE(0x240)
-                 DRGNN_KA_LINE(0x280) "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(t) : "s"(__builtin_amdgcn_kernarg_segment_ptr()) : "memory");
-}
+// after the other.  One batch of scalar loads (one word of every line, results discarded) makes it a single miss time:
+// co_kernarg_touch below (round 2: the step's lines; round 5: + the builder's, before the role is known).
 // The step kernels read their arguments through the kernel-argument segment pointer, not through the by-value parameter:
 // with run-time indices into its arrays (dims) the compiler may keep a PRIVATE COPY of the whole 2.4 KB argument block in
 // scratch memory (2.5 KB of scratch per lane, a ~10x slower kernel).  Which instances are hit changes with unrelated edits
 // and with -O3 / -Os: in round 3 the generic-width sGAT kernels were (profiles/r03_kernarg_scratch.txt).
 DEV const StepCoLaunch& step_kernarg() {
     return *reinterpret_cast<const StepCoLaunch*>((const char*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+// Both parts of a co-launch's arguments in ONE batch, before the workgroup knows its role (n_net lies in the last line): the step's
+// lines [0, 0x340) (descriptors, pointers, strides, the head: everything but the per-graph dims) and the builder's.
+DEV void co_kernarg_touch() {
+    constexpr int first = (int)offsetof(StepCoLaunch, topo), end = (int)sizeof(StepCoLaunch);
+    constexpr int N0 = 13, N1 = DRGNN_KA_LINES(first, end);
+    static_assert(offsetof(StepLaunch, dims) + sizeof(int) >= 0x2c0 && sizeof(StepLaunch) >= 0x340, "the touched lines lie inside the step arguments");
+    static_assert(N1 >= 1 && N1 <= 13, "one asm statement covers 13 lines per part");
+    const char* b0 = (const char*)__builtin_amdgcn_kernarg_segment_ptr();
+    const char* b1 = b0 + (first & ~63);
+    int t;
+#define DRGNN_KA_OFF(k, N) "i"(64 * ((k) < N ? (k) : N - 1))
+#define DRGNN_KA_13(b) "s_load_dword %0, " b ", %3\n s_load_dword %0, " b ", %4\n s_load_dword %0, " b ", %5\n s_load_dword %0, " b ", %6\n" \
+                       "s_load_dword %0, " b ", %7\n s_load_dword %0, " b ", %8\n s_load_dword %0, " b ", %9\n s_load_dword %0, " b ", %10\n" \
+                       "s_load_dword %0, " b ", %11\n s_load_dword %0, " b ", %12\n s_load_dword %0, " b ", %13\n s_load_dword %0, " b ", %14\n" \
+                       "s_load_dword %0, " b ", %15\n"
+    // (offsets past a part's last line are clamped to that line: it is touched again)
+    asm volatile(DRGNN_KA_13("%1")
+                 "s_load_dword %0, %2, %16\n s_load_dword %0, %2, %17\n s_load_dword %0, %2, %18\n s_load_dword %0, %2, %19\n"
+                 "s_load_dword %0, %2, %20\n s_load_dword %0, %2, %21\n s_load_dword %0, %2, %22\n s_load_dword %0, %2, %23\n"
+                 "s_load_dword %0, %2, %24\n s_load_dword %0, %2, %25\n s_load_dword %0, %2, %26\n s_load_dword %0, %2, %27\n"
+                 "s_load_dword %0, %2, %28\n s_waitcnt lgkmcnt(0)"
+                 : "=&s"(t)
+                 : "s"(b0), "s"(b1),
+                   DRGNN_KA_OFF(0, N0), DRGNN_KA_OFF(1, N0), DRGNN_KA_OFF(2, N0), DRGNN_KA_OFF(3, N0), DRGNN_KA_OFF(4, N0), DRGNN_KA_OFF(5, N0),
+                   DRGNN_KA_OFF(6, N0), DRGNN_KA_OFF(7, N0), DRGNN_KA_OFF(8, N0), DRGNN_KA_OFF(9, N0), DRGNN_KA_OFF(10, N0), DRGNN_KA_OFF(11, N0),
+                   DRGNN_KA_OFF(12, N0),
+                   DRGNN_KA_OFF(0, N1), DRGNN_KA_OFF(1, N1), DRGNN_KA_OFF(2, N1), DRGNN_KA_OFF(3, N1), DRGNN_KA_OFF(4, N1), DRGNN_KA_OFF(5, N1),
+                   DRGNN_KA_OFF(6, N1), DRGNN_KA_OFF(7, N1), DRGNN_KA_OFF(8, N1), DRGNN_KA_OFF(9, N1), DRGNN_KA_OFF(10, N1), DRGNN_KA_OFF(11, N1),
+                   DRGNN_KA_OFF(12, N1)
+                 : "memory");
+#undef DRGNN_KA_13
+#undef DRGNN_KA_OFF
 }
 // Which workgroups of a co-launch are the step's and which the builder's (or, cached mode, the prefetcher's).
 // DRGNN_TOPO_FIRST (experiment switch): the builder's workgroups take the FIRST block ids -- they are dispatched first, and
@@ -753,8 +804,8 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step_co_topo(StepCoLaunch C_
     extern __shared__ __attribute__((aligned(16))) float smem_s[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
+    co_kernarg_touch();
     STEP_CO_ROLES(C);
-    if (co_is_step_) step_kernarg_touch();
     if (co_is_step_) step_block<KIND, XF, GATHER, CLS>(C.step, co_step_blk_, smem_s, 0);
     else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, co_topo_blk_, (int*)smem_s);      // (train_step_impl keeps weighted requests of the other kinds out of the launch)
 }
@@ -765,8 +816,8 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C
     extern __shared__ __attribute__((aligned(16))) float smem_s1[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
+    co_kernarg_touch();
     STEP_CO_ROLES(C);
-    if (co_is_step_) step_kernarg_touch();
     if (co_is_step_) step_block_both<XF, GATHER, PAIRED, CLS>(C.step, co_step_blk_, smem_s1);
     else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s1);
 }
@@ -776,8 +827,8 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step2_co_topo(StepCoLaunch C
     extern __shared__ __attribute__((aligned(16))) float smem_s2[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
+    co_kernarg_touch();
     STEP_CO_ROLES(C);
-    if (co_is_step_) step_kernarg_touch();
     if (co_is_step_) step2_block<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(C.step, co_step_blk_, smem_s2);
     else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, co_topo_blk_, (int*)smem_s2);
 }
@@ -787,8 +838,8 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3_co_topo(StepCoLaunch C
     extern __shared__ __attribute__((aligned(16))) float smem_s3[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
+    co_kernarg_touch();
     STEP_CO_ROLES(C);
-    if (co_is_step_) step_kernarg_touch();
     if (co_is_step_) step3_block<XF, GATHER, CLS, TRAIN>(C.step, co_step_blk_, smem_s3);
     else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s3);
 }
@@ -798,8 +849,8 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3b_co_topo(StepCoLaunch 
     extern __shared__ __attribute__((aligned(16))) float smem_s3b[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
+    co_kernarg_touch();
     STEP_CO_ROLES(C);
-    if (co_is_step_) step_kernarg_touch();
     if (co_is_step_) step3b_block<XF, GATHER, CLS, TRAIN>(C.step, co_step_blk_, smem_s3b);
     else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s3b);
 }
@@ -860,6 +911,7 @@ __global__ void __launch_bounds__(256) k_head_reduce(HeadReduceArgs a) {
 // behind the load of the step index, which used to sit in front of wave 0's slab loads -- and hands them over through LDS.
 #define DRGNN_UPDATE_THREADS 320
 __global__ void __launch_bounds__(DRGNN_UPDATE_THREADS) k_update(UpdateArgs u) {
+    kernarg_touch_lines<DRGNN_KA_LINES(0, (int)sizeof(UpdateArgs))>(0);
     __shared__ float quarter[4][64];
     __shared__ float bias_scalars[2];
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
