@@ -123,7 +123,7 @@ static int topo_prepare(TopoLaunch& L, int64_t* lds_out, const int64_t* edge_ind
     L.gscratch = scratch_i32;
     L.level1_only = 0;
     L.roles = 1;
-    L.pf_ids = nullptr; L.pf_n = 0;
+    L.pf_ids = nullptr; L.pf_n = 0; L.pf_graphs = 0;
     L.user_nptr = (node_ptr && edge_ptr) ? node_ptr : nullptr;
     L.user_eptr = (node_ptr && edge_ptr) ? edge_ptr : nullptr;
     int64_t lds = 0;
@@ -1062,7 +1062,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         C.step = L; C.n_net = blocks;
         int64_t both = k.lds;
         int extra = 0;
-        C.topo.pf_ids = nullptr; C.topo.pf_n = 0;
+        C.topo.pf_ids = nullptr; C.topo.pf_n = 0; C.topo.pf_graphs = 0;
         if (co_ok) { C.topo = T; both = k.lds > tlds ? k.lds : tlds; extra = T.args.n_graphs * T.roles; }
         else if (gather_ids && hints && hints->next_ids && hints->n_next > 0 && (blocks % 8) == 0 &&
                  blocks + hints->n_next <= device_cu_count() && getenv("DRGNN_NO_PREFETCH") == nullptr) {
@@ -1071,7 +1071,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             TopoLaunch& Q = C.topo;
             memset(&Q, 0, sizeof(Q));
             Q.tv = a.tv;
-            Q.pf_ids = hints->next_ids; Q.pf_n = (int)hints->n_next;
+            Q.pf_ids = hints->next_ids; Q.pf_n = (int)hints->n_next; Q.pf_graphs = a.ws_graphs;
             const int TF = (F + 3) & ~3;
             Q.pf_tiles = a.tiles; Q.pf_f = TF; Q.pf_tile_nodes = n_nodes;
             Q.pf_x = (kind == DRGNN_GINET) ? nullptr : (F & 3) ? a.tiles + n_nodes * (TF + 2) : x;

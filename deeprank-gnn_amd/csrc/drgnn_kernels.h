@@ -70,7 +70,7 @@ struct TopoLaunch {
     // Cached-topology launches build nothing: the extra workgroups of the launch (CUs the step leaves idle) instead PREFETCH
     // the graphs of the NEXT mini-batch into the L2 of the XCD that will step them (prefetch_block).  pf_ids: their numbers in
     // the cached set (DEVICE memory), null = a builder launch
-    const int32_t* pf_ids; int pf_n;
+    const int32_t* pf_ids; int pf_n; int pf_graphs;      // pf_graphs: graphs of the cached set (numbers outside it are skipped)
     const float* pf_tiles; const float* pf_x; int pf_f; int pf_coef;      // tiles / x rows of the set (x: nets that read it), F, D / C too
     long long pf_tile_nodes;
     const void* pf_y; int pf_y_bytes;
@@ -90,6 +90,7 @@ DEV void prefetch_block(const TopoLaunch& L, int g) {
     if (g >= L.pf_n) return;
     const int32_t* const* P = L.tv.p;
     const int id = __builtin_amdgcn_readfirstlane(L.pf_ids[g]);
+    if (id < 0 || id >= L.pf_graphs) return;      // (the list is the caller's; nothing is read on its word alone)
     const int n0 = P[DRGNN_TI_NPTR][id], n1 = P[DRGNN_TI_NPTR][id + 1];
     const int e0 = P[DRGNN_TI_EPTR][id], e1 = P[DRGNN_TI_EPTR][id + 1];
     const int N = n1 - n0, E = e1 - e0, rowbase = n0 + id, t = threadIdx.x;

@@ -502,7 +502,8 @@ typedef struct drgnn_step_hints {
     const drgnn_step_plan* plan;
     /* cached-topology launches (drgnn_net_train_step_cached) only, optional: the graph numbers of the NEXT mini-batch (DEVICE
      * memory, n_next of them).  While the launch leaves CUs idle, one extra workgroup per such graph requests everything its
-     * step will stage, so that the next launch finds it in the L2 of the XCD that steps it (no effect on any result). */
+     * step will stage, so that the next launch finds it in the L2 of the XCD that steps it (no effect on any result; numbers
+     * outside the cached set are skipped). */
     const int32_t* next_ids; int64_t n_next;
 } drgnn_step_hints;
 /* uint64 exchange words per graph the fused step needs for these bounds (GINet: n_branch x max(H, 32); the split layout
