@@ -29,6 +29,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# DRGNN_BENCH_WATCHDOG=<seconds> (diagnosis): dump every thread's stack to stderr after that long and exit, instead of hanging
+if os.environ.get("DRGNN_BENCH_WATCHDOG"):
+    import faulthandler
+    faulthandler.dump_traceback_later(float(os.environ["DRGNN_BENCH_WATCHDOG"]), exit=True)
+
 import torch
 import torch.nn.functional as F
 
@@ -176,12 +181,17 @@ def main():
             dist.init_process_group(args.backend)
     elif args.force_dp_path and args.backend == "nccl":
         # one-rank RCCL group: the DP schedule then issues a REAL (identity) all-reduce launch per step
-        import socket
-        with socket.socket() as sk:
-            sk.bind(("127.0.0.1", 0))
-            port = sk.getsockname()[1]
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
-                                device_id=dev)
+        if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") and os.environ.get("MASTER_PORT"):
+            # under torch.distributed.run the rendezvous store is the agent's: a private tcp:// address would be CONNECTED to,
+            # not served, and never answer
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                    device_id=dev)
 
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd import _lib
