@@ -791,10 +791,11 @@ static StepPick step_pick(const StepAsk& q) {
     // whose LDS layout is a compile-time constant (of the one-workgroup product-first GINet layouts the paired form; of the
     // aggregation-first kernels the training instances)
 #ifndef DRGNN_EMU
-    if (!q.ov.no_class && k.width == 32 && q.capN <= STEP_CLS_N && q.capE <= STEP_CLS_E && q.capC <= STEP_CLS_C &&
-        !(k.kernel == SK_STEP1 && !k.paired) && !(k.lean_ok && !q.train) &&
+    // (48-wide: the aggregation-first kernels only -- the feature count of the reference's shipped regression models)
+    if (!q.ov.no_class && (k.width == 32 || (k.width == 48 && k.lean_ok)) && q.capN <= STEP_CLS_N && q.capE <= STEP_CLS_E &&
+        q.capC <= STEP_CLS_C && !(k.kernel == SK_STEP1 && !k.paired) && !(k.lean_ok && !q.train) &&
         (k.lean_ok ? step_af_width(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
-                   : step_variant(q.kind, nullptr, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)) == 32) {
+                   : step_variant(q.kind, nullptr, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)) == k.width) {
         const int64_t lc = k.kernel == SK_AF3B ? 4 * step3b_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                          : k.kernel == SK_AF3 ? 4 * step3_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                          : k.kernel == SK_AF2 ? 4 * step2_scratch_words(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)

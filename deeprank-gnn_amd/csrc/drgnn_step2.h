@@ -579,7 +579,9 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
 
     // ---- prologue: one burst of independent loads ----------------------------------------------------------------------
     PHASE_MARK();
-    constexpr int BJ = (CLS == 1) ? 2 : 4;                 // float4 per lane of a row tile (capacity class: 200 x 32 floats)
+    // float4 per lane of a row tile (capacity class: STEP_CLS_N rows of XF floats over 1024 lanes -- 2 at 32, 3 at 48 features)
+    constexpr int BJ = (CLS == 1) ? (STEP_CLS_N * (XF / 4) + DRGNN_BCAP - 1) / DRGNN_BCAP : 4;
+    static_assert(BJ >= 1 && BJ <= 4, "a class row tile is one burst");
     // the graph's x rows and aggregation tiles (node order).  Rows of the tiles are TF = pad4(F) floats long (zero padded by the
     // builder); with F % 4 != 0 the x rows come from the tiles' padded copy instead of the (unaligned) input
     const int TF = (F + 3) & ~3;

@@ -1,6 +1,6 @@
 // drgnn_step_af.h -- which __global__ instance of the AGGREGATION-FIRST step families (drgnn_step2.h: sGAT / FoutNet;
 // drgnn_step3.h: GINet) a launch takes.  The families are instantiated per padded feature width 16 / 32 / 48 / 64,
-// {per-mini-batch, cached whole-set workspace}, {training, inference}; training launches of the 32-wide kernels also with the
+// {per-mini-batch, cached whole-set workspace}, {training, inference}; training launches of the 32- and 48-wide kernels also with the
 // capacity-class LDS layout (CLS = 1, drgnn_step.h), the single-branch nets with one or two workgroups per graph.
 //
 // One lookup function per (family, width).  In the library build (Makefile: DRGNN_SPLIT_TU) each is DEFINED in the translation
@@ -19,15 +19,16 @@ typedef void (*drgnn_step_kernel_t)(StepCoLaunch);
 #define DRGNN_AF_FOUT 4           // k_step2_co_topo<DRGNN_FOUT>
 #define DRGNN_AF_SGAT_WHOLE 5     // k_step2_co_topo<DRGNN_SGAT, ., false, ., 1, true>: a unit of its own, see af_pick_single
 
-// (cls: 1 = capacity-class layout, honoured for training launches of the 32-wide kernels only -- the host asks for nothing else)
+// (cls: 1 = capacity-class layout, honoured for training launches of the 32- and 48-wide kernels only -- the host asks for
+// nothing else; 48: the feature count of the reference's shipped regression models)
 template <int XF> drgnn_step_kernel_t af_pick_ginet_two(bool gather, int cls, bool train) {
-    constexpr int C1 = (XF == 32) ? 1 : 0;
+    constexpr int C1 = (XF == 32 || XF == 48) ? 1 : 0;
     if (!train) return gather ? k_step3_co_topo<XF, true, 0, false> : k_step3_co_topo<XF, false, 0, false>;
     if (cls && C1) return gather ? k_step3_co_topo<XF, true, C1, true> : k_step3_co_topo<XF, false, C1, true>;
     return gather ? k_step3_co_topo<XF, true, 0, true> : k_step3_co_topo<XF, false, 0, true>;
 }
 template <int XF> drgnn_step_kernel_t af_pick_ginet_one(bool gather, int cls, bool train) {
-    constexpr int C1 = (XF == 32) ? 1 : 0;
+    constexpr int C1 = (XF == 32 || XF == 48) ? 1 : 0;
     if (!train) return gather ? k_step3b_co_topo<XF, true, 0, false> : k_step3b_co_topo<XF, false, 0, false>;
     if (cls && C1) return gather ? k_step3b_co_topo<XF, true, C1, true> : k_step3b_co_topo<XF, false, C1, true>;
     return gather ? k_step3b_co_topo<XF, true, 0, true> : k_step3b_co_topo<XF, false, 0, true>;
@@ -36,6 +37,8 @@ template <int XF> drgnn_step_kernel_t af_pick_ginet_one(bool gather, int cls, bo
 // one workgroup per graph working BOTH chains off, with edge weights -- bounds the launch (batch 128 and beyond, topology
 // rebuilt).  The single-branch units are compiled at -Os (Makefile), which suits the step's phases and costs that builder chain
 // 1 us (profiles/r05_ab_opt_level.txt): these instances live in a unit of their own, compiled at -O3.
+// (48 features: the class instance of THIS launch is slower than the run-time layout -- 27.45 against 26.77 us per step at batch
+// 128, profiles/r05_cls48_ab.txt -- although it does not spill: the run-time layout with the class's capacities steps those)
 template <int XF> drgnn_step_kernel_t af_pick_sgat_whole(int cls) {
     constexpr int C1 = (XF == 32) ? 1 : 0;
     if (cls && C1) return k_step2_co_topo<DRGNN_SGAT, XF, false, C1, 1, true>;
@@ -44,7 +47,7 @@ template <int XF> drgnn_step_kernel_t af_pick_sgat_whole(int cls) {
 template <int XF> drgnn_step_kernel_t af_sgat_whole(int cls);      // (defined per width below: af_sgat_whole_<W>)
 // split: workgroups per graph (2: training launches only)
 template <int KIND, int XF> drgnn_step_kernel_t af_pick_single(bool gather, int cls, int split, bool train) {
-    constexpr int C1 = (XF == 32) ? 1 : 0;
+    constexpr int C1 = (XF == 32 || XF == 48) ? 1 : 0;
     if (!train) return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, false> : k_step2_co_topo<KIND, XF, false, 0, 1, false>;
     if (split == 2) {
         if (cls && C1) return gather ? k_step2_co_topo<KIND, XF, true, C1, 2, true> : k_step2_co_topo<KIND, XF, false, C1, 2, true>;

@@ -403,10 +403,13 @@ def test_benchmark_schedule_is_reproducible_and_graph_replays_equal_eager_launch
     assert np.isfinite(runs[0][0]).all() and np.isfinite(runs[0][3]).all()
 
 
-@pytest.mark.parametrize("net_name,cached,n_graphs", [(n, c, 64) for n in NETS for c in (False, True)] +
-                         [("GINet", False, 136), ("GINet", True, 136), ("sGAT", False, 136)])
-def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, cached, n_graphs):
-    """A batch inside the capacity class (200 nodes / 1024 edges / 52 clusters per graph, 32 features) is stepped by kernels
+@pytest.mark.parametrize("net_name,cached,n_graphs,n_feat", [(n, c, 64, 32) for n in NETS for c in (False, True)] +
+                         [("GINet", False, 136, 32), ("GINet", True, 136, 32), ("sGAT", False, 136, 32)] +
+                         [(n, c, 64, 48) for n in NETS for c in (False, True)] +
+                         [("GINet", False, 128, 48), ("GINet", True, 128, 44), ("sGAT", False, 128, 48), ("FoutNet", False, 128, 48)])
+def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, cached, n_graphs, n_feat):
+    """A batch inside the capacity class (200 nodes / 1024 edges / 52 clusters per graph, 32 features -- or up to 48, the feature
+    count of the reference's shipped regression models, for the aggregation-first kernels) is stepped by kernels
     whose LDS layout is a compile-time constant (drgnn_step.h: CLS); the layout moves arrays, not arithmetic: three training
     steps give the same bits with the class kernels (default) and without (plan override no_class), rebuilt and cached;
     136 graphs: GINet's one-workgroup (paired) layout and the other kinds beyond one round of workgroups."""
@@ -420,19 +423,19 @@ def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, c
     dev = _dev()
     api = _lib.get()
     Net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[net_name]
-    batch = synth.make_batch(0, n_graphs).to(dev)
-    rs = ResidentGraphSet([synth.make_graph(i) for i in range(n_graphs)], dev) if cached else None
+    batch = synth.make_batch(0, n_graphs, n_feat=n_feat).to(dev)
+    rs = ResidentGraphSet([synth.make_graph(i, n_feat=n_feat) for i in range(n_graphs)], dev) if cached else None
     cache = rs.topology_cache(need_weights=(net_name == "sGAT")) if cached else None
     out = []
     for no_class in (0, 1):
         torch.manual_seed(3)
-        tr = FusedTrainer(Net(32, 1, 1).to(dev), lr=1e-2, task="reg", seed=5)
+        tr = FusedTrainer(Net(n_feat, 1, 1).to(dev), lr=1e-2, task="reg", seed=5)
         tr.plan_overrides = {"no_class": no_class}
         if cached:
             assert tr._cached_prepare(cache, list(range(n_graphs)))["plan"].cls == 1 - no_class
         else:
             from deeprank_gnn_amd.topology import Topology
-            assert tr._plan_for(Topology.from_batch(batch, need_weights=(net_name == "sGAT")), 32).cls == 1 - no_class
+            assert tr._plan_for(Topology.from_batch(batch, need_weights=(net_name == "sGAT")), n_feat).cls == 1 - no_class
         for _ in range(3):
             if cached:
                 tr.train_step_cached(cache, list(range(n_graphs)))
