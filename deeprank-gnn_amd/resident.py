@@ -254,10 +254,24 @@ class ResidentGraphSet(object):
         if slot[1] is not None:
             slot[1].synchronize()                  # (four uploads ago: long done)
         slot[0][:n].copy_(host)
-        out = torch.empty(n, dtype=torch.int32, device=self.device)
-        out.copy_(slot[0][:n], non_blocking=True)
-        slot[1] = torch.cuda.Event()
-        slot[1].record()
+        # The copy runs on a stream of its own: enqueued on the caller's stream it would sit BEHIND the previous epoch and cost
+        # every epoch a 4 us blit on the critical path (profiles/r05_epoch_boundary.txt); here it is done long before the
+        # caller's stream gets to the event.  The tensor is allocated from the side stream's pool (a block just freed on the
+        # caller's stream may still be read by launches that have not run yet) and handed over with record_stream.
+        main = torch.cuda.current_stream(self.device)
+        side = ring.get("stream")
+        if side is None:
+            side = ring["stream"] = torch.cuda.Stream(self.device)
+        if torch.cuda.is_current_stream_capturing():
+            side = main
+        with torch.cuda.stream(side):
+            out = torch.empty(n, dtype=torch.int32, device=self.device)
+            out.copy_(slot[0][:n], non_blocking=True)
+            slot[1] = torch.cuda.Event()
+            slot[1].record()
+        if side is not main:
+            main.wait_event(slot[1])
+            out.record_stream(main)
         return out
 
     def batch_offsets(self, ids_dev, batch_size):
