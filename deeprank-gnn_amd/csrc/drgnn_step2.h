@@ -151,7 +151,19 @@ template <int J> DEV void burst_store_x4_rows(const BurstX<J>& b, const BurstRow
     }
 }
 
-template <int CLS>
+// SPIN: the run-time layout's offsets pinned in SCALAR registers.  sGAT's training kernels with the run-time layout sat at the
+// 128-VGPR limit of a 16-wave workgroup with 31 - 39 registers spilled to scratch memory; with the ~36 offsets in SGPRs (some of
+// which the compiler parks in lanes of a VGPR: no memory) they need 94 - 97 and spill nothing: batch 64, 32 features 21.05 ->
+// 19.70 us per step rebuilt, 20.65 -> 19.32 cached, 48 features 23.0 -> 21.07 (profiles/r05_sgat_spin_ab.txt).  NOT for the
+// one-workgroup launches that carry the one-role weighted builder (family 5 of drgnn_step_af.h): the scalar registers are what
+// that builder chain lives on, 24.0 -> 24.75 us at batch 128; and not for the one-workgroup launches on a cached workspace
+// either (31 - 35 spilled, yet 19.4 -> 19.9 us at batch 128 with the scalar pin): the two-workgroup launches only.
+#ifdef DRGNN_EMU
+#define STEP2_PIN(x) ((void)0)
+#else
+#define STEP2_PIN(x) do { if (SPIN) { asm volatile("" : "+s"(x)); } else { STEP_PIN(x); } } while (0)
+#endif
+template <int CLS, bool SPIN = false>
 DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, int capC, int H, int O) {
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
     const int xld = step_pad16(F) + 4;
@@ -159,7 +171,7 @@ DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, i
     int o = 0;
     // run-time capacities: every offset pinned in a register once (drgnn_step.h, step_carve); capacity class: immediates
 #define X(name, words, cond)                                                          \
-    { int off = o; if (CLS == 0) { STEP_PIN(off); } s.name = (decltype(s.name))(base + off);          \
+    { int off = o; if (CLS == 0) { STEP2_PIN(off); } s.name = (decltype(s.name))(base + off);         \
       o = off + ((cond) ? (int)(((long)(words) + 3) & ~3L) : 0); }
     STEP2_CARVE_LIST(X)
 #undef X
@@ -558,7 +570,8 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     typedef typename StepIdx<NARROW>::type EIdx;
     const int F = a.net.n_feat;
     const int O = hf.O;
-    Step2Scratch s = step2_carve<CLS>(scratch, KIND, XF, capN, capE, capC, WREF, O);
+    constexpr bool SPIN = KIND == DRGNN_SGAT && TRAIN && SPLIT == 2;      // (see step2_carve)
+    Step2Scratch s = step2_carve<CLS, SPIN>(scratch, KIND, XF, capN, capE, capC, WREF, O);
     EXIT_AFTER(0);
     WBlockRegs<1> wreg;
     int* const dummy = (int*)(s.misc + 64);
