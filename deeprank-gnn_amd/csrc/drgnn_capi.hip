@@ -796,7 +796,9 @@ static StepPick step_pick(const StepAsk& q) {
         q.capC <= STEP_CLS_C && !(k.kernel == SK_STEP1 && !k.paired) && !(k.lean_ok && !q.train) &&
         (k.lean_ok ? step_af_width(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                    : step_variant(q.kind, nullptr, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)) == k.width) {
-        const int64_t lc = k.kernel == SK_AF3B ? 4 * step3b_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
+        // (the 32-wide class instance of the one-workgroup kernel keeps Z1 / XP / dS per branch: STEP3B_DUAL)
+        const int64_t lc = k.kernel == SK_AF3B ? 4 * (step3b_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O) +
+                                                      (STEP3B_DUAL(k.width, 1, q.train) ? step3b_dual_extra_words(STEP_CLS_N, STEP_CLS_C) : 0))
                          : k.kernel == SK_AF3 ? 4 * step3_scratch_words(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                          : k.kernel == SK_AF2 ? 4 * step2_scratch_words(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                          : k.kernel == SK_STEP1 ? step1_lds_bytes_form(q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O, 1)

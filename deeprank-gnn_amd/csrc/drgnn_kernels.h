@@ -572,6 +572,9 @@ DEV void step3_block(const StepLaunch& L, int blk, float* lds) {
 // GINet, aggregation first, both branches of a graph in one workgroup (drgnn_step3.h, net_step3_graph_both)
 template <int XF, bool GATHER, int CLS, bool TRAIN>
 DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
+    // the capacity-class training instance of the 32-wide kernel works the two branches off side by side (drgnn_step3.h: DUAL;
+    // step_pick sizes the launch's LDS for it)
+    constexpr bool DUAL = STEP3B_DUAL(XF, CLS, TRAIN);
     if (g >= L.a.n_graphs) return;
     if (L.dims.count > 0) {
         const int gi = GATHER ? L.dims.gi[g] : g;
@@ -580,7 +583,7 @@ DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
         d.rowbase = d.n0 + gi;
         d.C = 0; d.E1 = 0; d.C1 = 0;
         const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
-        net_step3_graph_both<XF, GATHER, CLS, TRAIN>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
+        net_step3_graph_both<XF, GATHER, CLS, TRAIN, DUAL>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
         return;
     }
     const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;
@@ -595,7 +598,7 @@ DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
         FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
         return;
     }
-    net_step3_graph_both<XF, GATHER, CLS, TRAIN>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
+    net_step3_graph_both<XF, GATHER, CLS, TRAIN, DUAL>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
 }
 #endif
 

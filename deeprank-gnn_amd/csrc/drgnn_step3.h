@@ -488,7 +488,168 @@ HD int64_t step3b_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t c
     return w + 16;
 }
 
+// (extra words of the side-by-side form below: per-branch Z1, XP, dS)
+#define STEP3B_DUAL(XF, CLS, TRAIN) ((XF) == 32 && (CLS) == 1 && (TRAIN))
+HD int64_t step3b_dual_extra_words(int64_t capN, int64_t capC) {
+    return (((capN + 4) * DRGNN_H1 + 3) & ~(int64_t)3) + 2 * ((((capC + 4) * STEP_XPLD) + 3) & ~(int64_t)3);
+}
+
 #ifndef DRGNN_EMU
+// =========================================================================================================================
+// The one-workgroup step with the two branches SIDE BY SIDE: waves 0 - 7 work branch 0 off, waves 8 - 15 branch 1, through the
+// same barrier-separated phases (13 instead of 21 behind the prologue).  Every phase behind conv1's product is over <= 52 pooled
+// rows -- a dependent chain of LDS round trips that a few lanes of a few waves wait for --, so two of them at once cost what one
+// costs; conv1's product (13 row tiles per branch) takes two trips of 8 waves instead of one of 16, as before for both branches.
+// Z1, XP and dS, which the branch-after-branch form reuses, exist per branch here (+ 22 KB at the capacity class's shape: the
+// layout of the 32-wide class kernel, 153.4 KB).  Every sum is formed by the same lanes in the same order as in
+// net_step3_graph_both: bit-identical results (test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit steps the two
+// against each other).  The head and d readout stay as they are (fc1's second column block lives in registers).
+#define STEP3D_NT (DRGNN_NTHREADS / 2)
+#define STEP3D_NW (DRGNN_NWAVES / 2)
+template <bool RELU>
+DEV void step3d_gemm_nn(int vwave, int M, int NT, int K, const float* A, int lda, const float* Bt, int ldbt, float* C, int ldc,
+                        int* dummy) {
+    const int lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int units = ((M + 15) >> 4) * NT;
+    for (int u = vwave; u < units; u += STEP3D_NW) {
+        const int ti = (NT == 1) ? u : (u >> 1), tj = (NT == 1) ? 0 : (u & 1);
+        const float* ap = A + (ti * 16 + lr) * lda + 4 * lq;
+        const float* bp = Bt + (tj * 16 + lr) * ldbt + 4 * lq;
+        drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < K; k0 += 32) {
+            const drgnn_f4 a0 = *(const drgnn_f4*)(ap + k0), b0 = *(const drgnn_f4*)(bp + k0);
+            const bool two = k0 + 16 < K;
+            drgnn_f4 a1 = a0, b1 = b0;
+            if (two) { a1 = *(const drgnn_f4*)(ap + k0 + 16); b1 = *(const drgnn_f4*)(bp + k0 + 16); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[j], b0[j], acc, 0, 0, 0);
+            if (two) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[j], b1[j], acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = ti * 16 + lq * 4 + r;
+            float* p = (ci < M) ? C + ci * ldc + tj * 16 + lr : (float*)dummy + lane;
+            float v = acc[r];
+            if (RELU) v = (v < 0.0f) ? 0.0f : v;
+            *p = v;
+        }
+    }
+}
+DEV void step3d_cluster_max(int tid, int nc, const int* hmp, const int* cid, const float* z, float* xp, short* a0, int a0ld) {
+    _Pragma("nounroll") for (int item = tid; item < nc * DRGNN_H1; item += STEP3D_NT) {
+        const int q = item >> 4, c = item & 15;
+        const int plo = hmp[q], phi = hmp[q + 1];
+        const int j = cid[q];
+        float best = DRGNN_NEG_INF;
+        int arg = -1;
+        for (int p = plo; p < phi; p += 4) {
+            int mm[4];
+            float vv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) mm[t] = (p + t < phi) ? p + t : phi - 1;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) vv[t] = z[mm[t] * DRGNN_H1 + c];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (vv[t] > best) { best = vv[t]; arg = mm[t]; }
+        }
+        if (arg < 0) best = 0.0f;
+        xp[ROW24(j, STEP_XPLD) + c] = best;
+        a0[c * a0ld + j] = (short)((best > 0.0f) ? arg : -1);
+    }
+}
+// (step_gather_rows / step3_gather_dxp: one routine, the index arrays are the caller's)
+template <int LD>
+DEV void step3d_gather16(int tid, int n, const int* ptr, const int* idx, const float* src, float* dst) {
+    const int items = ((n * 16) + 63) & ~63;
+    for (int item = tid; item < items; item += STEP3D_NT) {
+        const int i = item >> 4, sl = (item >> 2) & 3, c = (item & 3) * 4;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        if (i < n) {
+            const int lo = ptr[i], hi = ptr[i + 1];
+            for (int k = lo + sl; k < hi; k += 4) {
+                const drgnn_f4 v = *(const drgnn_f4*)(src + ROW24(idx[k], LD) + c);
+                a0 += v[0]; a1 += v[1]; a2 += v[2]; a3 += v[3];
+            }
+        }
+        a0 += dpp_take<0x128>(a0); a1 += dpp_take<0x128>(a1); a2 += dpp_take<0x128>(a2); a3 += dpp_take<0x128>(a3);
+        a0 += dpp_take<0x124>(a0); a1 += dpp_take<0x124>(a1); a2 += dpp_take<0x124>(a2); a3 += dpp_take<0x124>(a3);
+        if (sl == 0 && i < n) *(drgnn_f4*)(dst + i * LD + c) = drgnn_f4{a0, a1, a2, a3};
+    }
+}
+// depth-1 max-pool + readout of ONE branch by 512 lanes (step_pool_readout's own shape: DRGNN_H2 x 16 lanes), column-major argmax
+template <int LDZ>
+DEV void step3d_pool_readout(int tid, int C1, const int* mp, const int* mem, const float* z, short* arg, const float* misc,
+                             float* xr, float* g_readout, int a1ld) {
+    int bad; memcpy(&bad, &misc[STEP_M_BAD], 4);
+    const float inv = 1.0f / (float)(C1 > 0 ? C1 : 1);
+    static_assert(DRGNN_H2 * 16 == STEP3D_NT, "one trip of a half workgroup");
+    const int c = tid >> 4, kk = tid & 15;
+    float acc = 0.0f;
+    for (int k = kk; k < C1; k += 16) {
+        float best = DRGNN_NEG_INF;
+        int am = -1;
+        const int plo = mp[k], phi = mp[k + 1];
+        for (int p = plo; p < phi; p += 4) {
+            int mm[4];
+            float vv[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mm[j] = mem[(p + j < phi) ? p + j : phi - 1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) vv[j] = z[ROW24(mm[j], LDZ) + c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (vv[j] > best) { best = vv[j]; am = mm[j]; }
+        }
+        if (am < 0) best = 0.0f;
+        arg[c * a1ld + k] = (short)((best > 0.0f) ? am : -1);
+        acc += best;
+    }
+    acc = lanes16_sum(acc) * inv;
+    if (bad) acc = DRGNN_NAN;
+    if (kk == 0) { xr[c] = acc; g_readout[c] = acc; }
+}
+// step3_dw1_sparse with the sixteen channels on eight waves (two channels per wave, one after the other)
+template <int XF>
+DEV void step3d_dw1_sparse(int vwave, int C, const short* a0, int a0ld, const float* dxp, const float* G, float* g_dw1, int F) {
+    constexpr int XLD = XF + 4, NSL = Dw1Shape<XF>::NSL;
+    const int fc = (threadIdx.x & 63) / NSL, sl = threadIdx.x & (NSL - 1);
+    const bool live = 4 * fc < XF;
+#pragma unroll 1
+    for (int h = vwave; h < DRGNN_H1; h += STEP3D_NW) {
+        drgnn_f4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = sl; j < C; j += 4 * NSL) {
+            int arg[4];
+            float d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = j + NSL * u;
+                arg[u] = (jj < C && live) ? (int)a0[h * a0ld + jj] : -1;
+                d[u] = (jj < C) ? dxp[jj * STEP_XPLD + h] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (arg[u] >= 0) {
+                    const drgnn_f4 g = *(const drgnn_f4*)(G + ROW24(arg[u], XLD) + 4 * fc);
+                    acc[0] = fmaf(d[u], g[0], acc[0]); acc[1] = fmaf(d[u], g[1], acc[1]);
+                    acc[2] = fmaf(d[u], g[2], acc[2]); acc[3] = fmaf(d[u], g[3], acc[3]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = step_slices_sum<NSL>(acc[i]);
+        if (sl == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (4 * fc + i < F) g_dw1[(4 * fc + i) * DRGNN_H1 + h] = acc[i];
+        }
+    }
+}
+
 template <int CLS>
 DEV Step3BScratch step3b_carve(float* base, int F, int capN, int capE, int capC, int H, int O) {
     const int xld = step_pad16(F) + 4;
@@ -528,7 +689,8 @@ DEV void step3b_head_fc1(const HeadFused& hf, int g, const float* wb, const WBlo
     }
 }
 
-template <int XF, bool GATHER, int CLS, bool TRAIN = true>
+// DUAL: the side-by-side form (see above); the caller has laid step3b_dual_extra_words more LDS out behind the arrays of the list
+template <int XF, bool GATHER, int CLS, bool TRAIN = true, bool DUAL = false>
 DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, int gi, float* scratch, int capN, int capE,
                               int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1) {
     static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
@@ -647,11 +809,40 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     }
     FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
 
+    // ---- the side-by-side form: the half workgroup's branch, its lane / wave numbers inside the half, its own Z1 / XP / dS ------
+    const int hbr = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9)) : 0;
+    const int htid = threadIdx.x & (STEP3D_NT - 1), hwave = my_wave & (STEP3D_NW - 1);
+    float* const dz1 = hbr ? s.end : s.z1;
+    float* const dxp = hbr ? s.end + (((capN + 4) * DRGNN_H1 + 3) & ~3) : s.xp;
+    float* const dp2 = hbr ? s.end + (((capN + 4) * DRGNN_H1 + 3) & ~3) + (((capC + 4) * STEP_XPLD + 3) & ~3) : s.p2;
+    float* const dw1t = hbr ? s.w1t[1] : s.w1t[0];
+    float* const dw2t = hbr ? s.w2t[1] : s.w2t[0];
+    float* const dw2n = hbr ? s.w2n[1] : s.w2n[0];
+    float* const du2 = hbr ? s.u2[1] : s.u2[0];
+    float* const dz2 = hbr ? s.z2[1] : s.z2[0];
+    short* const da0 = hbr ? s.a0[1] : s.a0[0];
+    short* const da1 = hbr ? s.a1[1] : s.a1[0];
+    if (DUAL) {
+        // (branch 1's XP rows past C: zero K padding of its pooled product, as the shared array's above)
+        if (hbr) { _Pragma("nounroll") for (int e = htid; e < (step_pad4(d.C) - d.C) * STEP_XPLD; e += STEP3D_NT) dxp[d.C * STEP_XPLD + e] = 0.0f; }
+        step3d_gemm_nn<true>(hwave, d.N, 1, XF, s.G, XLD, dw1t, XLD, dz1, DRGNN_H1, dummy);
+        BARRIER();
+        step3d_cluster_max(htid, d.C, s.hmp, s.mem1, dz1, dxp, da0, STEP3_A1LD(capC));
+        BARRIER();
+        step3d_gather16<STEP_XPLD>(htid, d.C, s.rp1, s.cx1, dxp, du2);
+        _Pragma("nounroll") for (int e = htid; e < (step_pad4(d.C) - d.C) * STEP_XPLD; e += STEP3D_NT) du2[d.C * STEP_XPLD + e] = 0.0f;
+        BARRIER();
+        step3d_gemm_nn<true>(hwave, d.C, 2, DRGNN_H1, du2, STEP_XPLD, dw2t, STEP_XPLD, dz2, Z2LD, dummy);
+        BARRIER();
+        step3d_pool_readout<Z2LD>(htid, d.C1, s.mp1, s.mem1, dz2, da1, s.misc, s.xr + hbr * DRGNN_H2,
+                                  const_cast<float*>(hf.readout) + (long)g * R + hbr * DRGNN_H2, STEP3_A1LD(capC));
+        BARRIER();
+    }
     // ---- forward, branch after branch (misc is read in the readout phases: four barriers away) -------------------------------
     // (the per-branch arrays are picked by selects on constant indices: a run-time index into the struct's pointer arrays
     // would put them in scratch memory)
 #pragma unroll 1
-    for (int br = 0; br < 2; ++br) {
+    for (int br = 0; br < (DUAL ? 0 : 2); ++br) {
         const bool b1 = br != 0;
         float* const w1t = b1 ? s.w1t[1] : s.w1t[0];
         float* const w2t = b1 ? s.w2t[1] : s.w2t[0];
@@ -700,6 +891,14 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     step3_dreadout_dw2<WREF>(s.wb, s.dhid, s.a1[1], STEP3_A1LD(capC), d.C1, s.u2[1], s.z2[1], p_w1n1 + w2off);
     BARRIER();
 
+    if (DUAL) {
+        step3d_gemm_nn<false>(hwave, d.C, 1, DRGNN_H2, dz2, Z2LD, dw2n, W2NLD, dp2, STEP_XPLD, dummy);
+        BARRIER();
+        step3d_gather16<STEP_XPLD>(htid, d.C, s.cp1, s.rx1, dp2, dxp);
+        BARRIER();
+        step3d_dw1_sparse<XF>(hwave, d.C, da0, STEP3_A1LD(capC), dxp, s.G, hbr ? p_w1n1 : p_w1n0, F);
+        return;
+    }
     // ---- backward body, branch after branch: dS = dZ2 W2^T, dXP through CSC1 (dense rows), dW1 through the depth-0 argmax ---
 #pragma unroll 1
     for (int br = 0; br < 2; ++br) {
@@ -714,5 +913,6 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
         step3_dw1_sparse<XF>(d.C, a0, STEP3_A1LD(capC), s.xp, s.G, b1 ? p_w1n1 : p_w1n0, F);      // (the next branch's first two phases leave xp, a0, G alone)
     }
 }
+
 #endif  // !DRGNN_EMU
 #endif
