@@ -25,6 +25,8 @@ batch = synth.make_batch(0, NB).to(dev)
 torch.manual_seed(0)
 net = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}[kind](32, 1, 1).to(dev)
 tr = FusedTrainer(net, lr=1e-3, task="reg", api=api)
+if os.environ.get("PROF_NOCLASS"):      # the run-time layout (GINet one workgroup per graph: branch after branch)
+    tr.plan_overrides = {"no_class": 1}
 need_w = kind == "sGAT"
 topo = Topology.from_batch(batch, api=api, need_weights=need_w)
 for rep in range(3):
