@@ -466,8 +466,8 @@ struct Step3BScratch {
     X(z1, (long)(capN + 4) * DRGNN_H1)                                                         \
     X(xp, (long)(capC + 4) * STEP_XPLD)                                                        \
     X(u2[0], (long)(capC + 4) * STEP_XPLD)                                                     \
-    X(u2[1], (long)(capC + 4) * STEP_XPLD)                                                     \
     X(z2[0], (long)(capC + 4) * STEP3_Z2LD)                                                    \
+    X(u2[1], (long)(capC + 4) * STEP_XPLD)      /* (u2[1], z2[1], p2 in a row: the side-by-side form's second Z1) */ \
     X(z2[1], (long)(capC + 4) * STEP3_Z2LD)                                                    \
     X(p2, (long)(capC + 4) * STEP_XPLD)                                                        \
     X(hw2, (long)O * H)                                                                        \
@@ -489,9 +489,10 @@ HD int64_t step3b_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t c
 }
 
 // (extra words of the side-by-side form below: per-branch Z1, XP, dS)
-#define STEP3B_DUAL(XF, CLS, TRAIN) ((XF) == 32 && (CLS) == 1 && (TRAIN))
+#define STEP3B_DUAL(XF, CLS, TRAIN) (((XF) == 32 || (XF) == 48) && (CLS) == 1 && (TRAIN))
 HD int64_t step3b_dual_extra_words(int64_t capN, int64_t capC) {
-    return (((capN + 4) * DRGNN_H1 + 3) & ~(int64_t)3) + 2 * ((((capC + 4) * STEP_XPLD) + 3) & ~(int64_t)3);
+    (void)capN;
+    return 2 * ((((capC + 4) * STEP_XPLD) + 3) & ~(int64_t)3);
 }
 
 #ifndef DRGNN_EMU
@@ -500,8 +501,9 @@ HD int64_t step3b_dual_extra_words(int64_t capN, int64_t capC) {
 // same barrier-separated phases (13 instead of 21 behind the prologue).  Every phase behind conv1's product is over <= 52 pooled
 // rows -- a dependent chain of LDS round trips that a few lanes of a few waves wait for --, so two of them at once cost what one
 // costs; conv1's product (13 row tiles per branch) takes two trips of 8 waves instead of one of 16, as before for both branches.
-// Z1, XP and dS, which the branch-after-branch form reuses, exist per branch here (+ 22 KB at the capacity class's shape: the
-// layout of the 32-wide class kernel, 153.4 KB).  Every sum is formed by the same lanes in the same order as in
+// Z1, XP and dS, which the branch-after-branch form reuses, exist per branch here: XP and dS behind the list's arrays (+ 9 KB at
+// the capacity class's shape: 140.4 KB for the 32-wide class kernel, 155.5 KB for the 48-wide one), branch 1's Z1 in the place of
+// its own [S2 | Z2] and of dS -- dead after the depth-0 cluster max, one barrier before S2 is first written.  Every sum is formed by the same lanes in the same order as in
 // net_step3_graph_both: bit-identical results (test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit steps the two
 // against each other).  The head and d readout stay as they are (fc1's second column block lives in registers).
 #define STEP3D_NT (DRGNN_NTHREADS / 2)
@@ -812,9 +814,11 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     // ---- the side-by-side form: the half workgroup's branch, its lane / wave numbers inside the half, its own Z1 / XP / dS ------
     const int hbr = DUAL ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 9)) : 0;
     const int htid = threadIdx.x & (STEP3D_NT - 1), hwave = my_wave & (STEP3D_NW - 1);
-    float* const dz1 = hbr ? s.end : s.z1;
-    float* const dxp = hbr ? s.end + (((capN + 4) * DRGNN_H1 + 3) & ~3) : s.xp;
-    float* const dp2 = hbr ? s.end + (((capN + 4) * DRGNN_H1 + 3) & ~3) + (((capC + 4) * STEP_XPLD + 3) & ~3) : s.p2;
+    static_assert(!DUAL || CLS == 1, "the side-by-side form is laid out for the capacity class");
+    static_assert((STEP_CLS_N + 4) * DRGNN_H1 <= (STEP_CLS_C + 4) * (2 * STEP_XPLD + STEP3_Z2LD), "branch 1's Z1 fits [S2 | Z2 | dS]");
+    float* const dz1 = hbr ? s.u2[1] : s.z1;
+    float* const dxp = hbr ? s.end : s.xp;
+    float* const dp2 = hbr ? s.end + (((capC + 4) * STEP_XPLD + 3) & ~3) : s.p2;
     float* const dw1t = hbr ? s.w1t[1] : s.w1t[0];
     float* const dw2t = hbr ? s.w2t[1] : s.w2t[0];
     float* const dw2n = hbr ? s.w2n[1] : s.w2n[0];

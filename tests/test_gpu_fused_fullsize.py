@@ -406,7 +406,8 @@ def test_benchmark_schedule_is_reproducible_and_graph_replays_equal_eager_launch
 @pytest.mark.parametrize("net_name,cached,n_graphs,n_feat", [(n, c, 64, 32) for n in NETS for c in (False, True)] +
                          [("GINet", False, 136, 32), ("GINet", True, 136, 32), ("sGAT", False, 136, 32)] +
                          [(n, c, 64, 48) for n in NETS for c in (False, True)] +
-                         [("GINet", False, 128, 48), ("GINet", True, 128, 44), ("sGAT", False, 128, 48), ("FoutNet", False, 128, 48)])
+                         [("GINet", False, 128, 48), ("GINet", True, 128, 44), ("sGAT", False, 128, 48), ("FoutNet", False, 128, 48),
+                          ("GINet", False, 136, 48), ("GINet", True, 136, 48)])
 def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, cached, n_graphs, n_feat):
     """A batch inside the capacity class (200 nodes / 1024 edges / 52 clusters per graph, 32 features -- or up to 48, the feature
     count of the reference's shipped regression models, for the aggregation-first kernels) is stepped by kernels
@@ -437,11 +438,11 @@ def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, c
             from deeprank_gnn_amd.topology import Topology
             plan = tr._plan_for(Topology.from_batch(batch, need_weights=(net_name == "sGAT")), n_feat)
             assert plan.cls == 1 - no_class
-            if net_name == "GINet" and n_graphs > 128 and n_feat == 32:
-                # beyond the resident batch size GINet steps both branches in ONE workgroup; its 32-wide class instance works them
-                # off side by side on the two halves of the workgroup (drgnn_step3.h: STEP3B_DUAL, per-branch Z1 / XP / dS: + 22 KB
-                # of LDS) -- compared here bit for bit with the branch-after-branch run-time layout
-                assert plan.wgs_per_graph == 1 and (plan.lds_bytes > 150000) == (no_class == 0), (plan.wgs_per_graph, plan.lds_bytes)
+            if net_name == "GINet" and n_graphs > 128:
+                # beyond the resident batch size GINet steps both branches in ONE workgroup; its 32- and 48-wide class instances
+                # work them off side by side on the two halves of the workgroup (drgnn_step3.h: STEP3B_DUAL, per-branch Z1 / XP /
+                # dS) -- compared here bit for bit with the branch-after-branch run-time layout
+                assert plan.wgs_per_graph == 1, (plan.wgs_per_graph, plan.lds_bytes)
         for _ in range(3):
             if cached:
                 tr.train_step_cached(cache, list(range(n_graphs)))
