@@ -1211,7 +1211,7 @@ static inline bool step_burst_guaranteed(int kind, const float* x, int F, int ca
 // trip less at the start of every workgroup (sizes -> arrays becomes a single wave of loads).
 // CLS: capacity class of the LDS layout.  0: laid out for the run-time capacities (capN, capE, capC = the maxima of the
 // batch, exact fit: that is what lets 200-node graphs into 160 KB at all).  1: the fixed layout STEP_CLS_N / _E / _C -- the
-// largest graph shape all three kinds fit at feature widths up to 32 -- with every array offset an immediate instead of
+// largest graph shape all three kinds fit at feature widths up to 32 (the aggregation-first kernels: up to 48) -- with every array offset an immediate instead of
 // ~40 pinned registers and run-time address arithmetic: 0.2 - 0.4 us per step.  The host takes it whenever the
 // batch's maxima lie inside the class (train_step_impl); LDS is one workgroup per CU either way.
 #define STEP_CLS_N 200

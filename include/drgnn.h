@@ -455,7 +455,8 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   slabs_per_graph  conv gradient slabs per graph in `partials` (what drgnn_step_update must be told)
  *   width    the padded feature width of the specialised kernel instance, 0 = the generic instance
  *   cls      1: the instance with the compile-time LDS layout of the capacity class (200 nodes, 1024 edges, 52 depth-0 clusters
- *            per graph; 32-wide kernels) -- the same arithmetic in the same order, bit-identical results
+ *            per graph; 32-wide kernels and the 48-wide aggregation-first training kernels) -- the same arithmetic in the same
+ *            order, bit-identical results
  *   lean_ok  1: the launch reads nothing a DRGNN_TOPO_LEAN build leaves out
  *   builder_wgs_per_graph  of the topology the same launch builds: 2 / 1; 0 = it gets a launch of its own
  *   lds_bytes  LDS one workgroup needs (<= 160 KiB whenever family != NONE); xchg_words: uint64 exchange words per graph
