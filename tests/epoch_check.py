@@ -39,6 +39,11 @@ def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=
             want_l.append(float(tr_b.train_step(b)))
             want_p.append(tr_b.last_pred.detach().cpu().clone())
         want_p = torch.cat(want_p)
+        # trainer.loss after an epoch: the LAST mini-batch's loss (copied in when read: no launch at the epoch boundary), in
+        # the one buffer the single-step launches write (recorded hipGraphs keep its address)
+        buf = tr_a.loss
+        assert buf.data_ptr() == tr_a._loss_buf.data_ptr() and tr_a._loss_pending is None
+        assert float(buf) == float(losses[-1])
         if exact:
             assert losses.cpu().tolist() == want_l
             assert torch.equal(pred.cpu(), want_p)

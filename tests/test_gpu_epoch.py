@@ -80,3 +80,37 @@ def test_native_epochs_match_oracle_training(net_name):
     sd = net.state_dict()
     for k, v in leaves.items():
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("cached", [False, True])
+def test_pipelined_epochs_equal_synchronised_epochs(cached):
+    """Thirty short epochs enqueued back to back WITHOUT a host synchronisation (the id upload of epoch e+1 runs on its own
+    stream under epoch e, its `losses` are not pre-filled, trainer.loss is filled on first read) against the same epochs with
+    a synchronisation after every one: losses, predictions and final parameters bit for bit."""
+    import copy
+    import numpy as np
+    import torch
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    graphs = [synth.make_graph(i, n_nodes=80, n_pairs=160) for i in range(96)]
+    torch.manual_seed(2)
+    net = GINet(32, 1, 1).to("cuda")
+    rs = ResidentGraphSet(graphs, "cuda")
+    ta = FusedTrainer(net, lr=1e-2, task="reg", seed=3)
+    tb = FusedTrainer(copy.deepcopy(net), lr=1e-2, task="reg", seed=3)
+    rng = np.random.default_rng(4)
+    orders = [rng.permutation(96).tolist() for _ in range(30)]
+    pending = [ta.train_epoch(rs, o, 16, cached=cached) for o in orders]          # six mini-batches each, nobody waits
+    want = []
+    for o in orders:
+        lo, pr = tb.train_epoch(rs, o, 16, cached=cached)
+        torch.cuda.synchronize()
+        want.append((lo.cpu().clone(), pr.cpu().clone(), float(tb.loss)))
+    torch.cuda.synchronize()
+    assert ta.faults() == 0 and tb.faults() == 0
+    for (la, pa), (lb, pb, last) in zip(pending, want):
+        assert torch.equal(la.cpu(), lb) and torch.equal(pa.cpu(), pb)
+        assert float(lb[-1]) == last
+    assert float(ta.loss) == float(want[-1][0][-1])
+    assert torch.equal(ta.flat_p.cpu(), tb.flat_p.cpu()) and torch.equal(ta.exp_avg_sq.cpu(), tb.exp_avg_sq.cpu())
