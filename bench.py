@@ -603,6 +603,10 @@ def main():
                 result["epoch_loop"] = measure_epoch_loop(Net, args.net, args.epoch_graphs, dev)
             except Exception as exc:                      # secondary figure: never lose the bench line over it
                 result["epoch_loop"] = {"error": repr(exc)[:200]}
+            try:
+                result["inference_loop"] = measure_inference_loop(Net, args.net, args.epoch_graphs, dev)
+            except Exception as exc:                      # secondary figure: never lose the bench line over it
+                result["inference_loop"] = {"error": repr(exc)[:200]}
         if world == 1 and native and args.net == "GINet" and not args.no_other_nets and N_FEAT == 32:
             # BASELINE.json configs[2] / configs[3] in the same line (driver evidence for the single-branch nets)
             result["other_nets"] = {}
@@ -1040,6 +1044,45 @@ def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=4):
             out[key] = c
         except Exception as exc:
             out[key] = {"error": repr(exc)[:200]}
+    return out
+
+
+def measure_inference_loop(Net, net_name, n_graphs, dev, passes=4):
+    """Secondary figure (not `value`, not the metric: forward + head only): predictions for every graph of a resident set
+    through the native loop (FusedTrainer.predict_epoch -- what NeuralNet.test() runs; eval mode, one launch per mini-batch, the
+    host never waits inside a pass), mini-batches of 64 and of 1024 graphs, topology rebuilt per mini-batch and cached."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    graphs = [synth.make_graph(GRAPHS_PER_GPU + i, n_feat=N_FEAT) for i in range(n_graphs)]
+    torch.manual_seed(0)
+    tr = FusedTrainer(Net(N_FEAT, 1, 1).to(dev), lr=1e-3, task="reg")
+    rs = ResidentGraphSet(graphs, dev)
+    order = torch.arange(n_graphs)
+    out = {"resident_graphs": n_graphs, "net": net_name, "passes": passes,
+           "what": "FusedTrainer.predict_epoch over the whole resident set (forward + head, eval mode), `passes` passes enqueued back "
+                   "to back; best of three repetitions"}
+    for bs in (GRAPHS_PER_GPU, 1024):
+        for cached in (False, True):
+            key = "batch%d_%s" % (bs, "cached" if cached else "rebuilt")
+            try:
+                pred = tr.predict_epoch(rs, order, bs, cached=cached)
+                if pred is None:
+                    raise RuntimeError("the native loop refused this configuration")
+                check = float(pred.sum())
+                runs = []
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    pending = [tr.predict_epoch(rs, order, bs, cached=cached) for _ in range(passes)]
+                    torch.cuda.synchronize()
+                    runs.append(time.perf_counter() - t0)
+                    del pending
+                best = min(runs)
+                nb = (n_graphs + bs - 1) // bs
+                out[key] = {"graphs_per_s": n_graphs * passes / best, "us_per_batch": best / (passes * nb) * 1e6, "pred_sum": check}
+            except Exception as exc:
+                out[key] = {"error": repr(exc)[:200]}
     return out
 
 

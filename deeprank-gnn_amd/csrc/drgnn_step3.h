@@ -489,7 +489,7 @@ HD int64_t step3b_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t c
 }
 
 // (extra words of the side-by-side form below: per-branch Z1, XP, dS)
-#define STEP3B_DUAL(XF, CLS, TRAIN) (((XF) == 32 || (XF) == 48) && (CLS) == 1 && (TRAIN))
+#define STEP3B_DUAL(XF, CLS, TRAIN) (((XF) == 32 || (XF) == 48) && (CLS) == 1)      // (training and inference instances)
 HD int64_t step3b_dual_extra_words(int64_t capN, int64_t capC) {
     (void)capN;
     return 2 * ((((capC + 4) * STEP_XPLD) + 3) & ~(int64_t)3);

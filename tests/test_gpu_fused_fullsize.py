@@ -448,10 +448,13 @@ def test_capacity_class_kernels_equal_the_runtime_layout_bit_for_bit(net_name, c
                 tr.train_step_cached(cache, list(range(n_graphs)))
             else:
                 tr.train_step(batch)
+        last_pred = tr.last_pred.detach().clone()
+        # the inference launch of the same graphs (GINet: class instances too, one workgroup per graph side by side)
+        inf = tr.predict_cached(cache, list(range(n_graphs))) if cached else tr.predict(batch)
         torch.cuda.synchronize()
         assert tr.faults() == 0
-        out.append([t.detach().cpu().numpy().copy() for t in (tr.flat_p, tr.exp_avg_sq, tr.loss, tr.last_pred)])
-    for a, b, name in zip(out[0], out[1], ("parameters", "exp_avg_sq", "loss", "predictions")):
+        out.append([t.detach().cpu().numpy().copy() for t in (tr.flat_p, tr.exp_avg_sq, tr.loss, last_pred, inf)])
+    for a, b, name in zip(out[0], out[1], ("parameters", "exp_avg_sq", "loss", "predictions", "inference predictions")):
         np.testing.assert_array_equal(a, b, err_msg=name)
     assert np.isfinite(out[0][0]).all()
 
