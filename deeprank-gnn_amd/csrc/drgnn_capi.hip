@@ -789,11 +789,11 @@ static StepPick step_pick(const StepAsk& q) {
     k.family = k.lean_ok ? DRGNN_STEP_FAMILY_AGGREGATE : DRGNN_STEP_FAMILY_PRODUCT;
     // Capacity class (drgnn_step.h: STEP_CLS_*): a batch whose maxima lie inside the class is stepped by the 32-wide kernels
     // whose LDS layout is a compile-time constant (of the one-workgroup product-first GINet layouts the paired form; of the
-    // aggregation-first kernels GINet's training and inference instances and the single-branch nets' training instances)
+    // aggregation-first kernels the training and the inference instances)
 #ifndef DRGNN_EMU
     // (48-wide: the aggregation-first kernels only -- the feature count of the reference's shipped regression models)
     if (!q.ov.no_class && (k.width == 32 || (k.width == 48 && k.lean_ok)) && q.capN <= STEP_CLS_N && q.capE <= STEP_CLS_E &&
-        q.capC <= STEP_CLS_C && !(k.kernel == SK_STEP1 && !k.paired) && !(k.kernel == SK_AF2 && !q.train) &&
+        q.capC <= STEP_CLS_C && !(k.kernel == SK_STEP1 && !k.paired) &&
         (k.lean_ok ? step_af_width(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                    : step_variant(q.kind, nullptr, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)) == k.width) {
         // (the 32-wide class instance of the one-workgroup kernel keeps Z1 / XP / dS per branch: STEP3B_DUAL)

@@ -19,9 +19,8 @@ typedef void (*drgnn_step_kernel_t)(StepCoLaunch);
 #define DRGNN_AF_FOUT 4           // k_step2_co_topo<DRGNN_FOUT>
 #define DRGNN_AF_SGAT_WHOLE 5     // k_step2_co_topo<DRGNN_SGAT, ., false, ., 1, true>: a unit of its own, see af_pick_single
 
-// (cls: 1 = capacity-class layout, honoured for the 32- and 48-wide kernels only -- GINet's training and inference launches,
-// the single-branch nets' training launches: the host asks for nothing else; 48: the feature count of the reference's shipped
-// regression models)
+// (cls: 1 = capacity-class layout, honoured for the 32- and 48-wide kernels only, training and inference launches -- the host
+// asks for nothing else; 48: the feature count of the reference's shipped regression models)
 template <int XF> drgnn_step_kernel_t af_pick_ginet_two(bool gather, int cls, bool train) {
     constexpr int C1 = (XF == 32 || XF == 48) ? 1 : 0;
     if (!train && cls && C1) return gather ? k_step3_co_topo<XF, true, C1, false> : k_step3_co_topo<XF, false, C1, false>;
@@ -51,6 +50,7 @@ template <int XF> drgnn_step_kernel_t af_sgat_whole(int cls);      // (defined p
 // split: workgroups per graph (2: training launches only)
 template <int KIND, int XF> drgnn_step_kernel_t af_pick_single(bool gather, int cls, int split, bool train) {
     constexpr int C1 = (XF == 32 || XF == 48) ? 1 : 0;
+    if (!train && cls && C1) return gather ? k_step2_co_topo<KIND, XF, true, C1, 1, false> : k_step2_co_topo<KIND, XF, false, C1, 1, false>;
     if (!train) return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, false> : k_step2_co_topo<KIND, XF, false, 0, 1, false>;
     if (split == 2) {
         if (cls && C1) return gather ? k_step2_co_topo<KIND, XF, true, C1, 2, true> : k_step2_co_topo<KIND, XF, false, C1, 2, true>;
