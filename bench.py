@@ -860,13 +860,23 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
     # are read from the summary under profiles/ that was collected from THIS build (matched by source hash and net),
     # and reported as null otherwise
     traffic, traffic_note, mfma, mfma_note = None, None, None, None
+
+    def own_step_kernel(name):
+        """is `name` (a kernel of a counter summary) the fused step kernel of THIS net?  (the default GINet run also launches
+        sGAT's and FoutNet's for `other_nets`: their rows sit in the same summary)"""
+        if "_co_topo" not in name or "k_step" not in name:
+            return False
+        kind = {"GINet": 0, "sGAT": 1, "FoutNet": 2}[net_name]
+        if "k_step3" in name or "k_step1_co_topo" in name:
+            return kind == 0
+        return ("co_topo<%d," % kind) in name
     if "_co_topo" in dom:
         pmc, where = counter_summary("pmc", net_name)
         if pmc is None:
             traffic_note = where
         else:
             for k, v in pmc.items():
-                if "k_step" in k and "_co_topo" in k:
+                if own_step_kernel(k):
                     traffic = v["hbm_bytes_per_launch"]
                     traffic_note = ("bytes/launch from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, "
                                     "profiles/%s, same sources as this build); FETCH doubled per "
@@ -876,7 +886,7 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
             mfma_note = where
         else:
             for k, v in sq.items():
-                if "k_step" in k and "_co_topo" in k:
+                if own_step_kernel(k):
                     # busy cycles summed over SIMDs / (1024 SIMDs x kernel cycles at the 2.28 GHz shader clock)
                     mfma = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (step_us * 1e3 * 2.28 * 1024.0)
                     mfma_note = "SQ_VALU_MFMA_BUSY_CYCLES from profiles/%s (same sources as this build)" % where
