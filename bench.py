@@ -132,6 +132,9 @@ def parse():
                     help="also time the same (data-parallel) schedule over a cycle of 32 DIFFERENT synthetic mini-batches per rank "
                          "(`dp_distinct` in the line): the figure without the L2 residency of a replayed mini-batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in loop figures (dropin_loop)")
+    ap.add_argument("--dropin-only", action="store_true",
+                    help="run ONLY the drop-in loop of --net at --graphs-per-gpu (profiling runs) and print its figures")
     ap.add_argument("--no-other-nets", action="store_true",
                     help="skip the secondary sGAT / FoutNet figures of the default GINet line (`other_nets`)")
     ap.add_argument("--epoch-graphs", type=int, default=4096,
@@ -209,6 +212,9 @@ def main():
     if args.step_layout != "auto":
         os.environ["DRGNN_STEP_PLAN"] = {"noclass": "noclass", "old": "product", "af1": "nosplit", "one": "one",
                                          "seq": "one,seq", "two": "two"}[args.step_layout]
+    if args.dropin_only:
+        print(json.dumps({"dropin_loop": measure_dropin_loop(dev, [(args.net, GRAPHS_PER_GPU)])}), flush=True)
+        return
     batch_cpu = synth.make_batch(rank * GRAPHS_PER_GPU, GRAPHS_PER_GPU, n_feat=N_FEAT)
     batch = batch_cpu.clone().to(dev)
     torch.manual_seed(0)
@@ -603,6 +609,9 @@ def main():
                 result["epoch_loop"] = measure_epoch_loop(Net, args.net, args.epoch_graphs, dev)
             except Exception as exc:                      # secondary figure: never lose the bench line over it
                 result["epoch_loop"] = {"error": repr(exc)[:200]}
+            if not args.no_dropin:
+                result["dropin_loop"] = measure_dropin_loop(dev, None if (args.net == "GINet" and GRAPHS_PER_GPU == 64)
+                                                            else [(args.net, GRAPHS_PER_GPU)])
             try:
                 result["inference_loop"] = measure_inference_loop(Net, args.net, args.epoch_graphs, dev)
             except Exception as exc:                      # secondary figure: never lose the bench line over it
@@ -949,7 +958,7 @@ def measure_other_net(net_name, batch, dev, steps=20):
             "whole_step_frac": rf["whole_step_frac"], "final_loss": float(tr.loss.item())}
 
 
-def measure_distinct_batches(Net, net_name, dev, n_batches=32, steps=32):
+def measure_distinct_batches(Net, net_name, dev, n_batches=32, steps=32, graphs=None, batches=None):
     """Secondary figure (not `value`): the same pipelined step replayed from a hipGraph, but every step on a DIFFERENT
     host-collated synthetic mini-batch (a cycle of `n_batches`, every one with a topology workspace of its own built by the
     previous step's launch).  `value` replays ONE mini-batch, whose graphs stay in the L2 of the XCD that worked on them a step
@@ -988,13 +997,126 @@ def measure_distinct_batches(Net, net_name, dev, n_batches=32, steps=32):
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / (reps * steps)
-    one = synth.make_batch(0, GRAPHS_PER_GPU, n_feat=N_FEAT).to(dev)
+    graphs = GRAPHS_PER_GPU if graphs is None else graphs
+    if batches is not None:          # (the caller's cycle: only the distinct figure)
+        us_distinct = timed(batches)
+        return {"us_per_step": us_distinct, "graphs_per_s": graphs / (us_distinct * 1e-6), "distinct_batches": len(batches),
+                "batch": graphs, "net": net_name}
+    one = synth.make_batch(0, graphs, n_feat=N_FEAT).to(dev)
     us_same = timed([one, one])
-    us_distinct = timed([synth.make_batch(GRAPHS_PER_GPU * (i + 1), GRAPHS_PER_GPU, n_feat=N_FEAT).to(dev) for i in range(n_batches)])
-    return {"us_per_step_same_batch": us_same, "us_per_step": us_distinct, "graphs_per_s": GRAPHS_PER_GPU / (us_distinct * 1e-6),
-            "distinct_batches": n_batches, "batch": GRAPHS_PER_GPU, "net": net_name,
+    us_distinct = timed([synth.make_batch(graphs * (i + 1), graphs, n_feat=N_FEAT).to(dev) for i in range(n_batches)])
+    return {"us_per_step_same_batch": us_same, "us_per_step": us_distinct, "graphs_per_s": graphs / (us_distinct * 1e-6),
+            "distinct_batches": n_batches, "batch": graphs, "net": net_name,
             "what": "the pipelined step (topology of step t+1 built inside step t's launch) replayed from a hipGraph over a cycle "
                     "of %d different synthetic mini-batches, against the same replay of one mini-batch" % n_batches}
+
+
+def measure_dropin_loop(dev, configs=None, n_batches=32):
+    """Secondary figure (not `value`): the loop body an UNCHANGED reference trainer runs (reference NeuralNet.py:489-506)
+
+        optimizer.zero_grad(); pred = model(batch); loss = MSELoss(pred.reshape(-1), y); loss.backward(); optimizer.step()
+
+    with `model` this package's net, `optimizer` torch.optim.Adam over model.parameters() as NeuralNet constructs it
+    (NeuralNet.py:183-184) and a cycle of `n_batches` different synthetic mini-batches -- the literal drop-in boundary
+    (deeprank-gnn_amd/fused_autograd.py: model(batch) and loss.backward() are one launch each of the aggregation-first step
+    kernels).  us per step, eager (host-bound) and recorded in a hipGraph (one graph over the cycle; Adam capturable=True, torch's
+    default foreach implementation and fused=True), with the batch's topology workspace kept with the batch object (`kept`: what
+    a DataLoader over pre-collated batches gives) and rebuilt by a builder launch in every call (`rebuilt`: fresh Batch objects
+    every epoch, as the reference's DataLoader collates them); next to the native trainer's step over the same cycle."""
+    import time as _time
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.fused_autograd import engine_for
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.sGAT import sGAT
+    from deeprank_gnn_amd.foutnet import FoutNet
+    nets = {"GINet": GINet, "sGAT": sGAT, "FoutNet": FoutNet}
+    if configs is None:
+        configs = [("GINet", 64), ("sGAT", 64), ("FoutNet", 64), ("GINet", 128)]
+    out = {"what": "optimizer.zero_grad(); pred = model(batch); loss = mse(pred, y); loss.backward(); torch.optim.Adam.step() over a "
+                   "cycle of %d distinct SYN mini-batches; us per step" % n_batches}
+    for net_name, B in configs:
+        key = net_name if B == 64 else "%s_b%d" % (net_name, B)
+        try:
+            batches = [synth.make_batch(B * (i + 1), B, n_feat=N_FEAT).to(dev) for i in range(n_batches)]
+            res = {"batch": B, "distinct_batches": n_batches}
+
+            def fresh(**adam):
+                torch.manual_seed(0)
+                net = nets[net_name](N_FEAT, 1, 1).to(dev)
+                net.train()
+                return net, torch.optim.Adam(net.parameters(), lr=1e-3, **adam)
+
+            def body(net, opt, b):
+                opt.zero_grad()
+                pred = net(b)
+                loss = F.mse_loss(pred.reshape(-1), b.y)
+                loss.backward()
+                opt.step()
+                return loss
+
+            # -- eager ---------------------------------------------------------------------------------------------------
+            for label, keep in (("eager_kept_us", True), ("eager_rebuilt_us", False)):
+                net, opt = fresh()
+                eng = engine_for(net)
+                eng.cache_topology = keep
+                for b in batches:
+                    body(net, opt, b)
+                assert eng.last_path == "jacobian", eng.last_path
+                torch.cuda.synchronize()
+                t0 = _time.perf_counter()
+                n = 0
+                while _time.perf_counter() - t0 < 0.6:
+                    for b in batches:
+                        loss = body(net, opt, b)
+                    n += len(batches)
+                    torch.cuda.synchronize()
+                res[label] = (_time.perf_counter() - t0) / n * 1e6
+                res["final_loss_" + label[:-3]] = float(loss.item())
+            res["plan"] = {"family": int(eng.last_plan.family), "wgs_per_graph": int(eng.last_plan.wgs_per_graph),
+                           "width": int(eng.last_plan.width), "cls": int(eng.last_plan.cls)}
+            # -- recorded ------------------------------------------------------------------------------------------------
+            for label, keep, adam in (("graph_kept_us", True, {}), ("graph_rebuilt_us", False, {}),
+                                      ("graph_kept_fused_adam_us", True, {"fused": True}),
+                                      ("graph_rebuilt_fused_adam_us", False, {"fused": True})):
+                net, opt = fresh(capturable=True, **adam)
+                eng = engine_for(net)
+                eng.cache_topology = keep
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for b in batches[:3]:
+                        body(net, opt, b)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                opt.zero_grad(set_to_none=True)
+                with torch.cuda.graph(g):
+                    for b in batches:
+                        loss = body(net, opt, b)
+                for _ in range(3):
+                    g.replay()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                reps = 60
+                for _ in range(reps):
+                    g.replay()
+                e1.record()
+                torch.cuda.synchronize()
+                res[label] = e0.elapsed_time(e1) * 1e3 / (reps * len(batches))
+                res["final_loss_" + label[:-3]] = float(loss.item())
+                del g
+            # -- the native trainer over the same cycle (topology of step t+1 built inside step t's launch) ---------------------
+            nat = measure_distinct_batches(nets[net_name], net_name, dev, n_batches=n_batches, graphs=B, batches=batches)
+            res["native_distinct_us"] = nat["us_per_step"]
+            res["graph_kept_over_native"] = res["graph_kept_us"] / nat["us_per_step"]
+            res["graph_kept_fused_adam_over_native"] = res["graph_kept_fused_adam_us"] / nat["us_per_step"]
+            res["graph_rebuilt_fused_adam_over_native"] = res["graph_rebuilt_fused_adam_us"] / nat["us_per_step"]
+            res["graphs_per_s_graph_kept_fused_adam"] = B / (res["graph_kept_fused_adam_us"] * 1e-6)
+            out[key] = res
+        except Exception as exc:                          # secondary figure: never lose the bench line over it
+            out[key] = {"error": repr(exc)[:300]}
+    return out
 
 
 def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=4):

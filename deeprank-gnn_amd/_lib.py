@@ -133,7 +133,8 @@ class HeadDesc(ctypes.Structure):
                 ("w1", _vp), ("b1", _vp), ("w2", _vp), ("b2", _vp), ("class_w", _vp), ("drop_mask", _vp)]
 
 
-TASK_REG, TASK_CLASS = 0, 1
+TASK_REG, TASK_CLASS, TASK_GRAD = 0, 1, 2      # (TASK_GRAD: `target` = d loss / d pred, the autograd boundary)
+ZERO_RANGES = 8
 
 
 def _ptr(t):
@@ -248,7 +249,10 @@ class Api(object):
         lib.drgnn_head_step.argtypes = [ctypes.POINTER(HeadDesc), _vp, _vp, _c_i64] + [_vp] * 5
         lib.drgnn_head_reduce.argtypes = [_vp, _c_i64, _c_i32, _c_i32, _c_i32] + [_vp] * 4
         lib.drgnn_adam_step.argtypes = [_vp] * 5 + [_c_i64] + [ctypes.c_float] * 5 + [_vp]
-        if lib.drgnn_abi_version() != 2:
+        lib.drgnn_step_gradients.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] + [ctypes.POINTER(ConvGrads)] * 2 +
+                                             [_vp, _vp] + [_c_i32] * 3 + [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_c_i64), _c_i32,
+                                                                       _vp, _c_i32, _vp])
+        if lib.drgnn_abi_version() != 3:
             raise DrgnnError("ABI mismatch in %s" % path)
 
     # -- topology ---------------------------------------------------------------
@@ -391,6 +395,15 @@ class Api(object):
             R, H, O, head_offset, _ptr(flat_p), _ptr(flat_g), _ptr(exp_avg), _ptr(exp_avg_sq), flat_p.numel(),
             _ptr(step2), _ptr(loss), lr, beta1, beta2, eps, 1 if apply_adam else 0, int(slabs_per_graph), stream),
             "drgnn_step_update")
+
+    def step_gradients(self, desc, conv_partials, n_graphs, g1, g2, head_partials, readout, R, H, O, head_grad,
+                       graph_weight, zero_ptr, zero_len, n_zero, step2, slabs_per_graph, stream):
+        """drgnn_step_gradients: the slabs of a fused step summed into the gradient tensors (each graph's slab times
+        ``graph_weight[g]`` when given); ``zero_ptr`` / ``zero_len``: ctypes arrays of the ranges to clear."""
+        _check(self.lib.drgnn_step_gradients(
+            ctypes.byref(desc), _ptr(conv_partials), n_graphs, g1, g2, _ptr(head_partials), _ptr(readout), R, H, O,
+            head_grad, _ptr(graph_weight), zero_ptr, zero_len, int(n_zero), _ptr(step2), int(slabs_per_graph), stream),
+            "drgnn_step_gradients")
 
     def net_step_xchg_elems(self, kind, max_nodes, max_c0, H):
         return int(self.lib.drgnn_net_step_xchg_elems(kind, max_nodes, max_c0, H))

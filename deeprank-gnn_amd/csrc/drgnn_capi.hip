@@ -926,7 +926,12 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     if (rc) return rc;
     if (!hd || !hd->w1 || !hd->b1 || !hd->w2 || !hd->b2 || !x || !step2 || !ws_i32 || !pred || !readout)
         return DRGNN_E_ARG;
-    if (hd->train && (!target || !head_partials || !partials)) return DRGNN_E_ARG;      // inference needs neither
+    // hd->train: 1 = the whole step; 0 = inference; 2 = the forward of a training step (predictions only, dropout on)
+    if (hd->train < 0 || hd->train > 2) return DRGNN_E_ARG;
+    const bool full_step = hd->train == 1;
+    if (full_step && (!target || !head_partials || !partials)) return DRGNN_E_ARG;      // inference needs neither
+    if (hd->task != DRGNN_TASK_REG && hd->task != DRGNN_TASK_CLASS && hd->task != DRGNN_TASK_GRAD) return DRGNN_E_ARG;
+    if (hd->task == DRGNN_TASK_GRAD && gather_ids) return DRGNN_E_ARG;      // (the upstream gradient is indexed by slot)
     if (net->n_branch > 1 && !xchg) return DRGNN_E_ARG;
     if (net->kind == DRGNN_SGAT && !ws_f32) return DRGNN_E_ARG;
     if (hd->R != DRGNN_H2 * net->n_branch || hd->H < 1 || hd->H > 512 || hd->O < 1 || hd->O > DRGNN_MAX_OUT)
@@ -953,7 +958,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     q.R = hd->R; q.H = hd->H; q.O = hd->O; q.B = n_graphs;
     q.co = co_ok ? (int64_t)T.args.n_graphs : 0;
     q.co_roles = co_ok ? T.roles : 1;
-    q.train = hd->train != 0;
+    q.train = full_step;
     q.x_ok = (((uintptr_t)x) & 15) == 0;
     q.topo_flags = hints ? hints->topo_flags : 0;
     // (the caller vouches for the tiles' flavour: weighted sums for sGAT, plain sums for FoutNet / GINet)
@@ -966,6 +971,9 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     if (k.rc) return k.rc;
     // a workspace built with DRGNN_TOPO_LEAN holds only what the aggregation-first kernels read
     if (hints && (hints->topo_flags & DRGNN_TOPO_LEAN) && !k.lean_ok) return DRGNN_E_ARG;
+    // the autograd boundary (an upstream gradient instead of a target, a forward with the dropout mask of the step) is the
+    // aggregation-first kernels': the product-first family predates it
+    if ((hd->task == DRGNN_TASK_GRAD || hd->train == 2) && !k.lean_ok) return DRGNN_E_ARG;
     if (co_ok && k.builder_roles == 0) co_ok = false;      // the builder gets a launch of its own
     if (co_ok) T.roles = k.builder_roles;
     const bool one_wg = (kind == DRGNN_GINET) && k.wgs == 1;
@@ -1017,10 +1025,10 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     a.xchg_stride = (int)step2_xchg_words(q.capC > 0 ? q.capC : 1);
     HeadFused& hf = a.hf;
     hf.enabled = 1; hf.B = (int)n_graphs; hf.R = hd->R; hf.H = hd->H; hf.O = hd->O; hf.task = hd->task;
-    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0; hf.train = hd->train ? 1 : 0; hf.sigmoid = hd->transform_sigmoid;
+    hf.p_drop = hd->train ? hd->p_drop : 0.0f; hf.seed = hd->seed; hf.step_bias = 0; hf.train = full_step ? 1 : 0; hf.sigmoid = hd->transform_sigmoid;
     hf.drop_mask = hd->train ? hd->drop_mask : nullptr;
     hf.w1 = hd->w1; hf.b1 = hd->b1; hf.w2 = hd->w2; hf.b2 = hd->b2; hf.class_w = hd->class_w;
-    hf.y_reg = (hd->task == DRGNN_TASK_REG) ? (const float*)target : nullptr;
+    hf.y_reg = (hd->task != DRGNN_TASK_CLASS) ? (const float*)target : nullptr;
     hf.y_cls = (hd->task == DRGNN_TASK_CLASS) ? (const int64_t*)target : nullptr;
     hf.readout = readout; hf.step = step2; hf.pred = pred; hf.partials = head_partials; hf.stage = 0;
 
@@ -1079,7 +1087,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             Q.pf_tiles = a.tiles; Q.pf_f = TF; Q.pf_tile_nodes = n_nodes;
             Q.pf_x = (kind == DRGNN_GINET) ? nullptr : (F & 3) ? a.tiles + n_nodes * (TF + 2) : x;
             Q.pf_coef = (kind != DRGNN_GINET) ? 1 : 0;
-            Q.pf_y = hd->train ? target : nullptr; Q.pf_y_bytes = (hd->task == DRGNN_TASK_REG) ? 4 : 8;
+            Q.pf_y = full_step ? target : nullptr; Q.pf_y_bytes = (hd->task == DRGNN_TASK_REG) ? 4 : 8;
             if (Q.pf_tiles != nullptr) extra = Q.pf_n; else Q.pf_ids = nullptr;
         }
         drgnn_step_kernel_t kern = nullptr;
@@ -1115,7 +1123,7 @@ int drgnn_net_train_step_cached(const drgnn_net_desc* net, const drgnn_head_desc
                                 float* readout, float* head_partials, float* partials, uint64_t* xchg,
                                 const drgnn_step_hints* hints, void* stream_) {
     if (!cache || !ids || !cache->ws_i32 || !cache->x || n_graphs < 0 || n_graphs > cache->n_graphs) return DRGNN_E_ARG;
-    if (hd && hd->train) {
+    if (hd && hd->train == 1) {
         if (!cache->y || cache->y_bytes != (hd->task == DRGNN_TASK_REG ? 4 : 8)) return DRGNN_E_ARG;
     }
     return train_step_impl(net, hd, cache->x, cache->y, step2, cache->ws_i32, cache->ws_f32, cache->n_nodes,
@@ -1405,6 +1413,61 @@ int drgnn_step_update(const drgnn_net_desc* net, const float* conv_partials, int
     return update_impl(slabs_per_graph, net, conv_partials, n_graphs, g_conv1, g_conv2, head_partials, n_graphs, readout, R, H, O,
                        head_offset, flat_param, flat_grad, exp_avg, exp_avg_sq, n_param, step2, loss, lr, beta1,
                        beta2, eps, apply_adam, stream_);
+}
+
+int drgnn_step_gradients(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+                         drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
+                         const float* readout, int32_t R, int32_t H, int32_t O, float* head_grad,
+                         const float* graph_weight, float* const* zero_ptr, const int64_t* zero_len, int32_t n_zero,
+                         int32_t* step2, int32_t slabs_per_graph, void* stream_) {
+    int rc = net_check(net);
+    if (rc) return rc;
+    if (!conv_partials || !g_conv1 || !g_conv2 || !head_partials || !readout || !head_grad || n_graphs < 0) return DRGNN_E_ARG;
+    if (n_zero < 0 || n_zero > DRGNN_ZERO_RANGES || (n_zero > 0 && (!zero_ptr || !zero_len))) return DRGNN_E_ARG;
+    if (slabs_per_graph != 0 && slabs_per_graph != net->n_branch && !(net->n_branch == 1 && slabs_per_graph == 2)) return DRGNN_E_ARG;
+    if (R != DRGNN_H2 * net->n_branch || H < 1 || H > 512 || O < 1 || O > DRGNN_MAX_OUT) return DRGNN_E_WIDTH;
+    GradArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    UpdateArgs& u = ga.u;
+    ReduceArgs& r = u.r;
+    const bool split = net->n_branch == 1 && slabs_per_graph == 2;
+    r.partials = conv_partials; r.n_graphs = (int)(split ? 2 * n_graphs : n_graphs); r.n_branch = net->n_branch;
+    r.n_feat = net->n_feat; r.n_partial = (int)net_partial_floats(net->n_feat); r.kind = net->kind;
+    for (int b = 0; b < DRGNN_MAX_BRANCH; ++b) {
+        r.lay1[b] = net->conv1[b]; r.lay2[b] = net->conv2[b];
+        if (b < net->n_branch) { r.g1[b] = g_conv1[b]; r.g2[b] = g_conv2[b]; }
+        else { r.g1[b] = drgnn_conv_grads{nullptr, nullptr, nullptr}; r.g2[b] = r.g1[b]; }
+    }
+    r.grad_x = nullptr; r.n_nodes = 0;
+    u.h.partials = head_partials; u.h.n_wg = (int)n_graphs; u.h.P = (int)head_compact_floats(R, H, O);
+    u.h.grad = head_grad; u.h.loss = nullptr; u.h.step = nullptr;
+    u.readout = readout; u.hR = R; u.hH = H; u.step2 = step2; u.apply_adam = 0;
+    u.blocks_per_branch = (r.n_partial + 63) / 64;
+    u.conv_blocks = net->n_branch * u.blocks_per_branch;
+    ga.graph_weight = graph_weight; ga.wshift = split ? 1 : 0; ga.n_zero = n_zero;
+    for (int i = 0; i < n_zero; ++i) {
+        if (!zero_ptr[i] || zero_len[i] < 0) return DRGNN_E_ARG;
+        ga.zero_ptr[i] = zero_ptr[i]; ga.zero_len[i] = zero_len[i];
+    }
+    const int head_items = H * R + u.h.P - 2;             // the gradient block (the loss / weight slots are not gradients)
+    const int head_blocks = (head_items + 63) / 64;
+#ifdef DRGNN_EMU
+    for (int64_t i = 0; i < (int64_t)net->n_branch * r.n_partial; ++i) {
+        const int br = (int)(i / r.n_partial), p = (int)(i % r.n_partial);
+        if (!reduce_live(r, p)) continue;
+        float* d = reduce_dst(r, br, p);
+        if (d) *d = graph_weight ? reduce_sum_w(r, br, p, 0, 1, graph_weight, ga.wshift) : reduce_sum(r, br, p, 0, 1);
+    }
+    for (int i = 0; i < head_items; ++i)
+        head_grad[i] = graph_weight ? update_head_sum_w(u, i, 0, 1, graph_weight) : update_head_sum(u, i, 0, 1);
+    for (int i = 0; i < n_zero; ++i) memset(ga.zero_ptr[i], 0, sizeof(float) * (size_t)ga.zero_len[i]);
+    if (step2) step2[0] = step2[1];
+    (void)stream_; (void)head_blocks;
+#else
+    hipLaunchKernelGGL(k_gradients, dim3((unsigned)(u.conv_blocks + head_blocks + 1)), dim3(256), 0, (hipStream_t)stream_, ga);
+    HIP_TRY(hipGetLastError());
+#endif
+    return 0;
 }
 
 // ---- stand-alone layers / pooling functions ---------------------------------------------------

@@ -324,6 +324,23 @@ DEV float reduce_sum(const ReduceArgs& a, int br, int p, int first, int stride) 
     return acc;
 }
 
+// ... with slab row g weighted by w[g >> wshift] (drgnn_step_gradients: the slabs hold d pred_g / d theta, w = d loss / d pred)
+DEV float reduce_sum_w(const ReduceArgs& a, int br, int p, int first, int stride, const float* w, int wshift) {
+    const float* src = a.partials + (int64_t)br * a.n_partial + p;
+    const int64_t step = (int64_t)a.n_branch * a.n_partial;
+    float acc = 0.0f;
+    float v[16], c[16];
+    int g = first;
+    for (; g + 15 * stride < a.n_graphs; g += 16 * stride) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k] = src[(int64_t)(g + k * stride) * step]; c[k] = w[(g + k * stride) >> wshift]; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(c[k], v[k], acc);
+    }
+    for (; g < a.n_graphs; g += stride) acc = fmaf(w[g >> wshift], src[(int64_t)g * step], acc);
+    return acc;
+}
+
 DEV void reduce_grad_x(const ReduceArgs& a, int64_t item) {
     if (a.grad_x != nullptr && a.n_branch > 1 && item < a.n_nodes * a.n_feat) {
         float acc = a.grad_x[item];
@@ -658,6 +675,32 @@ DEV float update_head_sum(const UpdateArgs& u, int item, int first, int stride) 
     for (; w < u.h.n_wg; w += stride) acc += src[(long)w * u.h.P];
     return acc;
 }
+// ... with slab w weighted by gw[w] (see reduce_sum_w)
+DEV float update_head_sum_w(const UpdateArgs& u, int item, int first, int stride, const float* gw) {
+    float acc = 0.0f;
+    if (u.readout) {
+        const int HR = u.hH * u.hR;
+        if (item < HR) {
+            const int h = item / u.hR, r = item - h * u.hR;
+            const float* dh = u.h.partials + h;
+            const float* xr = u.readout + r;
+            for (int w = first; w < u.h.n_wg; w += stride) acc = fmaf(gw[w] * dh[(long)w * u.h.P], xr[(long)w * u.hR], acc);
+            return acc;
+        }
+        item -= HR;
+    }
+    const float* src = u.h.partials + item;
+    for (int w = first; w < u.h.n_wg; w += stride) acc = fmaf(gw[w], src[(long)w * u.h.P], acc);
+    return acc;
+}
+struct GradArgs {
+    UpdateArgs u;                  // (u.ad unused, u.apply_adam = 0)
+    const float* graph_weight;     // [n_graphs] or null
+    int wshift;                    // conv slab row -> graph: row >> wshift (1 for the split layout's two half-graph slabs)
+    int n_zero;
+    float* zero_ptr[DRGNN_ZERO_RANGES];
+    int64_t zero_len[DRGNN_ZERO_RANGES];
+};
 DEV void update_head_store(const UpdateArgs& u, int item, float acc) {
     const int n_grad = update_head_items(u) - 1;
     if (item < n_grad) update_store(u, u.h.grad + item, acc);
@@ -975,6 +1018,42 @@ __global__ void __launch_bounds__(DRGNN_UPDATE_THREADS) k_update(UpdateArgs u) {
     }
     // nobody reads step2[0] in this launch (Adam reads step2[1]): safe to commit it here
     if (u.step2 && blockIdx.x == 0 && threadIdx.x == 0) u.step2[0] = u.step2[1];
+}
+// drgnn_step_gradients: k_update's fixed-order sums without the optimiser -- the gradient of the step's slabs, each slab
+// optionally weighted by its graph's d loss / d pred (the autograd boundary, include/drgnn.h), plus one block that clears the
+// ranges no kernel writes (GINet's dead attention parameters).  4 waves: interleaved quarters of the slabs, combined in fixed order.
+__global__ void __launch_bounds__(256) k_gradients(GradArgs ga) {
+    __shared__ float quarter[4][64];
+    const UpdateArgs& u = ga.u;
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int n_sum = u.conv_blocks + (update_head_items(u) - 1 + 63) / 64;
+    if ((int)blockIdx.x >= n_sum) {          // the clearing block
+        for (int r = 0; r < ga.n_zero; ++r)
+            for (int64_t i = threadIdx.x; i < ga.zero_len[r]; i += 256) ga.zero_ptr[r][i] = 0.0f;
+        if (u.step2 && threadIdx.x == 0) u.step2[0] = u.step2[1];      // (nobody reads step2 in this launch)
+        return;
+    }
+    const bool conv = (int)blockIdx.x < u.conv_blocks;
+    const float* gw = ga.graph_weight;
+    float* d = nullptr;
+    bool live = false;
+    if (conv) {
+        const ReduceArgs& a = u.r;
+        int br = 0, blk = (int)blockIdx.x;
+        while (blk >= u.blocks_per_branch && br + 1 < a.n_branch) { blk -= u.blocks_per_branch; ++br; }
+        const int p_raw = blk * 64 + lane;
+        live = p_raw < a.n_partial && reduce_live(a, p_raw);
+        const int p = live ? p_raw : 0;
+        d = (q == 0 && live) ? reduce_dst(a, br, p) : nullptr;
+        quarter[q][lane] = !live ? 0.0f : gw ? reduce_sum_w(a, br, p, q, 4, gw, ga.wshift) : reduce_sum(a, br, p, q, 4);
+    } else {
+        const int item = ((int)blockIdx.x - u.conv_blocks) * 64 + lane;
+        live = item < update_head_items(u) - 1;       // (the loss item is not a gradient)
+        d = (q == 0 && live) ? u.h.grad + item : nullptr;
+        quarter[q][lane] = !live ? 0.0f : gw ? update_head_sum_w(u, item, q, 4, gw) : update_head_sum(u, item, q, 4);
+    }
+    __syncthreads();
+    if (d) *d = (quarter[0][lane] + quarter[1][lane]) + (quarter[2][lane] + quarter[3][lane]);
 }
 __global__ void __launch_bounds__(DRGNN_P2P_THREADS) k_allreduce_oneshot(P2PArgs a) { p2p_block(a, blockIdx.x); }
 __global__ void __launch_bounds__(256) k_adam(AdamArgs a) {

@@ -993,13 +993,16 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
             FOR_TID(o, O) {
                 float acc = b2[o];
                 for (int h = 0; h < H; ++h) acc = fmaf(hid[h], w2[o * H + h], acc);
-                if (hf.sigmoid && hf.task == DRGNN_TASK_REG) acc = drgnn_sigmoid(acc);
+                if (hf.sigmoid && hf.task != DRGNN_TASK_CLASS) acc = drgnn_sigmoid(acc);
                 hf.pred[(long)g * O + o] = acc;
             }
         }
         return;
     }
-    const bool sig = hf.sigmoid && hf.task == DRGNN_TASK_REG;
+    // (DRGNN_TASK_GRAD: d loss / d pred comes from the caller's autograd -- misc[STEP_M_Y] holds it when O == 1, the row
+    // hf.y_reg[g * O ..] otherwise -- and the loss slot is written as 0; regression in every other respect)
+    const bool ext = hf.task == DRGNN_TASK_GRAD;
+    const bool sig = hf.sigmoid && hf.task != DRGNN_TASK_CLASS;
     const float denom = misc[STEP_M_DENOM], wy = misc[STEP_M_WY];
 #ifdef DRGNN_EMU
     float outs[DRGNN_MAX_OUT], douts[DRGNN_MAX_OUT];
@@ -1010,7 +1013,9 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
         if (sig) outs[o] = drgnn_sigmoid(outs[o]);
     }
     float loss = 0.0f, wsum = 1.0f;
-    if (hf.task == DRGNN_TASK_REG) {
+    if (ext) {
+        for (int o = 0; o < O; ++o) douts[o] = hf.y_reg[(long)g * O + o] * (sig ? outs[o] * (1.0f - outs[o]) : 1.0f);
+    } else if (hf.task == DRGNN_TASK_REG) {
         const float inv = 1.0f / (float)(hf.B * O);
         for (int o = 0; o < O; ++o) {
             const float d = outs[o] - misc[STEP_M_Y];
@@ -1048,7 +1053,7 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
     // others would just repeat the same ~150 instructions on the same SIMDs
     if ((int)(threadIdx.x & ~63u) >= H && threadIdx.x >= 64) return;
     const int lane = threadIdx.x & 63;
-    if (HC != 0 && HC <= 128 && OC == 1 && hf.task == DRGNN_TASK_REG) {
+    if (HC != 0 && HC <= 128 && OC == 1 && hf.task != DRGNN_TASK_CLASS) {
         // The reference heads (one output, MSE): this phase is ONE dependent chain in one or two waves while fourteen wait,
         // so every LDS operand is requested up front (one round trip instead of six), the wave sum runs once (the loss of a
         // single output needs none) and no value travels through a lane read: out and d loss / d out are wave-uniform.
@@ -1065,7 +1070,7 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
         if (sig) out = drgnn_sigmoid(out);
         const float inv = 1.0f / (float)(hf.B * O);
         const float d = out - yv;
-        const float dout = 2.0f * d * inv * (sig ? out * (1.0f - out) : 1.0f);
+        const float dout = (ext ? yv : 2.0f * d * inv) * (sig ? out * (1.0f - out) : 1.0f);
         const int wv_id = (int)(threadIdx.x >> 6);
         float hme = hv[0], wme = wv[0];
 #pragma unroll
@@ -1079,7 +1084,7 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
             if (threadIdx.x == 0) {
                 hf.pred[(long)g] = out;
                 p_hb2[0] = dout;
-                p_loss[0] = (d * d * inv);
+                p_loss[0] = ext ? 0.0f : (d * d * inv);
                 p_loss[1] = 1.0f;
             }
         }
@@ -1094,7 +1099,10 @@ DEV void step_head_loss_t(const HeadFused& hf, int g, int br, const float* hid, 
     }
     if (sig) my_out = drgnn_sigmoid(my_out);
     float my_dout = 0.0f, loss, wsum = 1.0f;
-    if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {      // (layout hint: the exp / log code of the other branch goes out of line)
+    if (ext) {
+        loss = 0.0f;
+        my_dout = lane < O ? hf.y_reg[(long)g * O + lane] * (sig ? my_out * (1.0f - my_out) : 1.0f) : 0.0f;
+    } else if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {      // (layout hint: the exp / log code of the other branch goes out of line)
         const float inv = 1.0f / (float)(hf.B * O);
         const float d = my_out - misc[STEP_M_Y];
         loss = lanes64_sum(lane < O ? d * d * inv : 0.0f);

@@ -290,7 +290,7 @@ DEV void net_step3_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     if (my_wave == 0) {
         m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
         if (!TRAIN) {
-        } else if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
+        } else if (__builtin_expect(hf.task != DRGNN_TASK_CLASS, 1)) {      // (DRGNN_TASK_GRAD: d loss / d pred_g, O == 1; gi == g there)
             m_y = __builtin_nontemporal_load((const int*)hf.y_reg + gi);
         } else {
             m_y = (int)hf.y_cls[gi];
@@ -751,7 +751,7 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     if (my_wave == 0) {
         m_bad = tv.p[DRGNN_TI_ERR][0] | tv.p[DRGNN_TI_GSTAT][gi] | tv.p[DRGNN_TI_GSTAT][(GATHER ? a.ws_graphs : a.n_graphs) + gi];
         if (!TRAIN) {
-        } else if (__builtin_expect(hf.task == DRGNN_TASK_REG, 1)) {
+        } else if (__builtin_expect(hf.task != DRGNN_TASK_CLASS, 1)) {      // (DRGNN_TASK_GRAD: d loss / d pred_g, O == 1; gi == g there)
             m_y = __builtin_nontemporal_load((const int*)hf.y_reg + gi);
         } else {
             m_y = (int)hf.y_cls[gi];

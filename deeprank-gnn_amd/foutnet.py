@@ -16,6 +16,7 @@ from torch.nn import Parameter
 from . import _lib
 from .functional import net_body
 from .topology import Topology
+from .fused_autograd import engine_for
 
 __all__ = ["FoutNet", "FoutLayer"]
 
@@ -71,6 +72,11 @@ class FoutNet(nn.Module):
         return net_body(_lib.FOUT, data.x, topo, live, n_branch=1)
 
     def forward(self, data, topo=None):
+        """pred [B, output_shape].  On the fused step kernels whenever the batch fits them (fused_autograd: one launch for
+        ``model(batch)``, one for ``loss.backward()``); otherwise the launch pair of ``body`` + the head in torch."""
+        pred = engine_for(self).run(data, topo)
+        if pred is not None:
+            return pred
         x = self.body(data, topo)
         x = F.relu(self.fc1(x))
         return self.fc2(x)

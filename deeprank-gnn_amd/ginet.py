@@ -20,6 +20,7 @@ import torch.nn.functional as F
 from . import _lib
 from .functional import net_body, zero_grad_passthrough
 from .topology import Topology
+from .fused_autograd import engine_for
 
 __all__ = ["GINet", "GINetConvLayer"]
 
@@ -101,6 +102,11 @@ class GINet(nn.Module):
         return zero_grad_passthrough(readout, dead)
 
     def forward(self, data, topo=None):
+        """pred [B, output_shape].  On the fused step kernels whenever the batch fits them (fused_autograd: one launch for
+        ``model(batch)``, one for ``loss.backward()``); otherwise the launch pair of ``body`` + the head in torch."""
+        pred = engine_for(self).run(data, topo)
+        if pred is not None:
+            return pred
         x = self.body(data, topo)
         x = F.relu(self.fc1(x))
         x = F.dropout(x, self.dropout, training=self.training)

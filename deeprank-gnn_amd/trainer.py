@@ -27,16 +27,7 @@ from .topology import Topology
 __all__ = ["FusedTrainer"]
 
 
-def _net_layout(net):
-    """(kind, n_branch, [conv modules in kernel order]) of one of the three reference nets."""
-    name = type(net).__name__
-    if name == "GINet":
-        return _lib.GINET, 2, [net.conv1, net.conv2, net.conv1_ext, net.conv2_ext]
-    if name == "sGAT":
-        return _lib.SGAT, 1, [net.conv1, net.conv2]
-    if name == "FoutNet":
-        return _lib.FOUT, 1, [net.conv1, net.conv2]
-    raise TypeError("FusedTrainer drives GINet / sGAT / FoutNet, not %s" % name)
+from .fused_autograd import net_layout as _net_layout      # noqa: E402  (kind, n_branch, convs) of a reference net
 
 
 class _BatchView(object):

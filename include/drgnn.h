@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DRGNN_ABI_VERSION 2
+#define DRGNN_ABI_VERSION 3
 
 /* host-side argument errors */
 #define DRGNN_E_ARG      (-1)   /* null pointer / negative size / bad mode            */
@@ -277,10 +277,19 @@ int drgnn_cluster_offset(int64_t* cluster, const int32_t* node_ptr, int64_t n_gr
  */
 #define DRGNN_TASK_REG   0
 #define DRGNN_TASK_CLASS 1
+/* DRGNN_TASK_GRAD -- the autograd boundary (NeuralNet.py:493-502: pred = model(batch); loss = loss_fn(pred, y); loss.backward()):
+ * the loss lives OUTSIDE the library, `target` is float [B, O] = d loss / d pred as the caller's autograd hands it over, and
+ * the launch back-propagates exactly that (the loss slot of the head slabs is written as 0).  With transform_sigmoid the
+ * upstream gradient is taken with respect to the transformed prediction.  Fused step launches of the aggregation-first
+ * family on a per-mini-batch workspace only (drgnn_net_train_step; DRGNN_E_ARG elsewhere). */
+#define DRGNN_TASK_GRAD  2
 typedef struct drgnn_head_desc {
     int32_t R, H, O;          /* readout width, hidden width, outputs (O <= 16)              */
     int32_t task;             /* DRGNN_TASK_REG: target float [B]; _CLASS: target int64 [B]   */
-    int32_t train;            /* 1: dropout + loss + gradients; 0: predictions only           */
+    int32_t train;            /* 1: dropout + loss + gradients; 0: predictions only (dropout off);
+                                 2 (fused step launches only): the FORWARD of a training step -- predictions only, dropout ON
+                                 with the mask of optimiser step step2[0], i.e. the mask a train = 1 launch draws until
+                                 step2[0] is committed (model(batch) in training mode, its backward being a later launch) */
     float   p_drop;           /* dropout probability (GINet 0.4, others 0)                    */
     uint32_t seed;            /* dropout stream seed (mixed with the device step counter)     */
     int32_t transform_sigmoid; /* regression only: pred = sigmoid(fc2 output) before the loss (reference
@@ -535,6 +544,24 @@ int drgnn_step_update(const drgnn_net_desc* net, const float* conv_partials, int
                       float* flat_param, float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
                       int32_t* step2, float* loss, float lr, float beta1, float beta2, float eps,
                       int32_t apply_adam, int32_t slabs_per_graph, void* stream);
+
+/* The gradient half of drgnn_step_update alone, for a caller whose optimiser lives outside the library (the drop-in boundary:
+ * an unchanged NeuralNet._epoch runs torch.optim.Adam over model.parameters(), NeuralNet.py:183-184,502-503): fixed-order sum of
+ * the conv slabs into g_conv1 / g_conv2 and of the head slabs (+ dW_fc1 = dhid^T readout) into head_grad = [fc1.weight |
+ * fc1.bias | fc2.weight | fc2.bias] (contiguous), no parameter update.
+ *   graph_weight  NULL, or float [n_graphs]: slab g enters the sum multiplied by graph_weight[g].  Every quantity of a graph's
+ *                 slab is linear in d loss / d pred_g, so a DRGNN_TASK_GRAD launch with O = 1 and an upstream gradient of ONE
+ *                 leaves d pred_g / d theta in the slabs, and this call with graph_weight = d loss / d pred contracts them with
+ *                 the real gradient of ANY loss: model(batch) is one launch, loss.backward() is this one.
+ *   zero_ptr / zero_len  up to DRGNN_ZERO_RANGES float ranges filled with 0 by the same launch (parameters the step kernels
+ *                 never touch: GINetConvLayer's fc_attention / fc_edge_attr, whose gradient is identically 0, ginet.py:63-66)
+ *   step2         optional: commit step2[0] = step2[1] (a new dropout stream for the next step), as drgnn_step_update does. */
+#define DRGNN_ZERO_RANGES 8
+int drgnn_step_gradients(const drgnn_net_desc* net, const float* conv_partials, int64_t n_graphs,
+                         drgnn_conv_grads* g_conv1, drgnn_conv_grads* g_conv2, const float* head_partials,
+                         const float* readout, int32_t R, int32_t H, int32_t O, float* head_grad,
+                         const float* graph_weight, float* const* zero_ptr, const int64_t* zero_len, int32_t n_zero,
+                         int32_t* step2, int32_t slabs_per_graph, void* stream);
 
 /* ---- graclus ---------------------------------------------------------------------
  * Greedy maximal matching of every graph of a built topology (CSR0), the clustering the README's custom net

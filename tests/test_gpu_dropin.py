@@ -1,0 +1,309 @@
+"""The drop-in boundary on the fused step kernels: what an UNCHANGED reference trainer runs per mini-batch
+(reference NeuralNet.py:489-506)
+
+    optimizer.zero_grad(); pred = model(batch); loss = loss_fn(pred, y); loss.backward(); optimizer.step()
+
+with ``model`` one of this package's GINet / sGAT / FoutNet (deeprank-gnn_amd/fused_autograd.py): ``model(batch)`` and
+``loss.backward()`` are one launch each of the aggregation-first family (csrc/drgnn_step2.h / drgnn_step3.h), asserted here
+through the engine's plan; the results are compared ELEMENT-WISE with the goldens recorded from the reference's own
+ginet.py / sGAT.py / foutnet.py (tests/golden/gen/make_golden.py, make_width_golden.py), tolerance tests/elementwise.py
+(1e-4 + 1e-4 |ref| per element, float64 arbiter <= 0.1 %), and with the native trainer's gradients where dropout is on.
+"""
+import copy
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import CASES, STEP_ONLY_CASES, golden, params_of
+from elementwise import Lazy64, check_step, new_stats, assert_arbiter_rate
+
+pytestmark = pytest.mark.gpu
+ALL_CASES = dict(CASES, **STEP_ONLY_CASES)
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def _build(net_name, params, n_out):
+    from test_gpu_parity import build
+    return build(net_name, params, n_out)      # load_state_dict(strict=True), dropout 0, on the device
+
+
+def _fw(net_name):
+    return {"looped": False} if net_name == "FoutNet" else {}
+
+
+def _loss(task, out, target):
+    return F.mse_loss(out.reshape(-1), target) if task == "reg" else F.cross_entropy(out, target)
+
+
+def _engine(net):
+    from deeprank_gnn_amd.fused_autograd import engine_for
+    return engine_for(net)
+
+
+@pytest.mark.parametrize("fname", sorted(ALL_CASES))
+def test_model_loss_backward_vs_reference_golden(fname):
+    """model(batch) -> loss -> backward with nothing but the batch handed over: the engine builds the lean + tiles workspace,
+    takes the aggregation-first family (asserted), and every gradient matches the reference's."""
+    from deeprank_gnn_amd import _lib
+    net_name, make_batch, task = ALL_CASES[fname]
+    g = golden(fname)
+    params = params_of(g)
+    n_out = g["out"].shape[1]
+    target_cpu = torch.from_numpy(g["target"])
+    lazy = Lazy64(net_name, params, make_batch(), target=target_cpu, task=task, **_fw(net_name))
+    batch = make_batch().to(_dev())
+    net = _build(net_name, params, n_out)
+    net.train()
+    out = net(batch)
+    eng = _engine(net)
+    assert eng.last_path == ("jacobian" if n_out == 1 else "two-launch"), eng.last_path
+    assert eng.last_plan.family == _lib.STEP_FAMILY_AGGREGATE
+    n_feat = int(batch.x.shape[1])
+    assert eng.last_plan.width == ((n_feat + 15) // 16) * 16
+    topo = eng.topology_for(batch)
+    assert topo.flags & _lib.TOPO_LEAN and topo.flags & _lib.TOPO_TILES      # the builder's short chains, tiles formed with it
+    loss = _loss(task, out, target_cpu.to(_dev()))
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {}
+    for name, p in net.named_parameters():
+        assert p.grad is not None, name
+        grads[name] = p.grad.cpu().numpy()
+    stats = new_stats()
+    check_step(fname + " [drop-in]", lazy, loss.item(), out.detach().cpu().numpy(), grads, float(g["loss"]), g["out"],
+               {name: g["grad/" + name] for name in grads}, stats)
+    assert_arbiter_rate(stats, fname)
+    # the same batch again: the kept workspace (no builder launch), the same numbers bit for bit
+    for p in net.parameters():
+        p.grad = None
+    out2 = net(batch)
+    assert eng.topology_for(batch) is topo
+    _loss(task, out2, target_cpu.to(_dev())).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out2.detach().cpu().numpy(), out.detach().cpu().numpy())
+    for name, p in net.named_parameters():
+        np.testing.assert_array_equal(p.grad.cpu().numpy(), grads[name], err_msg=name)
+    # inference launch (eval, no_grad): the training launch's predictions (dropout 0)
+    net.eval()
+    with torch.no_grad():
+        pred = net(batch)
+    assert eng.last_path == "inference" and eng.last_plan.family == _lib.STEP_FAMILY_AGGREGATE
+    np.testing.assert_allclose(pred.cpu().numpy(), out.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def _legacy_grads(net, batch, loss_fn):
+    """the launch pair (functional.net_body) + the head in torch: plain autograd through every stage"""
+    for p in net.parameters():
+        p.grad = None
+    x = net.body(batch)
+    x = F.relu(net.fc1(x))
+    out = net.fc2(x)
+    loss_fn(out).backward()
+    return out.detach(), {n: p.grad.clone() for n, p in net.named_parameters()}
+
+
+@pytest.mark.parametrize("net_name", ["GINet", "sGAT", "FoutNet"])
+def test_any_loss_through_the_slabs(net_name):
+    """The one-launch backward contracts d pred_g / d theta with WHATEVER d loss / d pred autograd hands over: losses the
+    library has never heard of, against plain autograd through the launch pair + torch head on the same net."""
+    import deeprank_gnn_amd.synthetic as synth
+    batch = synth.make_batch(0, 16).to(_dev())
+    torch.manual_seed(3)
+    from test_gpu_parity import nets
+    net = nets()[net_name](32, 1, 1).to(_dev())
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0
+    net.train()
+    y = batch.y
+    losses = {
+        "l1": lambda o: F.l1_loss(o.reshape(-1), y),
+        "huber": lambda o: F.smooth_l1_loss(o.reshape(-1), y, beta=0.5),
+        "weighted_cubic": lambda o: ((o.reshape(-1) - y) ** 3 * torch.linspace(0.1, 2.0, o.shape[0], device=o.device)).sum(),
+        "sum": lambda o: o.sum(),                       # (an expanded, non-contiguous upstream gradient)
+    }
+    for name, fn in losses.items():
+        ref_out, ref = _legacy_grads(net, batch, fn)
+        for p in net.parameters():
+            p.grad = None
+        out = net(batch)
+        assert _engine(net).last_path == "jacobian"
+        fn(out).backward()
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        for n, p in net.named_parameters():
+            r = ref[n].cpu().numpy()
+            np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(r).max())),
+                                       err_msg="%s %s %s" % (net_name, name, n))
+
+
+@pytest.mark.parametrize("task,n_out", [("reg", 1), ("class", 2)])
+def test_dropout_on_equals_the_native_step(task, n_out):
+    """GINet with dropout 0.4 (ginet.py:138): the drop-in step draws the mask of the native step (same seed, same step index),
+    so pred and every gradient equal FusedTrainer.compute_gradients' -- one output through the slabs, two outputs through the
+    forward-only launch + the training launch fed with d loss / d pred."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.ginet import GINet
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    from deeprank_gnn_amd.topology import Topology
+    batch = synth.make_batch(0, 24).to(_dev())
+    if task == "class":
+        batch.y = (batch.y > 10).to(torch.int64)
+    torch.manual_seed(11)
+    net = GINet(32, n_out, 1).to(_dev())
+    twin = copy.deepcopy(net)
+    net.train()
+    out = net(batch)
+    eng = _engine(net)
+    assert eng.last_path == ("jacobian" if n_out == 1 else "two-launch")
+    _loss(task, out, batch.y).backward()
+    tr = FusedTrainer(twin, lr=0.01, task=task, seed=eng.seed)
+    tr.compute_gradients(batch, topo=Topology.from_batch(batch, need_weights=False))
+    torch.cuda.synchronize()
+    assert float((out.detach() - tr.last_pred).abs().max()) <= 1e-6
+    # (a dropped unit is an exact zero in both: the masks agree or the predictions could not)
+    for (n, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+        r = q.grad.cpu().numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=1e-4, atol=1e-6 * max(1.0, float(np.abs(r).max())), err_msg=n)
+    # the step index moved on with the backward: the next forward draws another mask
+    with torch.no_grad():
+        again = net(batch)
+    assert float((again - out.detach()).abs().max()) > 1e-4
+
+
+def test_two_forwards_before_a_backward_and_accumulation():
+    """(l(a) + l(b)).backward() with both forwards in flight (the second keeps private slabs), and autograd's accumulation
+    into existing .grad (zero_grad(set_to_none=False)): never a buffer added to itself."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.sGAT import sGAT
+    a = synth.make_batch(0, 8).to(_dev())
+    b = synth.make_batch(8, 8).to(_dev())
+    torch.manual_seed(5)
+    net = sGAT(32, 1, 1).to(_dev())
+    net.train()
+
+    def grads_of(fn):
+        for p in net.parameters():
+            p.grad = None
+        fn()
+        torch.cuda.synchronize()
+        return {n: p.grad.clone() for n, p in net.named_parameters()}
+    ga = grads_of(lambda: F.mse_loss(net(a).reshape(-1), a.y).backward())
+    gb = grads_of(lambda: F.mse_loss(net(b).reshape(-1), b.y).backward())
+    both = grads_of(lambda: (F.mse_loss(net(a).reshape(-1), a.y) + F.mse_loss(net(b).reshape(-1), b.y)).backward())
+    for n in ga:
+        np.testing.assert_allclose(both[n].cpu().numpy(), (ga[n] + gb[n]).cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
+    # accumulation: zeroed in place, then two backward passes
+    opt = torch.optim.SGD(net.parameters(), lr=0.0)
+    opt.zero_grad(set_to_none=False)
+    F.mse_loss(net(a).reshape(-1), a.y).backward()
+    F.mse_loss(net(b).reshape(-1), b.y).backward()
+    torch.cuda.synchronize()
+    for n, p in net.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), (ga[n] + gb[n]).cpu().numpy(), rtol=1e-5, atol=1e-6, err_msg=n)
+
+
+def test_outside_the_fused_kernels_the_launch_pair_runs():
+    """x.requires_grad (d loss / d x is the launch pair's), and a copy of the net starts with its own engine."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.foutnet import FoutNet
+    batch = synth.make_batch(0, 4).to(_dev())
+    torch.manual_seed(7)
+    net = FoutNet(32, 1, 1).to(_dev())
+    net.train()
+    out = net(batch)
+    assert _engine(net).last_path == "jacobian"
+    twin = copy.deepcopy(net)
+    assert twin.__dict__.get("_drgnn_engine") is None
+    batch2 = batch.clone()
+    batch2.x.requires_grad_(True)
+    out2 = twin(batch2)
+    assert _engine(twin).last_path is None
+    out2.sum().backward()
+    assert batch2.x.grad is not None and bool(torch.isfinite(batch2.x.grad).all())
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), out.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("net_name", ["GINet", "sGAT", "FoutNet"])
+def test_reference_epoch_loop_eager_and_captured(net_name):
+    """NeuralNet._epoch's loop body with torch.optim.Adam over model.parameters() (NeuralNet.py:183-184,489-506), five steps
+    eager against five steps of the native trainer (its Adam follows torch's arithmetic), then the same body recorded in
+    a hipGraph and replayed: the parameters after the replays equal the eager run's."""
+    import deeprank_gnn_amd.synthetic as synth
+    from test_gpu_parity import nets
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    batches = [synth.make_batch(16 * i, 16).to(_dev()) for i in range(5)]
+    torch.manual_seed(13)
+    net = nets()[net_name](32, 1, 1).to(_dev())
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0
+    start = copy.deepcopy(net.state_dict())
+    net.train()
+    opt = torch.optim.Adam(net.parameters(), lr=0.01)
+    for b in batches:
+        opt.zero_grad()
+        pred = net(b)
+        assert _engine(net).last_path == "jacobian"
+        loss = F.mse_loss(pred.reshape(-1), b.y)
+        loss.backward()
+        opt.step()
+    torch.cuda.synchronize()
+    eager = {k: v.clone() for k, v in net.state_dict().items()}
+    native = nets()[net_name](32, 1, 1).to(_dev())
+    native.load_state_dict(start)
+    if hasattr(native, "dropout"):
+        native.dropout = 0.0
+    tr = FusedTrainer(native, lr=0.01, task="reg")
+    for b in batches:
+        tr.train_step(b)
+    torch.cuda.synchronize()
+    for k, v in native.state_dict().items():
+        np.testing.assert_allclose(eager[k].cpu().numpy(), v.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+    # recorded: one graph per batch, the optimiser capturable
+    cap = nets()[net_name](32, 1, 1).to(_dev())
+    cap.load_state_dict(start)
+    if hasattr(cap, "dropout"):
+        cap.dropout = 0.0
+    cap.train()
+    copt = torch.optim.Adam(cap.parameters(), lr=0.01, capturable=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):      # warm-up on a side stream (optimiser state, engine buffers, workspaces)
+        for b in batches:
+            copt.zero_grad(set_to_none=True)
+            F.mse_loss(cap(b).reshape(-1), b.y).backward()
+            copt.step()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    cap.load_state_dict(start)
+    copt = torch.optim.Adam(cap.parameters(), lr=0.01, capturable=True)
+    with torch.cuda.stream(side):
+        copt.zero_grad(set_to_none=True)
+        F.mse_loss(cap(batches[0]).reshape(-1), batches[0].y).backward()
+        copt.step()                     # (state initialised outside the capture)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    cap.load_state_dict(start)
+    for st in copt.state.values():
+        st["step"].zero_(); st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+    graphs = []
+    for b in batches:
+        gr = torch.cuda.CUDAGraph()
+        copt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(gr):
+            F.mse_loss(cap(b).reshape(-1), b.y).backward()
+            copt.step()
+        graphs.append(gr)
+    cap.load_state_dict(start)
+    for st in copt.state.values():
+        st["step"].zero_(); st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+    for gr in graphs:
+        gr.replay()
+    torch.cuda.synchronize()
+    for k, v in cap.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), eager[k].cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
