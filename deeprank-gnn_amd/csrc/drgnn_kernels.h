@@ -684,13 +684,32 @@ DEV float update_head_sum_w(const UpdateArgs& u, int item, int first, int stride
             const int h = item / u.hR, r = item - h * u.hR;
             const float* dh = u.h.partials + h;
             const float* xr = u.readout + r;
-            for (int w = first; w < u.h.n_wg; w += stride) acc = fmaf(gw[w] * dh[(long)w * u.h.P], xr[(long)w * u.hR], acc);
+            // (all the loads of a lane's share in flight at once, as update_head_sum)
+            float va[16], vb[16], vc[16];
+            int w = first;
+            for (; w + 15 * stride < u.h.n_wg; w += 16 * stride) {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    va[k] = dh[(long)(w + k * stride) * u.h.P]; vb[k] = xr[(long)(w + k * stride) * u.hR]; vc[k] = gw[w + k * stride];
+                }
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc = fmaf(vc[k] * va[k], vb[k], acc);
+            }
+            for (; w < u.h.n_wg; w += stride) acc = fmaf(gw[w] * dh[(long)w * u.h.P], xr[(long)w * u.hR], acc);
             return acc;
         }
         item -= HR;
     }
     const float* src = u.h.partials + item;
-    for (int w = first; w < u.h.n_wg; w += stride) acc = fmaf(gw[w], src[(long)w * u.h.P], acc);
+    float v[16], c[16];
+    int w = first;
+    for (; w + 15 * stride < u.h.n_wg; w += 16 * stride) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k] = src[(long)(w + k * stride) * u.h.P]; c[k] = gw[w + k * stride]; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = fmaf(c[k], v[k], acc);
+    }
+    for (; w < u.h.n_wg; w += stride) acc = fmaf(gw[w], src[(long)w * u.h.P], acc);
     return acc;
 }
 struct GradArgs {
@@ -1023,6 +1042,7 @@ __global__ void __launch_bounds__(DRGNN_UPDATE_THREADS) k_update(UpdateArgs u) {
 // optionally weighted by its graph's d loss / d pred (the autograd boundary, include/drgnn.h), plus one block that clears the
 // ranges no kernel writes (GINet's dead attention parameters).  4 waves: interleaved quarters of the slabs, combined in fixed order.
 __global__ void __launch_bounds__(256) k_gradients(GradArgs ga) {
+    kernarg_touch_lines<DRGNN_KA_LINES(0, (int)sizeof(GradArgs))>(0);
     __shared__ float quarter[4][64];
     const UpdateArgs& u = ga.u;
     const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;

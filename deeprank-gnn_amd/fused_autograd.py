@@ -20,8 +20,8 @@ workgroup, serve this boundary in two ways (include/drgnn.h: DRGNN_TASK_GRAD, dr
 
 The topology workspace of the batch (CSR, consecutive clusters, pooled graph, level-0 aggregation tiles) is a lean + tiles
 build (DRGNN_TOPO_LEAN | DRGNN_TOPO_TILES), kept with the batch object while its index tensors are unchanged.  Buffers are
-grow-only per batch size; nothing is allocated per call except ``pred``.  Gradients land in one flat buffer the parameters'
-``.grad`` are views of.  No CPU path, and no silent other path: ``run`` returns None (the caller then takes the launch pair
+grow-only per batch size; per call only ``pred`` and one flat gradient buffer are allocated (cached-allocator blocks, no
+launch); the parameters' ``.grad`` become views of that buffer without a copy.  No CPU path, and no silent other path: ``run`` returns None (the caller then takes the launch pair
 of functional.net_body) only for shapes outside the fused kernels -- ``last_path`` says which one ran.
 """
 import ctypes
@@ -104,10 +104,12 @@ class StepEngine(object):
         if len(self.dead) > _lib.ZERO_RANGES:
             raise _lib.DrgnnError("more untouched parameters than drgnn_step_gradients clears")
         self.R, self.H, self.O = net.fc1.in_features, net.fc1.out_features, net.fc2.out_features
-        # two gradient buffers: a backward never writes into the one the parameters' .grad still alias (zero_grad(set_to_none=
-        # False) followed by autograd's in-place accumulation would otherwise add a buffer to itself)
-        self.flat_g = [torch.zeros(self.total, dtype=torch.float32, device=dev) for _ in range(2)]
-        self._grad_desc = [None, None]
+        # Every backward writes ONE fresh flat buffer (a cached-allocator block, no launch) and hands autograd fresh views of it:
+        # nobody else holds them, so AccumulateGrad adopts them as the parameters' .grad without a copy (16 copy launches per
+        # step otherwise), and a gradient still referenced somewhere -- a .grad kept by the caller, a sum over several forwards
+        # in flight inside autograd's input buffers -- is never written again.
+        self._shapes = [(self.offset[n], p.numel(), tuple(p.shape)) for n, p in named]
+        self._live_slots = None
         self.step2 = torch.zeros(4, dtype=torch.int32, device=dev)
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFF
         self._desc_key, self._desc, self._head_ptrs = None, None, None
@@ -117,6 +119,7 @@ class StepEngine(object):
         self._fwd_readout = {}     # per batch size: the readout of forward-only launches (an output nobody reads)
         self._topos = weakref.WeakKeyDictionary()
         self._pending = weakref.WeakSet()
+        self._uncommitted = False  # a training launch has written step2[1] and no slab sum has committed it yet
         self.plan_overrides = {}
         self.cache_topology = True
         self.last_path = None      # 'jacobian' / 'two-launch' / 'inference' / None (the caller's launch pair)
@@ -141,29 +144,26 @@ class StepEngine(object):
                 _lib.require_device(*self.params)
             self._desc = _describe(self.kind, n_feat, tuple(p.detach() for p in self.live), self.n_branch)
             self._desc_key = key
-            self._grad_desc = [None, None]
         return self._desc
 
-    def _grads_for(self, k, n_feat):
-        gd = self._grad_desc[k]
-        if gd is None or gd[0] != n_feat:
-            flat = self.flat_g[k]
-            lookup = dict(zip(self.names, self.params))
-            views = {n: flat[self.offset[n]:self.offset[n] + lookup[n].numel()].view(lookup[n].shape) for n in self.names}
-            by_id = {id(lookup[n]): views[n] for n in self.names}
-            live_grads = tuple(by_id[id(p)] for p in self.live)
-            g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-            g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-            for b, (l1, l2) in enumerate(_split(self.kind, live_grads, self.n_branch)):
-                _fill_grads(g1[b], self.kind, l1, n_feat, H1)
-                _fill_grads(g2[b], self.kind, l2, H1, H2)
-            zp = (ctypes.c_void_p * _lib.ZERO_RANGES)()
-            zl = (ctypes.c_int64 * _lib.ZERO_RANGES)()
-            for i, (off, n) in enumerate(self.dead):
-                zp[i], zl[i] = flat.data_ptr() + 4 * off, n
-            gd = self._grad_desc[k] = (n_feat, g1, g2, zp, zl, tuple(views[n] for n in self.names),
-                                       flat.data_ptr() + 4 * self.head_offset)
-        return gd
+    def _grads_for(self, flat, n_feat):
+        """(g_conv1, g_conv2, zero ranges, per-parameter views, head block address) of the flat gradient buffer ``flat``."""
+        views = tuple(flat[off:off + n].view(shape) for off, n, shape in self._shapes)
+        if self._live_slots is None:
+            index = {id(p): i for i, p in enumerate(self.params)}
+            self._live_slots = tuple(index[id(p)] for p in self.live)
+        live_grads = tuple(views[i] for i in self._live_slots)
+        g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+        g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+        for b, (l1, l2) in enumerate(_split(self.kind, live_grads, self.n_branch)):
+            _fill_grads(g1[b], self.kind, l1, n_feat, H1)
+            _fill_grads(g2[b], self.kind, l2, H1, H2)
+        zp = (ctypes.c_void_p * _lib.ZERO_RANGES)()
+        zl = (ctypes.c_int64 * _lib.ZERO_RANGES)()
+        base = flat.data_ptr()
+        for i, (off, n) in enumerate(self.dead):
+            zp[i], zl[i] = base + 4 * off, n
+        return g1, g2, zp, zl, views, base + 4 * self.head_offset
 
     def _head_desc(self, train, task, p_drop):
         hd = _lib.HeadDesc()
@@ -330,6 +330,11 @@ class StepEngine(object):
         pred = torch.empty((B, self.O), dtype=torch.float32, device=x.device)
         xchg = self._xchg_for(call.plan, B)
         if call.mode == "jacobian":
+            if self._uncommitted:
+                # a training launch whose backward has not run (yet): its step index was never committed, and a second launch
+                # with the same index would find the first one's exchange words carrying its own tag
+                self.step2[0:1].copy_(self.step2[1:2])
+            self._uncommitted = True
             (readout, partials, hp), slabs = self._buffers(call.plan, call.n_feat, B, call)
             ones = self._ones.get(B)
             if ones is None:
@@ -350,14 +355,6 @@ class StepEngine(object):
                                hints=call.hints[0])
         return pred
 
-    def _pick_grad_buffer(self):
-        for k in (0, 1):
-            lo = self.flat_g[k].data_ptr()
-            hi = lo + 4 * self.total
-            if not any(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.params):
-                return k
-        raise _lib.DrgnnError("both gradient buffers are aliased by parameter gradients")
-
     def _backward_launch(self, call, gpred):
         api, B = self.api, call.B
         if call.done:
@@ -365,8 +362,8 @@ class StepEngine(object):
         gpred = gpred.to(torch.float32).contiguous()
         stream = _lib.current_stream(call.x)
         desc = self._descs(call.n_feat)
-        k = self._pick_grad_buffer()
-        _, g1, g2, zp, zl, views, head_grad = self._grads_for(k, call.n_feat)
+        flat = torch.empty(self.total, dtype=torch.float32, device=self.device)
+        g1, g2, zp, zl, views, head_grad = self._grads_for(flat, call.n_feat)
         if call.mode == "jacobian":
             readout, partials, hp, slabs = call.bufs
             weight = gpred.view(-1)
@@ -382,6 +379,7 @@ class StepEngine(object):
             weight = None
         api.step_gradients(desc, partials, B, g1, g2, hp, readout, self.R, self.H, self.O, head_grad, weight, zp, zl,
                            len(self.dead), self.step2, slabs, stream)
+        self._uncommitted = False
         call.done = True
         return views
 

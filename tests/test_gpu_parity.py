@@ -163,12 +163,20 @@ def test_global_scratch_path_matches_lds_path():
     batch = synth.make_batch(0, 6, n_nodes=80, n_pairs=150).to(dev())
     params = cpu_ref.init_params("sGAT", 32, 1, 1, seed=7)
     net = build("sGAT", params, 1)
+    # (the launch pair of functional.net_body: what runs outside the fused step kernels' LDS budget)
     topo = Topology.from_batch(batch)
-    a = net(batch, topo=topo)
+    a = net.body(batch, topo=topo)
     topo2 = Topology.from_batch(batch)
     topo2.max_nodes = 0                                 # forces the global-scratch variant
-    b = net(batch, topo=topo2)
+    b = net.body(batch, topo=topo2)
     assert torch.equal(a, b)
+    # ... and the whole net through it (unknown bounds: no fused step) against the fused step kernels' predictions
+    from deeprank_gnn_amd.fused_autograd import engine_for
+    fused = net(batch, topo=topo)
+    assert engine_for(net).last_path == "jacobian"
+    pair = net(batch, topo=topo2)
+    assert engine_for(net).last_path is None
+    np.testing.assert_allclose(fused.detach().cpu().numpy(), pair.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
 
 
 def test_batch_invariance():
