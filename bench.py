@@ -1193,13 +1193,20 @@ def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=4):
         return {"graphs_per_s": GRAPHS_PER_GPU / (best * 1e-6) * (n_graphs * passes / float(nb * GRAPHS_PER_GPU)),
                 "us_per_batch": best, "us_per_batch_runs": [round(r, 2) for r in runs],
                 "batches_per_epoch": nb, "last_epoch_loss_sum": sums[-1]}
-    out = run(False, 1)
+    # the top-level entry is what NeuralNet.train runs by default (cached_topology = "auto": the per-graph topology built once
+    # at upload whenever it fits the budget -- this set's does); `rebuilt_topology` = NeuralNet.cached_topology = False
+    out = run(True, 1)
     out.update({"epochs": epochs, "resident_graphs": n_graphs, "batch": GRAPHS_PER_GPU, "net": net_name,
-                "what": "shuffled epochs via drgnn_train_epoch (native loop, mini-batches read in place from the resident "
-                        "set, topology rebuilt for every mini-batch; epoch e+1 enqueued while epoch e runs, outputs left on "
-                        "the device)"})
+                "topology": "cached per graph, built once at upload (NeuralNet's default, cached_topology = 'auto')",
+                "topology_cache_MiB": round(sum(t.numel() * t.element_size() for t in (
+                    rs.topology_cache(need_weights=(net_name == "sGAT")).topo.ws_i32,
+                    rs.topology_cache(need_weights=(net_name == "sGAT")).topo.tiles) if t is not None) / 2 ** 20, 1),
+                "what": "shuffled epochs via drgnn_train_epoch (native loop; every mini-batch a different random selection of the "
+                        "resident set's graphs, stepped straight out of the set's cached topology; epoch e+1 enqueued while epoch "
+                        "e runs, outputs left on the device)"})
     for key, cached, passes, what in (
-            ("cached_topology", True, 1, "same loop, declared cached-topology mode (per-graph topology built once at upload)"),
+            ("rebuilt_topology", False, 1, "same loop, topology rebuilt for every mini-batch by the builder workgroups co-launched "
+                                           "with the previous step (NeuralNet.cached_topology = False; round 5's top-level entry)"),
             ("long_epochs", False, 16, "1024 mini-batches per epoch (16 shuffled passes over the set enqueued as one epoch), rebuilt"),
             ("long_epochs_cached", True, 16, "1024 mini-batches per epoch, cached topology")):
         try:

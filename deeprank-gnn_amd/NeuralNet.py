@@ -167,9 +167,14 @@ class NeuralNet(object):
         self.data = {}
         self._resident_sets = {}
         self.native_epoch = True      # False: step mini-batch by mini-batch from Python (same results)
-        # declared mode: per-graph topology built once when a set is uploaded and read in place by every step (no
-        # builder work per mini-batch); False rebuilds every mini-batch's topology as the reference does per forward
-        self.cached_topology = False
+        # Per-graph topology (CSR, consecutive clusters, pooled graph, aggregation tiles) depends on the graph alone -- the
+        # reference itself precomputes the clustering once per dataset (DataSet.py:45-88) and redoes only the index work in every
+        # forward (community_pooling.py:25-30,197-216).  "auto" (default): build it ONCE when a set is uploaded and let every
+        # step read it in place (no builder work per mini-batch: same results bit for bit, tests/test_gpu_epoch.py) whenever
+        # the cache fits ``topology_cache_budget`` bytes of HBM, else rebuild per mini-batch; True / False force either.
+        self.cached_topology = "auto"
+        self.topology_cache_budget = 32 << 30       # bytes per resident set (an MI355X holds 288 GB)
+        self._cache_choice = {}
         self.exported = []            # (epoch, file) of the epoch data written so far
 
     # ------------------------------------------------------------------------------
@@ -188,6 +193,26 @@ class NeuralNet(object):
             for key in [k for k in self._resident_sets if k not in keep][:-2]:
                 del self._resident_sets[key]                       # test sets of earlier test() calls
         return rs
+
+    def _use_cache(self, rs):
+        """Whether the steps over the resident set ``rs`` read its cached topology (``cached_topology``; logged once per set)."""
+        mode = self.cached_topology
+        if mode is True or mode is False:
+            return mode
+        key = id(rs)
+        choice = self._cache_choice.get(key)
+        if choice is None:
+            need_w = self.trainer.kind == _lib.SGAT
+            ok = bool(rs.has_c0 and rs.has_c1) and not (need_w and rs.edge_attr is None)
+            nbytes = rs.topology_cache_bytes(need_weights=need_w) if ok else 0
+            choice = ok and nbytes <= int(self.topology_cache_budget)
+            self._cache_choice[key] = choice
+            import logging
+            logging.getLogger("deeprank_gnn_amd").info(
+                "resident set of %d graphs: topology %s (cache %.1f MiB, budget %.1f MiB)", len(rs),
+                "cached per graph, built once" if choice else "rebuilt per mini-batch", nbytes / 2 ** 20,
+                int(self.topology_cache_budget) / 2 ** 20)
+        return choice
 
     def _batches(self, dataset, indices, shuffle):
         order = [int(i) for i in indices]
@@ -280,7 +305,7 @@ class NeuralNet(object):
             order = torch.as_tensor([int(i) for i in self.train_index], dtype=torch.int64)
             if self.shuffle:
                 order = order[torch.randperm(order.numel())]
-            done = self.trainer.train_epoch(rs, order, self.batch_size, cached=self.cached_topology)
+            done = self.trainer.train_epoch(rs, order, self.batch_size, cached=self._use_cache(rs))
             if done is not None:
                 losses, pred = done
                 store['_pred'].append(pred)
@@ -344,12 +369,12 @@ class NeuralNet(object):
         if native:
             local_bs = len(parts[0])
             mine = [g for p in parts for g in p]
-            ok = self.trainer.train_epoch(rs, mine, local_bs, cached=self.cached_topology, dp_global_sizes=sizes, probe=True)
+            ok = self.trainer.train_epoch(rs, mine, local_bs, cached=self._use_cache(rs), dp_global_sizes=sizes, probe=True)
             flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if on_dev else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             native = bool(int(flag.item()))
         if native:
-            done = self.trainer.train_epoch(rs, mine, local_bs, cached=self.cached_topology, dp_global_sizes=sizes)
+            done = self.trainer.train_epoch(rs, mine, local_bs, cached=self._use_cache(rs), dp_global_sizes=sizes)
             if done is None:       # cannot happen after a successful probe; never continue with mismatched collectives
                 raise _lib.DrgnnError("the native epoch loop refused a configuration its probe had accepted")
             losses, pred = done
@@ -399,7 +424,7 @@ class NeuralNet(object):
         order = [int(i) for i in indices]
         if self.native_epoch and order:
             rs = self._resident(dataset)
-            pred = self.trainer.predict_epoch(rs, order, self.batch_size, cached=self.cached_topology)
+            pred = self.trainer.predict_epoch(rs, order, self.batch_size, cached=self._use_cache(rs))
             if pred is not None:
                 store['_pred'].append(pred)
                 store['mol'] += [rs.mols[i] for i in order]

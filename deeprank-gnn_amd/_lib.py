@@ -88,7 +88,7 @@ class EpochPlan(ctypes.Structure):
                 ("flat_param", _vp), ("flat_grad", _vp), ("exp_avg", _vp), ("exp_avg_sq", _vp), ("n_param", _c_i64),
                 ("step2", _vp),
                 ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
-                ("cache", _vp), ("exchange", _vp), ("exchange_user", _vp), ("step_overrides", _vp)]
+                ("cache", _vp), ("exchange", _vp), ("exchange_user", _vp), ("step_overrides", _vp), ("last_loss", _vp)]
 
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p)

@@ -72,7 +72,7 @@ int64_t drgnn_topology_lds_bytes(int32_t max_nodes, int32_t max_edges) {
 int64_t drgnn_topology_tiles_elems(int64_t n_nodes, int32_t n_feat) {
     if (n_nodes < 0 || n_feat <= 0) return 0;
     const int64_t TF = ((int64_t)n_feat + 3) & ~(int64_t)3;      // S [n][TF] | D [n] | C [n] | (F % 4 != 0) X [n][TF]
-    return n_nodes * (TF + 2) + ((n_feat & 3) ? n_nodes * TF : 0);
+    return (n_feat & 3) ? drgnn_tiles_x_off(n_nodes, TF) + n_nodes * TF : n_nodes * (TF + 2);
 }
 int32_t drgnn_topology_tiles_ok(int32_t max_nodes, int32_t max_edges, int32_t n_feat) {
     return topo_tiles_shape_ok(max_nodes, max_edges, n_feat) ? 1 : 0;
@@ -974,6 +974,12 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
     // the autograd boundary (an upstream gradient instead of a target, a forward with the dropout mask of the step) is the
     // aggregation-first kernels': the product-first family predates it
     if ((hd->task == DRGNN_TASK_GRAD || hd->train == 2) && !k.lean_ok) return DRGNN_E_ARG;
+    // a plan handed along with its `out` members filled (drgnn_net_step_plan) is a commitment: the launch takes the kernel
+    // family, width class and slab layout the caller planned (and sized its buffers / made its assertions from) or fails --
+    // never a silent third layout (a plan of another mode -- training against inference -- is only a carrier of overrides)
+    if (plan && plan->family != DRGNN_STEP_FAMILY_NONE && (plan->train != 0) == q.train &&
+        (plan->family != k.family || plan->width != k.width || plan->cls != k.cls || plan->slabs_per_graph != k.slabs))
+        return DRGNN_E_CAPACITY;
     if (co_ok && k.builder_roles == 0) co_ok = false;      // the builder gets a launch of its own
     if (co_ok) T.roles = k.builder_roles;
     const bool one_wg = (kind == DRGNN_GINET) && k.wgs == 1;
@@ -1085,7 +1091,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             Q.pf_ids = hints->next_ids; Q.pf_n = (int)hints->n_next; Q.pf_graphs = a.ws_graphs;
             const int TF = (F + 3) & ~3;
             Q.pf_tiles = a.tiles; Q.pf_f = TF; Q.pf_tile_nodes = n_nodes;
-            Q.pf_x = (kind == DRGNN_GINET) ? nullptr : (F & 3) ? a.tiles + n_nodes * (TF + 2) : x;
+            Q.pf_x = (kind == DRGNN_GINET) ? nullptr : (F & 3) ? a.tiles + drgnn_tiles_x_off(n_nodes, TF) : x;
             Q.pf_coef = (kind != DRGNN_GINET) ? 1 : 0;
             Q.pf_y = full_step ? target : nullptr; Q.pf_y_bytes = (hd->task == DRGNN_TASK_REG) ? 4 : 8;
             if (Q.pf_tiles != nullptr) extra = Q.pf_n; else Q.pf_ids = nullptr;
@@ -1337,7 +1343,7 @@ static int update_impl(int32_t slabs_per_graph, const drgnn_net_desc* net, const
                        int64_t head_offset, float* flat_param,
                        float* flat_grad, float* exp_avg, float* exp_avg_sq, int64_t n_param,
                        int32_t* step, float* loss, float lr, float beta1, float beta2, float eps,
-                       int32_t apply_adam, void* stream_) {
+                       int32_t apply_adam, void* stream_, float* loss2 = nullptr) {
     int rc = net_check(net);
     if (rc) return rc;
     if (!conv_partials || !g_conv1 || !g_conv2 || !head_partials || !flat_grad) return DRGNN_E_ARG;
@@ -1361,6 +1367,7 @@ static int update_impl(int32_t slabs_per_graph, const drgnn_net_desc* net, const
     u.h.grad = flat_grad + head_offset; u.h.loss = loss; u.h.step = nullptr;
     u.readout = readout; u.hR = R; u.hH = H;
     u.step2 = readout ? step : nullptr;
+    u.loss2 = loss ? loss2 : nullptr;
     u.ad.param = flat_param; u.ad.grad = flat_grad; u.ad.exp_avg = exp_avg; u.ad.exp_avg_sq = exp_avg_sq;
     u.ad.step = (readout && step) ? step + 1 : step; u.ad.n = n_param;
     u.ad.lr = lr; u.ad.beta1 = beta1; u.ad.beta2 = beta2; u.ad.eps = eps; u.ad.weight_decay = 0.0f;
@@ -1858,9 +1865,12 @@ static int epoch_update(const drgnn_epoch_plan* p, const EpochCarve& c, int64_t 
                         int slabs_per_graph = 0) {
     const drgnn_head_desc* hd = p->head;
     const int fused = p->exchange ? 0 : 1;
-    int rc = drgnn_step_update(p->net, c.partials, B, p->g_conv1, p->g_conv2, c.head_partials, c.readout, hd->R, hd->H,
-                               hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
-                               p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, fused, slabs_per_graph, stream);
+    // (the last mini-batch of the call also writes the caller's loss word, drgnn_epoch_plan.last_loss)
+    const int64_t nb = (p->n_ids + p->batch_size - 1) / p->batch_size;
+    int rc = update_impl(slabs_per_graph, p->net, c.partials, B, p->g_conv1, p->g_conv2, c.head_partials, B, c.readout, hd->R, hd->H,
+                         hd->O, p->head_offset, p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->n_param,
+                         p->step2, losses + k, p->lr, p->beta1, p->beta2, p->eps, fused, stream,
+                         (k == nb - 1) ? p->last_loss : nullptr);
     if (rc || fused) return rc;
     if ((rc = p->exchange(p->exchange_user, k, B, stream))) return rc;
     return drgnn_adam_step(p->flat_param, p->flat_grad, p->exp_avg, p->exp_avg_sq, p->step2, p->n_param, p->lr, p->beta1,

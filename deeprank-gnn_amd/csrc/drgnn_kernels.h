@@ -214,7 +214,7 @@ DEV void tiles_block(const TilesArgs& a, int g) {
     float* ts = a.tiles + (long long)n0 * TF;
     float* td = a.tiles + a.n_nodes * TF + n0;
     float* tc = td + a.n_nodes;
-    float* tx = (F & 3) ? a.tiles + a.n_nodes * (TF + 2) + (long long)n0 * TF : nullptr;
+    float* tx = (F & 3) ? a.tiles + drgnn_tiles_x_off(a.n_nodes, TF) + (long long)n0 * TF : nullptr;
     FOR_TID(pad, N * (TF - F)) {
         const int i = pad / (TF - F), f = F + pad % (TF - F);
         ts[(long long)i * TF + f] = 0.0f;
@@ -632,6 +632,7 @@ struct UpdateArgs {
     const float* readout;   // [n_wg][R] or null (legacy slabs that already hold dW_fc1)
     int hR, hH;
     int32_t* step2;         // non-null: commit step2[0] = step2[1] (the step index Adam just used)
+    float* loss2;           // optional second destination of the batch loss (the epoch loop's last mini-batch: the trainer's loss word)
 };
 
 DEV void update_store(const UpdateArgs& u, float* dst, float g) {
@@ -723,7 +724,7 @@ struct GradArgs {
 DEV void update_head_store(const UpdateArgs& u, int item, float acc) {
     const int n_grad = update_head_items(u) - 1;
     if (item < n_grad) update_store(u, u.h.grad + item, acc);
-    else if (item == n_grad && u.h.loss) u.h.loss[0] = acc;
+    else if (item == n_grad && u.h.loss) { u.h.loss[0] = acc; if (u.loss2) u.loss2[0] = acc; }
 }
 
 #ifndef DRGNN_EMU
@@ -1033,6 +1034,7 @@ __global__ void __launch_bounds__(DRGNN_UPDATE_THREADS) k_update(UpdateArgs u) {
             if (upd) adam_apply(u.ad, idx, g, pre);
         } else if (!conv && live && item == n_grad && u.h.loss) {
             u.h.loss[0] = g;
+            if (u.loss2) u.loss2[0] = g;
         }
     }
     // nobody reads step2[0] in this launch (Adam reads step2[1]): safe to commit it here

@@ -598,7 +598,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     // the graph's x rows and aggregation tiles (node order).  Rows of the tiles are TF = pad4(F) floats long (zero padded by the
     // builder); with F % 4 != 0 the x rows come from the tiles' padded copy instead of the (unaligned) input
     const int TF = (F + 3) & ~3;
-    const float* xgl = (F & 3) ? a.tiles + a.tile_nodes * (TF + 2) + (long)d.n0 * TF : a.x + (long)d.n0 * F;
+    const float* xgl = (F & 3) ? a.tiles + drgnn_tiles_x_off(a.tile_nodes, TF) + (long)d.n0 * TF : a.x + (long)d.n0 * F;
     const float* sgl = a.tiles + (long)d.n0 * TF;
     const float* tdg = a.tiles + a.tile_nodes * TF + d.n0;
     const float* tcg = tdg + a.tile_nodes;

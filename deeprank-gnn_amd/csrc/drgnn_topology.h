@@ -11,6 +11,11 @@
 #include "drgnn_rt.h"
 #include "../../include/drgnn.h"
 
+// element offset of the padded X copy inside an aggregation-tiles buffer laid out for n nodes (include/drgnn.h, DRGNN_TOPO_TILES:
+// S [n][TF] | D [n] | C [n] | X [n][TF]): behind D and C, rounded up to a multiple of 4 floats so that X rows are 16-byte aligned
+// whatever the parity of n (the step kernels read them with 128-bit requests)
+HD long long drgnn_tiles_x_off(long long n, int TF) { return n * TF + ((2 * n + 3) & ~3LL); }
+
 #ifdef DRGNN_EMU
 #define LAMBDA_DEV
 #else
@@ -937,7 +942,7 @@ DEV TopoTile topo_tile_of(const TopoArgs& a, const TopoSrc& src, int n0, float* 
     t.ts = (t.F > 0) ? a.tiles + (long long)n0 * t.TF : nullptr;
     t.td = (t.F > 0) ? a.tiles + a.tile_nodes * t.TF + n0 : nullptr;
     t.tc = (t.F > 0) ? t.td + a.tile_nodes : nullptr;
-    t.tx = (t.F > 0 && (t.F & 3)) ? a.tiles + a.tile_nodes * (t.TF + 2) + (long long)n0 * t.TF : nullptr;
+    t.tx = (t.F > 0 && (t.F & 3)) ? a.tiles + drgnn_tiles_x_off(a.tile_nodes, t.TF) + (long long)n0 * t.TF : nullptr;
     t.xs = xs;
     return t;
 }

@@ -144,6 +144,16 @@ class ResidentGraphSet(object):
             cache = self._topo_cache[key] = TopologyCache(self, key)
         return cache
 
+    def topology_cache_bytes(self, need_weights=False):
+        """HBM bytes ``topology_cache`` takes for this set (workspace + edge weights + aggregation tiles); 0 once it exists."""
+        key = bool(need_weights and self.has_attr)
+        if getattr(self, "_topo_cache", {}).get(key) is not None:
+            return 0
+        G = len(self)
+        N, E = int(self.node_ptr[-1]), int(self.edge_ptr[-1])
+        off_i, off_f = self.api.topology_layout(N, E, G)
+        return 4 * (int(off_i[-1]) + (int(off_f[-1]) if key else 0) + int(self.api.topology_tiles_elems(N, self.n_feat)) + 3 * (G + 1))
+
     # -- native container: the uploaded image, optionally with the cached topology ------------------------------
     def save_native(self, path, with_topology=True, need_weights=None):
         """Write the set as ONE native container (container.py): sections ``set/*`` = the concatenated arrays exactly as

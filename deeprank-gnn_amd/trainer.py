@@ -80,7 +80,6 @@ class FusedTrainer(object):
         self._desc_cache, self._slab_cache = {}, {}
         self._epoch_scratch = None
         self._loss_buf = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._loss_pending = None
         self.offset = {}
         off = 0
         with torch.no_grad():
@@ -108,13 +107,9 @@ class FusedTrainer(object):
     # ---------------------------------------------------------------------------
     @property
     def loss(self):
-        """[1] device tensor: the loss of the last training step (one fixed buffer -- recorded hipGraphs keep its address).
-        After ``train_epoch`` the last mini-batch's loss is copied in on first access (stream-ordered behind the epoch)."""
-        src = self._loss_pending
-        if src is not None:
-            self._loss_pending = None
-            if not (self._loss_buf.is_cuda and torch.cuda.is_current_stream_capturing()):
-                self._loss_buf.copy_(src)
+        """[1] device tensor: the loss of the last training step, ONE fixed buffer (recorded hipGraphs keep its address; a
+        reference to it stays current).  Every update launch writes it -- ``train_step`` directly, ``train_epoch`` through its
+        last mini-batch's update launch (drgnn_epoch_plan.last_loss) -- on the stream of that launch: no lazy state."""
         return self._loss_buf
 
     def _head_desc(self, train):
@@ -238,6 +233,7 @@ class FusedTrainer(object):
         topo_flags = self._usable_flags(topo, x)
         if (int(getattr(topo, "flags", 0)) & _lib.TOPO_TILES) and not (topo_flags & _lib.TOPO_TILES) and \
                 self._tiles_match(topo) and getattr(topo, "tiles", None) is not None and \
+                getattr(topo, "_inputs", None) is not None and \
                 (x.shape[1] % 4 != 0 or x.data_ptr() % 16 == 0) and tuple(x.shape) == tuple(topo.x.shape):
             # the tiles were formed from other node features than the ones being stepped (x replaced or modified in place
             # since the build): form them again from this x (own launch, same stream)
@@ -615,6 +611,8 @@ class FusedTrainer(object):
         if self.plan_overrides:
             ov = _lib.StepPlan()
             for key, val in self.plan_overrides.items():
+                if key not in _lib.StepPlan.OVERRIDES:
+                    raise KeyError("unknown step-plan override %r" % (key,))
                 setattr(ov, key, int(val))
             plan.step_overrides = ctypes.addressof(ov)
         callback = None
@@ -658,6 +656,8 @@ class FusedTrainer(object):
                     plan.host_ids = ids_host.ctypes.data + 4 * lo
                     plan.n_ids = hi - lo
                     self._dp_first_batch = c0
+                # the last mini-batch of the LAST piece writes the trainer's loss word as well
+                plan.last_loss = self._loss_buf.data_ptr() if (c1 == nb and not inference) else None
                 if dev.type == "cuda" and len(in_flight) >= 2:
                     in_flight.pop(0).synchronize()
                 self.api.train_epoch(plan, scratch, pred[lo:], losses[c0:], stream)
@@ -675,7 +675,6 @@ class FusedTrainer(object):
         if not inference:
             self.last_pred = pred[(nb - 1) * batch_size:]
             self.last_batch_size = n - (nb - 1) * batch_size
-            self._loss_pending = losses[nb - 1:nb]      # (copied into ``loss`` when somebody looks: 4.6 us per epoch otherwise)
         return losses, pred
 
     # -- torch.optim.Adam compatible optimiser state --------------------------------------

@@ -356,7 +356,8 @@ typedef struct drgnn_topology_request {
  *     S [n][TF]  S_i = sum over the edges e = (i, j) in edge-id order of [w_e] x_j     (w_e: with edge weights only)
  *     D [n]      1 / deg_i (without weights: 0 for an isolated node; with weights: 1 / max(deg_i, 1))
  *     C [n]      with weights: mean edge weight of the row (sum_e w_e) D_i; without: 1
- *     X [n][TF]  only when F % 4 != 0: the node features, rows zero padded (what sGAT / FoutNet multiply with their self weights)
+ *     X [n][TF]  only when F % 4 != 0: the node features, rows zero padded (what sGAT / FoutNet multiply with their self weights);
+ *                starts at element n TF + (2 n rounded up to a multiple of 4): 16-byte aligned rows whatever the parity of n
  * GINetConvLayer (ginet.py:50-73) is relu(S W); FoutLayer (foutnet.py:56-82) relu(D (S Wn) + x Wc + b); sGraphAttentionLayer
  * (sGAT.py:62-93) relu(D (S Wn) + C (x Ws) + b).  Needs drgnn_topology_tiles_ok() and, when F % 4 == 0, 16-byte aligned x. */
 #define DRGNN_TOPO_TILES 4
@@ -667,6 +668,9 @@ typedef struct drgnn_epoch_plan {
     drgnn_exchange_fn exchange; void* exchange_user;
     /* optional: the override members of this plan apply to every step launch of the loop (tests, A/B runs) */
     const drgnn_step_plan* step_overrides;
+    /* optional: one more destination of the LAST mini-batch's loss (its update launch writes losses[n_batches - 1] and this
+     * word): a trainer's fixed "loss of the last step" word stays current without a copy behind the epoch */
+    float* last_loss;
 } drgnn_epoch_plan;
 int64_t drgnn_train_epoch_scratch_bytes(const drgnn_epoch_plan* plan);
 int drgnn_train_epoch(const drgnn_epoch_plan* plan, void* scratch, int64_t scratch_bytes, float* pred,

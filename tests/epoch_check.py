@@ -28,6 +28,7 @@ def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=
     tr_a = FusedTrainer(net, lr=1e-2, task=task, api=api, seed=7)
     tr_b = FusedTrainer(copy.deepcopy(net), lr=1e-2, task=task, api=api, seed=7)
     rng = np.random.default_rng(seed)
+    held_loss = tr_a.loss
     for _ in range(epochs):
         order = rng.permutation(len(graphs)).tolist()
         got = tr_a.train_epoch(rs, order, batch_size, cached=cached)
@@ -39,11 +40,12 @@ def check_epoch(Net, graphs, n_feat, task, device, batch_size, api=None, epochs=
             want_l.append(float(tr_b.train_step(b)))
             want_p.append(tr_b.last_pred.detach().cpu().clone())
         want_p = torch.cat(want_p)
-        # trainer.loss after an epoch: the LAST mini-batch's loss (copied in when read: no launch at the epoch boundary), in
-        # the one buffer the single-step launches write (recorded hipGraphs keep its address)
+        # trainer.loss after an epoch: the LAST mini-batch's loss, written by that mini-batch's update launch itself
+        # (drgnn_epoch_plan.last_loss: no copy, no lazy state) into the one buffer the single-step launches write -- a reference
+        # taken BEFORE the epoch sees it (recorded hipGraphs and callers keep the buffer's address)
         buf = tr_a.loss
-        assert buf.data_ptr() == tr_a._loss_buf.data_ptr() and tr_a._loss_pending is None
-        assert float(buf) == float(losses[-1])
+        assert buf.data_ptr() == tr_a._loss_buf.data_ptr() and buf is held_loss
+        assert float(held_loss) == float(losses[-1])
         if exact:
             assert losses.cpu().tolist() == want_l
             assert torch.equal(pred.cpu(), want_p)

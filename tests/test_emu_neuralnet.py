@@ -134,3 +134,29 @@ def test_resident_batches_train_like_host_collated_batches(tmp_path):
     np.testing.assert_allclose(nn.train_loss, losses, rtol=1e-6)
     np.testing.assert_allclose(nn.data['train']['outputs'], outs, rtol=1e-6)
     assert nn.data['train']['mol'] == [twin.dataset.mols[i] for i in twin.train_index]
+
+
+def test_cached_topology_is_the_default_and_changes_nothing(tmp_path):
+    """``cached_topology = "auto"``: the per-graph topology is built once per resident set when it fits the budget (the
+    reference precomputes its clustering once per dataset too, DataSet.py:45-88), else rebuilt per mini-batch -- and either
+    way the training run is the same, bit for bit."""
+    runs = {}
+    for mode in ("auto", False, "auto-no-budget"):
+        torch.manual_seed(2)
+        np.random.seed(2)
+        nn = NeuralNet(DB, GINet, node_feature=NODE_FEATURES, edge_feature=['dist'], target='irmsd', batch_size=4,
+                       percent=[1.0, 0.0], shuffle=False, outdir=str(tmp_path), _api=emu(), device='cpu')
+        nn.model.dropout = 0.0
+        assert nn.cached_topology == "auto"
+        if mode is False:
+            nn.cached_topology = False
+        elif mode == "auto-no-budget":
+            nn.topology_cache_budget = 1024
+        rs = nn._resident(nn.dataset)
+        assert nn._use_cache(rs) == (mode == "auto")
+        nn.train(nepoch=2, validate=False)
+        runs[mode] = (list(nn.train_loss), {k: v.clone() for k, v in nn.model.state_dict().items()})
+    for mode in (False, "auto-no-budget"):
+        assert runs[mode][0] == runs["auto"][0]
+        for k, v in runs["auto"][1].items():
+            assert torch.equal(v, runs[mode][1][k]), k

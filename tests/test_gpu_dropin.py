@@ -313,3 +313,28 @@ def test_reference_epoch_loop_eager_and_captured(net_name):
     # turns a last-bit difference of a tiny gradient into 1e-4 of an update; lr 0.01, five steps)
     for k, v in cap.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), eager[k].cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("net_name", ["sGAT", "FoutNet"])
+def test_feature_count_not_a_multiple_of_four_on_an_odd_node_total(net_name):
+    """7 features (rows padded to 8 floats in the tiles' X copy) on 5 x 45 = 225 nodes: the X copy starts at a multiple of 4 floats
+    whatever the parity of the node total, so the step kernels' 128-bit row loads are aligned."""
+    import deeprank_gnn_amd.synthetic as synth
+    from test_gpu_parity import nets
+    batch = synth.make_batch(4, 5, n_nodes=45, n_pairs=80, n_feat=7, n_c1=4, n_internal=10).to(_dev())
+    assert batch.x.shape[0] % 2 == 1
+    torch.manual_seed(9)
+    net = nets()[net_name](7, 1, 1).to(_dev())
+    net.train()
+    fn = lambda o: F.mse_loss(o.reshape(-1), batch.y)           # noqa: E731
+    ref_out, ref = _legacy_grads(net, batch, fn)
+    for p in net.parameters():
+        p.grad = None
+    out = net(batch)
+    assert _engine(net).last_path == "jacobian"
+    fn(out).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    for n, p in net.named_parameters():
+        r = ref[n].cpu().numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=n)

@@ -115,6 +115,11 @@ def test_net_vs_reference_golden(fname):
     readout = net.body(batch, topo)
     check(fname + " readout", readout.detach().cpu().numpy(), g["readout"], lambda: lazy.traced("readout"), stats)
     out = net(batch)                                   # default path: builds its own topology
+    # ... and runs on the aggregation-first step kernels (fused_autograd), like test_fused_step_vs_reference_golden's launches
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.fused_autograd import engine_for
+    eng = engine_for(net)
+    assert eng.last_path == ("jacobian" if out.shape[1] == 1 else "two-launch") and eng.last_plan.family == _lib.STEP_FAMILY_AGGREGATE
     target = target_cpu.to(dev())
     loss = F.mse_loss(out.reshape(-1), target) if task == "reg" else F.cross_entropy(out, target)
     loss.backward()
@@ -249,6 +254,7 @@ def test_aggregation_tiles_on_the_device(weights, lean):
     for batch_cpu in (synth.make_batch(0, 64), synth.make_batch(3, 5, n_nodes=37, n_pairs=60, n_feat=8, n_c1=4, n_internal=10),
                       synth.make_batch(0, 170, n_nodes=20, n_pairs=30, n_feat=4, n_c1=3, n_internal=6),
                       synth.make_batch(7, 6, n_nodes=45, n_pairs=80, n_feat=7, n_c1=4, n_internal=10),      # (rows padded to 8 floats)
+                      synth.make_batch(4, 5, n_nodes=45, n_pairs=80, n_feat=7, n_c1=4, n_internal=10),      # (an ODD node total: 225)
                       synth.make_batch(1, 9, n_nodes=132, n_pairs=300, n_feat=26, n_c1=9, n_internal=60)):  # (... to 28)
         batch = batch_cpu.clone().to(dev)
         topo = Topology.from_batch(batch, need_weights=weights, flags=flags)

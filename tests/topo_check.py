@@ -156,6 +156,16 @@ def check_tiles(topo, batch, weights):
     else:
         np.testing.assert_allclose(D, np.where(deg > 0, 1.0 / np.maximum(deg, 1.0), 0.0), rtol=1e-6)
         np.testing.assert_array_equal(C, np.ones(n, dtype=np.float32))
+    F = x.shape[1]
+    if F % 4:
+        # the padded copy of the node features (what sGAT / FoutNet multiply with their self weights when rows are not multiples of
+        # 16 bytes): behind D and C at a multiple of 4 floats -- 16-byte aligned rows whatever the parity of n (include/drgnn.h)
+        TF = (F + 3) // 4 * 4
+        off = n * TF + (2 * n + 3) // 4 * 4
+        assert (topo.tiles.data_ptr() + 4 * off) % 16 == 0
+        X = topo.tiles[off:off + n * TF].view(n, TF).cpu().numpy()
+        np.testing.assert_array_equal(X[:, :F], batch.x.cpu().numpy())
+        np.testing.assert_array_equal(X[:, F:], np.zeros((n, TF - F), dtype=np.float32))
     # IHORD is the inverse of HORD, graph by graph
     nptr = topo.array("NPTR").cpu().numpy()
     hord, ihord = topo.array("HORD").cpu().numpy(), topo.array("IHORD").cpu().numpy()
