@@ -80,6 +80,8 @@ class StepEngine(object):
         self.convs = convs
         named = list(net.named_parameters())
         self.names = [n for n, _ in named]
+        owner, _, self.first_name = self.names[0].rpartition(".")
+        self._first_owner = weakref.proxy(net.get_submodule(owner) if owner else net)
         self.params = [p for _, p in named]
         dev = self.params[0].device
         self.device = dev
@@ -109,10 +111,13 @@ class StepEngine(object):
         # step otherwise), and a gradient still referenced somewhere -- a .grad kept by the caller, a sum over several forwards
         # in flight inside autograd's input buffers -- is never written again.
         self._shapes = [(self.offset[n], p.numel(), tuple(p.shape)) for n, p in named]
+        self._sizes = [n for _, n, _ in self._shapes]
+        self._view_shapes = [None if len(shape) == 1 else shape for _, _, shape in self._shapes]
         self._live_slots = None
+        self._grad_tpl = {}
         self.step2 = torch.zeros(4, dtype=torch.int32, device=dev)
         self.seed = int(torch.initial_seed()) & 0xFFFFFFFF
-        self._desc_key, self._desc, self._head_ptrs = None, None, None
+        self._desc_key, self._desc, self._heads = None, None, {}
         self._bufs = {}            # (B, n_feat, slabs) -> [readout, partials, head slabs, owner weakref]
         self._xchg = {}
         self._ones = {}
@@ -144,39 +149,56 @@ class StepEngine(object):
                 _lib.require_device(*self.params)
             self._desc = _describe(self.kind, n_feat, tuple(p.detach() for p in self.live), self.n_branch)
             self._desc_key = key
+            self._heads = {}          # (they hold the head's parameter addresses)
         return self._desc
 
     def _grads_for(self, flat, n_feat):
-        """(g_conv1, g_conv2, zero ranges, per-parameter views, head block address) of the flat gradient buffer ``flat``."""
-        views = tuple(flat[off:off + n].view(shape) for off, n, shape in self._shapes)
-        if self._live_slots is None:
-            index = {id(p): i for i, p in enumerate(self.params)}
-            self._live_slots = tuple(index[id(p)] for p in self.live)
-        live_grads = tuple(views[i] for i in self._live_slots)
-        g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-        g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
-        for b, (l1, l2) in enumerate(_split(self.kind, live_grads, self.n_branch)):
-            _fill_grads(g1[b], self.kind, l1, n_feat, H1)
-            _fill_grads(g2[b], self.kind, l2, H1, H2)
-        zp = (ctypes.c_void_p * _lib.ZERO_RANGES)()
-        zl = (ctypes.c_int64 * _lib.ZERO_RANGES)()
+        """(g_conv1, g_conv2, zero ranges, per-parameter views, head block address) of the flat gradient buffer ``flat``.  The
+        descriptor structures are built once per feature count; per call only their pointers move with the buffer."""
+        # (one split call + a view per matrix: fresh tensor objects every time, nobody else holds them)
+        views = tuple(part if shape is None else part.view(shape)
+                      for part, shape in zip(flat.split(self._sizes), self._view_shapes))
         base = flat.data_ptr()
+        tpl = self._grad_tpl.get(n_feat)
+        if tpl is None:
+            if self._live_slots is None:
+                index = {id(p): i for i, p in enumerate(self.params)}
+                self._live_slots = tuple(index[id(p)] for p in self.live)
+            live_grads = tuple(views[i] for i in self._live_slots)
+            g1 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+            g2 = (_lib.ConvGrads * _lib.MAX_BRANCH)()
+            for b, (l1, l2) in enumerate(_split(self.kind, live_grads, self.n_branch)):
+                _fill_grads(g1[b], self.kind, l1, n_feat, H1)
+                _fill_grads(g2[b], self.kind, l2, H1, H2)
+            patch = [(g[b], f, getattr(g[b], f) - base) for g in (g1, g2) for b in range(self.n_branch)
+                     for f in ("w_nbr", "w_self", "bias") if getattr(g[b], f)]
+            zp = (ctypes.c_void_p * _lib.ZERO_RANGES)()
+            zl = (ctypes.c_int64 * _lib.ZERO_RANGES)()
+            for i, (off, n) in enumerate(self.dead):
+                zl[i] = n
+            tpl = self._grad_tpl[n_feat] = (g1, g2, zp, zl, patch)
+        g1, g2, zp, zl, patch = tpl
+        for struct, field, off in patch:
+            setattr(struct, field, base + off)
         for i, (off, n) in enumerate(self.dead):
-            zp[i], zl[i] = base + 4 * off, n
+            zp[i] = base + 4 * off
         return g1, g2, zp, zl, views, base + 4 * self.head_offset
 
     def _head_desc(self, train, task, p_drop):
-        hd = _lib.HeadDesc()
-        n = self.net
-        hd.R, hd.H, hd.O, hd.task, hd.train = self.R, self.H, self.O, task, int(train)
-        hd.p_drop = float(p_drop)
-        hd.seed = self.seed
-        hd.transform_sigmoid = 0        # (NeuralNet.format_output transforms outside the model, NeuralNet.py:616-631)
-        hd.w1, hd.b1 = n.fc1.weight.data_ptr(), n.fc1.bias.data_ptr()
-        hd.w2, hd.b2 = n.fc2.weight.data_ptr(), n.fc2.bias.data_ptr()
-        hd.class_w = None
         mask = getattr(self, "drop_mask", None) if train else None        # test hook, as FusedTrainer's
-        hd.drop_mask = None if mask is None else mask.data_ptr()
+        key = (int(train), task, float(p_drop), None if mask is None else mask.data_ptr())
+        hd = self._heads.get(key)
+        if hd is None:
+            hd = self._heads[key] = _lib.HeadDesc()
+            n = self.net
+            hd.R, hd.H, hd.O, hd.task, hd.train = self.R, self.H, self.O, task, int(train)
+            hd.p_drop = float(p_drop)
+            hd.seed = self.seed
+            hd.transform_sigmoid = 0        # (NeuralNet.format_output transforms outside the model, NeuralNet.py:616-631)
+            hd.w1, hd.b1 = n.fc1.weight.data_ptr(), n.fc1.bias.data_ptr()
+            hd.w2, hd.b2 = n.fc2.weight.data_ptr(), n.fc2.bias.data_ptr()
+            hd.class_w = None
+            hd.drop_mask = None if mask is None else mask.data_ptr()
         return hd
 
     # -- topology of a batch ---------------------------------------------------------------------------------------------
@@ -211,7 +233,7 @@ class StepEngine(object):
         topo.rebuild(flags)
         if self.cache_topology:
             try:
-                self._topos[data] = (stamp, topo)
+                self._topos[data] = (stamp, topo, {})
             except TypeError:
                 pass
         return topo
@@ -276,13 +298,30 @@ class StepEngine(object):
             _lib.require_device(x)
         if self.params[0].device != x.device or self.params[0].device != self.device:
             return None
+        held = None
         if topo is None:
             topo = self.topology_for(data)
+            if self.cache_topology:
+                try:
+                    held = self._topos.get(data)        # (stamp, topo, launch contexts of this batch by mode)
+                except TypeError:
+                    held = None
         B, n_feat = topo.n_graphs, int(x.shape[1])
         if B <= 0 or topo.max_nodes <= 0 or x.shape[0] != topo.n_nodes:
             return None
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
         p_drop = float(getattr(net, "dropout", 0.0)) if net.training else 0.0
+        mode = "inference"
+        if want_grad:
+            mode = "jacobian" if self.O == 1 else "two-launch"
+        ctx_key = (mode, tuple(sorted(self.plan_overrides.items())))
+        ctx = held[2].get(ctx_key) if held is not None and held[1] is topo else None
+        if ctx is not None:
+            # the same batch object, tensors unchanged (topology_for compared the stamp): plan and launch hints as last time
+            flags, plan, hints, bplan, bhints = ctx
+            if mode == "two-launch" and p_drop > 0.0 and any(not c.done for c in self._pending):
+                return None
+            return self._issue(mode, x, topo, plan, hints, bplan, bhints, B, n_feat, p_drop, want_grad)
         flags = self._usable_flags(topo, x)
         if not (flags & _lib.TOPO_TILES) and getattr(topo, "tiles", None) is not None and \
                 ((topo.ws_f32 is not None) == (self.kind == _lib.SGAT)) and tuple(topo.x.shape) == tuple(x.shape) and \
@@ -291,22 +330,16 @@ class StepEngine(object):
             topo.x = x
             topo.rebuild(int(topo.flags) | _lib.TOPO_TILES)
             flags = self._usable_flags(topo, x)
-        mode = "inference"
-        if want_grad:
-            mode = "jacobian" if self.O == 1 else "two-launch"
         plan = self._plan(n_feat, topo, mode == "jacobian", flags)
         if plan.family != _lib.STEP_FAMILY_AGGREGATE or not (0 < plan.lds_bytes <= 160 * 1024):
             return None
         if mode == "two-launch":
-            bplan = self._plan(n_feat, topo, True, flags)
-            if bplan.family != _lib.STEP_FAMILY_AGGREGATE or not (0 < bplan.lds_bytes <= 160 * 1024):
+            chk = self._plan(n_feat, topo, True, flags)
+            if chk.family != _lib.STEP_FAMILY_AGGREGATE or not (0 < chk.lds_bytes <= 160 * 1024):
                 return None
             if p_drop > 0.0 and any(not c.done for c in self._pending):
                 return None      # (an earlier forward's backward would move the dropout stream between this forward and its own)
-        call = _Call()
-        call.mode, call.x, call.topo, call.plan, call.B, call.n_feat, call.p_drop = mode, x, topo, plan, B, n_feat, p_drop
-        call.done = not want_grad
-        call.stream = _lib.current_stream(x)
+        bplan = bhints = None
         bd = getattr(data, "__dict__", {})
         hn, he = bd.get("_host_node_ptr"), bd.get("_host_edge_ptr")
         tiles = topo.tiles if (flags & _lib.TOPO_TILES) else None
@@ -315,9 +348,22 @@ class StepEngine(object):
             if hn is not None and he is not None and len(hn) == B + 1 and B <= 64:
                 return _lib.step_hints(node_ptr=hn, edge_ptr=he, topo_flags=flags, tiles=tiles, plan=pl)
             return _lib.step_hints(topo_flags=flags, tiles=tiles, plan=pl)
-        call.hints = hints_for(plan)
+        hints = hints_for(plan)
         if mode == "two-launch":
-            call.bufs = (bplan, hints_for(bplan))
+            bplan = self._plan(n_feat, topo, True, flags)
+            bhints = hints_for(bplan)
+        if held is not None and held[1] is topo:
+            held[2][ctx_key] = (flags, plan, hints, bplan, bhints)
+        return self._issue(mode, x, topo, plan, hints, bplan, bhints, B, n_feat, p_drop, want_grad)
+
+    def _issue(self, mode, x, topo, plan, hints, bplan, bhints, B, n_feat, p_drop, want_grad):
+        call = _Call()
+        call.mode, call.x, call.topo, call.plan, call.B, call.n_feat, call.p_drop = mode, x, topo, plan, B, n_feat, p_drop
+        call.done = not want_grad
+        call.stream = _lib.current_stream(x)
+        call.hints = hints
+        if mode == "two-launch":
+            call.bufs = (bplan, bhints)
         self.last_path, self.last_plan = mode, plan
         if want_grad:
             self._pending.add(call)
@@ -385,10 +431,12 @@ class StepEngine(object):
 
 
 def engine_for(net):
-    """The net's engine (created on first use; rebuilt when the parameters moved to another device)."""
+    """The net's engine (created on first use; rebuilt when parameters were replaced or moved to another device).  The check
+    is two identity tests, not a walk over the module tree: this runs in front of every ``model(batch)``."""
     eng = net.__dict__.get("_drgnn_engine")
-    p0 = next(net.parameters())
-    if eng is None or eng.device != p0.device or len(eng.params) != sum(1 for _ in net.parameters()) or \
-            any(a is not b for a, b in zip(eng.params, net.parameters())):
-        eng = net.__dict__["_drgnn_engine"] = StepEngine(net)
+    if eng is not None:
+        first, last = eng.params[0], eng.params[-1]
+        if net.fc2.bias is last and eng._first_owner._parameters.get(eng.first_name) is first and first.device == eng.device:
+            return eng
+    eng = net.__dict__["_drgnn_engine"] = StepEngine(net)
     return eng
