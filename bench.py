@@ -115,7 +115,7 @@ def parse():
     ap.add_argument("--graphs-per-gpu", type=int, default=GRAPHS_PER_GPU,
                     help="mini-batch per GPU; %d is BASELINE.json's configuration, other values are for the "
                          "batch-size sweep in DESIGN.md" % GRAPHS_PER_GPU)
-    ap.add_argument("--step-layout", choices=["auto", "one", "seq", "two", "noclass", "old", "af1"], default="auto",
+    ap.add_argument("--step-layout", choices=["auto", "one", "two", "noclass", "af1"], default="auto",
                     help="GINet: workgroups per graph of the fused step -- auto (default): two while every workgroup of the "
                          "launch is resident, else one (both branches in sequence); one / two: forced, for A/B runs; noclass: "
                          "auto without the capacity-class kernels (compile-time LDS layout for batches inside 200 / 1024 / 52)")
@@ -207,11 +207,9 @@ def main():
 
     # same-box A/B runs of the whole program: the process default of the launch plan's overrides (drgnn_step_plan; the library
     # reads DRGNN_STEP_PLAN once, at its first plan query -- none has been made yet).  noclass: the run-time LDS layout also
-    # where the capacity class applies; old: the product-first kernels (round 3) everywhere; af1: sGAT / FoutNet aggregation
-    # first with ONE workgroup per graph; one / two: workgroups per graph; seq: one workgroup, branch after branch
+    # where the capacity class applies; af1: sGAT / FoutNet with ONE workgroup per graph; one / two: workgroups per graph
     if args.step_layout != "auto":
-        os.environ["DRGNN_STEP_PLAN"] = {"noclass": "noclass", "old": "product", "af1": "nosplit", "one": "one",
-                                         "seq": "one,seq", "two": "two"}[args.step_layout]
+        os.environ["DRGNN_STEP_PLAN"] = {"noclass": "noclass", "af1": "nosplit", "one": "one", "two": "two"}[args.step_layout]
     if args.dropin_only:
         print(json.dumps({"dropin_loop": measure_dropin_loop(dev, [(args.net, GRAPHS_PER_GPU)])}), flush=True)
         return
@@ -824,7 +822,7 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
     elif plan.family == _lib.STEP_FAMILY_AGGREGATE:
         kname = "k_step3%s_co_topo<GINet,%d> (aggregation first, %s)" % ("" if plan.wgs_per_graph == 2 else "b", plan.width, wg_txt)
     else:
-        kname = "k_step_co_topo<%s,%d> (product first, %s)" % (net_name, variant, wg_txt)
+        raise RuntimeError("the benchmarked shape is stepped by the aggregation-first kernels; plan family %d" % plan.family)
     out = {}
     first = ((kname + " (fwd + head/loss + bwd, topology read from the per-graph cache)", k_step_cached, alg) if cache else
              (kname + " (fwd + head/loss + bwd, + topology of the next batch)", k_step_co, alg))

@@ -652,6 +652,12 @@ static StepOverrides step_env_overrides() {
     }
     return env;
 }
+// DRGNN_NO_PREFETCH (A/B runs): cached-topology launches without the next mini-batch's prefetch workgroups; read once
+static bool step_no_prefetch() {
+    static int v = -1;
+    if (v < 0) v = getenv("DRGNN_NO_PREFETCH") != nullptr ? 1 : 0;
+    return v != 0;
+}
 static StepOverrides step_overrides_of(const drgnn_step_plan* p) {
     if (p && (p->force_wgs || p->no_class || p->no_aggregate || p->no_split || p->no_paired))
         return StepOverrides{p->force_wgs, p->no_class, p->no_aggregate, p->no_split, p->no_paired};
@@ -728,14 +734,23 @@ static StepPick step_pick(const StepAsk& q) {
     const bool af_shape = !q.ov.no_aggregate && (q.topo_flags & DRGNN_TOPO_HIER) && (q.topo_flags & DRGNN_TOPO_TILES) && af_w != 0 &&
                           (q.kind == DRGNN_GINET || (q.F & 3) != 0 || q.x_ok);
 #endif
+    // The PRODUCT-FIRST family (drgnn_step.h / drgnn_step1.h, rounds 2 - 3) is the host emulation's only: the device library
+    // instantiates the aggregation-first kernels alone (round 6), and a launch they do not cover -- a head that is not the
+    // reference's, more than 64 features, a workspace without the hierarchical order or usable tiles, the no_aggregate override --
+    // is family NONE: the launch pair (drgnn_net_forward + drgnn_net_backward_fused_head) steps it.
+#ifdef DRGNN_EMU
+    const bool old_ok = true;
+#else
+    const bool old_ok = false;
+#endif
     if (q.kind == DRGNN_GINET) {
         const bool narrow = q.H < DRGNN_H2;      // (the exchange words of a graph are 2 x 32 of its 2 x H: a narrower head runs one workgroup per graph)
         const int64_t l2af = af_shape ? 4 * step3_scratch_words(q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
-        const int64_t l2old = step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O);
+        const int64_t l2old = old_ok ? step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O) : STEP_LDS_NEVER;
         const int64_t l1af = af_shape ? 4 * step3b_scratch_words(q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
-        const int64_t l1p = step1_lds_bytes_form(q.F, q.capN, q.capE, q.capC, q.H, q.O, 1);
+        const int64_t l1p = old_ok ? step1_lds_bytes_form(q.F, q.capN, q.capE, q.capC, q.H, q.O, 1) : STEP_LDS_NEVER;
         const bool paired = !q.ov.no_paired && l1p <= DRGNN_LDS_LIMIT;
-        const int64_t l1old = paired ? l1p : step1_lds_bytes_form(q.F, q.capN, q.capE, q.capC, q.H, q.O, 0);
+        const int64_t l1old = paired ? l1p : old_ok ? step1_lds_bytes_form(q.F, q.capN, q.capE, q.capC, q.H, q.O, 0) : STEP_LDS_NEVER;
         const bool af_two = l2af <= DRGNN_LDS_LIMIT, af_one = l1af <= DRGNN_LDS_LIMIT;
         const bool can_two = !narrow && (af_two || l2old <= DRGNN_LDS_LIMIT);
         const bool can_one = af_one || l1old <= DRGNN_LDS_LIMIT;
@@ -753,7 +768,7 @@ static StepPick step_pick(const StepAsk& q) {
         k.xchg_words = 2 * (int64_t)(q.H > DRGNN_H2 ? q.H : DRGNN_H2);
     } else {
         const int64_t laf = af_shape ? 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
-        const int64_t lold = step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O);
+        const int64_t lold = old_ok ? step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O) : STEP_LDS_NEVER;
         const bool af_ok = laf <= DRGNN_LDS_LIMIT;
         // the node-split layout: training launches of the aggregation-first kernels under GINet's residency rule
         int wgs = 1;
@@ -852,38 +867,6 @@ int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int
 }
 
 #ifndef DRGNN_EMU
-// the product-first kernels (drgnn_step.h / drgnn_step1.h) by template arguments
-static drgnn_step_kernel_t step_old_kernel(int kind, int width, bool gather, int cls) {
-#define DRGNN_OLD_G(K, XF, CL) (gather ? (drgnn_step_kernel_t)k_step_co_topo<K, XF, true, CL> : (drgnn_step_kernel_t)k_step_co_topo<K, XF, false, CL>)
-#define DRGNN_OLD_W(K)                                                          \
-    switch (width) {                                                            \
-        case 16: return DRGNN_OLD_G(K, 16, 0);                                  \
-        case 32: return cls ? DRGNN_OLD_G(K, 32, 1) : DRGNN_OLD_G(K, 32, 0);    \
-        case 48: return DRGNN_OLD_G(K, 48, 0);                                  \
-        case 64: return DRGNN_OLD_G(K, 64, 0);                                  \
-        default: return DRGNN_OLD_G(K, 0, 0);                                   \
-    }
-    if (kind == DRGNN_GINET) { DRGNN_OLD_W(DRGNN_GINET) }
-    if (kind == DRGNN_SGAT) { DRGNN_OLD_W(DRGNN_SGAT) }
-    DRGNN_OLD_W(DRGNN_FOUT)
-#undef DRGNN_OLD_W
-#undef DRGNN_OLD_G
-}
-static drgnn_step_kernel_t step_old1_kernel(int width, bool gather, bool paired, int cls) {
-#define DRGNN_OLD1(XF, P, CL) (gather ? (drgnn_step_kernel_t)k_step1_co_topo<XF, true, P, CL> : (drgnn_step_kernel_t)k_step1_co_topo<XF, false, P, CL>)
-    if (paired) {
-        if (cls) return DRGNN_OLD1(32, true, 1);
-        return width == 32 ? DRGNN_OLD1(32, true, 0) : DRGNN_OLD1(0, true, 0);
-    }
-    switch (width) {
-        case 16: return DRGNN_OLD1(16, false, 0);
-        case 32: return DRGNN_OLD1(32, false, 0);
-        case 48: return DRGNN_OLD1(48, false, 0);
-        case 64: return DRGNN_OLD1(64, false, 0);
-        default: return DRGNN_OLD1(0, false, 0);
-    }
-#undef DRGNN_OLD1
-}
 // One launch of a step kernel instance (+ the co-launched builder's workgroups).  These kernels use up to the whole 160 KiB of
 // LDS: the attribute is raised once per kernel instance and device (the call costs host time on every launch otherwise).
 static int step_launch(drgnn_step_kernel_t kern, int64_t lds_bytes, unsigned grid, hipStream_t stream, const StepCoLaunch& C) {
@@ -1082,7 +1065,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         C.topo.pf_ids = nullptr; C.topo.pf_n = 0; C.topo.pf_graphs = 0;
         if (co_ok) { C.topo = T; both = k.lds > tlds ? k.lds : tlds; extra = T.args.n_graphs * T.roles; }
         else if (gather_ids && hints && hints->next_ids && hints->n_next > 0 && (blocks % 8) == 0 &&
-                 blocks + hints->n_next <= device_cu_count() && getenv("DRGNN_NO_PREFETCH") == nullptr) {
+                 blocks + hints->n_next <= device_cu_count() && !step_no_prefetch()) {
             // cached topology, CUs to spare: one extra workgroup per graph of the NEXT mini-batch warms the L2 of the XCD that
             // will step it (prefetch_block; beyond the resident size the workgroups would only queue behind the step's)
             TopoLaunch& Q = C.topo;
@@ -1102,8 +1085,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             case SK_AF3: kern = af_step_kernel(DRGNN_AF_GINET_TWO, k.width, gather, k.cls, 1, q.train); break;
             case SK_AF3B: kern = af_step_kernel(DRGNN_AF_GINET_ONE, k.width, gather, k.cls, 1, q.train); break;
             case SK_AF2: kern = af_step_kernel(kind == DRGNN_SGAT ? DRGNN_AF_SGAT : DRGNN_AF_FOUT, k.width, gather, k.cls, k.wgs, q.train); break;
-            case SK_STEP1: kern = step_old1_kernel(k.width, gather, k.paired != 0, k.cls); break;
-            default: kern = step_old_kernel(kind, k.width, gather, k.cls); break;
+            default: return DRGNN_E_CAPACITY;      // (the product-first family is not part of the device library: step_pick never picks it)
         }
         if ((rc = step_launch(kern, both, (unsigned)(blocks + extra), (hipStream_t)stream_, C))) return rc;
 #endif

@@ -1092,37 +1092,9 @@ __global__ void __launch_bounds__(256) k_topo_begin(const int32_t* node_ptr, con
     if (i < 4) err[i] = 0;
 }
 #endif  // DRGNN_KERNELS_MAIN
-// The instantiations of the fused step kernel live in drgnn_step_tu.hip (one translation unit per kind of net) when
-// the library is built from several translation units (Makefile: DRGNN_SPLIT_TU); a single-unit build (profiling
-// variants) instantiates them implicitly at their launch sites.
-#define DRGNN_STEP_FOR_WIDTHS(X, K) X(K, 0) X(K, 16) X(K, 32) X(K, 48) X(K, 64)
-#if defined(DRGNN_SPLIT_TU) && defined(DRGNN_KERNELS_MAIN)
-#define DRGNN_STEP_EXTERN(K, XF)                                                   \
-    extern template __global__ void k_step_co_topo<K, XF, false>(StepCoLaunch);    \
-    extern template __global__ void k_step_co_topo<K, XF, true>(StepCoLaunch);
-DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_GINET)
-DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_SGAT)
-DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP_EXTERN, DRGNN_FOUT)
-#undef DRGNN_STEP_EXTERN
-// the capacity-class layout (net_step_graph: CLS = 1), 32-wide kernels only
-#define DRGNN_STEP_CLS_EXTERN(K)                                                      \
-    extern template __global__ void k_step_co_topo<K, 32, false, 1>(StepCoLaunch);    \
-    extern template __global__ void k_step_co_topo<K, 32, true, 1>(StepCoLaunch);
-DRGNN_STEP_CLS_EXTERN(DRGNN_GINET)
-DRGNN_STEP_CLS_EXTERN(DRGNN_SGAT)
-DRGNN_STEP_CLS_EXTERN(DRGNN_FOUT)
-#undef DRGNN_STEP_CLS_EXTERN
-#define DRGNN_STEP1_EXTERN(K, XF)                                                         \
-    extern template __global__ void k_step1_co_topo<XF, false, false>(StepCoLaunch);      \
-    extern template __global__ void k_step1_co_topo<XF, true, false>(StepCoLaunch);
-DRGNN_STEP_FOR_WIDTHS(DRGNN_STEP1_EXTERN, 0)
-#undef DRGNN_STEP1_EXTERN
-extern template __global__ void k_step1_co_topo<0, false, true>(StepCoLaunch);
-extern template __global__ void k_step1_co_topo<0, true, true>(StepCoLaunch);
-extern template __global__ void k_step1_co_topo<32, false, true>(StepCoLaunch);
-extern template __global__ void k_step1_co_topo<32, true, true>(StepCoLaunch);
-extern template __global__ void k_step1_co_topo<32, false, true, 1>(StepCoLaunch);      // (capacity-class LDS layout)
-extern template __global__ void k_step1_co_topo<32, true, true, 1>(StepCoLaunch);
-#endif
+// The instantiations of the aggregation-first step kernels live in drgnn_step_tu.hip (one translation unit per (family, width),
+// drgnn_step_af.h) when the library is built from several translation units (Makefile: DRGNN_SPLIT_TU); a single-unit build
+// (profiling variants) instantiates them at their lookup functions.  k_step_co_topo / k_step1_co_topo (the product-first family)
+// are not instantiated in the device library at all: the host emulation steps through their bodies.
 #endif  // !DRGNN_EMU
 #include "drgnn_step_af.h"

@@ -50,8 +50,9 @@ def check_fused_matches_pair(Net, n_feat, task, device, api=None, seed=0, steps=
         lb = tb.train_step(batch)
         from deeprank_gnn_amd.topology import Topology
         from deeprank_gnn_amd import _lib
-        topo = Topology.from_batch(batch, build=False, need_weights=(ta.kind == _lib.SGAT), **kw)
-        fused_used = fused_used or ta._can_fuse(topo, n_feat)
+        # (the workspace train_step builds for itself: hierarchical order + aggregation tiles -- what the device's fused kernels need)
+        topo = Topology.from_batch(batch, need_weights=(ta.kind == _lib.SGAT), **kw)
+        fused_used = fused_used or ta._can_fuse(topo, n_feat, None, True, batch.x)
         isolated = Net.__name__ == "FoutNet"       # FoutLayer: NaN rows for isolated nodes are dropped by the max-pool
         np.testing.assert_allclose(float(la), float(lb), rtol=2e-5, equal_nan=isolated)
         np.testing.assert_allclose(ta.last_pred.cpu().numpy(), tb.last_pred.cpu().numpy(), rtol=1e-4, atol=1e-5)

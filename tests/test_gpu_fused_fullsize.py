@@ -255,8 +255,8 @@ def test_ginet_one_workgroup_step_at_syn_size_matches_oracle_and_two_workgroup_s
     tr.compute_gradients(small, topo=t64)                  # (no update in between: same parameters)
     pred_af = tr.last_pred.cpu().numpy().copy()            # the two-workgroup kernel of the same family (drgnn_step3.h)
     np.testing.assert_array_equal(pred_one, pred_af)       # forward arithmetic is the same code in both layouts
-    tr.plan_overrides = {"no_aggregate": 1}                # ... and the product-first kernels (drgnn_step.h): same numbers to rounding
-    assert tr._plan_for(t64, 32).family == _lib.STEP_FAMILY_PRODUCT
+    tr.plan_overrides = {"no_aggregate": 1}                # ... and the launch pair (family NONE: drgnn_net.h): same numbers to rounding
+    assert tr._plan_for(t64, 32).family == _lib.STEP_FAMILY_NONE
     tr.compute_gradients(small, topo=t64)
     pred_two = tr.last_pred.cpu().numpy()
     tr.plan_overrides = {}
@@ -467,7 +467,10 @@ def _check_family(tr, c, layout):
     """the plan a prepared step carries is the family / layout the test means to exercise"""
     from deeprank_gnn_amd import _lib
     plan = c["plan"]
-    assert plan.family == (_lib.STEP_FAMILY_PRODUCT if layout == "old" else _lib.STEP_FAMILY_AGGREGATE), (layout, plan.family)
+    if layout == "old":      # (round 6: the product-first family is not in the device library -- the launch pair steps it)
+        assert plan.family == _lib.STEP_FAMILY_NONE, plan.family
+        return
+    assert plan.family == _lib.STEP_FAMILY_AGGREGATE, (layout, plan.family)
     assert c["slabs"] == plan.slabs_per_graph == (2 if layout == "af2" else 1), (layout, plan.slabs_per_graph)
     assert plan.wgs_per_graph == (2 if layout == "af2" else 1)
 
@@ -566,15 +569,17 @@ def test_step_families_ragged_batches_vs_oracle(net_name, layout):
         else:
             tr.plan_overrides = dict(AF_LAYOUTS[layout])
         topo = Topology.from_batch(batch, need_weights=need_w)
-        assert tr._can_fuse(topo, n_feat, None, True, batch.x)
+        assert tr._can_fuse(topo, n_feat, None, True, batch.x) == (layout != "old")
         c = tr._fused_prepare(batch, topo)
-        if net_name == "GINet":
-            assert c["plan"].family == (_lib.STEP_FAMILY_PRODUCT if layout == "old" else _lib.STEP_FAMILY_AGGREGATE)
+        if layout == "old":      # (the launch pair: drgnn_net_forward + drgnn_net_backward_fused_head)
+            assert c["plan"].family == _lib.STEP_FAMILY_NONE
+        elif net_name == "GINet":
+            assert c["plan"].family == _lib.STEP_FAMILY_AGGREGATE
             assert c["plan"].wgs_per_graph == (1 if layout == "af1" else 2)
         else:
             _check_family(tr, c, layout)
-        # (the product-first kernels are width-specialised for multiples of 4 only: the generic instance otherwise)
-        assert c["plan"].width == (0 if (layout == "old" and n_feat % 4) else ((n_feat + 15) // 16) * 16)
+        if layout != "old":
+            assert c["plan"].width == ((n_feat + 15) // 16) * 16
         loss = tr.compute_gradients(batch, topo=topo)
         torch.cuda.synchronize()
         assert tr.faults() == 0

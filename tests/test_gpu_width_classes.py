@@ -194,7 +194,7 @@ def test_two_trainers_keep_their_own_forced_layouts_in_one_process():
     base = sGAT(32, 1, 1)
     base.dropout = 0.0
     want = {"split": ({}, _lib.STEP_FAMILY_AGGREGATE, 2), "whole": ({"no_split": 1}, _lib.STEP_FAMILY_AGGREGATE, 1),
-            "product": ({"no_aggregate": 1}, _lib.STEP_FAMILY_PRODUCT, 1)}
+            "product": ({"no_aggregate": 1}, _lib.STEP_FAMILY_NONE, 0)}       # (the launch pair: no fused kernel of that family on the device)
     solo = {}
     for name, (ov, fam, wgs) in want.items():
         tr = FusedTrainer(copy.deepcopy(base).to(dev), lr=0.01, task="reg")
