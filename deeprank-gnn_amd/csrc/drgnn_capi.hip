@@ -772,6 +772,9 @@ static StepPick step_pick(const StepAsk& q) {
         const bool af_ok = laf <= DRGNN_LDS_LIMIT;
         // the node-split layout: training launches of the aggregation-first kernels under GINet's residency rule
         int wgs = 1;
+        // (training launches only.  Round 6 instantiated the split layout for inference launches too and measured it on the same
+        // box, predict_epoch at batch 64: sGAT 14.8 us per mini-batch against 13.35 with one workgroup per graph (cached topology),
+        // FoutNet 14.6 against 13.1 -- a forward alone is too short for its two hand-offs, profiles/r06_split_inference_ab.txt)
         const bool may_split = q.train && af_ok && !q.ov.no_split;
         if (q.commit_wgs == 2) {
             // the caller sized its buffers for two workgroups per graph: no silent fallback to another layout
