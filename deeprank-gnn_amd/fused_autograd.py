@@ -342,6 +342,8 @@ class StepEngine(object):
         bplan = bhints = None
         bd = getattr(data, "__dict__", {})
         hn, he = bd.get("_host_node_ptr"), bd.get("_host_edge_ptr")
+        if hn is None:           # (a foreign batch object: the tables Topology.from_batch derived)
+            hn, he = getattr(topo, "host_node_ptr", None), getattr(topo, "host_edge_ptr", None)
         tiles = topo.tiles if (flags & _lib.TOPO_TILES) else None
 
         def hints_for(pl):

@@ -33,6 +33,7 @@ class Topology(object):
         self.max_nodes = 0
         self.max_edges = 0
         self.max_c0 = 0
+        self.host_node_ptr = self.host_edge_ptr = None      # host copies of the offsets, when derived here (from_batch)
         self.has_level1 = False
         self.flags = _lib.TOPO_HIER      # what the last build put into the workspace (drgnn_topology_request.flags)
         # level-0 aggregation tiles (TOPO_TILES): the node features they are formed from and the output buffer
@@ -49,7 +50,7 @@ class Topology(object):
     # ---------------------------------------------------------------------------
     @classmethod
     def from_batch(cls, data, api=None, with_level1=True, check=False, need_weights=True, graph_only=False,
-                   build=True, flags=None, with_tiles=True):
+                   build=True, flags=None, with_tiles=True, host_tables=True):
         """Build from a ``Batch``-like object (attribute access only).  ``need_weights=False``
         skips everything that involves ``edge_attr`` (GINet's attention is identically 1 and
         FoutLayer never reads it, so only sGAT needs the pooled, summed edge attributes)."""
@@ -90,13 +91,42 @@ class Topology(object):
         topo = cls(api, n_nodes, n_edges, n_graphs, device, edge_attr is not None)
         max_nodes = int(d.get("_max_nodes", 0))
         max_edges = int(d.get("_max_edges", 0))
-        if max_nodes == 0 and n_nodes:
-            counts = torch.bincount(batch, minlength=n_graphs)
-            max_nodes = int(counts.max())
-            if n_edges:
-                max_edges = int(torch.bincount(batch[edge_index[0]], minlength=n_graphs).max())
+        max_c0 = int(d.get("_max_c0", 0))
+        if max_nodes == 0 and n_nodes and n_graphs:
+            # A batch object that is not this package's (a torch_geometric Batch: attribute access only): the per-graph sizes are
+            # derived here -- nodes, edges and distinct depth-0 clusters per graph, ONE host round trip for all of it -- so that it
+            # gets the same bounds (LDS layout of the fused kernels) and, with ``host_tables``, the same offset tables (lean
+            # builder chains, offsets in the kernel arguments) as a batch collated by data.Batch.from_data_list.  Tables that do
+            # not add up (batch vector / edge list not grouped by graph, cluster1 of the wrong length) are left to the device,
+            # which derives what it can and flags the rest (DRGNN_S_*).
+            cn = torch.bincount(batch, minlength=n_graphs)
+            be = batch[edge_index[0]] if n_edges else None
+            ce = torch.bincount(be, minlength=n_graphs) if n_edges else torch.zeros_like(cn)
+            cc = torch.zeros_like(cn)
+            if cluster0 is not None:
+                lo = cluster0.min()
+                span = cluster0.max() - lo + 1
+                keys = torch.unique(batch * span + (cluster0 - lo))
+                cc = torch.bincount(torch.div(keys, span, rounding_mode="floor"), minlength=n_graphs)
+            grouped = (batch[1:] >= batch[:-1]).all() if n_nodes > 1 else torch.ones((), dtype=torch.bool, device=device)
+            if n_edges > 1:
+                grouped = grouped & (be[1:] >= be[:-1]).all()
+            flag = grouped.to(cn.dtype).reshape(1).expand(n_graphs)
+            counts = torch.stack([cn[:n_graphs], ce[:n_graphs], cc[:n_graphs], flag]).cpu()
+            max_nodes, max_edges = int(counts[0].max()), int(counts[1].max())
+            if cluster0 is not None:
+                max_c0 = int(counts[2].max())
+            if host_tables and node_ptr is None and bool(counts[3, 0]) and int(counts[0].sum()) == n_nodes and \
+                    int(counts[1].sum()) == n_edges and cn.numel() == n_graphs:
+                ptr = torch.zeros((3, n_graphs + 1), dtype=torch.int32)
+                ptr[:, 1:] = torch.cumsum(counts[:3], dim=1).to(torch.int32)
+                dev_ptr = ptr.to(device)
+                node_ptr, edge_ptr = dev_ptr[0], dev_ptr[1]
+                if cluster1 is not None and int(counts[2].sum()) == cluster1.numel():
+                    c1_ptr = dev_ptr[2]
+                topo.host_node_ptr, topo.host_edge_ptr = ptr[0].numpy(), ptr[1].numpy()
         topo.max_nodes, topo.max_edges = max_nodes, max_edges
-        topo.max_c0 = int(d.get("_max_c0", 0))
+        topo.max_c0 = max_c0
         scratch = None
         lds_limit = 160 * 1024
         need = api.topology_lds_bytes(max_nodes, max_edges)

@@ -41,13 +41,17 @@ def random_graph(rng, n, e, n_c0, n_c1, sym=True, self_loops=False, dup=False):
 
 @pytest.mark.parametrize("make", [lambda: fixture_batch(8), lambda: fixture_batch(10), syn4_batch,
                                   lambda: synth.make_batch(0, 3)])
-@pytest.mark.parametrize("derive", [False, True])
+@pytest.mark.parametrize("derive", [False, "host", "device"])
 @pytest.mark.parametrize("weights", [True, False])      # False: pooled graph through the bitmap path
 def test_topology_matches_oracle(make, derive, weights):
+    # derive: the batch has forgotten its collate-time offsets (a foreign Batch object): "host" = from_batch derives the tables
+    # with one host round trip (the default), "device" = the builder's own derivation (k_ptrs; host_tables=False)
     batch = make()
     if derive:
         strip_layout(batch)
-    topo = Topology.from_batch(batch, api=emu(), need_weights=weights)
+    topo = Topology.from_batch(batch, api=emu(), need_weights=weights, host_tables=(derive != "device"))
+    if derive == "host":
+        assert topo.host_node_ptr is not None and topo.max_c0 > 0
     assert topo.status()[0] == 0
     check_against_oracle(topo, batch, weights=weights)
 

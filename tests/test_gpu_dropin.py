@@ -338,3 +338,169 @@ def test_feature_count_not_a_multiple_of_four_on_an_odd_node_total(net_name):
     for n, p in net.named_parameters():
         r = ref[n].cpu().numpy()
         np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=n)
+
+
+@pytest.mark.parametrize("net_name", ["GINet", "sGAT", "FoutNet"])
+@pytest.mark.parametrize("n_feat,task", [(5, "reg"), (16, "class"), (40, "reg")])
+def test_ragged_batches_against_the_launch_pair(net_name, n_feat, task):
+    """Ragged batches (single-node graphs, no edges, self loops, duplicate edges, odd feature counts), regression and 3-class
+    classification with class weights in the CALLER's loss (torch's CrossEntropyLoss(weight), NeuralNet.py:247-263): the
+    drop-in boundary against plain autograd through the launch pair + torch head."""
+    from step_check import ragged_batch
+    from test_gpu_parity import nets
+    batch = ragged_batch(7 + n_feat, n_feat)
+    n_out = 1 if task == "reg" else 3
+    if task == "class":
+        batch.y = torch.tensor([k % 3 for k in range(batch.num_graphs)])
+        crit = torch.nn.CrossEntropyLoss(weight=torch.tensor([0.2, 0.5, 0.3], device=_dev()))
+    else:
+        batch.y = torch.arange(batch.num_graphs, dtype=torch.float32) * 0.3 - 1.0
+        crit = torch.nn.MSELoss()
+    batch = batch.to(_dev())
+    torch.manual_seed(n_feat)
+    net = nets()[net_name](n_feat, n_out, 1).to(_dev())
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0
+    net.train()
+    fn = (lambda o: crit(o.reshape(-1), batch.y)) if task == "reg" else (lambda o: crit(o, batch.y))
+    ref_out, ref = _legacy_grads(net, batch, fn)
+    for p in net.parameters():
+        p.grad = None
+    out = net(batch)
+    assert _engine(net).last_path == ("jacobian" if n_out == 1 else "two-launch")
+    fn(out).backward()
+    torch.cuda.synchronize()
+    nan_ok = net_name == "FoutNet"          # (FoutLayer: NaN rows of isolated nodes, dropped by the max-pool)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref_out.cpu().numpy(), rtol=1e-4, atol=1e-5, equal_nan=nan_ok)
+    for n, p in net.named_parameters():
+        r = ref[n].cpu().numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=2e-4, atol=2e-5 * max(1.0, float(np.nanmax(np.abs(r)))),
+                                   err_msg=n, equal_nan=nan_ok)
+
+
+def test_foreign_batch_objects_and_large_batches():
+    """A batch that is NOT this package's Batch (attribute access only, as a torch_geometric Batch would be: no host offset
+    tables -- Topology.from_batch derives them with one host round trip), and 160 graphs (GINet: both branches in one workgroup;
+    no offsets in the kernel arguments): same predictions and gradients as our Batch / as two halves."""
+    import types
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.ginet import GINet
+    mine = synth.make_batch(0, 12).to(_dev())
+    foreign = types.SimpleNamespace(x=mine.x, edge_index=mine.edge_index, edge_attr=mine.edge_attr, batch=mine.batch,
+                                    cluster0=mine.cluster0, cluster1=mine.cluster1, y=mine.y, num_graphs=12)
+    torch.manual_seed(21)
+    net = GINet(32, 1, 1).to(_dev())
+    net.dropout = 0.0
+    net.train()
+
+    def step(b):
+        for p in net.parameters():
+            p.grad = None
+        out = net(b)
+        assert _engine(net).last_path == "jacobian"
+        F.mse_loss(out.reshape(-1), b.y).backward()
+        torch.cuda.synchronize()
+        return out.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters()}
+    a_out, a = step(mine)
+    b_out, b = step(foreign)
+    assert torch.equal(a_out, b_out)
+    for n in a:
+        assert torch.equal(a[n], b[n]), n
+    big = synth.make_batch(0, 160).to(_dev())      # (2 x 160 workgroups > 256 CUs: one workgroup per graph)
+    o_big, g_big = step(big)
+    assert _engine(net).last_plan.wgs_per_graph == 1
+    halves = [synth.make_batch(0, 80).to(_dev()), synth.make_batch(80, 80).to(_dev())]
+    outs, grads = zip(*[step(h) for h in halves])
+    np.testing.assert_allclose(o_big.cpu().numpy(), torch.cat(outs).cpu().numpy(), rtol=1e-5, atol=1e-6)
+    for n in g_big:      # (mean loss over 160 = mean of the two halves' mean losses)
+        want = 0.5 * (grads[0][n] + grads[1][n])
+        np.testing.assert_allclose(g_big[n].cpu().numpy(), want.cpu().numpy(), rtol=2e-4, atol=1e-6 * max(1.0, float(want.abs().max())), err_msg=n)
+
+
+def test_eval_mode_with_gradients_and_parameter_surgery():
+    """model.eval() with autograd on (dropout off, gradients wanted: the jacobian launch without a mask); in-place
+    load_state_dict keeps the engine, replacing a parameter object or moving the net builds a new one."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.ginet import GINet
+    batch = synth.make_batch(0, 8).to(_dev())
+    torch.manual_seed(4)
+    net = GINet(32, 1, 1).to(_dev())
+    net.eval()
+    out = net(batch)
+    eng = _engine(net)
+    assert eng.last_path == "jacobian"
+    out.sum().backward()
+    with torch.no_grad():
+        again = net(batch)
+    # no dropout in eval mode: the same numbers (training and inference instances of the kernel: to rounding)
+    np.testing.assert_allclose(again.cpu().numpy(), out.detach().cpu().numpy(), rtol=1e-6, atol=1e-6)
+    net.load_state_dict({k: v * 0.5 for k, v in net.state_dict().items()})
+    assert _engine(net) is eng
+    with torch.no_grad():
+        halved = net(batch)
+    assert not torch.equal(halved, again)            # (the launches read the parameters in place)
+    net.fc2.bias = torch.nn.Parameter(torch.zeros_like(net.fc2.bias))
+    assert _engine(net) is not eng
+    with torch.no_grad():
+        net(batch)
+    assert _engine(net).last_path == "inference"
+
+
+def test_classification_loop_recorded_in_a_graph():
+    """GINet, two classes, dropout 0.4, CrossEntropyLoss + Adam: the two-launch form of the boundary (forward-only launch with the
+    step's mask, training launch fed d loss / d pred) recorded in a hipGraph -- replays equal the eager steps (same mask stream:
+    the step index lives on the device)."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.ginet import GINet
+    batches = [synth.make_batch(16 * i, 16).to(_dev()) for i in range(4)]
+    for b in batches:
+        b.y = (b.y > 10).to(torch.int64)
+
+    def fresh():
+        torch.manual_seed(17)
+        net = GINet(32, 2, 1).to(_dev())
+        net.train()
+        return net, torch.optim.Adam(net.parameters(), lr=0.01, capturable=True)
+
+    def body(net, opt, b):
+        opt.zero_grad(set_to_none=True)
+        loss = F.cross_entropy(net(b), b.y)
+        loss.backward()
+        opt.step()
+        return loss
+    net, opt = fresh()
+    eager_losses = [float(body(net, opt, b)) for b in batches]
+    assert _engine(net).last_path == "two-launch"
+    eager = {k: v.clone() for k, v in net.state_dict().items()}
+    cap, copt = fresh()
+    start = copy.deepcopy(cap.state_dict())
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for b in batches:
+            body(cap, copt, b)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+    def reset():
+        cap.load_state_dict(start)
+        for st in copt.state.values():
+            st["step"].zero_(); st["exp_avg"].zero_(); st["exp_avg_sq"].zero_()
+        _engine(cap).step2.zero_()
+    reset()
+    graphs, losses = [], []
+    for b in batches:
+        gr = torch.cuda.CUDAGraph()
+        copt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(gr):
+            losses.append(body(cap, copt, b))
+        graphs.append(gr)
+    reset()
+    got = []
+    for gr, l in zip(graphs, losses):
+        gr.replay()
+        got.append(float(l))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(got, eager_losses, rtol=1e-5)
+    for k, v in cap.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), eager[k].cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
