@@ -702,6 +702,7 @@ enum { SK_STEP = 0, SK_STEP1 = 1, SK_AF2 = 2, SK_AF3 = 3, SK_AF3B = 4 };
 struct StepPick {
     int rc;                 // 0, or the error a launch of this shape returns (family NONE)
     int family, kernel, wgs, slabs, width, cls, paired, lean_ok, builder_roles;
+    int xg;                 // sGAT / FoutNet, 64-wide: the x-from-memory form (the S and the x tile together do not fit the LDS)
     int64_t lds, xchg_words;
     int capN, capE, capC;   // the LDS capacities the kernel is launched with (the class's when cls)
 };
@@ -767,7 +768,12 @@ static StepPick step_pick(const StepAsk& q) {
         else { k.kernel = af_one ? SK_AF3B : SK_STEP1; k.lds = af_one ? l1af : l1old; k.paired = (!af_one && paired) ? 1 : 0; }
         k.xchg_words = 2 * (int64_t)(q.H > DRGNN_H2 ? q.H : DRGNN_H2);
     } else {
-        const int64_t laf = af_shape ? 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
+        int64_t laf = af_shape ? 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
+        if (af_shape && laf > DRGNN_LDS_LIMIT && af_w == 64) {
+            // 49 - 64 features on graphs whose S and x tiles do not fit together: the x rows stay in memory (drgnn_step2.h, XG)
+            const int64_t lxg = 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O, 1);
+            if (lxg <= DRGNN_LDS_LIMIT) { laf = lxg; k.xg = 1; }
+        }
         const int64_t lold = old_ok ? step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O) : STEP_LDS_NEVER;
         const bool af_ok = laf <= DRGNN_LDS_LIMIT;
         // the node-split layout: training launches of the aggregation-first kernels under GINet's residency rule
@@ -1087,7 +1093,8 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         switch (k.kernel) {
             case SK_AF3: kern = af_step_kernel(DRGNN_AF_GINET_TWO, k.width, gather, k.cls, 1, q.train); break;
             case SK_AF3B: kern = af_step_kernel(DRGNN_AF_GINET_ONE, k.width, gather, k.cls, 1, q.train); break;
-            case SK_AF2: kern = af_step_kernel(kind == DRGNN_SGAT ? DRGNN_AF_SGAT : DRGNN_AF_FOUT, k.width, gather, k.cls, k.wgs, q.train); break;
+            case SK_AF2: kern = af_step_kernel(k.xg ? (kind == DRGNN_SGAT ? DRGNN_AF_SGAT_XG : DRGNN_AF_FOUT_XG)
+                                                    : (kind == DRGNN_SGAT ? DRGNN_AF_SGAT : DRGNN_AF_FOUT), k.width, gather, k.cls, k.wgs, q.train); break;
             default: return DRGNN_E_CAPACITY;      // (the product-first family is not part of the device library: step_pick never picks it)
         }
         if ((rc = step_launch(kern, both, (unsigned)(blocks + extra), (hipStream_t)stream_, C))) return rc;

@@ -510,7 +510,7 @@ DEV void step_block_both(const StepLaunch& L, int g, float* lds) {
 // sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h).  SPLIT = 2: the two halves of a graph are 8
 // block ids apart (same XCD: they read the same x tile and topology and hand each other pooled rows), graphs in groups
 // of 8 like GINet's branch workgroups.
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN>
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN, bool XG = false>
 DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
     int g, half;
     if (SPLIT == 2) { g = ((blk >> 4) << 3) + (blk & 7); half = (blk >> 3) & 1; }
@@ -525,7 +525,7 @@ DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
         const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
         const int32_t* hs = L.a.tv.p[DRGNN_TI_HSPLIT] + 4 * gi;
         const int hk = (SPLIT == 2) ? hs[0] : 0, hq = (SPLIT == 2) ? hs[1] : 0, hn = (SPLIT == 2) ? hs[2] : 0;
-        net_step2_graph<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1,
+        net_step2_graph<KIND, XF, GATHER, CLS, SPLIT, TRAIN, XG>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1,
                                                              cnt_c1, hk, hq, hn);
         return;
     }
@@ -545,7 +545,7 @@ DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
         }
         return;
     }
-    net_step2_graph<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, false, 0, 0, 0, hk, hq, hn);
+    net_step2_graph<KIND, XF, GATHER, CLS, SPLIT, TRAIN, XG>(L.a, d, g, gi, half, lds, L.capN, L.capE, L.capC, false, 0, 0, 0, hk, hq, hn);
 }
 #endif
 
@@ -889,14 +889,14 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C
     else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s1);
 }
 // sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h) + the builder's workgroups
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN>
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN, bool XG = false>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step2_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s2[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
     co_kernarg_touch();
     STEP_CO_ROLES(C);
-    if (co_is_step_) step2_block<KIND, XF, GATHER, CLS, SPLIT, TRAIN>(C.step, co_step_blk_, smem_s2);
+    if (co_is_step_) step2_block<KIND, XF, GATHER, CLS, SPLIT, TRAIN, XG>(C.step, co_step_blk_, smem_s2);
     else topo_block<true, (KIND == DRGNN_SGAT) ? -1 : 0>(C.topo, co_topo_blk_, (int*)smem_s2);
 }
 // GINet, aggregation first (drgnn_step3.h) + the builder's workgroups

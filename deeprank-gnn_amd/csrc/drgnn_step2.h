@@ -47,6 +47,7 @@ struct Step2Scratch {
     float* misc; float* xr; float* hid; float* dhid; float* hb1; float* bsum; float* wb;
     float* w1t; float* ws1t; float* b1; float* wc2t; float* wc2n; float* b2;
     float* xs;
+    int* hord;
     int* hmp; int* cid; int* mp1;
     int* rp1; int* cx1; float* ew1; int* cp1; int* rx1; int* ts1;
     short* a0; short* a1;
@@ -76,7 +77,8 @@ struct Step2Scratch {
     X(wc2t, DRGNN_H2 * STEP2_TSLD, 1)                                                          \
     X(wc2n, DRGNN_H2 * STEP2_TSLD, 1)                                                          \
     X(b2, DRGNN_H2, 1)                                                                         \
-    X(xs, (long)(capN + 4) * xld, 1)                                                           \
+    X(xs, (long)(capN + 4) * xld, !xg)                                                         \
+    X(hord, capN, xg)                                                                          \
     X(hmp, capC + 1, 1)                                                                        \
     X(cid, capC, 1)                                                                            \
     X(mp1, capC + 1, 1)                                                                        \
@@ -103,7 +105,9 @@ struct Step2Scratch {
 #endif  // !DRGNN_EMU
 
 // (host + device; also compiled by the emulation build, whose plan function must answer "never" consistently)
-HD int64_t step2_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O) {
+// xg: the X-FROM-GLOBAL form of the 64-wide kernels (net_step2_graph<..., XG = true>): the x rows are not staged (the self
+// product and the sparse dWs read them from memory: L2), the hierarchical order is (position -> node) instead
+HD int64_t step2_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O, int xg = 0) {
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
     const int64_t xld = step_pad16((int)F) + 4;
     int64_t w = 0;
@@ -112,7 +116,7 @@ HD int64_t step2_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, 
     STEP2_CARVE_LIST(X)
 #undef X
 #else
-    (void)sg; (void)xld; (void)capN; (void)capE; (void)capC; (void)H; (void)O;
+    (void)sg; (void)xld; (void)capN; (void)capE; (void)capC; (void)H; (void)O; (void)xg;
     w = (int64_t)1 << 40;      // the emulation build has no node-split kernels
 #endif
     return w + 16;
@@ -163,9 +167,10 @@ template <int J> DEV void burst_store_x4_rows(const BurstX<J>& b, const BurstRow
 #else
 #define STEP2_PIN(x) do { if (SPIN) { asm volatile("" : "+s"(x)); } else { STEP_PIN(x); } } while (0)
 #endif
-template <int CLS, bool SPIN = false>
+template <int CLS, bool SPIN = false, bool XG = false>
 DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, int capC, int H, int O) {
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
+    constexpr int xg = XG ? 1 : 0;
     const int xld = step_pad16(F) + 4;
     Step2Scratch s;
     int o = 0;
@@ -183,9 +188,10 @@ DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, i
 }
 
 // ---- phase B: Z1 = relu(D . (S Wn) + C . (X Ws) + b) over the own rows (S, X rows at their local positions) ---------------
-template <int KIND, int XF>
+// XG: the x rows come from memory (xs = the graph's rows in NODE order, `xtf` floats apart; hord: position -> node)
+template <int KIND, int XF, bool XG = false>
 DEV void step2_conv1(int n, int nmax, const float* G, const float* xs, const float* w1t, const float* ws1t, const float* b1,
-                     const float* dv, const float* sc, float* z1, int* dummy) {
+                     const float* dv, const float* sc, float* z1, int* dummy, const int* hord = nullptr, int xtf = 0) {
     constexpr int XLD = XF + 4;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int lr = lane & 15, lq = lane >> 4;
@@ -194,13 +200,19 @@ DEV void step2_conv1(int n, int nmax, const float* G, const float* xs, const flo
         const int prow = ti * 16 + lr;
         const int row = prow < nmax ? prow : nmax - 1;      // rows past the own range: any valid row (results discarded)
         const float* ag = G + row * XLD + 4 * lq;
-        const float* ax = xs + row * XLD + 4 * lq;
+        const float* ax = XG ? xs + (long)hord[row] * xtf + 4 * lq : xs + row * XLD + 4 * lq;
+        drgnn_f4 xv[XF / 16];
+        if (XG) {      // (all of the row's chunks requested at once; chunks past the row's end -- padded widths -- are zero)
+#pragma unroll
+            for (int k0 = 0; k0 < XF; k0 += 16)
+                xv[k0 / 16] = (k0 + 4 * lq < xtf) ? *(const drgnn_f4*)(ax + k0) : drgnn_f4{0.f, 0.f, 0.f, 0.f};
+        }
         const float* bn = w1t + lr * XLD + 4 * lq;
         const float* bs = ws1t + lr * XLD + 4 * lq;
         drgnn_f32x4 accn = {0.f, 0.f, 0.f, 0.f}, accs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k0 = 0; k0 < XF; k0 += 16) {
-            const drgnn_f4 a = *(const drgnn_f4*)(ag + k0), x = *(const drgnn_f4*)(ax + k0);
+            const drgnn_f4 a = *(const drgnn_f4*)(ag + k0), x = XG ? xv[k0 / 16] : *(const drgnn_f4*)(ax + k0);
             const drgnn_f4 wn = *(const drgnn_f4*)(bn + k0), ws = *(const drgnn_f4*)(bs + k0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -507,9 +519,9 @@ template <int NSL> DEV float step_slices_sum(float v) {
     if (NSL >= 16) v += dpp_take<0x140>(v);   // row_mirror
     return v;
 }
-template <int XF>
+template <int XF, bool XG = false>
 DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float* G, const float* xs, const float* dv,
-                          const float* sc, float* g_dwn, float* g_dws, float* g_db1, int F) {
+                          const float* sc, float* g_dwn, float* g_dws, float* g_db1, int F, const int* hord = nullptr, int xtf = 0) {
     constexpr int XLD = XF + 4, NSL = Dw1Shape<XF>::NSL;
     const int h = threadIdx.x >> 6, fc = (threadIdx.x & 63) / NSL, sl = threadIdx.x & (NSL - 1);
     const bool live = 4 * fc < XF;
@@ -529,7 +541,8 @@ DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float
             if (arg[u] >= 0) {
                 const float dn = d[u] * dv[arg[u]], ds = d[u] * sc[arg[u]];
                 const drgnn_f4 g = *(const drgnn_f4*)(G + ROW24(arg[u], XLD) + 4 * fc);
-                const drgnn_f4 x = *(const drgnn_f4*)(xs + ROW24(arg[u], XLD) + 4 * fc);
+                const drgnn_f4 x = !XG ? *(const drgnn_f4*)(xs + ROW24(arg[u], XLD) + 4 * fc)
+                                   : (4 * fc < xtf) ? *(const drgnn_f4*)(xs + (long)hord[arg[u]] * xtf + 4 * fc) : drgnn_f4{0.f, 0.f, 0.f, 0.f};
                 an[0] = fmaf(dn, g[0], an[0]); an[1] = fmaf(dn, g[1], an[1]); an[2] = fmaf(dn, g[2], an[2]); an[3] = fmaf(dn, g[3], an[3]);
                 as[0] = fmaf(ds, x[0], as[0]); as[1] = fmaf(ds, x[1], as[1]); as[2] = fmaf(ds, x[2], as[2]); as[3] = fmaf(ds, x[3], as[3]);
                 bsum += d[u];
@@ -553,7 +566,9 @@ DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float
 // head width); CLS as in drgnn_step.h; SPLIT: workgroups per graph; half: which one.  `late` as in net_step_graph: sizes and
 // offsets came with the launch arguments, the device-computed counts (clusters, pooled edges, split point) are in flight.
 // TRAIN = false: the inference launch (forward + head, predictions only; one workgroup per graph).
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN = true>
+// XG (64-wide only): x rows read from memory instead of staged in LDS -- what lets 200-node graphs with up to 64 features into the
+// 160 KiB (133 KB instead of 189 KB at SYN size); the host takes it only when the staged form does not fit.
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN = true, bool XG = false>
 DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi, int half, float* scratch, int capN, int capE,
                          int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1, int hs_k, int hs_q, int hs_n) {
     static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
@@ -571,7 +586,8 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     const int F = a.net.n_feat;
     const int O = hf.O;
     constexpr bool SPIN = KIND == DRGNN_SGAT && TRAIN && SPLIT == 2;      // (see step2_carve)
-    Step2Scratch s = step2_carve<CLS, SPIN>(scratch, KIND, XF, capN, capE, capC, WREF, O);
+    static_assert(!XG || (XF == 64 && CLS == 0), "the x-from-memory form exists for the 64-wide run-time layout");
+    Step2Scratch s = step2_carve<CLS, SPIN, XG>(scratch, KIND, XF, capN, capE, capC, WREF, O);
     EXIT_AFTER(0);
     WBlockRegs<1> wreg;
     int* const dummy = (int*)(s.misc + 64);
@@ -626,6 +642,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
         case 16 + 11: if (TRAIN) j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
         case 16 + 12: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 0); break;
         case 16 + 13: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, nar}, 1); break;
+        case 16 + 14: if (XG) j = StageJob{P[DRGNN_TI_HORD] + d.n0, d.N, s.hord, 0}; break;
 
         case 32 + 0: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 0); break;
         case 32 + 1: if (KIND == DRGNN_SGAT) j = stage_half(StageJob{tv.w1 + d.e0, bE1, s.ew1, 0}, 1); break;
@@ -662,8 +679,8 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
         }
     }
     burst_load_x(bsum, sgl, d.N, TF);
-    burst_load_x(bx, xgl, d.N, TF);
-    burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
+    if (!XG) burst_load_x(bx, xgl, d.N, TF);
+    burst_load_rowmap(brow, bsum, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);      // (the S and the x tile have the same geometry)
     // per-node coefficients D, C and the node's position (one node per lane: d.N <= threads, step_burst_guaranteed)
     float n_d = 0.0f, n_c = 0.0f;
     int n_pos = -1;
@@ -698,7 +715,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     const int nmax = imax(Nh, 1);
     // the S and x rows of the OWN positions -> LDS row (position - nbase); D, C likewise
     burst_store_x4_rows(bsum, brow, s.G, XLD, nbase, Nh);
-    burst_store_x4_rows(bx, brow, s.xs, XLD, nbase, Nh);
+    if (!XG) burst_store_x4_rows(bx, brow, s.xs, XLD, nbase, Nh);
     if ((unsigned)(n_pos - nbase) < (unsigned)Nh) { s.dv0[n_pos - nbase] = n_d; s.sc0[n_pos - nbase] = n_c; }
     FOR_TID(e, step_pad4(Nh) - Nh) { s.dv0[Nh + e] = 0.0f; s.sc0[Nh + e] = 0.0f; }      // (coefficients of the K padding rows)
     burst_store_wt(bw1, s.w1t, XLD);
@@ -706,7 +723,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     wstage_store(wst);
     if (XF > TF) {     // zero padding of the k columns [TF, XF) of the row tiles ...
         const int padg = XF - TF;
-        FOR_TID(e, Nh * padg) { s.xs[(e / padg) * XLD + TF + e % padg] = 0.0f; s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+        FOR_TID(e, Nh * padg) { if (!XG) { s.xs[(e / padg) * XLD + TF + e % padg] = 0.0f; } s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
     }
     if (XF > F) {      // ... and [F, XF) of the weights
         const int padc = XF - F;
@@ -722,7 +739,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     EXIT_AFTER(1);
     EXIT_AFTER(2);
     // ---- B: conv1's product ------------------------------------------------------------------------------------------------
-    PH(2) step2_conv1<KIND, XF>(Nh, nmax, s.G, s.xs, s.w1t, s.ws1t, s.b1, s.dv0, s.sc0, s.z1, dummy);
+    PH(2) step2_conv1<KIND, XF, XG>(Nh, nmax, s.G, XG ? xgl : s.xs, s.w1t, s.ws1t, s.b1, s.dv0, s.sc0, s.z1, dummy, XG ? s.hord + nbase : nullptr, TF);
     FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
     BARRIER();
     EXIT_AFTER(3);
@@ -808,7 +825,8 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     BARRIER();
     EXIT_AFTER(14);
     // ---- N: dWn, dWs, db1 through the depth-0 argmax ------------------------------------------------------------------------------
-    PH(16) step2_dw1_sparse<XF>(Ch, s.a0, s.z2, s.G, s.xs, s.dv0, s.sc0, p_w1n, p_w1n + (long)F * DRGNN_H1, p_b1, F);
+    PH(16) step2_dw1_sparse<XF, XG>(Ch, s.a0, s.z2, s.G, XG ? xgl : s.xs, s.dv0, s.sc0, p_w1n, p_w1n + (long)F * DRGNN_H1, p_b1, F,
+                                    XG ? s.hord + nbase : nullptr, TF);
 }
 
 #endif  // !DRGNN_EMU

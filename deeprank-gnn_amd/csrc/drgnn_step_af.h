@@ -18,6 +18,8 @@ typedef void (*drgnn_step_kernel_t)(StepCoLaunch);
 #define DRGNN_AF_SGAT 3           // k_step2_co_topo<DRGNN_SGAT>
 #define DRGNN_AF_FOUT 4           // k_step2_co_topo<DRGNN_FOUT>
 #define DRGNN_AF_SGAT_WHOLE 5     // k_step2_co_topo<DRGNN_SGAT, ., false, ., 1, true>: a unit of its own, see af_pick_single
+#define DRGNN_AF_SGAT_XG 6        // k_step2_co_topo<DRGNN_SGAT, 64, ., 0, ., ., true>: x rows read from memory (64-wide only)
+#define DRGNN_AF_FOUT_XG 7        // ... of FoutNet
 
 // (cls: 1 = capacity-class layout, honoured for the 32- and 48-wide kernels only, training and inference launches -- the host
 // asks for nothing else; 48: the feature count of the reference's shipped regression models)
@@ -66,6 +68,17 @@ template <int KIND, int XF> drgnn_step_kernel_t af_pick_single(bool gather, int 
     }
 }
 
+// the x-from-memory form of the 64-wide kernels (run-time LDS layout only): graphs whose S AND x tiles do not fit the 160 KiB
+template <int KIND> drgnn_step_kernel_t af_pick_single_xg(bool gather, int split, bool train) {
+    if (!train) return gather ? k_step2_co_topo<KIND, 64, true, 0, 1, false, true> : k_step2_co_topo<KIND, 64, false, 0, 1, false, true>;
+    if (split == 2) return gather ? k_step2_co_topo<KIND, 64, true, 0, 2, true, true> : k_step2_co_topo<KIND, 64, false, 0, 2, true, true>;
+    return gather ? k_step2_co_topo<KIND, 64, true, 0, 1, true, true> : k_step2_co_topo<KIND, 64, false, 0, 1, true, true>;
+}
+drgnn_step_kernel_t af_sgat_xg_64(bool gather, int split, bool train);
+drgnn_step_kernel_t af_fout_xg_64(bool gather, int split, bool train);
+#define DRGNN_AF_DEFINE_SGAT_XG(W) drgnn_step_kernel_t af_sgat_xg_64(bool gather, int split, bool train) { return af_pick_single_xg<DRGNN_SGAT>(gather, split, train); }
+#define DRGNN_AF_DEFINE_FOUT_XG(W) drgnn_step_kernel_t af_fout_xg_64(bool gather, int split, bool train) { return af_pick_single_xg<DRGNN_FOUT>(gather, split, train); }
+
 #define DRGNN_AF_DECLARE(W)                                                                     \
     drgnn_step_kernel_t af_ginet_two_##W(bool gather, int cls, bool train);                    \
     drgnn_step_kernel_t af_ginet_one_##W(bool gather, int cls, bool train);                    \
@@ -105,9 +118,13 @@ DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_GINET_ONE)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_FOUT)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT_WHOLE)
+DRGNN_AF_DEFINE_SGAT_XG(64)
+DRGNN_AF_DEFINE_FOUT_XG(64)
 #endif
 // family: DRGNN_AF_*; width: 16 / 32 / 48 / 64.  nullptr: no such instance
 static drgnn_step_kernel_t af_step_kernel(int family, int width, bool gather, int cls, int split, bool train) {
+    if (family == DRGNN_AF_SGAT_XG) return width == 64 ? af_sgat_xg_64(gather, split, train) : nullptr;
+    if (family == DRGNN_AF_FOUT_XG) return width == 64 ? af_fout_xg_64(gather, split, train) : nullptr;
 #define DRGNN_AF_CASE(W)                                                                       \
     case W:                                                                                     \
         switch (family) {                                                                       \

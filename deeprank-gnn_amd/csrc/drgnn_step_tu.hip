@@ -14,8 +14,12 @@ DRGNN_AF_DEFINE_SGAT(DRGNN_AF_W)
 DRGNN_AF_DEFINE_FOUT(DRGNN_AF_W)
 #elif DRGNN_AF_FAM == DRGNN_AF_SGAT_WHOLE
 DRGNN_AF_DEFINE_SGAT_WHOLE(DRGNN_AF_W)
+#elif DRGNN_AF_FAM == DRGNN_AF_SGAT_XG
+DRGNN_AF_DEFINE_SGAT_XG(DRGNN_AF_W)
+#elif DRGNN_AF_FAM == DRGNN_AF_FOUT_XG
+DRGNN_AF_DEFINE_FOUT_XG(DRGNN_AF_W)
 #else
-#error "DRGNN_AF_FAM: 1 .. 5"
+#error "DRGNN_AF_FAM: 1 .. 7"
 #endif
 #else
 #error "compile with -DDRGNN_AF_FAM=<family> -DDRGNN_AF_W=<width>"

@@ -111,13 +111,15 @@ def test_shipped_regression_model_inference_known_answer():
         np.testing.assert_allclose(net(batch).cpu().numpy(), g["pred_batched"], rtol=1e-4, atol=1e-4)
 
 
-# (sGAT / FoutNet keep the S AND the x rows of a graph in LDS: 200-node graphs fit their fused kernels up to width 48 -- 157 -
-# 160 KB since conv1's activations share their place with the pooled level's [S | T] and Z2 --; at 64 features they are stepped by
-# the launch pair (family NONE: covered by the edge-case tests), so the 64-wide single-branch kernels are exercised on 120-node
-# graphs)
+# (sGAT / FoutNet keep the S AND the x rows of a graph in LDS: 200-node graphs fit that way up to width 48 -- 157 - 160 KB since
+# conv1's activations share their place with the pooled level's [S | T] and Z2.  At 49 - 64 features the 64-wide kernels stage both
+# tiles for graphs up to ~150 nodes (the 120-node cases) and, round 6, read the x rows from memory beyond that (drgnn_step2.h, XG:
+# the 200-node cases; 52 = rows shorter than the padded width, 50 = the tiles' padded x copy) -- every reference net shape up to
+# 64 features runs a fused step)
 SHAPES = [("GINet", 48, 200, 128), ("GINet", 16, 200, 64), ("GINet", 64, 200, 64),
           ("sGAT", 16, 200, 64), ("sGAT", 48, 200, 128), ("sGAT", 64, 120, 64),
-          ("FoutNet", 16, 200, 64), ("FoutNet", 48, 200, 128), ("FoutNet", 64, 120, 64)]
+          ("FoutNet", 16, 200, 64), ("FoutNet", 48, 200, 128), ("FoutNet", 64, 120, 64),
+          ("sGAT", 64, 200, 64), ("FoutNet", 64, 200, 64), ("FoutNet", 52, 200, 64), ("sGAT", 50, 200, 64)]
 
 
 @pytest.mark.parametrize("net_name,n_feat,n_nodes,B", SHAPES)
@@ -148,7 +150,7 @@ def test_fused_step_other_widths_match_oracle_elementwise(net_name, n_feat, n_no
     nxt = Topology.from_batch(batch, need_weights=need_w, build=False)
     c = tr._fused_prepare(batch, topo, True, nxt)
     assert c["plan"].family == _lib.STEP_FAMILY_AGGREGATE, (net_name, n_feat, c["plan"].family)
-    assert c["plan"].width == n_feat
+    assert c["plan"].width == ((n_feat + 15) // 16) * 16
     loss = tr.compute_gradients(batch, topo=topo, next_topo=nxt)
     torch.cuda.synchronize()
     assert tr.faults() == 0
@@ -166,7 +168,7 @@ def test_fused_step_other_widths_match_oracle_elementwise(net_name, n_feat, n_no
     cache = rs.topology_cache(need_weights=need_w)
     net2, tr2 = _trainer(net_name, params, 1, "reg")
     cc = tr2._cached_prepare(cache, list(range(B)))
-    assert cc["plan"].family == _lib.STEP_FAMILY_AGGREGATE and cc["plan"].width == n_feat
+    assert cc["plan"].family == _lib.STEP_FAMILY_AGGREGATE and cc["plan"].width == ((n_feat + 15) // 16) * 16
     tr2.train_step_cached(cache, list(range(B)), apply_adam=False)
     torch.cuda.synchronize()
     if cc["plan"].wgs_per_graph == c["plan"].wgs_per_graph:
