@@ -255,9 +255,34 @@ def _to_rows(src, index, dim):
     return flat, restore
 
 
+def _per_column(fn, src, index, dim, out, dim_size):
+    """torch_scatter's general form: ``index`` has (or broadcasts to) the SHAPE of ``src`` -- every column scatters along ``dim``
+    by its own index vector.  Neither the reference nor its layers use it (their indices are 1-D: ginet.py:71,133); it is served
+    column by column through the 1-D path (h x the launches): completeness of the function API, not a hot path."""
+    if out is not None:
+        raise NotImplementedError("scatter_*: out= with an N-D index")
+    d = dim % src.dim()
+    idx = index.expand_as(src).movedim(d, 0)
+    moved = src.movedim(d, 0)
+    rest = tuple(moved.shape[1:])
+    s2, i2 = moved.reshape(moved.size(0), -1), idx.reshape(moved.size(0), -1)
+    if dim_size is None:
+        dim_size = int(i2.max()) + 1 if i2.numel() else 0
+    cols = [fn(s2[:, j:j + 1].contiguous(), i2[:, j].contiguous(), 0, None, dim_size) for j in range(s2.size(1))]
+
+    def join(parts):
+        t = torch.cat(parts, dim=1) if parts else s2.new_zeros((dim_size, 0))
+        return t.reshape((t.size(0),) + rest).movedim(0, d)
+    if cols and isinstance(cols[0], tuple):
+        return join([c[0] for c in cols]), join([c[1] for c in cols])
+    return join(cols)
+
+
 def scatter_max(src, index, dim=0, out=None, dim_size=None):
     """torch_scatter.scatter_max: (maxima, argmax along ``dim``); absent ids -> 0 / ``src.size(dim)``.  With ``out=``: the
     result is ``max(out, segment maxima)`` written into ``out`` (argmax = ``src.size(dim)`` where ``out`` keeps its value)."""
+    if index.dim() > 1:
+        return _per_column(scatter_max, src, index, dim, out, dim_size)
     if src.dim() != 2 or dim not in (0, -2) or out is not None:
         flat, restore = _to_rows(src, index, dim)
         n = flat.size(0)
@@ -313,6 +338,8 @@ def _scatter_reduce(src, index, dim, out, dim_size, mean):
     """torch_scatter.scatter_sum / scatter_mean along dim 0.  With ``out=``: the segment sums are
     ADDED into ``out`` (``out.scatter_add_``) and, for the mean, the WHOLE buffer -- old content included -- is divided
     by the clamped counts, in place; ``out`` itself is returned (what the reference's sGAT layer relies on, sGAT.py:82-87)."""
+    if index.dim() > 1:
+        return _per_column(lambda s, i, d, o, n: _scatter_reduce(s, i, d, o, n, mean), src, index, dim, out, dim_size)
     if src.dim() >= 1 and (dim % src.dim()) != 0:
         # any other dimension: bring it to the front, reduce, put it back (``out=``: the same view of the caller's buffer)
         d = dim % src.dim()

@@ -21,6 +21,7 @@ from . import _lib
 from .functional import net_body, zero_grad_passthrough
 from .topology import Topology
 from .fused_autograd import engine_for
+from .composed import composed_forward, default_layers
 
 __all__ = ["GINet", "GINetConvLayer"]
 
@@ -104,6 +105,9 @@ class GINet(nn.Module):
     def forward(self, data, topo=None):
         """pred [B, output_shape].  On the fused step kernels whenever the batch fits them (fused_autograd: one launch for
         ``model(batch)``, one for ``loss.backward()``); otherwise the launch pair of ``body`` + the head in torch."""
+        if not default_layers(self):
+            # a layer built with an option the reference nets do not use: the general path, stage by stage (composed.py)
+            return composed_forward(self, data)
         pred = engine_for(self).run(data, topo)
         if pred is not None:
             return pred

@@ -504,3 +504,75 @@ def test_classification_loop_recorded_in_a_graph():
     np.testing.assert_allclose(got, eager_losses, rtol=1e-5)
     for k, v in cap.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), eager[k].cpu().numpy(), rtol=2e-4, atol=2e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("net_name", ["GINet", "sGAT", "FoutNet"])
+def test_composed_forward_equals_the_fused_path(net_name):
+    """The general path (composed.py: the reference's own composition of layers and pooling functions, ginet.py:99-141) on a
+    net with the reference's options: the fused path's predictions and gradients."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.composed import composed_forward, default_layers
+    from test_gpu_parity import nets
+    batch = synth.make_batch(0, 6, n_nodes=60, n_pairs=120, n_feat=20, n_c1=5, n_internal=20).to(_dev())
+    torch.manual_seed(31)
+    net = nets()[net_name](20, 1, 1).to(_dev())
+    if hasattr(net, "dropout"):
+        net.dropout = 0.0
+    net.train()
+    assert default_layers(net)
+    out = net(batch)
+    assert _engine(net).last_path == "jacobian"
+    F.mse_loss(out.reshape(-1), batch.y).backward()
+    fused = {n: p.grad.clone() for n, p in net.named_parameters()}
+    for p in net.parameters():
+        p.grad = None
+    x_before = batch.x.clone()
+    out2 = composed_forward(net, batch)
+    assert torch.equal(batch.x, x_before)                  # the caller's batch is left alone
+    F.mse_loss(out2.reshape(-1), batch.y).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out2.detach().cpu().numpy(), out.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    for n, p in net.named_parameters():
+        if p.grad is None:          # (GINet's dead attention parameters: no gradient at all through the layer functions' autograd?)
+            assert float(fused[n].abs().max()) == 0.0, n
+            continue
+        r = fused[n].cpu().numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(r).max())), err_msg=n)
+
+
+@pytest.mark.parametrize("net_name", ["sGAT", "FoutNet"])
+def test_layer_options_the_reference_nets_do_not_use(net_name):
+    """sGraphAttentionLayer(bias=False, undirected=False) (sGAT.py:50-53,86-87) / FoutLayer(bias=False) (foutnet.py:43-46) inside
+    the nets: model(batch) takes the general path and matches the oracle's composition of the same layer functions."""
+    import deeprank_gnn_amd.synthetic as synth
+    from oracle import cpu_ref
+    from deeprank_gnn_amd.sGAT import sGAT, sGraphAttentionLayer
+    from deeprank_gnn_amd.foutnet import FoutNet, FoutLayer
+    batch_cpu = synth.make_batch(0, 5, n_nodes=50, n_pairs=100, n_feat=12, n_c1=4, n_internal=20)
+    torch.manual_seed(33)
+    if net_name == "sGAT":
+        net = sGAT(12, 1, 1)
+        net.conv1 = sGraphAttentionLayer(12, 16, bias=False, undirected=False)
+        net.conv2 = sGraphAttentionLayer(16, 32, bias=False, undirected=False)
+        conv = lambda pre: (lambda x, ei, ea: cpu_ref.sgat_conv(x, ei, ea, P[pre + ".weight"], None, undirected=False))   # noqa: E731
+    else:
+        net = FoutNet(12, 1, 1)
+        net.conv1 = FoutLayer(12, 16, bias=False)
+        net.conv2 = FoutLayer(16, 32, bias=False)
+        conv = lambda pre: (lambda x, ei, ea: cpu_ref.fout_conv(x, ei, P[pre + ".Wc"], P[pre + ".Wn"], None, looped=False))  # noqa: E731
+    P = {k: v.detach().clone().requires_grad_(True) for k, v in net.state_dict().items()}
+    x2, b2 = cpu_ref._branch(cpu_ref._as_ns(batch_cpu), conv("conv1"), conv("conv2"), None, "a.")
+    feat = cpu_ref.scatter_mean(x2, b2)
+    ref = F.linear(F.relu(F.linear(feat, P["fc1.weight"], P["fc1.bias"])), P["fc2.weight"], P["fc2.bias"])
+    F.mse_loss(ref.reshape(-1), batch_cpu.y).backward()
+    net = net.to(_dev())
+    net.train()
+    batch = batch_cpu.clone().to(_dev())
+    out = net(batch)
+    assert net.__dict__.get("_drgnn_engine") is None        # the general path: no fused step for these options
+    F.mse_loss(out.reshape(-1), batch.y).backward()
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-4)
+    for n, p in net.named_parameters():
+        r = P[n].grad.numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(r).max())), err_msg=n)

@@ -96,3 +96,33 @@ def test_native_trainer_on_a_ragged_batch_with_class_weights():
         np.testing.assert_allclose(float(got), float(loss), rtol=1e-4)
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.gpu
+def test_scatter_functions_with_an_index_of_the_shape_of_src():
+    """torch_scatter's general form (index broadcast to src's shape: every column its own index vector) -- not used by the
+    reference (1-D indices: ginet.py:71,133), served column by column: against a plain loop."""
+    from deeprank_gnn_amd.community_pooling import scatter_sum, scatter_mean, scatter_max
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    src = torch.randn((30, 4), generator=gen)
+    index = torch.randint(0, 7, (30, 4), generator=gen)
+    want_sum = torch.zeros((7, 4)).scatter_add_(0, index, src)
+    cnt = torch.zeros((7, 4)).scatter_add_(0, index, torch.ones_like(src)).clamp(min=1)
+    want_max = torch.zeros((7, 4))
+    want_arg = torch.full((7, 4), 30, dtype=torch.int64)
+    for j in range(4):
+        for k in range(7):
+            rows = (index[:, j] == k).nonzero().reshape(-1)
+            if rows.numel():
+                v, a = src[rows, j].max(dim=0)
+                want_max[k, j], want_arg[k, j] = v, rows[a]
+    s, i = src.to(dev), index.to(dev)
+    np.testing.assert_allclose(scatter_sum(s, i, dim=0).cpu().numpy(), want_sum.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(scatter_mean(s, i, dim=0).cpu().numpy(), (want_sum / cnt).numpy(), rtol=1e-5, atol=1e-6)
+    mx, arg = scatter_max(s, i, dim=0)
+    np.testing.assert_allclose(mx.cpu().numpy(), want_max.numpy(), rtol=1e-6)
+    np.testing.assert_array_equal(arg.cpu().numpy(), want_arg.numpy())
+    # along the last dimension, with dim_size
+    got = scatter_sum(s.t().contiguous(), i.t().contiguous(), dim=1, dim_size=9)
+    np.testing.assert_allclose(got.cpu().numpy(), torch.cat([want_sum, torch.zeros((2, 4))]).t().numpy(), rtol=1e-5, atol=1e-6)
