@@ -576,3 +576,68 @@ def test_layer_options_the_reference_nets_do_not_use(net_name):
     for n, p in net.named_parameters():
         r = P[n].grad.numpy()
         np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=1e-3, atol=1e-4 * max(1.0, float(np.abs(r).max())), err_msg=n)
+
+
+@pytest.mark.parametrize("net_name,task", [("GINet", "reg"), ("sGAT", "reg"), ("FoutNet", "reg"), ("GINet", "class")])
+def test_reference_trainer_call_pattern_on_the_fixture(net_name, task):
+    """BASELINE configs[0]'s shape through the boundary the way the reference trainer drives it (NeuralNet.py:153-154,
+    183-184,239-263,489-523): a DataLoader over the fixture's ten 1ATN graphs (batch 8 + a ragged last batch of 2, shuffled),
+    `data_batch.to(device)`, `model(data_batch)`, MSELoss / CrossEntropyLoss on `.reshape(-1)` / logits, `loss.backward()`,
+    `torch.optim.Adam(model.parameters(), lr)`, `F.softmax(pred, dim=1)` for the class outputs; then `model.eval()` + no_grad
+    over the same loader.  Three epochs: the loss falls, every step ran the fused kernels, and a twin net driven through the
+    launch pair (fused path switched off) ends with the same parameters."""
+    from helpers import fixture_graphs
+    from deeprank_gnn_amd.data import DataLoader
+    from deeprank_gnn_amd import fused_autograd
+    from test_gpu_parity import nets
+    graphs = fixture_graphs(target="irmsd" if task == "reg" else "binclass")
+    n_feat = int(graphs[0].x.shape[1])
+    n_out = 1 if task == "reg" else 2
+
+    def run(fused):
+        torch.manual_seed(41)
+        net = nets()[net_name](n_feat, n_out, 1).to(_dev())
+        if hasattr(net, "dropout"):
+            net.dropout = 0.0
+        opt = torch.optim.Adam(net.parameters(), lr=0.005)
+        crit = torch.nn.MSELoss() if task == "reg" else torch.nn.CrossEntropyLoss()
+        gen = torch.Generator().manual_seed(3)
+        loader = DataLoader(graphs, batch_size=8, shuffle=True, generator=gen)
+        saved = fused_autograd.StepEngine.run
+        if not fused:
+            fused_autograd.StepEngine.run = lambda self, data, topo=None: None        # (every call takes the launch pair)
+        try:
+            losses, paths = [], set()
+            for epoch in range(3):
+                net.train()
+                running = 0.0
+                for data_batch in loader:
+                    data_batch = data_batch.to(_dev())
+                    opt.zero_grad()
+                    pred = net(data_batch)
+                    if fused:
+                        paths.add(fused_autograd.engine_for(net).last_path)
+                    y = data_batch.y if task == "reg" else data_batch.y.to(torch.int64)
+                    loss = crit(pred.reshape(-1), y) if task == "reg" else crit(pred, y)
+                    running += float(loss.detach())
+                    loss.backward()
+                    opt.step()
+                    if task == "class":
+                        assert bool(torch.isfinite(F.softmax(pred, dim=1)).all())
+                losses.append(running)
+            net.eval()
+            outs = []
+            with torch.no_grad():
+                for data_batch in DataLoader(graphs, batch_size=8, shuffle=False):
+                    outs.append(net(data_batch.to(_dev())))
+            return net, losses, paths, torch.cat(outs)
+        finally:
+            fused_autograd.StepEngine.run = saved
+    net_a, losses_a, paths, out_a = run(True)
+    assert paths == {"jacobian" if n_out == 1 else "two-launch"}, paths
+    assert losses_a[-1] < losses_a[0] and np.isfinite(losses_a).all()
+    net_b, losses_b, _, out_b = run(False)
+    np.testing.assert_allclose(losses_a, losses_b, rtol=2e-3)
+    np.testing.assert_allclose(out_a.cpu().numpy(), out_b.cpu().numpy(), rtol=5e-3, atol=5e-3)
+    for (n, p), (_, q) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=5e-3, atol=5e-4, err_msg=n)
