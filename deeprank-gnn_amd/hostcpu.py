@@ -5,7 +5,7 @@ ops around it (shuffling, concatenating, gathering index rows) go through torch'
 thread per VISIBLE core (256 on the MI355X hosts), its threads spin for a while after every parallel region, and a container
 whose cgroup grants fewer CPUs than it shows (cpu.max "1600000 100000" = 16 CPUs on the measured boxes) then runs out of quota
 within each 100 ms CFS period: every thread of the process -- the launching one included -- is frozen until the next period.
-Measured (tools/throttle_probe.sh, profiles/r03_throttle_probe.txt): 1024-mini-batch epochs 38 - 45 us/batch with 13 throttled
+Measured (tools/history/throttle_probe.sh, profiles/r03_throttle_probe.txt): 1024-mini-batch epochs 38 - 45 us/batch with 13 throttled
 periods (10.1 s of throttled thread time) at the default pool, 21.1 / 20.5 us/batch and no throttling with a 4-thread pool.
 
 `fit_torch_threads()` sizes the pool to what the cgroup really grants (half the quota, shared between the ranks of the node),
