@@ -54,13 +54,30 @@ class _Staged(object):
     later: the epoch loop enqueues the next epoch before it looks at the previous one's numbers, so the device never
     idles while the host turns outputs into the reference's Python lists (NeuralNet.py:446-460,508-523 syncs per batch)."""
 
+    # Pinned buffers are reused: allocating page-locked memory costs ~50 us a piece, three pieces per epoch -- as much host time
+    # as enqueuing eight mini-batches.  A ring of eight per (shape, dtype): at most four passes of a shape are in flight (train()
+    # reads epoch e - 1 while epoch e runs), and a buffer is handed out again only after its reader has let go of it (get()).
+    _ring = {}
+
+    @classmethod
+    def _pinned(cls, shape, dtype):
+        key = (tuple(shape), dtype)
+        slots = cls._ring.setdefault(key, {"bufs": [], "next": 0})
+        if len(slots["bufs"]) < 8:
+            buf = torch.empty(shape, dtype=dtype, pin_memory=True)
+            slots["bufs"].append(buf)
+            return buf
+        buf = slots["bufs"][slots["next"]]
+        slots["next"] = (slots["next"] + 1) % 8
+        return buf
+
     def __init__(self, **tensors):
         self.host, self.event = {}, None
         for k, t in tensors.items():
             if t is None or not torch.is_tensor(t):
                 self.host[k] = t
             elif t.is_cuda:
-                h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                h = self._pinned(t.shape, t.dtype)
                 h.copy_(t.detach(), non_blocking=True)
                 self.host[k] = h
                 self.event = self.event or torch.cuda.Event()
@@ -73,7 +90,57 @@ class _Staged(object):
         if self.event is not None:
             self.event.synchronize()
             self.event = None
+            # (the pinned buffers go back to the ring: the caller gets copies it may keep)
+            self.host = {k: (v.clone() if torch.is_tensor(v) and v.is_pinned() else v) for k, v in self.host.items()}
         return self.host
+
+
+class _PassStore(dict):
+    """The reference's per-pass record ``{'outputs', 'raw_outputs', 'targets', 'mol'}`` (NeuralNet.py:440-460,508-523: Python
+    lists, one entry per graph) whose lists are FORMED WHEN READ: a training run reads the lists of the few epochs it exports
+    and of the last one, while building them costs more host time per epoch than enqueuing the epoch's launches (2048 graphs:
+    ~0.4 ms of list building against 0.25 ms of launches).  ``defer(key, fn)``: ``fn()`` gives the entries to append to
+    ``self[key]`` the first time somebody looks.  ``arrays``: (outputs, targets) of the pass as numpy arrays in the space the
+    accuracy is judged in (what _accuracy reads instead of the lists)."""
+    LISTS = ('outputs', 'raw_outputs', 'targets', 'mol')
+
+    def __init__(self):
+        super().__init__({'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': [], '_pred': [], '_y': []})
+        self._deferred = {}
+        self.arrays = None
+
+    def defer(self, key, fn):
+        self._deferred.setdefault(key, []).append(fn)
+
+    def _settle(self, key):
+        fns = self._deferred.pop(key, None)
+        if fns:
+            cur = dict.__getitem__(self, key)
+            for fn in fns:
+                cur += fn()
+
+    def __getitem__(self, key):
+        if key in self._deferred:
+            self._settle(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        if key in self._deferred:
+            self._settle(key)
+        return dict.get(self, key, default)
+
+    def items(self):
+        for key in list(self._deferred):
+            self._settle(key)
+        return dict.items(self)
+
+    def values(self):
+        for key in list(self._deferred):
+            self._settle(key)
+        return dict.values(self)
+
+    def has_targets(self):
+        return bool(self._deferred.get('targets')) or bool(dict.__getitem__(self, 'targets'))
 
 
 class NeuralNet(object):
@@ -175,6 +242,7 @@ class NeuralNet(object):
         self.cached_topology = "auto"
         self.topology_cache_budget = 32 << 30       # bytes per resident set (an MI355X holds 288 GB)
         self._cache_choice = {}
+        self._order_cache, self._eval_targets = {}, {}
         self.exported = []            # (epoch, file) of the epoch data written so far
 
     # ------------------------------------------------------------------------------
@@ -251,32 +319,44 @@ class NeuralNet(object):
         loss = None if loss is None else float(loss)
         if pred is None:
             return loss
+        # (the lists of the reference's record are formed when somebody reads them: _PassStore)
         if self.task == 'class':
             prob = torch.softmax(pred, dim=1)
-            store['raw_outputs'] += prob.tolist()
-            store['outputs'] += [self.idx_to_classes[i] for i in prob.argmax(dim=1).tolist()]
+            top = prob.argmax(dim=1)
+            store.defer('raw_outputs', lambda: prob.tolist())
+            store.defer('outputs', lambda: [self.idx_to_classes[i] for i in top.tolist()])
             if y is not None:
-                store['targets'] += [self.idx_to_classes[int(i)] for i in y.tolist()]
+                store.defer('targets', lambda: [self.idx_to_classes[int(i)] for i in y.tolist()])
+            store.arrays = (top.numpy(), None if y is None else y.numpy().astype(np.int64))
         else:
-            out = pred.reshape(-1).tolist()
-            store['raw_outputs'] += out
-            store['outputs'] += out
+            flat = pred.reshape(-1)
+            store.defer('raw_outputs', lambda: flat.tolist())
+            store.defer('outputs', lambda: flat.tolist())
             if y is not None:
-                store['targets'] += y.tolist()
+                store.defer('targets', lambda: y.tolist())
+            store.arrays = (flat.numpy(), None if y is None else y.numpy())
         return loss
 
     def _accuracy(self, store, threshold=None):
         """Metrics(...).accuracy of the reference (Metrics.py:10-31,113-120,170): predictions and targets are made
         binary at ``threshold`` -- in class-INDEX space for classification (NeuralNet.get_metrics, NeuralNet.py:548-549)
         -- '>' for fnat / bin_class, '<' for the others, and the accuracy is the fraction on which the two agree."""
-        if not store['targets']:
+        arrays = getattr(store, "arrays", None)
+        if arrays is not None and arrays[1] is None:
+            return None
+        if arrays is None and not store['targets']:
             return None
         threshold = self.threshold if threshold is None else threshold
         if self.task == 'class':
             # (test()'s default threshold 4 is a capri class; other class sets fall back to the trainer's threshold)
             thr = self.classes_to_idx[threshold if threshold in self.classes_to_idx else self.threshold]
-            o = np.asarray([self.classes_to_idx[v] for v in store['outputs']])
-            t = np.asarray([self.classes_to_idx[v] for v in store['targets']])
+            if arrays is not None:          # (class INDICES already: what the lists' labels map back to)
+                o, t = arrays
+            else:
+                o = np.asarray([self.classes_to_idx[v] for v in store['outputs']])
+                t = np.asarray([self.classes_to_idx[v] for v in store['targets']])
+        elif arrays is not None:
+            thr, (o, t) = threshold, arrays
         else:
             thr, o, t = threshold, np.asarray(store['outputs']), np.asarray(store['targets'])
         if self.target in ('fnat', 'bin_class'):
@@ -285,7 +365,15 @@ class NeuralNet(object):
 
     @staticmethod
     def _new_store():
-        return {'outputs': [], 'raw_outputs': [], 'targets': [], 'mol': [], '_pred': [], '_y': []}
+        return _PassStore()
+
+    def _order_of(self, indices):
+        """``indices`` as an int64 tensor, built once per index list (the train / validation split does not change)."""
+        key = (id(indices), len(indices))
+        held = self._order_cache.get(key)
+        if held is None or held[0] is not indices:
+            held = self._order_cache[key] = (indices, torch.as_tensor([int(i) for i in indices], dtype=torch.int64))
+        return held[1]
 
     def _epoch(self, epoch):
         """One pass over the training set (NeuralNet.py:477-537) on the native step, ENQUEUED: no host synchronisation
@@ -302,16 +390,17 @@ class NeuralNet(object):
             # the whole epoch enqueued by the native loop (drgnn_train_epoch): collate, step (+ next topology) and
             # update launches for every mini-batch
             rs = self._resident(self.dataset)
-            order = torch.as_tensor([int(i) for i in self.train_index], dtype=torch.int64)
+            order = self._order_of(self.train_index)
             if self.shuffle:
                 order = order[torch.randperm(order.numel())]
             done = self.trainer.train_epoch(rs, order, self.batch_size, cached=self._use_cache(rs))
             if done is not None:
                 losses, pred = done
                 store['_pred'].append(pred)
-                store['_y'].append(rs.y[_index_on(rs.y.device, order)])
-                order = order.tolist()
-                store['mol'] += [rs.mols[i] for i in order]
+                # the pass's targets and molecule names in visiting order: a host gather of the set's host copy and a list
+                # formed when somebody reads it -- no device work, no per-graph Python per epoch
+                store['_y'].append(rs.y_host[order])
+                store.defer('mol', lambda: [rs.mols[i] for i in order.tolist()])
                 return self._stage(store, losses.sum())
         running = torch.zeros((), dtype=torch.float32, device=self.device)
         need_w = self.trainer.kind == _lib.SGAT
@@ -427,12 +516,15 @@ class NeuralNet(object):
             pred = self.trainer.predict_epoch(rs, order, self.batch_size, cached=self._use_cache(rs))
             if pred is not None:
                 store['_pred'].append(pred)
-                store['mol'] += [rs.mols[i] for i in order]
+                store.defer('mol', lambda: [rs.mols[i] for i in order])
                 total = None
                 if rs.y is not None:
-                    y = rs.y[_index_on(rs.y.device, order)]
-                    store['_y'].append(y)
-                    total = self._sum_of_batch_losses(pred, y)
+                    held = self._eval_targets.get((id(rs), id(indices), len(order)))
+                    if held is None or held[0] is not indices:      # (a validation / test pass visits the same graphs every time)
+                        idx = torch.as_tensor(order, dtype=torch.int64)
+                        held = self._eval_targets[(id(rs), id(indices), len(order))] = (indices, rs.y[_index_on(rs.y.device, order)], rs.y_host[idx])
+                    store['_y'].append(held[2])
+                    total = self._sum_of_batch_losses(pred, held[1])
                 return self._stage(store, total)
         total = torch.zeros((), dtype=torch.float32, device=self.device)
         need_w = self.trainer.kind == _lib.SGAT
@@ -525,7 +617,7 @@ class NeuralNet(object):
         loss, store = self.eval(ds, list(range(len(ds))))
         self.data = {'test': store}
         self.test_loss = loss
-        self.test_acc = self._accuracy(store, threshold) if store['targets'] else None
+        self.test_acc = self._accuracy(store, threshold) if store.has_targets() else None
         if hdf5:
             self.export(self.update_name(self._rank_name(hdf5), self.outdir), {'epoch_0000': self.data})
         return store

@@ -84,8 +84,10 @@ class ResidentGraphSet(object):
         self.cluster0 = cluster0.to(torch.int64).contiguous().to(dev) if self.has_c0 else None
         self.cluster1 = cluster1.to(torch.int64).contiguous().to(dev) if self.has_c1 else None
         self.y = None
+        self.y_host = None      # the targets on the host as well (a pass's targets in visiting order are a host gather: no device work)
         if self.has_y:
-            self.y = (y.to(torch.float32) if y.is_floating_point() else y.to(torch.int64)).contiguous().to(dev)
+            self.y_host = (y.to(torch.float32) if y.is_floating_point() else y.to(torch.int64)).contiguous().cpu()
+            self.y = self.y_host.to(dev)
         self._ptr_dev = [torch.from_numpy(p).to(dev) for p in (self.node_ptr, self.edge_ptr, self.c1_ptr)]
         gs = _lib.GraphSet()
         gs.n_graphs, gs.n_nodes, gs.n_edges = len(self.mols), int(self.node_ptr[-1]), int(self.edge_ptr[-1])
@@ -234,7 +236,8 @@ class ResidentGraphSet(object):
         y = y.reshape(-1)
         if y.numel() != len(self):
             raise ValueError("expected %d targets, got %d" % (len(self), y.numel()))
-        self.y = (y.to(torch.float32) if y.is_floating_point() else y.to(torch.int64)).contiguous().to(self.device)
+        self.y_host = (y.to(torch.float32) if y.is_floating_point() else y.to(torch.int64)).contiguous().cpu()
+        self.y = self.y_host.to(self.device)
         self.has_y = True
         self._desc.y = self.y.data_ptr()
         self._desc.y_bytes = self.y.element_size()
