@@ -611,6 +611,10 @@ def main():
                 result["dropin_loop"] = measure_dropin_loop(dev, None if (args.net == "GINet" and GRAPHS_PER_GPU == 64)
                                                             else [(args.net, GRAPHS_PER_GPU)])
             try:
+                result["neuralnet_train"] = measure_neuralnet_train(Net, args.net, dev)
+            except Exception as exc:                      # secondary figure: never lose the bench line over it
+                result["neuralnet_train"] = {"error": repr(exc)[:200]}
+            try:
                 result["inference_loop"] = measure_inference_loop(Net, args.net, args.epoch_graphs, dev)
             except Exception as exc:                      # secondary figure: never lose the bench line over it
                 result["inference_loop"] = {"error": repr(exc)[:200]}
@@ -1147,6 +1151,46 @@ def measure_dropin_loop(dev, configs=None, n_batches=32):
         except Exception as exc:                          # secondary figure: never lose the bench line over it
             out[key] = {"error": repr(exc)[:300]}
     return out
+
+
+def measure_neuralnet_train(Net, net_name, dev, n_graphs=2048, epochs=20):
+    """Secondary figure (not `value`): what a user of the trainer counterpart gets END TO END -- `deeprank_gnn_amd.NeuralNet(database,
+    Net, ...).train(nepoch)` (the reference's NeuralNet.py:265-355 call) on a graph file of `n_graphs` synthetic graphs: upload
+    once, shuffled epochs through the native loop (cached topology: the default), every host-side piece of an epoch included
+    (shuffle, bookkeeping of outputs / targets / accuracy, the progress line).  us per mini-batch over whole train() calls,
+    best of three."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd.NeuralNet import NeuralNet
+    tmp = tempfile.mkdtemp()
+    try:
+        db = synth.save_store(os.path.join(tmp, "syn.npz"), n_graphs, first_id=GRAPHS_PER_GPU, n_feat=N_FEAT)
+        torch.manual_seed(0)
+        quiet = io.StringIO()
+        with contextlib.redirect_stdout(quiet):
+            nn = NeuralNet(db, Net, node_feature=["feat"], edge_feature=["dist"], target="irmsd", batch_size=GRAPHS_PER_GPU,
+                           percent=[1.0, 0.0], outdir=tmp, lr=1e-3)
+            nn.train(nepoch=3, save_model=None, hdf5=None)      # upload, topology cache, allocations
+        torch.cuda.synchronize()
+        nb = (n_graphs + GRAPHS_PER_GPU - 1) // GRAPHS_PER_GPU
+        runs = []
+        for _ in range(3):
+            with contextlib.redirect_stdout(quiet):
+                t0 = time.perf_counter()
+                nn.train(nepoch=epochs, save_model=None, hdf5=None)
+                torch.cuda.synchronize()
+                runs.append((time.perf_counter() - t0) / (epochs * nb) * 1e6)
+        best = min(runs)
+        return {"us_per_batch": best, "us_per_batch_runs": [round(r, 2) for r in runs], "graphs_per_s": n_graphs / (best * nb * 1e-6),
+                "graphs": n_graphs, "batch": GRAPHS_PER_GPU, "batches_per_epoch": nb, "epochs_per_call": epochs, "net": net_name,
+                "cached_topology": bool(nn._use_cache(nn._resident(nn.dataset))), "last_train_loss": float(nn.train_loss[-1]),
+                "what": "deeprank_gnn_amd.NeuralNet(file of synthetic graphs, Net).train(%d) wall time per mini-batch, everything the "
+                        "call does on the host included" % epochs}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def measure_epoch_loop(Net, net_name, n_graphs, dev, epochs=4):

@@ -116,3 +116,32 @@ def make_graph(graph_id, n_nodes=200, n_pairs=500, n_feat=32, n_c1=16, n_interna
 
 def make_batch(first_id=0, n_graphs=64, **kw):
     return Batch.from_data_list([make_graph(first_id + i, **kw) for i in range(n_graphs)])
+
+
+def save_store(path, n_graphs, first_id=0, **kw):
+    """``n_graphs`` synthetic graphs written as a graph file in the GraphStore ``.npz`` layout (the reference's HDF5 tree,
+    Graph.py:61-139: per molecule ``node_data/*``, ``edge_index`` (undirected pairs), ``edge_data/dist``,
+    ``internal_edge_*``, ``score/irmsd``, ``clustering/mcl/depth_{0,1}``) -- what ``NeuralNet(database, Net, node_feature=['feat'],
+    edge_feature=['dist'], target='irmsd')`` reads back into exactly these graphs (up to the float32 rounding of the distance)."""
+    arrays, mols = {}, []
+    for i in range(n_graphs):
+        g = make_graph(first_id + i, **kw)
+        m = "syn_%06d" % (first_id + i)
+        mols.append(m)
+        half = g.edge_index.shape[1] // 2
+        ih = g.internal_edge_index.shape[1] // 2
+        attr = g.edge_attr.reshape(-1)[:half].double().numpy()
+        iattr = g.internal_edge_attr.reshape(-1)[:ih].double().numpy()
+        inv = lambda a: 2.0 * (2.0 - np.arctanh(np.clip(a - 1.0, -0.999999, 0.999999)))       # noqa: E731  (tanh(-d/2 + 2) + 1)^-1
+        arrays[m + "/node_data/feat"] = g.x.numpy()
+        arrays[m + "/node_data/pos"] = g.pos.numpy()
+        arrays[m + "/edge_index"] = g.edge_index[:, :half].t().contiguous().numpy()
+        arrays[m + "/edge_data/dist"] = inv(attr)
+        arrays[m + "/internal_edge_index"] = g.internal_edge_index[:, :ih].t().contiguous().numpy()
+        arrays[m + "/internal_edge_data/dist"] = inv(iattr)
+        arrays[m + "/score/irmsd"] = np.float64(g.y.item())
+        arrays[m + "/clustering/mcl/depth_0"] = g.cluster0.numpy()
+        arrays[m + "/clustering/mcl/depth_1"] = g.cluster1.numpy()
+    arrays["__mols__"] = np.array(mols)
+    np.savez(path, **arrays)
+    return path

@@ -25,25 +25,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 E = int(sys.argv[3]) if len(sys.argv) > 3 else 20
 tmp = tempfile.mkdtemp()
 db = os.path.join(tmp, "syn.npz")
-arrays, mols = {}, []
-for i in range(G):
-    g = synth.make_graph(i)
-    m = "syn_%05d" % i
-    mols.append(m)
-    half = g.edge_index.shape[1] // 2
-    ih = g.internal_edge_index.shape[1] // 2
-    attr = g.edge_attr.reshape(-1)[:half].double().numpy()
-    arrays[m + "/node_data/feat"] = g.x.numpy()
-    arrays[m + "/node_data/pos"] = g.pos.numpy()
-    arrays[m + "/edge_index"] = g.edge_index[:, :half].t().contiguous().numpy()
-    arrays[m + "/edge_data/dist"] = 2.0 * (2.0 - np.arctanh(np.clip(attr - 1.0, -0.999999, 0.999999)))      # inverse of tanh(-d/2+2)+1
-    arrays[m + "/internal_edge_index"] = g.internal_edge_index[:, :ih].t().contiguous().numpy()
-    arrays[m + "/internal_edge_data/dist"] = np.full(ih, 4.0)
-    arrays[m + "/score/irmsd"] = np.float64(g.y.item())
-    arrays[m + "/clustering/mcl/depth_0"] = g.cluster0.numpy()
-    arrays[m + "/clustering/mcl/depth_1"] = g.cluster1.numpy()
-arrays["__mols__"] = np.array(mols)
-np.savez(db, **arrays)
+synth.save_store(db, G)
 torch.manual_seed(0)
 quiet = io.StringIO()
 with redirect_stdout(quiet):
