@@ -38,6 +38,10 @@ ep = g.get("epoch_loop") or {}
 rows.append(("`epoch_loop`, NeuralNet default (cached per set), 64 mini-batches per epoch", "%s µs per mini-batch (rebuilt: %s; 1024 per epoch: %s cached / %s rebuilt)" % (
     us(ep.get("us_per_batch")), us((ep.get("rebuilt_topology") or {}).get("us_per_batch")),
     us((ep.get("long_epochs_cached") or {}).get("us_per_batch")), us((ep.get("long_epochs") or {}).get("us_per_batch")))))
+nt = g.get("neuralnet_train") or {}
+if nt.get("us_per_batch"):
+    rows.append(("`neuralnet_train`: `NeuralNet(file, GINet).train(20)` end to end, %d graphs, batch %d" % (nt["graphs"], nt["batch"]),
+                 "%.2f µs per mini-batch (%.2f M graphs/s), host bookkeeping included" % (nt["us_per_batch"], nt["graphs_per_s"] / 1e6)))
 inf = g.get("inference_loop") or {}
 for k, v in inf.items():
     if isinstance(v, dict) and "us_per_batch" in v:
