@@ -468,8 +468,8 @@ class NeuralNet(object):
                 raise _lib.DrgnnError("the native epoch loop refused a configuration its probe had accepted")
             losses, pred = done
             store['_pred'].append(pred)
-            store['_y'].append(rs.y[_index_on(rs.y.device, mine)])
-            store['mol'] += [rs.mols[i] for i in mine]
+            store['_y'].append(rs.y_host[torch.as_tensor(mine, dtype=torch.int64)])      # (host gather: no device work)
+            store.defer('mol', lambda: [rs.mols[i] for i in mine])
             total = (losses * w).sum()
         else:
             # per mini-batch: the same global mini-batches, each rank steps its shard.  A rank without a graph of a
