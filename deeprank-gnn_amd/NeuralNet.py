@@ -242,7 +242,7 @@ class NeuralNet(object):
         self.cached_topology = "auto"
         self.topology_cache_budget = 32 << 30       # bytes per resident set (an MI355X holds 288 GB)
         self._cache_choice = {}
-        self._order_cache, self._eval_targets = {}, {}
+        self._order_cache, self._eval_targets, self._batch_counts = {}, {}, {}
         self.exported = []            # (epoch, file) of the epoch data written so far
 
     # ------------------------------------------------------------------------------
@@ -490,14 +490,34 @@ class NeuralNet(object):
 
     def _sum_of_batch_losses(self, pred, y):
         """Sum over the mini-batches of each batch's mean loss (what the reference accumulates, NeuralNet.py:441-447)."""
-        bs = self.batch_size
-        total = torch.zeros((), dtype=torch.float32, device=pred.device)
-        for lo in range(0, pred.size(0), bs):
-            if self.task == 'reg':
-                total += torch.nn.functional.mse_loss(pred[lo:lo + bs].reshape(-1), y[lo:lo + bs])
-            else:
-                total += torch.nn.functional.cross_entropy(pred[lo:lo + bs], y[lo:lo + bs], weight=self.trainer.class_w)
-        return total
+        # (one segmented mean over all mini-batches instead of a loss call per mini-batch: a validation pass of 8 mini-batches
+        # cost the host 0.2 ms that way -- as much as enqueuing the pass itself)
+        bs, n = int(self.batch_size), int(pred.size(0))
+        nfull = n // bs
+
+        def per_batch(v):
+            """[n] -> [n_batches]: sums over the mini-batches (full ones through a reshape: fixed summation order)"""
+            parts = []
+            if nfull:
+                parts.append(v[:nfull * bs].reshape(nfull, bs).sum(dim=1))
+            if n > nfull * bs:
+                parts.append(v[nfull * bs:].sum().reshape(1))
+            return torch.cat(parts) if len(parts) > 1 else parts[0]
+        def counts():
+            key = (n, bs, pred.device)
+            c = self._batch_counts.get(key)
+            if c is None:
+                c = self._batch_counts[key] = torch.tensor([float(bs)] * nfull + ([float(n - nfull * bs)] if n > nfull * bs else []),
+                                                           dtype=torch.float32, device=pred.device)
+            return c
+        if self.task == 'reg':
+            per = ((pred.reshape(n, -1) - y.reshape(n, 1).to(pred.dtype)) ** 2).mean(dim=1)
+            denom = counts()
+        else:
+            w = self.trainer.class_w
+            per = torch.nn.functional.cross_entropy(pred, y, weight=w, reduction='none')
+            denom = counts() if w is None else per_batch(w[y].to(per.dtype))
+        return (per_batch(per) / denom).sum()
 
     def eval(self, dataset=None, indices=None):
         """Forward only (NeuralNet.py:414-475); returns (loss_sum, store)."""
