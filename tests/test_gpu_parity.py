@@ -153,6 +153,10 @@ def test_full_size_batch_vs_oracle_and_determinism(net_name):
         return out.detach().clone(), {k: p.grad.detach().clone() for k, p in net.named_parameters()}
 
     out1, g1 = run()
+    # (the boundary an unchanged reference trainer drives, on the fused step kernels: fused_autograd)
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.fused_autograd import engine_for
+    assert engine_for(net).last_path == "jacobian" and engine_for(net).last_plan.family == _lib.STEP_FAMILY_AGGREGATE
     out2, g2 = run()
     assert torch.equal(out1, out2)                     # bit-reproducible: no float atomics
     for k in g1:
