@@ -133,6 +133,10 @@ def parse():
                          "(`dp_distinct` in the line): the figure without the L2 residency of a replayed mini-batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dropin", action="store_true", help="skip the drop-in loop figures (dropin_loop)")
+    ap.add_argument("--counter-pass", action="store_true",
+                    help="for rocprofv3 --pmc passes (tools/collect_profiles.sh): skip the roofline leg that launches the step "
+                         "kernel WITHOUT the co-launched builder, so that the per-kernel-name counter average is over one kind "
+                         "of launch (the main loop's); with --topology cached the other way round")
     ap.add_argument("--dropin-only", action="store_true",
                     help="run ONLY the drop-in loop of --net at --graphs-per-gpu (profiling runs) and print its figures")
     ap.add_argument("--no-other-nets", action="store_true",
@@ -147,8 +151,9 @@ def parse():
 
 
 def main():
-    global GRAPHS_PER_GPU, N_FEAT
+    global GRAPHS_PER_GPU, N_FEAT, COUNTER_PASS
     args = parse()
+    COUNTER_PASS = bool(args.counter_pass)
     # RCCL writes its version banner to STDOUT (NCCL_DEBUG unset or =VERSION, as this image exports it); stdout
     # carries the ONE json line.  Other NCCL_DEBUG levels are left as the user set them.
     if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
@@ -761,6 +766,9 @@ def two_flavours_parity(state):
     return state["k"] == 1
 
 
+COUNTER_PASS = False      # --counter-pass
+
+
 def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=None):
     """Average duration of each launch of the native step, measured LIVE with HIP events around `iters`
     back-to-back launches (20 per hipGraph replay, on torch's current stream = the stream the kernels are launched
@@ -838,6 +846,8 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
             (kname + " without the co-launched topology (not on the pipelined path)", k_step, alg)):
         if fn is k_topo_lean and lean_t is None:
             continue
+        if COUNTER_PASS and (fn is k_step or (cache and fn is k_step_co)):
+            continue
         # 20 back-to-back launches per hipGraph replay: the device-side duration, not the host's launch rate
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -875,6 +885,7 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
     # are read from the summary under profiles/ that was collected from THIS build (matched by source hash and net),
     # and reported as null otherwise
     traffic, traffic_note, mfma, mfma_note = None, None, None, None
+    traffic_cached = None     # the same counters of the launch WITHOUT a co-launched builder (cached topology), same summary
 
     def own_step_kernel(name):
         """is `name` (a kernel of a counter summary) the fused step kernel of THIS net?  (the default GINet run also launches
@@ -896,6 +907,9 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
                     traffic_note = ("bytes/launch from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, "
                                     "profiles/%s, same sources as this build); FETCH doubled per "
                                     "MI355X_MICROARCH.md" % where)
+            for k, v in (pmc.get("_cached_topology") or {}).items():
+                if own_step_kernel(k):
+                    traffic_cached = v["hbm_bytes_per_launch"]
         sq, where = counter_summary("sq", net_name)
         if sq is None:
             mfma_note = where
@@ -906,7 +920,7 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
                     mfma = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (step_us * 1e3 * 2.28 * 1024.0)
                     mfma_note = "SQ_VALU_MFMA_BUSY_CYCLES from profiles/%s (same sources as this build)" % where
     return {"bound": "hbm", "kernel": dom, "kernel_us": out[dom]["avg_us"], "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+            "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note, "traffic_cached_topology": traffic_cached,
             "mfma_util": mfma, "mfma_note": mfma_note,
             "alg_bytes_per_graph": alg, "graphs_per_launch": B, "source_hash": source_hash(),
             "with_builder": {"achieved": with_builder, "frac": with_builder / HBM_PEAK_GBS,

@@ -129,6 +129,7 @@ class StepEngine(object):
         self.cache_topology = True
         self.last_path = None      # 'jacobian' / 'two-launch' / 'inference' / None (the caller's launch pair)
         self.last_plan = None
+        self.last_reason = None    # why the last call was outside the fused kernels (last_path None)
 
     # (an engine is launch state, not model state: copies and pickles of the net start without one)
     def __deepcopy__(self, memo):
@@ -285,19 +286,24 @@ class StepEngine(object):
         return buf
 
     # -- one call --------------------------------------------------------------------------------------------------------
+    def _outside(self, why):
+        """This call is the caller's launch pair's; ``last_reason`` says why."""
+        self.last_reason = why
+        return None
+
     def run(self, data, topo=None):
         """pred [B, O] through the fused kernels, or None when this call is outside them (see the module docstring)."""
         net = self.net
         x = data.x
-        self.last_path = None
+        self.last_path = self.last_reason = None
         if not (torch.is_tensor(x) and x.dim() == 2 and x.dtype == torch.float32 and x.is_contiguous()) or x.requires_grad:
-            return None
+            return self._outside("node features are not a contiguous float32 [n, F] tensor without gradient")
         if topo is not None and topo.api is not self.api:
-            return None          # (a workspace of another library build -- the CPU suite's emulation: its launch pair)
+            return self._outside("workspace of another library build")          # (a workspace of another library build -- the CPU suite's emulation: its launch pair)
         if self.api is _lib._API and not x.is_cuda:
             _lib.require_device(x)
         if self.params[0].device != x.device or self.params[0].device != self.device:
-            return None
+            return self._outside("parameters and node features on different devices")
         held = None
         if topo is None:
             topo = self.topology_for(data)
@@ -308,7 +314,7 @@ class StepEngine(object):
                     held = None
         B, n_feat = topo.n_graphs, int(x.shape[1])
         if B <= 0 or topo.max_nodes <= 0 or x.shape[0] != topo.n_nodes:
-            return None
+            return self._outside("empty batch or a workspace of another batch")
         want_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.params)
         p_drop = float(getattr(net, "dropout", 0.0)) if net.training else 0.0
         mode = "inference"
@@ -320,7 +326,7 @@ class StepEngine(object):
             # the same batch object, tensors unchanged (topology_for compared the stamp): plan and launch hints as last time
             flags, plan, hints, bplan, bhints = ctx
             if mode == "two-launch" and p_drop > 0.0 and any(not c.done for c in self._pending):
-                return None
+                return self._outside("dropout with an earlier forward still awaiting its backward")
             return self._issue(mode, x, topo, plan, hints, bplan, bhints, B, n_feat, p_drop, want_grad)
         flags = self._usable_flags(topo, x)
         if not (flags & _lib.TOPO_TILES) and getattr(topo, "tiles", None) is not None and \
@@ -332,13 +338,15 @@ class StepEngine(object):
             flags = self._usable_flags(topo, x)
         plan = self._plan(n_feat, topo, mode == "jacobian", flags)
         if plan.family != _lib.STEP_FAMILY_AGGREGATE or not (0 < plan.lds_bytes <= 160 * 1024):
-            return None
+            return self._outside("no fused kernel for this launch (family %d, topology flags 0x%x, %d features, %d / %d / %d "
+                                 "nodes / edges / clusters per graph at most)" % (plan.family, flags, n_feat, topo.max_nodes,
+                                                                                  topo.max_edges, topo.max_c0))
         if mode == "two-launch":
             chk = self._plan(n_feat, topo, True, flags)
             if chk.family != _lib.STEP_FAMILY_AGGREGATE or not (0 < chk.lds_bytes <= 160 * 1024):
-                return None
+                return self._outside("no fused training kernel for this launch (family %d)" % chk.family)
             if p_drop > 0.0 and any(not c.done for c in self._pending):
-                return None      # (an earlier forward's backward would move the dropout stream between this forward and its own)
+                return self._outside("dropout with an earlier forward still awaiting its backward")      # (an earlier forward's backward would move the dropout stream between this forward and its own)
         bplan = bhints = None
         bd = getattr(data, "__dict__", {})
         hn, he = bd.get("_host_node_ptr"), bd.get("_host_edge_ptr")

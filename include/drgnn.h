@@ -454,9 +454,11 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   family   DRGNN_STEP_FAMILY_AGGREGATE: csrc/drgnn_step2.h (sGAT / FoutNet) / drgnn_step3.h (GINet) -- conv1 starts from the
  *            aggregation tiles the topology builder formed (DRGNN_TOPO_TILES), rows in the builder's hierarchical order
  *            (DRGNN_TOPO_HIER); padded feature widths 16 / 32 / 48 / 64, the reference heads (fc1 width 128 / 64), training and
- *            inference launches.  DRGNN_STEP_FAMILY_PRODUCT: csrc/drgnn_step.h / drgnn_step1.h -- any feature width <= 256, any
- *            head, any built topology.  DRGNN_STEP_FAMILY_NONE: a graph does not fit the fused kernels' LDS budget (use
- *            drgnn_net_forward + drgnn_net_backward_fused_head).
+ *            inference launches.  DRGNN_STEP_FAMILY_NONE: no fused kernel covers the launch -- a graph beyond the LDS budget,
+ *            more than 64 features, a head that is not the reference's, a workspace without hierarchical order / tiles (use
+ *            drgnn_net_forward + drgnn_net_backward_fused_head).  DRGNN_STEP_FAMILY_PRODUCT (csrc/drgnn_step.h / drgnn_step1.h,
+ *            the product-first kernels of rounds 2 - 3): the host emulation build of the CPU test suite only; the device
+ *            library does not instantiate them and never reports this family.
  *   wgs_per_graph  GINet (ginet.py:99-141: two branches over the same edge_index): 2 = one workgroup per branch, readouts
  *            exchanged, taken ONLY while all 2 * n_graphs (+ the co-launched builder's) workgroups are resident at once (one
  *            workgroup per CU: HIP promises nothing about dispatch order); 1 = both branches in one workgroup, no cross-workgroup
@@ -472,9 +474,10 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   lds_bytes  LDS one workgroup needs (<= 160 KiB whenever family != NONE); xchg_words: uint64 exchange words per graph
  * Overrides (0 = automatic; tests and same-box A/B runs): force_wgs 1 / 2 = always that many workgroups per graph (2 beyond the
  * resident size is MEASUREMENT ONLY: the exchange then leans on in-order dispatch; bounded wait + fault bit); no_class;
- * no_aggregate (the product-first family everywhere); no_split (sGAT / FoutNet never divided); no_paired (the one-workgroup
- * product-first GINet kernel runs branch after branch).  The environment variable DRGNN_STEP_PLAN (comma list of one, two,
- * noclass, product, nosplit, seq; read once) sets the defaults of a process for plans that override nothing. */
+ * no_aggregate (never the aggregation-first family: family NONE on the device, the launch pair steps the mini-batch);
+ * no_split (sGAT / FoutNet never divided); no_paired (emulation build: the one-workgroup product-first GINet kernel runs
+ * branch after branch).  The environment variable DRGNN_STEP_PLAN (comma list of one, two, noclass, product, nosplit, seq;
+ * read once) sets the defaults of a process for plans that override nothing. */
 #define DRGNN_STEP_FAMILY_NONE 0
 #define DRGNN_STEP_FAMILY_PRODUCT 1
 #define DRGNN_STEP_FAMILY_AGGREGATE 2
@@ -502,7 +505,7 @@ typedef struct drgnn_step_hints {
     const int32_t* host_node_ptr; const int32_t* host_edge_ptr;       /* per mini-batch (drgnn_net_train_step) */
     const int64_t* set_node_ptr; const int64_t* set_edge_ptr; const int32_t* host_ids;   /* cached mode */
     /* topo_flags: the DRGNN_TOPO_* flags the topology workspace was BUILT with -- what the caller vouches for (0: a caller
-     *             that knows nothing of the hierarchical order: the product-first family) */
+     *             that knows nothing of the hierarchical order: no fused kernel, DRGNN_E_CAPACITY) */
     int32_t topo_flags, reserved;
     /* DRGNN_TOPO_TILES in topo_flags: the aggregation tiles the builder formed for this workspace (DEVICE memory, laid out
      * for the workspace's node count): the aggregation-first kernels start conv1 from them. */
@@ -523,8 +526,9 @@ int64_t drgnn_net_step_xchg_elems(int32_t kind, int32_t max_nodes, int32_t max_c
 int64_t drgnn_net_step_lds_bytes(int32_t kind, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                  int32_t max_c0, int32_t R, int32_t H, int32_t O);
 int64_t drgnn_head_compact_elems(int32_t R, int32_t H, int32_t O);
-/* Which instantiation of the PRODUCT-FIRST step kernel a launch of these bounds takes: the padded feature width
- * (16/32/48/64) of the width-specialised kernel, or 0 for the generic one.  Host-side only. */
+/* Which instantiation of the PRODUCT-FIRST step kernel (emulation build; kept in the ABI for hosts that query it) a launch of
+ * these bounds would take: the padded feature width (16/32/48/64) of the width-specialised kernel, or 0 for the generic
+ * one.  The device library's launches are described by drgnn_net_step_plan (width / cls).  Host-side only. */
 int32_t drgnn_net_step_variant(int32_t kind, const float* x, int32_t n_feat, int32_t max_nodes, int32_t max_edges,
                                int32_t max_c0, int32_t H, int32_t O);
 int drgnn_net_train_step(const drgnn_net_desc* net, const drgnn_head_desc* head, const float* x,

@@ -469,7 +469,7 @@ def test_classification_loop_recorded_in_a_graph():
         opt.step()
         return loss
     net, opt = fresh()
-    eager_losses = [float(body(net, opt, b)) for b in batches]
+    eager_losses = [float(body(net, opt, b).detach()) for b in batches]
     assert _engine(net).last_path == "two-launch"
     eager = {k: v.clone() for k, v in net.state_dict().items()}
     cap, copt = fresh()

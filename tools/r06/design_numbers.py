@@ -1,12 +1,12 @@
 """Regenerates the ONE table of current numbers in DESIGN.md (between the numbers:begin / numbers:end markers) from the bench
 lines collected by tools/collect_profiles.sh + tools/summarize_profile.py:  profiles/<name>_{GINet,sGAT,FoutNet}_benchline.json
-    python tools/r06/design_numbers.py r06_v1"""
+    python tools/r06/design_numbers.py r06_v3"""
 import json
 import os
 import sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
-name = sys.argv[1] if len(sys.argv) > 1 else "r06_v1"
+name = sys.argv[1] if len(sys.argv) > 1 else "r06_v3"
 
 
 def load(net, suffix="benchline"):
@@ -32,6 +32,9 @@ rows.append(("dominant kernel `%s`" % rf["kernel"].split(" (")[0], "%.2f µs (HI
 if rf.get("traffic"):
     rows.append(("counter traffic of that launch (FETCH×2 + WRITE)", "%.2f MB = %.2f× the algorithmic 10.10 MB; MFMA utilisation %.1f %%" % (
         rf["traffic"] / 1e6, rf["traffic"] / (157876 * 64), 100 * (rf.get("mfma_util") or 0))))
+if rf.get("traffic_cached_topology"):
+    rows.append(("… of the launch without a builder (cached topology, NeuralNet's default mode)", "%.2f MB = %.2f×" % (
+        rf["traffic_cached_topology"] / 1e6, rf["traffic_cached_topology"] / (157876 * 64))))
 db = g.get("distinct_batches") or {}
 rows.append(("`distinct_batches` (cycle of 32 different mini-batches)", "%s µs" % us(db.get("us_per_step"))))
 ep = g.get("epoch_loop") or {}
@@ -52,7 +55,9 @@ for net in ("sGAT", "FoutNet"):
         r = o["roofline"]
         rows.append(("%s SYN64, own bench line" % net, "%.2f µs per step; `%s` %.2f µs = %.1f %%; traffic %s" % (
             o["ms_per_step"] * 1e3, r["kernel"].split(" (")[0], r["kernel_us"], 100 * r["frac"],
-            ("%.2f× algorithmic" % (r["traffic"] / (r["alg_bytes_per_graph"] * 64))) if r.get("traffic") else "—")))
+            ("%.2f× algorithmic" % (r["traffic"] / (r["alg_bytes_per_graph"] * 64))) if r.get("traffic") else "—") + (
+            (" (builder inside the launch; %.2f× without it: cached topology)" % (r["traffic_cached_topology"] / (r["alg_bytes_per_graph"] * 64)))
+            if r.get("traffic_cached_topology") else "")))
     elif g.get("other_nets", {}).get(net):
         o = g["other_nets"][net]
         rows.append(("%s SYN64 (`other_nets`)" % net, "%.2f µs per step; kernel %.2f µs = %.1f %%" % (o["us_per_step"], o["kernel_us"], 100 * o["frac"])))

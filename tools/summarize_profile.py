@@ -53,7 +53,7 @@ def agg(path, counter):
     return {k: sum(v) / len(v) for k, v in d.items()}
 
 
-pmc = {}
+pmc, cached = {}, {}
 fetch, write = find("fetch", "counter_collection.csv"), find("write", "counter_collection.csv")
 if fetch and write:
     fe, wr = agg(fetch, "FETCH_SIZE"), agg(write, "WRITE_SIZE")
@@ -63,7 +63,18 @@ if fetch and write:
                       "hbm_bytes_per_launch": (2.0 * fe[k] + (wr.get(k) or 0.0)) * 1024.0,
                       "note": "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced reads); "
                               "WRITE_SIZE uncalibrated; Infinity-Cache hits are counted"}
-    json.dump(dict(pmc, _meta=meta), open(os.path.join(out, name + "_pmc.json"), "w"), indent=1)
+    # the launches WITHOUT a co-launched builder (bench.py --topology cached: the default mode of NeuralNet.train), own passes;
+    # kept under one key of their own: bench.py's roofline.traffic stays the headline launch's
+    cached = {}
+    fc, wc = find("fetch_cached", "counter_collection.csv"), find("write_cached", "counter_collection.csv")
+    if fc and wc:
+        fe_c, wr_c = agg(fc, "FETCH_SIZE"), agg(wc, "WRITE_SIZE")
+        for k in fe_c:
+            if "k_" in k[:12]:
+                cached[k] = {"FETCH_SIZE_KB_avg": fe_c[k], "WRITE_SIZE_KB_avg": wr_c.get(k),
+                             "hbm_bytes_per_launch": (2.0 * fe_c[k] + (wr_c.get(k) or 0.0)) * 1024.0}
+    extra = {"_cached_topology": cached} if cached else {}
+    json.dump(dict(pmc, _meta=meta, **extra), open(os.path.join(out, name + "_pmc.json"), "w"), indent=1)
 sq = collections.defaultdict(dict)
 for sub in ("sq1", "sq2"):
     path = find(sub, "counter_collection.csv")
@@ -82,7 +93,7 @@ for b in ("benchline.json", "benchline_driver_args.json"):
     if os.path.exists(os.path.join(src, b)) and os.path.getsize(os.path.join(src, b)) > 0:
         shutil.copy(os.path.join(src, b), os.path.join(out, name + "_" + b))
 with open(os.path.join(out, name + "_summary.md"), "w") as f:
-    f.write("# %s -- rocprofv3 --kernel-trace --stats -- python bench.py --net %s --no-cpu-baseline --epoch-graphs 0\n\n" % (name, net))
+    f.write("# %s -- rocprofv3 --kernel-trace --stats -- python bench.py --net %s --no-cpu-baseline --epoch-graphs 0 --no-dropin\n\n" % (name, net))
     f.write("kernel sources hash `%s`\n\n" % meta["source_hash"])
     f.write("| kernel | calls | avg us | min us | max us | % of GPU time |\n|---|---|---|---|---|---|\n")
     for r in rows[:16]:
@@ -92,6 +103,11 @@ with open(os.path.join(out, name + "_summary.md"), "w") as f:
         f.write("\n## HBM traffic per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)\n\n")
         f.write("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | corrected bytes/launch |\n|---|---|---|---|\n")
         for k, v in pmc.items():
+            f.write("| `%s` | %.1f | %.1f | %.0f |\n" % (k[:60], v["FETCH_SIZE_KB_avg"], v["WRITE_SIZE_KB_avg"] or 0, v["hbm_bytes_per_launch"]))
+    if pmc and cached:
+        f.write("\n## The same counters, cached topology (bench.py --topology cached: no builder inside the launch)\n\n")
+        f.write("| kernel | FETCH_SIZE KB | WRITE_SIZE KB | corrected bytes/launch |\n|---|---|---|---|\n")
+        for k, v in cached.items():
             f.write("| `%s` | %.1f | %.1f | %.0f |\n" % (k[:60], v["FETCH_SIZE_KB_avg"], v["WRITE_SIZE_KB_avg"] or 0, v["hbm_bytes_per_launch"]))
     if sq:
         # MI355X: 256 CUs x 4 SIMDs; SQ_WAVE_CYCLES / WAIT / ACTIVE count in the same unit (ratios are unit free);
