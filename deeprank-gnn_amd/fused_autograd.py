@@ -338,9 +338,13 @@ class StepEngine(object):
             flags = self._usable_flags(topo, x)
         plan = self._plan(n_feat, topo, mode == "jacobian", flags)
         if plan.family != _lib.STEP_FAMILY_AGGREGATE or not (0 < plan.lds_bytes <= 160 * 1024):
+            why = ""
+            if getattr(topo, "tiles", None) is not None and (topo.ws_f32 is not None) != (self.kind == _lib.SGAT):
+                why = "; the workspace's tiles are %s sums, this net starts from %s ones (Topology.from_batch(need_weights=...))" % (
+                    ("edge-weighted", "plain") if topo.ws_f32 is not None else ("plain", "edge-weighted"))
             return self._outside("no fused kernel for this launch (family %d, topology flags 0x%x, %d features, %d / %d / %d "
-                                 "nodes / edges / clusters per graph at most)" % (plan.family, flags, n_feat, topo.max_nodes,
-                                                                                  topo.max_edges, topo.max_c0))
+                                 "nodes / edges / clusters per graph at most%s)" % (plan.family, flags, n_feat, topo.max_nodes,
+                                                                                   topo.max_edges, topo.max_c0, why))
         if mode == "two-launch":
             chk = self._plan(n_feat, topo, True, flags)
             if chk.family != _lib.STEP_FAMILY_AGGREGATE or not (0 < chk.lds_bytes <= 160 * 1024):
