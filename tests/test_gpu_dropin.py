@@ -499,7 +499,7 @@ def test_classification_loop_recorded_in_a_graph():
     got = []
     for gr, l in zip(graphs, losses):
         gr.replay()
-        got.append(float(l))
+        got.append(float(l.detach()))
     torch.cuda.synchronize()
     np.testing.assert_allclose(got, eager_losses, rtol=1e-5)
     for k, v in cap.state_dict().items():

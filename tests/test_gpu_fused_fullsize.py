@@ -183,7 +183,7 @@ def test_fused_step_syn64_three_adam_steps_match_oracle(net_name):
         loss.backward()
         opt.step()
         got = tr.train_step(batch, topo=topos[it & 1], next_topo=topos[1 - (it & 1)])
-        np.testing.assert_allclose(float(got), float(loss), rtol=TOL)
+        np.testing.assert_allclose(float(got), float(loss.detach()), rtol=TOL)
         np.testing.assert_allclose(tr.last_pred.cpu().numpy(), pred.detach().numpy(), rtol=TOL, atol=TOL)
     sd = net.state_dict()
     for k, v in leaves.items():
