@@ -104,7 +104,8 @@ class StepPlan(ctypes.Structure):
                 ("no_paired", _c_i32),
                 ("family", _c_i32), ("wgs_per_graph", _c_i32), ("slabs_per_graph", _c_i32), ("width", _c_i32),
                 ("cls", _c_i32), ("lean_ok", _c_i32), ("builder_wgs_per_graph", _c_i32),
-                ("lds_bytes", _c_i64), ("xchg_words", _c_i64)]
+                ("lds_bytes", _c_i64), ("xchg_words", _c_i64),
+                ("from_memory", _c_i32), ("reserved", _c_i32)]
 
     OVERRIDES = ("force_wgs", "no_class", "no_aggregate", "no_split", "no_paired")
 
@@ -252,7 +253,7 @@ class Api(object):
         lib.drgnn_step_gradients.argtypes = ([ctypes.POINTER(NetDesc), _vp, _c_i64] + [ctypes.POINTER(ConvGrads)] * 2 +
                                              [_vp, _vp] + [_c_i32] * 3 + [_vp, _vp, ctypes.POINTER(_vp), ctypes.POINTER(_c_i64), _c_i32,
                                                                        _vp, _c_i32, _vp])
-        if lib.drgnn_abi_version() != 3:
+        if lib.drgnn_abi_version() != 4:
             raise DrgnnError("ABI mismatch in %s" % path)
 
     # -- topology ---------------------------------------------------------------

@@ -677,10 +677,11 @@ static int step_variant(int kind, const float* x, int F, int capN, int capE, int
 
 // ... of the AGGREGATION-FIRST kernels: they read padded tile rows, so any feature count up to 64 has a width class; what
 // remains of step_burst_guaranteed are the head width and the burst capacities
-static int step_af_width(int kind, int F, int capN, int capE, int capC, int H, int O) {
+// from_memory: the form that reads the S rows of the tiles from memory (GINet, drgnn_step3.h SG): no register burst of the tile
+static int step_af_width(int kind, int F, int capN, int capE, int capC, int H, int O, bool from_memory = false) {
     if (H != ((kind == DRGNN_GINET) ? 128 : 64) || F < 1 || F > 64) return 0;
     const int TF = (F + 3) & ~3;
-    const bool ok = (F * DRGNN_H1 <= DRGNN_BCAP) && ((long)capN * TF <= 16L * DRGNN_BCAP) && (capN + 1 <= DRGNN_BCAP) &&
+    const bool ok = (F * DRGNN_H1 <= DRGNN_BCAP) && (from_memory || (long)capN * TF <= 16L * DRGNN_BCAP) && (capN + 1 <= DRGNN_BCAP) &&
                     (capE <= 2 * DRGNN_BCAP) && (capC * DRGNN_H1 <= 4 * DRGNN_BCAP) && O * H <= 2 * DRGNN_BCAP &&
                     H * 8 <= STEP_WB_J * DRGNN_BCAP;
     return ok ? step_pad16(F) : 0;
@@ -702,7 +703,8 @@ enum { SK_STEP = 0, SK_STEP1 = 1, SK_AF2 = 2, SK_AF3 = 3, SK_AF3B = 4 };
 struct StepPick {
     int rc;                 // 0, or the error a launch of this shape returns (family NONE)
     int family, kernel, wgs, slabs, width, cls, paired, lean_ok, builder_roles;
-    int xg;                 // sGAT / FoutNet, 64-wide: the x-from-memory form (the S and the x tile together do not fit the LDS)
+    int xg;                 // sGAT / FoutNet: the x-from-memory form (the S and the x tile together do not fit the LDS)
+    int sg;                 // GINet, one workgroup per graph: the S-from-memory form (the S tile does not fit the LDS)
     int64_t lds, xchg_words;
     int capN, capE, capC;   // the LDS capacities the kernel is launched with (the class's when cls)
 };
@@ -731,9 +733,11 @@ static StepPick step_pick(const StepAsk& q) {
 #else
     // (the single-branch nets read x rows next to the tiles: the input's when F % 4 == 0 -- 16-byte aligned then --, else the
     // tiles' padded copy; GINet reads the tiles only)
-    const int af_w = step_af_width(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O);
-    const bool af_shape = !q.ov.no_aggregate && (q.topo_flags & DRGNN_TOPO_HIER) && (q.topo_flags & DRGNN_TOPO_TILES) && af_w != 0 &&
-                          (q.kind == DRGNN_GINET || (q.F & 3) != 0 || q.x_ok);
+    int af_w = step_af_width(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O);
+    const bool af_ws = !q.ov.no_aggregate && (q.topo_flags & DRGNN_TOPO_HIER) && (q.topo_flags & DRGNN_TOPO_TILES);
+    const bool af_shape = af_ws && af_w != 0 && (q.kind == DRGNN_GINET || (q.F & 3) != 0 || q.x_ok);
+    // (GINet's one-workgroup kernel with the S rows left in memory: graphs the staged forms have no LDS -- or no register burst -- for)
+    const int sg_w = (q.kind == DRGNN_GINET && af_ws) ? step_af_width(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O, true) : 0;
 #endif
     // The PRODUCT-FIRST family (drgnn_step.h / drgnn_step1.h, rounds 2 - 3) is the host emulation's only: the device library
     // instantiates the aggregation-first kernels alone (round 6), and a launch they do not cover -- a head that is not the
@@ -748,7 +752,13 @@ static StepPick step_pick(const StepAsk& q) {
         const bool narrow = q.H < DRGNN_H2;      // (the exchange words of a graph are 2 x 32 of its 2 x H: a narrower head runs one workgroup per graph)
         const int64_t l2af = af_shape ? 4 * step3_scratch_words(q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
         const int64_t l2old = old_ok ? step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O) : STEP_LDS_NEVER;
-        const int64_t l1af = af_shape ? 4 * step3b_scratch_words(q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
+        int64_t l1af = af_shape ? 4 * step3b_scratch_words(q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
+#ifndef DRGNN_EMU
+        if (l1af > DRGNN_LDS_LIMIT && sg_w != 0) {
+            const int64_t l1sg = 4 * step3b_scratch_words(q.F, q.capN, q.capE, q.capC, q.H, q.O, 1);
+            if (l1sg <= DRGNN_LDS_LIMIT) { l1af = l1sg; k.sg = 1; af_w = sg_w; }
+        }
+#endif
         const int64_t l1p = old_ok ? step1_lds_bytes_form(q.F, q.capN, q.capE, q.capC, q.H, q.O, 1) : STEP_LDS_NEVER;
         const bool paired = !q.ov.no_paired && l1p <= DRGNN_LDS_LIMIT;
         const int64_t l1old = paired ? l1p : old_ok ? step1_lds_bytes_form(q.F, q.capN, q.capE, q.capC, q.H, q.O, 0) : STEP_LDS_NEVER;
@@ -766,11 +776,13 @@ static StepPick step_pick(const StepAsk& q) {
         k.wgs = wgs;
         if (wgs == 2) { k.kernel = af_two ? SK_AF3 : SK_STEP; k.lds = af_two ? l2af : l2old; }
         else { k.kernel = af_one ? SK_AF3B : SK_STEP1; k.lds = af_one ? l1af : l1old; k.paired = (!af_one && paired) ? 1 : 0; }
+        if (wgs == 2) k.sg = 0;      // (the S-from-memory form is the one-workgroup kernel's)
         k.xchg_words = 2 * (int64_t)(q.H > DRGNN_H2 ? q.H : DRGNN_H2);
     } else {
         int64_t laf = af_shape ? 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O) : STEP_LDS_NEVER;
-        if (af_shape && laf > DRGNN_LDS_LIMIT && af_w == 64) {
-            // 49 - 64 features on graphs whose S and x tiles do not fit together: the x rows stay in memory (drgnn_step2.h, XG)
+        if (af_shape && laf > DRGNN_LDS_LIMIT) {
+            // graphs whose S and x tiles do not fit together (49 - 64 features at 200 nodes, 260+ nodes at the narrower widths):
+            // the x rows stay in memory (drgnn_step2.h, XG)
             const int64_t lxg = 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O, 1);
             if (lxg <= DRGNN_LDS_LIMIT) { laf = lxg; k.xg = 1; }
         }
@@ -816,7 +828,7 @@ static StepPick step_pick(const StepAsk& q) {
     // aggregation-first kernels the training and the inference instances)
 #ifndef DRGNN_EMU
     // (48-wide: the aggregation-first kernels only -- the feature count of the reference's shipped regression models)
-    if (!q.ov.no_class && (k.width == 32 || (k.width == 48 && k.lean_ok)) && q.capN <= STEP_CLS_N && q.capE <= STEP_CLS_E &&
+    if (!q.ov.no_class && !k.sg && !k.xg && (k.width == 32 || (k.width == 48 && k.lean_ok)) && q.capN <= STEP_CLS_N && q.capE <= STEP_CLS_E &&
         q.capC <= STEP_CLS_C && !(k.kernel == SK_STEP1 && !k.paired) &&
         (k.lean_ok ? step_af_width(q.kind, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)
                    : step_variant(q.kind, nullptr, q.F, STEP_CLS_N, STEP_CLS_E, STEP_CLS_C, q.H, q.O)) == k.width) {
@@ -844,7 +856,7 @@ static bool step_bounds_ok(int32_t max_nodes, int32_t max_edges, int32_t n_feat)
 int32_t drgnn_net_step_plan(drgnn_step_plan* p) {
     if (!p) return 0;
     p->family = DRGNN_STEP_FAMILY_NONE; p->wgs_per_graph = 0; p->slabs_per_graph = 0; p->width = 0; p->cls = 0; p->lean_ok = 0;
-    p->builder_wgs_per_graph = 0; p->lds_bytes = 0; p->xchg_words = 0;
+    p->builder_wgs_per_graph = 0; p->lds_bytes = 0; p->xchg_words = 0; p->from_memory = 0; p->reserved = 0;
     if (!step_bounds_ok(p->max_nodes, p->max_edges, p->n_feat) || p->n_graphs < 0 || p->H < 1 || p->H > 512 || p->O < 1 ||
         p->O > DRGNN_MAX_OUT || p->kind < 0 || p->kind > DRGNN_FOUT)
         return 0;
@@ -860,6 +872,7 @@ int32_t drgnn_net_step_plan(drgnn_step_plan* p) {
     if (k.rc) return 0;
     p->family = k.family; p->wgs_per_graph = k.wgs; p->slabs_per_graph = k.slabs; p->width = k.width; p->cls = k.cls;
     p->lean_ok = k.lean_ok; p->builder_wgs_per_graph = k.builder_roles; p->lds_bytes = k.lds; p->xchg_words = k.xchg_words;
+    p->from_memory = (k.sg || k.xg) ? 1 : 0;
     return k.wgs;
 }
 
@@ -1092,7 +1105,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
         const bool gather = gather_ids != nullptr;
         switch (k.kernel) {
             case SK_AF3: kern = af_step_kernel(DRGNN_AF_GINET_TWO, k.width, gather, k.cls, 1, q.train); break;
-            case SK_AF3B: kern = af_step_kernel(DRGNN_AF_GINET_ONE, k.width, gather, k.cls, 1, q.train); break;
+            case SK_AF3B: kern = af_step_kernel(k.sg ? DRGNN_AF_GINET_SG : DRGNN_AF_GINET_ONE, k.width, gather, k.cls, 1, q.train); break;
             case SK_AF2: kern = af_step_kernel(k.xg ? (kind == DRGNN_SGAT ? DRGNN_AF_SGAT_XG : DRGNN_AF_FOUT_XG)
                                                     : (kind == DRGNN_SGAT ? DRGNN_AF_SGAT : DRGNN_AF_FOUT), k.width, gather, k.cls, k.wgs, q.train); break;
             default: return DRGNN_E_CAPACITY;      // (the product-first family is not part of the device library: step_pick never picks it)

@@ -587,11 +587,11 @@ DEV void step3_block(const StepLaunch& L, int blk, float* lds) {
 
 #ifndef DRGNN_EMU
 // GINet, aggregation first, both branches of a graph in one workgroup (drgnn_step3.h, net_step3_graph_both)
-template <int XF, bool GATHER, int CLS, bool TRAIN>
+template <int XF, bool GATHER, int CLS, bool TRAIN, bool SG = false>
 DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
     // the capacity-class training instance of the 32-wide kernel works the two branches off side by side (drgnn_step3.h: DUAL;
     // step_pick sizes the launch's LDS for it)
-    constexpr bool DUAL = STEP3B_DUAL(XF, CLS, TRAIN);
+    constexpr bool DUAL = !SG && STEP3B_DUAL(XF, CLS, TRAIN);
     if (g >= L.a.n_graphs) return;
     if (L.dims.count > 0) {
         const int gi = GATHER ? L.dims.gi[g] : g;
@@ -600,7 +600,7 @@ DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
         d.rowbase = d.n0 + gi;
         d.C = 0; d.E1 = 0; d.C1 = 0;
         const int cnt_c = L.a.tv.p[DRGNN_TI_NC0][gi], cnt_e1 = L.a.tv.p[DRGNN_TI_NE1][gi], cnt_c1 = L.a.tv.p[DRGNN_TI_NC1][gi];
-        net_step3_graph_both<XF, GATHER, CLS, TRAIN, DUAL>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
+        net_step3_graph_both<XF, GATHER, CLS, TRAIN, DUAL, SG>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, true, cnt_c, cnt_e1, cnt_c1);
         return;
     }
     const int gi = GATHER ? WG_UNIFORM(L.a.gather_ids[g]) : g;
@@ -615,7 +615,7 @@ DEV void step3b_block(const StepLaunch& L, int g, float* lds) {
         FOR_TID(o, L.a.hf.O) { L.a.hf.pred[(long)g * L.a.hf.O + o] = DRGNN_NAN; }
         return;
     }
-    net_step3_graph_both<XF, GATHER, CLS, TRAIN, DUAL>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
+    net_step3_graph_both<XF, GATHER, CLS, TRAIN, DUAL, SG>(L.a, d, g, gi, lds, L.capN, L.capE, L.capC, false, 0, 0, 0);
 }
 #endif
 
@@ -911,14 +911,15 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3_co_topo(StepCoLaunch C
     else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s3);
 }
 // ... its form with both branches of a graph in one workgroup (beyond the resident batch size)
-template <int XF, bool GATHER, int CLS, bool TRAIN>
+// SG: the S-from-memory form (drgnn_step3.h: graphs beyond the staged form's LDS budget)
+template <int XF, bool GATHER, int CLS, bool TRAIN, bool SG = false>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step3b_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s3b[];
     PHASE_BEGIN();
     const StepCoLaunch& C = step_kernarg();
     co_kernarg_touch();
     STEP_CO_ROLES(C);
-    if (co_is_step_) step3b_block<XF, GATHER, CLS, TRAIN>(C.step, co_step_blk_, smem_s3b);
+    if (co_is_step_) step3b_block<XF, GATHER, CLS, TRAIN, SG>(C.step, co_step_blk_, smem_s3b);
     else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s3b);
 }
 #ifdef DRGNN_KERNELS_MAIN

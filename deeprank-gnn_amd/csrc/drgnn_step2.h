@@ -105,7 +105,7 @@ struct Step2Scratch {
 #endif  // !DRGNN_EMU
 
 // (host + device; also compiled by the emulation build, whose plan function must answer "never" consistently)
-// xg: the X-FROM-GLOBAL form of the 64-wide kernels (net_step2_graph<..., XG = true>): the x rows are not staged (the self
+// xg: the X-FROM-GLOBAL form (net_step2_graph<..., XG = true>, run-time layout): the x rows are not staged (the self
 // product and the sparse dWs read them from memory: L2), the hierarchical order is (position -> node) instead
 HD int64_t step2_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O, int xg = 0) {
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
@@ -566,8 +566,9 @@ DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float
 // head width); CLS as in drgnn_step.h; SPLIT: workgroups per graph; half: which one.  `late` as in net_step_graph: sizes and
 // offsets came with the launch arguments, the device-computed counts (clusters, pooled edges, split point) are in flight.
 // TRAIN = false: the inference launch (forward + head, predictions only; one workgroup per graph).
-// XG (64-wide only): x rows read from memory instead of staged in LDS -- what lets 200-node graphs with up to 64 features into the
-// 160 KiB (133 KB instead of 189 KB at SYN size); the host takes it only when the staged form does not fit.
+// XG: x rows read from memory instead of staged in LDS -- what lets 200-node graphs with up to 64 features into the 160 KiB
+// (133 KB instead of 189 KB at SYN size) and, at the narrower widths, graphs of 260 - 350 nodes; the host takes it only when
+// the staged form does not fit.
 template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN = true, bool XG = false>
 DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi, int half, float* scratch, int capN, int capE,
                          int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1, int hs_k, int hs_q, int hs_n) {
@@ -586,7 +587,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     const int F = a.net.n_feat;
     const int O = hf.O;
     constexpr bool SPIN = KIND == DRGNN_SGAT && TRAIN && SPLIT == 2;      // (see step2_carve)
-    static_assert(!XG || (XF == 64 && CLS == 0), "the x-from-memory form exists for the 64-wide run-time layout");
+    static_assert(!XG || CLS == 0, "the x-from-memory form has the run-time layout");
     Step2Scratch s = step2_carve<CLS, SPIN, XG>(scratch, KIND, XF, capN, capE, capC, WREF, O);
     EXIT_AFTER(0);
     WBlockRegs<1> wreg;

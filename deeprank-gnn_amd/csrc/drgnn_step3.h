@@ -190,8 +190,10 @@ DEV void step3_gather_dxp(int n, const int* cp, const int* ridx, const float* sr
 }
 // dW1[f][h] = sum over the pooled nodes j of dXP[j][h] G[a0[j][h]][f].  Wave = channel h; in a wave NCH feature chunks (float4)
 // x NSL slices of the pooled nodes (consecutive lanes: the slice sums meet in DPP adds; Dw1Shape, drgnn_step2.h)
-template <int XF>
-DEV void step3_dw1_sparse(int C, const short* a0, int a0ld, const float* dxp, const float* G, float* g_dw1, int F) {
+// SG: G = the graph's S rows in memory (node order, `gtf` floats apart), hord: row position -> node
+template <int XF, bool SG = false>
+DEV void step3_dw1_sparse(int C, const short* a0, int a0ld, const float* dxp, const float* G, float* g_dw1, int F,
+                          const int* hord = nullptr, int gtf = 0) {
     constexpr int XLD = XF + 4, NSL = Dw1Shape<XF>::NSL;
     const int h = threadIdx.x >> 6, fc = (threadIdx.x & 63) / NSL, sl = threadIdx.x & (NSL - 1);
     const bool live = 4 * fc < XF;
@@ -208,7 +210,9 @@ DEV void step3_dw1_sparse(int C, const short* a0, int a0ld, const float* dxp, co
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             if (arg[u] >= 0) {
-                const drgnn_f4 g = *(const drgnn_f4*)(G + ROW24(arg[u], XLD) + 4 * fc);
+                // (SG: chunks past the row's end -- padded widths -- hold nothing: their sums are never stored, F <= gtf)
+                const drgnn_f4 g = !SG ? *(const drgnn_f4*)(G + ROW24(arg[u], XLD) + 4 * fc)
+                                       : (4 * fc < gtf ? *(const drgnn_f4*)(G + (long)hord[arg[u]] * gtf + 4 * fc) : drgnn_f4{0.f, 0.f, 0.f, 0.f});
                 acc[0] = fmaf(d[u], g[0], acc[0]); acc[1] = fmaf(d[u], g[1], acc[1]);
                 acc[2] = fmaf(d[u], g[2], acc[2]); acc[3] = fmaf(d[u], g[3], acc[3]);
             }
@@ -220,6 +224,41 @@ DEV void step3_dw1_sparse(int C, const short* a0, int a0ld, const float* dxp, co
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if (4 * fc + i < F) g_dw1[(4 * fc + i) * DRGNN_H1 + h] = acc[i];
+    }
+}
+
+// Z1 = relu(S W1) with the S rows read from MEMORY (the S-from-memory form): row position r of the hierarchical order is node
+// hord[r] of the graph's rows `sgl` (gtf floats apart).  The fragments, the order of the k chunks and of the matrix instructions
+// are step_gemm_nn's: the same bits as the staged form.  All of a row's chunks are requested at once.
+template <int XF>
+DEV void step3_conv1_sg(int n, const float* sgl, int gtf, const int* hord, const float* w1t, float* z1, int* dummy) {
+    constexpr int XLD = XF + 4;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int units = (n + 15) >> 4;
+    for (int ti = wave; ti < units; ti += DRGNN_NWAVES) {
+        const int prow = ti * 16 + lr;
+        const int row = prow < n ? prow : n - 1;          // rows past the graph: any valid row (results discarded)
+        const float* ag = sgl + (long)hord[row] * gtf + 4 * lq;
+        drgnn_f4 av[XF / 16];
+#pragma unroll
+        for (int k0 = 0; k0 < XF; k0 += 16)
+            av[k0 / 16] = (k0 + 4 * lq < gtf) ? *(const drgnn_f4*)(ag + k0) : drgnn_f4{0.f, 0.f, 0.f, 0.f};
+        const float* bp = w1t + lr * XLD + 4 * lq;
+        drgnn_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k0 = 0; k0 < XF; k0 += 16) {
+            const drgnn_f4 a = av[k0 / 16], b = *(const drgnn_f4*)(bp + k0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[j], b[j], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ci = ti * 16 + lq * 4 + r;
+            float* p = (ci < n) ? z1 + ci * DRGNN_H1 + lr : (float*)dummy + lane;
+            const float v = acc[r];
+            *p = (v < 0.0f) ? 0.0f : v;
+        }
     }
 }
 
@@ -436,8 +475,13 @@ struct Step3BScratch {
     float* G; float* z1;
     float* xp; float* u2[2]; float* z2[2]; float* p2;
     float* hw2; float* hb2;
+    int* hord;
     float* end; float* gp;
 };
+// sg: the S-FROM-MEMORY form (net_step3_graph_both<..., SG = true>): the S rows of the tiles are not staged -- conv1's product
+// and dW1 read them from memory through the hierarchical order (hord: position -> node), 4 bytes of LDS per node instead of
+// 4 (XF + 4): graphs beyond the LDS budget of the staged form (200 - 270 nodes, by width) up to what the builder forms tiles
+// for (drgnn_topology_tiles_ok)
 #define STEP3B_CARVE_LIST(X)                                                                   \
     X(misc, 128)                                                                               \
     X(xr, 2 * DRGNN_H2)                                                                        \
@@ -462,7 +506,7 @@ struct Step3BScratch {
     X(a0[1], ((long)STEP3_A1LD(capC) * DRGNN_H1 + 1) / 2)                                      \
     X(a1[0], ((long)STEP3_A1LD(capC) * DRGNN_H2 + 1) / 2)                                      \
     X(a1[1], ((long)STEP3_A1LD(capC) * DRGNN_H2 + 1) / 2)                                      \
-    X(G, (long)(capN + 4) * xld)                                                               \
+    X(G, sg ? 4 : (long)(capN + 4) * xld)                                                      \
     X(z1, (long)(capN + 4) * DRGNN_H1)                                                         \
     X(xp, (long)(capC + 4) * STEP_XPLD)                                                        \
     X(u2[0], (long)(capC + 4) * STEP_XPLD)                                                     \
@@ -471,10 +515,11 @@ struct Step3BScratch {
     X(z2[1], (long)(capC + 4) * STEP3_Z2LD)                                                    \
     X(p2, (long)(capC + 4) * STEP_XPLD)                                                        \
     X(hw2, (long)O * H)                                                                        \
-    X(hb2, O)
+    X(hb2, O)                                                                                  \
+    X(hord, sg ? capN : 0)
 #endif  // !DRGNN_EMU
 
-HD int64_t step3b_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O) {
+HD int64_t step3b_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O, int sg = 0) {
     const int64_t xld = step_pad16((int)F) + 4;
     int64_t w = 0;
 #ifndef DRGNN_EMU
@@ -482,7 +527,7 @@ HD int64_t step3b_scratch_words(int64_t F, int64_t capN, int64_t capE, int64_t c
     STEP3B_CARVE_LIST(X)
 #undef X
 #else
-    (void)xld; (void)capN; (void)capE; (void)capC; (void)H; (void)O;
+    (void)xld; (void)capN; (void)capE; (void)capC; (void)H; (void)O; (void)sg;
     w = (int64_t)1 << 40;
 #endif
     return w + 16;
@@ -652,9 +697,10 @@ DEV void step3d_dw1_sparse(int vwave, int C, const short* a0, int a0ld, const fl
     }
 }
 
-template <int CLS>
+template <int CLS, bool SG = false>
 DEV Step3BScratch step3b_carve(float* base, int F, int capN, int capE, int capC, int H, int O) {
     const int xld = step_pad16(F) + 4;
+    constexpr int sg = SG ? 1 : 0;
     Step3BScratch s;
     int o = 0;
 #define X(name, words)                                                                          \
@@ -692,7 +738,8 @@ DEV void step3b_head_fc1(const HeadFused& hf, int g, const float* wb, const WBlo
 }
 
 // DUAL: the side-by-side form (see above); the caller has laid step3b_dual_extra_words more LDS out behind the arrays of the list
-template <int XF, bool GATHER, int CLS, bool TRAIN = true, bool DUAL = false>
+// SG: the S-from-memory form (see STEP3B_CARVE_LIST): run-time layout, branch after branch
+template <int XF, bool GATHER, int CLS, bool TRAIN = true, bool DUAL = false, bool SG = false>
 DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, int gi, float* scratch, int capN, int capE,
                               int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1) {
     static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
@@ -705,7 +752,8 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     constexpr int XLD = XF + 4, Z2LD = STEP3_Z2LD, W2NLD = DRGNN_H2 + 4;
     const int F = a.net.n_feat;
     const int O = hf.O;
-    Step3BScratch s = step3b_carve<CLS>(scratch, XF, capN, capE, capC, WREF, O);
+    static_assert(!SG || (CLS == 0 && !DUAL), "the S-from-memory form has the run-time layout");
+    Step3BScratch s = step3b_carve<CLS, SG>(scratch, XF, capN, capE, capC, WREF, O);
     WBlockRegs<1> wreg, wother;
     int* const dummy = (int*)(s.misc + 64);
     const uint32_t done = (uint32_t)a.step2[0];
@@ -737,6 +785,7 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
         case 10: if (TRAIN) j = StageJob{P[DRGNN_TI_COLPTR1] + d.rowbase, bC + 1, s.cp1, 0}; break;
         case 11: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 0); break;
         case 12: if (TRAIN) j = stage_half(StageJob{P[DRGNN_TI_ROWIDX1] + d.e0, bE1, s.rx1, 0}, 1); break;
+        case 13: if (SG) j = StageJob{P[DRGNN_TI_HORD] + d.n0, d.N, s.hord, 0}; break;
         default: break;
         }
         return j;
@@ -767,8 +816,10 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
             m_bad = __builtin_amdgcn_readfirstlane(m_bad);
         }
     }
-    burst_load_x(bx, sgl, d.N, TF);
-    burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
+    if (!SG) {
+        burst_load_x(bx, sgl, d.N, TF);
+        burst_load_rowmap(brow, bx, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);
+    }
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
         const drgnn_conv_params& c1 = a.net.conv1[br];
@@ -779,7 +830,7 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     wstage_load(wst, stage_job(my_wave));
     step_wblock_load(wreg, hf, 0);
     step_wblock_load(wother, hf, 1);
-    burst_store_x4_rows(bx, brow, s.G, XLD);
+    if (!SG) burst_store_x4_rows(bx, brow, s.G, XLD);
 #pragma unroll
     for (int br = 0; br < 2; ++br) {
         burst_store_wt(bw1[br], s.w1t[br], XLD);
@@ -788,10 +839,12 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
     }
     step_wblock_store(wreg, hf, 0, s.wb);
     wstage_store(wst);
-    FOR_TID(e, (step_pad4(d.N) - d.N) * XLD) { s.G[d.N * XLD + e] = 0.0f; }
-    if (XF > TF) {
-        const int padg = XF - TF;
-        FOR_TID(e, d.N * padg) { s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+    if (!SG) {
+        FOR_TID(e, (step_pad4(d.N) - d.N) * XLD) { s.G[d.N * XLD + e] = 0.0f; }
+        if (XF > TF) {
+            const int padg = XF - TF;
+            FOR_TID(e, d.N * padg) { s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+        }
     }
     if (XF > F) {
         const int padc = XF - F;
@@ -854,7 +907,8 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
         float* const z2 = b1 ? s.z2[1] : s.z2[0];
         short* const a0 = b1 ? s.a0[1] : s.a0[0];
         short* const a1 = b1 ? s.a1[1] : s.a1[0];
-        step_gemm_nn<true>(d.N, 1, XF, s.G, XLD, w1t, XLD, s.z1, DRGNN_H1, dummy);
+        if (SG) step3_conv1_sg<XF>(d.N, sgl, TF, s.hord, w1t, s.z1, dummy);
+        else step_gemm_nn<true>(d.N, 1, XF, s.G, XLD, w1t, XLD, s.z1, DRGNN_H1, dummy);
         BARRIER();
         step3_cluster_max(d.C, s.hmp, s.mem1, s.z1, s.xp, a0, STEP3_A1LD(capC));
         BARRIER();
@@ -914,7 +968,9 @@ DEV void net_step3_graph_both(const StepArgs& a, const GraphDims& d_in, int g, i
         BARRIER();
         step3_gather_dxp<STEP_XPLD>(d.C, s.cp1, s.rx1, s.p2, s.xp);
         BARRIER();
-        step3_dw1_sparse<XF>(d.C, a0, STEP3_A1LD(capC), s.xp, s.G, b1 ? p_w1n1 : p_w1n0, F);      // (the next branch's first two phases leave xp, a0, G alone)
+        // (the next branch's first two phases leave xp, a0, G alone)
+        if (SG) step3_dw1_sparse<XF, true>(d.C, a0, STEP3_A1LD(capC), s.xp, sgl, b1 ? p_w1n1 : p_w1n0, F, s.hord, TF);
+        else step3_dw1_sparse<XF>(d.C, a0, STEP3_A1LD(capC), s.xp, s.G, b1 ? p_w1n1 : p_w1n0, F);
     }
 }
 

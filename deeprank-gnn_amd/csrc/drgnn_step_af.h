@@ -18,8 +18,9 @@ typedef void (*drgnn_step_kernel_t)(StepCoLaunch);
 #define DRGNN_AF_SGAT 3           // k_step2_co_topo<DRGNN_SGAT>
 #define DRGNN_AF_FOUT 4           // k_step2_co_topo<DRGNN_FOUT>
 #define DRGNN_AF_SGAT_WHOLE 5     // k_step2_co_topo<DRGNN_SGAT, ., false, ., 1, true>: a unit of its own, see af_pick_single
-#define DRGNN_AF_SGAT_XG 6        // k_step2_co_topo<DRGNN_SGAT, 64, ., 0, ., ., true>: x rows read from memory (64-wide only)
+#define DRGNN_AF_SGAT_XG 6        // k_step2_co_topo<DRGNN_SGAT, ., ., 0, ., ., true>: x rows read from memory (graphs beyond the staged form's LDS)
 #define DRGNN_AF_FOUT_XG 7        // ... of FoutNet
+#define DRGNN_AF_GINET_SG 8       // k_step3b_co_topo<., ., 0, ., true>: S rows read from memory (graphs beyond the staged form's LDS)
 
 // (cls: 1 = capacity-class layout, honoured for the 32- and 48-wide kernels only, training and inference launches -- the host
 // asks for nothing else; 48: the feature count of the reference's shipped regression models)
@@ -36,6 +37,10 @@ template <int XF> drgnn_step_kernel_t af_pick_ginet_one(bool gather, int cls, bo
     if (!train) return gather ? k_step3b_co_topo<XF, true, 0, false> : k_step3b_co_topo<XF, false, 0, false>;
     if (cls && C1) return gather ? k_step3b_co_topo<XF, true, C1, true> : k_step3b_co_topo<XF, false, C1, true>;
     return gather ? k_step3b_co_topo<XF, true, 0, true> : k_step3b_co_topo<XF, false, 0, true>;
+}
+template <int XF> drgnn_step_kernel_t af_pick_ginet_sg(bool gather, bool train) {
+    if (!train) return gather ? k_step3b_co_topo<XF, true, 0, false, true> : k_step3b_co_topo<XF, false, 0, false, true>;
+    return gather ? k_step3b_co_topo<XF, true, 0, true, true> : k_step3b_co_topo<XF, false, 0, true, true>;
 }
 // sGAT's training launches with one workgroup per graph on a per-mini-batch workspace are the ones whose co-launched builder --
 // one workgroup per graph working BOTH chains off, with edge weights -- bounds the launch (batch 128 and beyond, topology
@@ -68,20 +73,25 @@ template <int KIND, int XF> drgnn_step_kernel_t af_pick_single(bool gather, int 
     }
 }
 
-// the x-from-memory form of the 64-wide kernels (run-time LDS layout only): graphs whose S AND x tiles do not fit the 160 KiB
-template <int KIND> drgnn_step_kernel_t af_pick_single_xg(bool gather, int split, bool train) {
-    if (!train) return gather ? k_step2_co_topo<KIND, 64, true, 0, 1, false, true> : k_step2_co_topo<KIND, 64, false, 0, 1, false, true>;
-    if (split == 2) return gather ? k_step2_co_topo<KIND, 64, true, 0, 2, true, true> : k_step2_co_topo<KIND, 64, false, 0, 2, true, true>;
-    return gather ? k_step2_co_topo<KIND, 64, true, 0, 1, true, true> : k_step2_co_topo<KIND, 64, false, 0, 1, true, true>;
+// the x-from-memory form (run-time LDS layout only): graphs whose S AND x tiles do not fit the 160 KiB
+template <int KIND, int XF> drgnn_step_kernel_t af_pick_single_xg(bool gather, int split, bool train) {
+    if (!train) return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, false, true> : k_step2_co_topo<KIND, XF, false, 0, 1, false, true>;
+    if (split == 2) return gather ? k_step2_co_topo<KIND, XF, true, 0, 2, true, true> : k_step2_co_topo<KIND, XF, false, 0, 2, true, true>;
+    return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, true, true> : k_step2_co_topo<KIND, XF, false, 0, 1, true, true>;
 }
-drgnn_step_kernel_t af_sgat_xg_64(bool gather, int split, bool train);
-drgnn_step_kernel_t af_fout_xg_64(bool gather, int split, bool train);
-#define DRGNN_AF_DEFINE_SGAT_XG(W) drgnn_step_kernel_t af_sgat_xg_64(bool gather, int split, bool train) { return af_pick_single_xg<DRGNN_SGAT>(gather, split, train); }
-#define DRGNN_AF_DEFINE_FOUT_XG(W) drgnn_step_kernel_t af_fout_xg_64(bool gather, int split, bool train) { return af_pick_single_xg<DRGNN_FOUT>(gather, split, train); }
+#define DRGNN_AF_DEFINE_SGAT_XG(W) DRGNN_AF_DEFINE_SGAT_XG_X(W)
+#define DRGNN_AF_DEFINE_FOUT_XG(W) DRGNN_AF_DEFINE_FOUT_XG_X(W)
+#define DRGNN_AF_DEFINE_SGAT_XG_X(W) \
+    drgnn_step_kernel_t af_sgat_xg_##W(bool gather, int split, bool train) { return af_pick_single_xg<DRGNN_SGAT, W>(gather, split, train); }
+#define DRGNN_AF_DEFINE_FOUT_XG_X(W) \
+    drgnn_step_kernel_t af_fout_xg_##W(bool gather, int split, bool train) { return af_pick_single_xg<DRGNN_FOUT, W>(gather, split, train); }
 
 #define DRGNN_AF_DECLARE(W)                                                                     \
     drgnn_step_kernel_t af_ginet_two_##W(bool gather, int cls, bool train);                    \
     drgnn_step_kernel_t af_ginet_one_##W(bool gather, int cls, bool train);                    \
+    drgnn_step_kernel_t af_ginet_sg_##W(bool gather, bool train);                              \
+    drgnn_step_kernel_t af_sgat_xg_##W(bool gather, int split, bool train);                    \
+    drgnn_step_kernel_t af_fout_xg_##W(bool gather, int split, bool train);                    \
     drgnn_step_kernel_t af_sgat_##W(bool gather, int cls, int split, bool train);              \
     drgnn_step_kernel_t af_fout_##W(bool gather, int cls, int split, bool train);              \
     drgnn_step_kernel_t af_sgat_whole_##W(int cls);                                            \
@@ -92,6 +102,9 @@ DRGNN_AF_DECLARE(16) DRGNN_AF_DECLARE(32) DRGNN_AF_DECLARE(48) DRGNN_AF_DECLARE(
 // (two levels: the width may itself be a macro -- the translation units pass DRGNN_AF_W)
 #define DRGNN_AF_DEFINE_GINET_TWO(W) DRGNN_AF_DEFINE_GINET_TWO_X(W)
 #define DRGNN_AF_DEFINE_GINET_ONE(W) DRGNN_AF_DEFINE_GINET_ONE_X(W)
+#define DRGNN_AF_DEFINE_GINET_SG(W) DRGNN_AF_DEFINE_GINET_SG_X(W)
+#define DRGNN_AF_DEFINE_GINET_SG_X(W) \
+    drgnn_step_kernel_t af_ginet_sg_##W(bool gather, bool train) { return af_pick_ginet_sg<W>(gather, train); }
 #define DRGNN_AF_DEFINE_SGAT(W) DRGNN_AF_DEFINE_SGAT_X(W)
 #define DRGNN_AF_DEFINE_FOUT(W) DRGNN_AF_DEFINE_FOUT_X(W)
 #define DRGNN_AF_DEFINE_SGAT_WHOLE(W) DRGNN_AF_DEFINE_SGAT_WHOLE_X(W)
@@ -115,21 +128,23 @@ DRGNN_AF_DECLARE(16) DRGNN_AF_DECLARE(32) DRGNN_AF_DECLARE(48) DRGNN_AF_DECLARE(
 #if !defined(DRGNN_SPLIT_TU)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_GINET_TWO)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_GINET_ONE)
+DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_GINET_SG)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_FOUT)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT_WHOLE)
-DRGNN_AF_DEFINE_SGAT_XG(64)
-DRGNN_AF_DEFINE_FOUT_XG(64)
+DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT_XG)
+DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_FOUT_XG)
 #endif
 // family: DRGNN_AF_*; width: 16 / 32 / 48 / 64.  nullptr: no such instance
 static drgnn_step_kernel_t af_step_kernel(int family, int width, bool gather, int cls, int split, bool train) {
-    if (family == DRGNN_AF_SGAT_XG) return width == 64 ? af_sgat_xg_64(gather, split, train) : nullptr;
-    if (family == DRGNN_AF_FOUT_XG) return width == 64 ? af_fout_xg_64(gather, split, train) : nullptr;
 #define DRGNN_AF_CASE(W)                                                                       \
     case W:                                                                                     \
         switch (family) {                                                                       \
         case DRGNN_AF_GINET_TWO: return af_ginet_two_##W(gather, cls, train);                   \
         case DRGNN_AF_GINET_ONE: return af_ginet_one_##W(gather, cls, train);                   \
+        case DRGNN_AF_GINET_SG: return af_ginet_sg_##W(gather, train);                          \
+        case DRGNN_AF_SGAT_XG: return af_sgat_xg_##W(gather, split, train);                     \
+        case DRGNN_AF_FOUT_XG: return af_fout_xg_##W(gather, split, train);                     \
         case DRGNN_AF_SGAT: return af_sgat_##W(gather, cls, split, train);                      \
         case DRGNN_AF_FOUT: return af_fout_##W(gather, cls, split, train);                      \
         default: return nullptr;                                                                \

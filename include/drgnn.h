@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DRGNN_ABI_VERSION 3
+#define DRGNN_ABI_VERSION 4
 
 /* host-side argument errors */
 #define DRGNN_E_ARG      (-1)   /* null pointer / negative size / bad mode            */
@@ -472,6 +472,10 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   lean_ok  1: the launch reads nothing a DRGNN_TOPO_LEAN build leaves out
  *   builder_wgs_per_graph  of the topology the same launch builds: 2 / 1; 0 = it gets a launch of its own
  *   lds_bytes  LDS one workgroup needs (<= 160 KiB whenever family != NONE); xchg_words: uint64 exchange words per graph
+ *   from_memory  1: graphs beyond the LDS budget of the staged kernels (200 - 270 nodes, by width) -- the instance that reads the
+ *            node-sized input tile from memory (L2) where it is used instead of staging it: GINet's one-workgroup kernel with the S
+ *            rows of the tiles left in memory, sGAT / FoutNet with the x rows left in memory; run-time LDS layout, up to what
+ *            the builder forms tiles for (drgnn_topology_tiles_ok: ~250 - 400 nodes, by width)
  * Overrides (0 = automatic; tests and same-box A/B runs): force_wgs 1 / 2 = always that many workgroups per graph (2 beyond the
  * resident size is MEASUREMENT ONLY: the exchange then leans on in-order dispatch; bounded wait + fault bit); no_class;
  * no_aggregate (never the aggregation-first family: family NONE on the device, the launch pair steps the mini-batch);
@@ -494,6 +498,7 @@ typedef struct drgnn_step_plan {
     /* out */
     int32_t family, wgs_per_graph, slabs_per_graph, width, cls, lean_ok, builder_wgs_per_graph;
     int64_t lds_bytes, xchg_words;
+    int32_t from_memory, reserved;   /* (ABI 4) 1: the instance that leaves the node-sized input tile in memory */
 } drgnn_step_plan;
 /* Returns wgs_per_graph (0: family NONE).  Host-side only. */
 int32_t drgnn_net_step_plan(drgnn_step_plan* plan);

@@ -35,7 +35,7 @@ def test_hip_library_exports_every_declared_symbol():
     missing = [n for n in declared() if not hasattr(lib, n)]
     assert not missing, missing
     lib.drgnn_abi_version.restype = ctypes.c_int
-    assert lib.drgnn_abi_version() == 3
+    assert lib.drgnn_abi_version() == 4
     # pure host-side helpers may be called without a GPU
     off_i = (ctypes.c_int64 * 64)()
     off_f = (ctypes.c_int64 * 8)()

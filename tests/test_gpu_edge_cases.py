@@ -93,7 +93,7 @@ def test_native_trainer_on_a_ragged_batch_with_class_weights():
         loss.backward()
         opt.step()
         got = tr.train_step(batch)
-        np.testing.assert_allclose(float(got), float(loss), rtol=1e-4)
+        np.testing.assert_allclose(float(got), float(loss.detach()), rtol=1e-4)
     for (k, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
         np.testing.assert_allclose(p.detach().cpu().numpy(), q.detach().cpu().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
 

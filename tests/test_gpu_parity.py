@@ -42,7 +42,7 @@ def test_library_is_the_hip_build():
     from deeprank_gnn_amd import _lib
     api = _lib.get()
     assert api.path.endswith("csrc/libdrgnn.so")
-    assert api.lib.drgnn_abi_version() == 3
+    assert api.lib.drgnn_abi_version() == 4
     mapped = [ln.split()[-1] for ln in open("/proc/self/maps") if "libdrgnn" in ln]
     assert any(m.endswith("csrc/libdrgnn.so") for m in mapped), mapped
     # the package's API object must be bound to the gfx950 build, not to the host-emulation build of the CPU suite

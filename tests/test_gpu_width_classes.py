@@ -119,7 +119,12 @@ def test_shipped_regression_model_inference_known_answer():
 SHAPES = [("GINet", 48, 200, 128), ("GINet", 16, 200, 64), ("GINet", 64, 200, 64),
           ("sGAT", 16, 200, 64), ("sGAT", 48, 200, 128), ("sGAT", 64, 120, 64),
           ("FoutNet", 16, 200, 64), ("FoutNet", 48, 200, 128), ("FoutNet", 64, 120, 64),
-          ("sGAT", 64, 200, 64), ("FoutNet", 64, 200, 64), ("FoutNet", 52, 200, 64), ("sGAT", 50, 200, 64)]
+          ("sGAT", 64, 200, 64), ("FoutNet", 64, 200, 64), ("FoutNet", 52, 200, 64), ("sGAT", 50, 200, 64),
+          # graphs beyond the LDS budget of the staged forms, up to what the builder forms tiles for: GINet's one-workgroup kernel
+          # with the S rows left in memory (drgnn_step3.h, SG), sGAT / FoutNet with the x rows left in memory at every width
+          ("GINet", 32, 340, 32), ("GINet", 48, 300, 32), ("GINet", 16, 400, 24), ("GINet", 64, 250, 32), ("GINet", 30, 330, 24),
+          ("sGAT", 32, 340, 32), ("FoutNet", 32, 340, 32), ("sGAT", 48, 300, 32), ("FoutNet", 48, 300, 32), ("FoutNet", 16, 400, 24),
+          ("sGAT", 30, 330, 24)]
 
 
 @pytest.mark.parametrize("net_name,n_feat,n_nodes,B", SHAPES)
@@ -179,6 +184,41 @@ def test_fused_step_other_widths_match_oracle_elementwise(net_name, n_feat, n_no
         np.testing.assert_allclose(float(tr2.loss), float(loss), rtol=1e-5)
     pc = tr2.predict_cached(cache, list(range(B)))
     check("cached inference", pc.cpu().numpy(), ref_pred.numpy(), lazy.pred, new_stats())
+    beyond = n_nodes > 200 or (net_name != "GINet" and n_feat > 48 and n_nodes >= 200)
+    if not beyond:
+        assert not c["plan"].from_memory
+        return
+    # Graphs beyond the staged kernels' LDS: the instances that leave the node-sized tile in memory (plan.from_memory).  sGAT /
+    # FoutNet took it above; GINet's is the one-workgroup kernel, which a batch this small reaches only when told to (two
+    # workgroups per graph hold less each): the same numbers again through it, training and inference.
+    if net_name != "GINet":
+        assert c["plan"].from_memory and cc["plan"].from_memory, (net_name, n_feat, n_nodes)
+        return
+    net3, tr3 = _trainer(net_name, params, 1, "reg")
+    tr3.plan_overrides = {"force_wgs": 1}
+    topo3 = Topology.from_batch(batch, need_weights=False)
+    c3 = tr3._fused_prepare(batch, topo3, True, None)
+    assert c3["plan"].family == _lib.STEP_FAMILY_AGGREGATE and c3["plan"].wgs_per_graph == 1 and c3["plan"].from_memory, \
+        (n_feat, n_nodes, c3["plan"].family, c3["plan"].wgs_per_graph, c3["plan"].from_memory)
+    loss3 = tr3.compute_gradients(batch, topo=topo3)
+    torch.cuda.synchronize()
+    assert tr3.faults() == 0
+    stats3 = new_stats()
+    check_step("%s %d graphs of %d nodes F=%d, S rows from memory" % (net_name, B, n_nodes, n_feat), lazy, float(loss3),
+               tr3.last_pred.cpu().numpy(), {k: p.grad.detach().cpu().numpy() for k, p in net3.named_parameters()}, ref_loss,
+               ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()}, stats3)
+    assert_arbiter_rate(stats3, "%s F=%d from memory" % (net_name, n_feat))
+    p3 = tr3.predict(batch, topo=topo3)
+    check("inference, S rows from memory", p3.cpu().numpy(), ref_pred.numpy(), lazy.pred, new_stats())
+    net4, tr4 = _trainer(net_name, params, 1, "reg")
+    tr4.plan_overrides = {"force_wgs": 1}
+    c4 = tr4._cached_prepare(cache, list(range(B)))
+    assert c4["plan"].from_memory and c4["plan"].wgs_per_graph == 1
+    tr4.train_step_cached(cache, list(range(B)), apply_adam=False)
+    torch.cuda.synchronize()
+    assert float(tr4.loss) == float(loss3)                 # cached topology, gathered: the same bits
+    for k, p in net4.named_parameters():
+        np.testing.assert_array_equal(p.grad.detach().cpu().numpy(), net3.get_parameter(k).grad.detach().cpu().numpy(), err_msg=k)
 
 
 def test_two_trainers_keep_their_own_forced_layouts_in_one_process():
