@@ -225,7 +225,7 @@ class StepEngine(object):
             return held[1]
         topo = Topology.from_batch(data, api=self.api, need_weights=need_w, build=False)
         flags = topo.full_flags()
-        if flags & _lib.TOPO_TILES:
+        if topo.tiles is not None:      # (also tiles the builder cannot stage: asked for only when a fused kernel will read them)
             x = data.x
             af = _lib.TOPO_HIER | _lib.TOPO_LEAN | _lib.TOPO_TILES
             p = self._plan(int(x.shape[1]), topo, True, af)

@@ -428,14 +428,26 @@ class TopologyCache(object):
             r.ids, r.x_out, r.y_out = p(ids), None, None
             r.flags = _lib.TOPO_HIER
             # the set's level-0 aggregation tiles: formed ONCE here, read by every training step on the cache
-            if scratch is None and (gset.n_feat % 4 != 0 or gset.x.data_ptr() % 16 == 0) and \
-                    api.topology_tiles_ok(self.max_nodes, self.max_edges, gset.n_feat):
+            x_ok = gset.n_feat % 4 != 0 or gset.x.data_ptr() % 16 == 0
+            separately = False
+            if scratch is None and x_ok and api.topology_tiles_ok(self.max_nodes, self.max_edges, gset.n_feat):
                 topo.tiles = torch.empty(max(api.topology_tiles_elems(N, gset.n_feat), 4), dtype=torch.float32, device=dev)
                 topo.n_feat = gset.n_feat
                 r.tiles, r.n_feat = p(topo.tiles), gset.n_feat
                 r.flags |= _lib.TOPO_TILES
+            elif x_ok and gset.n_feat <= 64:
+                # the set's LARGEST graph is beyond what the builder stages an x tile for (or beyond its LDS altogether): the
+                # tiles come from the built workspace in a launch of their own (drgnn_topology_tiles: the builder's sums in the
+                # builder's order, the same bits), so that the mini-batches of smaller graphs keep their fused kernels
+                separately = True
             topo.flags = int(r.flags)
             api.topology_build_request(r, _lib.current_stream(gset.x))
+            if separately:
+                topo.tiles = torch.empty(max(api.topology_tiles_elems(N, gset.n_feat), 4), dtype=torch.float32, device=dev)
+                topo.n_feat = gset.n_feat
+                api.topology_tiles(topo.ws_i32, topo.ws_f32, N, E, G, gset.x, gset.n_feat, self.with_weights, topo.tiles,
+                                   _lib.current_stream(gset.x))
+                topo.flags |= _lib.TOPO_TILES
             topo._inputs = None
             self._keep = (ids, scratch)
         self.topo = topo

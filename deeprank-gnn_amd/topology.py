@@ -141,9 +141,13 @@ class Topology(object):
             F = int(x.shape[1])
             # (float4 loads of the rows where rows are multiples of 16 bytes; any other feature count is staged word by word)
             if x.shape[0] == n_nodes and F > 0 and (F % 4 != 0 or x.data_ptr() % 16 == 0) and \
-                    api.topology_tiles_ok(max_nodes, max_edges, F):
+                    (api.topology_tiles_ok(max_nodes, max_edges, F) or (F <= 64 and max_nodes < 1024 and max_edges <= 2048)):
                 topo.x, topo.n_feat = x, F
                 topo.tiles = torch.empty(max(api.topology_tiles_elems(n_nodes, F), 4), dtype=torch.float32, device=device)
+                # a graph beyond what the builder stages an x tile for: the tiles are formed from the built workspace by a
+                # launch of their own (drgnn_topology_tiles: the same bits) behind every rebuild(); a launch that CO-builds
+                # this workspace leaves it without tiles
+                topo._tiles_separately = not api.topology_tiles_ok(max_nodes, max_edges, F)
         if build:
             topo.rebuild(flags)
             if check:
@@ -163,6 +167,10 @@ class Topology(object):
         r.max_nodes, r.max_edges = self.max_nodes, self.max_edges
         r.ws_i32, r.ws_f32, r.scratch_i32 = p(self.ws_i32), p(self.ws_f32), p(scratch)
         r.flags = self.full_flags() if flags is None else int(flags)
+        self._tiles_pending = False
+        if (r.flags & _lib.TOPO_TILES) and getattr(self, "_tiles_separately", False):
+            r.flags &= ~_lib.TOPO_TILES
+            self._tiles_pending = True
         if r.flags & _lib.TOPO_TILES:
             if self.tiles is None:
                 raise ValueError("this topology has no aggregation tiles (no float32 x the builder's LDS holds a tile of)")
@@ -174,8 +182,10 @@ class Topology(object):
         return r
 
     def full_flags(self):
-        """Everything the builder can put into this workspace."""
-        return _lib.TOPO_HIER | (_lib.TOPO_TILES if self.tiles is not None else 0)
+        """Everything the builder can put into this workspace (tiles it cannot stage are formed on explicit request only:
+        ``rebuild(flags | TOPO_TILES)``)."""
+        own = self.tiles is not None and not getattr(self, "_tiles_separately", False)
+        return _lib.TOPO_HIER | (_lib.TOPO_TILES if own else 0)
 
     def rebuild(self, flags=None):
         """(Re)run the builder into this object's existing buffers, on torch's current stream --
@@ -188,7 +198,14 @@ class Topology(object):
         if flags is None:
             flags = self.full_flags()
         if int(flags) != _lib.TOPO_HIER:
-            self.api.topology_build_request(self.request(flags), _lib.current_stream(batch))
+            stream = _lib.current_stream(batch)
+            self.api.topology_build_request(self.request(flags), stream)
+            if getattr(self, "_tiles_pending", False):
+                self.api.topology_tiles(self.ws_i32, self.ws_f32, self.n_nodes, self.n_edges, self.n_graphs, self.x, self.n_feat,
+                                        self.ws_f32 is not None, self.tiles, stream)
+                self._tiles_x_version = self.x._version
+                self.flags |= _lib.TOPO_TILES
+                self._tiles_pending = False
             return self
         self.flags = _lib.TOPO_HIER          # (drgnn_topology_build always builds the hierarchical order)
         self.api.topology_build(edge_index, edge_attr, batch, cluster0, cluster1, node_ptr, edge_ptr, c1_ptr,

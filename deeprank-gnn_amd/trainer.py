@@ -265,7 +265,7 @@ class FusedTrainer(object):
         aggregation-first kernels (judged by its plan, for a following mini-batch of the same size): the hierarchical node
         order, the aggregation tiles, and nothing those kernels do not read (TOPO_LEAN: the builder's short chains);
         _fused_launch_step rebuilds in full should that turn out wrong.  Otherwise the plain build."""
-        if getattr(topo, "tiles", None) is not None and self._tiles_match(topo):
+        if getattr(topo, "tiles", None) is not None and self._tiles_match(topo) and not getattr(topo, "_tiles_separately", False):
             af = _lib.TOPO_HIER | _lib.TOPO_LEAN | _lib.TOPO_TILES
             if self._plan(n_feat, topo.max_nodes, topo.max_edges, topo.max_c0, topo.n_graphs, topo.n_graphs, train, af).lean_ok:
                 return af

@@ -687,3 +687,41 @@ def test_boundary_edge_cases(net_name):
             scale = float(np.nanmax(np.abs(r))) if np.isfinite(r).any() else 1.0
             np.testing.assert_allclose(p.grad.cpu().numpy(), r, rtol=2e-4, atol=2e-5 * max(1.0, scale), equal_nan=nan_ok,
                                        err_msg="%s %s" % (what, n))
+
+
+@pytest.mark.parametrize("net_name,n_feat,n_nodes", [("GINet", 48, 380), ("GINet", 64, 330), ("sGAT", 32, 340), ("FoutNet", 48, 300)])
+def test_graphs_beyond_the_staged_layout_through_the_drop_in_boundary(net_name, n_feat, n_nodes):
+    """model(batch) / loss.backward() on graphs beyond the staged kernels' LDS budget: the from-memory instances
+    (plan.from_memory) -- for the GINet shapes also beyond what the builder stages an x tile for, so the engine has the
+    aggregation tiles formed by the stand-alone launch behind the build -- against the oracle."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.data import Batch
+    from oracle import cpu_ref
+    shape = dict(n_nodes=n_nodes, n_pairs=(5 * n_nodes) // 2, n_c1=max(4, n_nodes // 12), n_internal=(7 * n_nodes) // 4)
+    batch_cpu = Batch.from_data_list([synth.make_graph(i, n_feat=n_feat, **shape) for i in range(10)])
+    params = cpu_ref.init_params(net_name, n_feat, 1, 1, seed=29)
+    kw = _fw(net_name)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **kw)
+    net = _build(net_name, params, 1)
+    net.train()
+    batch = batch_cpu.clone().to(_dev())
+    out = net(batch)
+    eng = _engine(net)
+    assert eng.last_path == "jacobian" and eng.last_plan.family == _lib.STEP_FAMILY_AGGREGATE and eng.last_plan.from_memory, \
+        eng.last_reason
+    topo = eng.topology_for(batch)
+    assert bool(getattr(topo, "_tiles_separately", False)) == (not _lib.get().topology_tiles_ok(n_nodes, 5 * n_nodes, n_feat))
+    loss = F.mse_loss(out.reshape(-1), batch.y)
+    loss.backward()
+    torch.cuda.synchronize()
+    stats = new_stats()
+    check_step("%s F=%d, %d nodes [drop-in, from memory]" % (net_name, n_feat, n_nodes), Lazy64(net_name, params, batch_cpu, **kw),
+               loss.item(), out.detach().cpu().numpy(), {k: p.grad.cpu().numpy() for k, p in net.named_parameters()}, ref_loss,
+               ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()}, stats)
+    assert_arbiter_rate(stats, net_name)
+    net.eval()
+    with torch.no_grad():
+        pred = net(batch)
+    assert eng.last_path == "inference" and eng.last_plan.from_memory
+    np.testing.assert_allclose(pred.cpu().numpy(), out.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)

@@ -97,7 +97,7 @@ def test_custom_net_from_layers_trains():
         loss = F.mse_loss(pred, batch.y)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert losses[-1] < losses[0]
 
 

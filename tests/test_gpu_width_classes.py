@@ -287,3 +287,71 @@ def test_stale_tiles_are_not_used():
         np.testing.assert_allclose(tr.last_pred.cpu().numpy(), ref_pred.numpy(), rtol=1e-4, atol=1e-4)
         batch = batch_cpu.clone().to(dev)
         topo = Topology.from_batch(batch, need_weights=False)
+
+
+def test_stand_alone_tiles_launch_gives_the_builders_bits():
+    """drgnn_topology_tiles (the launch that forms aggregation tiles from a BUILT workspace: the other flavour of a shared cache,
+    and the tiles of a set whose largest graph the builder cannot stage) == the tiles the builder forms itself, bit for bit,
+    plain and edge-weighted, with rows shorter than the padded width too."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    dev = _dev()
+    for n_feat in (32, 30):
+        graphs = [synth.make_graph(i, n_feat=n_feat) for i in range(12)]
+        rs = ResidentGraphSet(graphs, dev)
+        for weighted in (False, True):
+            cache = rs.topology_cache(need_weights=weighted)
+            t = cache.topo
+            assert t.flags & _lib.TOPO_TILES
+            again = torch.full_like(t.tiles, float("nan"))
+            rs.api.topology_tiles(t.ws_i32, t.ws_f32, t.n_nodes, t.n_edges, t.n_graphs, rs.x, n_feat, weighted, again,
+                                  _lib.current_stream(rs.x))
+            torch.cuda.synchronize()
+            n = rs.api.topology_tiles_elems(t.n_nodes, n_feat)
+            assert torch.equal(again[:n].view(torch.int32), t.tiles[:n].view(torch.int32)), (n_feat, weighted)
+
+
+def test_one_large_graph_does_not_take_the_fused_kernels_from_the_rest_of_the_set():
+    """A resident set whose LARGEST graph is beyond what the builder stages an x tile for (380 nodes at 48 features; the limit is
+    310) still gets aggregation tiles -- formed by the stand-alone launch -- so its mini-batches keep the fused kernels: the ones
+    of ordinary graphs the staged instances, the one with the large graph GINet's from-memory instance (sGAT: beyond its own
+    kernels' LDS too -- no fused kernel for THAT mini-batch, which the trainers step through the per-batch path).  Each against the
+    oracle."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    dev = _dev()
+    n_feat = 48
+
+    def shape(n):
+        return dict(n_nodes=n, n_pairs=(5 * n) // 2, n_c1=max(4, n // 12), n_internal=(7 * n) // 4)
+    graphs = [synth.make_graph(i, n_feat=n_feat, **shape(150)) for i in range(23)] + [synth.make_graph(99, n_feat=n_feat, **shape(380))]
+    assert not _lib.get().topology_tiles_ok(380, 1900, n_feat)
+    rs = ResidentGraphSet(graphs, dev)
+    for net_name in ("GINet", "sGAT"):
+        need_w = net_name == "sGAT"
+        cache = rs.topology_cache(need_weights=need_w)
+        assert cache.topo.flags & _lib.TOPO_TILES and cache.topo.tiles is not None
+        params = cpu_ref.init_params(net_name, n_feat, 1, 1, seed=23)
+        for ids, big in ((list(range(0, 12)), False), (list(range(12, 24)), True)):
+            net, tr = _trainer(net_name, params, 1, "reg")
+            if big and net_name == "sGAT":
+                with pytest.raises(_lib.DrgnnError):
+                    tr._cached_prepare(cache, ids)
+                continue
+            c = tr._cached_prepare(cache, ids)
+            assert c["plan"].family == _lib.STEP_FAMILY_AGGREGATE and bool(c["plan"].from_memory) == big, (net_name, big)
+            loss = tr.train_step_cached(cache, ids, apply_adam=False)
+            torch.cuda.synchronize()
+            assert tr.faults() == 0
+            batch_cpu = Batch.from_data_list([graphs[i] for i in ids])
+            kw = _fw(net_name)
+            ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **kw)
+            stats = new_stats()
+            check_step("%s cached, %s graphs" % (net_name, "with the 380-node graph" if big else "150-node"),
+                       Lazy64(net_name, params, batch_cpu, **kw), float(loss), tr.last_pred.cpu().numpy(),
+                       {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}, ref_loss, ref_pred.numpy(),
+                       {k: v.numpy() for k, v in ref_grads.items()}, stats)
+            assert_arbiter_rate(stats, net_name)
