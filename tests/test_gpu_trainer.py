@@ -30,7 +30,7 @@ def test_five_native_steps_match_oracle_training(net_name):
         loss.backward()
         opt.step()
         got = tr.train_step(batch)
-        np.testing.assert_allclose(float(got), float(loss), rtol=1e-4)
+        np.testing.assert_allclose(float(got), float(loss.detach()), rtol=1e-4)
     sd = net.state_dict()
     for k, v in leaves.items():
         np.testing.assert_allclose(sd[k].cpu().numpy(), v.detach().numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
@@ -198,7 +198,7 @@ def test_transform_sigmoid_on_the_device(net_name):
         loss.backward()
         opt.step()
         got = tr.train_step(batch)
-        np.testing.assert_allclose(float(got), float(loss), rtol=1e-4)
+        np.testing.assert_allclose(float(got), float(loss.detach()), rtol=1e-4)
         np.testing.assert_allclose(tr.last_pred.reshape(-1).cpu().numpy(), pred.detach().numpy(), rtol=1e-4, atol=1e-5)
     sd = net.state_dict()
     for k, v in leaves.items():

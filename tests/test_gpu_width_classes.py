@@ -355,3 +355,17 @@ def test_one_large_graph_does_not_take_the_fused_kernels_from_the_rest_of_the_se
                        {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}, ref_loss, ref_pred.numpy(),
                        {k: v.numpy() for k, v in ref_grads.items()}, stats)
             assert_arbiter_rate(stats, net_name)
+    # ... and the native epoch loop over that set (cached topology, GINet): mini-batch by mini-batch the same launches
+    cache = rs.topology_cache(need_weights=False)
+    params = cpu_ref.init_params("GINet", n_feat, 1, 1, seed=23)
+    order = list(range(24))
+    net_a, tr_a = _trainer("GINet", params, 1, "reg")
+    done = tr_a.train_epoch(rs, order, 12, cached=True)
+    assert done is not None
+    losses, pred = done
+    net_b, tr_b = _trainer("GINet", params, 1, "reg")
+    want = [float(tr_b.train_step_cached(cache, order[k:k + 12])) for k in (0, 12)]
+    torch.cuda.synchronize()
+    assert [float(v) for v in losses.cpu()] == want
+    for (k, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
+        assert torch.equal(pa, pb), k
