@@ -725,3 +725,35 @@ def test_graphs_beyond_the_staged_layout_through_the_drop_in_boundary(net_name, 
         pred = net(batch)
     assert eng.last_path == "inference" and eng.last_plan.from_memory
     np.testing.assert_allclose(pred.cpu().numpy(), out.detach().cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_classification_on_graphs_beyond_the_staged_layout():
+    """Several outputs on such graphs: the forward-only from-memory instance, then the training instance fed d loss / d pred
+    (two launches); cross-entropy against the oracle."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.data import Batch
+    from oracle import cpu_ref
+    n_feat, n_nodes = 32, 360
+    shape = dict(n_nodes=n_nodes, n_pairs=(5 * n_nodes) // 2, n_c1=max(4, n_nodes // 12), n_internal=(7 * n_nodes) // 4)
+    batch_cpu = Batch.from_data_list([synth.make_graph(i, n_feat=n_feat, **shape) for i in range(9)])
+    target = torch.tensor([0, 2, 1, 1, 0, 2, 2, 0, 1])
+    for net_name in ("GINet", "FoutNet"):
+        params = cpu_ref.init_params(net_name, n_feat, 3, 1, seed=31)
+        kw = _fw(net_name)
+        ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, target, task="class", **kw)
+        net = _build(net_name, params, 3)
+        net.train()
+        batch = batch_cpu.clone().to(_dev())
+        out = net(batch)
+        eng = _engine(net)
+        assert eng.last_path == "two-launch" and eng.last_plan.from_memory, eng.last_reason
+        loss = F.cross_entropy(out, target.to(_dev()))
+        loss.backward()
+        torch.cuda.synchronize()
+        stats = new_stats()
+        check_step("%s 3 classes, %d nodes [drop-in, from memory]" % (net_name, n_nodes),
+                   Lazy64(net_name, params, batch_cpu, target=target, task="class", **kw), loss.item(), out.detach().cpu().numpy(),
+                   {k: p.grad.cpu().numpy() for k, p in net.named_parameters()}, ref_loss, ref_pred.numpy(),
+                   {k: v.numpy() for k, v in ref_grads.items()}, stats)
+        assert_arbiter_rate(stats, net_name)
