@@ -703,7 +703,7 @@ enum { SK_STEP = 0, SK_STEP1 = 1, SK_AF2 = 2, SK_AF3 = 3, SK_AF3B = 4 };
 struct StepPick {
     int rc;                 // 0, or the error a launch of this shape returns (family NONE)
     int family, kernel, wgs, slabs, width, cls, paired, lean_ok, builder_roles;
-    int xg;                 // sGAT / FoutNet: the x-from-memory form (the S and the x tile together do not fit the LDS)
+    int xg;                 // sGAT / FoutNet: 1 = the x-from-memory form (the S and the x tile together do not fit the LDS), 2 = S too
     int sg;                 // GINet, one workgroup per graph: the S-from-memory form (the S tile does not fit the LDS)
     int64_t lds, xchg_words;
     int capN, capE, capC;   // the LDS capacities the kernel is launched with (the class's when cls)
@@ -736,8 +736,9 @@ static StepPick step_pick(const StepAsk& q) {
     int af_w = step_af_width(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O);
     const bool af_ws = !q.ov.no_aggregate && (q.topo_flags & DRGNN_TOPO_HIER) && (q.topo_flags & DRGNN_TOPO_TILES);
     const bool af_shape = af_ws && af_w != 0 && (q.kind == DRGNN_GINET || (q.F & 3) != 0 || q.x_ok);
-    // (GINet's one-workgroup kernel with the S rows left in memory: graphs the staged forms have no LDS -- or no register burst -- for)
-    const int sg_w = (q.kind == DRGNN_GINET && af_ws) ? step_af_width(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O, true) : 0;
+    // (the forms that leave the tiles' S rows in memory -- GINet's one-workgroup kernel, the 48- / 64-wide single-branch kernels:
+    // graphs the staged forms have no LDS -- or no register burst -- for)
+    const int sg_w = af_ws ? step_af_width(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O, true) : 0;
 #endif
     // The PRODUCT-FIRST family (drgnn_step.h / drgnn_step1.h, rounds 2 - 3) is the host emulation's only: the device library
     // instantiates the aggregation-first kernels alone (round 6), and a launch they do not cover -- a head that is not the
@@ -786,6 +787,13 @@ static StepPick step_pick(const StepAsk& q) {
             const int64_t lxg = 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O, 1);
             if (lxg <= DRGNN_LDS_LIMIT) { laf = lxg; k.xg = 1; }
         }
+#ifndef DRGNN_EMU
+        if (laf > DRGNN_LDS_LIMIT && sg_w >= 32 && ((q.F & 3) != 0 || q.x_ok)) {
+            // ... and where the S tile alone is too much (the 32-, 48- and 64-wide kernels beyond 250 - 360 nodes): the S rows too
+            const int64_t lxg = 4 * step2_scratch_words(q.kind, q.F, q.capN, q.capE, q.capC, q.H, q.O, 2);
+            if (lxg <= DRGNN_LDS_LIMIT) { laf = lxg; k.xg = 2; af_w = sg_w; }
+        }
+#endif
         const int64_t lold = old_ok ? step_lds_bytes(q.kind, q.F, q.capN, q.capE, q.capC, q.R, q.H, q.O) : STEP_LDS_NEVER;
         const bool af_ok = laf <= DRGNN_LDS_LIMIT;
         // the node-split layout: training launches of the aggregation-first kernels under GINet's residency rule
@@ -1107,7 +1115,7 @@ static int train_step_impl(const drgnn_net_desc* net, const drgnn_head_desc* hd,
             case SK_AF3: kern = af_step_kernel(DRGNN_AF_GINET_TWO, k.width, gather, k.cls, 1, q.train); break;
             case SK_AF3B: kern = af_step_kernel(k.sg ? DRGNN_AF_GINET_SG : DRGNN_AF_GINET_ONE, k.width, gather, k.cls, 1, q.train); break;
             case SK_AF2: kern = af_step_kernel(k.xg ? (kind == DRGNN_SGAT ? DRGNN_AF_SGAT_XG : DRGNN_AF_FOUT_XG)
-                                                    : (kind == DRGNN_SGAT ? DRGNN_AF_SGAT : DRGNN_AF_FOUT), k.width, gather, k.cls, k.wgs, q.train); break;
+                                                    : (kind == DRGNN_SGAT ? DRGNN_AF_SGAT : DRGNN_AF_FOUT), k.width, gather, k.cls, k.wgs, q.train, k.xg); break;
             default: return DRGNN_E_CAPACITY;      // (the product-first family is not part of the device library: step_pick never picks it)
         }
         if ((rc = step_launch(kern, both, (unsigned)(blocks + extra), (hipStream_t)stream_, C))) return rc;

@@ -510,7 +510,7 @@ DEV void step_block_both(const StepLaunch& L, int g, float* lds) {
 // sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h).  SPLIT = 2: the two halves of a graph are 8
 // block ids apart (same XCD: they read the same x tile and topology and hand each other pooled rows), graphs in groups
 // of 8 like GINet's branch workgroups.
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN, bool XG = false>
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN, int XG = 0>
 DEV void step2_block(const StepLaunch& L, int blk, float* lds) {
     int g, half;
     if (SPLIT == 2) { g = ((blk >> 4) << 3) + (blk & 7); half = (blk >> 3) & 1; }
@@ -889,7 +889,7 @@ __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step1_co_topo(StepCoLaunch C
     else topo_block<true, 0>(C.topo, co_topo_blk_, (int*)smem_s1);
 }
 // sGAT / FoutNet, aggregation first, SPLIT workgroups per graph (drgnn_step2.h) + the builder's workgroups
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN, bool XG = false>
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN, int XG = 0>
 __global__ void __launch_bounds__(DRGNN_NTHREADS) k_step2_co_topo(StepCoLaunch C_by_value) {
     extern __shared__ __attribute__((aligned(16))) float smem_s2[];
     PHASE_BEGIN();

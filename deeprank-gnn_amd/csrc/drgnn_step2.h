@@ -90,7 +90,7 @@ struct Step2Scratch {
     X(ts1, (sg ? (capE + 1) / 2 : capE), sg)                                                   \
     X(a0, ((long)capC * DRGNN_H1 + 1) / 2, 1)                                                  \
     X(a1, ((long)capC * DRGNN_H2 + 1) / 2, 1)                                                  \
-    X(G, (long)(capN + 4) * xld, 1)                                                            \
+    X(G, (long)(capN + 4) * xld, xg < 2)                                                       \
     X(z1, STEP2_Z1U_WORDS(capN, capC), 1)                                                      \
     X(dv0, capN + 4, 1)                                                                        \
     X(sc0, capN + 4, 1)                                                                        \
@@ -105,8 +105,9 @@ struct Step2Scratch {
 #endif  // !DRGNN_EMU
 
 // (host + device; also compiled by the emulation build, whose plan function must answer "never" consistently)
-// xg: the X-FROM-GLOBAL form (net_step2_graph<..., XG = true>, run-time layout): the x rows are not staged (the self
-// product and the sparse dWs read them from memory: L2), the hierarchical order is (position -> node) instead
+// xg: the FROM-MEMORY forms (net_step2_graph<..., XG = 1 | 2>, run-time layout).  1: the x rows are not staged (the self
+// product and the sparse dWs read them from memory: L2), the hierarchical order is (position -> node) instead; 2: neither are
+// the S rows of the tiles (conv1's neighbour product and dWn read them the same way)
 HD int64_t step2_scratch_words(int kind, int64_t F, int64_t capN, int64_t capE, int64_t capC, int64_t H, int64_t O, int xg = 0) {
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
     const int64_t xld = step_pad16((int)F) + 4;
@@ -167,10 +168,10 @@ template <int J> DEV void burst_store_x4_rows(const BurstX<J>& b, const BurstRow
 #else
 #define STEP2_PIN(x) do { if (SPIN) { asm volatile("" : "+s"(x)); } else { STEP_PIN(x); } } while (0)
 #endif
-template <int CLS, bool SPIN = false, bool XG = false>
+template <int CLS, bool SPIN = false, int XG = 0>
 DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, int capC, int H, int O) {
     const int sg = (kind == DRGNN_SGAT) ? 1 : 0;
-    constexpr int xg = XG ? 1 : 0;
+    constexpr int xg = XG;
     const int xld = step_pad16(F) + 4;
     Step2Scratch s;
     int o = 0;
@@ -189,7 +190,7 @@ DEV Step2Scratch step2_carve(float* base, int kind, int F, int capN, int capE, i
 
 // ---- phase B: Z1 = relu(D . (S Wn) + C . (X Ws) + b) over the own rows (S, X rows at their local positions) ---------------
 // XG: the x rows come from memory (xs = the graph's rows in NODE order, `xtf` floats apart; hord: position -> node)
-template <int KIND, int XF, bool XG = false>
+template <int KIND, int XF, int XG = 0>
 DEV void step2_conv1(int n, int nmax, const float* G, const float* xs, const float* w1t, const float* ws1t, const float* b1,
                      const float* dv, const float* sc, float* z1, int* dummy, const int* hord = nullptr, int xtf = 0) {
     constexpr int XLD = XF + 4;
@@ -199,20 +200,26 @@ DEV void step2_conv1(int n, int nmax, const float* G, const float* xs, const flo
     for (int ti = wave; ti < units; ti += DRGNN_NWAVES) {
         const int prow = ti * 16 + lr;
         const int row = prow < nmax ? prow : nmax - 1;      // rows past the own range: any valid row (results discarded)
-        const float* ag = G + row * XLD + 4 * lq;
+        // (XG == 2: G = the graph's S rows in memory, laid out like xs)
+        const float* ag = (XG == 2) ? G + (long)hord[row] * xtf + 4 * lq : G + row * XLD + 4 * lq;
         const float* ax = XG ? xs + (long)hord[row] * xtf + 4 * lq : xs + row * XLD + 4 * lq;
-        drgnn_f4 xv[XF / 16];
+        drgnn_f4 xv[XF / 16], gv[XF / 16];
         if (XG) {      // (all of the row's chunks requested at once; chunks past the row's end -- padded widths -- are zero)
 #pragma unroll
             for (int k0 = 0; k0 < XF; k0 += 16)
                 xv[k0 / 16] = (k0 + 4 * lq < xtf) ? *(const drgnn_f4*)(ax + k0) : drgnn_f4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (XG == 2) {
+#pragma unroll
+            for (int k0 = 0; k0 < XF; k0 += 16)
+                gv[k0 / 16] = (k0 + 4 * lq < xtf) ? *(const drgnn_f4*)(ag + k0) : drgnn_f4{0.f, 0.f, 0.f, 0.f};
         }
         const float* bn = w1t + lr * XLD + 4 * lq;
         const float* bs = ws1t + lr * XLD + 4 * lq;
         drgnn_f32x4 accn = {0.f, 0.f, 0.f, 0.f}, accs = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k0 = 0; k0 < XF; k0 += 16) {
-            const drgnn_f4 a = *(const drgnn_f4*)(ag + k0), x = XG ? xv[k0 / 16] : *(const drgnn_f4*)(ax + k0);
+            const drgnn_f4 a = (XG == 2) ? gv[k0 / 16] : *(const drgnn_f4*)(ag + k0), x = XG ? xv[k0 / 16] : *(const drgnn_f4*)(ax + k0);
             const drgnn_f4 wn = *(const drgnn_f4*)(bn + k0), ws = *(const drgnn_f4*)(bs + k0);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -519,7 +526,7 @@ template <int NSL> DEV float step_slices_sum(float v) {
     if (NSL >= 16) v += dpp_take<0x140>(v);   // row_mirror
     return v;
 }
-template <int XF, bool XG = false>
+template <int XF, int XG = 0>
 DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float* G, const float* xs, const float* dv,
                           const float* sc, float* g_dwn, float* g_dws, float* g_db1, int F, const int* hord = nullptr, int xtf = 0) {
     constexpr int XLD = XF + 4, NSL = Dw1Shape<XF>::NSL;
@@ -540,7 +547,8 @@ DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float
         for (int u = 0; u < 2; ++u) {
             if (arg[u] >= 0) {
                 const float dn = d[u] * dv[arg[u]], ds = d[u] * sc[arg[u]];
-                const drgnn_f4 g = *(const drgnn_f4*)(G + ROW24(arg[u], XLD) + 4 * fc);
+                const drgnn_f4 g = (XG < 2) ? *(const drgnn_f4*)(G + ROW24(arg[u], XLD) + 4 * fc)
+                                   : (4 * fc < xtf) ? *(const drgnn_f4*)(G + (long)hord[arg[u]] * xtf + 4 * fc) : drgnn_f4{0.f, 0.f, 0.f, 0.f};
                 const drgnn_f4 x = !XG ? *(const drgnn_f4*)(xs + ROW24(arg[u], XLD) + 4 * fc)
                                    : (4 * fc < xtf) ? *(const drgnn_f4*)(xs + (long)hord[arg[u]] * xtf + 4 * fc) : drgnn_f4{0.f, 0.f, 0.f, 0.f};
                 an[0] = fmaf(dn, g[0], an[0]); an[1] = fmaf(dn, g[1], an[1]); an[2] = fmaf(dn, g[2], an[2]); an[3] = fmaf(dn, g[3], an[3]);
@@ -568,8 +576,8 @@ DEV void step2_dw1_sparse(int Ch, const short* a0, const float* dxp, const float
 // TRAIN = false: the inference launch (forward + head, predictions only; one workgroup per graph).
 // XG: x rows read from memory instead of staged in LDS -- what lets 200-node graphs with up to 64 features into the 160 KiB
 // (133 KB instead of 189 KB at SYN size) and, at the narrower widths, graphs of 260 - 350 nodes; the host takes it only when
-// the staged form does not fit.
-template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN = true, bool XG = false>
+// the staged form does not fit.  XG = 2 (32-, 48- and 64-wide): the S rows of the tiles stay in memory as well.
+template <int KIND, int XF, bool GATHER, int CLS, int SPLIT, bool TRAIN = true, int XG = 0>
 DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi, int half, float* scratch, int capN, int capE,
                          int capC, bool late, int cnt_c, int cnt_e1, int cnt_c1, int hs_k, int hs_q, int hs_n) {
     static_assert(XF == 16 || XF == 32 || XF == 48 || XF == 64, "width-specialised kernels only");
@@ -679,9 +687,9 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
             m_bad = __builtin_amdgcn_readfirstlane(m_bad);
         }
     }
-    burst_load_x(bsum, sgl, d.N, TF);
+    if (XG < 2) burst_load_x(bsum, sgl, d.N, TF);
     if (!XG) burst_load_x(bx, xgl, d.N, TF);
-    burst_load_rowmap(brow, bsum, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);      // (the S and the x tile have the same geometry)
+    if (XG < 2) burst_load_rowmap(brow, bsum, tv.p[DRGNN_TI_IHORD] + d.n0, d.N);      // (the S and the x tile have the same geometry)
     // per-node coefficients D, C and the node's position (one node per lane: d.N <= threads, step_burst_guaranteed)
     float n_d = 0.0f, n_c = 0.0f;
     int n_pos = -1;
@@ -715,7 +723,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     const int Co = d.C - Ch, qbase_o = (SPLIT == 2 && half == 0) ? hs_q : 0;      // the partner's pooled rows
     const int nmax = imax(Nh, 1);
     // the S and x rows of the OWN positions -> LDS row (position - nbase); D, C likewise
-    burst_store_x4_rows(bsum, brow, s.G, XLD, nbase, Nh);
+    if (XG < 2) burst_store_x4_rows(bsum, brow, s.G, XLD, nbase, Nh);
     if (!XG) burst_store_x4_rows(bx, brow, s.xs, XLD, nbase, Nh);
     if ((unsigned)(n_pos - nbase) < (unsigned)Nh) { s.dv0[n_pos - nbase] = n_d; s.sc0[n_pos - nbase] = n_c; }
     FOR_TID(e, step_pad4(Nh) - Nh) { s.dv0[Nh + e] = 0.0f; s.sc0[Nh + e] = 0.0f; }      // (coefficients of the K padding rows)
@@ -724,7 +732,10 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     wstage_store(wst);
     if (XF > TF) {     // zero padding of the k columns [TF, XF) of the row tiles ...
         const int padg = XF - TF;
-        FOR_TID(e, Nh * padg) { if (!XG) { s.xs[(e / padg) * XLD + TF + e % padg] = 0.0f; } s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+        FOR_TID(e, Nh * padg) {
+            if (!XG) { s.xs[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+            if (XG < 2) { s.G[(e / padg) * XLD + TF + e % padg] = 0.0f; }
+        }
     }
     if (XF > F) {      // ... and [F, XF) of the weights
         const int padc = XF - F;
@@ -740,7 +751,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     EXIT_AFTER(1);
     EXIT_AFTER(2);
     // ---- B: conv1's product ------------------------------------------------------------------------------------------------
-    PH(2) step2_conv1<KIND, XF, XG>(Nh, nmax, s.G, XG ? xgl : s.xs, s.w1t, s.ws1t, s.b1, s.dv0, s.sc0, s.z1, dummy, XG ? s.hord + nbase : nullptr, TF);
+    PH(2) step2_conv1<KIND, XF, XG>(Nh, nmax, (XG == 2) ? sgl : s.G, XG ? xgl : s.xs, s.w1t, s.ws1t, s.b1, s.dv0, s.sc0, s.z1, dummy, XG ? s.hord + nbase : nullptr, TF);
     FOR_TID(e, (step_pad4(d.C) - d.C) * STEP_XPLD) { s.xp[d.C * STEP_XPLD + e] = 0.0f; }
     BARRIER();
     EXIT_AFTER(3);
@@ -826,7 +837,7 @@ DEV void net_step2_graph(const StepArgs& a, const GraphDims& d_in, int g, int gi
     BARRIER();
     EXIT_AFTER(14);
     // ---- N: dWn, dWs, db1 through the depth-0 argmax ------------------------------------------------------------------------------
-    PH(16) step2_dw1_sparse<XF, XG>(Ch, s.a0, s.z2, s.G, XG ? xgl : s.xs, s.dv0, s.sc0, p_w1n, p_w1n + (long)F * DRGNN_H1, p_b1, F,
+    PH(16) step2_dw1_sparse<XF, XG>(Ch, s.a0, s.z2, (XG == 2) ? sgl : s.G, XG ? xgl : s.xs, s.dv0, s.sc0, p_w1n, p_w1n + (long)F * DRGNN_H1, p_b1, F,
                                     XG ? s.hord + nbase : nullptr, TF);
 }
 

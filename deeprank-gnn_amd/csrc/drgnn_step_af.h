@@ -73,25 +73,30 @@ template <int KIND, int XF> drgnn_step_kernel_t af_pick_single(bool gather, int 
     }
 }
 
-// the x-from-memory form (run-time LDS layout only): graphs whose S AND x tiles do not fit the 160 KiB
-template <int KIND, int XF> drgnn_step_kernel_t af_pick_single_xg(bool gather, int split, bool train) {
-    if (!train) return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, false, true> : k_step2_co_topo<KIND, XF, false, 0, 1, false, true>;
-    if (split == 2) return gather ? k_step2_co_topo<KIND, XF, true, 0, 2, true, true> : k_step2_co_topo<KIND, XF, false, 0, 2, true, true>;
-    return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, true, true> : k_step2_co_topo<KIND, XF, false, 0, 1, true, true>;
+// the from-memory forms (run-time LDS layout only): graphs whose S AND x tiles do not fit the 160 KiB -- level 1: the x rows
+// stay in memory; level 2 (32-, 48- and 64-wide: the widths whose S tile fills the LDS before the edge arrays do): the S rows too
+template <int KIND, int XF, int LV> drgnn_step_kernel_t af_pick_single_xg_level(bool gather, int split, bool train) {
+    if (!train) return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, false, LV> : k_step2_co_topo<KIND, XF, false, 0, 1, false, LV>;
+    if (split == 2) return gather ? k_step2_co_topo<KIND, XF, true, 0, 2, true, LV> : k_step2_co_topo<KIND, XF, false, 0, 2, true, LV>;
+    return gather ? k_step2_co_topo<KIND, XF, true, 0, 1, true, LV> : k_step2_co_topo<KIND, XF, false, 0, 1, true, LV>;
+}
+template <int KIND, int XF> drgnn_step_kernel_t af_pick_single_xg(bool gather, int split, bool train, int level) {
+    if constexpr (XF >= 32) { if (level == 2) return af_pick_single_xg_level<KIND, XF, 2>(gather, split, train); }
+    return level == 1 ? af_pick_single_xg_level<KIND, XF, 1>(gather, split, train) : nullptr;
 }
 #define DRGNN_AF_DEFINE_SGAT_XG(W) DRGNN_AF_DEFINE_SGAT_XG_X(W)
 #define DRGNN_AF_DEFINE_FOUT_XG(W) DRGNN_AF_DEFINE_FOUT_XG_X(W)
 #define DRGNN_AF_DEFINE_SGAT_XG_X(W) \
-    drgnn_step_kernel_t af_sgat_xg_##W(bool gather, int split, bool train) { return af_pick_single_xg<DRGNN_SGAT, W>(gather, split, train); }
+    drgnn_step_kernel_t af_sgat_xg_##W(bool gather, int split, bool train, int level) { return af_pick_single_xg<DRGNN_SGAT, W>(gather, split, train, level); }
 #define DRGNN_AF_DEFINE_FOUT_XG_X(W) \
-    drgnn_step_kernel_t af_fout_xg_##W(bool gather, int split, bool train) { return af_pick_single_xg<DRGNN_FOUT, W>(gather, split, train); }
+    drgnn_step_kernel_t af_fout_xg_##W(bool gather, int split, bool train, int level) { return af_pick_single_xg<DRGNN_FOUT, W>(gather, split, train, level); }
 
 #define DRGNN_AF_DECLARE(W)                                                                     \
     drgnn_step_kernel_t af_ginet_two_##W(bool gather, int cls, bool train);                    \
     drgnn_step_kernel_t af_ginet_one_##W(bool gather, int cls, bool train);                    \
     drgnn_step_kernel_t af_ginet_sg_##W(bool gather, bool train);                              \
-    drgnn_step_kernel_t af_sgat_xg_##W(bool gather, int split, bool train);                    \
-    drgnn_step_kernel_t af_fout_xg_##W(bool gather, int split, bool train);                    \
+    drgnn_step_kernel_t af_sgat_xg_##W(bool gather, int split, bool train, int level);         \
+    drgnn_step_kernel_t af_fout_xg_##W(bool gather, int split, bool train, int level);         \
     drgnn_step_kernel_t af_sgat_##W(bool gather, int cls, int split, bool train);              \
     drgnn_step_kernel_t af_fout_##W(bool gather, int cls, int split, bool train);              \
     drgnn_step_kernel_t af_sgat_whole_##W(int cls);                                            \
@@ -136,15 +141,16 @@ DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_SGAT_XG)
 DRGNN_AF_FOR_WIDTHS(DRGNN_AF_DEFINE_FOUT_XG)
 #endif
 // family: DRGNN_AF_*; width: 16 / 32 / 48 / 64.  nullptr: no such instance
-static drgnn_step_kernel_t af_step_kernel(int family, int width, bool gather, int cls, int split, bool train) {
+// level: 1 / 2 of the from-memory families (DRGNN_AF_SGAT_XG / _FOUT_XG)
+static drgnn_step_kernel_t af_step_kernel(int family, int width, bool gather, int cls, int split, bool train, int level = 0) {
 #define DRGNN_AF_CASE(W)                                                                       \
     case W:                                                                                     \
         switch (family) {                                                                       \
         case DRGNN_AF_GINET_TWO: return af_ginet_two_##W(gather, cls, train);                   \
         case DRGNN_AF_GINET_ONE: return af_ginet_one_##W(gather, cls, train);                   \
         case DRGNN_AF_GINET_SG: return af_ginet_sg_##W(gather, train);                          \
-        case DRGNN_AF_SGAT_XG: return af_sgat_xg_##W(gather, split, train);                     \
-        case DRGNN_AF_FOUT_XG: return af_fout_xg_##W(gather, split, train);                     \
+        case DRGNN_AF_SGAT_XG: return af_sgat_xg_##W(gather, split, train, level);              \
+        case DRGNN_AF_FOUT_XG: return af_fout_xg_##W(gather, split, train, level);              \
         case DRGNN_AF_SGAT: return af_sgat_##W(gather, cls, split, train);                      \
         case DRGNN_AF_FOUT: return af_fout_##W(gather, cls, split, train);                      \
         default: return nullptr;                                                                \

@@ -474,9 +474,9 @@ int drgnn_train_update(const drgnn_net_desc* net, const float* conv_partials, in
  *   lds_bytes  LDS one workgroup needs (<= 160 KiB whenever family != NONE); xchg_words: uint64 exchange words per graph
  *   from_memory  1: graphs beyond the LDS budget of the staged kernels (200 - 270 nodes, by width) -- the instance that reads the
  *            node-sized input tile from memory (L2) where it is used instead of staging it: GINet's one-workgroup kernel with the S
- *            rows of the tiles left in memory (up to ~400 nodes / 2048 edges), sGAT / FoutNet with the x rows left in memory (up
- *            to 400 / 360 / 300 / 250 nodes at 16 / 32 / 48 / 64 features); run-time LDS layout.  Beyond what the builder stages
- *            an x tile for (drgnn_topology_tiles_ok) the tiles come from drgnn_topology_tiles on the built workspace
+ *            rows of the tiles left in memory, sGAT / FoutNet with the x rows -- and, where that is not enough, the S rows too --
+ *            left in memory; run-time LDS layout; every net and width up to ~400 nodes / 2048 edges per graph.  Beyond what the
+ *            builder stages an x tile for (drgnn_topology_tiles_ok) the tiles come from drgnn_topology_tiles on the built workspace
  * Overrides (0 = automatic; tests and same-box A/B runs): force_wgs 1 / 2 = always that many workgroups per graph (2 beyond the
  * resident size is MEASUREMENT ONLY: the exchange then leans on in-order dispatch; bounded wait + fault bit); no_class;
  * no_aggregate (never the aggregation-first family: family NONE on the device, the launch pair steps the mini-batch);

@@ -689,7 +689,10 @@ def test_boundary_edge_cases(net_name):
                                        err_msg="%s %s" % (what, n))
 
 
-@pytest.mark.parametrize("net_name,n_feat,n_nodes", [("GINet", 48, 380), ("GINet", 64, 330), ("sGAT", 32, 340), ("FoutNet", 48, 300)])
+@pytest.mark.parametrize("net_name,n_feat,n_nodes", [("GINet", 48, 380), ("GINet", 64, 330), ("sGAT", 32, 340), ("FoutNet", 48, 300),
+                                                       # (sGAT / FoutNet with the S rows left in memory as well)
+                                                       ("sGAT", 48, 380), ("FoutNet", 64, 390), ("sGAT", 64, 330), ("FoutNet", 44, 370),
+                                                       ("sGAT", 32, 395), ("FoutNet", 30, 390)])
 def test_graphs_beyond_the_staged_layout_through_the_drop_in_boundary(net_name, n_feat, n_nodes):
     """model(batch) / loss.backward() on graphs beyond the staged kernels' LDS budget: the from-memory instances
     (plan.from_memory) -- for the GINet shapes also beyond what the builder stages an x tile for, so the engine has the

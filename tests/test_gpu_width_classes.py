@@ -315,9 +315,7 @@ def test_stand_alone_tiles_launch_gives_the_builders_bits():
 def test_one_large_graph_does_not_take_the_fused_kernels_from_the_rest_of_the_set():
     """A resident set whose LARGEST graph is beyond what the builder stages an x tile for (380 nodes at 48 features; the limit is
     310) still gets aggregation tiles -- formed by the stand-alone launch -- so its mini-batches keep the fused kernels: the ones
-    of ordinary graphs the staged instances, the one with the large graph GINet's from-memory instance (sGAT: beyond its own
-    kernels' LDS too -- no fused kernel for THAT mini-batch, which the trainers step through the per-batch path).  Each against the
-    oracle."""
+    of ordinary graphs the staged instances, the one with the large graph the from-memory instances.  Each against the oracle."""
     import deeprank_gnn_amd.synthetic as synth
     from deeprank_gnn_amd import _lib
     from deeprank_gnn_amd.data import Batch
@@ -337,10 +335,6 @@ def test_one_large_graph_does_not_take_the_fused_kernels_from_the_rest_of_the_se
         params = cpu_ref.init_params(net_name, n_feat, 1, 1, seed=23)
         for ids, big in ((list(range(0, 12)), False), (list(range(12, 24)), True)):
             net, tr = _trainer(net_name, params, 1, "reg")
-            if big and net_name == "sGAT":
-                with pytest.raises(_lib.DrgnnError):
-                    tr._cached_prepare(cache, ids)
-                continue
             c = tr._cached_prepare(cache, ids)
             assert c["plan"].family == _lib.STEP_FAMILY_AGGREGATE and bool(c["plan"].from_memory) == big, (net_name, big)
             loss = tr.train_step_cached(cache, ids, apply_adam=False)
@@ -369,3 +363,40 @@ def test_one_large_graph_does_not_take_the_fused_kernels_from_the_rest_of_the_se
     assert [float(v) for v in losses.cpu()] == want
     for (k, pa), (_, pb) in zip(net_a.named_parameters(), net_b.named_parameters()):
         assert torch.equal(pa, pb), k
+
+
+@pytest.mark.parametrize("net_name,n_feat,n_nodes", [("sGAT", 48, 380), ("FoutNet", 64, 390), ("sGAT", 64, 300), ("FoutNet", 32, 395),
+                                                      ("GINet", 48, 390), ("GINet", 20, 400)])
+def test_largest_graphs_of_the_fused_kernels_on_a_cached_set(net_name, n_feat, n_nodes):
+    """The far end of the fused kernels' reach (~400 nodes, 2000 edges per graph) out of a resident set's cached topology: the
+    set's tiles come from the stand-alone launch (the builder stages no x tile for graphs this large), the step is the
+    from-memory instance (sGAT / FoutNet: neither the x nor the S rows staged), training and inference against the oracle."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    dev = _dev()
+    B = 12
+    shape = dict(n_nodes=n_nodes, n_pairs=(5 * n_nodes) // 2, n_c1=max(4, n_nodes // 12), n_internal=(7 * n_nodes) // 4)
+    graphs = [synth.make_graph(i, n_feat=n_feat, **shape) for i in range(B)]
+    batch_cpu = Batch.from_data_list(graphs)
+    params = cpu_ref.init_params(net_name, n_feat, 1, 1, seed=37)
+    kw = _fw(net_name)
+    ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **kw)
+    lazy = Lazy64(net_name, params, batch_cpu, **kw)
+    rs = ResidentGraphSet(graphs, dev)
+    cache = rs.topology_cache(need_weights=(net_name == "sGAT"))
+    assert cache.topo.flags & _lib.TOPO_TILES
+    net, tr = _trainer(net_name, params, 1, "reg")
+    c = tr._cached_prepare(cache, list(range(B)))
+    assert c["plan"].family == _lib.STEP_FAMILY_AGGREGATE and c["plan"].from_memory, (net_name, n_feat, n_nodes)
+    loss = tr.train_step_cached(cache, list(range(B)), apply_adam=False)
+    torch.cuda.synchronize()
+    assert tr.faults() == 0
+    stats = new_stats()
+    check_step("%s %d nodes F=%d, cached, from memory" % (net_name, n_nodes, n_feat), lazy, float(loss), tr.last_pred.cpu().numpy(),
+               {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}, ref_loss, ref_pred.numpy(),
+               {k: v.numpy() for k, v in ref_grads.items()}, stats)
+    assert_arbiter_rate(stats, net_name)
+    pc = tr.predict_cached(cache, list(range(B)))
+    check("cached inference", pc.cpu().numpy(), ref_pred.numpy(), lazy.pred, new_stats())

@@ -52,6 +52,53 @@ def timed(Net, n_feat, n_nodes, B, ov):
     return e0.elapsed_time(e1) * 1e3 / 1000, plan, float(tr.loss)
 
 
+def timed_cached(Net, n_feat, n_nodes, B):
+    """the same step out of a resident set's cached topology (tiles formed by the stand-alone launch where the builder stages
+    none): what NeuralNet.train runs by default"""
+    from deeprank_gnn_amd.resident import ResidentGraphSet
+    shape = dict(n_nodes=n_nodes, n_pairs=(5 * n_nodes) // 2, n_c1=max(4, n_nodes // 12), n_internal=(7 * n_nodes) // 4)
+    rs = ResidentGraphSet([synth.make_graph(i, n_feat=n_feat, **shape) for i in range(B)], dev)
+    cache = rs.topology_cache(need_weights=(Net is sGAT))
+    torch.manual_seed(0)
+    tr = FusedTrainer(Net(n_feat, 1, 1).to(dev), lr=1e-3, task="reg")
+    ids = list(range(B))
+    ids_dev = rs.upload_ids(ids)
+    plan = tr._cached_prepare(cache, ids, ids_dev)["plan"]
+
+    def chunk():
+        for k in range(20):
+            tr.train_step_cached(cache, ids, ids_dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        chunk()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        chunk()
+    for _ in range(3):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(50):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / 1000, plan
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "cached":
+    for Net, F, N, B in [(GINet, 48, 390, 128), (sGAT, 48, 380, 64), (FoutNet, 48, 380, 128), (sGAT, 64, 390, 64), (FoutNet, 64, 390, 64)]:
+        us, plan = timed_cached(Net, F, N, B)
+        print("%-8s F=%d, %3d nodes, batch %3d, cached topology          family %d wgs %d from_memory %d lds %6d B: %8.2f us per step = %5.2f M graphs/s" % (
+            Net.__name__, F, N, B, plan.family, plan.wgs_per_graph, plan.from_memory, plan.lds_bytes, us, B / us), flush=True)
+        us, plan, loss = timed(Net, F, N, B, {"no_aggregate": 1})
+        print("%-8s F=%d, %3d nodes, batch %3d, launch pair (before)     family %d: %8.2f us per step = %5.2f M graphs/s" % (
+            Net.__name__, F, N, B, plan.family, us, B / us), flush=True)
+    sys.exit(0)
+
 CASES = [(GINet, 32, 340, 64), (GINet, 32, 340, 128), (GINet, 48, 300, 128), (sGAT, 32, 340, 64), (FoutNet, 32, 340, 64),
          (sGAT, 48, 300, 128), (FoutNet, 48, 300, 128)]
 for Net, F, N, B in CASES:
