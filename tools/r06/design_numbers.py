@@ -1,12 +1,12 @@
 """Regenerates the ONE table of current numbers in DESIGN.md (between the numbers:begin / numbers:end markers) from the bench
 lines collected by tools/collect_profiles.sh + tools/summarize_profile.py:  profiles/<name>_{GINet,sGAT,FoutNet}_benchline.json
-    python tools/r06/design_numbers.py r06_v4"""
+    python tools/r06/design_numbers.py r06_v5"""
 import json
 import os
 import sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
-name = sys.argv[1] if len(sys.argv) > 1 else "r06_v4"
+name = sys.argv[1] if len(sys.argv) > 1 else "r06_v5"
 
 
 def load(net, suffix="benchline"):
