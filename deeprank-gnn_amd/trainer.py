@@ -360,6 +360,19 @@ class FusedTrainer(object):
         self._cached_launch_step(c, False)
         return c["pred"]
 
+    def _topology_of(self, batch, train):
+        """The workspace of a mini-batch nobody built one for.  Graphs the builder stages no x tile for
+        (``Topology._tiles_separately``) get their aggregation tiles from the stand-alone launch when a fused kernel will read
+        them (the from-memory instances: drgnn_step_plan.from_memory)."""
+        topo = Topology.from_batch(batch, api=self.api, need_weights=(self.kind == _lib.SGAT), build=False)
+        flags = topo.full_flags()
+        if getattr(topo, "_tiles_separately", False) and topo.tiles is not None and self.fused_step and topo.max_nodes > 0:
+            with_tiles = flags | _lib.TOPO_TILES
+            p = self._plan(int(batch.x.shape[1]), topo.max_nodes, topo.max_edges, topo.max_c0, topo.n_graphs, 0, train, with_tiles)
+            if p.family == _lib.STEP_FAMILY_AGGREGATE:
+                flags = with_tiles
+        return topo.rebuild(flags)
+
     def _backward(self, batch, topo, apply_adam, next_topo=None):
         """Fused step when every graph fits LDS (see _fused); else fwd (++step) -> bwd with the per-graph
         head + loss inside (and, when given, the NEXT mini-batch's topology build sharing that launch)
@@ -367,7 +380,7 @@ class FusedTrainer(object):
         ``apply_adam``."""
         api = self.api
         if topo is None:
-            topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
+            topo = self._topology_of(batch, True)
         if self._can_fuse(topo, batch.x.shape[1], next_topo, True, batch.x):
             return self._fused(batch, topo, apply_adam, next_topo)
         if int(getattr(topo, "flags", 0)) & _lib.TOPO_LEAN:
@@ -758,7 +771,7 @@ class FusedTrainer(object):
         training: a stream of batches needs one launch per batch."""
         api = self.api
         if topo is None:
-            topo = Topology.from_batch(batch, api=api, need_weights=(self.kind == _lib.SGAT))
+            topo = self._topology_of(batch, False)
         if self._can_fuse(topo, batch.x.shape[1], next_topo, False, batch.x):
             c = self._fused_prepare(batch, topo, False, next_topo)
             if (int(getattr(topo, "flags", 0)) & _lib.TOPO_LEAN) and not c["plan"].lean_ok:

@@ -400,3 +400,12 @@ def test_largest_graphs_of_the_fused_kernels_on_a_cached_set(net_name, n_feat, n
     assert_arbiter_rate(stats, net_name)
     pc = tr.predict_cached(cache, list(range(B)))
     check("cached inference", pc.cpu().numpy(), ref_pred.numpy(), lazy.pred, new_stats())
+    # the same mini-batch handed to the trainer as a Batch (no workspace given): the same launches, the same bits
+    net2, tr2 = _trainer(net_name, params, 1, "reg")
+    batch = batch_cpu.clone().to(dev)
+    loss2 = tr2.compute_gradients(batch)
+    torch.cuda.synchronize()
+    assert float(loss2) == float(loss)
+    for k, p in net2.named_parameters():
+        np.testing.assert_array_equal(p.grad.detach().cpu().numpy(), net.get_parameter(k).grad.detach().cpu().numpy(), err_msg=k)
+    np.testing.assert_array_equal(tr2.predict(batch).cpu().numpy(), pc.cpu().numpy())
