@@ -906,7 +906,9 @@ def measure_roofline(net, net_name, batch, dev, graphs_per_s, iters=400, cache=N
                     traffic = v["hbm_bytes_per_launch"]
                     traffic_note = ("bytes/launch from rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE (separate passes, "
                                     "profiles/%s, same sources as this build); FETCH doubled per "
-                                    "MI355X_MICROARCH.md" % where)
+                                    "MI355X_MICROARCH.md; averaged over launches WITH the co-launched builder only "
+                                    "(--counter-pass; rounds 4 - 5 averaged over both kinds of launch), "
+                                    "traffic_cached_topology: the step launch alone" % where)
             for k, v in (pmc.get("_cached_topology") or {}).items():
                 if own_step_kernel(k):
                     traffic_cached = v["hbm_bytes_per_launch"]
