@@ -343,6 +343,53 @@ def test_fused_step_random_shapes_match_oracle(net_name):
 
 
 @pytest.mark.parametrize("net_name", NETS)
+def test_fused_step_random_shapes_with_a_large_graph_match_oracle(net_name):
+    """The same kind of sweep with ONE graph of 280 .. 400 nodes in every mini-batch (the others 4 .. 260): the launch takes
+    the from-memory instance for all of them (counted: a sparse large graph may still fit the staged layout) -- tiny graphs next to the large one, every width, rows shorter than
+    the padded width, the tiles formed by the stand-alone launch where the builder stages none -- against the oracle.  The
+    trainer is handed the Batch only (it builds the workspace itself)."""
+    import deeprank_gnn_amd.synthetic as synth
+    from deeprank_gnn_amd import _lib
+    from deeprank_gnn_amd.data import Batch
+    from deeprank_gnn_amd.trainer import FusedTrainer
+    from test_gpu_parity import build
+    dev = _dev()
+    rng = np.random.default_rng(20260930)
+    sweep_stats = new_stats()
+    from_memory = 0
+    for case in range(7):
+        n_feat = int(rng.choice([7, 20, 32, 44, 48, 64]))
+        n_graphs = int(rng.integers(2, 8))
+        big = int(rng.integers(0, n_graphs))
+        graphs = []
+        for k in range(n_graphs):
+            n_nodes = int(rng.integers(280, 401)) if k == big else int(rng.integers(4, 261))
+            half = n_nodes // 2
+            n_pairs = int(rng.integers(1, max(2, min(1000, 3 * n_nodes, half * (n_nodes - half)))))      # (<= 2000 directed edges)
+            n_int = int(rng.integers(1, max(2, min(3 * n_nodes, half * (half - 1) // 2 + 1))))
+            graphs.append(synth.make_graph(5000 + 100 * case + k, n_nodes=n_nodes, n_pairs=n_pairs, n_feat=n_feat,
+                                           n_c1=int(rng.integers(1, 20)), n_internal=n_int))
+        batch_cpu = Batch.from_data_list(graphs)
+        params = cpu_ref.init_params(net_name, n_feat, 1, 1, seed=300 + case)
+        ref_pred, ref_loss, ref_grads = cpu_ref.loss_and_grads(net_name, params, batch_cpu, batch_cpu.y, **_fw_kwargs(net_name))
+        net = build(net_name, params, 1)
+        tr = FusedTrainer(net, lr=0.01, task="reg")
+        batch = batch_cpu.clone().to(dev)
+        topo = tr._topology_of(batch, True)
+        where = "case %d: F=%d, nodes %s" % (case, n_feat, [int(g.x.shape[0]) for g in graphs])
+        plan = tr._plan_for(topo, n_feat, None, True, batch.x)
+        assert plan.family == _lib.STEP_FAMILY_AGGREGATE, (where, plan.family, topo.max_edges)
+        from_memory += int(plan.from_memory)          # (a sparse 300-node graph still fits the staged layout)
+        loss = tr.compute_gradients(batch, topo=topo)
+        torch.cuda.synchronize()
+        assert tr.faults() == 0
+        check_step(where, Lazy64(net_name, params, batch_cpu, **_fw_kwargs(net_name)), loss, tr.last_pred.cpu().numpy(),
+                   _grads_of(net), ref_loss, ref_pred.numpy(), {k: v.numpy() for k, v in ref_grads.items()}, sweep_stats)
+    assert from_memory >= 4, from_memory
+    assert_arbiter_rate(sweep_stats, "%s large-graph sweep" % net_name)
+
+
+@pytest.mark.parametrize("net_name", NETS)
 def test_benchmark_schedule_is_reproducible_and_graph_replays_equal_eager_launches(net_name):
     """Size-independent property of the benchmarked schedule (pipelined topology build, dropout ON for GINet): 240 steps run
     (a) launch by launch, (b) launch by launch again, (c) as hipGraph replays of 20 recorded steps give the same parameters,
